@@ -1,0 +1,382 @@
+#!/usr/bin/env python
+"""Generate golden fixtures by running the REFERENCE ITSELF (read-only, imported from
+/root/reference) in the dev container.  Runs only here (the GPU box has no reference);
+the .npz outputs are committed next to this script.
+
+The reference is Python-2 / torch-0.3 code.  Nothing under /root/reference is edited;
+this harness only restores the environment it expects, in-process:
+  * sys.modules stubs for easydict, tensorboardX, cv2, pycocotools, `_ext` (TH/THC C
+    extensions that cannot be built here; `cpu_nms` is supplied by oracle.boxes.nms,
+    restating nms.c:35-63) and scipy.misc.imresize (PIL-backed, scipy<=1.2 semantics);
+  * np.float alias; Tensor.cuda()/Module.cuda() identity (no GPU here);
+  * affine_grid/grid_sample default align_corners=True (torch 0.3 behaviour);
+  * comparison results of `max_overlaps` in proposal_target_layer.py:143-146 returned
+    as uint8 (torch-0.3 ByteTensor) so that `(a<b)+(c>=d)==2` keeps its meaning;
+  * numpy.random.choice is wrapped only to RECORD what it drew (fixtures carry the
+    draws as per-element priority keys).
+`Network.forward()` is bypassed (its `.data[0]` raises on 0-dim tensors): the harness
+sets the same attributes forward() sets (NET:632-648) and calls `_predict()` /
+`_add_losses()` / backward / torch.optim.SGD exactly as NET:650-662,712-715, TV:194-220.
+
+Usage: python tests/golden/make_golden.py [tiny|full|leaf|all]
+"""
+import os
+import sys
+import types
+import warnings
+import numpy as np
+
+warnings.filterwarnings('ignore')
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from PIL import Image
+
+from oracle import boxes as OB
+from oracle import weights as OW
+from oracle import synth as OS
+
+CHOICE_LOG = []
+
+
+def install_harness():
+    # --- easydict ---
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            d = dict(d or {}, **kw)
+            for k, v in d.items():
+                setattr(self, k, v)
+
+        def __setattr__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            dict.__setitem__(self, k, v)
+            object.__setattr__(self, k, v)
+        __setitem__ = __setattr__
+    m = types.ModuleType('easydict'); m.EasyDict = EasyDict; sys.modules['easydict'] = m
+
+    # --- scipy.misc.imresize (scipy<=1.2 pilutil semantics) ---
+    def bytescale(data):
+        if data.dtype == np.uint8:
+            return data
+        cmin, cmax = data.min(), data.max()
+        cscale = cmax - cmin
+        if cscale == 0:
+            cscale = 1
+        scale = 255.0 / cscale
+        return ((data - cmin) * scale + 0.5).clip(0, 255).astype(np.uint8)
+
+    def imresize(arr, size, interp='bilinear', mode=None):
+        im = Image.fromarray(bytescale(np.asarray(arr)))
+        if isinstance(size, (int, np.integer)):
+            size = tuple((np.array(im.size) * (size / 100.0)).astype(int))
+        elif isinstance(size, float):
+            size = tuple((np.array(im.size) * size).astype(int))
+        else:
+            size = (int(size[1]), int(size[0]))
+        func = {'nearest': 0, 'lanczos': 1, 'bilinear': 2, 'bicubic': 3, 'cubic': 3}
+        return np.array(im.resize(size, resample=func[interp]))
+    import scipy.misc
+    scipy.misc.imresize = imresize
+
+    # --- empty third-party stubs ---
+    for name in ['tensorboardX', 'cv2', 'pycocotools', 'pycocotools.mask']:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['pycocotools'].mask = sys.modules['pycocotools.mask']
+    sys.modules['tensorboardX'].summary = types.SimpleNamespace()
+    sys.modules['tensorboardX'].writer = types.SimpleNamespace()
+
+    # --- native extensions (`from _ext import nms`, `from _ext import roi_pooling`) ---
+    ext = types.ModuleType('_ext')
+
+    def cpu_nms(keep_out, num_out, boxes, order, areas, thresh):
+        dets = boxes.numpy()
+        keep = OB.nms(dets, thresh, 'ge')
+        keep_out[:len(keep)] = torch.from_numpy(keep)
+        num_out[0] = len(keep)
+        return 1
+    ext.nms = types.SimpleNamespace(cpu_nms=cpu_nms)
+    ext.roi_pooling = types.SimpleNamespace()
+    sys.modules['_ext'] = ext
+
+    np.float = float
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    _ag, _gs = F.affine_grid, F.grid_sample
+    F.affine_grid = lambda theta, size, align_corners=True: _ag(theta, size, align_corners=align_corners)
+    F.grid_sample = lambda inp, grid, mode='bilinear', padding_mode='zeros', align_corners=True: \
+        _gs(inp, grid, mode=mode, padding_mode=padding_mode, align_corners=align_corners)
+
+    _choice = np.random.choice
+
+    def rec_choice(a, size=None, replace=True, p=None):
+        r = _choice(a, size=size, replace=replace, p=p)
+        CHOICE_LOG.append(dict(a=np.array(a).copy(), size=size, replace=replace, result=np.array(r).copy()))
+        return r
+    np.random.choice = rec_choice
+
+    sys.path.insert(0, os.path.join(REF, 'lib'))
+    sys.path.insert(0, os.path.join(REF, 'pyutils/mask-faster-rcnn/lib'))
+
+    # ByteTensor comparison semantics for proposal_target_layer.py:143-146
+    import layer_utils.proposal_target_layer as PTL
+    import utils.bbox as UB
+
+    class ByteCmp(torch.Tensor):
+        def __lt__(self, o):
+            return torch.Tensor.__lt__(self.as_subclass(torch.Tensor), o).to(torch.uint8)
+
+        def __ge__(self, o):
+            return torch.Tensor.__ge__(self.as_subclass(torch.Tensor), o).to(torch.uint8)
+
+    def bbox_overlaps_byte(b, q):
+        return UB.bbox_overlaps(b, q).as_subclass(ByteCmp)
+    PTL.bbox_overlaps = bbox_overlaps_byte
+
+
+def digest(t, nsamp=2048):
+    a = t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    a = a.astype(np.float64).ravel()
+    stride = max(1, a.size // nsamp)
+    return dict(shape=np.array(t.shape), sum=a.sum(), abssum=np.abs(a).sum(),
+                stride=stride, sample=a[::stride][:nsamp].astype(np.float32))
+
+
+def flat(prefix, d, out):
+    for k, v in d.items():
+        out[prefix + '.' + k] = v
+
+
+def keys_from_log(n_total, cand, drawn, disable_mode):
+    """Turn one recorded npr.choice into uint32 priority keys (smallest first)."""
+    keys = np.full(n_total, 0xFFFFFFFF, dtype=np.uint32)
+    drawn = np.asarray(drawn).ravel()
+    rest = np.setdiff1d(np.asarray(cand), drawn, assume_unique=False)
+    keys[drawn] = np.arange(len(drawn), dtype=np.uint32)
+    keys[rest] = len(drawn) + np.arange(len(rest), dtype=np.uint32)
+    return keys
+
+
+def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain=4.0, full_tensors=True):
+    from model.config import cfg
+    import nets.resnet_v1_cycle_res5_2 as RESM
+    import nets.network_cycle_res5_2 as NETM
+    from oracle.net import DEFAULT_CFG
+    import copy
+    ocfg = copy.deepcopy(DEFAULT_CFG)
+    for k, v in cfg_over.items():
+        ocfg['TRAIN'][k] = v
+        setattr(cfg.TRAIN, k, v)
+    cfg.ANCHOR_SCALES = list(ocfg['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(ocfg['ANCHOR_RATIOS'])
+    opt = OW.default_opt(vocab_size=V, seq_length=T)
+    sd = OW.make_state_dict(opt, seed=seed_w, head_gain=head_gain)
+    blob = OS.make_blob(H, W, T, V, seed=seed_blob)
+
+    torch.manual_seed(0)
+    net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
+    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    ref_sd = net.state_dict()
+    for k, v in sd.items():
+        assert k in ref_sd and tuple(ref_sd[k].shape) == v.shape, k
+        ref_sd[k].copy_(torch.from_numpy(v))
+    # optimizer exactly as TV:194-220 (FROM_FRCN False)
+    lr = cfg.TRAIN.LEARNING_RATE
+    params = []
+    for key, value in dict(net.named_parameters()).items():
+        if value.requires_grad:
+            if 'bias' in key:
+                params += [{'params': [value], 'lr': lr * (cfg.TRAIN.DOUBLE_BIAS + 1),
+                            'weight_decay': cfg.TRAIN.BIAS_DECAY and cfg.TRAIN.WEIGHT_DECAY or 0}]
+            else:
+                params += [{'params': [value], 'lr': lr, 'weight_decay': cfg.TRAIN.WEIGHT_DECAY}]
+    optimizer = torch.optim.SGD(params, momentum=cfg.TRAIN.MOMENTUM)
+    net.train()
+    for mod in net.modules():                       # dropout off (parity runs inject masks = identity)
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    np.random.seed(cfg.RNG_SEED)
+    del CHOICE_LOG[:]
+    # NET:632-648 attribute setup (forward() bypassed)
+    net._image = torch.from_numpy(blob['data'].transpose([0, 3, 1, 2]).copy())
+    net._im_info = blob['im_info']
+    net._gt_boxes = torch.from_numpy(blob['gt_boxes'])
+    net._gt_masks = blob['gt_masks']
+    net._labels = torch.from_numpy(blob['labels'])
+    net._cap_labels = blob['cap_labels']; net._cap_masks = blob['cap_masks']
+    net._mode = 'TRAIN'
+    net._image_gt_summaries = {}
+    net_conv, rois, cls_prob, bbox_pred, mask_prob = net._predict()
+    net._predictions['net_conv'] = net_conv
+    net._add_losses()
+    L = {k: float(v) for k, v in net._losses.items()}
+    optimizer.zero_grad()
+    net._losses['total_loss'].backward()
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters() if p.requires_grad}
+    optimizer.step()
+
+    out = dict(meta_H=H, meta_W=W, meta_T=T, meta_V=V, meta_seed_w=seed_w, meta_seed_blob=seed_blob,
+               meta_head_gain=head_gain)
+    for k, v in cfg_over.items():
+        out['cfg.' + k] = v
+    for k, v in L.items():
+        out['loss.' + k] = v
+    # sampling draws -> keys
+    Hc, Wc = net_conv.shape[2], net_conv.shape[3]
+    A = net._num_anchors
+    n_anchor = Hc * Wc * A
+    anchors = net._anchors.numpy()
+    inside = np.where((anchors[:, 0] >= 0) & (anchors[:, 1] >= 0) & (anchors[:, 2] < W) & (anchors[:, 3] < H))[0]
+    log = list(CHOICE_LOG)
+    # order of calls in one TRAIN forward: [ATL fg?] [ATL bg?] PTL fg, PTL bg
+    n_post = int(net._predictions['rois'].shape[0])  # sampled rois (256); proposals count recorded below
+    ptl_bg = log[-1]; ptl_fg = log[-2]; atl = log[:-2]
+    rpn_fg_keys = np.full(n_anchor, 0xFFFFFFFF, np.uint32)
+    rpn_bg_keys = np.full(n_anchor, 0xFFFFFFFF, np.uint32)
+    rpn_lab = net._anchor_targets['rpn_labels'].numpy().reshape(A, Hc, Wc).transpose(1, 2, 0).reshape(-1)
+    for e in atl:
+        cand_inside = e['a']                                   # indices into `inside`
+        cand = inside[cand_inside]
+        drawn = inside[e['result']]
+        keys = keys_from_log(n_anchor, cand, drawn, True)
+        # fg call draws from labels==1 candidates, bg call from labels==0
+        if len(atl) == 2 and e is atl[0]:
+            rpn_fg_keys = keys
+        else:
+            # single call: decide by whether candidates contain a positive anchor
+            if (rpn_lab[cand] == 1).any() and not (rpn_lab[cand] == 0).any() and len(atl) == 1 and len(cand) < 2000:
+                rpn_fg_keys = keys
+            else:
+                rpn_bg_keys = keys
+    out['samp.rpn_fg_keys'] = rpn_fg_keys; out['samp.rpn_bg_keys'] = rpn_bg_keys
+    # PTL draws are positions into fg_inds / bg_inds of the proposal list
+    prop = net._proposal_targets
+    # recompute candidate lists from the reference's own proposals
+    from utils.bbox import bbox_overlaps as ub
+    all_rois = PROPOSALS['rois']
+    ov = ub(torch.from_numpy(all_rois[:, 1:5]), torch.from_numpy(blob['gt_boxes'][:, :4])).numpy()
+    mx = ov.max(1)
+    fg_inds = np.where(mx >= cfg.TRAIN.FG_THRESH)[0]
+    bg_inds = np.where((mx < cfg.TRAIN.BG_THRESH_HI) & (mx >= cfg.TRAIN.BG_THRESH_LO))[0]
+    n_prop = all_rois.shape[0]
+    print('n_prop', n_prop, 'fg', len(fg_inds), 'bg', len(bg_inds), 'log', [(len(e['a']), e['size'], e['replace']) for e in log])
+    assert len(ptl_fg['a']) == len(fg_inds) and len(ptl_bg['a']) == len(bg_inds), (len(ptl_fg['a']), len(fg_inds), len(ptl_bg['a']), len(bg_inds))
+    assert not ptl_bg['replace'], 'fixture expects the without-replacement path'
+    out['samp.roi_fg_keys'] = keys_from_log(n_prop, fg_inds, fg_inds[ptl_fg['result']], False)
+    out['samp.roi_bg_keys'] = keys_from_log(n_prop, bg_inds, bg_inds[ptl_bg['result']], False)
+    out['int.proposal_rois'] = all_rois
+    out['int.proposal_scores'] = PROPOSALS['scores']
+    out['int.rpn_labels'] = net._anchor_targets['rpn_labels'].numpy().astype(np.int8)
+    out['int.rois'] = prop['rois'].detach().numpy()
+    out['int.labels'] = prop['labels'].numpy().astype(np.int64).reshape(-1)
+    out['int.mask_targets'] = prop['mask_targets'].numpy().astype(np.uint8)
+    out['int.num_fg'] = prop['mask_targets'].shape[0]
+    tens = dict(net_conv=net_conv, response=None, rpn_cls_prob=net._predictions['rpn_cls_prob'],
+                rpn_bbox_pred=net._predictions['rpn_bbox_pred'], rpn_bbox_targets=net._anchor_targets['rpn_bbox_targets'],
+                rpn_bbox_outside=net._anchor_targets['rpn_bbox_outside_weights'],
+                bbox_targets=prop['bbox_targets'], cls_score=net._predictions['cls_score'],
+                bbox_pred=net._predictions['bbox_pred'], mask_score=net._predictions['mask_score'])
+    for k, v in tens.items():
+        if v is not None:
+            flat('t.' + k, digest(v), out)
+    # a few exact small tensors
+    out['x.cls_score'] = net._predictions['cls_score'].detach().numpy()[:, :8]
+    out['x.bbox_pred'] = net._predictions['bbox_pred'].detach().numpy()[:8, :16]
+    gsel = ['resnet.layer2.0.conv1.weight', 'resnet.layer3.22.conv2.weight', 'resnet.layer4.2.conv3.weight',
+            'resnet.layer4.0.downsample.0.weight', 'rpn_net.weight', 'rpn_cls_score_net.bias', 'cls_score_net.weight',
+            'bbox_pred_net.bias', 'mask_up_sampling.weight', 'mask_pred_net.weight', 'dynamic_fc_3.weight',
+            'response_fc.weight', 'rnn_encoder.embedding.weight', 'rnn_encoder.rnn.weight_hh_l0_reverse',
+            'rnn_encoder.mlp.0.bias', 'caption_model.att_embed.0.weight', 'caption_model.logit.weight',
+            'caption_model.core.h2h.weight', 'caption_model.core.a2c.bias', 'caption_model.core.attention.alpha_net.weight',
+            'caption_model.embed.0.weight', 'caption_model.ctx2att.weight']
+    for k in gsel:
+        g = grads[k]
+        flat('g.' + k, digest(g if g is not None else torch.zeros(1)), out)
+        flat('w1.' + k, digest(dict(net.named_parameters())[k]), out)
+    np.savez_compressed(os.path.join(HERE, 'ref_%s.npz' % tag), **out)
+    print(tag, 'losses', L, 'num_fg', out['int.num_fg'], 'n_prop', n_prop, 'choices', [(len(e['a']), e['size']) for e in log])
+    return out
+
+
+PROPOSALS = {}
+
+
+def hook_proposals():
+    """Record what proposal_layer returned (its output is consumed, not stored, by NET:256-259)."""
+    import nets.network_cycle_res5_2 as NETM
+    orig = NETM.proposal_layer
+
+    def rec(*a, **k):
+        rois, scores = orig(*a, **k)
+        PROPOSALS['rois'] = rois.detach().numpy().copy()
+        PROPOSALS['scores'] = scores.detach().numpy().reshape(-1).copy()
+        return rois, scores
+    NETM.proposal_layer = rec
+
+
+def run_leaf():
+    """Leaf functions imported straight from the reference (no substitution)."""
+    from layer_utils.snippets import generate_anchors_pre
+    from layer_utils.generate_anchors import generate_anchors
+    from model.bbox_transform import bbox_transform, bbox_transform_inv, clip_boxes
+    from utils.bbox import bbox_overlaps
+    rs = np.random.RandomState(7)
+    out = {}
+    out['anchors.base'] = generate_anchors()
+    a, n = generate_anchors_pre(5, 7, [16, ], (4, 8, 16, 32), (0.5, 1, 2))
+    out['anchors.pre_5x7'] = a
+    ex = rs.uniform(0, 300, (50, 4)).astype(np.float32); ex[:, 2:] += ex[:, :2]
+    gt = rs.uniform(0, 300, (50, 4)).astype(np.float32); gt[:, 2:] += gt[:, :2]
+    out['bt.ex'] = ex; out['bt.gt'] = gt
+    out['bt.targets'] = bbox_transform(torch.from_numpy(ex), torch.from_numpy(gt)).numpy()
+    d = rs.normal(0, 0.5, (50, 4)).astype(np.float32)
+    out['bt.deltas'] = d
+    inv = bbox_transform_inv(torch.from_numpy(ex), torch.from_numpy(d))
+    out['bt.inv'] = inv.numpy()
+    out['bt.clip'] = clip_boxes(inv, (200, 320)).numpy()
+    out['bt.iou'] = bbox_overlaps(torch.from_numpy(ex), torch.from_numpy(gt[:7])).numpy()
+    # language encoder + captioner + criterion, small vocab, imported as-is
+    from layers.lang_encoder import RNNEncoder
+    import caption_models
+    import misc.utils as mutils
+    opt = OW.default_opt(vocab_size=37, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=11)
+    enc = RNNEncoder(37, 512, 512, 512, bidirectional=True, input_dropout_p=0.0, dropout_p=0.0, n_layers=1,
+                     rnn_type='lstm', variable_lengths=True)
+    enc.load_state_dict({k[len('rnn_encoder.'):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith('rnn_encoder.')})
+    labels = torch.from_numpy(rs.randint(1, 37, (1, 6)).astype(np.int64))
+    _, hidden, _ = enc(labels)
+    out['enc.labels'] = labels.numpy(); out['enc.hidden'] = hidden.detach().numpy()
+    cap = caption_models.setup(opt)
+    cap.load_state_dict({k[len('caption_model.'):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith('caption_model.')})
+    for mod in cap.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    att = torch.from_numpy(rs.normal(0, 1, (1, 14, 14, 4096)).astype(np.float32))
+    seq = np.zeros((1, 8), np.int64); seq[0, 1:7] = rs.randint(1, 37, 6)
+    lp = cap(torch.zeros(1, 4096), att, torch.from_numpy(seq))
+    msk = torch.ones(1, 8)
+    loss = mutils.LanguageModelCriterion()(lp, torch.from_numpy(seq)[:, 1:], msk[:, 1:])
+    out['cap.att'] = att.numpy().astype(np.float16); out['cap.seq'] = seq
+    out['cap.logprobs'] = lp.detach().numpy(); out['cap.loss'] = float(loss)
+    np.savez_compressed(os.path.join(HERE, 'ref_leaf.npz'), **out)
+    print('leaf done', out['cap.loss'])
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    install_harness()
+    if what in ('leaf', 'all'):
+        run_leaf()
+    if what in ('tiny', 'all'):
+        hook_proposals()
+        run_reference('tiny', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,
+                                                    RPN_BATCHSIZE=64), head_gain=float(os.environ.get('HG', '4')))
+    if what in ('full', 'all'):
+        hook_proposals()
+        run_reference('full', 600, 1000, 20, 3349, dict(BATCH_SIZE=256, RPN_PRE_NMS_TOP_N=12000,
+                                                         RPN_POST_NMS_TOP_N=2000, RPN_BATCHSIZE=256))

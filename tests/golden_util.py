@@ -1,0 +1,38 @@
+"""Helpers shared by the golden-fixture tests."""
+import os
+import copy
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(tag):
+    return dict(np.load(os.path.join(GOLD, 'ref_%s.npz' % tag), allow_pickle=False))
+
+
+def check_digest(g, prefix, arr, rtol=1e-4, atol=1e-4):
+    a = np.asarray(arr, dtype=np.float64).ravel()
+    assert list(g[prefix + '.shape']) == list(np.asarray(arr).shape), (prefix, g[prefix + '.shape'], np.asarray(arr).shape)
+    stride = int(g[prefix + '.stride'])
+    samp = g[prefix + '.sample'].astype(np.float64)
+    mine = a[::stride][:samp.size]
+    scale = max(1.0, float(np.abs(samp).max()))
+    err = np.abs(mine - samp).max()
+    assert err <= atol * scale + rtol * scale, (prefix, 'sample max err', err, 'scale', scale)
+    assert abs(a.sum() - float(g[prefix + '.sum'])) <= (rtol * float(g[prefix + '.abssum']) + atol), (prefix, 'sum')
+    return err
+
+
+def setup_from_fixture(g):
+    """(opt, state_dict, blob, cfg, samp) reproducing the inputs the reference was run on."""
+    from oracle import weights as OW, synth as OS, net as ON
+    opt = OW.default_opt(vocab_size=int(g['meta_V']), seq_length=int(g['meta_T']))
+    sd = OW.make_state_dict(opt, seed=int(g['meta_seed_w']), head_gain=float(g['meta_head_gain']))
+    blob = OS.make_blob(int(g['meta_H']), int(g['meta_W']), int(g['meta_T']), int(g['meta_V']), seed=int(g['meta_seed_blob']))
+    cfg = copy.deepcopy(ON.DEFAULT_CFG)
+    for k in g:
+        if k.startswith('cfg.'):
+            cfg['TRAIN'][k[4:]] = int(g[k])
+    samp = dict(rpn_fg_keys=g['samp.rpn_fg_keys'], rpn_bg_keys=g['samp.rpn_bg_keys'],
+                roi_fg_keys=g['samp.roi_fg_keys'], roi_bg_keys=g['samp.roi_bg_keys'])
+    return opt, sd, blob, cfg, samp

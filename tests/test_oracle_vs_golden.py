@@ -1,0 +1,76 @@
+"""Pin the oracle (oracle/*.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as OB, weights as OW, net as ON
+from golden_util import load, check_digest, setup_from_fixture
+
+
+def test_anchor_known_answer():
+    """generate_anchors.py:14-39 docstring (Matlab, 1-based) minus 1."""
+    doc = np.array([[-83, -39, 100, 56], [-175, -87, 192, 104], [-359, -183, 376, 200],
+                    [-55, -55, 72, 72], [-119, -119, 136, 136], [-247, -247, 264, 264],
+                    [-35, -79, 52, 96], [-79, -167, 96, 184], [-167, -343, 184, 360]], np.float64)
+    assert np.array_equal(OB.generate_anchors(), doc - 1)
+
+
+def test_leaf_boxes():
+    g = load('leaf')
+    assert np.array_equal(OB.generate_anchors(), g['anchors.base'])
+    a, n = OB.generate_anchors_pre(5, 7, 16, (4, 8, 16, 32), (0.5, 1, 2))
+    assert np.array_equal(a, g['anchors.pre_5x7'])
+    assert np.allclose(OB.bbox_transform(g['bt.ex'], g['bt.gt']), g['bt.targets'], rtol=1e-6, atol=1e-6)
+    inv = OB.bbox_transform_inv(g['bt.ex'], g['bt.deltas'])
+    assert np.allclose(inv, g['bt.inv'], rtol=1e-6, atol=1e-4)
+    assert np.allclose(OB.clip_boxes(inv, (200, 320)), g['bt.clip'], rtol=1e-6, atol=1e-4)
+    assert np.allclose(OB.bbox_overlaps(g['bt.ex'], g['bt.gt'][:7]), g['bt.iou'], rtol=1e-6, atol=1e-7)
+
+
+def test_leaf_language():
+    g = load('leaf')
+    opt = OW.default_opt(vocab_size=37, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=11)
+    net = ON.OracleNet(sd, opt)
+    with torch.no_grad():
+        hid = net.rnn_encoder(torch.from_numpy(g['enc.labels']))
+        assert np.allclose(hid.numpy(), g['enc.hidden'], atol=1e-5)
+        att = torch.from_numpy(g['cap.att'].astype(np.float32)).view(1, 196, 4096)
+        lp = net.caption(att, torch.from_numpy(g['cap.seq']))
+        assert np.allclose(lp.numpy(), g['cap.logprobs'], atol=1e-4)
+
+
+def _run_e2e(tag):
+    g = load(tag)
+    opt, sd, blob, cfg, samp = setup_from_fixture(g)
+    net = ON.OracleNet(sd, opt, cfg)
+    # proposal order / NMS keeps are discontinuous in fp32 scores (near-ties swap rows): compare the
+    # oracle's own proposals as a SET with tolerance, then teacher-force the reference's list so that
+    # everything downstream (sampling, targets, heads, losses, grads) can be compared tightly.
+    samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
+    T, L = net.forward_train(blob, samp)
+    assert T['proposal_rois'].shape == g['int.proposal_rois'].shape
+    key = lambda r: r[np.lexsort(np.round(r[:, ::-1] * 8).T)]
+    assert np.allclose(key(T['proposal_rois']), key(g['int.proposal_rois']), atol=2e-3)
+    assert np.array_equal(T['rpn_labels'].astype(np.int8), g['int.rpn_labels'])
+    assert np.allclose(T['rois'], g['int.rois'], atol=2e-3)
+    assert np.array_equal(T['labels'].reshape(-1).astype(np.int64), g['int.labels'])
+    assert np.array_equal(T['mask_targets'].astype(np.uint8), g['int.mask_targets'])
+    for k in ['net_conv', 'rpn_cls_prob', 'rpn_bbox_pred', 'cls_score', 'bbox_pred', 'mask_score']:
+        check_digest(g, 't.' + k, T[k].detach().numpy())
+    check_digest(g, 't.rpn_bbox_targets', T['rpn_bbox_targets'])
+    check_digest(g, 't.rpn_bbox_outside', T['rpn_bbox_outside'])
+    check_digest(g, 't.bbox_targets', T['bbox_targets'])
+    for k, v in L.items():
+        assert abs(float(v) - float(g['loss.' + k])) < 1e-4 * max(1, abs(float(g['loss.' + k]))), (k, float(v), g['loss.' + k])
+    grads = net.backward()
+    net.sgd_step()
+    names = sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')})
+    for n in names:
+        check_digest(g, 'g.' + n, grads[n].numpy(), rtol=2e-4, atol=1e-7)
+        check_digest(g, 'w1.' + n, net.p[n].detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_train_step_tiny():
+    _run_e2e('tiny')
