@@ -1,0 +1,221 @@
+/* lang2seg_hip.h — C ABI of liblang2seg_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the hot path of wenz116/lang2seg: every arithmetic op of
+ * Network.train_step (pyutils/mask-faster-rcnn/lib/nets/network_cycle_res5_2.py:702-719) that the
+ * reference delegates to cuDNN / THC / its own torch.utils.ffi extensions is one entry point here.
+ * Conventions (mirroring the reference FFI in lib/nms/src/nms_cuda.c:17 and
+ * lib/layer_utils/roi_pooling/src/roi_pooling_cuda.c:7,49, but re-entrant and stream-explicit):
+ *   - plain pointers (DEVICE memory unless stated) + explicit sizes, no torch types;
+ *   - caller-owned outputs and workspaces, no hidden allocation, no host sync, graph-capturable;
+ *   - every call enqueues on `stream` and returns 0 (L2S_OK) or a nonzero error code, never aborts;
+ *   - `dtype` selects the activation storage type: L2S_F32 (verification mode, exact-f32 MFMA) or
+ *     L2S_BF16 (bf16 storage, fp32 accumulate).  Parameters, gradients, losses, box math: fp32.
+ *   - activations are NHWC ([pixel][channel]); conv weights are [Cout][KH][KW][Cin].
+ */
+#ifndef LANG2SEG_HIP_H
+#define LANG2SEG_HIP_H
+#include <stdint.h>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#else
+typedef struct ihipStream_t* hipStream_t;
+#endif
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2S_F32 0
+#define L2S_BF16 1
+
+int l2s_version(void);
+
+/* ---------------------------------------------------------------- convolution / GEMM ------- */
+/* replaces nn.Conv2d / F.conv2d / nn.Linear / nn.ConvTranspose2d(k2,s2) forward and data-gradient:
+ * resnet_v1_cycle_res5_2.py:83-88,121,147,324-335; network_cycle_res5_2.py:236-251,279-301. */
+#define L2S_CONV_RELU 1        /* y = max(y, 0) after bias/add */
+#define L2S_CONV_OUT_F32 4     /* y is float regardless of dtype */
+#define L2S_CONV_DECONV2X2 8   /* Cout = 4*Cq, n = (dy*2+dx)*Cq + co; pixel-shuffled 2x upsampled output */
+#define L2S_CONV_SCATTER 16    /* output pixel (n, oy*out_stride, ox*out_stride) in an out_h x out_w grid */
+typedef struct {
+  const void* x;      /* [n_img, IH, IW, ldx] activations (dtype) */
+  const void* w;      /* [Cout][KH*KW*Cin] (dtype) */
+  void* y;            /* [rows][ldy] (dtype, or float with OUT_F32) */
+  const float* bias;  /* [Cout] or NULL (indexed by co for DECONV2X2) */
+  const void* add;    /* [rows][ldadd] (dtype) added before relu/mask, or NULL */
+  const void* ref;    /* [rows][ldref] (dtype): y = ref > 0 ? y : 0 (ReLU backward), or NULL */
+  int n_img, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int ldx, ldy, ldadd, ldref;
+  int flags;
+  int out_h, out_w, out_stride; /* SCATTER */
+  int tile;                     /* 0 = auto, 64 or 128 */
+} l2s_conv_desc;
+int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);
+
+/* weight gradient: dw[Cout][KH*KW*Cin] (float) += sum_pixels dy[p][co] * x(p,tap)[ci]  (atomic accumulate) */
+typedef struct {
+  const void* dy;  /* [n_img*OH*OW][lddy] (dtype) */
+  const void* x;   /* [n_img, IH, IW, ldx] (dtype) */
+  float* dw;
+  int n_img, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int lddy, ldx;
+  int split_k;     /* 0 = auto */
+  int tile;        /* 0 = auto */
+} l2s_wgrad_desc;
+int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
+
+/* shadow weights: dst(dtype)[Cout][taps][Cin] = scale[co] * src[Cout][taps][Cin]  (scale may be NULL) */
+int l2s_weight_cast(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
+/* data-gradient layout: dst(dtype)[Cin][taps][Cout], tap order reversed (180-degree flip), * scale[co] */
+int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
+/* column sums: out[c] += sum_r a[r][c] (bias gradients) */
+int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s);
+
+/* stem: conv 7x7 s2 p3 (3->64) + frozen-BN affine + ReLU (RES:121-124), input float NHWC; then maxpool k3 s2 p1 (RES:126) */
+int l2s_stem_conv(const float* img, const float* w /*[64][7][7][3]*/, const float* scale, const float* bias,
+                  void* y, int H, int W, int OH, int OW, int dtype, hipStream_t s);
+int l2s_maxpool3x3s2(const void* x, void* y, int IH, int IW, int C, int OH, int OW, int dtype, hipStream_t s);
+
+/* ---------------------------------------------------------------- pooling / elementwise ---- */
+int l2s_fill_f32(float* p, float v, long n, hipStream_t s);
+int l2s_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, hipStream_t s);
+/* dst(dtype) = a(dtype) + b(dtype) + c(float)   (any of b, c may be NULL) */
+int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s);
+/* spatial mean over hw pixels per image: y[n][c] = mean_p x[n][p][c]  (NET:278) and its backward */
+int l2s_avgpool_fwd(const void* x, void* y, int n_img, int hw, int C, int dtype, hipStream_t s);
+int l2s_avgpool_bwd(const void* dy, void* dx, const void* addend, const void* relu_ref, int n_img, int hw, int C, int dtype, hipStream_t s);
+/* adaptive_avg_pool2d (H,W)->(OH,OW), bins [floor(i*H/OH), ceil((i+1)*H/OH)) (NET:419,432); optional {0,1} pixel mask */
+int l2s_adaptive_pool_fwd(const void* x, const float* pixmask, void* y, int H, int W, int C, int OH, int OW, int ldy, int dtype, hipStream_t s);
+/* dx[p][c] (+)= sum over bins containing p of dy_all[bin][c]/cnt + pixmask[p]*dy_mask[bin][c]/cnt ; then ReLU-masked by relu_ref */
+int l2s_adaptive_pool_bwd(const void* dy, int lddy, int off_all, int off_mask, const float* pixmask, void* dx,
+                          const void* relu_ref, int H, int W, int C, int OH, int OW, int dtype, hipStream_t s);
+/* gt mask (uint8 HxW) -> adaptive avg pool to (h,w) -> >= 0.5 (NET:424-428) */
+int l2s_mask_downsample(const uint8_t* mask, float* out, int H, int W, int h, int w, hipStream_t s);
+/* dropout mask (scaled by 1/(1-p)) from a counter-based hash RNG */
+int l2s_dropout_mask(float* mask, long n, float p, uint64_t seed, hipStream_t s);
+
+/* ---------------------------------------------------------------- RoI path ------------------ */
+/* RPN pair-softmax + box decode + clip (NET:242-246, proposal_layer.py:42-46, bbox_transform.py:36-80).
+ * heads: float [HW][ldh] with columns [0,2A) = cls scores (bg A, fg A), [2A,6A) = bbox deltas.
+ * outputs: prob [HW][2A] float, boxes [HW*A][4] float, scores [HW*A] float (fg prob) */
+int l2s_rpn_decode(const float* heads, int ldh, const float* base_anchors /*[A][4]*/, int H, int W, int A, int feat_stride,
+                   float im_h, float im_w, float* prob, float* boxes, float* scores, hipStream_t s);
+/* descending stable rank sort (ties: lower index first), emits the top-k boxes/scores in order.
+ * rank_out[n] int32 workspace; sorted_boxes [k][4], sorted_scores [k], sorted_idx [k] (int32) */
+int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* rank_ws, float* sorted_boxes,
+                  float* sorted_scores, int* sorted_idx, hipStream_t s);
+/* greedy NMS over score-sorted boxes (replaces gpu_nms / cpu_nms, nms_cuda.c:17, nms.c:4).
+ * cmp_mode 0: suppress when IoU >= thresh (cpu_nms, nms.c:59); 1: IoU > thresh (nms_kernel.cu:63).
+ * mask_ws: n * ceil(n/64) uint64 workspace. keep_out[max_keep] int32 (indices into the sorted list),
+ * num_out[1] int32 — both DEVICE memory (the 18 MB D2H + host loop of nms_cuda.c:47-58 is gone). */
+size_t l2s_nms_workspace_bytes(int n);
+int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_mode, int max_keep, uint64_t* mask_ws,
+            int* keep_out, int* num_out, hipStream_t s);
+/* gather kept proposals: rois[max_keep][5] = [0, box], roi_scores[max_keep]; rows >= *num_out are zero */
+int l2s_gather_rois(const float* sorted_boxes, const float* sorted_scores, const int* keep, const int* num, int max_keep,
+                    float* rois, float* roi_scores, hipStream_t s);
+/* uint32 priority keys from a counter hash (perf mode sampling) */
+int l2s_random_keys(uint32_t* keys, long n, uint64_t seed, hipStream_t s);
+
+/* anchor_target_layer.py:19-153 on device.  gt float [n_gt][5]; keys uint32 [HWA] (smallest keys are disabled first).
+ * outputs: labels int32 [A*H*W] in the (a,h,w) order of ATL:133-134 (-1,0,1), targets/inside/outside float [HW][4A].
+ * ws: int32/float scratch of l2s_anchor_target_ws_ints(HWA) ints. */
+long l2s_anchor_target_ws_ints(int hwa);
+int l2s_anchor_target(const float* gt, int n_gt, const float* base_anchors, int H, int W, int A, int feat_stride,
+                      float im_h, float im_w, const uint32_t* fg_keys, const uint32_t* bg_keys,
+                      float neg_ov, float pos_ov, int batch, float fg_frac,
+                      int* labels, float* targets, float* inside_w, float* outside_w, int* ws, hipStream_t s);
+
+/* proposal_target_layer.py:22-204 on device (torch-0.3 ByteTensor semantics at :146).
+ * rois [n_max][5], n_rois device int; gt [n_gt][5]; gt_masks uint8 [n_gt][im_h][im_w].
+ * outputs: out_rois [R][5], labels int32 [R], bbox_targets/inside/outside [R][4*ncls], mask_targets float
+ * [fg_max][ms*ms], counts int32[4] = {num_fg, n_fg_cand, n_bg_cand, appended_gt}.  ws: int32 [4*(n_max+n_gt)+16]. */
+int l2s_proposal_target(const float* rois, const float* roi_scores, const int* n_rois, int n_max, const float* gt, int n_gt,
+                        const uint8_t* gt_masks, int im_h, int im_w, const uint32_t* fg_keys, const uint32_t* bg_keys,
+                        const uint32_t* bg_rand, int R, int fg_max, float fg_thresh, float bg_hi, float bg_lo,
+                        const float* means4, const float* stds4, const float* inw4, int ncls, int ms,
+                        float* out_rois, int* labels, float* bbox_targets, float* bbox_inside, float* bbox_outside,
+                        float* mask_targets, int* counts, int* ws, hipStream_t s);
+
+/* crop-and-resize RoIAlign = affine_grid + grid_sample, align_corners=True, zero padding (NET:107-149) */
+int l2s_roialign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
+                     void* out, int dtype, hipStream_t s);
+/* scatter dout [R*P*P][C] back into dfeat float [H*W][C] (atomic) */
+int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
+                     float* dfeat, int dtype, hipStream_t s);
+
+/* ---------------------------------------------------------------- losses -------------------- */
+/* loss slots in the float loss[8] buffer */
+#define L2S_LOSS_RPN_CLS 0
+#define L2S_LOSS_RPN_BOX 1
+#define L2S_LOSS_CLS 2
+#define L2S_LOSS_BOX 3
+#define L2S_LOSS_MASK 4
+#define L2S_LOSS_CAP 5
+#define L2S_LOSS_TOTAL 6
+/* RPN CE over anchors with label != -1 (NET:377-382) + smooth-L1 sigma=3 (NET:385-390).
+ * heads as in l2s_rpn_decode; labels in (a,h,w) order.  dheads(dtype) [HW][ldd] receives d(loss)/d(heads)*gscale. */
+int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
+                 const float* outside_w, int H, int W, int A, float sigma, float gscale, float* loss, void* dheads, int ldd,
+                 int dtype, hipStream_t s);
+/* RCNN CE mean over R (NET:393-395) + smooth-L1 sigma=1 (NET:398-402). heads float [R][ldh]: [0,ncls) cls, [ncls,5ncls) bbox */
+int l2s_rcnn_loss(const float* heads, int ldh, const int* labels, const float* bbox_targets, const float* inside_w,
+                  const float* outside_w, int R, int ncls, float gscale, float* loss, void* dheads, int ldd, int dtype, hipStream_t s);
+/* mask BCE-with-logits on the class channel of the first num_fg rois (NET:405-413). score float [fg_max*ms2][ldsc] */
+int l2s_mask_loss(const float* score, int ldsc, const int* labels, const float* mask_targets, const int* num_fg, int fg_max,
+                  int ms2, float gscale, float* loss, float* dscore /*[fg_max*ms2]*/, hipStream_t s);
+/* total = cls + box + rpn_cls + rpn_box + mask + w*cap (NET:448) */
+int l2s_total_loss(float* loss, float cap_w, hipStream_t s);
+/* mask_pred_net backward (only the label channel carries gradient): dx(dtype)[fg_max*ms2][C] = dscore[p]*W[label][:],
+ * dW[label][:] += sum dscore[p]*x[p][:], db[label] += sum dscore[p] */
+int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C,
+                     const float* w /*[ncls][C]*/, const void* x, const void* relu_ref, void* dx, float* dw, float* db, int dtype, hipStream_t s);
+
+/* ---------------------------------------------------------------- language side ------------- */
+/* small-M linear layers, fp32: y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y_in)) ; act 0 none, 1 relu, 2 tanh */
+int l2s_linear_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K, int act,
+                   int accumulate, hipStream_t s);
+/* dx[m][k] (+)= sum_n dy[m][n] w[n][k] */
+int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate, hipStream_t s);
+/* dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n] */
+int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, hipStream_t s);
+/* activation backward in place: dy *= act'(y)  (act 1 relu, 2 tanh) */
+int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream_t s);
+/* embedding gather out[t][:] = table[ids[t]][:] * (mask ? mask[t][:] : 1), optional relu; and scatter-add backward */
+int l2s_embed_fwd(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu, hipStream_t s);
+int l2s_embed_bwd(const float* dout, const float* out, const int64_t* ids, const float* mask, float* dtable, int T, int D, int relu, hipStream_t s);
+/* nn.LSTM cell (gate order i,f,g,o; lang_encoder.py:21-24): gates[4H] pre-activations (already x-proj + h-proj + biases) */
+int l2s_lstm_cell_fwd(const float* gates, const float* c_prev, float* c, float* h, float* act /*[4H] saved*/, int Hh, hipStream_t s);
+int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const float* act, const float* c_prev, const float* c,
+                      float* dgates, float* dc_prev, int Hh, hipStream_t s);
+/* dynamic-filter correlation (NET:504-562): filt float [7][C] (tanh'ed), r float [7].
+ * y(dtype)[HW][C] = x * resp, resp float [HW], respk float [HW][7] (masked per-filter responses) */
+int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,
+                      int dtype, hipStream_t s);
+/* dy(dtype) -> dx(dtype), dfilt float [7][C] (+=), dr float [7] (+=); dresp_ws float [HW] */
+int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
+                      void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype, hipStream_t s);
+/* att2in2 attention (AttModel.py:406-423): patt [L][D], att [L][D] float; att_h [D]; alpha w[D], b.
+ * out: weight [L] (softmax), att_res [D] */
+int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,
+                          float* tanh_ws /*[L][D]*/, float* weight, float* att_res, hipStream_t s);
+int l2s_cap_attention_bwd(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
+                          float* dpatt /*[L][D] +=*/, float* datt /*[L][D] +=*/, float* datt_h /*[D] =*/, float* daw /*[D] +=*/, float* dab /*+=*/, hipStream_t s);
+/* att2in2 core gates (AttModel.py:446-466): s[5R] = i2h+h2h, a2c[2R]; maxout candidate, no tanh */
+int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save /*[6R]: sig(3R), sel(R), cand(R), tanh(c)(R)*/, int R, hipStream_t s);
+int l2s_cap_gates_bwd(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* dsums /*[5R]*/, float* da2c /*[2R]*/, float* dc_prev, int R, hipStream_t s);
+/* log_softmax + masked NLL (AttModel.py:98, misc/utils.py:43-53): logits [S][V1]; dlogits = gscale*(softmax - onehot)*mask/sum(mask) */
+int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale, float* loss_slot,
+                       float* dlogits, float* logprobs_opt, hipStream_t s);
+
+/* ---------------------------------------------------------------- optimizer ---------------- */
+/* torch.optim.SGD with momentum as configured at train_val_cycle.py:194-220, fused over a flat parameter buffer.
+ * seg table (device): per segment {offset, count, rows, wd_flag}; rowscale (optional, per segment offset into a float array,
+ * -1 = none) multiplies the gradient per output row (folded frozen-BN scale). */
+typedef struct { long offset; long count; int row_len; int weight_decay; long rowscale_off; float lr_mult; int pad; } l2s_sgd_seg;
+int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+                     float lr, float momentum, float wd, float grad_scale, hipStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

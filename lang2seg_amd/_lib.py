@@ -1,0 +1,123 @@
+"""ctypes binding of liblang2seg_hip.so (C ABI in include/lang2seg_hip.h).
+
+No CPU fallback exists: if the library is missing or a symbol is absent this module
+raises, so a GPU box can never silently run a non-HIP path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'liblang2seg_hip.so')
+F32, BF16 = 0, 1
+
+vp, i32, i64, f32, u64, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', vp), ('w', vp), ('y', vp), ('bias', vp), ('add', vp), ('ref', vp),
+                ('n_img', i32), ('IH', i32), ('IW', i32), ('Cin', i32), ('OH', i32), ('OW', i32), ('Cout', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
+                ('ldx', i32), ('ldy', i32), ('ldadd', i32), ('ldref', i32), ('flags', i32),
+                ('out_h', i32), ('out_w', i32), ('out_stride', i32), ('tile', i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('dy', vp), ('x', vp), ('dw', vp),
+                ('n_img', i32), ('IH', i32), ('IW', i32), ('Cin', i32), ('OH', i32), ('OW', i32), ('Cout', i32),
+                ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('lddy', i32), ('ldx', i32),
+                ('split_k', i32), ('tile', i32)]
+
+
+class SgdSeg(C.Structure):
+    _fields_ = [('offset', i64), ('count', i64), ('row_len', i32), ('weight_decay', i32), ('rowscale_off', i64),
+                ('lr_mult', f32), ('pad', i32)]
+
+
+CONV_RELU, CONV_OUT_F32, CONV_DECONV2X2, CONV_SCATTER = 1, 4, 8, 16
+LOSS_RPN_CLS, LOSS_RPN_BOX, LOSS_CLS, LOSS_BOX, LOSS_MASK, LOSS_CAP, LOSS_TOTAL = range(7)
+
+# name -> (restype, argtypes); the stream is always the last argument
+SIGS = {
+    'l2s_version': (i32, []),
+    'l2s_conv_igemm': (i32, [C.POINTER(ConvDesc), i32, vp]),
+    'l2s_conv_wgrad': (i32, [C.POINTER(WgradDesc), i32, vp]),
+    'l2s_weight_cast': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_weight_transpose': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_colsum': (i32, [vp, i32, i32, i32, vp, i32, vp]),
+    'l2s_stem_conv': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'l2s_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'l2s_fill_f32': (i32, [vp, f32, i64, vp]),
+    'l2s_cast': (i32, [vp, i32, vp, i32, i64, vp]),
+    'l2s_add3': (i32, [vp, vp, vp, vp, i64, i32, vp]),
+    'l2s_avgpool_fwd': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_avgpool_bwd': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_adaptive_pool_fwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'l2s_adaptive_pool_bwd': (i32, [vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'l2s_mask_downsample': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_dropout_mask': (i32, [vp, i64, f32, u64, vp]),
+    'l2s_rpn_decode': (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]),
+    'l2s_sort_topk': (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    'l2s_nms_workspace_bytes': (sz, [i32]),
+    'l2s_nms': (i32, [vp, i32, f32, i32, i32, vp, vp, vp, vp]),
+    'l2s_gather_rois': (i32, [vp, vp, vp, vp, i32, vp, vp, vp]),
+    'l2s_random_keys': (i32, [vp, i64, u64, vp]),
+    'l2s_anchor_target_ws_ints': (i64, [i32]),
+    'l2s_anchor_target': (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, f32, f32, i32, f32, vp, vp, vp, vp, vp, vp]),
+    'l2s_proposal_target': (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, i32, i32, f32, f32, f32,
+                                  vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'l2s_roialign_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, i32, vp]),
+    'l2s_roialign_bwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, i32, vp]),
+    'l2s_rpn_loss': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp]),
+    'l2s_rcnn_loss': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, f32, vp, vp, i32, i32, vp]),
+    'l2s_mask_loss': (i32, [vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
+    'l2s_total_loss': (i32, [vp, f32, vp]),
+    'l2s_maskpred_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_linear_fwd': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'l2s_linear_bwd_x': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'l2s_linear_bwd_w': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]),
+    'l2s_act_bwd': (i32, [vp, vp, i64, i32, vp]),
+    'l2s_embed_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    'l2s_embed_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    'l2s_lstm_cell_fwd': (i32, [vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_lstm_cell_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_dynfilter_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_dynfilter_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_cap_attention_fwd': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
+    'l2s_cap_attention_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+    'l2s_cap_gates_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_cap_gates_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_logsoftmax_nll': (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
+    'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp]),
+}
+
+_lib = None
+
+
+class L2SError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and bind every symbol the header declares (loud on any miss)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise L2SError('%s not found: run `python __graft_entry__.py` (hipcc build) first; there is no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """torch tensor (or None) -> raw device/host address."""
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    r = getattr(load(), name)(*args)
+    if r != 0:
+        raise L2SError('%s returned error %d' % (name, r))

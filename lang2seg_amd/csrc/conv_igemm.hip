@@ -1,0 +1,420 @@
+// Implicit-GEMM convolution on CDNA4 matrix cores (gfx950), NHWC activations.
+//
+//   l2s_conv_igemm : forward conv / 1x1 / Linear / data-gradient, no im2col buffer.
+//                    C[m][n] = sum_k A(m,k) * W[n][k],  m = output pixel, n = output channel,
+//                    k = (tap, cin); A gathered on the fly from the NHWC input (zero padded).
+//   l2s_conv_wgrad : weight gradient, dW[n][tap][c] += sum_m dY[m][n] * X(m,tap)[c]
+//                    (reduction over pixels; both operands are pixel-major in HBM, so the bf16
+//                    path feeds the MFMA through ds_read_b64_tr_b16 transposed LDS reads).
+//
+// Replaces the cuDNN calls behind nn.Conv2d / F.conv2d / nn.Linear in the reference
+// (pyutils/mask-faster-rcnn/lib/nets/resnet_v1_cycle_res5_2.py:83-88,121,147,324-335 and
+// network_cycle_res5_2.py:236-251,279-301).
+//
+// Tiling: 256 threads = 4 waves (2x2); block tile BMxBN (128x128 or 64x64); K consumed in 128-byte
+// slices per row (64 bf16 / 32 f32) staged global -> registers -> LDS (double buffered, one barrier per
+// slice); 16x16 MFMA tiles: v_mfma_f32_16x16x32_bf16 or the exact-f32 v_mfma_f32_16x16x4_f32
+// ("verification mode").  LDS rows are padded by 16 B so the ds_read_b128 fragment reads are
+// conflict-free.  The MFMA is issued with operands swapped (rows = n, cols = m) so that each lane ends
+// up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+#include "common.h"
+#include "../../include/lang2seg_hip.h"
+
+namespace {
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // 16 k per 64-byte group: lane group g holds k = 4g..4g+3; step e multiplies k = 4g+e of every group.
+  static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+};
+
+constexpr int ROWB = 128;        // bytes of K per LDS row per slice
+constexpr int LROW = ROWB + 16;  // padded LDS row
+
+template <typename T, int BM, int BN, bool OUTF32>
+__global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
+  constexpr int VE = 16 / (int)sizeof(T);    // elements per 16-byte vector
+  constexpr int BK = ROWB / (int)sizeof(T);  // K elements per slice
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int NA = BM / 32, NB = BN / 32;  // 16-byte vectors per thread per slice
+  constexpr int BUF = (BM + BN) * LROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ Wt = (const T*)p.w;
+
+  // ---- per-thread loader coordinates (rows fixed for the whole K loop) ----
+  const int lrow = tid >> 3, cv = tid & 7;
+  int a_iy0[NA], a_ix0[NA]; long a_base[NA]; bool a_ok[NA];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    int m = m0 + lrow + 32 * j;
+    a_ok[j] = m < M;
+    int mm = a_ok[j] ? m : 0;
+    int n_img = mm / ohw, rem = mm - n_img * ohw;
+    int oy = rem / p.OW, ox = rem - oy * p.OW;
+    a_iy0[j] = oy * p.stride - p.pad;
+    a_ix0[j] = ox * p.stride - p.pad;
+    a_base[j] = (long)n_img * p.IH * p.IW;
+  }
+  long b_off[NB]; bool b_ok[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    int n = n0 + lrow + 32 * j;
+    b_ok[j] = n < p.Cout;
+    b_off[j] = (long)(b_ok[j] ? n : 0) * K;
+  }
+
+  uint4 ra[NA], rb[NB];
+  auto load_slice = [&](int kt) {
+    const int k0 = kt * BK;
+    int tap = 0, c0 = k0;
+    if (p.KH * p.KW > 1) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; }
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int kk = k0 + cv * VE;
+    const bool kin = kk < K;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+      bool ok = a_ok[j] && kin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *(const uint4*)(X + ((a_base[j] + (long)iy * p.IW + ix) * p.ldx + c0 + cv * VE));
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_ok[j] && kin) v = *(const uint4*)(Wt + b_off[j] + kk);
+      rb[j] = v;
+    }
+  };
+  auto store_slice = [&](int buf) {
+    char* a = smem + buf * BUF;
+    char* b = a + BM * LROW;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *(uint4*)(a + (lrow + 32 * j) * LROW + cv * 16) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *(uint4*)(b + (lrow + 32 * j) * LROW + cv * 16) = rb[j];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int KT = (K + BK - 1) / BK;
+  load_slice(0);
+  store_slice(0);
+  __syncthreads();
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) load_slice(kt + 1);
+    const char* a = smem + cur * BUF + (wm * WM + fr) * LROW + fg * 16;
+    const char* b = smem + cur * BUF + BM * LROW + (wn * WN + fr) * LROW + fg * 16;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(a + i * 16 * LROW + kg * 64);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(b + j * 16 * LROW + kg * 64);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
+    }
+    if (kt + 1 < KT) store_slice(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 tile ----
+  const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + fr;
+    if (m >= M) continue;
+    long orow = m;
+    int n_img = 0, oy = 0, ox = 0;
+    if (p.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) {
+      n_img = m / ohw; int rem = m - n_img * ohw; oy = rem / p.OW; ox = rem - oy * p.OW;
+      if (p.flags & L2S_CONV_SCATTER) orow = ((long)n_img * p.out_h + (long)oy * p.out_stride) * p.out_w + (long)ox * p.out_stride;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fg * 4;
+      if (n >= p.Cout) continue;
+      int oc = n; long orow2 = orow;
+      if (p.flags & L2S_CONV_DECONV2X2) {
+        int tap = n / Cq; oc = n - tap * Cq;
+        orow2 = ((long)n_img * 2 * p.OH + 2 * oy + (tap >> 1)) * (2 * p.OW) + 2 * ox + (tap & 1);
+      }
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      const bool full = (n + 3 < p.Cout);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (!full && n + r >= p.Cout) break;
+        if (p.bias) v[r] += p.bias[oc + r];
+        if (p.add) v[r] += Elem<T>::ld((const T*)p.add + orow2 * p.ldadd + oc + r);
+        if (p.flags & L2S_CONV_RELU) v[r] = fmaxf(v[r], 0.f);
+        if (p.ref) { if (!(Elem<T>::ld((const T*)p.ref + orow2 * p.ldref + oc + r) > 0.f)) v[r] = 0.f; }
+      }
+      if (OUTF32) {
+        float* o = (float*)p.y + orow2 * p.ldy + oc;
+        if (full && ((p.ldy & 3) == 0) && ((oc & 3) == 0)) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int r = 0; r < 4 && n + r < p.Cout; ++r) o[r] = v[r];
+      } else {
+        T* o = (T*)p.y + orow2 * p.ldy + oc;
+        if (sizeof(T) == 4) {
+          if (full && ((p.ldy & 3) == 0) && ((oc & 3) == 0)) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+          else for (int r = 0; r < 4 && n + r < p.Cout; ++r) Elem<T>::st(o + r, v[r]);
+        } else {
+          if (full && ((p.ldy & 3) == 0) && ((oc & 3) == 0)) {
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *(uint2*)o = pk;
+          } else for (int r = 0; r < 4 && n + r < p.Cout; ++r) Elem<T>::st(o + r, v[r]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct WG;
+template <> struct WG<bf16_t> {
+  static constexpr int BKP = 32;  // pixels per slice (= one 16x16x32 MFMA k-step)
+  static __device__ __forceinline__ int lrow(int bm) { return bm * 2 + 32; }  // stride == 8 dwords (mod 64): tr reads conflict-free
+};
+template <> struct WG<float> {
+  static constexpr int BKP = 16;
+  static __device__ __forceinline__ int lrow(int bm) { return bm * 4 + 64; }  // stride == 16 dwords (mod 32)
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  constexpr int BKP = WG<T>::BKP;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int LRA = BM * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
+  constexpr int LRB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
+  constexpr int VPA = BM / VE, VPB = BN / VE;            // vectors per row
+  constexpr int NVA = BKP * VPA / 256, NVB = BKP * VPB / 256;  // vectors per thread
+  static_assert(NVA >= 1 && NVB >= 1, "tile too small");
+  constexpr int BUF = BKP * (LRA + LRB);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int co0 = blockIdx.x * BM;
+  const int cblocks = (p.Cin + BN - 1) / BN;
+  const int tap = blockIdx.y / cblocks, ci0 = (blockIdx.y - tap * cblocks) * BN;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int M = p.n_img * p.OH * p.OW;
+  const int ohw = p.OH * p.OW;
+  const float r_ohw = 1.0f / (float)ohw, r_ow = 1.0f / (float)p.OW;
+  const T* __restrict__ DY = (const T*)p.dy;
+  const T* __restrict__ X = (const T*)p.x;
+
+  const int nslices = (M + BKP - 1) / BKP;
+  const int per = (nslices + gridDim.z - 1) / gridDim.z;
+  const int s_begin = blockIdx.z * per;
+  const int s_end = min(nslices, s_begin + per);
+  if (s_begin >= s_end) return;
+
+  uint4 ra[NVA], rb[NVB];
+  auto load_slice = [&](int s) {
+    const int pb = s * BKP;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      int v = tid + j * 256; int r = v / VPA, c = v - r * VPA;
+      int pix = pb + r, co = co0 + c * VE;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (pix < M && co < p.Cout) val = *(const uint4*)(DY + (long)pix * p.lddy + co);
+      ra[j] = val;
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      int v = tid + j * 256; int r = v / VPB, c = v - r * VPB;
+      int pix = pb + r, ci = ci0 + c * VE;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (pix < M && ci < p.Cin) {
+        int n_img = fast_div(pix, ohw, r_ohw); int rem = pix - n_img * ohw;
+        int oy = fast_div(rem, p.OW, r_ow), ox = rem - oy * p.OW;
+        int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+        if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+          val = *(const uint4*)(X + (((long)n_img * p.IH + iy) * p.IW + ix) * p.ldx + ci);
+      }
+      rb[j] = val;
+    }
+  };
+  auto store_slice = [&](int buf) {
+    char* a = smem + buf * BUF;
+    char* b = a + BKP * LRA;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) { int v = tid + j * 256; int r = v / VPA, c = v - r * VPA; *(uint4*)(a + r * LRA + c * 16) = ra[j]; }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) { int v = tid + j * 256; int r = v / VPB, c = v - r * VPB; *(uint4*)(b + r * LRB + c * 16) = rb[j]; }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_slice(s_begin);
+  store_slice(0);
+  __syncthreads();
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int cur = (s - s_begin) & 1;
+    if (s + 1 < s_end) load_slice(s + 1);
+    const char* a = smem + cur * BUF;
+    const char* b = a + BKP * LRA;
+    if constexpr (sizeof(T) == 2) {
+      // k mapping inside the 32-pixel slice: lane group g, half h, element e  <->  pixel 16h + 4g + e
+      // (same map for both operands, so the contraction is consistent; chosen so a 32-lane half reads
+      // 8 consecutive LDS rows -> conflict-free with the 8-dword row skew).
+      const int trow = 4 * fg + ((lane >> 2) & 3), tcol = 8 * (lane & 3);
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const char* q = a + trow * LRA + (wm * WM + i * 16) * 2 + tcol;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRA));
+        fa[i] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const char* q = b + trow * LRB + (wn * WN + j * 16) * 2 + tcol;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRB));
+        fb[j] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < BKP / 4; ++ks) {
+        float fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *(const float*)(a + (ks * 4 + fg) * LRA + (wm * WM + i * 16 + fr) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *(const float*)(b + (ks * 4 + fg) * LRB + (wn * WN + j * 16 + fr) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < s_end) store_slice(cur ^ 1);
+    __syncthreads();
+  }
+  // D[row = co][col = ci]: col = lane&15, row = 4*(lane>>4) + r
+  const long Kw = (long)p.KH * p.KW * p.Cin;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ci = ci0 + wn * WN + j * 16 + fr;
+      if (ci >= p.Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * WM + i * 16 + fg * 4 + r;
+        if (co < p.Cout) atomicAdd(p.dw + (long)co * Kw + (long)tap * p.Cin + ci, acc[i][j][r]);
+      }
+    }
+}
+
+template <typename T, int BM, int BN, bool OUTF32>
+int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN));
+  size_t lds = 2 * (BM + BN) * LROW;
+  static bool attr_done = false;
+  if (!attr_done) { hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, OUTF32>), grid, dim3(256), lds, st, d);
+  return l2s_check_launch();
+}
+
+template <typename T, int BM, int BN>
+int launch_wgrad(const l2s_wgrad_desc& d, int split, hipStream_t st) {
+  const int taps = d.KH * d.KW;
+  dim3 grid(cdiv(d.Cout, BM), taps * cdiv(d.Cin, BN), split);
+  constexpr int LRA = BM * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
+  constexpr int LRB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
+  size_t lds = 2 * WG<T>::BKP * (LRA + LRB);
+  hipLaunchKernelGGL((wgrad_kernel<T, BM, BN>), grid, dim3(256), lds, st, d);
+  return l2s_check_launch();
+}
+
+}  // namespace
+
+extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream) {
+  if (!d || !d->x || !d->w || !d->y) return L2S_EINVAL;
+  const int ve = dtype == L2S_BF16 ? 8 : 4;
+  const int K = d->KH * d->KW * d->Cin;
+  if (d->ldx % ve || K % ve || (d->KH * d->KW > 1 && d->Cin % (dtype == L2S_BF16 ? 64 : 32))) return L2S_EINVAL;
+  if ((d->flags & L2S_CONV_DECONV2X2) && (d->Cout % 16)) return L2S_EINVAL;
+  const long M = (long)d->n_img * d->OH * d->OW;
+  if (M >= (1 << 24)) return L2S_EINVAL;
+  const bool f32o = d->flags & L2S_CONV_OUT_F32;
+  // tile choice: prefer 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64
+  const long t128 = (long)cdiv(M, 128) * cdiv(d->Cout, 128);
+  int tile = d->tile ? d->tile : ((t128 >= 200 && d->Cout >= 96) ? 128 : 64);
+#define GO(T, BM, BN) (f32o ? launch_igemm<T, BM, BN, true>(*d, stream) : launch_igemm<T, BM, BN, false>(*d, stream))
+  if (dtype == L2S_BF16) return tile == 128 ? GO(bf16_t, 128, 128) : GO(bf16_t, 64, 64);
+  if (dtype == L2S_F32) return tile == 128 ? GO(float, 128, 128) : GO(float, 64, 64);
+#undef GO
+  return L2S_EINVAL;
+}
+
+extern "C" int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream) {
+  if (!d || !d->dy || !d->x || !d->dw) return L2S_EINVAL;
+  const int ve = dtype == L2S_BF16 ? 8 : 4;
+  if (d->lddy % ve || d->ldx % ve || d->Cin % ve || d->Cout % ve) return L2S_EINVAL;
+  const long M = (long)d->n_img * d->OH * d->OW;
+  if (M >= (1 << 24)) return L2S_EINVAL;
+  const int taps = d->KH * d->KW;
+  int tile = d->tile ? d->tile : ((d->Cout >= 128 && d->Cin >= 128) ? 128 : 64);
+  const long tiles = (long)cdiv(d->Cout, tile) * taps * cdiv(d->Cin, tile);
+  const int bkp = dtype == L2S_BF16 ? 32 : 16;
+  int split = d->split_k;
+  if (split <= 0) {
+    split = (int)((512 + tiles - 1) / tiles);          // aim at ~2 workgroups per CU
+    int maxs = cdiv(M, bkp * 8);                       // at least 8 slices per split
+    if (split > maxs) split = maxs;
+    if (split < 1) split = 1;
+    if (split > 64) split = 64;
+  }
+  if (dtype == L2S_BF16) return tile == 128 ? launch_wgrad<bf16_t, 128, 128>(*d, split, stream) : launch_wgrad<bf16_t, 64, 64>(*d, split, stream);
+  if (dtype == L2S_F32) return tile == 128 ? launch_wgrad<float, 128, 128>(*d, split, stream) : launch_wgrad<float, 64, 64>(*d, split, stream);
+  return L2S_EINVAL;
+}

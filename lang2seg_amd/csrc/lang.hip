@@ -1,0 +1,434 @@
+// Language side of the lang2seg train step on gfx950: skinny (batch-1) linear layers, the bi-LSTM cell,
+// the spatial dynamic-filter correlation and the att2in2 captioner core, forward + backward, fp32.
+// Reference: lib/layers/lang_encoder.py:27-82, lib/caption_models/AttModel.py:60-101,406-466,
+// lib/misc/utils.py:43-53, pyutils/mask-faster-rcnn/lib/nets/network_cycle_res5_2.py:504-562.
+// Everything here is GEMV-shaped (M = 1..21): weights are streamed once per call, one wave per output row,
+// wave-level shuffle reductions; HBM/L2-bandwidth- and latency-bound, no MFMA reshaping.
+#include "common.h"
+#include "../../include/lang2seg_hip.h"
+
+namespace {
+
+constexpr int MAXM = 24;   // rows handled per wave pass in the skinny kernels
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return tanhf(v);
+  return v;
+}
+
+// y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y[m][n]));  one wave per n, M <= MAXM per pass
+template <int MT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx_, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* y, int ldy, int m0, int M, int N, int K,
+                                                        int act, int accumulate) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  const float* wr = w + (long)n * K;
+  for (int k = lane * 4; k < K; k += 256) {
+    float4 wv;
+    if (k + 3 < K) wv = *(const float4*)(wr + k);
+    else { wv.x = wr[k]; wv.y = k + 1 < K ? wr[k + 1] : 0.f; wv.z = k + 2 < K ? wr[k + 2] : 0.f; wv.w = 0.f; }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m0 + m < M) {
+        const float* xr = x + (long)(m0 + m) * ldx_ + k;
+        float4 xv;
+        if (k + 3 < K) xv = *(const float4*)xr;
+        else { xv.x = xr[0]; xv.y = k + 1 < K ? xr[1] : 0.f; xv.z = k + 2 < K ? xr[2] : 0.f; xv.w = 0.f; }
+        acc[m] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[m]))));
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (m0 + m < M) {
+        float v = acc[m] + (b ? b[n] : 0.f);
+        float* o = y + (long)(m0 + m) * ldy + n;
+        if (accumulate) v += *o;
+        *o = act_apply(v, act);
+      }
+  }
+}
+
+// dx[m][k] (+)= sum_n dy[m][n] w[n][k]; thread per k, loops n (w rows coalesced along k)
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w, float* dx,
+                                                          int lddx, int M, int N, int K, int accumulate, int nsplit) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  const int sp = blockIdx.z;
+  if (k >= K) return;
+  const int per = (N + nsplit - 1) / nsplit, nb = sp * per, ne = min(N, nb + per);
+  float acc = 0.f;
+  const float* dyr = dy + (long)m * lddy;
+  for (int n = nb; n < ne; ++n) acc = fmaf(dyr[n], w[(long)n * K + k], acc);
+  if (nsplit > 1) atomicAdd(dx + (long)m * lddx + k, acc);
+  else if (accumulate) dx[(long)m * lddx + k] += acc;
+  else dx[(long)m * lddx + k] = acc;
+}
+
+// dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n]
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx_,
+                                                          float* dw, float* db, int M, int N, int K) {
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < K) {
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc = fmaf(dy[(long)m * lddy + n], x[(long)m * ldx_ + k], acc);
+    dw[(long)n * K + k] += acc;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(long)m * lddy + n];
+    db[n] += s;
+  }
+}
+
+__global__ void act_bwd_kernel(float* dy, const float* y, long n, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = y[i];
+    if (act == 1) { if (!(v > 0.f)) dy[i] = 0.f; }
+    else if (act == 2) dy[i] *= (1.f - v * v);
+  }
+}
+
+__global__ void embed_fwd_kernel(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu) {
+  const int t = blockIdx.x;
+  const float* row = table + ids[t] * (long)D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float v = row[d];
+    if (relu) v = fmaxf(v, 0.f);
+    if (mask) v *= mask[(long)t * D + d];
+    out[(long)t * D + d] = v;
+  }
+}
+__global__ void embed_bwd_kernel(const float* dout, const float* out, const int64_t* ids, const float* mask, float* dtable, int T, int D, int relu) {
+  const int t = blockIdx.x;
+  float* row = dtable + ids[t] * (long)D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float g = dout[(long)t * D + d];
+    if (mask) g *= mask[(long)t * D + d];
+    if (relu && out[(long)t * D + d] == 0.f) g = 0.f;   // relu killed it (or the mask did, then g is 0 already)
+    atomicAdd(row + d, g);   // the same token may occur twice in one expression
+  }
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void lstm_cell_fwd_kernel(const float* g, const float* c_prev, float* c, float* h, float* act, int Hh) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Hh) return;
+  const float i = sigm(g[j]), f = sigm(g[Hh + j]), gg = tanhf(g[2 * Hh + j]), o = sigm(g[3 * Hh + j]);
+  const float cn = f * c_prev[j] + i * gg;
+  c[j] = cn; h[j] = o * tanhf(cn);
+  act[j] = i; act[Hh + j] = f; act[2 * Hh + j] = gg; act[3 * Hh + j] = o;
+}
+__global__ void lstm_cell_bwd_kernel(const float* dh, const float* dc_in, const float* act, const float* c_prev, const float* c,
+                                     float* dg, float* dc_prev, int Hh) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Hh) return;
+  const float i = act[j], f = act[Hh + j], gg = act[2 * Hh + j], o = act[3 * Hh + j];
+  const float tc = tanhf(c[j]);
+  const float dcn = (dc_in ? dc_in[j] : 0.f) + dh[j] * o * (1.f - tc * tc);
+  dg[j] = dcn * gg * i * (1.f - i);
+  dg[Hh + j] = dcn * c_prev[j] * f * (1.f - f);
+  dg[2 * Hh + j] = dcn * i * (1.f - gg * gg);
+  dg[3 * Hh + j] = dh[j] * tc * o * (1.f - o);
+  dc_prev[j] = dcn * f;
+}
+
+// ---------------------------------------------------------------- dynamic filter correlation
+__device__ __forceinline__ void spatial_mask7(int y, int x, int H, int W, float m[7]) {
+  // NET:530-557 (python-2 true division then int())
+  m[0] = 1.f;
+  m[1] = (y < (int)(H / 2.0)) ? 1.f : 0.f;
+  m[2] = (y >= (int)(H / 2.0)) ? 1.f : 0.f;
+  m[3] = (x < (int)(W / 2.0)) ? 1.f : 0.f;
+  m[4] = (x >= (int)(W / 2.0)) ? 1.f : 0.f;
+  m[5] = (y >= (int)(H / 4.0) && y < (int)(H * 3 / 4.0)) ? 1.f : 0.f;
+  m[6] = (x >= (int)(W / 4.0) && x < (int)(W * 3 / 4.0)) ? 1.f : 0.f;
+}
+// one wave per pixel: 7 masked channel dot products, 7->1 mix, modulate
+__global__ __launch_bounds__(256) void dynfilter_fwd_kernel(const void* x, const float* __restrict__ filt, const float* __restrict__ r, void* y,
+                                                           float* resp, float* respk, int H, int W, int C, int dt) {
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pix >= H * W) return;
+  float d[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int c = lane; c < C; c += 64) {
+    const float v = ldx(x, (long)pix * C + c, dt);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) d[k] = fmaf(v, filt[k * C + c], d[k]);
+  }
+  float m[7]; spatial_mask7(pix / W, pix % W, H, W, m);
+  float rs = 0.f;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { d[k] = wave_sum(d[k]) * m[k]; rs = fmaf(r[k], d[k], rs); }
+  if (lane < 7) respk[(long)pix * 7 + lane] = d[lane];
+  if (lane == 0) resp[pix] = rs;
+  for (int c = lane; c < C; c += 64) stx(y, (long)pix * C + c, dt, ldx(x, (long)pix * C + c, dt) * rs);
+}
+// pass 1: dresp[p] = sum_c dy[p][c] x[p][c]; dr[k] += sum_p dresp[p]*respk[p][k]
+__global__ __launch_bounds__(256) void dynfilter_bwd1_kernel(const void* dy, const void* x, const float* respk, float* dresp, float* dr, int HW, int C, int dt) {
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pix >= HW) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(ldx(dy, (long)pix * C + c, dt), ldx(x, (long)pix * C + c, dt), s);
+  s = wave_sum(s);
+  if (lane == 0) dresp[pix] = s;
+  if (lane < 7) atomicAdd(dr + lane, s * respk[(long)pix * 7 + lane]);
+}
+// pass 2: dx[p][c] = dy*resp + dresp[p]*sum_k r_k m_k[p] f_k[c] (ReLU-masked by relu_ref); dfilt[k][c] += sum_p dresp r_k m_k x[p][c]
+// block = 64 channels x 4 pixel lanes, grid.y over pixel chunks
+__global__ __launch_bounds__(256) void dynfilter_bwd2_kernel(const void* dy, const void* x, const float* __restrict__ filt, const float* __restrict__ r,
+                                                            const float* __restrict__ resp, const float* __restrict__ dresp, void* dx, const void* ref,
+                                                            float* dfilt, int H, int W, int C, int dt, int pchunk) {
+  __shared__ float red[4][7][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+  const int p0 = blockIdx.y * pchunk, p1 = min(H * W, p0 + pchunk);
+  float fk[7], acc[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { fk[k] = (c < C) ? filt[k * C + c] * r[k] : 0.f; acc[k] = 0.f; }
+  for (int p = p0 + pl; p < p1; p += 4) {
+    if (c >= C) break;
+    float m[7]; spatial_mask7(p / W, p % W, H, W, m);
+    const float dr_ = dresp[p];
+    const float xv = ldx(x, (long)p * C + c, dt);
+    float g = ldx(dy, (long)p * C + c, dt) * resp[p];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { t = fmaf(m[k], fk[k], t); acc[k] = fmaf(dr_ * m[k], xv, acc[k]); }
+    g = fmaf(dr_, t, g);
+    if (ref && !(ldx(ref, (long)p * C + c, dt) > 0.f)) g = 0.f;
+    stx(dx, (long)p * C + c, dt, g);
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) red[pl][k][threadIdx.x & 63] = acc[k];
+  __syncthreads();
+  if (pl == 0 && c < C) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int l = threadIdx.x;
+      atomicAdd(dfilt + k * C + c, (red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l]) * r[k]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- att2in2 attention (single workgroup, L <= 256)
+__global__ __launch_bounds__(1024) void cap_att_fwd_kernel(const float* __restrict__ patt, const float* __restrict__ att, const float* __restrict__ att_h,
+                                                          const float* __restrict__ aw, const float* __restrict__ ab, int L, int D,
+                                                          float* tanh_ws, float* weight, float* att_res) {
+  __shared__ float dots[256];
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int l = wave; l < L; l += nw) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float t = tanhf(patt[(long)l * D + d] + att_h[d]);
+      tanh_ws[(long)l * D + d] = t;
+      s = fmaf(t, aw[d], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) dots[l] = s + ab[0];
+  }
+  __syncthreads();
+  float v = tid < L ? dots[tid] : -INFINITY;
+  const float mx = block_max(v, red);
+  const float e = tid < L ? expf(v - mx) : 0.f;
+  const float sum = block_sum(e, red);
+  if (tid < L) { dots[tid] = e / sum; weight[tid] = e / sum; }
+  __syncthreads();
+  for (int d = tid; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s = fmaf(dots[l], att[(long)l * D + d], s);
+    att_res[d] = s;
+  }
+}
+__global__ __launch_bounds__(1024) void cap_att_bwd_kernel(const float* __restrict__ dres, const float* __restrict__ att, const float* __restrict__ tanh_ws,
+                                                          const float* __restrict__ weight, const float* __restrict__ aw, int L, int D,
+                                                          float* dpatt, float* datt, float* datt_h, float* daw, float* dab) {
+  __shared__ float dw_[256];
+  __shared__ float ddot[256];
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  // dweight[l] = dres . att[l]
+  for (int l = wave; l < L; l += nw) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s = fmaf(dres[d], att[(long)l * D + d], s);
+    s = wave_sum(s);
+    if (lane == 0) dw_[l] = s;
+  }
+  __syncthreads();
+  const float wl = tid < L ? weight[tid] : 0.f;
+  const float dot = block_sum(tid < L ? wl * dw_[tid] : 0.f, red);
+  if (tid < L) ddot[tid] = wl * (dw_[tid] - dot);      // softmax backward
+  __syncthreads();
+  const float sdd = block_sum(tid < L ? ddot[tid] : 0.f, red);
+  if (tid == 0) dab[0] += sdd;
+  // per-d accumulations
+  for (int d = tid; d < D; d += blockDim.x) {
+    float sah = 0.f, saw = 0.f;
+    const float a = aw[d], dr = dres[d];
+    for (int l = 0; l < L; ++l) {
+      const float t = tanh_ws[(long)l * D + d];
+      const float dd = ddot[l];
+      const float dt_ = dd * a * (1.f - t * t);
+      dpatt[(long)l * D + d] += dt_;
+      datt[(long)l * D + d] += weight[l] * dr;
+      sah += dt_;
+      saw = fmaf(dd, t, saw);
+    }
+    datt_h[d] = sah;
+    daw[d] += saw;
+  }
+}
+
+__global__ void cap_gates_fwd_kernel(const float* s, const float* a2c, const float* c_prev, float* c, float* h, float* save, int R) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R) return;
+  const float ig = sigm(s[j]), fg = sigm(s[R + j]), og = sigm(s[2 * R + j]);
+  const float t0 = s[3 * R + j] + a2c[j], t1 = s[4 * R + j] + a2c[R + j];
+  const float it = fmaxf(t0, t1);
+  const float cn = fg * c_prev[j] + ig * it;
+  const float tc = tanhf(cn);
+  c[j] = cn; h[j] = og * tc;
+  save[j] = ig; save[R + j] = fg; save[2 * R + j] = og; save[3 * R + j] = (t0 >= t1) ? 0.f : 1.f;  // torch.max(a,b): first wins ties
+  save[4 * R + j] = it; save[5 * R + j] = tc;
+}
+__global__ void cap_gates_bwd_kernel(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* ds, float* da2c,
+                                     float* dc_prev, int R) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R) return;
+  const float ig = save[j], fg = save[R + j], og = save[2 * R + j], sel = save[3 * R + j], it = save[4 * R + j];
+  const float tc = save[5 * R + j];
+  const float dcn = (dc_in ? dc_in[j] : 0.f) + dh[j] * og * (1.f - tc * tc);
+  ds[j] = dcn * it * ig * (1.f - ig);
+  ds[R + j] = dcn * c_prev[j] * fg * (1.f - fg);
+  ds[2 * R + j] = dh[j] * tc * og * (1.f - og);
+  const float dit = dcn * ig;
+  const float d0 = sel == 0.f ? dit : 0.f, d1 = sel == 0.f ? 0.f : dit;
+  ds[3 * R + j] = d0; ds[4 * R + j] = d1;
+  da2c[j] = d0; da2c[R + j] = d1;
+  dc_prev[j] = dcn * fg;
+}
+
+// log_softmax + masked NLL over S rows (one workgroup per row)
+__global__ __launch_bounds__(1024) void lsm_nll_kernel(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale,
+                                                      float* loss_slot, float* dlogits, float* logprobs) {
+  __shared__ float red[16];
+  const int srow = blockIdx.x, tid = threadIdx.x;
+  const float* lr = logits + (long)srow * V1;
+  float mx = -INFINITY;
+  for (int v = tid; v < V1; v += blockDim.x) mx = fmaxf(mx, lr[v]);
+  mx = block_max(mx, red);
+  float se = 0.f;
+  for (int v = tid; v < V1; v += blockDim.x) se += expf(lr[v] - mx);
+  se = block_sum(se, red);
+  const float lse = mx + logf(se);
+  float msum = 0.f;
+  for (int i = 0; i < S; ++i) msum += mask[i];
+  const float mk = mask[srow];
+  const int tg = (int)target[srow];
+  for (int v = tid; v < V1; v += blockDim.x) {
+    const float lp = lr[v] - lse;
+    if (logprobs) logprobs[(long)srow * V1 + v] = lp;
+    if (dlogits) dlogits[(long)srow * V1 + v] = gscale * mk / msum * (expf(lp) - (v == tg ? 1.f : 0.f));
+  }
+  if (tid == 0) atomicAdd(loss_slot, -(lr[tg] - lse) * mk / msum);
+}
+
+}  // namespace
+
+extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, const float* b, float* y, int ldy, int M, int N, int K, int act,
+                              int accumulate, hipStream_t s) {
+  if (M <= 0 || N <= 0) return L2S_OK;
+  if ((K & 3) || (ldx_ & 3)) return L2S_EINVAL;
+  for (int m0 = 0; m0 < M; m0 += MAXM) {
+    const int rem = M - m0;
+    dim3 grid(cdiv(N, 4));
+    if (rem <= 1) hipLaunchKernelGGL(linear_fwd_kernel<1>, grid, dim3(256), 0, s, x, ldx_, w, b, y, ldy, m0, M, N, K, act, accumulate);
+    else if (rem <= 8) hipLaunchKernelGGL(linear_fwd_kernel<8>, grid, dim3(256), 0, s, x, ldx_, w, b, y, ldy, m0, M, N, K, act, accumulate);
+    else hipLaunchKernelGGL(linear_fwd_kernel<MAXM>, grid, dim3(256), 0, s, x, ldx_, w, b, y, ldy, m0, M, N, K, act, accumulate);
+  }
+  return l2s_check_launch();
+}
+extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate, hipStream_t s) {
+  if (M <= 0) return L2S_OK;
+  int nsplit = 1;
+  if (N >= 1024 && (long)M * cdiv(K, 256) < 128) nsplit = 8;
+  if (nsplit > 1 && !accumulate) {
+    for (int m = 0; m < M; ++m) hipMemsetAsync(dx + (long)m * lddx, 0, (size_t)K * 4, s);
+  }
+  hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(K, 256), M, nsplit), dim3(256), 0, s, dy, lddy, w, dx, lddx, M, N, K, accumulate, nsplit);
+  return l2s_check_launch();
+}
+extern "C" int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx_, float* dw, float* db, int M, int N, int K, hipStream_t s) {
+  if (M <= 0) return L2S_OK;
+  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
+  return l2s_check_launch();
+}
+extern "C" int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream_t s) {
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, s, dy, y, n, act);
+  return l2s_check_launch();
+}
+extern "C" int l2s_embed_fwd(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu, hipStream_t s) {
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(T), dim3(256), 0, s, table, ids, mask, out, T, D, relu);
+  return l2s_check_launch();
+}
+extern "C" int l2s_embed_bwd(const float* dout, const float* out, const int64_t* ids, const float* mask, float* dtable, int T, int D, int relu, hipStream_t s) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(T), dim3(256), 0, s, dout, out, ids, mask, dtable, T, D, relu);
+  return l2s_check_launch();
+}
+extern "C" int l2s_lstm_cell_fwd(const float* gates, const float* c_prev, float* c, float* h, float* act, int Hh, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(Hh, 256)), dim3(256), 0, s, gates, c_prev, c, h, act, Hh);
+  return l2s_check_launch();
+}
+extern "C" int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const float* act, const float* c_prev, const float* c,
+                                 float* dgates, float* dc_prev, int Hh, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(Hh, 256)), dim3(256), 0, s, dh, dc_in, act, c_prev, c, dgates, dc_prev, Hh);
+  return l2s_check_launch();
+}
+extern "C" int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,
+                                 int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
+                                 void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype);
+  const int pchunk = 64;
+  hipLaunchKernelGGL(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), cdiv(H * W, pchunk)), dim3(256), 0, s, dy, x, filt, r, resp, dresp_ws, dx, relu_ref,
+                     dfilt, H, W, C, dtype, pchunk);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,
+                                     float* tanh_ws, float* weight, float* att_res, hipStream_t s) {
+  if (L > 256) return L2S_EINVAL;
+  hipLaunchKernelGGL(cap_att_fwd_kernel, dim3(1), dim3(1024), 0, s, patt, att, att_h, aw, ab, L, D, tanh_ws, weight, att_res);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_attention_bwd(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
+                                     float* dpatt, float* datt, float* datt_h, float* daw, float* dab, hipStream_t s) {
+  if (L > 256) return L2S_EINVAL;
+  hipLaunchKernelGGL(cap_att_bwd_kernel, dim3(1), dim3(1024), 0, s, datt_res, att, tanh_ws, weight, aw, L, D, dpatt, datt, datt_h, daw, dab);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save, int R, hipStream_t s) {
+  hipLaunchKernelGGL(cap_gates_fwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, sums, a2c, c_prev, c, h, save, R);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_gates_bwd(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* dsums, float* da2c,
+                                 float* dc_prev, int R, hipStream_t s) {
+  hipLaunchKernelGGL(cap_gates_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, dh, dc_in, save, c_prev, dsums, da2c, dc_prev, R);
+  return l2s_check_launch();
+}
+extern "C" int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale, float* loss_slot,
+                                  float* dlogits, float* logprobs_opt, hipStream_t s) {
+  hipLaunchKernelGGL(lsm_nll_kernel, dim3(S), dim3(1024), 0, s, logits, target, mask, S, V1, gscale, loss_slot, dlogits, logprobs_opt);
+  return l2s_check_launch();
+}

@@ -1,0 +1,178 @@
+// Detection / mask losses of the lang2seg train step with fused gradients (gfx950).
+// Reference: pyutils/mask-faster-rcnn/lib/nets/network_cycle_res5_2.py:360-413,448.
+// Small reductions: latency-bound; each kernel writes its loss into the shared float loss[8] buffer
+// and the gradient w.r.t. the head outputs in the activation dtype (consumed by the igemm dgrad/wgrad).
+#include "common.h"
+#include "../../include/lang2seg_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float smooth_l1(float d, float s2, float& grad) {
+  const float ad = fabsf(d);
+  if (ad < 1.f / s2) { grad = s2 * d; return 0.5f * s2 * d * d; }
+  grad = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  return ad - 0.5f / s2;
+}
+
+__global__ __launch_bounds__(1024) void rpn_loss_kernel(const float* heads, int ldh, const int* labels, const float* tgt, const float* inw,
+                                                       const float* outw, int H, int W, int A, float sigma, float gscale, float* loss,
+                                                       void* dheads, int ldd, int dt) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n = H * W * A;
+  float cnt = 0.f;
+  for (int i = tid; i < n; i += nt) cnt += (labels[i] != -1) ? 1.f : 0.f;
+  cnt = block_sum(cnt, red);
+  const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+  const float s2 = sigma * sigma;
+  float lce = 0.f, lbox = 0.f;
+  for (int i = tid; i < n; i += nt) {
+    // i enumerates (h, w, a); the label array is laid out (a, h, w)
+    const int a = i % A, pix = i / A, w = pix % W, h = pix / W;
+    const int l = labels[(a * H + h) * W + w];
+    const float* hr = heads + (long)pix * ldh;
+    float dbg = 0.f, dfg = 0.f;
+    if (l != -1) {
+      const float bg = hr[a], fg = hr[A + a];
+      const float m = fmaxf(bg, fg);
+      const float lse = m + logf(expf(bg - m) + expf(fg - m));
+      lce += lse - (l == 1 ? fg : bg);
+      const float pb = expf(bg - lse), pf = expf(fg - lse);
+      dbg = (pb - (l == 0 ? 1.f : 0.f)) * inv;
+      dfg = (pf - (l == 1 ? 1.f : 0.f)) * inv;
+    }
+    stx(dheads, (long)pix * ldd + a, dt, dbg * gscale);
+    stx(dheads, (long)pix * ldd + A + a, dt, dfg * gscale);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long ti = (long)i * 4 + k;
+      const float iw = inw[ti], ow = outw[ti];
+      float g;
+      const float v = smooth_l1(iw * (hr[2 * A + a * 4 + k] - tgt[ti]), s2, g);
+      lbox += ow * v;
+      stx(dheads, (long)pix * ldd + 2 * A + a * 4 + k, dt, ow * iw * g * gscale);
+    }
+  }
+  lce = block_sum(lce, red);
+  lbox = block_sum(lbox, red);
+  if (tid == 0) { loss[L2S_LOSS_RPN_CLS] = lce * inv; loss[L2S_LOSS_RPN_BOX] = lbox; }
+  // zero the padding columns of dheads so the dgrad GEMM can run over ldd columns
+  for (long e = tid; e < (long)H * W * (ldd - 6 * A); e += nt) {
+    const long pix = e / (ldd - 6 * A); const int c = 6 * A + (int)(e % (ldd - 6 * A));
+    stx(dheads, pix * ldd + c, dt, 0.f);
+  }
+}
+
+// one wave per roi
+__global__ __launch_bounds__(256) void rcnn_loss_kernel(const float* heads, int ldh, const int* labels, const float* bt, const float* bi,
+                                                       const float* bo, int R, int ncls, float gscale, float* loss, void* dheads, int ldd, int dt) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* hr = heads + (long)r * ldh;
+  const int lab = labels[r];
+  float mx = -INFINITY;
+  for (int c = lane; c < ncls; c += 64) mx = fmaxf(mx, hr[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < ncls; c += 64) se += expf(hr[c] - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  const float invR = 1.f / (float)R;
+  for (int c = lane; c < ncls; c += 64)
+    stx(dheads, (long)r * ldd + c, dt, (expf(hr[c] - lse) - (c == lab ? 1.f : 0.f)) * invR * gscale);
+  float lb = 0.f;
+  for (int c = lane; c < 4 * ncls; c += 64) {
+    const long ti = (long)r * 4 * ncls + c;
+    float g;
+    const float v = smooth_l1(bi[ti] * (hr[ncls + c] - bt[ti]), 1.f, g);
+    lb += bo[ti] * v;
+    stx(dheads, (long)r * ldd + ncls + c, dt, bo[ti] * bi[ti] * g * invR * gscale);
+  }
+  for (int c = 5 * ncls + lane; c < ldd; c += 64) stx(dheads, (long)r * ldd + c, dt, 0.f);
+  lb = wave_sum(lb);
+  if (lane == 0) {
+    atomicAdd(loss + L2S_LOSS_CLS, (lse - hr[lab]) * invR);
+    atomicAdd(loss + L2S_LOSS_BOX, lb * invR);
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_loss_kernel(const float* score, int ldsc, const int* labels, const float* mt, const int* num_fg,
+                                                       int fg_max, int ms2, float gscale, float* loss, float* dscore) {
+  __shared__ float red[4];
+  const int nfg = min(*num_fg, fg_max);
+  const float inv = nfg > 0 ? 1.f / (float)(nfg * ms2) : 0.f;
+  float l = 0.f;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < fg_max * ms2; e += gridDim.x * blockDim.x) {
+    const int s = e / ms2;
+    float d = 0.f;
+    if (s < nfg) {
+      const float x = score[(long)e * ldsc + labels[s]], t = mt[e];
+      l += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));          // BCE with logits (NET:413)
+      d = (1.f / (1.f + expf(-x)) - t) * inv * gscale;
+    }
+    dscore[e] = d;
+  }
+  l = block_sum(l, red);
+  if (threadIdx.x == 0) atomicAdd(loss + L2S_LOSS_MASK, l * inv);
+}
+
+__global__ void total_loss_kernel(float* loss, float cap_w) {
+  loss[L2S_LOSS_TOTAL] = loss[L2S_LOSS_CLS] + loss[L2S_LOSS_BOX] + loss[L2S_LOSS_RPN_CLS] + loss[L2S_LOSS_RPN_BOX] +
+                         loss[L2S_LOSS_MASK] + cap_w * loss[L2S_LOSS_CAP];
+}
+
+// block per roi: dx[p][c] = dscore[p] * W[label][c] (ReLU-masked by x); dW[label][c] += sum_p dscore[p] x[p][c]
+__global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C,
+                                                          const float* w, const void* x, const void* ref, void* dx, float* dw, float* db, int dt) {
+  const int s = blockIdx.x;
+  const int nfg = min(*num_fg, fg_max);
+  const bool valid = s < nfg;
+  const int lab = valid ? labels[s] : 0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float wv = w[(long)lab * C + c];
+    float acc = 0.f;
+    for (int p = 0; p < ms2; ++p) {
+      const long o = ((long)s * ms2 + p) * C + c;
+      const float d = valid ? dscore[s * ms2 + p] : 0.f;
+      const float xv = ldx(x, o, dt);
+      acc = fmaf(d, xv, acc);
+      float g = d * wv;
+      if (ref && !(ldx(ref, o, dt) > 0.f)) g = 0.f;
+      stx(dx, o, dt, g);
+    }
+    if (valid) atomicAdd(dw + (long)lab * C + c, acc);
+  }
+  if (valid && threadIdx.x == 0) {
+    float sb = 0.f;
+    for (int p = 0; p < ms2; ++p) sb += dscore[s * ms2 + p];
+    atomicAdd(db + lab, sb);
+  }
+}
+
+}  // namespace
+
+extern "C" int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
+                            const float* outside_w, int H, int W, int A, float sigma, float gscale, float* loss, void* dheads, int ldd,
+                            int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(1024), 0, s, heads, ldh, labels, targets, inside_w, outside_w, H, W, A, sigma, gscale, loss, dheads, ldd, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_rcnn_loss(const float* heads, int ldh, const int* labels, const float* bbox_targets, const float* inside_w,
+                             const float* outside_w, int R, int ncls, float gscale, float* loss, void* dheads, int ldd, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(rcnn_loss_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, heads, ldh, labels, bbox_targets, inside_w, outside_w, R, ncls, gscale, loss, dheads, ldd, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_mask_loss(const float* score, int ldsc, const int* labels, const float* mask_targets, const int* num_fg, int fg_max,
+                             int ms2, float gscale, float* loss, float* dscore, hipStream_t s) {
+  hipLaunchKernelGGL(mask_loss_kernel, dim3(cdiv(fg_max * ms2, 256)), dim3(256), 0, s, score, ldsc, labels, mask_targets, num_fg, fg_max, ms2, gscale, loss, dscore);
+  return l2s_check_launch();
+}
+extern "C" int l2s_total_loss(float* loss, float cap_w, hipStream_t s) {
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, loss, cap_w);
+  return l2s_check_launch();
+}
+extern "C" int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C, const float* w,
+                                const void* x, const void* relu_ref, void* dx, float* dw, float* db, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(maskpred_bwd_kernel, dim3(fg_max), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, dw, db, dtype);
+  return l2s_check_launch();
+}

@@ -1,0 +1,315 @@
+// Bandwidth-bound helpers of the lang2seg train step (gfx950): shadow-weight generation, stem conv,
+// pooling, elementwise glue and the fused SGD-momentum update.  All are HBM-bound byte movers: coalesced
+// channel-contiguous (NHWC) accesses, grid-stride loops capped at ~8 blocks/CU.
+#include "common.h"
+#include "../../include/lang2seg_hip.h"
+
+namespace {
+
+inline int grid_for(long n, int block = 256, int cap = 2048) {
+  long g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+__global__ void weight_cast_kernel(const float* __restrict__ src, const float* __restrict__ scale, void* dst,
+                                   long per_row, long total, int dt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v = src[i];
+    if (scale) v *= scale[i / per_row];
+    stx(dst, i, dt, v);
+  }
+}
+
+// src [Cout][taps][Cin] -> dst [Cin][taps(reversed)][Cout]; 32x32 LDS tile transpose per tap
+__global__ void weight_transpose_kernel(const float* __restrict__ src, const float* __restrict__ scale, void* dst,
+                                        int Cout, int taps, int Cin, int dt) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) { v = src[((long)co * taps + tap) * Cin + ci]; if (scale) v *= scale[co]; }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  const int otap = taps - 1 - tap;
+  for (int r = ty; r < 32; r += 8) {
+    int ci = ci0 + r, co = co0 + tx;
+    if (co < Cout && ci < Cin) stx(dst, ((long)ci * taps + otap) * Cout + co, dt, tile[tx][r]);
+  }
+}
+
+__global__ void colsum_kernel(const void* a, int rows, int cols, int lda, float* out, int dt) {
+  // block: 64 columns x 4 row-groups
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * 256;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + rg; r < min(rows, r0 + 256); r += 4) s += ldx(a, (long)r * lda + c, dt);
+  sh[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) atomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// stem: one thread = one output pixel x 16 output channels; weights [64][7][7][3] staged in LDS as [tap*3+c][64]
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                  const float* __restrict__ scale, const float* __restrict__ bias, void* y,
+                                                  int H, int W, int OH, int OW, int dt) {
+  __shared__ float ws[147 * 64];
+  for (int i = threadIdx.x; i < 147 * 64; i += 256) { int k = i >> 6, co = i & 63; ws[i] = w[co * 147 + k]; }
+  __syncthreads();
+  const int cg = threadIdx.x & 3;                       // 4 channel groups of 16
+  const long pix = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (pix >= (long)OH * OW) return;
+  const int oy = (int)(pix / OW), ox = (int)(pix - (long)oy * OW);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int ky = 0; ky < 7; ++ky) {
+    int iy = oy * 2 - 3 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 7; ++kx) {
+      int ix = ox * 2 - 3 + kx;
+      if (ix < 0 || ix >= W) continue;
+      const float* px = img + ((long)iy * W + ix) * 3;
+      const float* wk = ws + ((ky * 7 + kx) * 3) * 64 + cg * 16;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = px[c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(v, wk[c * 64 + i], acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int co = cg * 16 + i;
+    stx(y, pix * 64 + co, dt, fmaxf(acc[i] * scale[co] + bias[co], 0.f));
+  }
+}
+
+__global__ void maxpool_kernel(const void* x, void* y, int IH, int IW, int C, int OH, int OW, int dt) {
+  const long total = (long)OH * OW * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long p = i / C; int ox = (int)(p % OW), oy = (int)(p / OW);
+    float m = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = oy * 2 - 1 + ky; if (iy < 0 || iy >= IH) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = ox * 2 - 1 + kx; if (ix < 0 || ix >= IW) continue;
+        m = fmaxf(m, ldx(x, ((long)iy * IW + ix) * C + c, dt));
+      }
+    }
+    stx(y, i, dt, m);
+  }
+}
+
+__global__ void fill_kernel(float* p, float v, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void cast_kernel(const void* s, int sd, void* d, int dd, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) stx(d, i, dd, ldx(s, i, sd));
+}
+__global__ void add3_kernel(const void* a, const void* b, const float* c, void* d, long n, int dt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = ldx(a, i, dt);
+    if (b) v += ldx(b, i, dt);
+    if (c) v += c[i];
+    stx(d, i, dt, v);
+  }
+}
+
+__global__ void avgpool_fwd_kernel(const void* x, void* y, int hw, int C, int dt) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int p = 0; p < hw; ++p) s += ldx(x, ((long)n * hw + p) * C + c, dt);
+  // reference: .mean(3).mean(2) -> mean over W then mean over H; for hw = P*P both are sums / P / P
+  stx(y, (long)n * C + c, dt, s / (float)hw);
+}
+__global__ void avgpool_bwd_kernel(const void* dy, void* dx, const void* addend, const void* ref, int hw, int C, long total, int dt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long n = i / ((long)hw * C);
+    float v = ldx(dy, n * C + c, dt) / (float)hw;
+    if (addend) v += ldx(addend, i, dt);
+    if (ref && !(ldx(ref, i, dt) > 0.f)) v = 0.f;
+    stx(dx, i, dt, v);
+  }
+}
+
+__device__ __forceinline__ int bin_lo(int i, int n_in, int n_out) { return (i * n_in) / n_out; }
+__device__ __forceinline__ int bin_hi(int i, int n_in, int n_out) { return ((i + 1) * n_in + n_out - 1) / n_out; }
+
+__global__ void adaptive_pool_fwd_kernel(const void* x, const float* pm, void* y, int H, int W, int C, int OH, int OW, int ldy, int dt) {
+  const int bin = blockIdx.y, oy = bin / OW, ox = bin - oy * OW;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int y0 = bin_lo(oy, H, OH), y1 = bin_hi(oy, H, OH), x0 = bin_lo(ox, W, OW), x1 = bin_hi(ox, W, OW);
+  float s = 0.f;
+  for (int yy = y0; yy < y1; ++yy)
+    for (int xx = x0; xx < x1; ++xx) {
+      float v = ldx(x, ((long)yy * W + xx) * C + c, dt);
+      if (pm) v *= pm[yy * W + xx];
+      s += v;
+    }
+  stx(y, (long)bin * ldy + c, dt, s / (float)((y1 - y0) * (x1 - x0)));
+}
+
+__global__ void adaptive_pool_bwd_kernel(const void* dy, int lddy, int off_all, int off_mask, const float* pm, void* dx,
+                                         const void* ref, int H, int W, int C, int OH, int OW, int dt) {
+  const int pix = blockIdx.y, yy = pix / W, xx = pix - yy * W;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // bins whose [lo,hi) range contains the pixel
+  float g = 0.f;
+  const float m = pm ? pm[pix] : 0.f;
+  for (int oy = 0; oy < OH; ++oy) {
+    int y0 = bin_lo(oy, H, OH), y1 = bin_hi(oy, H, OH);
+    if (yy < y0 || yy >= y1) continue;
+    for (int ox = 0; ox < OW; ++ox) {
+      int x0 = bin_lo(ox, W, OW), x1 = bin_hi(ox, W, OW);
+      if (xx < x0 || xx >= x1) continue;
+      float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+      long b = (long)(oy * OW + ox) * lddy;
+      float d = ldx(dy, b + off_all + c, dt);
+      if (pm) d += m * ldx(dy, b + off_mask + c, dt);
+      g += d * inv;
+    }
+  }
+  long o = (long)pix * C + c;
+  if (ref && !(ldx(ref, o, dt) > 0.f)) g = 0.f;
+  stx(dx, o, dt, g);
+}
+
+__global__ void mask_downsample_kernel(const uint8_t* mask, float* out, int H, int W, int h, int w) {
+  // one wave per output pixel
+  const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= h * w) return;
+  const int oy = o / w, ox = o - oy * w;
+  const int y0 = bin_lo(oy, H, h), y1 = bin_hi(oy, H, h), x0 = bin_lo(ox, W, w), x1 = bin_hi(ox, W, w);
+  const int bw = x1 - x0, n = (y1 - y0) * bw;
+  float s = 0.f;
+  for (int i = lane; i < n; i += 64) { int yy = y0 + i / bw, xx = x0 + i % bw; s += (float)mask[(long)yy * W + xx]; }
+  s = wave_sum(s);
+  if (lane == 0) out[o] = (s / (float)n >= 0.5f) ? 1.f : 0.f;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void dropout_kernel(float* m, long n, float p, uint64_t seed) {
+  const float keep = 1.f - p, inv = keep > 0.f ? 1.f / keep : 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    uint32_t r = (uint32_t)(mix64(seed * 0x100000001B3ull + (uint64_t)i) >> 40);  // 24 bits
+    m[i] = ((float)r * (1.f / 16777216.f) < keep) ? inv : 0.f;
+  }
+}
+__global__ void keys_kernel(uint32_t* k, long n, uint64_t seed) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    k[i] = (uint32_t)(mix64(seed * 0x100000001B3ull + (uint64_t)i) >> 32);
+}
+
+__global__ void sgd_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ mom,
+                           const l2s_sgd_seg* __restrict__ segs, int nseg, const float* __restrict__ rowscale,
+                           float lr, float momentum, float wd, float gscale) {
+  // blockIdx.y = segment; grid-stride over the segment's elements
+  const l2s_sgd_seg sg = segs[blockIdx.y];
+  const float lwd = sg.weight_decay ? wd : 0.f;
+  const float llr = lr * sg.lr_mult;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < sg.count; i += (long)gridDim.x * blockDim.x) {
+    const long o = sg.offset + i;
+    float g = grad[o] * gscale;
+    if (sg.rowscale_off >= 0) g *= rowscale[sg.rowscale_off + i / sg.row_len];
+    const float w = param[o];
+    g += lwd * w;
+    const float m = momentum * mom[o] + g;
+    mom[o] = m;
+    param[o] = w - llr * m;
+  }
+}
+
+}  // namespace
+
+extern "C" int l2s_version(void) { return 100; }
+
+extern "C" int l2s_weight_cast(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s) {
+  long per_row = (long)taps * Cin, total = per_row * Cout;
+  hipLaunchKernelGGL(weight_cast_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, scale, dst, per_row, total, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s) {
+  dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), taps);
+  hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, s, src, scale, dst, Cout, taps, Cin, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s) {
+  dim3 grid(cdiv(cols, 64), cdiv(rows, 256));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, a, rows, cols, lda, out, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_stem_conv(const float* img, const float* w, const float* scale, const float* bias, void* y, int H, int W,
+                             int OH, int OW, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(stem_kernel, dim3(cdiv((long)OH * OW, 64)), dim3(256), 0, s, img, w, scale, bias, y, H, W, OH, OW, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_maxpool3x3s2(const void* x, void* y, int IH, int IW, int C, int OH, int OW, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((long)OH * OW * C)), dim3(256), 0, s, x, y, IH, IW, C, OH, OW, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_fill_f32(float* p, float v, long n, hipStream_t s) {
+  if (n <= 0) return L2S_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, v, n);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cast(const void* src, int sd, void* dst, int dd, long n, hipStream_t s) {
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, sd, dst, dd, n);
+  return l2s_check_launch();
+}
+extern "C" int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(add3_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, dst, n, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_avgpool_fwd(const void* x, void* y, int n_img, int hw, int C, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv(C, 256), n_img), dim3(256), 0, s, x, y, hw, C, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_avgpool_bwd(const void* dy, void* dx, const void* addend, const void* ref, int n_img, int hw, int C, int dtype, hipStream_t s) {
+  long total = (long)n_img * hw * C;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, dx, addend, ref, hw, C, total, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_adaptive_pool_fwd(const void* x, const float* pm, void* y, int H, int W, int C, int OH, int OW, int ldy, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(adaptive_pool_fwd_kernel, dim3(cdiv(C, 256), OH * OW), dim3(256), 0, s, x, pm, y, H, W, C, OH, OW, ldy, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_adaptive_pool_bwd(const void* dy, int lddy, int off_all, int off_mask, const float* pm, void* dx, const void* ref,
+                                     int H, int W, int C, int OH, int OW, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3(cdiv(C, 256), H * W), dim3(256), 0, s, dy, lddy, off_all, off_mask, pm, dx, ref, H, W, C, OH, OW, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_mask_downsample(const uint8_t* mask, float* out, int H, int W, int h, int w, hipStream_t s) {
+  hipLaunchKernelGGL(mask_downsample_kernel, dim3(cdiv(h * w, 4)), dim3(256), 0, s, mask, out, H, W, h, w);
+  return l2s_check_launch();
+}
+extern "C" int l2s_dropout_mask(float* mask, long n, float p, uint64_t seed, hipStream_t s) {
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, mask, n, p, seed);
+  return l2s_check_launch();
+}
+extern "C" int l2s_random_keys(uint32_t* keys, long n, uint64_t seed, hipStream_t s) {
+  hipLaunchKernelGGL(keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, keys, n, seed);
+  return l2s_check_launch();
+}
+extern "C" int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+                                float lr, float momentum, float wd, float grad_scale, hipStream_t s) {
+  if (nseg <= 0) return L2S_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(64, nseg), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale);
+  return l2s_check_launch();
+}

@@ -1,0 +1,535 @@
+// RoI path of the lang2seg train step on gfx950, fully on device (no host round trips):
+// RPN softmax + box decode, stable top-k sort, greedy NMS (bitmask + single-workgroup scan), anchor / proposal
+// target assignment with key-based sampling, mask targets and crop-and-resize RoIAlign.
+// Reference: pyutils/mask-faster-rcnn/lib/{layer_utils/proposal_layer.py, anchor_target_layer.py,
+// proposal_target_layer.py, model/bbox_transform.py, utils/bbox.py, nms/src/nms.c, nms/src/cuda/nms_kernel.cu,
+// nms/src/nms_cuda.c} and nets/network_cycle_res5_2.py:107-149.  Integer / byte / compare work: HBM- and
+// latency-bound, wave64-native (one u64 NMS mask word per lane).
+#include "common.h"
+#include "../../include/lang2seg_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ RPN decode
+__global__ void rpn_decode_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ base, int H, int W, int A,
+                                  int fs, float im_h, float im_w, float* prob, float* boxes, float* scores) {
+  const int n = H * W * A;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int a = i % A, pix = i / A, w = pix % W, h = pix / W;
+    const float* hr = heads + (long)pix * ldh;
+    const float bg = hr[a], fg = hr[A + a];
+    const float m = fmaxf(bg, fg);
+    const float e0 = expf(bg - m), e1 = expf(fg - m);
+    const float s = e0 + e1;
+    prob[(long)pix * 2 * A + a] = e0 / s;
+    prob[(long)pix * 2 * A + A + a] = e1 / s;
+    scores[i] = e1 / s;
+    // anchors (snippets.py:13-29) and bbox_transform_inv (bbox_transform.py:36-62), fp32
+    const float ax1 = base[a * 4 + 0] + (float)(w * fs), ay1 = base[a * 4 + 1] + (float)(h * fs);
+    const float ax2 = base[a * 4 + 2] + (float)(w * fs), ay2 = base[a * 4 + 3] + (float)(h * fs);
+    const float aw = ax2 - ax1 + 1.0f, ah = ay2 - ay1 + 1.0f;
+    const float cx = ax1 + 0.5f * aw, cy = ay1 + 0.5f * ah;
+    const float* d = hr + 2 * A + a * 4;
+    const float pcx = d[0] * aw + cx, pcy = d[1] * ah + cy;
+    const float pw = expf(d[2]) * aw, ph = expf(d[3]) * ah;
+    float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    x1 = fminf(fmaxf(x1, 0.f), im_w - 1.f); y1 = fminf(fmaxf(y1, 0.f), im_h - 1.f);
+    x2 = fminf(fmaxf(x2, 0.f), im_w - 1.f); y2 = fminf(fmaxf(y2, 0.f), im_h - 1.f);
+    *(float4*)(boxes + (long)i * 4) = make_float4(x1, y1, x2, y2);
+  }
+}
+
+// ------------------------------------------------------------------ stable descending rank sort
+__device__ __forceinline__ uint64_t sort_key(float s, int idx) {
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // order-preserving
+  return ((uint64_t)u << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)idx);  // ties: lower index ranks higher
+}
+__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int n, int k,
+                                                   float* sboxes, float* sscores, int* sidx) {
+  __shared__ uint64_t tile[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const uint64_t mine = i < n ? sort_key(scores[i], i) : 0;
+  int rank = 0;
+  for (int t0 = 0; t0 < n; t0 += 1024) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = (t0 + j < n) ? sort_key(scores[t0 + j], t0 + j) : 0;
+    __syncthreads();
+    const int lim = min(1024, n - t0);
+    int j = 0;
+    for (; j + 4 <= lim; j += 4) {
+      rank += (tile[j] > mine) + (tile[j + 1] > mine) + (tile[j + 2] > mine) + (tile[j + 3] > mine);
+    }
+    for (; j < lim; ++j) rank += (tile[j] > mine);
+  }
+  if (i < n && rank < k) {
+    sidx[rank] = i;
+    sscores[rank] = scores[i];
+    *(float4*)(sboxes + (long)rank * 4) = *(const float4*)(boxes + (long)i * 4);
+  }
+}
+
+// ------------------------------------------------------------------ NMS
+__device__ __forceinline__ bool nms_hit(const float4& a, float aarea, const float4& b, float thr, int cmp) {
+  const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+  const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
+  const float inter = w * h;
+  const float barea = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  const float ovr = inter / (aarea + barea - inter);     // nms.c:55-58
+  return cmp ? (ovr > thr) : (ovr >= thr);
+}
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int cb, uint64_t* mask) {
+  const int rb = blockIdx.y, cbk = blockIdx.x;
+  if (cbk < rb) return;
+  __shared__ float4 cbox[64];
+  const int lane = threadIdx.x;
+  const int cj = cbk * 64 + lane;
+  cbox[lane] = cj < n ? *(const float4*)(boxes + (long)cj * 4) : make_float4(0, 0, -1, -1);
+  __syncthreads();
+  const int ri = rb * 64 + lane;
+  if (ri >= n) return;
+  const float4 a = *(const float4*)(boxes + (long)ri * 4);
+  const float aarea = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+  const int csize = min(64, n - cbk * 64);
+  uint64_t t = 0;
+  const int start = (rb == cbk) ? lane + 1 : 0;
+  for (int j = start; j < csize; ++j)
+    if (nms_hit(a, aarea, cbox[j], thr, cmp)) t |= 1ull << j;
+  mask[(long)ri * cb + cbk] = t;
+}
+__global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out) {
+  extern __shared__ unsigned long long remv[];   // cb words + 2
+  __shared__ unsigned long long kept_sh;
+  __shared__ int nk_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < cb; c += 1024) remv[c] = 0ull;
+  if (tid == 0) nk_sh = 0;
+  __syncthreads();
+  for (int b = 0; b < cb; ++b) {
+    if (wave == 0) {
+      const int row = b * 64 + lane;
+      const unsigned long long d = row < n ? mask[(long)row * cb + b] : 0ull;
+      unsigned long long rb = remv[b];
+      unsigned long long K = 0ull;
+      const int lim = min(64, n - b * 64);
+      const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
+      for (int i = 0; i < lim; ++i) {
+        if (!((rb >> i) & 1ull)) {
+          K |= 1ull << i;
+          unsigned int lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
+          rb |= ((unsigned long long)hi << 32) | lo;
+        }
+      }
+      const int nk = nk_sh;
+      if ((K >> lane) & 1ull) {
+        int pos = nk + __popcll(K & ((1ull << lane) - 1ull));
+        if (pos < max_keep) keep[pos] = row;
+      }
+      if (lane == 0) { kept_sh = K; nk_sh = nk + __popcll(K); }
+    }
+    __syncthreads();
+    const unsigned long long K = kept_sh;
+    if (nk_sh >= max_keep) break;
+    // OR the kept rows of this block into the columns to the right: thread = (column, 16-row group)
+    const int g = tid >> 8;
+    for (int c = b + 1 + (tid & 255); c < cb; c += 256) {
+      unsigned long long Kg = (K >> (16 * g)) & 0xFFFFull, acc = 0ull;
+      while (Kg) {
+        int i = __ffsll((long long)Kg) - 1; Kg &= Kg - 1;
+        acc |= mask[(long)(b * 64 + 16 * g + i) * cb + c];
+      }
+      if (acc) atomicOr(&remv[c], acc);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *num_out = min(nk_sh, max_keep);
+}
+__global__ void gather_rois_kernel(const float* sboxes, const float* sscores, const int* keep, const int* num, int max_keep, float* rois, float* rs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_keep) return;
+  float4 b = make_float4(0, 0, 0, 0); float sc = 0.f;
+  if (i < *num) { int k = keep[i]; b = *(const float4*)(sboxes + (long)k * 4); sc = sscores[k]; }
+  rois[i * 5 + 0] = 0.f; rois[i * 5 + 1] = b.x; rois[i * 5 + 2] = b.y; rois[i * 5 + 3] = b.z; rois[i * 5 + 4] = b.w;
+  rs[i] = sc;
+}
+
+// ------------------------------------------------------------------ anchor targets
+struct AtlWs { int* cnt; unsigned long long* gtmax; double* maxov; int* argmax; int* lab; };
+__device__ __forceinline__ AtlWs atl_ws(int* ws, int n) {
+  AtlWs w;
+  w.cnt = ws; w.gtmax = (unsigned long long*)(ws + 16); w.maxov = (double*)(ws + 16 + 64);
+  w.argmax = ws + 16 + 64 + 2 * n; w.lab = w.argmax + n;
+  return w;
+}
+__device__ __forceinline__ void anchor_at(const float* base, int i, int A, int W, int fs, float& x1, float& y1, float& x2, float& y2) {
+  const int a = i % A, pix = i / A, w = pix % W, h = pix / W;
+  x1 = base[a * 4 + 0] + (float)(w * fs); y1 = base[a * 4 + 1] + (float)(h * fs);
+  x2 = base[a * 4 + 2] + (float)(w * fs); y2 = base[a * 4 + 3] + (float)(h * fs);
+}
+__device__ __forceinline__ double iou64(float ax1, float ay1, float ax2, float ay2, const float* g) {
+  // utils/bbox.py:21-29 evaluated in float64 (anchor_target_layer.py:62-64)
+  const double bx1 = ax1, by1 = ay1, bx2 = ax2, by2 = ay2, qx1 = g[0], qy1 = g[1], qx2 = g[2], qy2 = g[3];
+  const double ba = (bx2 - bx1 + 1) * (by2 - by1 + 1), qa = (qx2 - qx1 + 1) * (qy2 - qy1 + 1);
+  double iw = fmin(bx2, qx2) - fmax(bx1, qx1) + 1; if (iw < 0) iw = 0;
+  double ih = fmin(by2, qy2) - fmax(by1, qy1) + 1; if (ih < 0) ih = 0;
+  return iw * ih / (ba + qa - iw * ih);
+}
+__global__ void atl_init_kernel(int* ws) { if (threadIdx.x < 16 + 64) ws[threadIdx.x] = 0; }
+__global__ void atl_iou_kernel(const float* gt, int n_gt, const float* base, int n, int W, int A, int fs, float im_h, float im_w, int* ws) {
+  AtlWs w = atl_ws(ws, n);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x1, y1, x2, y2; anchor_at(base, i, A, W, fs, x1, y1, x2, y2);
+  const bool inside = x1 >= 0.f && y1 >= 0.f && x2 < im_w && y2 < im_h;
+  double best = -1.0; int arg = 0;
+  if (inside) {
+    for (int g = 0; g < n_gt; ++g) {
+      double o = iou64(x1, y1, x2, y2, gt + g * 5);
+      if (o > best) { best = o; arg = g; }
+      atomicMax(&w.gtmax[g], (unsigned long long)__double_as_longlong(o));
+    }
+  }
+  w.maxov[i] = best; w.argmax[i] = arg;
+  w.lab[i] = inside ? -1 : -2;    // -2: outside the image, never a candidate
+}
+__global__ void atl_label_kernel(const float* gt, int n_gt, const float* base, int n, int W, int A, int fs, float neg_ov, float pos_ov, int* ws) {
+  AtlWs w = atl_ws(ws, n);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || w.lab[i] == -2) return;
+  float x1, y1, x2, y2; anchor_at(base, i, A, W, fs, x1, y1, x2, y2);
+  const double mo = w.maxov[i];
+  int l = -1;
+  if (mo < (double)neg_ov) l = 0;                               // ATL:75
+  for (int g = 0; g < n_gt; ++g)
+    if (iou64(x1, y1, x2, y2, gt + g * 5) == __longlong_as_double((long long)w.gtmax[g])) l = 1;   // ATL:70,78 (all ties)
+  if (mo >= (double)pos_ov) l = 1;                              // ATL:81
+  w.lab[i] = l;
+  if (l == 1) atomicAdd(&w.cnt[0], 1);
+  if (l == 0) atomicAdd(&w.cnt[1], 1);
+}
+// disable the D smallest-key candidates with label == which (single workgroup, radix select on 32-bit keys)
+__device__ void select_disable(int* lab, const uint32_t* keys, int n, int which, int D, int* hist /*256*/, int* sh /*4*/) {
+  const int tid = threadIdx.x;
+  if (D <= 0) return;
+  uint32_t prefix = 0, pmask = 0; int need = D;   // find key value t: #(key < t) < D <= #(key <= t)
+  for (int pass = 3; pass >= 0; --pass) {
+    for (int b = tid; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x)
+      if (lab[i] == which && (keys[i] & pmask) == prefix) atomicAdd(&hist[(keys[i] >> (8 * pass)) & 255], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0, b = 0;
+      for (; b < 256; ++b) { if (acc + hist[b] >= need) break; acc += hist[b]; }
+      sh[0] = b; sh[1] = need - acc;
+    }
+    __syncthreads();
+    prefix |= ((uint32_t)sh[0]) << (8 * pass); pmask |= 255u << (8 * pass); need = sh[1];
+    __syncthreads();
+  }
+  // disable key < prefix, and the first `need` (by index) of key == prefix
+  if (tid == 0) sh[2] = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+    const int i = i0 + tid;
+    bool cand = i < n && lab[i] == which;
+    if (cand && keys[i] < prefix) { lab[i] = -1; cand = false; }
+    const bool tie = cand && keys[i] == prefix;
+    // ties are rare: serialise through an atomic ticket in index order per chunk
+    if (tie) { int tk = atomicAdd(&sh[2], 1); if (tk < need) lab[i] = -1; }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(1024) void atl_sample_kernel(const uint32_t* fg_keys, const uint32_t* bg_keys, int n, int batch, float fg_frac, int* ws) {
+  __shared__ int hist[256];
+  __shared__ int sh[4];
+  AtlWs w = atl_ws(ws, n);
+  const int num_fg = (int)(fg_frac * (float)batch);
+  const int nfg = w.cnt[0], nbg = w.cnt[1];
+  __syncthreads();
+  select_disable(w.lab, fg_keys, n, 1, nfg - num_fg, hist, sh);      // ATL:88-93
+  __syncthreads();
+  const int fg_after = min(nfg, num_fg);
+  const int num_bg = batch - fg_after;                                // ATL:96
+  select_disable(w.lab, bg_keys, n, 0, nbg - num_bg, hist, sh);       // ATL:97-101
+  __syncthreads();
+  if (threadIdx.x == 0) w.cnt[2] = fg_after + min(nbg, num_bg);       // num_examples = sum(labels >= 0)
+}
+__global__ void atl_out_kernel(const float* gt, const float* base, int n, int H, int W, int A, int fs, const int* ws_c,
+                               int* labels, float* targets, float* inw, float* outw) {
+  AtlWs w = atl_ws((int*)ws_c, n);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = i % A, pix = i / A, ww = pix % W, h = pix / W;
+  int l = w.lab[i];
+  const bool inside = l != -2;
+  if (!inside) l = -1;
+  labels[(a * H + h) * W + ww] = l;                                    // ATL:133-134 layout (1,1,A*H,W)
+  float t[4] = {0, 0, 0, 0};
+  if (inside) {
+    float x1, y1, x2, y2; anchor_at(base, i, A, W, fs, x1, y1, x2, y2);
+    const float* g = gt + w.argmax[i] * 5;
+    const float ew = x2 - x1 + 1.0f, eh = y2 - y1 + 1.0f, ecx = x1 + 0.5f * ew, ecy = y1 + 0.5f * eh;
+    const float gw = g[2] - g[0] + 1.0f, gh = g[3] - g[1] + 1.0f, gcx = g[0] + 0.5f * gw, gcy = g[1] + 0.5f * gh;
+    t[0] = (gcx - ecx) / ew; t[1] = (gcy - ecy) / eh; t[2] = logf(gw / ew); t[3] = logf(gh / eh);
+  }
+  const float iw = (l == 1) ? 1.f : 0.f;
+  const float ow = (l >= 0) ? (float)(1.0 / (double)w.cnt[2]) : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { targets[(long)i * 4 + k] = t[k]; inw[(long)i * 4 + k] = iw; outw[(long)i * 4 + k] = ow; }
+}
+
+// ------------------------------------------------------------------ proposal targets (single workgroup)
+__device__ __forceinline__ float iou32(const float* b, const float* q) {   // utils/bbox.py:21-29 in fp32
+  const float ba = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f), qa = (q[2] - q[0] + 1.f) * (q[3] - q[1] + 1.f);
+  const float iw = fmaxf(fminf(b[2], q[2]) - fmaxf(b[0], q[0]) + 1.f, 0.f);
+  const float ih = fmaxf(fminf(b[3], q[3]) - fmaxf(b[1], q[1]) + 1.f, 0.f);
+  const float ua = ba + qa - iw * ih;
+  return iw * ih / ua;
+}
+__global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const float* scores_in, const int* n_rois, int n_max,
+                                                   const float* gt, int n_gt, const uint8_t* gt_masks, int im_h, int im_w,
+                                                   const uint32_t* fg_keys, const uint32_t* bg_keys, const uint32_t* bg_rand,
+                                                   int R, int fg_max, float fg_thresh, float bg_hi, float bg_lo,
+                                                   const float* means4, const float* stds4, const float* inw4, int ncls, int ms,
+                                                   float* out_rois, int* labels, float* bt, float* bi, float* bo, float* mt,
+                                                   int* counts, int* ws) {
+  __shared__ int sh_cnt[4];
+  __shared__ float red[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int cap = n_max + n_gt;
+  int* fg_list = ws; int* bg_list = ws + cap; int* argm = ws + 2 * cap; int* cls = ws + 3 * cap; int* slot = ws + 4 * cap;  // slot[R]
+  int n = min(*n_rois, n_max);
+  int appended = 0;
+  auto roi_ptr = [&](int i, float* b) {
+    if (i < n - appended * n_gt) { for (int k = 0; k < 4; ++k) b[k] = rois_in[(long)i * 5 + 1 + k]; }
+    else { const float* g = gt + (i - (n - appended * n_gt)) * 5; for (int k = 0; k < 4; ++k) b[k] = g[k]; }
+  };
+  auto fkey = [&](int i) -> uint32_t { return (i < n - appended * n_gt) ? fg_keys[i] : 0u; };
+  auto bkey = [&](int i) -> uint32_t { return (i < n - appended * n_gt) ? bg_keys[i] : 0xFFFFFFFFu; };
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid < 4) sh_cnt[tid] = 0;
+    __syncthreads();
+    // classify candidates; lists are built in index order by a chunked ballot scan
+    for (int i0 = 0; i0 < n; i0 += nt) {
+      const int i = i0 + tid;
+      int kind = 0;  // 1 fg, 2 bg
+      if (i < n) {
+        float b[4]; roi_ptr(i, b);
+        float best = -1.f; int arg = 0;
+        for (int g = 0; g < n_gt; ++g) { float o = iou32(b, gt + g * 5); if (o > best) { best = o; arg = g; } }
+        argm[i] = arg;
+        if (best >= fg_thresh) kind = 1;                                  // PTL:143
+        else if (best < bg_hi && best >= bg_lo) kind = 2;                 // PTL:146 (byte add == 2)
+        cls[i] = kind;
+      }
+      // ordered compaction: per-wave ballots + serial wave order via shared counters
+      for (int wv = 0; wv < (nt >> 6); ++wv) {
+        if ((tid >> 6) == wv) {
+          unsigned long long mf = __ballot(kind == 1), mb = __ballot(kind == 2);
+          const int lane = tid & 63;
+          const int bf = sh_cnt[0], bb = sh_cnt[1];
+          if (kind == 1) fg_list[bf + __popcll(mf & ((1ull << lane) - 1ull))] = i;
+          if (kind == 2) bg_list[bb + __popcll(mb & ((1ull << lane) - 1ull))] = i;
+          if (lane == 0) { sh_cnt[0] = bf + __popcll(mf); sh_cnt[1] = bb + __popcll(mb); }
+        }
+        __syncthreads();
+      }
+    }
+    if (sh_cnt[0] > 0 || attempt == 1) break;
+    // PTL:159-167: no foreground -> append the gt boxes as candidates and retry
+    appended = 1; n += n_gt;
+    __syncthreads();
+  }
+  const int n_fg = sh_cnt[0], n_bg = sh_cnt[1];
+  int nfg_sel, nbg_sel; bool fg_repl = false, bg_repl = false;
+  if (n_bg > 0) { nfg_sel = min(fg_max, n_fg); nbg_sel = R - nfg_sel; bg_repl = n_bg < nbg_sel; }
+  else { nfg_sel = R; nbg_sel = 0; fg_repl = n_fg < R; }
+  for (int s = tid; s < R; s += nt) slot[s] = -1;
+  __syncthreads();
+  // rank by key inside each list; the k smallest keys are emitted in key order (= fg_inds[npr.choice(n,k,False)])
+  if (!fg_repl) {
+    for (int a = tid; a < n_fg; a += nt) {
+      const int i = fg_list[a]; const uint32_t ki = fkey(i); int rank = 0;
+      for (int b = 0; b < n_fg; ++b) { const int j = fg_list[b]; const uint32_t kj = fkey(j); rank += (kj < ki) || (kj == ki && j < i); }
+      if (rank < nfg_sel) slot[rank] = i;
+    }
+  } else {
+    for (int s = tid; s < nfg_sel; s += nt) slot[s] = fg_list[bg_rand[s] % (uint32_t)n_fg];
+  }
+  if (nbg_sel > 0) {
+    if (!bg_repl) {
+      for (int a = tid; a < n_bg; a += nt) {
+        const int i = bg_list[a]; const uint32_t ki = bkey(i); int rank = 0;
+        for (int b = 0; b < n_bg; ++b) { const int j = bg_list[b]; const uint32_t kj = bkey(j); rank += (kj < ki) || (kj == ki && j < i); }
+        if (rank < nbg_sel) slot[nfg_sel + rank] = i;
+      }
+    } else {
+      for (int s = tid; s < nbg_sel; s += nt) slot[nfg_sel + s] = bg_list[bg_rand[s] % (uint32_t)n_bg];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { counts[0] = min(nfg_sel, fg_max); counts[1] = n_fg; counts[2] = n_bg; counts[3] = appended; }
+  // outputs
+  const int W4 = 4 * ncls;
+  for (long e = tid; e < (long)R * W4; e += nt) { bt[e] = 0.f; bi[e] = 0.f; bo[e] = 0.f; }
+  __syncthreads();
+  for (int s = tid; s < R; s += nt) {
+    const int i = slot[s];
+    float b[4] = {0, 0, 0, 0}; int lab = 0;
+    if (i >= 0) {
+      roi_ptr(i, b);
+      const float* g = gt + argm[i] * 5;
+      lab = (s < nfg_sel) ? (int)g[4] : 0;                               // PTL:174
+      if (lab > 0) {
+        const float ew = b[2] - b[0] + 1.0f, eh = b[3] - b[1] + 1.0f, ecx = b[0] + 0.5f * ew, ecy = b[1] + 0.5f * eh;
+        const float gw = g[2] - g[0] + 1.0f, gh = g[3] - g[1] + 1.0f, gcx = g[0] + 0.5f * gw, gcy = g[1] + 0.5f * gh;
+        float t[4] = {(gcx - ecx) / ew, (gcy - ecy) / eh, logf(gw / ew), logf(gh / eh)};
+        for (int k = 0; k < 4; ++k) {
+          bt[(long)s * W4 + 4 * lab + k] = (t[k] - means4[k]) / stds4[k];
+          bi[(long)s * W4 + 4 * lab + k] = inw4[k];
+          bo[(long)s * W4 + 4 * lab + k] = inw4[k] > 0.f ? 1.f : 0.f;
+        }
+      }
+    }
+    out_rois[s * 5 + 0] = 0.f;
+    for (int k = 0; k < 4; ++k) out_rois[s * 5 + 1 + k] = b[k];
+    labels[s] = lab;
+  }
+  // mask targets (PTL:193-201): crop gt mask to the roi, PIL-NEAREST resize to ms x ms
+  const int nm = min(nfg_sel, fg_max);
+  for (int e = tid; e < fg_max * ms * ms; e += nt) {
+    const int s = e / (ms * ms), r = e - s * ms * ms, py = r / ms, px = r - py * ms;
+    float v = 0.f;
+    if (s < nm && slot[s] >= 0) {
+      const int i = slot[s];
+      float b[4]; roi_ptr(i, b);
+      const int x1 = (int)b[0], y1 = (int)b[1];
+      int x2 = (int)b[2] + 1, y2 = (int)b[3] + 1;                       // python slice end, clipped by numpy
+      x2 = min(x2, im_w); y2 = min(y2, im_h);
+      const int cw = x2 - x1, ch = y2 - y1;
+      if (cw > 0 && ch > 0) {
+        // PIL nearest: xo = 0.5*s; idx_k = (int)xo; xo += s  (float64, sequential adds)
+        const double sx = (double)cw / (double)ms, sy = (double)ch / (double)ms;
+        double xo = 0.5 * sx, yo = 0.5 * sy;
+        for (int k = 0; k < px; ++k) xo += sx;
+        for (int k = 0; k < py; ++k) yo += sy;
+        const int ix = min((int)xo, cw - 1), iy = min((int)yo, ch - 1);
+        v = (float)gt_masks[((long)argm[i] * im_h + (y1 + iy)) * im_w + (x1 + ix)];
+      }
+    }
+    mt[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------ RoIAlign (crop-and-resize)
+struct Samp { int x0, y0; float wx1, wy1; };
+__device__ __forceinline__ Samp roi_sample(const float* roi, int H, int W, int P, int py, int px, float sscale) {
+  // NET:122-147: theta from roi/16, affine_grid + grid_sample, align_corners = True
+  const float x1 = roi[1] * sscale, y1 = roi[2] * sscale, x2 = roi[3] * sscale, y2 = roi[4] * sscale;
+  const float t00 = (x2 - x1) / (float)(W - 1), t02 = (x1 + x2 - (float)W + 1.f) / (float)(W - 1);
+  const float t11 = (y2 - y1) / (float)(H - 1), t12 = (y1 + y2 - (float)H + 1.f) / (float)(H - 1);
+  const float step = 2.f / (float)(P - 1);
+  // torch.linspace(-1, 1, P): start-based for i < P/2, end-based otherwise
+  const float bx = (px < P / 2) ? (-1.f + step * (float)px) : (1.f - step * (float)(P - 1 - px));
+  const float by = (py < P / 2) ? (-1.f + step * (float)py) : (1.f - step * (float)(P - 1 - py));
+  const float gx = t00 * bx + t02, gy = t11 * by + t12;
+  const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1), iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+  Samp s;
+  const float fx = floorf(ix), fy = floorf(iy);
+  s.x0 = (int)fx; s.y0 = (int)fy; s.wx1 = ix - fx; s.wy1 = iy - fy;
+  return s;
+}
+__global__ void roialign_fwd_kernel(const void* feat, int H, int W, int C, const float* rois, int P, float sscale, void* out, int dt) {
+  const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
+  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale);
+  const float w00 = (1.f - s.wx1) * (1.f - s.wy1), w01 = s.wx1 * (1.f - s.wy1), w10 = (1.f - s.wx1) * s.wy1, w11 = s.wx1 * s.wy1;
+  const bool vx0 = s.x0 >= 0 && s.x0 < W, vx1 = s.x0 + 1 >= 0 && s.x0 + 1 < W, vy0 = s.y0 >= 0 && s.y0 < H, vy1 = s.y0 + 1 >= 0 && s.y0 + 1 < H;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float v = 0.f;
+    if (vy0 && vx0) v += w00 * ldx(feat, ((long)s.y0 * W + s.x0) * C + c, dt);
+    if (vy0 && vx1) v += w01 * ldx(feat, ((long)s.y0 * W + s.x0 + 1) * C + c, dt);
+    if (vy1 && vx0) v += w10 * ldx(feat, ((long)(s.y0 + 1) * W + s.x0) * C + c, dt);
+    if (vy1 && vx1) v += w11 * ldx(feat, ((long)(s.y0 + 1) * W + s.x0 + 1) * C + c, dt);
+    stx(out, (long)cell * C + c, dt, v);
+  }
+}
+__global__ void roialign_bwd_kernel(const void* dout, int H, int W, int C, const float* rois, int P, float sscale, float* dfeat, int dt) {
+  const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
+  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale);
+  const float w00 = (1.f - s.wx1) * (1.f - s.wy1), w01 = s.wx1 * (1.f - s.wy1), w10 = (1.f - s.wx1) * s.wy1, w11 = s.wx1 * s.wy1;
+  const bool vx0 = s.x0 >= 0 && s.x0 < W, vx1 = s.x0 + 1 >= 0 && s.x0 + 1 < W, vy0 = s.y0 >= 0 && s.y0 < H, vy1 = s.y0 + 1 >= 0 && s.y0 + 1 < H;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float g = ldx(dout, (long)cell * C + c, dt);
+    if (vy0 && vx0) atomicAdd(dfeat + ((long)s.y0 * W + s.x0) * C + c, w00 * g);
+    if (vy0 && vx1) atomicAdd(dfeat + ((long)s.y0 * W + s.x0 + 1) * C + c, w01 * g);
+    if (vy1 && vx0) atomicAdd(dfeat + ((long)(s.y0 + 1) * W + s.x0) * C + c, w10 * g);
+    if (vy1 && vx1) atomicAdd(dfeat + ((long)(s.y0 + 1) * W + s.x0 + 1) * C + c, w11 * g);
+  }
+}
+
+}  // namespace
+
+extern "C" int l2s_rpn_decode(const float* heads, int ldh, const float* base_anchors, int H, int W, int A, int feat_stride,
+                              float im_h, float im_w, float* prob, float* boxes, float* scores, hipStream_t s) {
+  const int n = H * W * A;
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, heads, ldh, base_anchors, H, W, A, feat_stride, im_h, im_w, prob, boxes, scores);
+  return l2s_check_launch();
+}
+extern "C" int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* rank_ws, float* sorted_boxes,
+                             float* sorted_scores, int* sorted_idx, hipStream_t s) {
+  (void)rank_ws;
+  hipLaunchKernelGGL(rank_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, scores, boxes, n, k, sorted_boxes, sorted_scores, sorted_idx);
+  return l2s_check_launch();
+}
+extern "C" size_t l2s_nms_workspace_bytes(int n) { return (size_t)n * (size_t)cdiv(n, 64) * 8; }
+extern "C" int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_mode, int max_keep, uint64_t* mask_ws,
+                       int* keep_out, int* num_out, hipStream_t s) {
+  if (n <= 0) return L2S_EINVAL;
+  const int cb = cdiv(n, 64);
+  if ((size_t)(cb + 2) * 8 > 60000) return L2S_EINVAL;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, cb, mask_ws);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(1024), (size_t)(cb + 2) * 8, s, (const uint64_t*)mask_ws, n, cb, max_keep, keep_out, num_out);
+  return l2s_check_launch();
+}
+extern "C" int l2s_gather_rois(const float* sorted_boxes, const float* sorted_scores, const int* keep, const int* num, int max_keep,
+                               float* rois, float* roi_scores, hipStream_t s) {
+  hipLaunchKernelGGL(gather_rois_kernel, dim3(cdiv(max_keep, 256)), dim3(256), 0, s, sorted_boxes, sorted_scores, keep, num, max_keep, rois, roi_scores);
+  return l2s_check_launch();
+}
+extern "C" long l2s_anchor_target_ws_ints(int hwa) { return 16 + 64 + 4L * hwa + 16; }
+extern "C" int l2s_anchor_target(const float* gt, int n_gt, const float* base_anchors, int H, int W, int A, int feat_stride,
+                                 float im_h, float im_w, const uint32_t* fg_keys, const uint32_t* bg_keys,
+                                 float neg_ov, float pos_ov, int batch, float fg_frac,
+                                 int* labels, float* targets, float* inside_w, float* outside_w, int* ws, hipStream_t s) {
+  if (n_gt < 1 || n_gt > 32) return L2S_EINVAL;
+  const int n = H * W * A;
+  hipLaunchKernelGGL(atl_init_kernel, dim3(1), dim3(128), 0, s, ws);
+  hipLaunchKernelGGL(atl_iou_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, im_h, im_w, ws);
+  hipLaunchKernelGGL(atl_label_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, neg_ov, pos_ov, ws);
+  hipLaunchKernelGGL(atl_sample_kernel, dim3(1), dim3(1024), 0, s, fg_keys, bg_keys, n, batch, fg_frac, ws);
+  hipLaunchKernelGGL(atl_out_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, base_anchors, n, H, W, A, feat_stride, (const int*)ws, labels, targets, inside_w, outside_w);
+  return l2s_check_launch();
+}
+extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, const int* n_rois, int n_max, const float* gt, int n_gt,
+                                   const uint8_t* gt_masks, int im_h, int im_w, const uint32_t* fg_keys, const uint32_t* bg_keys,
+                                   const uint32_t* bg_rand, int R, int fg_max, float fg_thresh, float bg_hi, float bg_lo,
+                                   const float* means4, const float* stds4, const float* inw4, int ncls, int ms,
+                                   float* out_rois, int* labels, float* bbox_targets, float* bbox_inside, float* bbox_outside,
+                                   float* mask_targets, int* counts, int* ws, hipStream_t s) {
+  if (n_gt < 1 || R < 1) return L2S_EINVAL;
+  hipLaunchKernelGGL(ptl_kernel, dim3(1), dim3(1024), 0, s, rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w,
+                     fg_keys, bg_keys, bg_rand, R, fg_max, fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms,
+                     out_rois, labels, bbox_targets, bbox_inside, bbox_outside, mask_targets, counts, ws);
+  return l2s_check_launch();
+}
+extern "C" int l2s_roialign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
+                                void* out, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(roialign_fwd_kernel, dim3(R * P * P), dim3(256), 0, s, feat, H, W, C, rois, P, spatial_scale, out, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
+                                float* dfeat, int dtype, hipStream_t s) {
+  hipLaunchKernelGGL(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, spatial_scale, dfeat, dtype);
+  return l2s_check_launch();
+}

@@ -1,0 +1,275 @@
+"""Thin tensor-level wrappers over the C ABI (include/lang2seg_hip.h).
+
+PyTorch is used for device memory and streams only: every wrapper passes raw
+`data_ptr()`s + sizes + the current HIP stream to liblang2seg_hip.so.  Outputs are
+caller- or wrapper-allocated torch tensors; no arithmetic happens in torch here."""
+import ctypes as C
+import torch
+from . import _lib
+from ._lib import ptr, call, F32, BF16, ConvDesc, WgradDesc
+
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_of(t):
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def empty(shape, dt, device='cuda'):
+    return torch.empty(shape, dtype=TORCH_DT[dt], device=device)
+
+
+# ------------------------------------------------------------------ conv / gemm
+def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
+               ref=None, relu=False, out_f32=False, deconv=False, scatter=None, ldx=None, ldy=None, ldadd=None,
+               ldref=None, tile=0, dt=None):
+    d = ConvDesc()
+    d.x, d.w, d.y = ptr(x), ptr(w), ptr(y)
+    d.bias, d.add, d.ref = ptr(bias), ptr(add), ptr(ref)
+    d.n_img, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = n_img, IH, IW, Cin, OH, OW, Cout
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.ldx = Cin if ldx is None else ldx
+    ocols = (Cout // 4) if deconv else Cout
+    d.ldy = ocols if ldy is None else ldy
+    d.ldadd = (ocols if ldadd is None else ldadd)
+    d.ldref = (ocols if ldref is None else ldref)
+    fl = 0
+    if relu:
+        fl |= _lib.CONV_RELU
+    if out_f32:
+        fl |= _lib.CONV_OUT_F32
+    if deconv:
+        fl |= _lib.CONV_DECONV2X2
+    if scatter is not None:
+        fl |= _lib.CONV_SCATTER
+        d.out_h, d.out_w, d.out_stride = scatter
+    d.flags = fl
+    d.tile = tile
+    call('l2s_conv_igemm', C.byref(d), dt_of(x) if dt is None else dt, stream())
+    return y
+
+
+def conv_wgrad(dy, x, dw, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, lddy=None, ldx=None,
+               split_k=0, tile=0):
+    d = WgradDesc()
+    d.dy, d.x, d.dw = ptr(dy), ptr(x), ptr(dw)
+    d.n_img, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = n_img, IH, IW, Cin, OH, OW, Cout
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.lddy = Cout if lddy is None else lddy
+    d.ldx = Cin if ldx is None else ldx
+    d.split_k, d.tile = split_k, tile
+    call('l2s_conv_wgrad', C.byref(d), dt_of(x), stream())
+    return dw
+
+
+def weight_cast(src, scale, dst, Cout, taps, Cin):
+    call('l2s_weight_cast', ptr(src), ptr(scale), ptr(dst), Cout, taps, Cin, dt_of(dst), stream())
+
+
+def weight_transpose(src, scale, dst, Cout, taps, Cin):
+    call('l2s_weight_transpose', ptr(src), ptr(scale), ptr(dst), Cout, taps, Cin, dt_of(dst), stream())
+
+
+def colsum(a, rows, cols, lda, out):
+    call('l2s_colsum', ptr(a), rows, cols, lda, ptr(out), dt_of(a), stream())
+
+
+def stem_conv(img, w, scale, bias, y, H, W, OH, OW):
+    call('l2s_stem_conv', ptr(img), ptr(w), ptr(scale), ptr(bias), ptr(y), H, W, OH, OW, dt_of(y), stream())
+
+
+def maxpool(x, y, IH, IW, Cc, OH, OW):
+    call('l2s_maxpool3x3s2', ptr(x), ptr(y), IH, IW, Cc, OH, OW, dt_of(x), stream())
+
+
+# ------------------------------------------------------------------ elementwise / pooling
+def fill(t, v):
+    call('l2s_fill_f32', ptr(t), float(v), t.numel(), stream())
+
+
+def cast(src, dst):
+    call('l2s_cast', ptr(src), dt_of(src), ptr(dst), dt_of(dst), src.numel(), stream())
+
+
+def add3(a, b, c, dst):
+    call('l2s_add3', ptr(a), ptr(b), ptr(c), ptr(dst), a.numel(), dt_of(a), stream())
+
+
+def avgpool_fwd(x, y, n_img, hw, Cc):
+    call('l2s_avgpool_fwd', ptr(x), ptr(y), n_img, hw, Cc, dt_of(x), stream())
+
+
+def avgpool_bwd(dy, dx, addend, ref, n_img, hw, Cc):
+    call('l2s_avgpool_bwd', ptr(dy), ptr(dx), ptr(addend), ptr(ref), n_img, hw, Cc, dt_of(dy), stream())
+
+
+def adaptive_pool_fwd(x, pixmask, y, H, W, Cc, OH, OW, ldy):
+    call('l2s_adaptive_pool_fwd', ptr(x), ptr(pixmask), ptr(y), H, W, Cc, OH, OW, ldy, dt_of(x), stream())
+
+
+def adaptive_pool_bwd(dy, lddy, off_all, off_mask, pixmask, dx, ref, H, W, Cc, OH, OW):
+    call('l2s_adaptive_pool_bwd', ptr(dy), lddy, off_all, off_mask, ptr(pixmask), ptr(dx), ptr(ref), H, W, Cc, OH, OW,
+         dt_of(dx), stream())
+
+
+def mask_downsample(mask_u8, out, H, W, h, w):
+    call('l2s_mask_downsample', ptr(mask_u8), ptr(out), H, W, h, w, stream())
+
+
+def dropout_mask(mask, p, seed):
+    call('l2s_dropout_mask', ptr(mask), mask.numel(), float(p), int(seed), stream())
+
+
+def random_keys(keys, seed):
+    call('l2s_random_keys', ptr(keys), keys.numel(), int(seed), stream())
+
+
+# ------------------------------------------------------------------ RoI path
+def rpn_decode(heads, ldh, base_anchors, H, W, A, fs, im_h, im_w, prob, boxes, scores):
+    call('l2s_rpn_decode', ptr(heads), ldh, ptr(base_anchors), H, W, A, fs, float(im_h), float(im_w), ptr(prob), ptr(boxes),
+         ptr(scores), stream())
+
+
+def sort_topk(scores, boxes, n, k, sboxes, sscores, sidx):
+    call('l2s_sort_topk', ptr(scores), ptr(boxes), n, k, None, ptr(sboxes), ptr(sscores), ptr(sidx), stream())
+
+
+def nms_workspace_bytes(n):
+    return int(_lib.load().l2s_nms_workspace_bytes(n))
+
+
+def nms(sboxes, n, thresh, cmp_mode, max_keep, mask_ws, keep, num):
+    call('l2s_nms', ptr(sboxes), n, float(thresh), cmp_mode, max_keep, ptr(mask_ws), ptr(keep), ptr(num), stream())
+
+
+def gather_rois(sboxes, sscores, keep, num, max_keep, rois, roi_scores):
+    call('l2s_gather_rois', ptr(sboxes), ptr(sscores), ptr(keep), ptr(num), max_keep, ptr(rois), ptr(roi_scores), stream())
+
+
+def anchor_target_ws_ints(hwa):
+    return int(_lib.load().l2s_anchor_target_ws_ints(hwa))
+
+
+def anchor_target(gt, n_gt, base_anchors, H, W, A, fs, im_h, im_w, fg_keys, bg_keys, neg_ov, pos_ov, batch, fg_frac,
+                  labels, targets, inw, outw, ws):
+    call('l2s_anchor_target', ptr(gt), n_gt, ptr(base_anchors), H, W, A, fs, float(im_h), float(im_w), ptr(fg_keys),
+         ptr(bg_keys), float(neg_ov), float(pos_ov), batch, float(fg_frac), ptr(labels), ptr(targets), ptr(inw),
+         ptr(outw), ptr(ws), stream())
+
+
+def proposal_target(rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w, fg_keys, bg_keys, bg_rand, R, fg_max,
+                    fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms, out_rois, labels, bt, bi, bo, mt, counts, ws):
+    call('l2s_proposal_target', ptr(rois), ptr(roi_scores), ptr(n_rois), n_max, ptr(gt), n_gt, ptr(gt_masks), im_h, im_w,
+         ptr(fg_keys), ptr(bg_keys), ptr(bg_rand), R, fg_max, float(fg_thresh), float(bg_hi), float(bg_lo), ptr(means4),
+         ptr(stds4), ptr(inw4), ncls, ms, ptr(out_rois), ptr(labels), ptr(bt), ptr(bi), ptr(bo), ptr(mt), ptr(counts),
+         ptr(ws), stream())
+
+
+def roialign_fwd(feat, H, W, Cc, rois, R, P, sscale, out):
+    call('l2s_roialign_fwd', ptr(feat), H, W, Cc, ptr(rois), R, P, float(sscale), ptr(out), dt_of(feat), stream())
+
+
+def roialign_bwd(dout, H, W, Cc, rois, R, P, sscale, dfeat):
+    call('l2s_roialign_bwd', ptr(dout), H, W, Cc, ptr(rois), R, P, float(sscale), ptr(dfeat), dt_of(dout), stream())
+
+
+# ------------------------------------------------------------------ losses
+def rpn_loss(heads, ldh, labels, targets, inw, outw, H, W, A, sigma, gscale, loss, dheads, ldd):
+    call('l2s_rpn_loss', ptr(heads), ldh, ptr(labels), ptr(targets), ptr(inw), ptr(outw), H, W, A, float(sigma), float(gscale),
+         ptr(loss), ptr(dheads), ldd, dt_of(dheads), stream())
+
+
+def rcnn_loss(heads, ldh, labels, bt, bi, bo, R, ncls, gscale, loss, dheads, ldd):
+    call('l2s_rcnn_loss', ptr(heads), ldh, ptr(labels), ptr(bt), ptr(bi), ptr(bo), R, ncls, float(gscale), ptr(loss),
+         ptr(dheads), ldd, dt_of(dheads), stream())
+
+
+def mask_loss(score, ldsc, labels, mt, num_fg, fg_max, ms2, gscale, loss, dscore):
+    call('l2s_mask_loss', ptr(score), ldsc, ptr(labels), ptr(mt), ptr(num_fg), fg_max, ms2, float(gscale), ptr(loss),
+         ptr(dscore), stream())
+
+
+def total_loss(loss, cap_w):
+    call('l2s_total_loss', ptr(loss), float(cap_w), stream())
+
+
+def maskpred_bwd(dscore, labels, num_fg, fg_max, ms2, Cc, w, x, ref, dx, dw, db):
+    call('l2s_maskpred_bwd', ptr(dscore), ptr(labels), ptr(num_fg), fg_max, ms2, Cc, ptr(w), ptr(x), ptr(ref), ptr(dx),
+         ptr(dw), ptr(db), dt_of(x), stream())
+
+
+# ------------------------------------------------------------------ language side (fp32)
+def linear_fwd(x, w, b, y, M, N, K, act=0, accumulate=False, ldx=None, ldy=None):
+    call('l2s_linear_fwd', ptr(x), K if ldx is None else ldx, ptr(w), ptr(b), ptr(y), N if ldy is None else ldy, M, N, K,
+         act, 1 if accumulate else 0, stream())
+
+
+def linear_bwd_x(dy, w, dx, M, N, K, accumulate=False, lddy=None, lddx=None):
+    call('l2s_linear_bwd_x', ptr(dy), N if lddy is None else lddy, ptr(w), ptr(dx), K if lddx is None else lddx, M, N, K,
+         1 if accumulate else 0, stream())
+
+
+def linear_bwd_w(dy, x, dw, db, M, N, K, lddy=None, ldx=None):
+    call('l2s_linear_bwd_w', ptr(dy), N if lddy is None else lddy, ptr(x), K if ldx is None else ldx, ptr(dw), ptr(db), M, N,
+         K, stream())
+
+
+def act_bwd(dy, y, act):
+    call('l2s_act_bwd', ptr(dy), ptr(y), dy.numel(), act, stream())
+
+
+def embed_fwd(table, ids, mask, out, T, D, relu):
+    call('l2s_embed_fwd', ptr(table), ptr(ids), ptr(mask), ptr(out), T, D, 1 if relu else 0, stream())
+
+
+def embed_bwd(dout, out, ids, mask, dtable, T, D, relu):
+    call('l2s_embed_bwd', ptr(dout), ptr(out), ptr(ids), ptr(mask), ptr(dtable), T, D, 1 if relu else 0, stream())
+
+
+def lstm_cell_fwd(gates, c_prev, c, h, act, Hh):
+    call('l2s_lstm_cell_fwd', ptr(gates), ptr(c_prev), ptr(c), ptr(h), ptr(act), Hh, stream())
+
+
+def lstm_cell_bwd(dh, dc_in, act, c_prev, c, dgates, dc_prev, Hh):
+    call('l2s_lstm_cell_bwd', ptr(dh), ptr(dc_in), ptr(act), ptr(c_prev), ptr(c), ptr(dgates), ptr(dc_prev), Hh, stream())
+
+
+def dynfilter_fwd(x, filt, r, y, resp, respk, H, W, Cc):
+    call('l2s_dynfilter_fwd', ptr(x), ptr(filt), ptr(r), ptr(y), ptr(resp), ptr(respk), H, W, Cc, dt_of(x), stream())
+
+
+def dynfilter_bwd(dy, x, filt, r, resp, respk, dx, ref, dfilt, dr, dresp_ws, H, W, Cc):
+    call('l2s_dynfilter_bwd', ptr(dy), ptr(x), ptr(filt), ptr(r), ptr(resp), ptr(respk), ptr(dx), ptr(ref), ptr(dfilt),
+         ptr(dr), ptr(dresp_ws), H, W, Cc, dt_of(x), stream())
+
+
+def cap_attention_fwd(patt, att, att_h, aw, ab, L, D, tanh_ws, weight, att_res):
+    call('l2s_cap_attention_fwd', ptr(patt), ptr(att), ptr(att_h), ptr(aw), ptr(ab), L, D, ptr(tanh_ws), ptr(weight),
+         ptr(att_res), stream())
+
+
+def cap_attention_bwd(datt_res, att, tanh_ws, weight, aw, L, D, dpatt, datt, datt_h, daw, dab):
+    call('l2s_cap_attention_bwd', ptr(datt_res), ptr(att), ptr(tanh_ws), ptr(weight), ptr(aw), L, D, ptr(dpatt), ptr(datt),
+         ptr(datt_h), ptr(daw), ptr(dab), stream())
+
+
+def cap_gates_fwd(sums, a2c, c_prev, c, h, save, R):
+    call('l2s_cap_gates_fwd', ptr(sums), ptr(a2c), ptr(c_prev), ptr(c), ptr(h), ptr(save), R, stream())
+
+
+def cap_gates_bwd(dh, dc_in, save, c_prev, dsums, da2c, dc_prev, R):
+    call('l2s_cap_gates_bwd', ptr(dh), ptr(dc_in), ptr(save), ptr(c_prev), ptr(dsums), ptr(da2c), ptr(dc_prev), R, stream())
+
+
+def logsoftmax_nll(logits, target, mask, S, V1, gscale, loss_slot, dlogits, logprobs=None):
+    call('l2s_logsoftmax_nll', ptr(logits), ptr(target), ptr(mask), S, V1, float(gscale), ptr(loss_slot), ptr(dlogits),
+         ptr(logprobs), stream())
+
+
+def sgd_momentum(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale=1.0):
+    call('l2s_sgd_momentum', ptr(param), ptr(grad), ptr(mom), ptr(segs_dev), nseg, ptr(rowscale), float(lr), float(momentum),
+         float(wd), float(gscale), stream())

@@ -1,0 +1,610 @@
+"""Per-kernel parity: every C-ABI entry point of liblang2seg_hip.so against the CPU oracle
+(oracle/*.py, torch-CPU fp32 autograd for float ops, numpy for integer/box work) on seeded
+inputs.  Tolerances: fp32 kernels 1e-4 relative (exact-f32 MFMA), bf16 storage 2e-2;
+integer / index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import boxes as OB
+from oracle import net as ON
+
+DEV = 'cuda'
+
+
+def ops():
+    from lang2seg_amd import ops as O
+    return O
+
+
+def rel_err(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def nhwc(x):  # NCHW cpu -> NHWC flat rows
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_dev(t, dt):
+    return t.to(DEV).to(torch.bfloat16 if dt == 1 else torch.float32).contiguous()
+
+
+def ohwi(w):  # OIHW -> [O][KH][KW][I]
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+TOL = {0: 2e-5, 1: 2e-2}
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+@pytest.mark.parametrize('cfg', [
+    dict(n=1, H=19, W=23, Cin=64, Cout=64, k=3, s=1, p=1),
+    dict(n=1, H=38, W=63, Cin=256, Cout=256, k=3, s=1, p=1),
+    dict(n=3, H=7, W=7, Cin=128, Cout=192, k=3, s=1, p=1),
+    dict(n=1, H=38, W=63, Cin=1024, Cout=72, k=1, s=1, p=0),
+    dict(n=1, H=20, W=26, Cin=256, Cout=128, k=1, s=2, p=0),
+    dict(n=40, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1, tile=128),
+    dict(n=1, H=9, W=11, Cin=96, Cout=40, k=1, s=1, p=0),
+])
+def test_conv_fwd(cfg, dt):
+    O = ops()
+    g = torch.Generator().manual_seed(1)
+    n, H, W, Cin, Cout, k, s, p = [cfg[x] for x in ['n', 'H', 'W', 'Cin', 'Cout', 'k', 's', 'p']]
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    OH = (H + 2 * p - k) // s + 1; OW = (W + 2 * p - k) // s + 1
+    res = torch.randn(n, Cout, OH, OW, generator=g)
+    xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
+    # the oracle sees the same rounded operands
+    xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(xr, wr, b, stride=s, padding=p) + rr)
+    y = O.empty((n * OH * OW, Cout), dt)
+    O.conv_igemm(xd, wd, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=b.to(DEV), add=rd, relu=True, tile=cfg.get('tile', 0))
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(n, OH, OW, Cout), nhwc(ref)) < TOL[dt]
+    # fp32 output + no epilogue
+    y2 = torch.empty((n * OH * OW, Cout), dtype=torch.float32, device=DEV)
+    O.conv_igemm(xd, wd, y2, n, H, W, Cin, OH, OW, Cout, k, k, s, p, out_f32=True)
+    ref2 = F.conv2d(xr, wr, None, stride=s, padding=p)
+    assert rel_err(y2.view(n, OH, OW, Cout), nhwc(ref2)) < (2e-5 if dt == 0 else 1e-4)
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+@pytest.mark.parametrize('cfg', [
+    dict(n=1, H=19, W=23, Cin=64, Cout=128, k=3, s=1, p=1),
+    dict(n=1, H=38, W=63, Cin=256, Cout=256, k=3, s=1, p=1),
+    dict(n=5, H=7, W=7, Cin=128, Cout=64, k=1, s=1, p=0),
+    dict(n=1, H=20, W=26, Cin=256, Cout=128, k=1, s=2, p=0),
+    dict(n=1, H=14, W=14, Cin=512, Cout=72, k=1, s=1, p=0),
+])
+def test_conv_bwd(cfg, dt):
+    """data gradient = igemm over dY with transposed/flipped weights; weight gradient = wgrad kernel."""
+    O = ops()
+    g = torch.Generator().manual_seed(2)
+    n, H, W, Cin, Cout, k, s, p = [cfg[x] for x in ['n', 'H', 'W', 'Cin', 'Cout', 'k', 's', 'p']]
+    OH = (H + 2 * p - k) // s + 1; OW = (W + 2 * p - k) // s + 1
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    dy = torch.randn(n, Cout, OH, OW, generator=g)
+    xd, dyd = to_dev(nhwc(x), dt), to_dev(nhwc(dy), dt)
+    w_master = ohwi(w).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5)
+    xr = xd.float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    dyr = dyd.float().cpu().permute(0, 3, 1, 2)
+    # effective (BN-folded) weight as the kernels see it
+    wt = O.empty((Cin, k * k, Cout), dt)
+    O.weight_transpose(w_master, scale.to(DEV), wt, Cout, k * k, Cin)
+    wf = O.empty((Cout, k * k, Cin), dt)
+    O.weight_cast(w_master, scale.to(DEV), wf, Cout, k * k, Cin)
+    torch.cuda.synchronize()
+    weff = wf.float().cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    assert rel_err(wf.float().view(Cout, k, k, Cin), ohwi(w) * scale.view(-1, 1, 1, 1)) < (1e-6 if dt == 0 else 1e-2)
+    out = F.conv2d(xr, weff, None, stride=s, padding=p)
+    out.backward(dyr)
+    # dgrad
+    dx = torch.zeros((n * H * W, Cin), dtype=O.TORCH_DT[dt], device=DEV)
+    if s == 1:
+        O.conv_igemm(dyd, wt, dx, n, OH, OW, Cout, H, W, Cin, k, k, 1, k - 1 - p)
+    else:
+        O.conv_igemm(dyd, wt, dx, n, OH, OW, Cout, OH, OW, Cin, 1, 1, 1, 0, scatter=(H, W, s))
+    torch.cuda.synchronize()
+    assert rel_err(dx.float().view(n, H, W, Cin), nhwc(xr.grad)) < TOL[dt]
+    # wgrad (accumulates on top of existing content)
+    dw = torch.ones((Cout, k * k, Cin), dtype=torch.float32, device=DEV)
+    O.conv_wgrad(dyd, xd, dw, n, H, W, Cin, OH, OW, Cout, k, k, s, p)
+    torch.cuda.synchronize()
+    refw = ohwi(weff.grad).view(Cout, k * k, Cin) + 1.0
+    assert rel_err(dw, refw) < (1e-4 if dt == 0 else 2e-2)
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+def test_deconv_and_colsum(dt):
+    O = ops()
+    g = torch.Generator().manual_seed(3)
+    n, Cin, Cq = 6, 256, 64
+    x = torch.randn(n, Cin, 7, 7, generator=g)
+    w = torch.randn(Cin, Cq, 2, 2, generator=g) * 0.05       # ConvTranspose2d layout (Cin, Cout, kh, kw)
+    b = torch.randn(Cq, generator=g)
+    xd = to_dev(nhwc(x), dt)
+    wg = w.permute(2, 3, 1, 0).contiguous().view(4 * Cq, Cin)  # [(dy,dx,co)][ci]
+    wd = to_dev(wg, dt)
+    xr = xd.float().cpu().permute(0, 3, 1, 2)
+    wr = wd.float().cpu().view(2, 2, Cq, Cin).permute(3, 2, 0, 1)
+    ref = F.relu(F.conv_transpose2d(xr, wr, b, stride=2))
+    y = O.empty((n * 14 * 14, Cq), dt)
+    O.conv_igemm(xd, wd, y, n, 7, 7, Cin, 7, 7, 4 * Cq, bias=b.to(DEV), relu=True, deconv=True)
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(n, 14, 14, Cq), nhwc(ref)) < TOL[dt]
+    out = torch.zeros(Cq, device=DEV)
+    O.colsum(y, n * 196, Cq, Cq, out)
+    torch.cuda.synchronize()
+    assert rel_err(out, y.float().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+def test_stem_maxpool(dt):
+    O = ops()
+    g = torch.Generator().manual_seed(4)
+    H, W = 61, 83
+    img = torch.randn(1, H, W, 3, generator=g) * 50
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.01
+    sc = torch.rand(64, generator=g) + 0.5; bi = torch.randn(64, generator=g) * 0.1
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    y = O.empty((OH * OW, 64), dt)
+    O.stem_conv(img.to(DEV), ohwi(w).to(DEV), sc.to(DEV), bi.to(DEV), y, H, W, OH, OW)
+    ref = F.relu(F.conv2d(img.permute(0, 3, 1, 2), w, None, stride=2, padding=3) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1))
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(1, OH, OW, 64), nhwc(ref)) < (1e-5 if dt == 0 else 1e-2)
+    PH, PW = (OH + 2 - 3) // 2 + 1, (OW + 2 - 3) // 2 + 1
+    yp = O.empty((PH * PW, 64), dt)
+    O.maxpool(y, yp, OH, OW, 64, PH, PW)
+    refp = F.max_pool2d(y.float().cpu().view(1, OH, OW, 64).permute(0, 3, 1, 2), 3, 2, 1)
+    torch.cuda.synchronize()
+    assert rel_err(yp.float().view(1, PH, PW, 64), nhwc(refp)) < 1e-6
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+def test_pools(dt):
+    O = ops()
+    g = torch.Generator().manual_seed(5)
+    n, hw, Cc = 5, 49, 192
+    x = torch.randn(n, hw, Cc, generator=g)
+    xd = to_dev(x, dt)
+    y = O.empty((n, Cc), dt)
+    O.avgpool_fwd(xd, y, n, hw, Cc)
+    torch.cuda.synchronize()
+    assert rel_err(y.float(), xd.float().mean(1)) < (1e-5 if dt == 0 else 1e-2)
+    dy = to_dev(torch.randn(n, Cc, generator=g), dt)
+    add = to_dev(torch.randn(n, hw, Cc, generator=g), dt)
+    dx = O.empty((n, hw, Cc), dt)
+    O.avgpool_bwd(dy, dx, add, xd, n, hw, Cc)
+    ref = (dy.float().cpu().unsqueeze(1) / hw + add.float().cpu()) * (xd.float().cpu() > 0)
+    torch.cuda.synchronize()
+    assert rel_err(dx.float(), ref) < (1e-5 if dt == 0 else 1e-2)
+    # adaptive pool 38x63 -> 14x14 with a pixel mask, forward and backward
+    H, W, Cc = 38, 63, 128
+    f = torch.randn(1, Cc, H, W, generator=g)
+    pm = (torch.rand(H, W, generator=g) > 0.5).float()
+    fd = to_dev(nhwc(f), dt)
+    fr = fd.float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ya = F.adaptive_avg_pool2d(fr, [14, 14]); ym = F.adaptive_avg_pool2d(fr * pm, [14, 14])
+    refy = torch.cat((ya.permute(0, 2, 3, 1), ym.permute(0, 2, 3, 1)), 3).reshape(196, 2 * Cc)
+    yo = O.empty((196, 2 * Cc), dt)
+    O.adaptive_pool_fwd(fd, None, yo, H, W, Cc, 14, 14, 2 * Cc)
+    O.adaptive_pool_fwd(fd, pm.to(DEV), yo[:, Cc:], H, W, Cc, 14, 14, 2 * Cc)
+    torch.cuda.synchronize()
+    assert rel_err(yo.float(), refy) < (1e-5 if dt == 0 else 1e-2)
+    dyo = to_dev(torch.randn(196, 2 * Cc, generator=g), dt)
+    refy.backward(dyo.float().cpu())
+    dxo = O.empty((H * W, Cc), dt)
+    O.adaptive_pool_bwd(dyo, 2 * Cc, 0, Cc, pm.to(DEV), dxo, None, H, W, Cc, 14, 14)
+    torch.cuda.synchronize()
+    assert rel_err(dxo.float().view(1, H, W, Cc), nhwc(fr.grad)) < (1e-5 if dt == 0 else 1e-2)
+    # gt mask downsample
+    m = (torch.rand(600, 1000, generator=g) > 0.6).to(torch.uint8)
+    out = torch.empty(38 * 63, device=DEV)
+    O.mask_downsample(m.to(DEV), out, 600, 1000, 38, 63)
+    refm = (F.adaptive_avg_pool2d(m.float()[None, None], [38, 63]) >= 0.5).float().view(-1)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), refm)
+
+
+def _rpn_inputs(H, W, A, seed, gain=1.0):
+    rs = np.random.RandomState(seed)
+    heads = rs.normal(0, gain, (H * W, 6 * A + 8)).astype(np.float32)
+    heads[:, 2 * A:6 * A] *= 0.3
+    return heads
+
+
+def test_rpn_decode_sort_nms():
+    O = ops()
+    H, W, A = 20, 26, 12
+    heads = _rpn_inputs(H, W, A, 6)
+    anchors, n = OB.generate_anchors_pre(H, W, 16, (4, 8, 16, 32), (0.5, 1, 2))
+    base = OB.generate_anchors(ratios=(0.5, 1, 2), scales=(4, 8, 16, 32)).astype(np.float32)
+    hd = torch.from_numpy(heads).to(DEV)
+    prob = torch.empty(H * W, 2 * A, device=DEV); boxes = torch.empty(n, 4, device=DEV); scores = torch.empty(n, device=DEV)
+    O.rpn_decode(hd, heads.shape[1], torch.from_numpy(base).to(DEV), H, W, A, 16, 320.0, 416.0, prob, boxes, scores)
+    cls = torch.from_numpy(heads[:, :2 * A]).view(H * W, 2, A)
+    p_ref = F.softmax(cls, 1).view(H * W, 2 * A)
+    deltas = heads[:, 2 * A:6 * A].reshape(-1, 4)
+    b_ref = OB.clip_boxes(OB.bbox_transform_inv(anchors, deltas), (320, 416))
+    torch.cuda.synchronize()
+    assert rel_err(prob, p_ref) < 1e-5
+    assert np.abs(boxes.cpu().numpy() - b_ref).max() < 2e-3
+    # stable sort + top-k: bit-exact order on the device's own scores
+    sc = scores.cpu().numpy(); bx = boxes.cpu().numpy()
+    k = 1500
+    sb = torch.empty(k, 4, device=DEV); ss = torch.empty(k, device=DEV); si = torch.empty(k, dtype=torch.int32, device=DEV)
+    O.sort_topk(scores, boxes, n, k, sb, ss, si)
+    order = OB.stable_desc_order(sc)[:k]
+    torch.cuda.synchronize()
+    assert np.array_equal(si.cpu().numpy(), order.astype(np.int32))
+    assert np.array_equal(sb.cpu().numpy(), bx[order])
+    # NMS, both comparators, bit-exact keep lists vs numpy and C oracles
+    import ctypes as C, os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_build', 'liboracle_ref.so')
+    clib = C.CDLL(so) if os.path.exists(so) else None
+    for cmp_mode, name in [(0, 'ge'), (1, 'gt')]:
+        for max_keep in [300, 5000]:
+            ws = torch.empty(O.nms_workspace_bytes(k) // 8 + 8, dtype=torch.int64, device=DEV)
+            keep = torch.full((max_keep,), -1, dtype=torch.int32, device=DEV); num = torch.zeros(1, dtype=torch.int32, device=DEV)
+            O.nms(sb, k, 0.7, cmp_mode, max_keep, ws, keep, num)
+            dets = np.hstack((bx[order], sc[order][:, None]))
+            ref_keep = OB.nms(dets, 0.7, name)[:max_keep]
+            torch.cuda.synchronize()
+            nk = int(num.item())
+            assert nk == len(ref_keep)
+            assert np.array_equal(keep.cpu().numpy()[:nk], ref_keep.astype(np.int32))
+            if clib is not None:
+                sbx = np.ascontiguousarray(bx[order]); ko = np.zeros(k, np.int64)
+                if cmp_mode == 0:
+                    od = np.arange(k, dtype=np.int64)
+                    cn = clib.oracle_cpu_nms(sbx.ctypes.data_as(C.c_void_p), od.ctypes.data_as(C.c_void_p), C.c_long(k), C.c_float(0.7), ko.ctypes.data_as(C.c_void_p))
+                else:
+                    cn = clib.oracle_gpu_nms(sbx.ctypes.data_as(C.c_void_p), C.c_long(k), C.c_float(0.7), ko.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(ko[:cn][:max_keep], ref_keep)
+    rois = torch.empty(300, 5, device=DEV); rsc = torch.empty(300, device=DEV)
+    keep = torch.full((300,), -1, dtype=torch.int32, device=DEV); num = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(O.nms_workspace_bytes(k) // 8 + 8, dtype=torch.int64, device=DEV)
+    O.nms(sb, k, 0.7, 0, 300, ws, keep, num)
+    O.gather_rois(sb, ss, keep, num, 300, rois, rsc)
+    torch.cuda.synchronize()
+    nk = int(num.item()); kk = keep.cpu().numpy()[:nk]
+    assert np.array_equal(rois.cpu().numpy()[:nk, 1:], bx[order][kk]) and (rois.cpu().numpy()[nk:] == 0).all()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_anchor_target(seed):
+    O = ops()
+    H, W, A = 20, 26, 12
+    rs = np.random.RandomState(seed)
+    n = H * W * A
+    gt = np.array([[60 + 20 * seed, 40, 260 + 30 * seed, 250, 7]], np.float32)
+    if seed == 2:
+        gt = np.vstack((gt, [[10, 10, 90, 120, 3]])).astype(np.float32)
+    anchors, _ = OB.generate_anchors_pre(H, W, 16, (4, 8, 16, 32), (0.5, 1, 2))
+    base = OB.generate_anchors(ratios=(0.5, 1, 2), scales=(4, 8, 16, 32)).astype(np.float32)
+    fgk = rs.permutation(n).astype(np.uint32); bgk = rs.permutation(n).astype(np.uint32)
+    ct = dict(ON.DEFAULT_CFG['TRAIN']); ct['RPN_BATCHSIZE'] = 64 if seed else 256
+    lab, tg, inw, outw = OB.anchor_target_layer(H, W, gt, np.array([320, 416, 1.0]), anchors, A, ct, fgk, bgk)
+    labels = torch.empty(n, dtype=torch.int32, device=DEV)
+    t = torch.empty(H * W, 4 * A, device=DEV); i_ = torch.empty_like(t); o_ = torch.empty_like(t)
+    ws = torch.empty(O.anchor_target_ws_ints(n), dtype=torch.int32, device=DEV)
+    O.anchor_target(torch.from_numpy(gt).to(DEV), gt.shape[0], torch.from_numpy(base).to(DEV), H, W, A, 16, 320.0, 416.0,
+                    torch.from_numpy(fgk.astype(np.int64)).to(torch.int32).to(DEV) if False else torch.from_numpy(fgk.view(np.int32)).to(DEV),
+                    torch.from_numpy(bgk.view(np.int32)).to(DEV), 0.3, 0.7, ct['RPN_BATCHSIZE'], 0.5, labels, t, i_, o_, ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(labels.cpu().numpy(), lab.reshape(-1).astype(np.int32))
+    assert np.abs(t.cpu().numpy() - tg.reshape(H * W, -1)).max() < 1e-5
+    assert np.array_equal(i_.cpu().numpy(), inw.reshape(H * W, -1))
+    assert np.abs(o_.cpu().numpy() - outw.reshape(H * W, -1)).max() < 1e-8
+
+
+@pytest.mark.parametrize('case', ['normal', 'few_bg', 'no_fg'])
+def test_proposal_target(case):
+    O = ops()
+    rs = np.random.RandomState(11)
+    im_h, im_w = 320, 416
+    gt = np.array([[100, 80, 300, 260, 17]], np.float32)
+    yy, xx = np.mgrid[0:im_h, 0:im_w]
+    gm = ((((xx - 200) / 100.) ** 2 + ((yy - 170) / 90.) ** 2) <= 1).astype(np.uint8)[None]
+    n_max, n = 300, 240
+    b = rs.uniform(0, 300, (n, 4)).astype(np.float32); b[:, 2:] = np.minimum(b[:, :2] + rs.uniform(20, 200, (n, 2)), [im_w - 1, im_h - 1])
+    if case != 'no_fg':
+        b[:40] = gt[0, :4] + rs.normal(0, 12, (40, 4)); b[:40] = np.clip(b[:40], 0, [im_w - 1, im_h - 1, im_w - 1, im_h - 1])
+    else:
+        b[:, 0] = np.minimum(b[:, 0], 60); b[:, 2] = np.minimum(b[:, 2], 90)
+    if case == 'few_bg':
+        n = 60
+    rois = np.zeros((n_max, 5), np.float32); rois[:n, 1:] = b[:n].astype(np.float32)
+    sc = rs.rand(n_max).astype(np.float32)
+    fgk = rs.permutation(n_max + 1).astype(np.uint32); bgk = rs.permutation(n_max + 1).astype(np.uint32)
+    bgr = rs.randint(0, 1 << 30, 64).astype(np.uint32)
+    ct = dict(ON.DEFAULT_CFG['TRAIN']); ct['BATCH_SIZE'] = 32
+    ref = OB.proposal_target_layer(rois[:n], sc[:n], gt, gm, 81, ct, 14, fgk[:n], bgk[:n], None, bgr)
+    R, fg_max = 32, 8
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    out_rois = torch.empty(R, 5, device=DEV); labels = torch.empty(R, dtype=torch.int32, device=DEV)
+    bt = torch.empty(R, 324, device=DEV); bi = torch.empty_like(bt); bo = torch.empty_like(bt)
+    mt = torch.empty(fg_max, 196, device=DEV); counts = torch.zeros(4, dtype=torch.int32, device=DEV)
+    ws = torch.empty(4 * (n_max + 1) + R + 16, dtype=torch.int32, device=DEV)
+    O.proposal_target(d(rois), d(sc), d(np.array([n], np.int32)), n_max, d(gt), 1, d(gm), im_h, im_w, d(fgk.view(np.int32)),
+                      d(bgk.view(np.int32)), d(bgr.view(np.int32)), R, fg_max, 0.5, 0.5, 0.0, d(np.zeros(4, np.float32)),
+                      d(np.array([.1, .1, .2, .2], np.float32)), d(np.ones(4, np.float32)), 81, 14, out_rois, labels, bt, bi, bo, mt,
+                      counts, ws)
+    torch.cuda.synchronize()
+    r_rois, _, r_lab, r_bt, r_bi, r_bo, r_mt, _ = ref
+    nfg = int(counts[0].item())
+    assert nfg == r_mt.shape[0]
+    assert np.array_equal(out_rois.cpu().numpy(), r_rois)
+    assert np.array_equal(labels.cpu().numpy(), r_lab.reshape(-1).astype(np.int32))
+    assert np.abs(bt.cpu().numpy() - r_bt).max() < 1e-4
+    assert np.array_equal(bi.cpu().numpy(), r_bi) and np.array_equal(bo.cpu().numpy(), r_bo)
+    assert np.array_equal(mt.cpu().numpy()[:nfg].reshape(nfg, 14, 14), r_mt)
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+def test_roialign(dt):
+    O = ops()
+    g = torch.Generator().manual_seed(7)
+    H, W, Cc, R = 20, 26, 96, 9
+    feat = torch.randn(1, Cc, H, W, generator=g)
+    rs = np.random.RandomState(3)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 1] = rs.uniform(0, 300, R); rois[:, 2] = rs.uniform(0, 200, R)
+    rois[:, 3] = np.minimum(rois[:, 1] + rs.uniform(10, 200, R), 415); rois[:, 4] = np.minimum(rois[:, 2] + rs.uniform(10, 200, R), 319)
+    rois[0, 1:] = [0, 0, 415, 319]
+    fd = to_dev(nhwc(feat), dt)
+    fr = fd.float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    net = ON.OracleNet.__new__(ON.OracleNet); net.cfg = ON.DEFAULT_CFG
+    ref = net.crop_pool(fr, torch.from_numpy(rois))
+    out = O.empty((R * 49, Cc), dt)
+    O.roialign_fwd(fd, H, W, Cc, torch.from_numpy(rois).to(DEV), R, 7, 1.0 / 16.0, out)
+    torch.cuda.synchronize()
+    assert rel_err(out.float().view(R, 7, 7, Cc), ref.permute(0, 2, 3, 1)) < (2e-5 if dt == 0 else 1e-2)
+    dout = to_dev(torch.randn(R, 7, 7, Cc, generator=g), dt)
+    ref.backward(dout.float().cpu().permute(0, 3, 1, 2))
+    dfeat = torch.zeros(H * W, Cc, device=DEV)
+    O.roialign_bwd(dout, H, W, Cc, torch.from_numpy(rois).to(DEV), R, 7, 1.0 / 16.0, dfeat)
+    torch.cuda.synchronize()
+    assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
+
+
+def test_losses():
+    O = ops()
+    g = torch.Generator().manual_seed(8)
+    H, W, A = 12, 16, 12
+    n = H * W * A
+    ldh = 6 * A + 8
+    heads = torch.randn(H * W, ldh, generator=g)
+    hr = heads.clone().requires_grad_(True)
+    labels_hwa = torch.randint(-1, 2, (H, W, A), generator=g)
+    lab_ahw = labels_hwa.permute(2, 0, 1).contiguous().view(-1)
+    tg = torch.randn(H * W, 4 * A, generator=g) * 0.3
+    inw = (labels_hwa == 1).float().view(H * W, A, 1).expand(-1, -1, 4).reshape(H * W, 4 * A).contiguous()
+    outw = (labels_hwa >= 0).float().view(H * W, A, 1).expand(-1, -1, 4).reshape(H * W, 4 * A).contiguous() / 50.0
+    # oracle: NET:377-390 on the NCHW-equivalent views
+    cls = hr[:, :2 * A].view(H * W, 2, A)                       # [pix][k][a]
+    cls_rs = cls.permute(2, 0, 1).reshape(-1, 2)                 # rows (a,h,w)
+    sel = (lab_ahw != -1).nonzero().view(-1)
+    l_cls = F.cross_entropy(cls_rs[sel], lab_ahw[sel])
+    l_box = ON.OracleNet.smooth_l1(hr[:, 2 * A:6 * A].view(1, H, W, 4 * A), tg.view(1, H, W, -1), inw.view(1, H, W, -1), outw.view(1, H, W, -1), 3.0, [1, 2, 3])
+    (l_cls + l_box).backward()
+    loss = torch.zeros(8, device=DEV)
+    dh = torch.full((H * W, ldh), 7.0, device=DEV)
+    O.rpn_loss(heads.to(DEV), ldh, lab_ahw.to(torch.int32).to(DEV), tg.to(DEV), inw.to(DEV), outw.to(DEV), H, W, A, 3.0, 1.0, loss, dh, ldh)
+    torch.cuda.synchronize()
+    assert abs(loss[0].item() - l_cls.item()) < 1e-5 and abs(loss[1].item() - l_box.item()) < 1e-5
+    assert rel_err(dh, hr.grad) < 1e-5
+    # rcnn
+    R, ncls = 32, 81
+    ldh = 5 * ncls + 3
+    heads = torch.randn(R, ldh, generator=g); hr = heads.clone().requires_grad_(True)
+    lab = torch.randint(0, ncls, (R,), generator=g)
+    bt = torch.randn(R, 4 * ncls, generator=g); bi = (torch.rand(R, 4 * ncls, generator=g) > 0.9).float(); bo = bi.clone()
+    l1 = F.cross_entropy(hr[:, :ncls], lab)
+    l2 = ON.OracleNet.smooth_l1(hr[:, ncls:5 * ncls], bt, bi, bo, 1.0, [1])
+    (l1 + l2).backward()
+    loss.zero_()
+    dh = torch.full((R, ldh), 7.0, device=DEV)
+    O.rcnn_loss(heads.to(DEV), ldh, lab.to(torch.int32).to(DEV), bt.to(DEV), bi.to(DEV), bo.to(DEV), R, ncls, 1.0, loss, dh, ldh)
+    torch.cuda.synchronize()
+    assert abs(loss[2].item() - l1.item()) < 1e-5 and abs(loss[3].item() - l2.item()) < 1e-5
+    assert rel_err(dh, hr.grad) < 1e-5
+    # mask loss + mask_pred backward
+    fg_max, nfg, Cc = 8, 5, 64
+    sc = torch.randn(fg_max * 196, ncls, generator=g); sr = sc.clone().requires_grad_(True)
+    mt = (torch.rand(fg_max, 196, generator=g) > 0.5).float()
+    labs = torch.randint(1, ncls, (fg_max,), generator=g)
+    picked = sr.view(fg_max, 196, ncls)[:nfg].gather(2, labs[:nfg].view(nfg, 1, 1).expand(nfg, 196, 1)).squeeze(2)
+    lm = F.binary_cross_entropy_with_logits(picked, mt[:nfg])
+    lm.backward()
+    loss.zero_()
+    dsc = torch.empty(fg_max * 196, device=DEV)
+    nf = torch.tensor([nfg], dtype=torch.int32, device=DEV)
+    O.mask_loss(sc.to(DEV), ncls, labs.to(torch.int32).to(DEV), mt.to(DEV), nf, fg_max, 196, 1.0, loss, dsc)
+    torch.cuda.synchronize()
+    assert abs(loss[4].item() - lm.item()) < 1e-5
+    dref = sr.grad.view(fg_max, 196, ncls).gather(2, labs.view(fg_max, 1, 1).expand(fg_max, 196, 1)).squeeze(2)
+    assert rel_err(dsc.view(fg_max, 196), dref) < 1e-5
+    u = F.relu(torch.randn(fg_max * 196, Cc, generator=g)); wm = torch.randn(ncls, Cc, generator=g)
+    ur = u.clone().requires_grad_(True); wr = wm.clone().requires_grad_(True); br = torch.zeros(ncls, requires_grad=True)
+    (F.linear(ur, wr, br) * sr.grad).sum().backward()
+    dx = torch.empty(fg_max * 196, Cc, device=DEV); dw = torch.zeros(ncls, Cc, device=DEV); db = torch.zeros(ncls, device=DEV)
+    O.maskpred_bwd(dsc, labs.to(torch.int32).to(DEV), nf, fg_max, 196, Cc, wm.to(DEV), u.to(DEV), u.to(DEV), dx, dw, db)
+    torch.cuda.synchronize()
+    assert rel_err(dx, ur.grad * (u > 0)) < 1e-5 and rel_err(dw, wr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    loss.zero_(); loss[:6] = torch.tensor([1., 2., 3., 4., 5., 6.])
+    O.total_loss(loss, 0.5)
+    torch.cuda.synchronize()
+    assert abs(loss[6].item() - 18.0) < 1e-6
+
+
+def test_linear_embed_lstm():
+    O = ops()
+    g = torch.Generator().manual_seed(9)
+    for (M, N, K, act) in [(1, 2048, 512, 0), (21, 3350, 512, 0), (7, 512, 512, 1), (1, 7175, 1024, 2), (30, 64, 128, 0)]:
+        x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / np.sqrt(K); b = torch.randn(N, generator=g)
+        xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+        pre = F.linear(xr, wr, br)
+        yref = pre if act == 0 else (F.relu(pre) if act == 1 else torch.tanh(pre))
+        y = torch.empty(M, N, device=DEV)
+        O.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), y, M, N, K, act)
+        torch.cuda.synchronize()
+        assert rel_err(y, yref) < 1e-5
+        dy = torch.randn(M, N, generator=g)
+        yref.backward(dy)
+        dyd = dy.to(DEV).clone()
+        if act:
+            O.act_bwd(dyd, y, act)
+        dx = torch.empty(M, K, device=DEV)
+        O.linear_bwd_x(dyd, w.to(DEV), dx, M, N, K)
+        dw = torch.zeros(N, K, device=DEV); db = torch.zeros(N, device=DEV)
+        O.linear_bwd_w(dyd, x.to(DEV), dw, db, M, N, K)
+        torch.cuda.synchronize()
+        assert rel_err(dx, xr.grad) < 1e-4 and rel_err(dw, wr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    # embedding (+relu, mask) fwd/bwd with a repeated token
+    V, D, T = 50, 512, 6
+    tab = torch.randn(V, D, generator=g); ids = torch.tensor([3, 7, 3, 0, 49, 7])
+    mask = (torch.rand(T, D, generator=g) > 0.5).float() * 2
+    tr = tab.clone().requires_grad_(True)
+    ref = F.relu(tr[ids]) * mask
+    out = torch.empty(T, D, device=DEV)
+    O.embed_fwd(tab.to(DEV), ids.to(DEV), mask.to(DEV), out, T, D, True)
+    dout = torch.randn(T, D, generator=g)
+    ref.backward(dout)
+    dtab = torch.zeros(V, D, device=DEV)
+    O.embed_bwd(dout.to(DEV), out, ids.to(DEV), mask.to(DEV), dtab, T, D, True)
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 1e-6 and rel_err(dtab, tr.grad) < 1e-5
+    # LSTM cell
+    Hh = 512
+    gates = torch.randn(4 * Hh, generator=g); c0 = torch.randn(Hh, generator=g)
+    gr = gates.clone().requires_grad_(True); cr = c0.clone().requires_grad_(True)
+    i, f, gg, o = torch.sigmoid(gr[:Hh]), torch.sigmoid(gr[Hh:2 * Hh]), torch.tanh(gr[2 * Hh:3 * Hh]), torch.sigmoid(gr[3 * Hh:])
+    c1 = f * cr + i * gg; h1 = o * torch.tanh(c1)
+    dh = torch.randn(Hh, generator=g); dc = torch.randn(Hh, generator=g)
+    (h1 * dh + c1 * dc).sum().backward()
+    c = torch.empty(Hh, device=DEV); h = torch.empty(Hh, device=DEV); act = torch.empty(4 * Hh, device=DEV)
+    O.lstm_cell_fwd(gates.to(DEV), c0.to(DEV), c, h, act, Hh)
+    dg = torch.empty(4 * Hh, device=DEV); dcp = torch.empty(Hh, device=DEV)
+    O.lstm_cell_bwd(dh.to(DEV), dc.to(DEV), act, c0.to(DEV), c, dg, dcp, Hh)
+    torch.cuda.synchronize()
+    assert rel_err(h, h1) < 1e-5 and rel_err(c, c1) < 1e-5 and rel_err(dg, gr.grad) < 1e-4 and rel_err(dcp, cr.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+def test_dynfilter(dt):
+    O = ops()
+    g = torch.Generator().manual_seed(10)
+    H, W, Cc = 13, 17, 256
+    x = F.relu(torch.randn(1, Cc, H, W, generator=g))
+    filt = torch.tanh(torch.randn(7, Cc, generator=g)); r = torch.tanh(torch.randn(7, generator=g))
+    xd = to_dev(nhwc(x), dt)
+    xr = xd.float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    fr = filt.clone().requires_grad_(True); rr = r.clone().requires_grad_(True)
+    masks = torch.from_numpy(ON.spatial_masks(H, W))
+    resp = [F.conv2d(xr * masks[k][None, None], fr[k].view(1, -1, 1, 1)) for k in range(7)]
+    response = F.conv2d(torch.cat(resp, 1), rr.view(1, 7, 1, 1))
+    yref = xr * response
+    y = O.empty((H * W, Cc), dt); rs_ = torch.empty(H * W, device=DEV); rk = torch.empty(H * W, 7, device=DEV)
+    O.dynfilter_fwd(xd, filt.to(DEV), r.to(DEV), y, rs_, rk, H, W, Cc)
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(1, H, W, Cc), nhwc(yref)) < (2e-5 if dt == 0 else 1e-2)
+    assert rel_err(rs_.view(H, W), response[0, 0]) < 1e-5
+    dy = to_dev(torch.randn(H * W, Cc, generator=g), dt)
+    yref.backward(dy.float().cpu().view(1, H, W, Cc).permute(0, 3, 1, 2))
+    dx = O.empty((H * W, Cc), dt); dfilt = torch.zeros(7, Cc, device=DEV); dr = torch.zeros(7, device=DEV); wsd = torch.empty(H * W, device=DEV)
+    O.dynfilter_bwd(dy, xd, filt.to(DEV), r.to(DEV), rs_, rk, dx, xd, dfilt, dr, wsd, H, W, Cc)
+    torch.cuda.synchronize()
+    tol = 1e-4 if dt == 0 else 2e-2
+    assert rel_err(dx.float().view(1, H, W, Cc), nhwc(xr.grad * (xr > 0))) < tol
+    assert rel_err(dfilt, fr.grad) < tol and rel_err(dr, rr.grad) < tol
+
+
+def test_captioner_pieces():
+    O = ops()
+    g = torch.Generator().manual_seed(12)
+    L, D = 196, 512
+    patt = torch.randn(L, D, generator=g); att = torch.randn(L, D, generator=g); ah = torch.randn(D, generator=g)
+    aw = torch.randn(D, generator=g) * 0.1; ab = torch.randn(1, generator=g)
+    pr, ar, hr, wr, br = [t.clone().requires_grad_(True) for t in (patt, att, ah, aw, ab)]
+    dot = torch.tanh(pr + hr) @ wr + br
+    wgt = F.softmax(dot, 0); res = wgt @ ar
+    dres = torch.randn(D, generator=g)
+    (res * dres).sum().backward()
+    tws = torch.empty(L, D, device=DEV); wd = torch.empty(L, device=DEV); rd = torch.empty(D, device=DEV)
+    O.cap_attention_fwd(patt.to(DEV), att.to(DEV), ah.to(DEV), aw.to(DEV), ab.to(DEV), L, D, tws, wd, rd)
+    dpatt = torch.zeros(L, D, device=DEV); datt = torch.zeros(L, D, device=DEV); dah = torch.empty(D, device=DEV)
+    daw = torch.zeros(D, device=DEV); dab = torch.zeros(1, device=DEV)
+    O.cap_attention_bwd(dres.to(DEV), att.to(DEV), tws, wd, aw.to(DEV), L, D, dpatt, datt, dah, daw, dab)
+    torch.cuda.synchronize()
+    assert rel_err(wd, wgt) < 1e-5 and rel_err(rd, res) < 1e-5
+    assert rel_err(dpatt, pr.grad) < 1e-4 and rel_err(datt, ar.grad) < 1e-4 and rel_err(dah, hr.grad) < 1e-4
+    assert rel_err(daw, wr.grad) < 1e-4 and abs(dab.item() - br.grad.item()) < 1e-5
+    # gates (maxout candidate, AttModel.py:449-462)
+    R = 512
+    s = torch.randn(5 * R, generator=g); a2c = torch.randn(2 * R, generator=g); c0 = torch.randn(R, generator=g)
+    sr, a2r, cr = [t.clone().requires_grad_(True) for t in (s, a2c, c0)]
+    sg = torch.sigmoid(sr[:3 * R]); it = sr[3 * R:] + a2r; it = torch.max(it[:R], it[R:])
+    c1 = sg[R:2 * R] * cr + sg[:R] * it; h1 = sg[2 * R:] * torch.tanh(c1)
+    dh = torch.randn(R, generator=g); dc = torch.randn(R, generator=g)
+    (h1 * dh + c1 * dc).sum().backward()
+    c = torch.empty(R, device=DEV); h = torch.empty(R, device=DEV); save = torch.empty(6 * R, device=DEV)
+    O.cap_gates_fwd(s.to(DEV), a2c.to(DEV), c0.to(DEV), c, h, save, R)
+    ds = torch.empty(5 * R, device=DEV); da = torch.empty(2 * R, device=DEV); dcp = torch.empty(R, device=DEV)
+    O.cap_gates_bwd(dh.to(DEV), dc.to(DEV), save, c0.to(DEV), ds, da, dcp, R)
+    torch.cuda.synchronize()
+    assert rel_err(h, h1) < 1e-5 and rel_err(c, c1) < 1e-5
+    assert rel_err(ds, sr.grad) < 1e-4 and rel_err(da, a2r.grad) < 1e-4 and rel_err(dcp, cr.grad) < 1e-4
+    # log-softmax + masked NLL
+    S, V1 = 7, 1200
+    lg = torch.randn(S, V1, generator=g) * 3; tgt = torch.randint(0, V1, (S,), generator=g); msk = torch.tensor([1, 1, 1, 1, 1, 0.0, 1])
+    lr_ = lg.clone().requires_grad_(True)
+    lp = F.log_softmax(lr_, 1)
+    lossr = (-lp.gather(1, tgt.view(-1, 1)).squeeze(1) * msk).sum() / msk.sum()
+    (lossr * 0.5).backward()
+    slot = torch.zeros(1, device=DEV); dl = torch.empty(S, V1, device=DEV); lpo = torch.empty(S, V1, device=DEV)
+    O.logsoftmax_nll(lg.to(DEV), tgt.to(DEV), msk.to(DEV), S, V1, 0.5, slot, dl, lpo)
+    torch.cuda.synchronize()
+    assert abs(slot.item() - lossr.item()) < 1e-5 and rel_err(dl, lr_.grad) < 1e-5 and rel_err(lpo, lp) < 1e-5
+
+
+def test_sgd_and_misc():
+    O = ops()
+    import ctypes as C
+    from lang2seg_amd._lib import SgdSeg
+    g = torch.Generator().manual_seed(13)
+    n1, rows, rl, n3 = 1000, 8, 96, 77
+    tot = n1 + rows * rl + n3
+    p = torch.randn(tot, generator=g); gr = torch.randn(tot, generator=g); m = torch.randn(tot, generator=g)
+    rowscale = torch.rand(rows, generator=g) + 0.5
+    segs = (SgdSeg * 3)()
+    segs[0].offset, segs[0].count, segs[0].row_len, segs[0].weight_decay, segs[0].rowscale_off, segs[0].lr_mult = 0, n1, 1, 1, -1, 1.0
+    segs[1].offset, segs[1].count, segs[1].row_len, segs[1].weight_decay, segs[1].rowscale_off, segs[1].lr_mult = n1, rows * rl, rl, 1, 0, 1.0
+    segs[2].offset, segs[2].count, segs[2].row_len, segs[2].weight_decay, segs[2].rowscale_off, segs[2].lr_mult = n1 + rows * rl, n3, 1, 0, -1, 2.0
+    sb = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(DEV)
+    pd, gd, md = p.to(DEV), gr.to(DEV), m.to(DEV)
+    O.sgd_momentum(pd, gd, md, sb, 3, rowscale.to(DEV), 0.01, 0.9, 1e-2)
+    ge = gr.clone(); ge[n1:n1 + rows * rl] = (ge[n1:n1 + rows * rl].view(rows, rl) * rowscale.view(-1, 1)).view(-1)
+    wd = torch.ones(tot) * 1e-2; wd[n1 + rows * rl:] = 0
+    lr = torch.ones(tot) * 0.01; lr[n1 + rows * rl:] = 0.02
+    mref = 0.9 * m + ge + wd * p; pref = p - lr * mref
+    torch.cuda.synchronize()
+    assert rel_err(md, mref) < 1e-6 and rel_err(pd, pref) < 1e-6
+    # dropout mask statistics + determinism, random keys
+    mk = torch.empty(100000, device=DEV); O.dropout_mask(mk, 0.5, 42)
+    mk2 = torch.empty(100000, device=DEV); O.dropout_mask(mk2, 0.5, 42)
+    torch.cuda.synchronize()
+    assert torch.equal(mk, mk2) and abs((mk > 0).float().mean().item() - 0.5) < 0.01 and set(mk.unique().tolist()) == {0.0, 2.0}
+    a = torch.randn(1000, generator=g); b = torch.randn(1000, generator=g); c = torch.randn(1000, generator=g)
+    out = torch.empty(1000, device=DEV); O.add3(a.to(DEV), b.to(DEV), c.to(DEV), out)
+    ob = torch.empty(1000, dtype=torch.bfloat16, device=DEV); O.cast(out, ob)
+    torch.cuda.synchronize()
+    assert rel_err(out, a + b + c) < 1e-6 and rel_err(ob.float(), (a + b + c)) < 1e-2
