@@ -78,6 +78,7 @@ int l2s_maxpool3x3s2(const void* x, void* y, int IH, int IW, int C, int OH, int 
 /* ---------------------------------------------------------------- pooling / elementwise ---- */
 int l2s_fill_f32(float* p, float v, long n, hipStream_t s);
 int l2s_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, hipStream_t s);
+int l2s_mul_f32(const float* a, const float* b, float* out, long n, hipStream_t s);
 /* dst(dtype) = a(dtype) + b(dtype) + c(float)   (any of b, c may be NULL) */
 int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s);
 /* spatial mean over hw pixels per image: y[n][c] = mean_p x[n][p][c]  (NET:278) and its backward */
@@ -213,7 +214,8 @@ int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* 
  * -1 = none) multiplies the gradient per output row (folded frozen-BN scale). */
 typedef struct { long offset; long count; int row_len; int weight_decay; long rowscale_off; float lr_mult; int pad; } l2s_sgd_seg;
 int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
-                     float lr, float momentum, float wd, float grad_scale, hipStream_t s);
+                     float lr, float momentum, float wd, float grad_scale, void* shadow /*optional: dtype copy of rowscale*param at the same offsets*/,
+                     int shadow_dtype, hipStream_t s);
 
 #ifdef __cplusplus
 }

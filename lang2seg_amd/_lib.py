@@ -86,7 +86,8 @@ SIGS = {
     'l2s_cap_gates_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_cap_gates_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_logsoftmax_nll': (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
-    'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp]),
+    'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp]),
+    'l2s_mul_f32': (i32, [vp, vp, vp, i64, vp]),
 }
 
 _lib = None

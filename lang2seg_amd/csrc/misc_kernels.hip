@@ -114,6 +114,9 @@ __global__ void fill_kernel(float* p, float v, long n) {
 __global__ void cast_kernel(const void* s, int sd, void* d, int dd, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) stx(d, i, dd, ldx(s, i, sd));
 }
+__global__ void mul_kernel(const float* a, const float* b, float* o, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
+}
 __global__ void add3_kernel(const void* a, const void* b, const float* c, void* d, long n, int dt) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float v = ldx(a, i, dt);
@@ -219,7 +222,7 @@ __global__ void keys_kernel(uint32_t* k, long n, uint64_t seed) {
 
 __global__ void sgd_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ mom,
                            const l2s_sgd_seg* __restrict__ segs, int nseg, const float* __restrict__ rowscale,
-                           float lr, float momentum, float wd, float gscale) {
+                           float lr, float momentum, float wd, float gscale, void* shadow, int sdt) {
   // blockIdx.y = segment; grid-stride over the segment's elements
   const l2s_sgd_seg sg = segs[blockIdx.y];
   const float lwd = sg.weight_decay ? wd : 0.f;
@@ -232,7 +235,9 @@ __global__ void sgd_kernel(float* __restrict__ param, const float* __restrict__ 
     g += lwd * w;
     const float m = momentum * mom[o] + g;
     mom[o] = m;
-    param[o] = w - llr * m;
+    const float wn = w - llr * m;
+    param[o] = wn;
+    if (shadow) stx(shadow, o, sdt, sg.rowscale_off >= 0 ? wn * rowscale[sg.rowscale_off + i / sg.row_len] : wn);
   }
 }
 
@@ -273,6 +278,10 @@ extern "C" int l2s_cast(const void* src, int sd, void* dst, int dd, long n, hipS
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, sd, dst, dd, n);
   return l2s_check_launch();
 }
+extern "C" int l2s_mul_f32(const float* a, const float* b, float* out, long n, hipStream_t s) {
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
+  return l2s_check_launch();
+}
 extern "C" int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s) {
   hipLaunchKernelGGL(add3_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, dst, n, dtype);
   return l2s_check_launch();
@@ -308,8 +317,8 @@ extern "C" int l2s_random_keys(uint32_t* keys, long n, uint64_t seed, hipStream_
   return l2s_check_launch();
 }
 extern "C" int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
-                                float lr, float momentum, float wd, float grad_scale, hipStream_t s) {
+                                float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, hipStream_t s) {
   if (nseg <= 0) return L2S_OK;
-  hipLaunchKernelGGL(sgd_kernel, dim3(64, nseg), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale);
+  hipLaunchKernelGGL(sgd_kernel, dim3(64, nseg), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype);
   return l2s_check_launch();
 }

@@ -270,6 +270,10 @@ def logsoftmax_nll(logits, target, mask, S, V1, gscale, loss_slot, dlogits, logp
          ptr(logprobs), stream())
 
 
-def sgd_momentum(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale=1.0):
+def sgd_momentum(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale=1.0, shadow=None):
     call('l2s_sgd_momentum', ptr(param), ptr(grad), ptr(mom), ptr(segs_dev), nseg, ptr(rowscale), float(lr), float(momentum),
-         float(wd), float(gscale), stream())
+         float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, stream())
+
+
+def mul(a, b, out):
+    call('l2s_mul_f32', ptr(a), ptr(b), ptr(out), a.numel(), stream())

@@ -591,13 +591,16 @@ def test_sgd_and_misc():
     segs[2].offset, segs[2].count, segs[2].row_len, segs[2].weight_decay, segs[2].rowscale_off, segs[2].lr_mult = n1 + rows * rl, n3, 1, 0, -1, 2.0
     sb = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(DEV)
     pd, gd, md = p.to(DEV), gr.to(DEV), m.to(DEV)
-    O.sgd_momentum(pd, gd, md, sb, 3, rowscale.to(DEV), 0.01, 0.9, 1e-2)
+    shadow = torch.empty(tot, dtype=torch.bfloat16, device=DEV)
+    O.sgd_momentum(pd, gd, md, sb, 3, rowscale.to(DEV), 0.01, 0.9, 1e-2, shadow=shadow)
     ge = gr.clone(); ge[n1:n1 + rows * rl] = (ge[n1:n1 + rows * rl].view(rows, rl) * rowscale.view(-1, 1)).view(-1)
     wd = torch.ones(tot) * 1e-2; wd[n1 + rows * rl:] = 0
     lr = torch.ones(tot) * 0.01; lr[n1 + rows * rl:] = 0.02
     mref = 0.9 * m + ge + wd * p; pref = p - lr * mref
     torch.cuda.synchronize()
     assert rel_err(md, mref) < 1e-6 and rel_err(pd, pref) < 1e-6
+    sref = pref.clone(); sref[n1:n1 + rows * rl] = (sref[n1:n1 + rows * rl].view(rows, rl) * rowscale.view(-1, 1)).view(-1)
+    assert rel_err(shadow.float(), sref) < 1e-2
     # dropout mask statistics + determinism, random keys
     mk = torch.empty(100000, device=DEV); O.dropout_mask(mk, 0.5, 42)
     mk2 = torch.empty(100000, device=DEV); O.dropout_mask(mk2, 0.5, 42)
