@@ -1,0 +1,281 @@
+"""Network — host-side mirror of the reference's model-graph layer
+(pyutils/mask-faster-rcnn/lib/nets/network_cycle_res5_2.py, "NET"): same public methods
+(`create_architecture`, `train_step`, `train_step_with_summary`, `get_summary`, `test_image`,
+`state_dict`/`load_state_dict`, `train`/`eval`/`cuda`), same losses tuple.  Every arithmetic op is a
+HIP kernel behind the C ABI (lang2seg_amd/ops.py); this file only sequences launches on one stream
+with an explicit, static activation plan (no autograd, no host round trips inside the step:
+NMS, target assignment and sampling stay on device, see csrc/roi.hip).
+
+Forward/backward structure follows NET:488-593 (_predict), NET:375-454 (_add_losses) and
+NET:702-719 (train_step); the manual backward is the adjoint of exactly those ops."""
+import numpy as np
+import torch
+
+from .. import ops as O
+from .._lib import F32, BF16, LOSS_CAP
+from ..model.config import cfg
+from .params import ParamStore
+from . import anchors as ANC
+
+
+class ConvOp(object):
+    """One convolution / linear layer on the MFMA implicit-GEMM kernels (forward, data-grad, weight-grad)."""
+
+    def __init__(self, net, wkey, Cin, Cout, k=1, stride=1, pad=0, bias_key=None, need_dgrad=True, group=None, Cout_pad=None):
+        self.net, self.wkey, self.Cin, self.Cout, self.k, self.stride, self.pad = net, wkey, Cin, Cout, k, stride, pad
+        self.bias_key, self.need_dgrad, self.group = bias_key, need_dgrad, group
+        self.Np = Cout if Cout_pad is None else Cout_pad      # padded output width (grouped heads)
+        P = net.P
+        taps = k * k
+        cnt = self.Np * taps * Cin
+        if group is not None:
+            self.trainable = True
+            self.w_master = P.gview(group[0], cnt)
+            self.w_grad = P.gview(group[0], cnt, P.grad)
+            self.wf = P.gview(group[0], cnt, P.shadow)
+            self.bias = P.gview(group[1], self.Np)
+            self.bias_grad = P.gview(group[1], self.Np, P.grad)
+            self.scale = None
+        else:
+            self.trainable = wkey in P.offsets
+            self.scale = P.bn_scale.get(wkey)
+            if self.trainable:
+                self.w_master = P.view(wkey); self.w_grad = P.view(wkey, P.grad); self.wf = P.view(wkey, P.shadow)
+            else:
+                self.w_master = P.frozen[wkey].view(-1)
+                self.w_grad = None
+                self.wf = O.empty((cnt,), net.dt)
+            if bias_key is not None:
+                self.bias = P.view(bias_key); self.bias_grad = P.view(bias_key, P.grad)
+            else:
+                self.bias = P.bn_bias.get(wkey); self.bias_grad = None
+        self.wb = O.empty((cnt,), net.dt) if (need_dgrad and self.trainable) else None
+        net.convs.append(self)
+
+    def refresh(self, full=False):
+        """(re)build the dtype copies the kernels read: forward [Cout][taps][Cin] (frozen layers only; trainable
+        ones are written by the SGD kernel) and the data-gradient layout [Cin][taps flipped][Cout]."""
+        taps = self.k * self.k
+        if not self.trainable and full:
+            O.weight_cast(self.w_master, self.scale, self.wf, self.Np, taps, self.Cin)
+        if self.wb is not None:
+            O.weight_transpose(self.w_master, self.scale, self.wb, self.Np, taps, self.Cin)
+
+    def out_hw(self, IH, IW):
+        return (IH + 2 * self.pad - self.k) // self.stride + 1, (IW + 2 * self.pad - self.k) // self.stride + 1
+
+    def fwd(self, x, n, IH, IW, y, add=None, relu=False, out_f32=False, tile=0):
+        OH, OW = self.out_hw(IH, IW)
+        O.conv_igemm(x, self.wf, y, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad,
+                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt)
+        return y
+
+    def dgrad(self, g, n, IH, IW, dx, add=None, ref=None):
+        """dx[n,IH,IW,Cin] = conv^T(g); epilogue: (+ add) then ReLU mask by ref > 0."""
+        OH, OW = self.out_hw(IH, IW)
+        if self.stride == 1:
+            O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, IH, IW, self.Cin, self.k, self.k, 1, self.k - 1 - self.pad,
+                         add=add, ref=ref, dt=self.net.dt)
+        else:
+            assert self.k == 1
+            O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, OH, OW, self.Cin, 1, 1, 1, 0, add=add, ref=ref,
+                         scatter=(IH, IW, self.stride), dt=self.net.dt)
+        return dx
+
+    def wgrad(self, g, x, n, IH, IW):
+        OH, OW = self.out_hw(IH, IW)
+        O.conv_wgrad(g, x, self.w_grad, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad)
+        if self.bias_grad is not None:
+            O.colsum(g, n * OH * OW, self.Np, self.Np, self.bias_grad)
+
+
+class Bottleneck(object):
+    """RES:78-114 (stride on the first 1x1)."""
+
+    def __init__(self, net, prefix, inplanes, planes, stride, has_down, need_dx=True):
+        self.net, self.prefix, self.stride, self.need_dx = net, prefix, stride, need_dx
+        self.inpl, self.planes = inplanes, planes
+        self.c1 = ConvOp(net, prefix + '.conv1.weight', inplanes, planes, 1, stride, 0, need_dgrad=need_dx)
+        self.c2 = ConvOp(net, prefix + '.conv2.weight', planes, planes, 3, 1, 1)
+        self.c3 = ConvOp(net, prefix + '.conv3.weight', planes, planes * 4, 1, 1, 0)
+        self.down = ConvOp(net, prefix + '.downsample.0.weight', inplanes, planes * 4, 1, stride, 0, need_dgrad=need_dx) if has_down else None
+
+    def fwd(self, x, n, IH, IW, tag):
+        net = self.net
+        OH, OW = self.c1.out_hw(IH, IW)
+        a1 = net.buf(tag + '.a1', (n * OH * OW, self.planes))
+        a2 = net.buf(tag + '.a2', (n * OH * OW, self.planes))
+        y = net.buf(tag + '.y', (n * OH * OW, self.planes * 4))
+        self.c1.fwd(x, n, IH, IW, a1, relu=True)
+        self.c2.fwd(a1, n, OH, OW, a2, relu=True)
+        if self.down is not None:
+            sc = net.buf(tag + '.sc', (n * OH * OW, self.planes * 4))
+            self.down.fwd(x, n, IH, IW, sc)
+            self.c3.fwd(a2, n, OH, OW, y, add=sc, relu=True)
+        else:
+            self.c3.fwd(a2, n, OH, OW, y, add=x, relu=True)
+        return y, OH, OW, (x, a1, a2, IH, IW, OH, OW, n)
+
+    def bwd(self, g, saved, tag, x_is_relu_out=True):
+        """g = dL/d(pre-ReLU sum) (already masked by y > 0).  Returns dL/dx masked by x > 0 when x is a ReLU output."""
+        net = self.net
+        x, a1, a2, IH, IW, OH, OW, n = saved
+        self.c3.wgrad(g, a2, n, OH, OW)
+        dz2 = net.buf(tag + '.dz2', (n * OH * OW, self.planes))
+        self.c3.dgrad(g, n, OH, OW, dz2, ref=a2)
+        self.c2.wgrad(dz2, a1, n, OH, OW)
+        dz1 = net.buf(tag + '.dz1', (n * OH * OW, self.planes))
+        self.c2.dgrad(dz2, n, OH, OW, dz1, ref=a1)
+        self.c1.wgrad(dz1, x, n, IH, IW)
+        if self.down is not None:
+            self.down.wgrad(g, x, n, IH, IW)
+        if not self.need_dx:
+            return None
+        dx = net.buf(tag + '.dx', (n * IH * IW, self.inpl))
+        ref = x if x_is_relu_out else None
+        if self.down is not None:
+            if self.stride != 1:
+                dx.zero_()                                    # scatter writes only the strided positions
+            self.c1.dgrad(dz1, n, IH, IW, dx)
+            self.down.dgrad(g, n, IH, IW, dx, add=dx, ref=ref)
+        else:
+            self.c1.dgrad(dz1, n, IH, IW, dx, add=g, ref=ref)
+        return dx
+
+
+class Network(object):
+    def __init__(self, batch_size=1):
+        self._feat_stride = [16, ]
+        self._batch_size = batch_size
+        self._predictions = {}
+        self._losses = {}
+        self._anchor_targets = {}
+        self._proposal_targets = {}
+        self._mode = 'TRAIN'
+        self.training = True
+        self.device = 'cuda'
+        self._bufs = {}
+        self.convs = []
+        self._step = 0
+        self.parity = None          # dict of injected sampling keys / dropout masks (tests); None = production RNG
+        self.dp = None              # data-parallel gradient reducer (lang2seg_amd/parallel.py)
+
+    # ------------------------------------------------------------------ construction
+    def create_architecture(self, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
+        assert tag is not None
+        self._tag = tag
+        self._num_classes = num_classes
+        self._anchor_scales, self._anchor_ratios = tuple(anchor_scales), tuple(anchor_ratios)
+        self._num_anchors = len(anchor_scales) * len(anchor_ratios)
+        self.dt = BF16 if cfg.COMPUTE_DTYPE == 'bf16' else F32
+        self._init_modules()
+
+    def buf(self, name, shape, dtype=None, zero=False):
+        """persistent activation plan: one device buffer per (site, shape), allocated on first use."""
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            td = O.TORCH_DT[self.dt] if dtype is None else dtype
+            t = torch.zeros(tuple(shape), dtype=td, device=self.device)
+            self._bufs[key] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def _init_modules(self):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ module-like API
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def cuda(self):
+        return self
+
+    def state_dict(self):
+        return self.P.state_dict()
+
+    def load_state_dict(self, sd, strict=False):
+        self.P.load_state_dict(sd, strict)
+        self.refresh_weights(full=True)
+
+    def named_parameters(self):
+        """(name, fp32 tensor in the REFERENCE layout) for every trainable tensor (TV:194-220 iterates these)."""
+        from .params import from_internal
+        for k in self.P.trainable:
+            yield k, from_internal(k, self.P.view(k), self.P.shapes[k])
+
+    def refresh_weights(self, full=False):
+        for c in self.convs:
+            c.refresh(full)
+
+    # ------------------------------------------------------------------ blobs
+    def upload_blob(self, blobs, idx):
+        """H2D of one (image, expression) pair (NET:628-648, 702-703).  Cached per blobs object so a blob that is
+        already resident is not re-sent for every sentence of the same image."""
+        cache = blobs.setdefault('_device', {}) if isinstance(blobs, dict) else {}
+        dev = self.device
+        if 'data' not in cache:
+            cache['data'] = torch.from_numpy(np.ascontiguousarray(blobs['data'], dtype=np.float32)).to(dev)
+        key = ('sent', idx)
+        if key not in cache:
+            labels = blobs['labels']
+            labels = labels.cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+            lab = labels[idx:idx + 1]
+            max_len = int((lab != 0).sum(1).max())                          # NET:629-630
+            lab = np.ascontiguousarray(lab[:, :max_len]).astype(np.int64)
+            cap = np.ascontiguousarray(blobs['cap_labels'][idx:idx + 1]).astype(np.int64)
+            # AttModel.py:75-93: steps i = 0.. until seq[:, i] == 0 for i >= 1
+            S = 1
+            while S < cap.shape[1] - 1 and cap[0, S] != 0:
+                S += 1
+            cm = np.ascontiguousarray(blobs['cap_masks'][idx:idx + 1]).astype(np.float32)
+            cache[key] = dict(
+                gt_boxes=torch.from_numpy(np.ascontiguousarray(blobs['gt_boxes'][idx:idx + 1], dtype=np.float32)).to(dev),
+                gt_masks=torch.from_numpy(np.ascontiguousarray(blobs['gt_masks'][idx:idx + 1], dtype=np.uint8)).to(dev),
+                labels=torch.from_numpy(lab[0]).to(dev), T=max_len, S=S,
+                cap_in=torch.from_numpy(cap[0, :S].copy()).to(dev), cap_tgt=torch.from_numpy(cap[0, 1:S + 1].copy()).to(dev),
+                cap_mask=torch.from_numpy(cm[0, 1:S + 1].copy()).to(dev))
+        d = dict(cache[key])
+        d['data'] = cache['data']
+        d['im_info'] = np.asarray(blobs['im_info'], dtype=np.float32).reshape(-1)[:3]
+        return d
+
+    # ------------------------------------------------------------------ train step (NET:702-719)
+    def train_step(self, blobs, idx, train_op):
+        dev = self.upload_blob(blobs, idx)
+        loss = self.forward_backward(dev)
+        if self.dp is not None:
+            self.dp.finish()
+        train_op.step()
+        vals = loss.cpu().numpy()          # the single host sync of the step (the reference does seven, NET:704-710)
+        self._step += 1
+        return tuple(float(vals[i]) for i in (0, 1, 2, 3, 4, 5, 6))
+
+    def train_step_async(self, blobs, idx, train_op):
+        """same as train_step without the loss read-back; returns the device loss[8] buffer."""
+        dev = self.upload_blob(blobs, idx)
+        loss = self.forward_backward(dev)
+        if self.dp is not None:
+            self.dp.finish()
+        train_op.step()
+        self._step += 1
+        return loss
+
+    def train_step_with_summary(self, blobs, idx, train_op):
+        r = self.train_step(blobs, idx, train_op)
+        names = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_caption', 'total_loss']
+        return r + ([(n, v) for n, v in zip(names, r)],)
+
+    def get_summary(self, blobs, idx):
+        was = self.training
+        self.eval()
+        dev = self.upload_blob(blobs, idx)
+        loss = self.forward_backward(dev, backward=False).cpu().numpy()
+        self.train(was)
+        names = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_caption', 'total_loss']
+        return [(n, float(loss[i])) for i, n in enumerate(names)]

@@ -1,0 +1,294 @@
+"""Parameter storage for the MI355X train step.
+
+All trainable tensors live in ONE flat fp32 device buffer (plus flat gradient and momentum
+buffers of the same layout) so that: the fused SGD kernel updates everything in one launch,
+the data-parallel all-reduce works on contiguous buckets, and a dtype "shadow" copy (bf16 or
+f32, frozen-BN scale folded in) is rewritten by the same SGD launch.  Key names and shapes of
+`state_dict()` are the reference's checkpoint format (RES:275-337, ENC:11-25,
+ATT:27-57,426-443); internally conv weights are stored [Cout][KH][KW][Cin] (NHWC kernels) and
+the 2x2 ConvTranspose as [Cin][dy][dx][Cout]."""
+import ctypes as C
+import numpy as np
+import torch
+
+from .. import ops as O
+from .._lib import SgdSeg
+
+RESNET_LAYERS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+BN_EPS = 1e-5
+
+
+def to_internal(name, t):
+    if t.dim() == 4 and name == 'mask_up_sampling.weight':
+        return t.permute(0, 2, 3, 1).contiguous()          # (Cin,Cout,2,2) -> [ci][dy][dx][co]
+    if t.dim() == 4:
+        return t.permute(0, 2, 3, 1).contiguous()          # OIHW -> OHWI
+    return t.contiguous()
+
+
+def from_internal(name, t, ref_shape):
+    if len(ref_shape) == 4 and name == 'mask_up_sampling.weight':
+        ci, co, kh, kw = ref_shape
+        return t.view(ci, kh, kw, co).permute(0, 3, 1, 2).contiguous()
+    if len(ref_shape) == 4:
+        o, i, kh, kw = ref_shape
+        return t.view(o, kh, kw, i).permute(0, 3, 1, 2).contiguous()
+    return t.view(ref_shape).contiguous()
+
+
+class ParamStore(object):
+    def __init__(self, opt, num_layers, num_classes, num_anchors, fixed_blocks, device, dt):
+        self.opt, self.device, self.dt = opt, device, dt
+        self.num_classes, self.A = num_classes, num_anchors
+        self.nblocks = RESNET_LAYERS[num_layers]
+        self.fixed_blocks = fixed_blocks
+        self.shapes = self._shapes()
+        self._layout()
+
+    # ---- registry ------------------------------------------------------
+    def _shapes(self):
+        o = self.opt; s = {}
+        V, E, WV, Hh = o['vocab_size'], o['word_embedding_size'], o['word_vec_size'], o['rnn_hidden_size']
+        s['rnn_encoder.embedding.weight'] = (V, E)
+        s['rnn_encoder.mlp.0.weight'] = (WV, E); s['rnn_encoder.mlp.0.bias'] = (WV,)
+        for sfx in ['', '_reverse']:
+            s['rnn_encoder.rnn.weight_ih_l0' + sfx] = (4 * Hh, WV)
+            s['rnn_encoder.rnn.weight_hh_l0' + sfx] = (4 * Hh, Hh)
+            s['rnn_encoder.rnn.bias_ih_l0' + sfx] = (4 * Hh,)
+            s['rnn_encoder.rnn.bias_hh_l0' + sfx] = (4 * Hh,)
+        R, IE, AH = o['rnn_size'], o['input_encoding_size'], o['att_hid_size']
+        s['caption_model.embed.0.weight'] = (V + 1, IE)
+        s['caption_model.att_embed.0.weight'] = (R, o['att_feat_size']); s['caption_model.att_embed.0.bias'] = (R,)
+        s['caption_model.logit.weight'] = (V + 1, R); s['caption_model.logit.bias'] = (V + 1,)
+        s['caption_model.ctx2att.weight'] = (AH, R); s['caption_model.ctx2att.bias'] = (AH,)
+        s['caption_model.core.a2c.weight'] = (2 * R, R); s['caption_model.core.a2c.bias'] = (2 * R,)
+        s['caption_model.core.i2h.weight'] = (5 * R, IE); s['caption_model.core.i2h.bias'] = (5 * R,)
+        s['caption_model.core.h2h.weight'] = (5 * R, R); s['caption_model.core.h2h.bias'] = (5 * R,)
+        s['caption_model.core.attention.h2att.weight'] = (AH, R); s['caption_model.core.attention.h2att.bias'] = (AH,)
+        s['caption_model.core.attention.alpha_net.weight'] = (1, AH); s['caption_model.core.attention.alpha_net.bias'] = (1,)
+
+        def bn(p, c):
+            for k in ['weight', 'bias', 'running_mean', 'running_var']:
+                s[p + '.' + k] = (c,)
+        s['resnet.conv1.weight'] = (64, 3, 7, 7); bn('resnet.bn1', 64)
+        inpl = 64
+        for li, (planes, nb) in enumerate(zip([64, 128, 256, 512], self.nblocks), 1):
+            for b in range(nb):
+                p = 'resnet.layer%d.%d' % (li, b)
+                s[p + '.conv1.weight'] = (planes, inpl, 1, 1); bn(p + '.bn1', planes)
+                s[p + '.conv2.weight'] = (planes, planes, 3, 3); bn(p + '.bn2', planes)
+                s[p + '.conv3.weight'] = (planes * 4, planes, 1, 1); bn(p + '.bn3', planes * 4)
+                if b == 0:
+                    s[p + '.downsample.0.weight'] = (planes * 4, inpl, 1, 1); bn(p + '.downsample.1', planes * 4)
+                inpl = planes * 4
+        s['resnet.fc.weight'] = (1000, 2048); s['resnet.fc.bias'] = (1000,)     # present in the module, never used (RES:133)
+        C4 = o['C4_feat_dim']; HD = o['rnn_num_layers'] * (2 if o['bidirectional'] else 1) * Hh
+        for k in range(7):
+            s['dynamic_fc_%d.weight' % k] = (C4, HD); s['dynamic_fc_%d.bias' % k] = (C4,)
+        s['response_fc.weight'] = (7, HD); s['response_fc.bias'] = (7,)
+        A, nc = self.A, self.num_classes
+        s['rpn_net.weight'] = (512, C4, 3, 3); s['rpn_net.bias'] = (512,)
+        s['rpn_cls_score_net.weight'] = (2 * A, 512, 1, 1); s['rpn_cls_score_net.bias'] = (2 * A,)
+        s['rpn_bbox_pred_net.weight'] = (4 * A, 512, 1, 1); s['rpn_bbox_pred_net.bias'] = (4 * A,)
+        s['cls_score_net.weight'] = (nc, 2048); s['cls_score_net.bias'] = (nc,)
+        s['bbox_pred_net.weight'] = (4 * nc, 2048); s['bbox_pred_net.bias'] = (4 * nc,)
+        s['mask_up_sampling.weight'] = (2048, 256, 2, 2); s['mask_up_sampling.bias'] = (256,)
+        s['mask_pred_net.weight'] = (nc, 256, 1, 1); s['mask_pred_net.bias'] = (nc,)
+        return s
+
+    def is_trainable(self, k):
+        """RES:290-306: conv1/bn1, layer1..FIXED_BLOCKS and every BN tensor are frozen; resnet.fc never gets a gradient."""
+        if k.startswith('resnet.'):
+            if '.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1') or k.startswith('resnet.conv1') or k.startswith('resnet.fc'):
+                return False
+            for fb in range(1, self.fixed_blocks + 1):
+                if k.startswith('resnet.layer%d.' % fb):
+                    return False
+        return True
+
+    @staticmethod
+    def bn_of(k):
+        """BN module whose frozen scale folds into conv weight `k` (None if none)."""
+        if not k.startswith('resnet.') or not k.endswith('.weight'):
+            return None
+        if k == 'resnet.conv1.weight':
+            return 'resnet.bn1'
+        if '.conv' in k:
+            return k.replace('.conv', '.bn')[:-len('.weight')]
+        if 'downsample.0' in k:
+            return k.replace('downsample.0', 'downsample.1')[:-len('.weight')]
+        return None
+
+    def _layout(self):
+        """Flat order = reverse execution order (gradients become final in this order during backward, so
+        contiguous buckets can be all-reduced while earlier layers are still back-propagating)."""
+        names = list(self.shapes.keys())
+        tr = [k for k in names if self.is_trainable(k)]
+        order = []
+        def take(pred):
+            sel = [k for k in tr if pred(k) and k not in order]
+            order.extend(sel)
+        take(lambda k: k.startswith('caption_model.'))
+        for b in reversed(range(self.nblocks[3])):
+            take(lambda k: k.startswith('resnet.layer4.%d.' % b))
+        # grouped heads (contiguous on purpose: they are used as one concatenated GEMM operand)
+        self.groups = {
+            'rcnn_w': ['cls_score_net.weight', 'bbox_pred_net.weight'], 'rcnn_b': ['cls_score_net.bias', 'bbox_pred_net.bias'],
+            'rpn_head_w': ['rpn_cls_score_net.weight', 'rpn_bbox_pred_net.weight'],
+            'rpn_head_b': ['rpn_cls_score_net.bias', 'rpn_bbox_pred_net.bias'],
+            'dyn_w': ['dynamic_fc_%d.weight' % k for k in range(7)] + ['response_fc.weight'],
+            'dyn_b': ['dynamic_fc_%d.bias' % k for k in range(7)] + ['response_fc.bias'],
+        }
+        plan = ['@rcnn_w', '@rcnn_b', 'mask_up_sampling.weight', 'mask_up_sampling.bias', 'mask_pred_net.weight', 'mask_pred_net.bias',
+                'rpn_net.weight', 'rpn_net.bias', '@rpn_head_w', '@rpn_head_b', '@dyn_w', '@dyn_b']
+        self.offsets, self.group_off = {}, {}
+        off = 0
+        def place(k, align=True):
+            nonlocal off
+            if align:
+                off = (off + 63) // 64 * 64      # 256-byte aligned tensors (16-byte vector loads in every dtype)
+            self.offsets[k] = off
+            off += int(np.prod(self.shapes[k]))
+        for k in list(order):
+            place(k)
+        nc = self.num_classes
+        self.rcnn_n = 5 * nc; self.rcnn_npad = (5 * nc + 7) // 8 * 8
+        self.rpn_n = 6 * self.A; self.rpn_npad = (6 * self.A + 7) // 8 * 8
+        for item in plan:
+            if item.startswith('@'):
+                g = item[1:]
+                off = (off + 63) // 64 * 64
+                self.group_off[g] = off
+                for k in self.groups[g]:
+                    place(k, align=False)        # members of a group are back to back
+                if g == 'rcnn_w':
+                    off += (self.rcnn_npad - self.rcnn_n) * 2048
+                elif g == 'rcnn_b':
+                    off += self.rcnn_npad - self.rcnn_n
+                elif g == 'rpn_head_w':
+                    off += (self.rpn_npad - self.rpn_n) * 512
+                elif g == 'rpn_head_b':
+                    off += self.rpn_npad - self.rpn_n
+            else:
+                off = (off + 63) // 64 * 64
+                place(item)
+            order.append(item)
+        rest_pred = [lambda k: k.startswith('rnn_encoder.')]
+        for p in rest_pred:
+            for k in [k for k in tr if p(k) and k not in self.offsets]:
+                off = (off + 63) // 64 * 64
+                place(k)
+        for li in (3, 2, 1):
+            for b in reversed(range(self.nblocks[li - 1])):
+                for k in [k for k in tr if k.startswith('resnet.layer%d.%d.' % (li, b)) and k not in self.offsets]:
+                    off = (off + 63) // 64 * 64
+                    place(k)
+        missing = [k for k in tr if k not in self.offsets]
+        assert not missing, missing
+        self.total = (off + 63) // 64 * 64
+        self.trainable = sorted(self.offsets.keys(), key=lambda k: self.offsets[k])
+        dev = self.device
+        self.param = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.mom = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(self.total, dtype=O.TORCH_DT[self.dt], device=dev)
+        self.frozen = {k: torch.zeros(self.shapes[k], dtype=torch.float32, device=dev) for k in self.shapes if k not in self.offsets}
+        # frozen-BN folded scale / bias per conv (RES:301-306,363-368: BN always in eval mode)
+        self.bn_scale, self.bn_bias = {}, {}
+        for k in self.shapes:
+            if self.bn_of(k) is not None:        # allocated once: kernels keep raw pointers to these
+                self.bn_scale[k] = torch.ones(self.shapes[k][0], dtype=torch.float32, device=dev)
+                self.bn_bias[k] = torch.zeros(self.shapes[k][0], dtype=torch.float32, device=dev)
+        # per-row gradient/shadow scale table for the SGD kernel
+        rs_list, self.rowscale_off = [], {}
+        n = 0
+        for k in self.trainable:
+            bn = self.bn_of(k)
+            if bn is not None:
+                self.rowscale_off[k] = n
+                n += self.shapes[k][0]
+        self.rowscale = torch.ones(max(n, 1), dtype=torch.float32, device=dev)
+
+    # ---- views ------------------------------------------------------------
+    def view(self, k, buf=None):
+        buf = self.param if buf is None else buf
+        o = self.offsets[k]
+        return buf[o:o + int(np.prod(self.shapes[k]))]
+
+    def gview(self, g, count, buf=None):
+        buf = self.param if buf is None else buf
+        o = self.group_off[g]
+        return buf[o:o + count]
+
+    # ---- (de)serialisation --------------------------------------------------
+    def load_state_dict(self, sd, strict=False):
+        """name+shape matched copy (TV:262-281 semantics live in the solver); tolerates missing
+        num_batches_tracked and torch-0.3 checkpoints."""
+        for k, shp in self.shapes.items():
+            if k not in sd:
+                if strict:
+                    raise KeyError(k)
+                continue
+            t = sd[k]
+            t = torch.from_numpy(np.ascontiguousarray(t)) if isinstance(t, np.ndarray) else t.detach().cpu()
+            t = t.float()
+            assert tuple(t.shape) == tuple(shp), (k, tuple(t.shape), shp)
+            ti = to_internal(k, t).reshape(-1).to(self.device)
+            if k in self.offsets:
+                self.view(k).copy_(ti)
+            else:
+                self.frozen[k].copy_(ti.view(self.frozen[k].shape) if k != 'resnet.conv1.weight' else ti.view(64, 7, 7, 3).reshape(self.frozen[k].shape))
+        self._fold_bn()
+        self.refresh_shadow_full()
+
+    def state_dict(self):
+        out = {}
+        for k, shp in self.shapes.items():
+            if k in self.offsets:
+                out[k] = from_internal(k, self.view(k).detach().clone(), shp).cpu()
+            else:
+                t = self.frozen[k].detach().clone()
+                if k == 'resnet.conv1.weight':
+                    t = t.view(64, 7, 7, 3).permute(0, 3, 1, 2).contiguous()
+                out[k] = t.cpu()
+        return out
+
+    def _fold_bn(self):
+        for k in self.shapes:
+            bn = self.bn_of(k)
+            if bn is None:
+                continue
+            g, b = self.frozen[bn + '.weight'], self.frozen[bn + '.bias']
+            m, v = self.frozen[bn + '.running_mean'], self.frozen[bn + '.running_var']
+            s = g / torch.sqrt(v + BN_EPS)
+            self.bn_scale[k].copy_(s)
+            self.bn_bias[k].copy_(b - m * s)
+            if k in self.rowscale_off:
+                o = self.rowscale_off[k]
+                self.rowscale[o:o + s.numel()].copy_(s)
+
+    # ---- SGD segment table (TV:194-220) ------------------------------------
+    def build_segments(self, double_bias=False, bias_decay=False):
+        segs = []
+        for k in self.trainable:
+            cnt = int(np.prod(self.shapes[k]))
+            is_bias = 'bias' in k
+            sg = SgdSeg()
+            sg.offset, sg.count = self.offsets[k], cnt
+            sg.row_len = cnt // self.shapes[k][0] if k in self.rowscale_off else 1
+            sg.weight_decay = 1 if (not is_bias or bias_decay) else 0
+            sg.rowscale_off = self.rowscale_off.get(k, -1)
+            sg.lr_mult = 2.0 if (is_bias and double_bias) else 1.0
+            segs.append(sg)
+        arr = (SgdSeg * len(segs))(*segs)
+        self.nseg = len(segs)
+        self.segs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        return self.nseg
+
+    def refresh_shadow_full(self):
+        """shadow = dtype(rowscale * param) for every trainable tensor (the SGD kernel keeps it current afterwards)."""
+        if not hasattr(self, 'segs_dev'):
+            self.build_segments()
+        zero = torch.zeros_like(self.grad)
+        # lr = 0, momentum = 1 (keeps the momentum buffer), wd = 0: a pure shadow rewrite through the same kernel
+        O.sgd_momentum(self.param, zero, self.mom, self.segs_dev, self.nseg, self.rowscale, 0.0, 1.0, 0.0, 0.0, shadow=self.shadow)

@@ -1,0 +1,471 @@
+"""resnetv1 — the ResNet-101 C4 lang2seg network with 7 spatial dynamic filters and the att2in2
+caption-cycle loss, i.e. the reference's nets/resnet_v1_cycle_res5_2.py ("RES") +
+nets/network_cycle_res5_2.py ("NET"), on the MI355X kernels.  Constructor, `create_architecture`,
+`train_step` and the state-dict key names are the reference's.
+
+Citations: ENC = lib/layers/lang_encoder.py, ATT = lib/caption_models/AttModel.py,
+CRIT = lib/misc/utils.py, PL/ATL/PTL = layer_utils/{proposal,anchor_target,proposal_target}_layer.py."""
+import numpy as np
+import torch
+
+from .. import ops as O
+from .._lib import F32, BF16
+from ..model.config import cfg
+from .network import Network, ConvOp, Bottleneck
+from .params import ParamStore
+from . import anchors as ANC
+
+f32 = torch.float32
+
+
+class resnetv1(Network):
+    def __init__(self, opt, batch_size=1, num_layers=50):
+        Network.__init__(self, batch_size=batch_size)
+        self._num_layers = num_layers
+        self.opt = dict(opt)
+        assert self.opt.get('rnn_type', 'lstm') == 'lstm' and self.opt.get('rnn_num_layers', 1) == 1 and self.opt.get('bidirectional', 1) > 0
+        assert self.opt.get('caption_model', 'att2in2') == 'att2in2', 'only the att2in2 captioner is on the hot path'
+        self._cap_loss_weight = float(self.opt['cap_loss_weight'])          # RES:253
+        self._C4_feat_dim = self.opt['C4_feat_dim']
+
+    # ------------------------------------------------------------------ RES:275-337
+    def _init_modules(self):
+        assert self._num_layers in (50, 101, 152)
+        assert 0 <= cfg.RESNET.FIXED_BLOCKS < 4
+        fb = cfg.RESNET.FIXED_BLOCKS
+        self.P = ParamStore(self.opt, self._num_layers, self._num_classes, self._num_anchors, fb, self.device, self.dt)
+        P = self.P
+        nb = P.nblocks
+        self.layers = {}
+        inpl = 64
+        for li, planes, stride in [(1, 64, 1), (2, 128, 2), (3, 256, 2), (4, 512, 1)]:
+            blocks = []
+            for b in range(nb[li - 1]):
+                need_dx = li > fb and not (li == fb + 1 and b == 0)          # nothing trainable below the first trainable block
+                blocks.append(Bottleneck(self, 'resnet.layer%d.%d' % (li, b), inpl, planes, stride if b == 0 else 1, b == 0, need_dx))
+                inpl = planes * 4
+            self.layers[li] = blocks
+        C4 = self._C4_feat_dim
+        A, nc = self._num_anchors, self._num_classes
+        self.rpn_conv = ConvOp(self, 'rpn_net.weight', C4, 512, 3, 1, 1, bias_key='rpn_net.bias')
+        self.rpn_heads = ConvOp(self, None, 512, 6 * A, group=('rpn_head_w', 'rpn_head_b'), Cout_pad=P.rpn_npad)
+        self.rcnn_heads = ConvOp(self, None, 2048, 5 * nc, group=('rcnn_w', 'rcnn_b'), Cout_pad=P.rcnn_npad)
+        self.mask_pred = ConvOp(self, 'mask_pred_net.weight', 256, nc, bias_key='mask_pred_net.bias', need_dgrad=False)
+        self.att_embed = ConvOp(self, 'caption_model.att_embed.0.weight', self.opt['att_feat_size'], self.opt['rnn_size'],
+                                bias_key='caption_model.att_embed.0.bias')
+        self.up_wT = O.empty((4 * 256 * 2048,), self.dt)     # ConvTranspose forward operand [(dy,dx,co)][ci]
+        self.base_anchors = torch.from_numpy(ANC.base_anchors(self._anchor_scales, self._anchor_ratios)).to(self.device)
+        self.init_weights()
+        P.build_segments(double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
+        self.load_state_dict(self._initial_state, strict=False)
+        del self._initial_state
+
+    def init_weights(self):
+        """NET:333-355 / RES:135-141 initialisers (host RNG, once, before the first load)."""
+        g = torch.Generator().manual_seed(cfg.RNG_SEED)
+        sd = {}
+        for k, shp in self.P.shapes.items():
+            n = int(np.prod(shp))
+            if k.endswith('running_var') or (('.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1')) and k.endswith('weight')):
+                t = torch.ones(n)
+            elif k.endswith('running_mean') or '.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1'):
+                t = torch.zeros(n)
+            elif k.startswith('resnet.') and len(shp) == 4:
+                t = torch.randn(n, generator=g) * float(np.sqrt(2.0 / (shp[2] * shp[3] * shp[0])))
+            elif k.startswith(('rpn_', 'cls_score', 'mask_')) and k.endswith('weight'):
+                t = torch.randn(n, generator=g) * 0.01
+            elif k.startswith('bbox_pred_net') and k.endswith('weight'):
+                t = torch.randn(n, generator=g) * 0.001
+            elif k.startswith(('rpn_', 'cls_score', 'mask_', 'bbox_pred')) and k.endswith('bias'):
+                t = torch.zeros(n)
+            elif 'embedding.weight' in k or 'embed.0.weight' in k:
+                t = torch.randn(n, generator=g)
+            else:
+                kk = 1.0 / float(np.sqrt(shp[-1] if len(shp) > 1 else 512))
+                t = (torch.rand(n, generator=g) * 2 - 1) * kk
+            sd[k] = t.view(shp)
+        self._initial_state = sd
+
+    def refresh_weights(self, full=False):
+        Network.refresh_weights(self, full)
+        # 2x2 deconv: forward operand = transpose of the master [ci][(dy,dx,co)]
+        O.weight_transpose(self.P.view('mask_up_sampling.weight'), None, self.up_wT, 2048, 1, 4 * 256)
+
+    # ------------------------------------------------------------------ helpers
+    def _drop(self, name, shape, p):
+        """dropout mask (scaled) or None.  Production: counter-hash RNG on device; parity: injected masks."""
+        if not self.training or p <= 0.0:
+            return None
+        if self.parity is not None:
+            m = (self.parity.get('drops') or {}).get(name)
+            return m
+        m = self.buf('drop.' + name, shape, f32)
+        O.dropout_mask(m, p, (self._step * 16 + hash(name) % 16) * 2654435761 % (1 << 62) + 12345)
+        return m
+
+    def _keys(self, name, n):
+        if self.parity is not None and self.parity.get(name) is not None:
+            return self.parity[name]
+        k = self.buf('keys.' + name, (n,), torch.int32)
+        O.random_keys(k, (self._step * 8 + hash(name) % 8) * 0x9E3779B1 % (1 << 62) + 777 + getattr(self, 'rank_seed', 0))
+        return k
+
+    # ------------------------------------------------------------------ language encoder (ENC:27-82)
+    def _encoder_fwd(self, d):
+        P, T = self.P, d['T']
+        Hh, E = self.opt['rnn_hidden_size'], self.opt['word_embedding_size']
+        t = self.t
+        emb = self.buf('enc.emb', (T, E), f32)
+        t['enc.drop'] = self._drop('word', (T, E), self.opt['word_drop_out'])
+        O.embed_fwd(P.view('rnn_encoder.embedding.weight'), d['labels'], t['enc.drop'], emb, T, E, False)
+        x = self.buf('enc.x', (T, Hh), f32)
+        O.linear_fwd(emb, P.view('rnn_encoder.mlp.0.weight'), P.view('rnn_encoder.mlp.0.bias'), x, T, Hh, E, act=1)
+        hidden = self.buf('enc.hidden', (2 * Hh,), f32)
+        zero = self.buf('enc.zero', (Hh,), f32)
+        for di, sfx in enumerate(['', '_reverse']):
+            g = self.buf('enc.gates' + sfx, (T, 4 * Hh), f32)
+            O.linear_fwd(x, P.view('rnn_encoder.rnn.weight_ih_l0' + sfx), P.view('rnn_encoder.rnn.bias_ih_l0' + sfx), g, T, 4 * Hh, Hh)
+            hs = self.buf('enc.h' + sfx, (T, Hh), f32); cs = self.buf('enc.c' + sfx, (T, Hh), f32)
+            act = self.buf('enc.act' + sfx, (T, 4 * Hh), f32)
+            order = list(range(T)) if di == 0 else list(range(T - 1, -1, -1))
+            hp, cp = zero, zero
+            for si, tt in enumerate(order):
+                O.linear_fwd(hp, P.view('rnn_encoder.rnn.weight_hh_l0' + sfx), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx), g[tt], 1, 4 * Hh, Hh,
+                             accumulate=True)
+                hout = hidden[di * Hh:(di + 1) * Hh] if si == T - 1 else hs[tt]
+                O.lstm_cell_fwd(g[tt], cp, cs[tt], hout, act[tt], Hh)
+                if si == T - 1:
+                    hs[tt].copy_(hout)
+                hp, cp = hs[tt], cs[tt]
+            t['enc.order' + sfx] = order
+        t['enc.emb'], t['enc.x'], t['hidden'] = emb, x, hidden
+        return hidden
+
+    def _encoder_bwd(self, d, dhidden):
+        P, T, t = self.P, d['T'], self.t
+        Hh, E = self.opt['rnn_hidden_size'], self.opt['word_embedding_size']
+        zero = self.buf('enc.zero', (Hh,), f32)
+        dx = self.buf('enc.dx', (T, Hh), f32, zero=True)
+        for di, sfx in enumerate(['', '_reverse']):
+            order = t['enc.order' + sfx]
+            hs = self.buf('enc.h' + sfx, (T, Hh), f32); cs = self.buf('enc.c' + sfx, (T, Hh), f32)
+            act = self.buf('enc.act' + sfx, (T, 4 * Hh), f32)
+            dg = self.buf('enc.dg' + sfx, (T, 4 * Hh), f32)
+            hprev = self.buf('enc.hprev' + sfx, (T, Hh), f32)
+            dh = self.buf('enc.dh' + sfx, (2, Hh), f32); dc = self.buf('enc.dc' + sfx, (2, Hh), f32, zero=True)
+            dh[0].copy_(dhidden[di * Hh:(di + 1) * Hh])
+            cur = 0
+            whh = P.view('rnn_encoder.rnn.weight_hh_l0' + sfx)
+            for si in range(T - 1, -1, -1):
+                tt = order[si]
+                cprev = cs[order[si - 1]] if si > 0 else zero
+                hprev[tt].copy_(hs[order[si - 1]] if si > 0 else zero)
+                O.lstm_cell_bwd(dh[cur], dc[cur], act[tt], cprev, cs[tt], dg[tt], dc[1 - cur], Hh)
+                O.linear_bwd_x(dg[tt], whh, dh[1 - cur], 1, 4 * Hh, Hh)
+                cur = 1 - cur
+            O.linear_bwd_w(dg, hprev, P.view('rnn_encoder.rnn.weight_hh_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx, P.grad), T, 4 * Hh, Hh)
+            O.linear_bwd_w(dg, t['enc.x'], P.view('rnn_encoder.rnn.weight_ih_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_ih_l0' + sfx, P.grad), T, 4 * Hh, Hh)
+            O.linear_bwd_x(dg, P.view('rnn_encoder.rnn.weight_ih_l0' + sfx), dx, T, 4 * Hh, Hh, accumulate=True)
+        O.act_bwd(dx, t['enc.x'], 1)
+        O.linear_bwd_w(dx, t['enc.emb'], P.view('rnn_encoder.mlp.0.weight', P.grad), P.view('rnn_encoder.mlp.0.bias', P.grad), T, Hh, E)
+        demb = self.buf('enc.demb', (T, E), f32)
+        O.linear_bwd_x(dx, P.view('rnn_encoder.mlp.0.weight'), demb, T, Hh, E)
+        O.embed_bwd(demb, t['enc.emb'], d['labels'], t['enc.drop'], P.view('rnn_encoder.embedding.weight', P.grad), T, E, False)
+
+    # ------------------------------------------------------------------ att2in2 captioner (ATT:60-101,406-466; CRIT:43-53)
+    def _caption_fwd(self, d, att_feats, loss):
+        P, t, S = self.P, self.t, d['S']
+        R, IE, AH, L = self.opt['rnn_size'], self.opt['input_encoding_size'], self.opt['att_hid_size'], 196
+        V1 = self.opt['vocab_size'] + 1
+        pv = lambda k: P.view('caption_model.' + k)
+        a = self.buf('cap.a', (L, R), f32)
+        self.att_embed.fwd(att_feats, L, 1, 1, a, relu=True, out_f32=True)
+        t['cap.a_pre'] = a
+        dm = self._drop('att', (L, R), self.opt['drop_prob_lm'])
+        t['cap.drop_att'] = dm
+        if dm is not None:
+            ad = self.buf('cap.ad', (L, R), f32); O.mul(a, dm, ad)
+        else:
+            ad = a
+        patt = self.buf('cap.patt', (L, AH), f32)
+        O.linear_fwd(ad, pv('ctx2att.weight'), pv('ctx2att.bias'), patt, L, AH, R)
+        xt = self.buf('cap.xt', (S, IE), f32)
+        t['cap.drop_xt'] = self._drop('xt', (S, IE), self.opt['drop_prob_lm'])
+        O.embed_fwd(pv('embed.0.weight'), d['cap_in'], t['cap.drop_xt'], xt, S, IE, True)
+        sums = self.buf('cap.sums', (S, 5 * R), f32)
+        O.linear_fwd(xt, pv('core.i2h.weight'), pv('core.i2h.bias'), sums, S, 5 * R, IE)
+        hs = self.buf('cap.h', (S, R), f32); cs = self.buf('cap.c', (S, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
+        att_h = self.buf('cap.att_h', (S, AH), f32); tanh_ws = self.buf('cap.tanh', (S, L, AH), f32)
+        wgt = self.buf('cap.wgt', (S, L), f32); ares = self.buf('cap.ares', (S, R), f32); a2c = self.buf('cap.a2c', (S, 2 * R), f32)
+        zero = self.buf('cap.zero', (R,), f32)
+        hp, cp = zero, zero
+        for i in range(S):
+            O.linear_fwd(hp, pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), att_h[i], 1, AH, R)
+            O.cap_attention_fwd(patt, ad, att_h[i], pv('core.attention.alpha_net.weight'), pv('core.attention.alpha_net.bias'), L, AH,
+                                tanh_ws[i], wgt[i], ares[i])
+            O.linear_fwd(hp, pv('core.h2h.weight'), pv('core.h2h.bias'), sums[i], 1, 5 * R, R, accumulate=True)
+            O.linear_fwd(ares[i], pv('core.a2c.weight'), pv('core.a2c.bias'), a2c[i], 1, 2 * R, R)
+            O.cap_gates_fwd(sums[i], a2c[i], cp, cs[i], hs[i], save[i], R)
+            hp, cp = hs[i], cs[i]
+        t['cap.drop_out'] = self._drop('out', (S, R), self.opt['drop_prob_lm'])
+        if t['cap.drop_out'] is not None:
+            ho = self.buf('cap.ho', (S, R), f32); O.mul(hs, t['cap.drop_out'], ho)
+        else:
+            ho = hs
+        logits = self.buf('cap.logits', (S, V1), f32)
+        O.linear_fwd(ho, pv('logit.weight'), pv('logit.bias'), logits, S, V1, R)
+        dlogits = self.buf('cap.dlogits', (S, V1), f32)
+        lp = self.buf('cap.logp', (S, V1), f32) if self.keep_logprobs else None
+        O.logsoftmax_nll(logits, d['cap_tgt'], d['cap_mask'], S, V1, self._cap_loss_weight, loss[5:6], dlogits, lp)
+        t.update({'cap.ad': ad, 'cap.patt': patt, 'cap.xt': xt, 'cap.ho': ho, 'cap.dlogits': dlogits, 'cap.logp': lp})
+
+    def _caption_bwd(self, d, att_feats):
+        """returns d(att_feats) in the activation dtype [196][att_feat_size]."""
+        P, t, S = self.P, self.t, d['S']
+        R, IE, AH, L = self.opt['rnn_size'], self.opt['input_encoding_size'], self.opt['att_hid_size'], 196
+        V1 = self.opt['vocab_size'] + 1
+        pv = lambda k: P.view('caption_model.' + k)
+        gv = lambda k: P.view('caption_model.' + k, P.grad)
+        hs = self.buf('cap.h', (S, R), f32); cs = self.buf('cap.c', (S, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
+        tanh_ws = self.buf('cap.tanh', (S, L, AH), f32); wgt = self.buf('cap.wgt', (S, L), f32)
+        ares = self.buf('cap.ares', (S, R), f32)
+        zero = self.buf('cap.zero', (R,), f32)
+        dlogits, ad = t['cap.dlogits'], t['cap.ad']
+        O.linear_bwd_w(dlogits, t['cap.ho'], gv('logit.weight'), gv('logit.bias'), S, V1, R)
+        dho = self.buf('cap.dho', (S, R), f32)
+        O.linear_bwd_x(dlogits, pv('logit.weight'), dho, S, V1, R)
+        if t['cap.drop_out'] is not None:
+            O.mul(dho, t['cap.drop_out'], dho)
+        dsums = self.buf('cap.dsums', (S, 5 * R), f32); da2c = self.buf('cap.da2c', (S, 2 * R), f32)
+        datt_h = self.buf('cap.datt_h', (S, AH), f32); dares = self.buf('cap.dares', (R,), f32)
+        dpatt = self.buf('cap.dpatt', (L, AH), f32, zero=True); dad = self.buf('cap.dad', (L, R), f32, zero=True)
+        hprev = self.buf('cap.hprev', (S, R), f32)
+        dh = self.buf('cap.dh', (2, R), f32, zero=True); dc = self.buf('cap.dc', (2, R), f32, zero=True)
+        cur = 0
+        for i in range(S - 1, -1, -1):
+            # dh[cur] holds the recurrent part; add this step's output gradient
+            O.add3(dh[cur], dho[i], None, dh[cur])
+            cprev = cs[i - 1] if i > 0 else zero
+            hprev[i].copy_(hs[i - 1] if i > 0 else zero)
+            O.cap_gates_bwd(dh[cur], dc[cur], save[i], cprev, dsums[i], da2c[i], dc[1 - cur], R)
+            O.linear_bwd_x(da2c[i], pv('core.a2c.weight'), dares, 1, 2 * R, R)
+            O.cap_attention_bwd(dares, ad, tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, dpatt, dad, datt_h[i],
+                                gv('core.attention.alpha_net.weight'), gv('core.attention.alpha_net.bias'))
+            O.linear_bwd_x(dsums[i], pv('core.h2h.weight'), dh[1 - cur], 1, 5 * R, R)
+            O.linear_bwd_x(datt_h[i], pv('core.attention.h2att.weight'), dh[1 - cur], 1, AH, R, accumulate=True)
+            cur = 1 - cur
+        O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R)
+        O.linear_bwd_w(dsums, hprev, gv('core.h2h.weight'), gv('core.h2h.bias'), S, 5 * R, R)
+        O.linear_bwd_w(datt_h, hprev, gv('core.attention.h2att.weight'), gv('core.attention.h2att.bias'), S, AH, R)
+        O.linear_bwd_w(dsums, t['cap.xt'], gv('core.i2h.weight'), gv('core.i2h.bias'), S, 5 * R, IE)
+        dxt = self.buf('cap.dxt', (S, IE), f32)
+        O.linear_bwd_x(dsums, pv('core.i2h.weight'), dxt, S, 5 * R, IE)
+        O.embed_bwd(dxt, t['cap.xt'], d['cap_in'], t['cap.drop_xt'], gv('embed.0.weight'), S, IE, True)
+        # ctx2att
+        O.linear_bwd_w(dpatt, ad, gv('ctx2att.weight'), gv('ctx2att.bias'), L, AH, R)
+        O.linear_bwd_x(dpatt, pv('ctx2att.weight'), dad, L, AH, R, accumulate=True)
+        if t['cap.drop_att'] is not None:
+            O.mul(dad, t['cap.drop_att'], dad)
+        O.act_bwd(dad, t['cap.a_pre'], 1)
+        dadT = self.buf('cap.dadT', (L, R))
+        O.cast(dad, dadT)
+        self.att_embed.wgrad(dadT, att_feats, L, 1, 1)
+        datt = self.buf('cap.datt_feats', (L, self.opt['att_feat_size']))
+        self.att_embed.dgrad(dadT, L, 1, 1, datt)
+        return datt
+
+    # ------------------------------------------------------------------ the step
+    keep_logprobs = False
+
+    def forward_backward(self, d, backward=True):
+        P, dt = self.P, self.dt
+        self.t = t = {}
+        TR = cfg.TRAIN
+        A, nc = self._num_anchors, self._num_classes
+        R = int(TR.BATCH_SIZE); FGM = int(round(TR.FG_FRACTION * R))
+        PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
+        C4 = self._C4_feat_dim
+        H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
+        im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
+        P.grad.zero_()
+        loss = self.buf('loss', (8,), f32, zero=True)
+        # ---- head: conv1/bn1/relu/maxpool/layer1-3 (RES:261-265,309-310) ----
+        OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        c1 = self.buf('stem.c1', (OH1 * OW1, 64))
+        O.stem_conv(d['data'], P.frozen['resnet.conv1.weight'], P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'],
+                    c1, H, W, OH1, OW1)
+        h, w = (OH1 + 2 - 3) // 2 + 1, (OW1 + 2 - 3) // 2 + 1
+        x = self.buf('stem.pool', (h * w, 64))
+        O.maxpool(c1, x, OH1, OW1, 64, h, w)
+        saved = {}
+        for li in (1, 2, 3):
+            for b, blk in enumerate(self.layers[li]):
+                x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
+                saved[(li, b)] = sv
+        base, Hc, Wc = x, h, w
+        HW = Hc * Wc
+        t['net_conv_base'] = base
+        # ---- expression encoding + dynamic filters (NET:501-562) ----
+        hidden = self._encoder_fwd(d)
+        HD = hidden.numel()
+        NF = 7 * C4 + 7
+        filt = self.buf('dyn.filt', (NF,), f32)
+        O.linear_fwd(hidden, P.gview('dyn_w', NF * HD), P.gview('dyn_b', NF), filt, 1, NF, HD, act=2)
+        net_conv = self.buf('dyn.y', (HW, C4)); resp = self.buf('dyn.resp', (HW,), f32); respk = self.buf('dyn.respk', (HW, 7), f32)
+        O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4)
+        t['net_conv'], t['response'] = net_conv, resp
+        # ---- RPN (NET:235-275) ----
+        rpn = self.buf('rpn.a', (HW, 512))
+        self.rpn_conv.fwd(net_conv, 1, Hc, Wc, rpn, relu=True)
+        NPR = P.rpn_npad
+        rheads = self.buf('rpn.heads', (HW, NPR), f32)
+        self.rpn_heads.fwd(rpn, 1, Hc, Wc, rheads, out_f32=True)
+        nA = HW * A
+        prob = self.buf('rpn.prob', (HW, 2 * A), f32); boxes = self.buf('rpn.boxes', (nA, 4), f32); scores = self.buf('rpn.scores', (nA,), f32)
+        O.rpn_decode(rheads, NPR, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, prob, boxes, scores)
+        t['rpn_heads'], t['rpn_cls_prob'] = rheads, prob
+        key = 'TRAIN' if self._mode == 'TRAIN' else 'TEST'
+        pre = int(cfg[key].RPN_PRE_NMS_TOP_N); post = int(cfg[key].RPN_POST_NMS_TOP_N)
+        pre = nA if pre <= 0 else min(pre, nA)
+        sb = self.buf('prop.sb', (pre, 4), f32); ss = self.buf('prop.ss', (pre,), f32); si = self.buf('prop.si', (pre,), torch.int32)
+        O.sort_topk(scores, boxes, nA, pre, sb, ss, si)                                      # PL:49-53
+        nms_ws = self.buf('prop.nmsws', (O.nms_workspace_bytes(pre) // 8 + 8,), torch.int64)
+        keep = self.buf('prop.keep', (post,), torch.int32); nkeep = self.buf('prop.nkeep', (1,), torch.int32)
+        O.nms(sb, pre, float(cfg[key].RPN_NMS_THRESH), 0 if cfg.NMS_CMP == 'ge' else 1, post, nms_ws, keep, nkeep)   # PL:56-60
+        rois_all = self.buf('prop.rois', (post, 5), f32); rsc_all = self.buf('prop.rsc', (post,), f32)
+        O.gather_rois(sb, ss, keep, nkeep, post, rois_all, rsc_all)
+        t['proposal_rois'], t['proposal_n'], t['proposal_scores'] = rois_all, nkeep, rsc_all
+        if self.parity is not None and self.parity.get('forced_proposals') is not None:
+            fr, fs = self.parity['forced_proposals']
+            rois_all = self.buf('prop.rois_forced', (post, 5), f32, zero=True); rsc_all = self.buf('prop.rsc_forced', (post,), f32, zero=True)
+            rois_all[:fr.shape[0]].copy_(fr); rsc_all[:fs.shape[0]].copy_(fs)
+            nkeep = torch.tensor([fr.shape[0]], dtype=torch.int32, device=self.device)
+        # ---- targets (ATL:19-153, PTL:22-204) ----
+        rl = self.buf('atl.labels', (nA,), torch.int32); rt = self.buf('atl.t', (HW, 4 * A), f32)
+        ri = self.buf('atl.i', (HW, 4 * A), f32); ro = self.buf('atl.o', (HW, 4 * A), f32)
+        aws = self.buf('atl.ws', (O.anchor_target_ws_ints(nA),), torch.int32)
+        n_gt = int(d['gt_boxes'].shape[0])
+        O.anchor_target(d['gt_boxes'], n_gt, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, self._keys('rpn_fg_keys', nA),
+                        self._keys('rpn_bg_keys', nA), TR.RPN_NEGATIVE_OVERLAP, TR.RPN_POSITIVE_OVERLAP, int(TR.RPN_BATCHSIZE),
+                        TR.RPN_FG_FRACTION, rl, rt, ri, ro, aws)
+        t.update({'rpn_labels': rl, 'rpn_bbox_targets': rt, 'rpn_bbox_inside': ri, 'rpn_bbox_outside': ro})
+        rois = self.buf('ptl.rois', (R, 5), f32); labels = self.buf('ptl.labels', (R,), torch.int32)
+        bt = self.buf('ptl.bt', (R, 4 * nc), f32); bi = self.buf('ptl.bi', (R, 4 * nc), f32); bo = self.buf('ptl.bo', (R, 4 * nc), f32)
+        mt = self.buf('ptl.mt', (FGM, MS * MS), f32); counts = self.buf('ptl.counts', (4,), torch.int32)
+        pws = self.buf('ptl.ws', (4 * (post + n_gt) + R + 16,), torch.int32)
+        cst = self._consts()
+        O.proposal_target(rois_all, rsc_all, nkeep, post, d['gt_boxes'], n_gt, d['gt_masks'], H, W, self._keys('roi_fg_keys', post + n_gt),
+                          self._keys('roi_bg_keys', post + n_gt), self._keys('roi_bg_rand', R), R, FGM, TR.FG_THRESH, TR.BG_THRESH_HI,
+                          TR.BG_THRESH_LO, cst['means'], cst['stds'], cst['inw'], nc, MS, rois, labels, bt, bi, bo, mt, counts, pws)
+        t.update({'rois': rois, 'labels': labels, 'bbox_targets': bt, 'bbox_inside': bi, 'bbox_outside': bo, 'mask_targets': mt, 'counts': counts})
+        # ---- RoI head (NET:572-586) ----
+        pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
+        O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5)
+        x, hh, ww = pool5, PS, PS
+        for b, blk in enumerate(self.layers[4]):
+            x, hh, ww, sv = blk.fwd(x, R, hh, ww, 'l4r.%d' % b)
+            saved[('4r', b)] = sv
+        fc7s = x
+        fc7 = self.buf('roi.fc7', (R, 2048))
+        O.avgpool_fwd(fc7s, fc7, R, PS * PS, 2048)
+        NPC = P.rcnn_npad
+        cheads = self.buf('roi.heads', (R, NPC), f32)
+        self.rcnn_heads.fwd(fc7, R, 1, 1, cheads, out_f32=True)
+        up = self.buf('mask.up', (FGM * MS * MS, 256))
+        O.conv_igemm(fc7s, self.up_wT, up, FGM, PS, PS, 2048, PS, PS, 4 * 256, bias=P.view('mask_up_sampling.bias'), relu=True, deconv=True, dt=dt)
+        mscore = self.buf('mask.score', (FGM * MS * MS, nc), f32)
+        self.mask_pred.fwd(up, FGM, MS, MS, mscore, out_f32=True)
+        t.update({'pool5': pool5, 'spatial_fc7': fc7s, 'rcnn_heads': cheads, 'mask_score': mscore})
+        # ---- detection losses + head gradients (NET:375-413) ----
+        d_rheads = self.buf('rpn.dheads', (HW, NPR)); d_cheads = self.buf('roi.dheads', (R, NPC)); dscore = self.buf('mask.dscore', (FGM * MS * MS,), f32)
+        O.rpn_loss(rheads, NPR, rl, rt, ri, ro, Hc, Wc, A, 3.0, 1.0, loss, d_rheads, NPR)
+        O.rcnn_loss(cheads, NPC, labels, bt, bi, bo, R, nc, 1.0, loss, d_cheads, NPC)
+        O.mask_loss(mscore, nc, labels, mt, counts, FGM, MS * MS, 1.0, loss, dscore)
+        # ---- caption-cycle branch (NET:415-439) ----
+        x, hh, ww = net_conv, Hc, Wc
+        for b, blk in enumerate(self.layers[4]):
+            x, hh, ww, sv = blk.fwd(x, 1, hh, ww, 'l4m.%d' % b)
+            saved[('4m', b)] = sv
+        feats = x
+        gm = self.buf('cap.gm', (HW,), f32)
+        O.mask_downsample(d['gt_masks'], gm, H, W, Hc, Wc)
+        AF = self.opt['att_feat_size']
+        att = self.buf('cap.att', (196, AF))
+        O.adaptive_pool_fwd(feats, None, att, Hc, Wc, 2048, 14, 14, AF)
+        O.adaptive_pool_fwd(feats, gm, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
+        t.update({'feats_all': feats, 'att_feats': att, 'gt_mask_small': gm})
+        self._caption_fwd(d, att, loss)
+        O.total_loss(loss, self._cap_loss_weight)
+        t['loss'] = loss
+        if not backward:
+            return loss
+        # =================================== backward ===================================
+        dp = self.dp
+        datt = self._caption_bwd(d, att)
+        g = self.buf('l4m.g', (HW, 2048))
+        O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
+        for b in reversed(range(len(self.layers[4]))):
+            g = self.layers[4][b].bwd(g, saved[('4m', b)], 'l4m.%d' % b, x_is_relu_out=(b > 0))
+        d_nc_cap = g
+        if dp is not None:
+            dp.ready('caption')
+        # rcnn heads -> fc7 -> spatial_fc7
+        self.rcnn_heads.wgrad(d_cheads, fc7, R, 1, 1)
+        dfc7 = self.buf('roi.dfc7', (R, 2048))
+        self.rcnn_heads.dgrad(d_cheads, R, 1, 1, dfc7)
+        # mask head
+        dup = self.buf('mask.dup', (FGM * MS * MS, 256))
+        O.maskpred_bwd(dscore, labels, counts, FGM, MS * MS, 256, P.view('mask_pred_net.weight'), up, up, dup,
+                       P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad))
+        O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
+        O.conv_wgrad(fc7s, dup, P.view('mask_up_sampling.weight', P.grad), FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0)
+        dmask_fc7 = self.buf('mask.dfc7s', (FGM * PS * PS, 2048))
+        O.conv_igemm(dup, P.view('mask_up_sampling.weight', P.shadow), dmask_fc7, FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0, dt=dt)
+        g = self.buf('l4r.g', (R * PS * PS, 2048))
+        O.avgpool_bwd(dfc7, g, dmask_fc7, fc7s, FGM, PS * PS, 2048)
+        if R > FGM:
+            off = FGM * PS * PS
+            O.avgpool_bwd(dfc7[FGM:], g[off:], None, fc7s[off:], R - FGM, PS * PS, 2048)
+        for b in reversed(range(len(self.layers[4]))):
+            g = self.layers[4][b].bwd(g, saved[('4r', b)], 'l4r.%d' % b, x_is_relu_out=(b > 0))
+        d_nc_roi = self.buf('roi.dfeat', (HW, C4), f32, zero=True)
+        O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
+        if dp is not None:
+            dp.ready('heads')
+        # rpn
+        self.rpn_heads.wgrad(d_rheads, rpn, 1, Hc, Wc)
+        drpn = self.buf('rpn.da', (HW, 512))
+        self.rpn_heads.dgrad(d_rheads, 1, Hc, Wc, drpn, ref=rpn)
+        self.rpn_conv.wgrad(drpn, net_conv, 1, Hc, Wc)
+        d_nc_rpn = self.buf('rpn.dnc', (HW, C4))
+        self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
+        d_nc = self.buf('dyn.dy', (HW, C4))
+        O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)
+        # dynamic filters (NET:504-562)
+        dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (HW,), f32)
+        O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4)
+        O.act_bwd(dfilt, filt, 2)
+        O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NF * HD, P.grad), P.gview('dyn_b', NF, P.grad), 1, NF, HD)
+        dhidden = self.buf('enc.dhidden', (HD,), f32)
+        O.linear_bwd_x(dfilt, P.gview('dyn_w', NF * HD), dhidden, 1, NF, HD)
+        self._encoder_bwd(d, dhidden)
+        if dp is not None:
+            dp.ready('language')
+        # backbone layer3, layer2 (layer1 and the stem are frozen: RES:290-299)
+        g = dbase
+        fb = cfg.RESNET.FIXED_BLOCKS
+        for li in (3, 2, 1):
+            if li <= fb:
+                break
+            for b in reversed(range(len(self.layers[li]))):
+                g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
+            if dp is not None:
+                dp.ready('layer%d' % li)
+        return loss
+
+    def _consts(self):
+        if not hasattr(self, '_cst'):
+            TR = cfg.TRAIN
+            mk = lambda v: torch.tensor(list(v), dtype=f32, device=self.device)
+            self._cst = dict(means=mk(TR.BBOX_NORMALIZE_MEANS), stds=mk(TR.BBOX_NORMALIZE_STDS), inw=mk(TR.BBOX_INSIDE_WEIGHTS))
+        return self._cst

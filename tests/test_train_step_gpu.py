@@ -1,0 +1,86 @@
+"""End-to-end parity of the HIP train step (forward, losses, backward, SGD) against the CPU oracle
+and the reference-generated golden fixture, exact-f32 verification mode (tolerance 1e-4 as stated in
+BASELINE.json north_star) plus a bf16 run with a loose tolerance."""
+import copy
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+from golden_util import load, check_digest, setup_from_fixture
+
+NAMES = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_caption', 'total_loss']
+
+
+def _setup(dtype):
+    from lang2seg_amd import selftest
+    g = load('tiny')
+    opt, sd, blob, ocfg, samp = setup_from_fixture(g)
+    samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
+    over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
+    net = selftest.build_net(opt, over, dtype, sd)
+    net.parity = selftest.parity_from_samp(samp)
+    return g, opt, sd, blob, ocfg, samp, net
+
+
+def test_train_step_f32_vs_fixture_and_oracle():
+    from oracle import net as ON
+    from lang2seg_amd.optim import SGD
+    from lang2seg_amd.nets.params import from_internal
+    g, opt, sd, blob, ocfg, samp, net = _setup('f32')
+    dev = net.upload_blob(blob, 0)
+    loss = net.forward_backward(dev)
+    torch.cuda.synchronize()
+    lv = loss.cpu().numpy()
+    t = net.t
+    # the device's own proposals as a set vs the reference's
+    n = int(t['proposal_n'].item())
+    mine = t['proposal_rois'].cpu().numpy()[:n]
+    ref = g['int.proposal_rois']
+    assert mine.shape == ref.shape
+    key = lambda r: r[np.lexsort(np.round(r[:, ::-1] * 8).T)]
+    assert np.allclose(key(mine), key(ref), atol=5e-3)
+    # integer outputs: bit-exact
+    assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
+    assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
+    nfg = int(t['counts'][0].item())
+    assert nfg == int(g['int.num_fg'])
+    assert np.array_equal(t['mask_targets'].cpu().numpy()[:nfg].reshape(nfg, 14, 14).astype(np.uint8), g['int.mask_targets'])
+    assert np.allclose(t['rois'].cpu().numpy(), g['int.rois'], atol=1e-4)
+    # losses vs the reference run (fixture) within 1e-4
+    for i, k in enumerate(NAMES):
+        assert abs(lv[i] - float(g['loss.' + k])) < 1e-4 * max(1.0, abs(float(g['loss.' + k]))), (k, lv[i], g['loss.' + k])
+    Hc, Wc = 20, 26
+    nc = t['net_conv'].float().cpu().view(1, Hc, Wc, -1).permute(0, 3, 1, 2)
+    check_digest(g, 't.net_conv', nc.numpy())
+    heads = t['rcnn_heads'].cpu().numpy()
+    assert np.allclose(heads[:, :8], g['x.cls_score'], atol=2e-4)
+    assert np.allclose(heads[:8, 81:97], g['x.bbox_pred'], atol=2e-4)
+    # gradients (reference layout) and post-SGD weights vs the fixture
+    names = sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')})
+    P = net.P
+    for nme in names:
+        gr = from_internal(nme, P.view(nme, P.grad).clone(), P.shapes[nme])
+        if nme in P.rowscale_off:                       # stored gradient is w.r.t. the BN-folded weight
+            gr = gr * P.bn_scale[nme].view(-1, *([1] * (gr.dim() - 1)))
+        check_digest(g, 'g.' + nme, gr.cpu().numpy(), rtol=5e-4, atol=1e-7)
+    SGD(net, 1e-4).step()
+    torch.cuda.synchronize()
+    sd1 = net.state_dict()
+    for nme in names:
+        check_digest(g, 'w1.' + nme, sd1[nme].numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_train_step_bf16_close():
+    g, opt, sd, blob, ocfg, samp, net = _setup('bf16')
+    dev = net.upload_blob(blob, 0)
+    lv = net.forward_backward(dev).cpu().numpy()
+    for i, k in enumerate(NAMES):
+        ref = float(g['loss.' + k])
+        assert abs(lv[i] - ref) < 0.05 * max(1.0, abs(ref)), (k, lv[i], ref)
+    assert np.isfinite(net.P.grad.float().abs().sum().item())
+
+
+def test_smoke_entry():
+    from lang2seg_amd import selftest
+    selftest.smoke()
