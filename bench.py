@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py — train images/sec of the lang2seg cycle train step (ResNet-101 C4 Mask R-CNN + bi-LSTM +
+7 spatial dynamic filters + att2in2 caption-cycle loss) on N MI355X of one node.
+
+One "step" = one `train_step` = one 600x1000 image x one 20-token expression: forward, losses,
+backward, SGD (the unit behind the reference's `speed: s / iter`, train_val_cycle.py:371,404-411).
+Workload = BASELINE.json configs[2] (`train_cycle.sh`, bf16) with the refcocog token/vocab sizes the
+headline metric is quoted on.  Inputs are synthetic and resident in HBM before the
+timed region; weights are the reference initialisers with a fixed seed.
+N > 1: one process per GPU (torchrun), per-GPU batch 1, RCCL all-reduce of the flat gradient buffer
+overlapped with backward (weak scaling).
+
+Prints ONE JSON line (rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# algorithmic work: forward 321.29 GMAC, backward 2x except frozen stem+layer1 (9.40 GMAC)
+STEP_FLOP = 2.0 * (321.29e9 + 2.0 * (321.29e9 - 9.40e9))
+PEAK_BF16 = 2.5e15      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(H, W, T, V):
+    """The oracle's fp32 CPU restatement of the same step on this box's host cores (baseline only)."""
+    import copy
+    from oracle import weights as OW, synth as OS, net as ON
+    opt = OW.default_opt(vocab_size=V, seq_length=T)
+    sd = OW.make_state_dict(opt, seed=3)
+    blob = OS.make_blob(H, W, T, V, seed=1234)
+    net = ON.OracleNet(sd, opt, copy.deepcopy(ON.DEFAULT_CFG))
+    t0 = time.time()
+    net.train_step(blob, dict(rng=np.random.RandomState(3)))
+    dt = time.time() - t0
+    return {'value': 1.0 / dt, 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 train step (600x1000 image, 20 tokens, 256 RoIs, fp32) = %.1f s' % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--height', type=int, default=600)
+    ap.add_argument('--width', type=int, default=1000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    from lang2seg_amd.model.config import cfg
+    from lang2seg_amd.nets.resnet_v1 import resnetv1
+    from lang2seg_amd.optim import SGD
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    from lang2seg_amd import ops as O
+
+    T, V = 20, 3349
+    cfg.COMPUTE_DTYPE = args.dtype
+    opt = dict(vocab_size=V, word_embedding_size=512, word_vec_size=512, rnn_hidden_size=512, bidirectional=1, word_drop_out=0.5,
+               rnn_drop_out=0.2, rnn_num_layers=1, rnn_type='lstm', variable_lengths=1, C4_feat_dim=1024, cap_loss_weight=1.0,
+               caption_model='att2in2', input_encoding_size=512, rnn_size=512, num_layers=1, drop_prob_lm=0.5, seq_length=T,
+               fc_feat_size=4096, att_feat_size=4096, att_hid_size=512)
+    np.random.seed(cfg.RNG_SEED)
+    net = resnetv1(opt, batch_size=1, num_layers=101)
+    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    net.train()
+    net.rank_seed = rank * 1000003
+    if world > 1:
+        from lang2seg_amd.parallel import GradReducer
+        net.dp = GradReducer(net, world)
+    optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
+    loader = SyntheticLoader(num_images=4, sents_per_image=1, H=args.height, W=args.width, T=T, vocab_size=V, rank=rank)
+    blobs = [loader.getBatch('train') for _ in range(4)]
+    for b in blobs:
+        net.upload_blob(b, 0)          # inputs resident in HBM before the timed region
+
+    # live timing of the dominant kernel: the implicit-GEMM conv on the layer4@RoIs 3x3 (M=12544, N=512, K=4608)
+    evs = []
+    doms = [blk.c2 for blk in net.layers[4]]
+    def wrap(conv):
+        orig = conv.fwd
+        def timed(x, n, IH, IW, y, **kw):
+            if n > 1 and wrap.on:
+                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                a.record(); r = orig(x, n, IH, IW, y, **kw); b.record(); evs.append((a, b)); return r
+            return orig(x, n, IH, IW, y, **kw)
+        conv.fwd = timed
+    wrap.on = False
+    for c in doms:
+        wrap(c)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        net.train_step_async(blobs[i % 4], 0, optim)
+    barrier()
+    wrap.on = True
+    t0 = time.time()
+    for i in range(args.steps):
+        loss = net.train_step_async(blobs[i % 4], 0, optim)
+    barrier()
+    dt = time.time() - t0
+    wrap.on = False
+    if world > 1:
+        tt = torch.tensor([dt], device='cuda')
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    lv = loss.cpu().numpy()
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        val = world * args.steps / dt
+        R = int(cfg.TRAIN.BATCH_SIZE)
+        kflop = 2.0 * (R * 49) * 512 * 4608
+        kms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else float('nan')
+        ach = kflop / (kms * 1e-3) / 1e12
+        out = {
+            'metric': 'train images/sec (cycle loss on), 600x1000 input', 'value': val, 'unit': 'img/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'train_cycle.sh step: ResNet-101 C4 + 7 spatial dynamic filters + att2in2 cycle loss, %dx%d image, '
+                                   '20-token expression (V=3349), 12000->2000 proposals, 256 RoIs, per-GPU batch 1' % (args.height, args.width),
+                       'parallelism': 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12},
+            'step_tflops_per_gpu': STEP_FLOP / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': STEP_FLOP / (ms * 1e-3) / PEAK_BF16,
+            'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel<bf16,128,128> on layer4@RoIs conv3x3 (M=%d,N=512,K=4608)' % (R * 49),
+                         'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': None,
+                         'avg_launch_ms': kms, 'launches_timed': len(evs)},
+            'final_losses': [float(x) for x in lv[:7]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.height, args.width, T, V)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -100,14 +100,14 @@ class resnetv1(Network):
             m = (self.parity.get('drops') or {}).get(name)
             return m
         m = self.buf('drop.' + name, shape, f32)
-        O.dropout_mask(m, p, (self._step * 16 + hash(name) % 16) * 2654435761 % (1 << 62) + 12345)
+        O.dropout_mask(m, p, (self._step * 16 + sum(map(ord, name)) % 16) * 2654435761 % (1 << 62) + 12345 + getattr(self, 'rank_seed', 0))
         return m
 
     def _keys(self, name, n):
         if self.parity is not None and self.parity.get(name) is not None:
             return self.parity[name]
         k = self.buf('keys.' + name, (n,), torch.int32)
-        O.random_keys(k, (self._step * 8 + hash(name) % 8) * 0x9E3779B1 % (1 << 62) + 777 + getattr(self, 'rank_seed', 0))
+        O.random_keys(k, (self._step * 64 + sum(map(ord, name)) % 64) * 0x9E3779B1 % (1 << 62) + 777 + getattr(self, 'rank_seed', 0))
         return k
 
     # ------------------------------------------------------------------ language encoder (ENC:27-82)

@@ -1,0 +1,56 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL (torch.distributed backend "nccl")
+over xGMI.  The reference has no distributed code at all; the natural sharding
+is one (image, expression) pair per rank per step (train_val_cycle.py:362-403), with a sum
+all-reduce of the flat fp32 gradient buffer averaged over ranks.
+
+The flat buffer is laid out in reverse execution order (nets/params.py), so `ready(stage)` can launch
+the all-reduce of a finished bucket on a side stream while earlier layers are still back-propagating;
+`finish()` joins before the optimiser."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class GradReducer(object):
+    STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
+
+    def __init__(self, net, world, backend_stream=True):
+        self.net, self.world = net, world
+        P = net.P
+        # bucket boundaries: prefix of the flat buffer that is final after each backward stage
+        def end_of(pred):
+            e = 0
+            for k in P.trainable:
+                if pred(k):
+                    e = max(e, P.offsets[k] + int(np.prod(P.shapes[k])))
+            return (e + 63) // 64 * 64
+        # layer4 weights get gradient from both the caption pass and the RoI pass -> final only after 'heads'
+        self.bounds = {
+            'caption': end_of(lambda k: k.startswith('caption_model.')),
+            'heads': end_of(lambda k: k.startswith(('caption_model.', 'resnet.layer4.', 'cls_score', 'bbox_pred', 'mask_'))),
+            'language': end_of(lambda k: not k.startswith(('resnet.layer3.', 'resnet.layer2.', 'resnet.layer1.'))),
+            'layer3': end_of(lambda k: not k.startswith(('resnet.layer2.', 'resnet.layer1.'))),
+            'layer2': end_of(lambda k: not k.startswith('resnet.layer1.')),
+            'layer1': P.total,
+        }
+        self.done = 0
+        self.side = torch.cuda.Stream()
+        self.works = []
+
+    def ready(self, stage):
+        end = min(self.bounds[stage], self.net.P.total)
+        if end <= self.done:
+            return
+        seg = self.net.P.grad[self.done:end]
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        self.done = end
+
+    def finish(self):
+        P = self.net.P
+        if self.done < P.total:
+            self.ready('layer1')
+        torch.cuda.current_stream().wait_stream(self.side)
+        self.done = 0
+        # average over ranks: folded into the optimiser's grad_scale by the caller

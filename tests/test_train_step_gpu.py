@@ -71,6 +71,35 @@ def test_train_step_f32_vs_fixture_and_oracle():
         check_digest(g, 'w1.' + nme, sd1[nme].numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_train_step_full_size_f32():
+    """BASELINE.json full size (600x1000, 12000->2000 proposals, 256 RoIs, 20 tokens, V=3349) vs the reference run."""
+    from lang2seg_amd import selftest
+    g = load('full')
+    opt, sd, blob, ocfg, samp = setup_from_fixture(g)
+    samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
+    over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
+    net = selftest.build_net(opt, over, 'f32', sd)
+    net.parity = selftest.parity_from_samp(samp)
+    lv = net.forward_backward(net.upload_blob(blob, 0)).cpu().numpy()
+    t = net.t
+    n = int(t['proposal_n'].item())
+    assert n == g['int.proposal_rois'].shape[0]
+    assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
+    assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
+    nfg = int(t['counts'][0].item())
+    assert nfg == int(g['int.num_fg'])
+    assert np.array_equal(t['mask_targets'].cpu().numpy()[:nfg].reshape(nfg, 14, 14).astype(np.uint8), g['int.mask_targets'])
+    for i, k in enumerate(NAMES):
+        assert abs(lv[i] - float(g['loss.' + k])) < 1e-4 * max(1.0, abs(float(g['loss.' + k]))), (k, lv[i], g['loss.' + k])
+    from lang2seg_amd.nets.params import from_internal
+    P = net.P
+    for nme in sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')}):
+        gr = from_internal(nme, P.view(nme, P.grad).clone(), P.shapes[nme])
+        if nme in P.rowscale_off:
+            gr = gr * P.bn_scale[nme].view(-1, *([1] * (gr.dim() - 1)))
+        check_digest(g, 'g.' + nme, gr.cpu().numpy(), rtol=1e-3, atol=1e-7)
+
+
 def test_train_step_bf16_close():
     g, opt, sd, blob, ocfg, samp, net = _setup('bf16')
     dev = net.upload_blob(blob, 0)
