@@ -67,6 +67,9 @@ int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
 int l2s_weight_cast(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
 /* data-gradient layout: dst(dtype)[Cin][taps][Cout], tap order reversed (180-degree flip), * scale[co] */
 int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
+/* all data-gradient copies of one step in one launch: table (DEVICE memory) of n descriptors */
+typedef struct { const float* src; const float* scale; void* dst; int Cout, taps, Cin, pad; } l2s_transpose_desc;
+int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int dtype, hipStream_t s);
 /* column sums: out[c] += sum_r a[r][c] (bias gradients) */
 int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s);
 
@@ -100,9 +103,10 @@ int l2s_dropout_mask(float* mask, long n, float p, uint64_t seed, hipStream_t s)
  * outputs: prob [HW][2A] float, boxes [HW*A][4] float, scores [HW*A] float (fg prob) */
 int l2s_rpn_decode(const float* heads, int ldh, const float* base_anchors /*[A][4]*/, int H, int W, int A, int feat_stride,
                    float im_h, float im_w, float* prob, float* boxes, float* scores, hipStream_t s);
-/* descending stable rank sort (ties: lower index first), emits the top-k boxes/scores in order.
- * rank_out[n] int32 workspace; sorted_boxes [k][4], sorted_scores [k], sorted_idx [k] (int32) */
-int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* rank_ws, float* sorted_boxes,
+/* descending stable sort (ties: lower index first), emits the top-k boxes/scores in order.
+ * ws: int32 workspace of l2s_sort_ws_ints(n); sorted_boxes [k][4], sorted_scores [k], sorted_idx [k] (int32) */
+long l2s_sort_ws_ints(int n);
+int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* ws, float* sorted_boxes,
                   float* sorted_scores, int* sorted_idx, hipStream_t s);
 /* greedy NMS over score-sorted boxes (replaces gpu_nms / cpu_nms, nms_cuda.c:17, nms.c:4).
  * cmp_mode 0: suppress when IoU >= thresh (cpu_nms, nms.c:59); 1: IoU > thresh (nms_kernel.cu:63).
@@ -196,11 +200,11 @@ int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y,
 int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
                       void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype, hipStream_t s);
 /* att2in2 attention (AttModel.py:406-423): patt [L][D], att [L][D] float; att_h [D]; alpha w[D], b.
- * out: weight [L] (softmax), att_res [D] */
+ * out: weight [L] (softmax), att_res [D + 256] (the tail is scratch for the raw dots) */
 int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,
                           float* tanh_ws /*[L][D]*/, float* weight, float* att_res, hipStream_t s);
 int l2s_cap_attention_bwd(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
-                          float* dpatt /*[L][D] +=*/, float* datt /*[L][D] +=*/, float* datt_h /*[D] =*/, float* daw /*[D] +=*/, float* dab /*+=*/, hipStream_t s);
+                          float* dpatt /*[L][D] +=*/, float* datt /*[L][D] +=*/, float* datt_h /*[D + 256] = (tail: scratch)*/, float* daw /*[D] +=*/, float* dab /*+=*/, hipStream_t s);
 /* att2in2 core gates (AttModel.py:446-466): s[5R] = i2h+h2h, a2c[2R]; maxout candidate, no tanh */
 int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save /*[6R]: sig(3R), sel(R), cand(R), tanh(c)(R)*/, int R, hipStream_t s);
 int l2s_cap_gates_bwd(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* dsums /*[5R]*/, float* da2c /*[2R]*/, float* dc_prev, int R, hipStream_t s);

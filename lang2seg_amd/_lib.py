@@ -27,6 +27,10 @@ class WgradDesc(C.Structure):
                 ('split_k', i32), ('tile', i32)]
 
 
+class TransposeDesc(C.Structure):
+    _fields_ = [('src', vp), ('scale', vp), ('dst', vp), ('Cout', i32), ('taps', i32), ('Cin', i32), ('pad', i32)]
+
+
 class SgdSeg(C.Structure):
     _fields_ = [('offset', i64), ('count', i64), ('row_len', i32), ('weight_decay', i32), ('rowscale_off', i64),
                 ('lr_mult', f32), ('pad', i32)]
@@ -43,6 +47,7 @@ SIGS = {
     'l2s_weight_cast': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_weight_transpose': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_colsum': (i32, [vp, i32, i32, i32, vp, i32, vp]),
+    'l2s_weight_transpose_batched': (i32, [vp, i32, i32, vp]),
     'l2s_stem_conv': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_fill_f32': (i32, [vp, f32, i64, vp]),
@@ -57,6 +62,7 @@ SIGS = {
     'l2s_rpn_decode': (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]),
     'l2s_sort_topk': (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_nms_workspace_bytes': (sz, [i32]),
+    'l2s_sort_ws_ints': (i64, [i32]),
     'l2s_nms': (i32, [vp, i32, f32, i32, i32, vp, vp, vp, vp]),
     'l2s_gather_rois': (i32, [vp, vp, vp, vp, i32, vp, vp, vp]),
     'l2s_random_keys': (i32, [vp, i64, u64, vp]),

@@ -57,20 +57,39 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   }
 }
 
-// dx[m][k] (+)= sum_n dy[m][n] w[n][k]; thread per k, loops n (w rows coalesced along k)
-__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w, float* dx,
-                                                          int lddx, int M, int N, int K, int accumulate, int nsplit) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  const int m = blockIdx.y;
-  const int sp = blockIdx.z;
-  if (k >= K) return;
-  const int per = (N + nsplit - 1) / nsplit, nb = sp * per, ne = min(N, nb + per);
-  float acc = 0.f;
-  const float* dyr = dy + (long)m * lddy;
-  for (int n = nb; n < ne; ++n) acc = fmaf(dyr[n], w[(long)n * K + k], acc);
-  if (nsplit > 1) atomicAdd(dx + (long)m * lddx + k, acc);
-  else if (accumulate) dx[(long)m * lddx + k] += acc;
-  else dx[(long)m * lddx + k] = acc;
+// dx[m][k] (+)= sum_n dy[m][n] w[n][k]  (transposed GEMV): block = 64 k-columns (one per lane) x 16 n-groups
+// (one per wave); every wave streams whole 256-byte rows of w; cross-wave reduction through LDS; no atomics.
+template <int MT>
+__global__ __launch_bounds__(1024) void gemvT_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w, float* dx,
+                                                    int lddx, int m0, int M, int N, int K, int accumulate) {
+  __shared__ float sh[MT][16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  if (k < K) {
+    for (int n = g; n < N; n += 16) {
+      const float wv = w[(long)n * K + k];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (m0 + m < M) acc[m] = fmaf(dy[(long)(m0 + m) * lddy + n], wv, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) sh[m][g][lane] = acc[m];
+  __syncthreads();
+  // 1024 threads reduce MT*64 outputs: thread -> (m = tid / 64, lane)
+  for (int o = threadIdx.x; o < MT * 64; o += 1024) {
+    const int m = o >> 6, l = o & 63, kk = blockIdx.x * 64 + l;
+    if (m0 + m < M && kk < K) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += sh[m][j][l];
+      float* out = dx + (long)(m0 + m) * lddx + kk;
+      *out = accumulate ? (*out + s) : s;
+    }
+  }
 }
 
 // dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n]
@@ -219,72 +238,84 @@ __global__ __launch_bounds__(256) void dynfilter_bwd2_kernel(const void* dy, con
   }
 }
 
-// ---------------------------------------------------------------- att2in2 attention (single workgroup, L <= 256)
-__global__ __launch_bounds__(1024) void cap_att_fwd_kernel(const float* __restrict__ patt, const float* __restrict__ att, const float* __restrict__ att_h,
-                                                          const float* __restrict__ aw, const float* __restrict__ ab, int L, int D,
-                                                          float* tanh_ws, float* weight, float* att_res) {
-  __shared__ float dots[256];
-  __shared__ float red[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  for (int l = wave; l < L; l += nw) {
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      const float t = tanhf(patt[(long)l * D + d] + att_h[d]);
-      tanh_ws[(long)l * D + d] = t;
-      s = fmaf(t, aw[d], s);
-    }
-    s = wave_sum(s);
-    if (lane == 0) dots[l] = s + ab[0];
+// ---------------------------------------------------------------- att2in2 attention (L <= 256)
+// forward: (A) one wave per location: dots[l] = alpha . tanh(patt[l] + att_h) ; (B) D/64 workgroups: softmax over L (recomputed per
+// workgroup, 196 values) and att_res[d] = sum_l w[l] att[l][d] with 4 l-groups per 64 channels.
+__global__ __launch_bounds__(256) void cap_att_dots_kernel(const float* __restrict__ patt, const float* __restrict__ att_h, const float* __restrict__ aw,
+                                                          const float* __restrict__ ab, int L, int D, float* tanh_ws, float* dots) {
+  const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (l >= L) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float t = tanhf(patt[(long)l * D + d] + att_h[d]);
+    tanh_ws[(long)l * D + d] = t;
+    s = fmaf(t, aw[d], s);
   }
-  __syncthreads();
-  float v = tid < L ? dots[tid] : -INFINITY;
+  s = wave_sum(s);
+  if (lane == 0) dots[l] = s + ab[0];
+}
+__global__ __launch_bounds__(256) void cap_att_apply_kernel(const float* __restrict__ att, const float* __restrict__ dots, int L, int D, float* weight, float* att_res) {
+  __shared__ float w[256];
+  __shared__ float red[4];
+  __shared__ float part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const float v = tid < L ? dots[tid] : -INFINITY;
   const float mx = block_max(v, red);
   const float e = tid < L ? expf(v - mx) : 0.f;
   const float sum = block_sum(e, red);
-  if (tid < L) { dots[tid] = e / sum; weight[tid] = e / sum; }
+  if (tid < L) { w[tid] = e / sum; if (blockIdx.x == 0) weight[tid] = e / sum; }
   __syncthreads();
-  for (int d = tid; d < D; d += blockDim.x) {
-    float s = 0.f;
-    for (int l = 0; l < L; ++l) s = fmaf(dots[l], att[(long)l * D + d], s);
-    att_res[d] = s;
-  }
+  const int d = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (d < D) for (int l = g; l < L; l += 4) s = fmaf(w[l], att[(long)l * D + d], s);
+  part[g][lane] = s;
+  __syncthreads();
+  if (g == 0 && d < D) att_res[d] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
-__global__ __launch_bounds__(1024) void cap_att_bwd_kernel(const float* __restrict__ dres, const float* __restrict__ att, const float* __restrict__ tanh_ws,
-                                                          const float* __restrict__ weight, const float* __restrict__ aw, int L, int D,
-                                                          float* dpatt, float* datt, float* datt_h, float* daw, float* dab) {
-  __shared__ float dw_[256];
+// backward: (A) dweight[l] = dres . att[l] (one wave per l); (B) D/64 workgroups: softmax backward over L (recomputed), then the
+// per-channel accumulations with 4 l-groups per 64 channels.
+__global__ __launch_bounds__(256) void cap_att_bwd_dw_kernel(const float* __restrict__ dres, const float* __restrict__ att, int L, int D, float* dweight) {
+  const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (l >= L) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s = fmaf(dres[d], att[(long)l * D + d], s);
+  s = wave_sum(s);
+  if (lane == 0) dweight[l] = s;
+}
+__global__ __launch_bounds__(256) void cap_att_bwd_kernel(const float* __restrict__ dres, const float* __restrict__ dweight, const float* __restrict__ tanh_ws,
+                                                         const float* __restrict__ weight, const float* __restrict__ aw, int L, int D,
+                                                         float* dpatt, float* datt, float* datt_h, float* daw, float* dab) {
   __shared__ float ddot[256];
-  __shared__ float red[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  // dweight[l] = dres . att[l]
-  for (int l = wave; l < L; l += nw) {
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) s = fmaf(dres[d], att[(long)l * D + d], s);
-    s = wave_sum(s);
-    if (lane == 0) dw_[l] = s;
-  }
-  __syncthreads();
+  __shared__ float wsh[256];
+  __shared__ float red[4];
+  __shared__ float p1[4][64], p2[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const float wl = tid < L ? weight[tid] : 0.f;
-  const float dot = block_sum(tid < L ? wl * dw_[tid] : 0.f, red);
-  if (tid < L) ddot[tid] = wl * (dw_[tid] - dot);      // softmax backward
+  const float dwl = tid < L ? dweight[tid] : 0.f;
+  const float dot = block_sum(wl * dwl, red);
+  const float dd = wl * (dwl - dot);                      // softmax backward
+  if (tid < 256) { ddot[tid] = tid < L ? dd : 0.f; wsh[tid] = wl; }
+  const float sdd = block_sum(tid < L ? dd : 0.f, red);
+  if (blockIdx.x == 0 && tid == 0) dab[0] += sdd;
   __syncthreads();
-  const float sdd = block_sum(tid < L ? ddot[tid] : 0.f, red);
-  if (tid == 0) dab[0] += sdd;
-  // per-d accumulations
-  for (int d = tid; d < D; d += blockDim.x) {
-    float sah = 0.f, saw = 0.f;
+  const int d = blockIdx.x * 64 + lane;
+  float sah = 0.f, saw = 0.f;
+  if (d < D) {
     const float a = aw[d], dr = dres[d];
-    for (int l = 0; l < L; ++l) {
+    for (int l = g; l < L; l += 4) {
       const float t = tanh_ws[(long)l * D + d];
-      const float dd = ddot[l];
-      const float dt_ = dd * a * (1.f - t * t);
+      const float dt_ = ddot[l] * a * (1.f - t * t);
       dpatt[(long)l * D + d] += dt_;
-      datt[(long)l * D + d] += weight[l] * dr;
+      datt[(long)l * D + d] += wsh[l] * dr;
       sah += dt_;
-      saw = fmaf(dd, t, saw);
+      saw = fmaf(ddot[l], t, saw);
     }
-    datt_h[d] = sah;
-    daw[d] += saw;
+  }
+  p1[g][lane] = sah; p2[g][lane] = saw;
+  __syncthreads();
+  if (g == 0 && d < D) {
+    datt_h[d] = p1[0][lane] + p1[1][lane] + p1[2][lane] + p1[3][lane];
+    daw[d] += p2[0][lane] + p2[1][lane] + p2[2][lane] + p2[3][lane];
   }
 }
 
@@ -359,12 +390,9 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, const fl
 }
 extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate, hipStream_t s) {
   if (M <= 0) return L2S_OK;
-  int nsplit = 1;
-  if (N >= 1024 && (long)M * cdiv(K, 256) < 128) nsplit = 8;
-  if (nsplit > 1 && !accumulate) {
-    for (int m = 0; m < M; ++m) hipMemsetAsync(dx + (long)m * lddx, 0, (size_t)K * 4, s);
-  }
-  hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(K, 256), M, nsplit), dim3(256), 0, s, dy, lddy, w, dx, lddx, M, N, K, accumulate, nsplit);
+  dim3 grid(cdiv(K, 64));
+  if (M == 1) hipLaunchKernelGGL(gemvT_kernel<1>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, 0, M, N, K, accumulate);
+  else for (int m0 = 0; m0 < M; m0 += 8) hipLaunchKernelGGL(gemvT_kernel<8>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, m0, M, N, K, accumulate);
   return l2s_check_launch();
 }
 extern "C" int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx_, float* dw, float* db, int M, int N, int K, hipStream_t s) {
@@ -409,13 +437,16 @@ extern "C" int l2s_dynfilter_bwd(const void* dy, const void* x, const float* fil
 extern "C" int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,
                                      float* tanh_ws, float* weight, float* att_res, hipStream_t s) {
   if (L > 256) return L2S_EINVAL;
-  hipLaunchKernelGGL(cap_att_fwd_kernel, dim3(1), dim3(1024), 0, s, patt, att, att_h, aw, ab, L, D, tanh_ws, weight, att_res);
+  // the softmax weights buffer doubles as the raw-dot scratch between the two launches
+  hipLaunchKernelGGL(cap_att_dots_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, patt, att_h, aw, ab, L, D, tanh_ws, att_res + D);
+  hipLaunchKernelGGL(cap_att_apply_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, att, att_res + D, L, D, weight, att_res);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_attention_bwd(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
                                      float* dpatt, float* datt, float* datt_h, float* daw, float* dab, hipStream_t s) {
   if (L > 256) return L2S_EINVAL;
-  hipLaunchKernelGGL(cap_att_bwd_kernel, dim3(1), dim3(1024), 0, s, datt_res, att, tanh_ws, weight, aw, L, D, dpatt, datt, datt_h, daw, dab);
+  hipLaunchKernelGGL(cap_att_bwd_dw_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, datt_res, att, L, D, datt_h + D);
+  hipLaunchKernelGGL(cap_att_bwd_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, datt_res, datt_h + D, tanh_ws, weight, aw, L, D, dpatt, datt, datt_h, daw, dab);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save, int R, hipStream_t s) {

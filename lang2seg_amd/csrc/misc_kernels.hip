@@ -42,6 +42,32 @@ __global__ void weight_transpose_kernel(const float* __restrict__ src, const flo
   }
 }
 
+// batched variant: one launch rebuilds every data-gradient weight copy of the step (descriptor table in device memory)
+__global__ void weight_transpose_batched_kernel(const l2s_transpose_desc* __restrict__ table, int dt) {
+  __shared__ float tile[32][33];
+  const l2s_transpose_desc d = table[blockIdx.y];
+  const int tci = (d.Cin + 31) / 32, tco = (d.Cout + 31) / 32;
+  const int ntiles = tci * tco * d.taps;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tap = t / (tci * tco), rem = t - tap * (tci * tco);
+    const int co0 = (rem / tci) * 32, ci0 = (rem % tci) * 32;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      int co = co0 + r, ci = ci0 + tx;
+      float v = 0.f;
+      if (co < d.Cout && ci < d.Cin) { v = d.src[((long)co * d.taps + tap) * d.Cin + ci]; if (d.scale) v *= d.scale[co]; }
+      tile[r][tx] = v;
+    }
+    __syncthreads();
+    const int otap = d.taps - 1 - tap;
+    for (int r = ty; r < 32; r += 8) {
+      int ci = ci0 + r, co = co0 + tx;
+      if (co < d.Cout && ci < d.Cin) stx(d.dst, ((long)ci * d.taps + otap) * d.Cout + co, dt, tile[tx][r]);
+    }
+  }
+}
+
 __global__ void colsum_kernel(const void* a, int rows, int cols, int lda, float* out, int dt) {
   // block: 64 columns x 4 row-groups
   __shared__ float sh[4][64];
@@ -227,7 +253,30 @@ __global__ void sgd_kernel(float* __restrict__ param, const float* __restrict__ 
   const l2s_sgd_seg sg = segs[blockIdx.y];
   const float lwd = sg.weight_decay ? wd : 0.f;
   const float llr = lr * sg.lr_mult;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < sg.count; i += (long)gridDim.x * blockDim.x) {
+  // vector body: 4 consecutive elements per thread when the segment start is 16-byte aligned and a row is a multiple of 4
+  const bool vec = ((sg.offset & 3) == 0) && (sg.rowscale_off < 0 || (sg.row_len & 3) == 0);
+  const long nvec = vec ? (sg.count >> 2) : 0;
+  for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+    const long i = v << 2, o = sg.offset + i;
+    float4 g4 = *(const float4*)(grad + o), w4 = *(const float4*)(param + o), m4 = *(const float4*)(mom + o);
+    const float rs = sg.rowscale_off >= 0 ? rowscale[sg.rowscale_off + i / sg.row_len] : 1.f;
+    float gg[4] = {g4.x, g4.y, g4.z, g4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g = gg[e] * gscale * rs + lwd * ww[e];
+      mm[e] = momentum * mm[e] + g;
+      ww[e] = ww[e] - llr * mm[e];
+    }
+    *(float4*)(mom + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *(float4*)(param + o) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+    if (shadow) {
+      if (sdt) {
+        uint2 pk; pk.x = (uint32_t)f2bf(ww[0] * rs) | ((uint32_t)f2bf(ww[1] * rs) << 16); pk.y = (uint32_t)f2bf(ww[2] * rs) | ((uint32_t)f2bf(ww[3] * rs) << 16);
+        *(uint2*)((bf16_t*)shadow + o) = pk;
+      } else *(float4*)((float*)shadow + o) = make_float4(ww[0] * rs, ww[1] * rs, ww[2] * rs, ww[3] * rs);
+    }
+  }
+  for (long i = (nvec << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < sg.count; i += (long)gridDim.x * blockDim.x) {
     const long o = sg.offset + i;
     float g = grad[o] * gscale;
     if (sg.rowscale_off >= 0) g *= rowscale[sg.rowscale_off + i / sg.row_len];
@@ -253,6 +302,11 @@ extern "C" int l2s_weight_cast(const float* src, const float* scale, void* dst, 
 extern "C" int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s) {
   dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), taps);
   hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, s, src, scale, dst, Cout, taps, Cin, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int dtype, hipStream_t s) {
+  if (n <= 0) return L2S_OK;
+  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3(48, n), dim3(256), 0, s, table_dev, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s) {

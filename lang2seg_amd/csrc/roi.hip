@@ -45,27 +45,77 @@ __device__ __forceinline__ uint64_t sort_key(float s, int idx) {
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // order-preserving
   return ((uint64_t)u << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)idx);  // ties: lower index ranks higher
 }
-__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int n, int k,
-                                                   float* sboxes, float* sscores, int* sidx) {
-  __shared__ uint64_t tile[1024];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const uint64_t mine = i < n ? sort_key(scores[i], i) : 0;
-  int rank = 0;
-  for (int t0 = 0; t0 < n; t0 += 1024) {
-    __syncthreads();
-    for (int j = threadIdx.x; j < 1024; j += 256) tile[j] = (t0 + j < n) ? sort_key(scores[t0 + j], t0 + j) : 0;
-    __syncthreads();
-    const int lim = min(1024, n - t0);
-    int j = 0;
-    for (; j + 4 <= lim; j += 4) {
-      rank += (tile[j] > mine) + (tile[j + 1] > mine) + (tile[j + 2] > mine) + (tile[j + 3] > mine);
-    }
-    for (; j < lim; ++j) rank += (tile[j] > mine);
+// Top-k by a monotone bucket partition (4096 linear buckets between min and max score) followed by an exact
+// rank-by-counting inside each bucket: O(n * bucket_size) compares instead of O(n^2).  Exactly the total order
+// (score desc, index asc) for any input; only the speed depends on how the scores spread.
+constexpr int NBKT = 4096;
+struct SortWs { unsigned int* mm; int* hist; int* base; int* cursor; int* members; };
+__device__ __forceinline__ SortWs sort_ws(int* ws) {
+  SortWs w; w.mm = (unsigned int*)ws; w.hist = ws + 16; w.base = w.hist + NBKT; w.cursor = w.base + NBKT; w.members = w.cursor + NBKT;
+  return w;
+}
+__device__ __forceinline__ unsigned int okey(float s) { unsigned int u = __float_as_uint(s); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float okey_inv(unsigned int k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+__global__ void sort_init_kernel(int* ws) {
+  SortWs w = sort_ws(ws);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * NBKT + 16; i += gridDim.x * blockDim.x) {
+    if (i == 0) w.mm[0] = 0xFFFFFFFFu; else if (i == 1) w.mm[1] = 0u; else if (i >= 16) ws[i] = 0;
   }
-  if (i < n && rank < k) {
-    sidx[rank] = i;
-    sscores[rank] = scores[i];
-    *(float4*)(sboxes + (long)rank * 4) = *(const float4*)(boxes + (long)i * 4);
+}
+__global__ void sort_minmax_kernel(const float* scores, int n, int* ws) {
+  SortWs w = sort_ws(ws);
+  unsigned int mn = 0xFFFFFFFFu, mx = 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { unsigned int k = okey(scores[i]); mn = min(mn, k); mx = max(mx, k); }
+  for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (unsigned int)__shfl_xor((int)mn, o, 64)); mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&w.mm[0], mn); atomicMax(&w.mm[1], mx); }
+}
+__device__ __forceinline__ int bucket_of(float s, float mn, float mx) {
+  if (!(mx > mn)) return 0;
+  int b = (int)((s - mn) * ((float)NBKT / (mx - mn)));
+  b = b < 0 ? 0 : (b >= NBKT ? NBKT - 1 : b);
+  return NBKT - 1 - b;     // descending
+}
+__global__ void sort_hist_kernel(const float* scores, int n, int* ws) {
+  SortWs w = sort_ws(ws);
+  const float mn = okey_inv(w.mm[0]), mx = okey_inv(w.mm[1]);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&w.hist[bucket_of(scores[i], mn, mx)], 1);
+}
+__global__ __launch_bounds__(1024) void sort_scan_kernel(int* ws) {
+  __shared__ int part[1024];
+  SortWs w = sort_ws(ws);
+  const int t = threadIdx.x;
+  int v[4], s = 0;
+  for (int j = 0; j < 4; ++j) { v[j] = w.hist[t * 4 + j]; s += v[j]; }
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) { int x = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += x; __syncthreads(); }
+  int run = part[t] - s;
+  for (int j = 0; j < 4; ++j) { w.base[t * 4 + j] = run; w.cursor[t * 4 + j] = run; run += v[j]; }
+}
+__global__ void sort_scatter_kernel(const float* scores, int n, int* ws) {
+  SortWs w = sort_ws(ws);
+  const float mn = okey_inv(w.mm[0]), mx = okey_inv(w.mm[1]);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int pos = atomicAdd(&w.cursor[bucket_of(scores[i], mn, mx)], 1);
+    w.members[pos] = i;
+  }
+}
+__global__ void sort_rank_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int n, int k, const int* ws_c,
+                                 float* sboxes, float* sscores, int* sidx) {
+  SortWs w = sort_ws((int*)ws_c);
+  const float mn = okey_inv(w.mm[0]), mx = okey_inv(w.mm[1]);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float si = scores[i];
+    const int b = bucket_of(si, mn, mx);
+    const int lo = w.base[b], cnt = w.hist[b];
+    if (lo >= k) continue;
+    const uint64_t mine = sort_key(si, i);
+    int rank = lo;
+    for (int j = 0; j < cnt; ++j) { const int m = w.members[lo + j]; rank += (sort_key(scores[m], m) > mine); }
+    if (rank < k) {
+      sidx[rank] = i; sscores[rank] = si;
+      *(float4*)(sboxes + (long)rank * 4) = *(const float4*)(boxes + (long)i * 4);
+    }
   }
 }
 
@@ -97,52 +147,70 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     if (nms_hit(a, aarea, cbox[j], thr, cmp)) t |= 1ull << j;
   mask[(long)ri * cb + cbk] = t;
 }
+// Greedy scan over the bitmask, one 64-box block per phase, single workgroup of 16 waves:
+//   wave 0 (critical path): scans block j against remv[j] (only the kept boxes cost an iteration), then ORs the kept rows'
+//           words of column j+1 straight into remv[j+1];
+//   waves 1..15 (bulk, one phase behind): OR the kept rows of block j-1 into every column >= j+1 with fire-and-forget LDS
+//           atomics (coalesced along the row), overlapping wave 0's latency chain.
+// One barrier per phase; stops as soon as max_keep boxes are kept (RPN_POST_NMS_TOP_N).
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out) {
-  extern __shared__ unsigned long long remv[];   // cb words + 2
-  __shared__ unsigned long long kept_sh;
-  __shared__ int nk_sh;
+  extern __shared__ unsigned long long remv[];   // cb words
+  __shared__ unsigned long long kept_sh[2];
+  __shared__ int nk_sh[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < cb; c += 1024) remv[c] = 0ull;
-  if (tid == 0) nk_sh = 0;
+  if (tid == 0) { nk_sh[0] = nk_sh[1] = 0; kept_sh[0] = kept_sh[1] = 0ull; }
+  int nk = 0;   // running keep count (wave 0)
   __syncthreads();
+  unsigned long long dnext = 0ull;
+  if (wave == 0) dnext = lane < n ? mask[(long)lane * cb] : 0ull;
   for (int b = 0; b < cb; ++b) {
     if (wave == 0) {
       const int row = b * 64 + lane;
-      const unsigned long long d = row < n ? mask[(long)row * cb + b] : 0ull;
-      unsigned long long rb = remv[b];
-      unsigned long long K = 0ull;
+      const unsigned long long d = dnext;
+      if (b + 1 < cb) { const int r2 = row + 64; dnext = r2 < n ? mask[(long)r2 * cb + b + 1] : 0ull; }   // prefetch next diagonal
+      unsigned long long rbv = remv[b];
+      unsigned long long rb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(rbv >> 32)) << 32) |
+                              (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)rbv);
       const int lim = min(64, n - b * 64);
+      if (lim < 64) rb |= ~0ull << lim;
+      unsigned long long K = 0ull;
       const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
-      for (int i = 0; i < lim; ++i) {
-        if (!((rb >> i) & 1ull)) {
-          K |= 1ull << i;
-          unsigned int lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
-          rb |= ((unsigned long long)hi << 32) | lo;
+      while (~rb) {
+        const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)~rb) - 1);
+        K |= 1ull << i;
+        const unsigned int lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
+        rb |= (((unsigned long long)hi << 32) | lo) | (1ull << i);
+      }
+      const bool mine = (K >> lane) & 1ull;
+      if (mine) { const int pos = nk + __popcll(K & ((1ull << lane) - 1ull)); if (pos < max_keep) keep[pos] = row; }
+      // direct OR of column b+1 (needed by the very next phase)
+      if (b + 1 < cb) {
+        unsigned long long v = mine ? mask[(long)row * cb + b + 1] : 0ull;
+        for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+        if (lane == 0 && v) atomicOr(&remv[b + 1], v);
+      }
+      nk += __popcll(K);
+      if (lane == 0) { kept_sh[b & 1] = K; nk_sh[b & 1] = nk; }
+    } else if (b > 0) {
+      // bulk: block b-1's kept rows into columns >= b+1
+      const unsigned long long Kp = kept_sh[(b - 1) & 1];
+      const int c0 = b + 1, ncol = cb - c0;
+      if (Kp && ncol > 0) {
+        const int total = ncol * 64;
+        for (int idx = tid - 64; idx < total; idx += 960) {
+          const int r = idx / ncol, c = c0 + (idx - r * ncol);
+          if ((Kp >> r) & 1ull) {
+            const unsigned long long v = mask[(long)((b - 1) * 64 + r) * cb + c];
+            if (v) atomicOr(&remv[c], v);
+          }
         }
       }
-      const int nk = nk_sh;
-      if ((K >> lane) & 1ull) {
-        int pos = nk + __popcll(K & ((1ull << lane) - 1ull));
-        if (pos < max_keep) keep[pos] = row;
-      }
-      if (lane == 0) { kept_sh = K; nk_sh = nk + __popcll(K); }
     }
     __syncthreads();
-    const unsigned long long K = kept_sh;
-    if (nk_sh >= max_keep) break;
-    // OR the kept rows of this block into the columns to the right: thread = (column, 16-row group)
-    const int g = tid >> 8;
-    for (int c = b + 1 + (tid & 255); c < cb; c += 256) {
-      unsigned long long Kg = (K >> (16 * g)) & 0xFFFFull, acc = 0ull;
-      while (Kg) {
-        int i = __ffsll((long long)Kg) - 1; Kg &= Kg - 1;
-        acc |= mask[(long)(b * 64 + 16 * g + i) * cb + c];
-      }
-      if (acc) atomicOr(&remv[c], acc);
-    }
-    __syncthreads();
+    if (nk_sh[b & 1] >= max_keep) break;
   }
-  if (tid == 0) *num_out = min(nk_sh, max_keep);
+  if (tid == 0) *num_out = min(nk, max_keep);
 }
 __global__ void gather_rois_kernel(const float* sboxes, const float* sscores, const int* keep, const int* num, int max_keep, float* rois, float* rs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,7 +363,8 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
                                                    float* out_rois, int* labels, float* bt, float* bi, float* bo, float* mt,
                                                    int* counts, int* ws) {
   __shared__ int sh_cnt[4];
-  __shared__ float red[16];
+  __shared__ unsigned int s_key[4096];
+  __shared__ int s_idx[4096];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int cap = n_max + n_gt;
   int* fg_list = ws; int* bg_list = ws + cap; int* argm = ws + 2 * cap; int* cls = ws + 3 * cap; int* slot = ws + 4 * cap;  // slot[R]
@@ -349,19 +418,28 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
   __syncthreads();
   // rank by key inside each list; the k smallest keys are emitted in key order (= fg_inds[npr.choice(n,k,False)])
   if (!fg_repl) {
+    const bool lds = n_fg <= 4096;
+    if (lds) { for (int a = tid; a < n_fg; a += nt) { const int i = fg_list[a]; s_idx[a] = i; s_key[a] = fkey(i); } }
+    __syncthreads();
     for (int a = tid; a < n_fg; a += nt) {
       const int i = fg_list[a]; const uint32_t ki = fkey(i); int rank = 0;
-      for (int b = 0; b < n_fg; ++b) { const int j = fg_list[b]; const uint32_t kj = fkey(j); rank += (kj < ki) || (kj == ki && j < i); }
+      if (lds) for (int b = 0; b < n_fg; ++b) { const int j = s_idx[b]; const uint32_t kj = s_key[b]; rank += (kj < ki) || (kj == ki && j < i); }
+      else for (int b = 0; b < n_fg; ++b) { const int j = fg_list[b]; const uint32_t kj = fkey(j); rank += (kj < ki) || (kj == ki && j < i); }
       if (rank < nfg_sel) slot[rank] = i;
     }
+    __syncthreads();
   } else {
     for (int s = tid; s < nfg_sel; s += nt) slot[s] = fg_list[bg_rand[s] % (uint32_t)n_fg];
   }
   if (nbg_sel > 0) {
     if (!bg_repl) {
+      const bool lds = n_bg <= 4096;
+      if (lds) { for (int a = tid; a < n_bg; a += nt) { const int i = bg_list[a]; s_idx[a] = i; s_key[a] = bkey(i); } }
+      __syncthreads();
       for (int a = tid; a < n_bg; a += nt) {
         const int i = bg_list[a]; const uint32_t ki = bkey(i); int rank = 0;
-        for (int b = 0; b < n_bg; ++b) { const int j = bg_list[b]; const uint32_t kj = bkey(j); rank += (kj < ki) || (kj == ki && j < i); }
+        if (lds) for (int b = 0; b < n_bg; ++b) { const int j = s_idx[b]; const uint32_t kj = s_key[b]; rank += (kj < ki) || (kj == ki && j < i); }
+        else for (int b = 0; b < n_bg; ++b) { const int j = bg_list[b]; const uint32_t kj = bkey(j); rank += (kj < ki) || (kj == ki && j < i); }
         if (rank < nbg_sel) slot[nfg_sel + rank] = i;
       }
     } else {
@@ -476,10 +554,17 @@ extern "C" int l2s_rpn_decode(const float* heads, int ldh, const float* base_anc
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, heads, ldh, base_anchors, H, W, A, feat_stride, im_h, im_w, prob, boxes, scores);
   return l2s_check_launch();
 }
-extern "C" int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* rank_ws, float* sorted_boxes,
+extern "C" long l2s_sort_ws_ints(int n) { return 16 + 3L * NBKT + n + 16; }
+extern "C" int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* ws, float* sorted_boxes,
                              float* sorted_scores, int* sorted_idx, hipStream_t s) {
-  (void)rank_ws;
-  hipLaunchKernelGGL(rank_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, scores, boxes, n, k, sorted_boxes, sorted_scores, sorted_idx);
+  if (!ws || n <= 0) return L2S_EINVAL;
+  const int g = cdiv(n, 256);
+  hipLaunchKernelGGL(sort_init_kernel, dim3(33), dim3(256), 0, s, ws);
+  hipLaunchKernelGGL(sort_minmax_kernel, dim3(g > 256 ? 256 : g), dim3(256), 0, s, scores, n, ws);
+  hipLaunchKernelGGL(sort_hist_kernel, dim3(g), dim3(256), 0, s, scores, n, ws);
+  hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, ws);
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3(g), dim3(256), 0, s, scores, n, ws);
+  hipLaunchKernelGGL(sort_rank_kernel, dim3(g), dim3(256), 0, s, scores, boxes, n, k, (const int*)ws, sorted_boxes, sorted_scores, sorted_idx);
   return l2s_check_launch();
 }
 extern "C" size_t l2s_nms_workspace_bytes(int n) { return (size_t)n * (size_t)cdiv(n, 64) * 8; }

@@ -87,9 +87,15 @@ class resnetv1(Network):
         self._initial_state = sd
 
     def refresh_weights(self, full=False):
+        if not hasattr(self, 'extra_transposes'):
+            # 2x2 deconv: its forward operand [(dy,dx,co)][ci] is the transpose of the master [ci][(dy,dx,co)]
+            class _T(object):
+                pass
+            e = _T(); e.w_master, e.scale, e.wb, e.Np, e.k, e.Cin = self.P.view('mask_up_sampling.weight'), None, self.up_wT, 2048, 1, 4 * 256
+            self.extra_transposes = [e]
         Network.refresh_weights(self, full)
-        # 2x2 deconv: forward operand = transpose of the master [ci][(dy,dx,co)]
-        O.weight_transpose(self.P.view('mask_up_sampling.weight'), None, self.up_wT, 2048, 1, 4 * 256)
+        if full:
+            O.weight_transpose(self.P.view('mask_up_sampling.weight'), None, self.up_wT, 2048, 1, 4 * 256)
 
     # ------------------------------------------------------------------ helpers
     def _drop(self, name, shape, p):
@@ -111,6 +117,8 @@ class resnetv1(Network):
         return k
 
     # ------------------------------------------------------------------ language encoder (ENC:27-82)
+    # hidden/cell states are kept in (T+1)-row arrays with one all-zero row so that "previous state" is always a row of
+    # the same array: forward direction h(t) = row t+1, h(t-1) = row t; reverse direction h(t) = row t, previous = row t+1.
     def _encoder_fwd(self, d):
         P, T = self.P, d['T']
         Hh, E = self.opt['rnn_hidden_size'], self.opt['word_embedding_size']
@@ -121,48 +129,38 @@ class resnetv1(Network):
         x = self.buf('enc.x', (T, Hh), f32)
         O.linear_fwd(emb, P.view('rnn_encoder.mlp.0.weight'), P.view('rnn_encoder.mlp.0.bias'), x, T, Hh, E, act=1)
         hidden = self.buf('enc.hidden', (2 * Hh,), f32)
-        zero = self.buf('enc.zero', (Hh,), f32)
         for di, sfx in enumerate(['', '_reverse']):
             g = self.buf('enc.gates' + sfx, (T, 4 * Hh), f32)
             O.linear_fwd(x, P.view('rnn_encoder.rnn.weight_ih_l0' + sfx), P.view('rnn_encoder.rnn.bias_ih_l0' + sfx), g, T, 4 * Hh, Hh)
-            hs = self.buf('enc.h' + sfx, (T, Hh), f32); cs = self.buf('enc.c' + sfx, (T, Hh), f32)
+            hs = self.buf('enc.hfull' + sfx, (T + 1, Hh), f32); cs = self.buf('enc.cfull' + sfx, (T + 1, Hh), f32)
             act = self.buf('enc.act' + sfx, (T, 4 * Hh), f32)
-            order = list(range(T)) if di == 0 else list(range(T - 1, -1, -1))
-            hp, cp = zero, zero
-            for si, tt in enumerate(order):
-                O.linear_fwd(hp, P.view('rnn_encoder.rnn.weight_hh_l0' + sfx), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx), g[tt], 1, 4 * Hh, Hh,
-                             accumulate=True)
-                hout = hidden[di * Hh:(di + 1) * Hh] if si == T - 1 else hs[tt]
-                O.lstm_cell_fwd(g[tt], cp, cs[tt], hout, act[tt], Hh)
-                if si == T - 1:
-                    hs[tt].copy_(hout)
-                hp, cp = hs[tt], cs[tt]
-            t['enc.order' + sfx] = order
+            whh, bhh = P.view('rnn_encoder.rnn.weight_hh_l0' + sfx), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx)
+            for tt in (range(T) if di == 0 else range(T - 1, -1, -1)):
+                cur, prev = (tt + 1, tt) if di == 0 else (tt, tt + 1)
+                O.linear_fwd(hs[prev], whh, bhh, g[tt], 1, 4 * Hh, Hh, accumulate=True)
+                O.lstm_cell_fwd(g[tt], cs[prev], cs[cur], hs[cur], act[tt], Hh)
+            hidden[di * Hh:(di + 1) * Hh].copy_(hs[T] if di == 0 else hs[0])      # ENC:76-80
         t['enc.emb'], t['enc.x'], t['hidden'] = emb, x, hidden
         return hidden
 
     def _encoder_bwd(self, d, dhidden):
         P, T, t = self.P, d['T'], self.t
         Hh, E = self.opt['rnn_hidden_size'], self.opt['word_embedding_size']
-        zero = self.buf('enc.zero', (Hh,), f32)
         dx = self.buf('enc.dx', (T, Hh), f32, zero=True)
         for di, sfx in enumerate(['', '_reverse']):
-            order = t['enc.order' + sfx]
-            hs = self.buf('enc.h' + sfx, (T, Hh), f32); cs = self.buf('enc.c' + sfx, (T, Hh), f32)
+            hs = self.buf('enc.hfull' + sfx, (T + 1, Hh), f32); cs = self.buf('enc.cfull' + sfx, (T + 1, Hh), f32)
             act = self.buf('enc.act' + sfx, (T, 4 * Hh), f32)
             dg = self.buf('enc.dg' + sfx, (T, 4 * Hh), f32)
-            hprev = self.buf('enc.hprev' + sfx, (T, Hh), f32)
             dh = self.buf('enc.dh' + sfx, (2, Hh), f32); dc = self.buf('enc.dc' + sfx, (2, Hh), f32, zero=True)
             dh[0].copy_(dhidden[di * Hh:(di + 1) * Hh])
-            cur = 0
+            k = 0
             whh = P.view('rnn_encoder.rnn.weight_hh_l0' + sfx)
-            for si in range(T - 1, -1, -1):
-                tt = order[si]
-                cprev = cs[order[si - 1]] if si > 0 else zero
-                hprev[tt].copy_(hs[order[si - 1]] if si > 0 else zero)
-                O.lstm_cell_bwd(dh[cur], dc[cur], act[tt], cprev, cs[tt], dg[tt], dc[1 - cur], Hh)
-                O.linear_bwd_x(dg[tt], whh, dh[1 - cur], 1, 4 * Hh, Hh)
-                cur = 1 - cur
+            for tt in (range(T - 1, -1, -1) if di == 0 else range(T)):
+                cur, prev = (tt + 1, tt) if di == 0 else (tt, tt + 1)
+                O.lstm_cell_bwd(dh[k], dc[k], act[tt], cs[prev], cs[cur], dg[tt], dc[1 - k], Hh)
+                O.linear_bwd_x(dg[tt], whh, dh[1 - k], 1, 4 * Hh, Hh)
+                k = 1 - k
+            hprev = hs[0:T] if di == 0 else hs[1:T + 1]
             O.linear_bwd_w(dg, hprev, P.view('rnn_encoder.rnn.weight_hh_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx, P.grad), T, 4 * Hh, Hh)
             O.linear_bwd_w(dg, t['enc.x'], P.view('rnn_encoder.rnn.weight_ih_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_ih_l0' + sfx, P.grad), T, 4 * Hh, Hh)
             O.linear_bwd_x(dg, P.view('rnn_encoder.rnn.weight_ih_l0' + sfx), dx, T, 4 * Hh, Hh, accumulate=True)
@@ -173,10 +171,12 @@ class resnetv1(Network):
         O.embed_bwd(demb, t['enc.emb'], d['labels'], t['enc.drop'], P.view('rnn_encoder.embedding.weight', P.grad), T, E, False)
 
     # ------------------------------------------------------------------ att2in2 captioner (ATT:60-101,406-466; CRIT:43-53)
+    # states live in (S+1)-row arrays, row 0 = zeros: h(i) = row i+1, h(i-1) = row i.
     def _caption_fwd(self, d, att_feats, loss):
         P, t, S = self.P, self.t, d['S']
         R, IE, AH, L = self.opt['rnn_size'], self.opt['input_encoding_size'], self.opt['att_hid_size'], 196
         V1 = self.opt['vocab_size'] + 1
+        SC = 256                                             # per-row scratch tail of the attention kernels
         pv = lambda k: P.view('caption_model.' + k)
         a = self.buf('cap.a', (L, R), f32)
         self.att_embed.fwd(att_feats, L, 1, 1, a, relu=True, out_f32=True)
@@ -194,24 +194,21 @@ class resnetv1(Network):
         O.embed_fwd(pv('embed.0.weight'), d['cap_in'], t['cap.drop_xt'], xt, S, IE, True)
         sums = self.buf('cap.sums', (S, 5 * R), f32)
         O.linear_fwd(xt, pv('core.i2h.weight'), pv('core.i2h.bias'), sums, S, 5 * R, IE)
-        hs = self.buf('cap.h', (S, R), f32); cs = self.buf('cap.c', (S, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
+        hs = self.buf('cap.hfull', (S + 1, R), f32); cs = self.buf('cap.cfull', (S + 1, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
         att_h = self.buf('cap.att_h', (S, AH), f32); tanh_ws = self.buf('cap.tanh', (S, L, AH), f32)
-        wgt = self.buf('cap.wgt', (S, L), f32); ares = self.buf('cap.ares', (S, R), f32); a2c = self.buf('cap.a2c', (S, 2 * R), f32)
-        zero = self.buf('cap.zero', (R,), f32)
-        hp, cp = zero, zero
+        wgt = self.buf('cap.wgt', (S, L), f32); ares = self.buf('cap.ares', (S, R + SC), f32); a2c = self.buf('cap.a2c', (S, 2 * R), f32)
         for i in range(S):
-            O.linear_fwd(hp, pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), att_h[i], 1, AH, R)
+            O.linear_fwd(hs[i], pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), att_h[i], 1, AH, R)
             O.cap_attention_fwd(patt, ad, att_h[i], pv('core.attention.alpha_net.weight'), pv('core.attention.alpha_net.bias'), L, AH,
                                 tanh_ws[i], wgt[i], ares[i])
-            O.linear_fwd(hp, pv('core.h2h.weight'), pv('core.h2h.bias'), sums[i], 1, 5 * R, R, accumulate=True)
+            O.linear_fwd(hs[i], pv('core.h2h.weight'), pv('core.h2h.bias'), sums[i], 1, 5 * R, R, accumulate=True)
             O.linear_fwd(ares[i], pv('core.a2c.weight'), pv('core.a2c.bias'), a2c[i], 1, 2 * R, R)
-            O.cap_gates_fwd(sums[i], a2c[i], cp, cs[i], hs[i], save[i], R)
-            hp, cp = hs[i], cs[i]
+            O.cap_gates_fwd(sums[i], a2c[i], cs[i], cs[i + 1], hs[i + 1], save[i], R)
         t['cap.drop_out'] = self._drop('out', (S, R), self.opt['drop_prob_lm'])
         if t['cap.drop_out'] is not None:
-            ho = self.buf('cap.ho', (S, R), f32); O.mul(hs, t['cap.drop_out'], ho)
+            ho = self.buf('cap.ho', (S, R), f32); O.mul(hs[1:], t['cap.drop_out'], ho)
         else:
-            ho = hs
+            ho = hs[1:]
         logits = self.buf('cap.logits', (S, V1), f32)
         O.linear_fwd(ho, pv('logit.weight'), pv('logit.bias'), logits, S, V1, R)
         dlogits = self.buf('cap.dlogits', (S, V1), f32)
@@ -224,12 +221,12 @@ class resnetv1(Network):
         P, t, S = self.P, self.t, d['S']
         R, IE, AH, L = self.opt['rnn_size'], self.opt['input_encoding_size'], self.opt['att_hid_size'], 196
         V1 = self.opt['vocab_size'] + 1
+        SC = 256
         pv = lambda k: P.view('caption_model.' + k)
         gv = lambda k: P.view('caption_model.' + k, P.grad)
-        hs = self.buf('cap.h', (S, R), f32); cs = self.buf('cap.c', (S, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
+        hs = self.buf('cap.hfull', (S + 1, R), f32); cs = self.buf('cap.cfull', (S + 1, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
         tanh_ws = self.buf('cap.tanh', (S, L, AH), f32); wgt = self.buf('cap.wgt', (S, L), f32)
-        ares = self.buf('cap.ares', (S, R), f32)
-        zero = self.buf('cap.zero', (R,), f32)
+        ares = self.buf('cap.ares', (S, R + SC), f32)
         dlogits, ad = t['cap.dlogits'], t['cap.ad']
         O.linear_bwd_w(dlogits, t['cap.ho'], gv('logit.weight'), gv('logit.bias'), S, V1, R)
         dho = self.buf('cap.dho', (S, R), f32)
@@ -237,26 +234,23 @@ class resnetv1(Network):
         if t['cap.drop_out'] is not None:
             O.mul(dho, t['cap.drop_out'], dho)
         dsums = self.buf('cap.dsums', (S, 5 * R), f32); da2c = self.buf('cap.da2c', (S, 2 * R), f32)
-        datt_h = self.buf('cap.datt_h', (S, AH), f32); dares = self.buf('cap.dares', (R,), f32)
+        datt_h = self.buf('cap.datt_h', (S, AH + SC), f32); dares = self.buf('cap.dares', (R,), f32)
         dpatt = self.buf('cap.dpatt', (L, AH), f32, zero=True); dad = self.buf('cap.dad', (L, R), f32, zero=True)
-        hprev = self.buf('cap.hprev', (S, R), f32)
         dh = self.buf('cap.dh', (2, R), f32, zero=True); dc = self.buf('cap.dc', (2, R), f32, zero=True)
-        cur = 0
+        k = 0
         for i in range(S - 1, -1, -1):
-            # dh[cur] holds the recurrent part; add this step's output gradient
-            O.add3(dh[cur], dho[i], None, dh[cur])
-            cprev = cs[i - 1] if i > 0 else zero
-            hprev[i].copy_(hs[i - 1] if i > 0 else zero)
-            O.cap_gates_bwd(dh[cur], dc[cur], save[i], cprev, dsums[i], da2c[i], dc[1 - cur], R)
+            O.add3(dh[k], dho[i], None, dh[k])                       # recurrent part + this step's output gradient
+            O.cap_gates_bwd(dh[k], dc[k], save[i], cs[i], dsums[i], da2c[i], dc[1 - k], R)
             O.linear_bwd_x(da2c[i], pv('core.a2c.weight'), dares, 1, 2 * R, R)
             O.cap_attention_bwd(dares, ad, tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, dpatt, dad, datt_h[i],
                                 gv('core.attention.alpha_net.weight'), gv('core.attention.alpha_net.bias'))
-            O.linear_bwd_x(dsums[i], pv('core.h2h.weight'), dh[1 - cur], 1, 5 * R, R)
-            O.linear_bwd_x(datt_h[i], pv('core.attention.h2att.weight'), dh[1 - cur], 1, AH, R, accumulate=True)
-            cur = 1 - cur
-        O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R)
+            O.linear_bwd_x(dsums[i], pv('core.h2h.weight'), dh[1 - k], 1, 5 * R, R)
+            O.linear_bwd_x(datt_h[i], pv('core.attention.h2att.weight'), dh[1 - k], 1, AH, R, accumulate=True)
+            k = 1 - k
+        hprev = hs[0:S]
+        O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R, ldx=R + SC)
         O.linear_bwd_w(dsums, hprev, gv('core.h2h.weight'), gv('core.h2h.bias'), S, 5 * R, R)
-        O.linear_bwd_w(datt_h, hprev, gv('core.attention.h2att.weight'), gv('core.attention.h2att.bias'), S, AH, R)
+        O.linear_bwd_w(datt_h, hprev, gv('core.attention.h2att.weight'), gv('core.attention.h2att.bias'), S, AH, R, lddy=AH + SC)
         O.linear_bwd_w(dsums, t['cap.xt'], gv('core.i2h.weight'), gv('core.i2h.bias'), S, 5 * R, IE)
         dxt = self.buf('cap.dxt', (S, IE), f32)
         O.linear_bwd_x(dsums, pv('core.i2h.weight'), dxt, S, 5 * R, IE)
@@ -328,7 +322,7 @@ class resnetv1(Network):
         pre = int(cfg[key].RPN_PRE_NMS_TOP_N); post = int(cfg[key].RPN_POST_NMS_TOP_N)
         pre = nA if pre <= 0 else min(pre, nA)
         sb = self.buf('prop.sb', (pre, 4), f32); ss = self.buf('prop.ss', (pre,), f32); si = self.buf('prop.si', (pre,), torch.int32)
-        O.sort_topk(scores, boxes, nA, pre, sb, ss, si)                                      # PL:49-53
+        O.sort_topk(scores, boxes, nA, pre, self.buf('prop.sortws', (O.sort_ws_ints(nA),), torch.int32), sb, ss, si)                                      # PL:49-53
         nms_ws = self.buf('prop.nmsws', (O.nms_workspace_bytes(pre) // 8 + 8,), torch.int64)
         keep = self.buf('prop.keep', (post,), torch.int32); nkeep = self.buf('prop.nkeep', (1,), torch.int32)
         O.nms(sb, pre, float(cfg[key].RPN_NMS_THRESH), 0 if cfg.NMS_CMP == 'ge' else 1, post, nms_ws, keep, nkeep)   # PL:56-60

@@ -74,6 +74,10 @@ def weight_transpose(src, scale, dst, Cout, taps, Cin):
     call('l2s_weight_transpose', ptr(src), ptr(scale), ptr(dst), Cout, taps, Cin, dt_of(dst), stream())
 
 
+def weight_transpose_batched(table_dev, n, dt):
+    call('l2s_weight_transpose_batched', ptr(table_dev), n, dt, stream())
+
+
 def colsum(a, rows, cols, lda, out):
     call('l2s_colsum', ptr(a), rows, cols, lda, ptr(out), dt_of(a), stream())
 
@@ -134,8 +138,12 @@ def rpn_decode(heads, ldh, base_anchors, H, W, A, fs, im_h, im_w, prob, boxes, s
          ptr(scores), stream())
 
 
-def sort_topk(scores, boxes, n, k, sboxes, sscores, sidx):
-    call('l2s_sort_topk', ptr(scores), ptr(boxes), n, k, None, ptr(sboxes), ptr(sscores), ptr(sidx), stream())
+def sort_ws_ints(n):
+    return int(_lib.load().l2s_sort_ws_ints(n))
+
+
+def sort_topk(scores, boxes, n, k, ws, sboxes, sscores, sidx):
+    call('l2s_sort_topk', ptr(scores), ptr(boxes), n, k, ptr(ws), ptr(sboxes), ptr(sscores), ptr(sidx), stream())
 
 
 def nms_workspace_bytes(n):
