@@ -68,7 +68,7 @@ int l2s_weight_cast(const float* src, const float* scale, void* dst, int Cout, i
 /* data-gradient layout: dst(dtype)[Cin][taps][Cout], tap order reversed (180-degree flip), * scale[co] */
 int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
 /* all data-gradient copies of one step in one launch: table (DEVICE memory) of n descriptors */
-typedef struct { const float* src; const float* scale; void* dst; int Cout, taps, Cin, pad; } l2s_transpose_desc;
+typedef struct { const float* src; const float* scale; void* dst; int Cout, taps, Cin, force_f32; } l2s_transpose_desc;
 int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int dtype, hipStream_t s);
 /* column sums: out[c] += sum_r a[r][c] (bias gradients) */
 int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s);
@@ -177,7 +177,7 @@ int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, 
 
 /* ---------------------------------------------------------------- language side ------------- */
 /* small-M linear layers, fp32: y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y_in)) ; act 0 none, 1 relu, 2 tanh */
-int l2s_linear_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K, int act,
+int l2s_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* b, float* y, int ldy, int M, int N, int K, int act,
                    int accumulate, hipStream_t s);
 /* dx[m][k] (+)= sum_n dy[m][n] w[n][k] */
 int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate, hipStream_t s);

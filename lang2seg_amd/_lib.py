@@ -28,7 +28,7 @@ class WgradDesc(C.Structure):
 
 
 class TransposeDesc(C.Structure):
-    _fields_ = [('src', vp), ('scale', vp), ('dst', vp), ('Cout', i32), ('taps', i32), ('Cin', i32), ('pad', i32)]
+    _fields_ = [('src', vp), ('scale', vp), ('dst', vp), ('Cout', i32), ('taps', i32), ('Cin', i32), ('force_f32', i32)]
 
 
 class SgdSeg(C.Structure):
@@ -77,7 +77,7 @@ SIGS = {
     'l2s_mask_loss': (i32, [vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     'l2s_total_loss': (i32, [vp, f32, vp]),
     'l2s_maskpred_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
-    'l2s_linear_fwd': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'l2s_linear_fwd': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_linear_bwd_x': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_linear_bwd_w': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]),
     'l2s_act_bwd': (i32, [vp, vp, i64, i32, vp]),

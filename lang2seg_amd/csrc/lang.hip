@@ -17,9 +17,10 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y[m][n]));  one wave per n, M <= MAXM per pass
-template <int MT>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx_, const float* __restrict__ w,
+// y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y[m][n]));  one wave per n, M <= MT rows per pass.
+// VEC: 16-byte loads (rows 16-byte aligned: ldw, ldx, K multiples of 4); otherwise scalar loads.
+template <int MT, bool VEC>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx_, const float* __restrict__ w, int ldw,
                                                         const float* __restrict__ b, float* y, int ldy, int m0, int M, int N, int K,
                                                         int act, int accumulate) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -27,20 +28,24 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   float acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-  const float* wr = w + (long)n * K;
-  for (int k = lane * 4; k < K; k += 256) {
-    float4 wv;
-    if (k + 3 < K) wv = *(const float4*)(wr + k);
-    else { wv.x = wr[k]; wv.y = k + 1 < K ? wr[k + 1] : 0.f; wv.z = k + 2 < K ? wr[k + 2] : 0.f; wv.w = 0.f; }
+  const float* wr = w + (long)n * ldw;
+  if (VEC) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 wv = *(const float4*)(wr + k);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (m0 + m < M) {
-        const float* xr = x + (long)(m0 + m) * ldx_ + k;
-        float4 xv;
-        if (k + 3 < K) xv = *(const float4*)xr;
-        else { xv.x = xr[0]; xv.y = k + 1 < K ? xr[1] : 0.f; xv.z = k + 2 < K ? xr[2] : 0.f; xv.w = 0.f; }
-        acc[m] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[m]))));
+      for (int m = 0; m < MT; ++m) {
+        if (m0 + m < M) {
+          const float4 xv = *(const float4*)(x + (long)(m0 + m) * ldx_ + k);
+          acc[m] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[m]))));
+        }
       }
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) {
+      const float wv = wr[k];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (m0 + m < M) acc[m] = fmaf(wv, x[(long)(m0 + m) * ldx_ + k], acc[m]);
     }
   }
 #pragma unroll
@@ -375,16 +380,17 @@ __global__ __launch_bounds__(1024) void lsm_nll_kernel(const float* logits, cons
 
 }  // namespace
 
-extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, const float* b, float* y, int ldy, int M, int N, int K, int act,
+extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw, const float* b, float* y, int ldy, int M, int N, int K, int act,
                               int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0) return L2S_OK;
-  if ((K & 3) || (ldx_ & 3)) return L2S_EINVAL;
+  const bool vec = !((K & 3) || (ldx_ & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15));
   for (int m0 = 0; m0 < M; m0 += MAXM) {
     const int rem = M - m0;
     dim3 grid(cdiv(N, 4));
-    if (rem <= 1) hipLaunchKernelGGL(linear_fwd_kernel<1>, grid, dim3(256), 0, s, x, ldx_, w, b, y, ldy, m0, M, N, K, act, accumulate);
-    else if (rem <= 8) hipLaunchKernelGGL(linear_fwd_kernel<8>, grid, dim3(256), 0, s, x, ldx_, w, b, y, ldy, m0, M, N, K, act, accumulate);
-    else hipLaunchKernelGGL(linear_fwd_kernel<MAXM>, grid, dim3(256), 0, s, x, ldx_, w, b, y, ldy, m0, M, N, K, act, accumulate);
+#define LF(MT) do { if (vec) hipLaunchKernelGGL((linear_fwd_kernel<MT, true>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
+                    else hipLaunchKernelGGL((linear_fwd_kernel<MT, false>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); } while (0)
+    if (rem <= 1) LF(1); else if (rem <= 8) LF(8); else LF(MAXM);
+#undef LF
   }
   return l2s_check_launch();
 }

@@ -46,6 +46,7 @@ __global__ void weight_transpose_kernel(const float* __restrict__ src, const flo
 __global__ void weight_transpose_batched_kernel(const l2s_transpose_desc* __restrict__ table, int dt) {
   __shared__ float tile[32][33];
   const l2s_transpose_desc d = table[blockIdx.y];
+  if (d.force_f32) dt = L2S_F32;
   const int tci = (d.Cin + 31) / 32, tco = (d.Cout + 31) / 32;
   const int ntiles = tci * tco * d.taps;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;

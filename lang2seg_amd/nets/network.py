@@ -210,19 +210,19 @@ class Network(object):
             yield k, from_internal(k, self.P.view(k), self.P.shapes[k])
 
     def refresh_weights(self, full=False):
-        """after every optimiser step: rebuild the data-gradient (transposed, BN-folded) weight copies in one launch."""
+        """after every optimiser step: rebuild the data-gradient (transposed, BN-folded) weight copies and the fp32
+        transposes of the skinny language-side matrices in ONE launch; `full` also re-casts the frozen layers."""
         if full:
             for c in self.convs:
-                c.refresh(True)
-            return
+                if not c.trainable:
+                    O.weight_cast(c.w_master, c.scale, c.wf, c.Np, c.k * c.k, c.Cin)
         if getattr(self, '_tr_table', None) is None:
-            import ctypes as C
             from .._lib import TransposeDesc
             items = [c for c in self.convs if c.wb is not None] + list(getattr(self, 'extra_transposes', []))
             arr = (TransposeDesc * len(items))()
             for i, c in enumerate(items):
                 arr[i].src, arr[i].scale, arr[i].dst = c.w_master.data_ptr(), (c.scale.data_ptr() if c.scale is not None else None), c.wb.data_ptr()
-                arr[i].Cout, arr[i].taps, arr[i].Cin = c.Np, c.k * c.k, c.Cin
+                arr[i].Cout, arr[i].taps, arr[i].Cin, arr[i].force_f32 = c.Np, c.k * c.k, c.Cin, int(getattr(c, 'force_f32', 0))
             self._tr_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             self._tr_n = len(items)
         O.weight_transpose_batched(self._tr_table, self._tr_n, self.dt)

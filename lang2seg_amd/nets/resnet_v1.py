@@ -86,16 +86,39 @@ class resnetv1(Network):
             sd[k] = t.view(shp)
         self._initial_state = sd
 
+    def _make_transposes(self):
+        """fp32 transposes [K][N] of the skinny (batch-1) matrices: their data gradients dx = dy . W then run through the same
+        one-wave-per-output GEMV kernel as the forward pass (no atomics, full-chip parallelism even at K = 512)."""
+        class _T(object):
+            pass
+        P = self.P
+        self.wT, self.extra_transposes = {}, []
+        def add(name, src, N, K, dst=None, f32=1):
+            e = _T(); e.w_master, e.scale, e.Np, e.k, e.Cin, e.force_f32 = src, None, N, 1, K, f32
+            e.wb = torch.zeros(K * N, dtype=torch.float32, device=self.device) if dst is None else dst
+            self.extra_transposes.append(e)
+            if dst is None:
+                self.wT[name] = (e.wb, N, K)
+        for sfx in ['', '_reverse']:
+            for w in ['rnn_encoder.rnn.weight_hh_l0', 'rnn_encoder.rnn.weight_ih_l0']:
+                add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
+        for k in ['rnn_encoder.mlp.0.weight', 'caption_model.logit.weight', 'caption_model.core.a2c.weight', 'caption_model.core.h2h.weight',
+                  'caption_model.core.attention.h2att.weight', 'caption_model.core.i2h.weight', 'caption_model.ctx2att.weight']:
+            add(k, P.view(k), *P.shapes[k])
+        NF, HD = 7 * self._C4_feat_dim + 7, P.shapes['response_fc.weight'][1]
+        add('dyn_w', P.gview('dyn_w', NF * HD), NF, HD)
+        # 2x2 deconv: its forward operand [(dy,dx,co)][ci] is the transpose of the master [ci][(dy,dx,co)] (activation dtype)
+        add('mask_up', P.view('mask_up_sampling.weight'), 2048, 4 * 256, dst=self.up_wT, f32=0)
+
+    def bwd_x(self, dy, name, dx, M, accumulate=False, lddy=None):
+        """dx[M][K] (+)= dy[M][N] . W[N][K] using the transposed copy."""
+        wT, N, K = self.wT[name]
+        O.linear_fwd(dy, wT, None, dx, M, K, N, accumulate=accumulate, ldx=N if lddy is None else lddy, ldw=N)
+
     def refresh_weights(self, full=False):
         if not hasattr(self, 'extra_transposes'):
-            # 2x2 deconv: its forward operand [(dy,dx,co)][ci] is the transpose of the master [ci][(dy,dx,co)]
-            class _T(object):
-                pass
-            e = _T(); e.w_master, e.scale, e.wb, e.Np, e.k, e.Cin = self.P.view('mask_up_sampling.weight'), None, self.up_wT, 2048, 1, 4 * 256
-            self.extra_transposes = [e]
+            self._make_transposes()
         Network.refresh_weights(self, full)
-        if full:
-            O.weight_transpose(self.P.view('mask_up_sampling.weight'), None, self.up_wT, 2048, 1, 4 * 256)
 
     # ------------------------------------------------------------------ helpers
     def _drop(self, name, shape, p):
@@ -158,16 +181,16 @@ class resnetv1(Network):
             for tt in (range(T - 1, -1, -1) if di == 0 else range(T)):
                 cur, prev = (tt + 1, tt) if di == 0 else (tt, tt + 1)
                 O.lstm_cell_bwd(dh[k], dc[k], act[tt], cs[prev], cs[cur], dg[tt], dc[1 - k], Hh)
-                O.linear_bwd_x(dg[tt], whh, dh[1 - k], 1, 4 * Hh, Hh)
+                self.bwd_x(dg[tt], 'rnn_encoder.rnn.weight_hh_l0' + sfx, dh[1 - k], 1)
                 k = 1 - k
             hprev = hs[0:T] if di == 0 else hs[1:T + 1]
             O.linear_bwd_w(dg, hprev, P.view('rnn_encoder.rnn.weight_hh_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx, P.grad), T, 4 * Hh, Hh)
             O.linear_bwd_w(dg, t['enc.x'], P.view('rnn_encoder.rnn.weight_ih_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_ih_l0' + sfx, P.grad), T, 4 * Hh, Hh)
-            O.linear_bwd_x(dg, P.view('rnn_encoder.rnn.weight_ih_l0' + sfx), dx, T, 4 * Hh, Hh, accumulate=True)
+            self.bwd_x(dg, 'rnn_encoder.rnn.weight_ih_l0' + sfx, dx, T, accumulate=True)
         O.act_bwd(dx, t['enc.x'], 1)
         O.linear_bwd_w(dx, t['enc.emb'], P.view('rnn_encoder.mlp.0.weight', P.grad), P.view('rnn_encoder.mlp.0.bias', P.grad), T, Hh, E)
         demb = self.buf('enc.demb', (T, E), f32)
-        O.linear_bwd_x(dx, P.view('rnn_encoder.mlp.0.weight'), demb, T, Hh, E)
+        self.bwd_x(dx, 'rnn_encoder.mlp.0.weight', demb, T)
         O.embed_bwd(demb, t['enc.emb'], d['labels'], t['enc.drop'], P.view('rnn_encoder.embedding.weight', P.grad), T, E, False)
 
     # ------------------------------------------------------------------ att2in2 captioner (ATT:60-101,406-466; CRIT:43-53)
@@ -230,7 +253,7 @@ class resnetv1(Network):
         dlogits, ad = t['cap.dlogits'], t['cap.ad']
         O.linear_bwd_w(dlogits, t['cap.ho'], gv('logit.weight'), gv('logit.bias'), S, V1, R)
         dho = self.buf('cap.dho', (S, R), f32)
-        O.linear_bwd_x(dlogits, pv('logit.weight'), dho, S, V1, R)
+        self.bwd_x(dlogits, 'caption_model.logit.weight', dho, S)
         if t['cap.drop_out'] is not None:
             O.mul(dho, t['cap.drop_out'], dho)
         dsums = self.buf('cap.dsums', (S, 5 * R), f32); da2c = self.buf('cap.da2c', (S, 2 * R), f32)
@@ -241,11 +264,11 @@ class resnetv1(Network):
         for i in range(S - 1, -1, -1):
             O.add3(dh[k], dho[i], None, dh[k])                       # recurrent part + this step's output gradient
             O.cap_gates_bwd(dh[k], dc[k], save[i], cs[i], dsums[i], da2c[i], dc[1 - k], R)
-            O.linear_bwd_x(da2c[i], pv('core.a2c.weight'), dares, 1, 2 * R, R)
+            self.bwd_x(da2c[i], 'caption_model.core.a2c.weight', dares, 1)
             O.cap_attention_bwd(dares, ad, tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, dpatt, dad, datt_h[i],
                                 gv('core.attention.alpha_net.weight'), gv('core.attention.alpha_net.bias'))
-            O.linear_bwd_x(dsums[i], pv('core.h2h.weight'), dh[1 - k], 1, 5 * R, R)
-            O.linear_bwd_x(datt_h[i], pv('core.attention.h2att.weight'), dh[1 - k], 1, AH, R, accumulate=True)
+            self.bwd_x(dsums[i], 'caption_model.core.h2h.weight', dh[1 - k], 1)
+            self.bwd_x(datt_h[i], 'caption_model.core.attention.h2att.weight', dh[1 - k], 1, accumulate=True)
             k = 1 - k
         hprev = hs[0:S]
         O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R, ldx=R + SC)
@@ -253,11 +276,11 @@ class resnetv1(Network):
         O.linear_bwd_w(datt_h, hprev, gv('core.attention.h2att.weight'), gv('core.attention.h2att.bias'), S, AH, R, lddy=AH + SC)
         O.linear_bwd_w(dsums, t['cap.xt'], gv('core.i2h.weight'), gv('core.i2h.bias'), S, 5 * R, IE)
         dxt = self.buf('cap.dxt', (S, IE), f32)
-        O.linear_bwd_x(dsums, pv('core.i2h.weight'), dxt, S, 5 * R, IE)
+        self.bwd_x(dsums, 'caption_model.core.i2h.weight', dxt, S)
         O.embed_bwd(dxt, t['cap.xt'], d['cap_in'], t['cap.drop_xt'], gv('embed.0.weight'), S, IE, True)
         # ctx2att
         O.linear_bwd_w(dpatt, ad, gv('ctx2att.weight'), gv('ctx2att.bias'), L, AH, R)
-        O.linear_bwd_x(dpatt, pv('ctx2att.weight'), dad, L, AH, R, accumulate=True)
+        self.bwd_x(dpatt, 'caption_model.ctx2att.weight', dad, L, accumulate=True)
         if t['cap.drop_att'] is not None:
             O.mul(dad, t['cap.drop_att'], dad)
         O.act_bwd(dad, t['cap.a_pre'], 1)
@@ -441,7 +464,7 @@ class resnetv1(Network):
         O.act_bwd(dfilt, filt, 2)
         O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NF * HD, P.grad), P.gview('dyn_b', NF, P.grad), 1, NF, HD)
         dhidden = self.buf('enc.dhidden', (HD,), f32)
-        O.linear_bwd_x(dfilt, P.gview('dyn_w', NF * HD), dhidden, 1, NF, HD)
+        self.bwd_x(dfilt, 'dyn_w', dhidden, 1)
         self._encoder_bwd(d, dhidden)
         if dp is not None:
             dp.ready('language')

@@ -211,9 +211,9 @@ def maskpred_bwd(dscore, labels, num_fg, fg_max, ms2, Cc, w, x, ref, dx, dw, db)
 
 
 # ------------------------------------------------------------------ language side (fp32)
-def linear_fwd(x, w, b, y, M, N, K, act=0, accumulate=False, ldx=None, ldy=None):
-    call('l2s_linear_fwd', ptr(x), K if ldx is None else ldx, ptr(w), ptr(b), ptr(y), N if ldy is None else ldy, M, N, K,
-         act, 1 if accumulate else 0, stream())
+def linear_fwd(x, w, b, y, M, N, K, act=0, accumulate=False, ldx=None, ldy=None, ldw=None):
+    call('l2s_linear_fwd', ptr(x), K if ldx is None else ldx, ptr(w), K if ldw is None else ldw, ptr(b), ptr(y),
+         N if ldy is None else ldy, M, N, K, act, 1 if accumulate else 0, stream())
 
 
 def linear_bwd_x(dy, w, dx, M, N, K, accumulate=False, lddy=None, lddx=None):
