@@ -48,6 +48,8 @@ typedef struct {
   int flags;
   int out_h, out_w, out_stride; /* SCATTER */
   int tile;                     /* 0 = auto, 64 or 128 */
+  int split_k;                  /* 0 = auto, 1 = off, n = force (needs ws) */
+  float* ws;                    /* optional ALL-ZERO float workspace >= rows*Cout for split-K partial sums; returned all-zero */
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);
 

@@ -120,13 +120,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int KT = (K + BK - 1) / BK;
-  load_slice(0);
+  const int KT_all = (K + BK - 1) / BK;
+  int kt0 = 0, KT = KT_all;
+  if (gridDim.z > 1) {                      // split-K: this workgroup owns slices [kt0, KT)
+    const int per = (KT_all + gridDim.z - 1) / gridDim.z;
+    kt0 = blockIdx.z * per; KT = min(KT_all, kt0 + per);
+    if (kt0 >= KT) return;
+  }
+  load_slice(kt0);
   store_slice(0);
   __syncthreads();
   const int fr = lane & 15, fg = lane >> 4;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < KT; ++kt) {
+    const int cur = (kt - kt0) & 1;
     if (kt + 1 < KT) load_slice(kt + 1);
     const char* a = smem + cur * BUF + (wm * WM + fr) * LROW + fg * 16;
     const char* b = smem + cur * BUF + BM * LROW + (wn * WN + fr) * LROW + fg * 16;
@@ -146,6 +152,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
     __syncthreads();
   }
 
+  if (gridDim.z > 1) {
+    // split-K partial sums: fp32 atomic accumulate into the (pre-zeroed) workspace; bias/add/ReLU run in splitk_epilogue
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WM + i * 16 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + fg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.Cout) atomicAdd(p.ws + (long)m * p.Cout + n + r, acc[i][j][r]);
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 tile ----
   const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
 #pragma unroll
@@ -353,14 +375,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p) {
     }
 }
 
+// y = epilogue(ws) and ws = 0 (so the workspace is clean for the next split-K launch)
+template <typename T, bool OUTF32>
+__global__ void splitk_epilogue_kernel(const l2s_conv_desc p, long total) {
+  for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; e < total; e += (long)gridDim.x * blockDim.x * 4) {
+    const long m = e / p.Cout; const int n = (int)(e - m * p.Cout);
+    float4 v4 = *(float4*)(p.ws + e);
+    *(float4*)(p.ws + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (p.bias) v[r] += p.bias[n + r];
+      if (p.add) v[r] += Elem<T>::ld((const T*)p.add + m * p.ldadd + n + r);
+      if (p.flags & L2S_CONV_RELU) v[r] = fmaxf(v[r], 0.f);
+      if (p.ref) { if (!(Elem<T>::ld((const T*)p.ref + m * p.ldref + n + r) > 0.f)) v[r] = 0.f; }
+    }
+    if (OUTF32) { float* o = (float*)p.y + m * p.ldy + n; for (int r = 0; r < 4; ++r) o[r] = v[r]; }
+    else { T* o = (T*)p.y + m * p.ldy + n; for (int r = 0; r < 4; ++r) Elem<T>::st(o + r, v[r]); }
+  }
+}
+
 template <typename T, int BM, int BN, bool OUTF32>
 int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
-  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN));
+  int split = 1;
+  if (d.ws && BM == 64 && !(d.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) && (d.Cout % 4 == 0)) {
+    const int K = d.KH * d.KW * d.Cin, KT = cdiv(K, ROWB / (int)sizeof(T));
+    const long tiles = (long)cdiv(M, BM) * cdiv(d.Cout, BN);
+    if (d.split_k > 0) split = d.split_k;
+    else if (tiles < 600 && KT >= 8) { split = (int)((1024 + tiles - 1) / tiles); if (split > KT / 2) split = KT / 2; if (split > 16) split = 16; }
+    if (split < 1) split = 1;
+  }
+  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN), split);
   size_t lds = 2 * (BM + BN) * LROW;
   static bool attr_done = false;
   if (!attr_done) { hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, OUTF32>), grid, dim3(256), lds, st, d);
+  if (split > 1) {
+    const long total = (long)M * d.Cout;
+    long g = (total / 4 + 255) / 256; if (g > 2048) g = 2048;
+    hipLaunchKernelGGL((splitk_epilogue_kernel<T, OUTF32>), dim3((int)g), dim3(256), 0, st, d, total);
+  }
   return l2s_check_launch();
 }
 

@@ -67,7 +67,7 @@ class ConvOp(object):
     def fwd(self, x, n, IH, IW, y, add=None, relu=False, out_f32=False, tile=0):
         OH, OW = self.out_hw(IH, IW)
         O.conv_igemm(x, self.wf, y, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad,
-                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt)
+                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt, ws=self.net.splitk_ws(n * OH * OW * self.Np))
         return y
 
     def dgrad(self, g, n, IH, IW, dx, add=None, ref=None):
@@ -75,7 +75,7 @@ class ConvOp(object):
         OH, OW = self.out_hw(IH, IW)
         if self.stride == 1:
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, IH, IW, self.Cin, self.k, self.k, 1, self.k - 1 - self.pad,
-                         add=add, ref=ref, dt=self.net.dt)
+                         add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin))
         else:
             assert self.k == 1
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, OH, OW, self.Cin, 1, 1, 1, 0, add=add, ref=ref,
@@ -181,6 +181,15 @@ class Network(object):
         elif zero:
             t.zero_()
         return t
+
+    def splitk_ws(self, need):
+        """shared all-zero fp32 workspace for split-K partial sums (every launch hands it back zeroed)."""
+        if need > 4 * 1024 * 1024:          # only small-M problems are split
+            return None
+        ws = getattr(self, '_skws', None)
+        if ws is None:
+            ws = self._skws = torch.zeros(4 * 1024 * 1024, dtype=torch.float32, device=self.device)
+        return ws
 
     def _init_modules(self):
         raise NotImplementedError

@@ -67,6 +67,14 @@ def test_conv_fwd(cfg, dt):
     O.conv_igemm(xd, wd, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=b.to(DEV), add=rd, relu=True, tile=cfg.get('tile', 0))
     torch.cuda.synchronize()
     assert rel_err(y.float().view(n, OH, OW, Cout), nhwc(ref)) < TOL[dt]
+    # split-K path (fp32 atomic partials + epilogue kernel), same epilogue
+    if Cout % 4 == 0:
+        ws = torch.zeros(n * OH * OW * Cout, dtype=torch.float32, device=DEV)
+        y3 = O.empty((n * OH * OW, Cout), dt)
+        O.conv_igemm(xd, wd, y3, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=b.to(DEV), add=rd, relu=True, tile=64, ws=ws, split_k=3)
+        torch.cuda.synchronize()
+        assert rel_err(y3.float().view(n, OH, OW, Cout), nhwc(ref)) < TOL[dt]
+        assert float(ws.abs().max()) == 0.0
     # fp32 output + no epilogue
     y2 = torch.empty((n * OH * OW, Cout), dtype=torch.float32, device=DEV)
     O.conv_igemm(xd, wd, y2, n, H, W, Cin, OH, OW, Cout, k, k, s, p, out_f32=True)
