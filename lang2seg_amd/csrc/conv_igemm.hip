@@ -19,6 +19,7 @@
 // up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 #include "common.h"
 #include "../../include/lang2seg_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,6 +42,93 @@ template <> struct Mma<float> {
 
 constexpr int ROWB = 128;        // bytes of K per LDS row per slice
 constexpr int LROW = ROWB + 16;  // padded LDS row
+
+// ---- shared epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 accumulator tile ----
+template <typename T, int TM, int TN, int WM, int WN, bool OUTF32>
+__device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M) {
+  const int ohw = p.OH * p.OW;
+  const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
+  const bool vec_ok = ((p.ldy & 3) == 0) && ((p.ldadd & 3) == 0) && ((p.ldref & 3) == 0) && ((Cq & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + fr;
+    if (m >= M) continue;
+    long orow = m;
+    int n_img = 0, oy = 0, ox = 0;
+    if (p.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) {
+      n_img = m / ohw; int rem = m - n_img * ohw; oy = rem / p.OW; ox = rem - oy * p.OW;
+      if (p.flags & L2S_CONV_SCATTER) orow = ((long)n_img * p.out_h + (long)oy * p.out_stride) * p.out_w + (long)ox * p.out_stride;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fg * 4;
+      if (n >= p.Cout) continue;
+      int oc = n; long orow2 = orow;
+      if (p.flags & L2S_CONV_DECONV2X2) {
+        int tap = n / Cq; oc = n - tap * Cq;
+        orow2 = ((long)n_img * 2 * p.OH + 2 * oy + (tap >> 1)) * (2 * p.OW) + 2 * ox + (tap & 1);
+      }
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      const bool full = (n + 3 < p.Cout);
+      if (full && vec_ok) {
+        if (p.bias) { const float4 b4 = *(const float4*)(p.bias + oc); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+        if (p.add) {
+          const T* ap = (const T*)p.add + orow2 * p.ldadd + oc;
+          if (sizeof(T) == 4) { const float4 a4 = *(const float4*)ap; v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w; }
+          else { const uint2 a2 = *(const uint2*)ap; v[0] += __uint_as_float(a2.x << 16); v[1] += __uint_as_float(a2.x & 0xFFFF0000u);
+                 v[2] += __uint_as_float(a2.y << 16); v[3] += __uint_as_float(a2.y & 0xFFFF0000u); }
+        }
+        if (p.flags & L2S_CONV_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (p.ref) {
+          const T* rp = (const T*)p.ref + orow2 * p.ldref + oc;
+          float rv[4];
+          if (sizeof(T) == 4) { const float4 r4 = *(const float4*)rp; rv[0] = r4.x; rv[1] = r4.y; rv[2] = r4.z; rv[3] = r4.w; }
+          else { const uint2 r2 = *(const uint2*)rp; rv[0] = __uint_as_float(r2.x << 16); rv[1] = __uint_as_float(r2.x & 0xFFFF0000u);
+                 rv[2] = __uint_as_float(r2.y << 16); rv[3] = __uint_as_float(r2.y & 0xFFFF0000u); }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (!(rv[r] > 0.f)) v[r] = 0.f;
+        }
+        if (OUTF32 || sizeof(T) == 4) {
+          *(float4*)((float*)p.y + orow2 * p.ldy + oc) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 pk;
+          pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *(uint2*)((T*)p.y + orow2 * p.ldy + oc) = pk;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.Cout) break;
+          if (p.bias) v[r] += p.bias[oc + r];
+          if (p.add) v[r] += Elem<T>::ld((const T*)p.add + orow2 * p.ldadd + oc + r);
+          if (p.flags & L2S_CONV_RELU) v[r] = fmaxf(v[r], 0.f);
+          if (p.ref) { if (!(Elem<T>::ld((const T*)p.ref + orow2 * p.ldref + oc + r) > 0.f)) v[r] = 0.f; }
+          if (OUTF32) ((float*)p.y)[orow2 * p.ldy + oc + r] = v[r];
+          else Elem<T>::st((T*)p.y + orow2 * p.ldy + oc + r, v[r]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_splitk_atomics(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fg * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < p.Cout) atomicAdd(p.ws + (long)m * p.Cout + n + r, acc[i][j][r]);
+    }
+  }
+}
 
 template <typename T, int BM, int BN, bool OUTF32>
 __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
@@ -152,75 +240,132 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
     __syncthreads();
   }
 
-  if (gridDim.z > 1) {
-    // split-K partial sums: fp32 atomic accumulate into the (pre-zeroed) workspace; bias/add/ReLU run in splitk_epilogue
+  if (gridDim.z > 1) { igemm_splitk_atomics<T, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, fr, fg, M); return; }
+  igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined variant: operands go HBM -> LDS directly (global_load_lds_dwordx4, no register staging) into a ring of
+// STAGES slices; each iteration waits (counted vmcnt) only for the oldest slice, so STAGES-1 slices of loads stay in
+// flight across the single per-slice barrier.  LDS rows are unpadded 128-byte rows (an LDS-DMA wave instruction writes
+// 1 KiB = 8 rows linearly), made bank-conflict-free by XOR-swizzling the 16-byte chunk index with (row & 7) on the
+// per-lane SOURCE address and on the fragment reads.  Out-of-image / out-of-range rows read a zero page.
+// The LDS-DMA is issued from inline asm so that hipcc's waitcnt pass does not drain it before every ds_read.
+// ------------------------------------------------------------------------------------------------
+__device__ uint4 l2s_zero_page[8];
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int STAGES, bool OUTF32>
+__global__ __launch_bounds__(256) void igemm_pipe_kernel(const l2s_conv_desc p) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int NA = BM / 32, NB = BN / 32;        // LDS-DMA instructions per wave per slice (A, B)
+  constexpr int IPS = NA + NB;
+  constexpr int BUF = (BM + BN) * ROWB;
+  static_assert((STAGES - 2) * IPS <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  const T* __restrict__ X = (const T*)p.x;
+  const T* __restrict__ Wt = (const T*)p.w;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const char* zp = (const char*)l2s_zero_page + (lane & 7) * 16;
+
+  // lane -> (row inside an 8-row DMA piece, physical 16-byte chunk); source chunk = phys ^ (row & 7)
+  const int prow = lane >> 3, pch = lane & 7, sch = pch ^ prow;
+  int a_iy0[NA], a_ix0[NA]; long a_base[NA]; bool a_ok[NA];
+  const int ohw = p.OH * p.OW;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * WM + i * 16 + fr;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + fg * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.Cout) atomicAdd(p.ws + (long)m * p.Cout + n + r, acc[i][j][r]);
-      }
-    }
-    return;
+  for (int j = 0; j < NA; ++j) {
+    const int m = m0 + 8 * (wave + 4 * j) + prow;
+    a_ok[j] = m < M;
+    const int mm = a_ok[j] ? m : 0;
+    const int n_img = mm / ohw, rem = mm - n_img * ohw;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    a_iy0[j] = oy * p.stride - p.pad;
+    a_ix0[j] = ox * p.stride - p.pad;
+    a_base[j] = (long)n_img * p.IH * p.IW;
   }
-  // ---- epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 tile ----
-  const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
+  long b_off[NB]; bool b_ok[NB];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * WM + i * 16 + fr;
-    if (m >= M) continue;
-    long orow = m;
-    int n_img = 0, oy = 0, ox = 0;
-    if (p.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) {
-      n_img = m / ohw; int rem = m - n_img * ohw; oy = rem / p.OW; ox = rem - oy * p.OW;
-      if (p.flags & L2S_CONV_SCATTER) orow = ((long)n_img * p.out_h + (long)oy * p.out_stride) * p.out_w + (long)ox * p.out_stride;
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + 8 * (wave + 4 * j) + prow;
+    b_ok[j] = n < p.Cout;
+    b_off[j] = (long)(b_ok[j] ? n : 0) * K;
+  }
+  auto issue_slice = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    int tap = 0, c0 = k0;
+    if (p.KH * p.KW > 1) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; }
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const bool kin = (k0 + sch * VE) < K;
+    const unsigned abase = lds0 + buf * BUF, bbase = abase + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+      const bool ok = a_ok[j] && kin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      const void* src = ok ? (const void*)(X + ((a_base[j] + (long)iy * p.IW + ix) * p.ldx + c0 + sch * VE)) : (const void*)zp;
+      glds16(src, abase + 8 * (wave + 4 * j) * ROWB);
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WN + j * 16 + fg * 4;
-      if (n >= p.Cout) continue;
-      int oc = n; long orow2 = orow;
-      if (p.flags & L2S_CONV_DECONV2X2) {
-        int tap = n / Cq; oc = n - tap * Cq;
-        orow2 = ((long)n_img * 2 * p.OH + 2 * oy + (tap >> 1)) * (2 * p.OW) + 2 * ox + (tap & 1);
-      }
-      float v[4];
+    for (int j = 0; j < NB; ++j) {
+      const void* src = (b_ok[j] && kin) ? (const void*)(Wt + b_off[j] + k0 + sch * VE) : (const void*)zp;
+      glds16(src, bbase + 8 * (wave + 4 * j) * ROWB);
+    }
+  };
+
+  f32x4 acc[TM][TN];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-      const bool full = (n + 3 < p.Cout);
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (!full && n + r >= p.Cout) break;
-        if (p.bias) v[r] += p.bias[oc + r];
-        if (p.add) v[r] += Elem<T>::ld((const T*)p.add + orow2 * p.ldadd + oc + r);
-        if (p.flags & L2S_CONV_RELU) v[r] = fmaxf(v[r], 0.f);
-        if (p.ref) { if (!(Elem<T>::ld((const T*)p.ref + orow2 * p.ldref + oc + r) > 0.f)) v[r] = 0.f; }
-      }
-      if (OUTF32) {
-        float* o = (float*)p.y + orow2 * p.ldy + oc;
-        if (full && ((p.ldy & 3) == 0) && ((oc & 3) == 0)) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-        else for (int r = 0; r < 4 && n + r < p.Cout; ++r) o[r] = v[r];
-      } else {
-        T* o = (T*)p.y + orow2 * p.ldy + oc;
-        if (sizeof(T) == 4) {
-          if (full && ((p.ldy & 3) == 0) && ((oc & 3) == 0)) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-          else for (int r = 0; r < 4 && n + r < p.Cout; ++r) Elem<T>::st(o + r, v[r]);
-        } else {
-          if (full && ((p.ldy & 3) == 0) && ((oc & 3) == 0)) {
-            uint2 pk;
-            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *(uint2*)o = pk;
-          } else for (int r = 0; r < 4 && n + r < p.Cout; ++r) Elem<T>::st(o + r, v[r]);
-        }
-      }
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int KT = (K + BK - 1) / BK;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < KT) issue_slice(s, s);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = fr & 7;
+  const int offa = (wm * WM + fr) * ROWB, offb = BM * ROWB + (wn * WN + fr) * ROWB;
+  for (int kt = 0; kt < KT; ++kt) {
+    // slices kt .. min(KT, kt+STAGES-1)-1 are in flight; wait until only the younger ones remain
+    const int younger = min(KT, kt + STAGES - 1) - kt - 1;
+    if (younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * IPS>();
+    else if (STAGES > 3 && younger == STAGES - 3) wait_vmcnt<(STAGES > 3 ? STAGES - 3 : 0) * IPS>();
+    else if (STAGES > 4 && younger == STAGES - 4) wait_vmcnt<(STAGES > 4 ? STAGES - 4 : 0) * IPS>();
+    else if (younger >= 1) wait_vmcnt<IPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + STAGES - 1 < KT) issue_slice(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    const char* base = smem + (kt % STAGES) * BUF;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int ch = ((kg * 4 + fg) ^ swz) << 4;
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * ROWB + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * ROWB + ch);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
     }
   }
+  igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,7 +548,7 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
     const int K = d.KH * d.KW * d.Cin, KT = cdiv(K, ROWB / (int)sizeof(T));
     const long tiles = (long)cdiv(M, BM) * cdiv(d.Cout, BN);
     if (d.split_k > 0) split = d.split_k;
-    else if (tiles < 600 && KT >= 8) { split = (int)((1024 + tiles - 1) / tiles); if (split > KT / 2) split = KT / 2; if (split > 16) split = 16; }
+    (void)tiles; (void)KT;   // auto split-K is off: fp32 atomics cost more than the latency they hide on these shapes (profiles/r01 notes)
     if (split < 1) split = 1;
   }
   dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN), split);
@@ -416,6 +561,17 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
     long g = (total / 4 + 255) / 256; if (g > 2048) g = 2048;
     hipLaunchKernelGGL((splitk_epilogue_kernel<T, OUTF32>), dim3((int)g), dim3(256), 0, st, d, total);
   }
+  return l2s_check_launch();
+}
+
+template <typename T, int BM, int BN, int STAGES, bool OUTF32>
+int launch_igemm_pipe(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN));
+  size_t lds = (size_t)STAGES * (BM + BN) * ROWB;
+  static bool attr_done = false;
+  if (!attr_done) { hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  hipLaunchKernelGGL((igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>), grid, dim3(256), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -444,6 +600,14 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   // tile choice: prefer 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64
   const long t128 = (long)cdiv(M, 128) * cdiv(d->Cout, 128);
   int tile = d->tile ? d->tile : ((t128 >= 200 && d->Cout >= 96) ? 128 : 64);
+  static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 1; }();
+  const bool split_req = d->ws && d->split_k > 1;
+  if (use_pipe && !split_req) {
+#define GP(T, BM, BN, S) (f32o ? launch_igemm_pipe<T, BM, BN, S, true>(*d, stream) : launch_igemm_pipe<T, BM, BN, S, false>(*d, stream))
+    if (dtype == L2S_BF16) return tile == 128 ? GP(bf16_t, 128, 128, 4) : GP(bf16_t, 64, 64, 8);
+    if (dtype == L2S_F32) return tile == 128 ? GP(float, 128, 128, 4) : GP(float, 64, 64, 8);
+#undef GP
+  }
 #define GO(T, BM, BN) (f32o ? launch_igemm<T, BM, BN, true>(*d, stream) : launch_igemm<T, BM, BN, false>(*d, stream))
   if (dtype == L2S_BF16) return tile == 128 ? GO(bf16_t, 128, 128) : GO(bf16_t, 64, 64);
   if (dtype == L2S_F32) return tile == 128 ? GO(float, 128, 128) : GO(float, 64, 64);
