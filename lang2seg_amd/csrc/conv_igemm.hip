@@ -600,7 +600,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   // tile choice: prefer 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64
   const long t128 = (long)cdiv(M, 128) * cdiv(d->Cout, 128);
   int tile = d->tile ? d->tile : ((t128 >= 200 && d->Cout >= 96) ? 128 : 64);
-  static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 1; }();
+  static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 0; }();   // measured slower than the register-staged kernel at 128x128/64x64 tiles (profiles/r01_conv_bench.txt): LDS-DMA issue cost
   const bool split_req = d->ws && d->split_k > 1;
   if (use_pipe && !split_req) {
 #define GP(T, BM, BN, S) (f32o ? launch_igemm_pipe<T, BM, BN, S, true>(*d, stream) : launch_igemm_pipe<T, BM, BN, S, false>(*d, stream))
