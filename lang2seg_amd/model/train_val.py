@@ -1,0 +1,200 @@
+"""SolverWrapper / train_net — the solver layer of the reference
+(pyutils/mask-faster-rcnn/lib/model/train_val_cycle.py, "TV"): same loop structure (TV:327-434: per image
+`loader.getBatch`, random sentence order, one `net.train_step` per sentence, LR step at STEPSIZE+1,
+display every cfg.TRAIN.DISPLAY iters as `speed: s / iter`, snapshot every SNAPSHOT_ITERS), same snapshot
+files (`<prefix>_iter_N.pth` state dict in the reference's key/shape format + `.pkl` sidecar with numpy /
+python RNG state, loader cursors and iter, TV:57-104) and the same resume rules (TV:106-165,227-310:
+newest snapshot, name+shape matched copy incl. the `[:, :-1]` partial rule, LR rescaled by passed steps).
+Data parallel (not in the reference): every rank runs the same loop on its shard; rank 0 snapshots."""
+import glob
+import os
+import pickle
+import random
+import time
+
+import numpy as np
+import torch
+
+from .config import cfg
+from ..optim import SGD
+
+
+class Timer(object):
+    """utils/timer.py:20-35: device-synchronised tic/toc, running average."""
+
+    def __init__(self):
+        self.total, self.calls, self.start, self.diff, self.avg = 0.0, 0, 0.0, 0.0, 0.0
+
+    def tic(self):
+        torch.cuda.synchronize()
+        self.start = time.time()
+
+    def toc(self, average=True):
+        torch.cuda.synchronize()
+        self.diff = time.time() - self.start
+        self.total += self.diff
+        self.calls += 1
+        self.avg = self.total / self.calls
+        return self.avg if average else self.diff
+
+    def average_time(self):
+        return self.avg
+
+
+def scale_lr(optimizer, scale):
+    for g in optimizer.param_groups:
+        g['lr'] *= scale
+
+
+class SolverWrapper(object):
+    def __init__(self, network, loader, output_dir, tbdir, pretrained_model=None, rank=0, world=1):
+        self.net, self.loader = network, loader
+        self.output_dir, self.tbdir, self.pretrained_model = output_dir, tbdir, pretrained_model
+        self.rank, self.world = rank, world
+        if rank == 0:
+            os.makedirs(output_dir, exist_ok=True)
+
+    # ---- TV:57-104 -----------------------------------------------------
+    def snapshot(self, it):
+        if self.rank != 0:
+            return None, None
+        filename = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it) + '.pth')
+        torch.save(self.net.state_dict(), filename)
+        print('Wrote snapshot to: {:s}'.format(filename))
+        nfilename = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it) + '.pkl')
+        with open(nfilename, 'wb') as fid:
+            pickle.dump(np.random.get_state(), fid, pickle.HIGHEST_PROTOCOL)
+            pickle.dump(random.getstate(), fid, pickle.HIGHEST_PROTOCOL)
+            for split in ('train', 'val'):
+                pickle.dump(self.loader.iterators[split], fid, pickle.HIGHEST_PROTOCOL)
+                pickle.dump(self.loader.perm[split], fid, pickle.HIGHEST_PROTOCOL)
+            pickle.dump(it, fid, pickle.HIGHEST_PROTOCOL)
+        return filename, nfilename
+
+    # ---- TV:106-165 ----------------------------------------------------
+    def load_matched(self, saved_state_dict):
+        """name+shape matched copy; `param[:, :-1]` partial rule for widened inputs (TV:117-129)."""
+        cur = self.net.state_dict()
+        n_part = n_miss = 0
+        for name, param in cur.items():
+            if name in saved_state_dict and tuple(param.shape) == tuple(saved_state_dict[name].shape):
+                cur[name] = saved_state_dict[name]
+            elif name in saved_state_dict and param.dim() == 4 and tuple(param[:, :-1].shape) == tuple(saved_state_dict[name].shape):
+                p = param.clone(); p[:, :-1] = saved_state_dict[name]; cur[name] = p; n_part += 1
+            else:
+                n_miss += 1
+        print('size partially match:', n_part); print('size not match:', n_miss)
+        self.net.load_state_dict(cur)
+
+    def from_snapshot(self, sfile, nfile):
+        print('Restoring model snapshots from {:s}'.format(sfile))
+        self.load_matched(torch.load(str(sfile), map_location='cpu'))
+        with open(nfile, 'rb') as fid:
+            np.random.set_state(pickle.load(fid))
+            random.setstate(pickle.load(fid))
+            for split in ('train', 'val'):
+                self.loader.iterators[split] = pickle.load(fid)
+                self.loader.perm[split] = pickle.load(fid)
+            last_snapshot_iter = pickle.load(fid)
+        return last_snapshot_iter
+
+    # ---- TV:167-225 ----------------------------------------------------
+    def construct_graph(self):
+        torch.manual_seed(cfg.RNG_SEED)
+        random.seed(cfg.RNG_SEED)
+        np.random.seed(cfg.RNG_SEED + self.rank)
+        if not hasattr(self.net, 'P'):
+            self.net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+        lr = cfg.TRAIN.LEARNING_RATE
+        self.net.P.build_segments(double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
+        self.optimizer = SGD(self.net, lr, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / self.world)
+        return lr, self.optimizer
+
+    def find_previous(self):
+        sfiles = glob.glob(os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pth'))
+        sfiles.sort(key=os.path.getmtime)
+        red = [os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}.pth'.format(s + 1)) for s in cfg.TRAIN.STEPSIZE]
+        sfiles = [s for s in sfiles if s not in red]
+        nfiles = glob.glob(os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pkl'))
+        nfiles.sort(key=os.path.getmtime)
+        red = [r.replace('.pth', '.pkl') for r in red]
+        nfiles = [n for n in nfiles if n not in red]
+        assert len(nfiles) == len(sfiles)
+        return len(sfiles), nfiles, sfiles
+
+    def initialize(self):
+        if self.pretrained_model and os.path.exists(self.pretrained_model):
+            print('Loading initial model weights from {:s}'.format(self.pretrained_model))
+            self.load_matched(torch.load(self.pretrained_model, map_location='cpu'))
+            print('Loaded.')
+        return cfg.TRAIN.LEARNING_RATE, 0, list(cfg.TRAIN.STEPSIZE), [], []
+
+    def restore(self, sfile, nfile):
+        last = self.from_snapshot(sfile, nfile)
+        lr_scale, stepsizes = 1, []
+        for s in cfg.TRAIN.STEPSIZE:
+            if last > s:
+                lr_scale *= cfg.TRAIN.GAMMA
+            else:
+                stepsizes.append(s)
+        scale_lr(self.optimizer, lr_scale)
+        return cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [nfile], [sfile]
+
+    def remove_snapshot(self, np_paths, ss_paths):
+        for paths in (np_paths, ss_paths):
+            while len(paths) > cfg.TRAIN.SNAPSHOT_KEPT:
+                f = paths.pop(0)
+                if self.rank == 0 and os.path.exists(str(f)):
+                    os.remove(str(f))
+
+    # ---- TV:327-434 ----------------------------------------------------
+    def train_model(self, max_iters):
+        lr, self.optimizer = self.construct_graph()
+        lsf, nfiles, sfiles = self.find_previous()
+        if lsf == 0:
+            lr, last_snapshot_iter, stepsizes, np_paths, ss_paths = self.initialize()
+        else:
+            lr, last_snapshot_iter, stepsizes, np_paths, ss_paths = self.restore(str(sfiles[-1]), str(nfiles[-1]))
+        it = last_snapshot_iter + 1
+        stepsizes.append(max_iters); stepsizes.reverse()
+        next_stepsize = stepsizes.pop()
+        self.net.train(); self.net.cuda()
+        timer = Timer()
+        while it < max_iters + 1:
+            blobs = self.loader.getBatch('train', self.net._batch_size)
+            sent_num = blobs['gt_boxes'].shape[0]
+            arr = np.random.permutation(sent_num)
+            for idx in range(sent_num):
+                timer.tic()
+                if it == next_stepsize + 1:
+                    self.snapshot(it)
+                    lr *= cfg.TRAIN.GAMMA
+                    scale_lr(self.optimizer, cfg.TRAIN.GAMMA)
+                    next_stepsize = stepsizes.pop()
+                rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, loss_mask, loss_caption, total_loss = \
+                    self.net.train_step(blobs, int(arr[idx]), self.optimizer)
+                timer.toc()
+                if it % cfg.TRAIN.DISPLAY == 0 and self.rank == 0:
+                    print('iter: %d / %d, total loss: %.6f\n >>> rpn_loss_cls: %.6f\n >>> rpn_loss_box: %.6f\n >>> loss_cls: %.6f\n'
+                          ' >>> loss_box: %.6f\n >>> loss_mask: %.6f\n >>> loss_caption: %.6f\n >>> lr: %f' %
+                          (it, max_iters, total_loss, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, loss_mask, loss_caption, lr))
+                    print('speed: {:.3f}s / iter'.format(timer.average_time()))
+                if it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                    last_snapshot_iter = it
+                    ss, nn = self.snapshot(it)
+                    np_paths.append(nn); ss_paths.append(ss)
+                    self.remove_snapshot(np_paths, ss_paths)
+                it += 1
+                if it >= max_iters + 1:
+                    break
+        if last_snapshot_iter != it - 1:
+            self.snapshot(it - 1)
+
+
+def train_net(network, loader, output_dir, tb_dir, pretrained_model=None, max_iters=40000, rank=0, world=1):
+    """TV:477-490."""
+    sw = SolverWrapper(network, loader, output_dir, tb_dir, pretrained_model=pretrained_model, rank=rank, world=world)
+    print('Solving...')
+    sw.train_model(max_iters)
+    print('done solving')
+    return sw

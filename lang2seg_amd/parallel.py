@@ -34,16 +34,19 @@ class GradReducer(object):
             'layer1': P.total,
         }
         self.done = 0
-        self.side = torch.cuda.Stream()
-        self.works = []
+        self.on_gpu = P.grad.is_cuda
+        self.side = torch.cuda.Stream() if self.on_gpu else None
 
     def ready(self, stage):
         end = min(self.bounds[stage], self.net.P.total)
         if end <= self.done:
             return
         seg = self.net.P.grad[self.done:end]
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
+        if self.on_gpu:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        else:                                   # CPU/gloo path (tests)
             dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         self.done = end
 
@@ -51,6 +54,7 @@ class GradReducer(object):
         P = self.net.P
         if self.done < P.total:
             self.ready('layer1')
-        torch.cuda.current_stream().wait_stream(self.side)
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.side)
         self.done = 0
         # average over ranks: folded into the optimiser's grad_scale by the caller
