@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
   constexpr int BK = ROWB / (int)sizeof(T);  // K elements per slice
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int NA = BM / 32, NB = BN / 32;  // 16-byte vectors per thread per slice
-  constexpr int BUF = (BM + BN) * LROW;
+  constexpr int BUF = (BM + BN) * ROWB;      // unpadded 128-byte rows, XOR-swizzled 16-byte chunks (chunk ^ (row & 7))
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,8 +147,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
   const T* __restrict__ X = (const T*)p.x;
   const T* __restrict__ Wt = (const T*)p.w;
 
-  // ---- per-thread loader coordinates (rows fixed for the whole K loop) ----
+  // ---- per-thread loader coordinates: rows lrow + 32 j, 16-byte chunk cv; fixed for the whole K loop ----
   const int lrow = tid >> 3, cv = tid & 7;
+  const int wchunk = ((cv ^ (lrow & 7)) << 4);          // swizzled LDS chunk offset (row & 7 == lrow & 7 for every j)
   int a_iy0[NA], a_ix0[NA]; long a_base[NA]; bool a_ok[NA];
   const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -162,51 +163,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
     a_ix0[j] = ox * p.stride - p.pad;
     a_base[j] = (long)n_img * p.IH * p.IW;
   }
-  long b_off[NB]; bool b_ok[NB];
+  const T* pb[NB]; bool b_ok[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     int n = n0 + lrow + 32 * j;
     b_ok[j] = n < p.Cout;
-    b_off[j] = (long)(b_ok[j] ? n : 0) * K;
+    pb[j] = Wt + (long)(b_ok[j] ? n : 0) * K + cv * VE;
   }
-
-  uint4 ra[NA], rb[NB];
-  auto load_slice = [&](int kt) {
-    const int k0 = kt * BK;
-    int tap = 0, c0 = k0;
-    if (p.KH * p.KW > 1) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; }
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    const int kk = k0 + cv * VE;
-    const bool kin = kk < K;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-      bool ok = a_ok[j] && kin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *(const uint4*)(X + ((a_base[j] + (long)iy * p.IW + ix) * p.ldx + c0 + cv * VE));
-      ra[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (b_ok[j] && kin) v = *(const uint4*)(Wt + b_off[j] + kk);
-      rb[j] = v;
-    }
-  };
-  auto store_slice = [&](int buf) {
-    char* a = smem + buf * BUF;
-    char* b = a + BM * LROW;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) *(uint4*)(a + (lrow + 32 * j) * LROW + cv * 16) = ra[j];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) *(uint4*)(b + (lrow + 32 * j) * LROW + cv * 16) = rb[j];
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int KT_all = (K + BK - 1) / BK;
   int kt0 = 0, KT = KT_all;
@@ -215,22 +178,76 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
     kt0 = blockIdx.z * per; KT = min(KT_all, kt0 + per);
     if (kt0 >= KT) return;
   }
-  load_slice(kt0);
+  // loader state, advanced incrementally: (tap, c0) and one pointer per row; pointers are rebuilt only when the tap changes
+  int c0 = kt0 * BK, tap = 0;
+  if (p.KH * p.KW > 1) { tap = c0 / p.Cin; c0 -= tap * p.Cin; }
+  const T* pa[NA]; bool va[NA];
+  auto set_tap = [&](int t) {
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+      va[j] = a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      pa[j] = X + ((a_base[j] + (long)(va[j] ? iy : 0) * p.IW + (va[j] ? ix : 0)) * p.ldx + c0 + cv * VE);
+    }
+  };
+  set_tap(tap);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) pb[j] += (long)kt0 * BK;
+
+  uint4 ra[NA], rb[NB];
+  auto load_slice = [&]() {
+    const bool kin = (c0 + cv * VE) < p.Cin;             // K tail (only 1x1 / Linear with Cin % BK != 0)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (va[j] && kin) v = *(const uint4*)pa[j];
+      ra[j] = v;
+      pa[j] += BK;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_ok[j] && kin) v = *(const uint4*)pb[j];
+      rb[j] = v;
+      pb[j] += BK;
+    }
+    c0 += BK;
+    if (c0 >= p.Cin && p.KH * p.KW > 1) { c0 = 0; ++tap; if (tap < p.KH * p.KW) set_tap(tap); }
+  };
+  auto store_slice = [&](int buf) {
+    char* a = smem + buf * BUF + lrow * ROWB + wchunk;
+    char* b = a + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *(uint4*)(a + 32 * j * ROWB) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *(uint4*)(b + 32 * j * ROWB) = rb[j];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_slice();
   store_slice(0);
   __syncthreads();
   const int fr = lane & 15, fg = lane >> 4;
+  const int swz = fr & 7;
+  const int offa = (wm * WM + fr) * ROWB, offb = BM * ROWB + (wn * WN + fr) * ROWB;
   for (int kt = kt0; kt < KT; ++kt) {
     const int cur = (kt - kt0) & 1;
-    if (kt + 1 < KT) load_slice(kt + 1);
-    const char* a = smem + cur * BUF + (wm * WM + fr) * LROW + fg * 16;
-    const char* b = smem + cur * BUF + BM * LROW + (wn * WN + fr) * LROW + fg * 16;
+    if (kt + 1 < KT) load_slice();
+    const char* base = smem + cur * BUF;
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
+      const int ch = ((kg * 4 + fg) ^ swz) << 4;
       uint4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(a + i * 16 * LROW + kg * 64);
+      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * ROWB + ch);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(b + j * 16 * LROW + kg * 64);
+      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * ROWB + ch);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -552,7 +569,7 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
     if (split < 1) split = 1;
   }
   dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN), split);
-  size_t lds = 2 * (BM + BN) * LROW;
+  size_t lds = 2 * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) { hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, OUTF32>), grid, dim3(256), lds, st, d);
