@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=1, help='replay the step as one captured hipGraph (single GPU)')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
     args = ap.parse_args()
@@ -76,6 +77,7 @@ def main():
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()
     net.rank_seed = rank * 1000003
+    net.use_graph = bool(args.graph) and world == 1
     if world > 1:
         from lang2seg_amd.parallel import GradReducer
         net.dp = GradReducer(net, world)
@@ -108,13 +110,21 @@ def main():
     for i in range(args.warmup):
         net.train_step_async(blobs[i % 4], 0, optim)
     barrier()
-    wrap.on = True
+    wrap.on = not net.use_graph        # HIP events cannot bracket kernels inside a captured graph
     t0 = time.time()
     for i in range(args.steps):
         loss = net.train_step_async(blobs[i % 4], 0, optim)
     barrier()
     dt = time.time() - t0
     wrap.on = False
+    if net.use_graph:
+        # dominant-kernel timing: the same launches, bracketed by HIP events, in eager steps right after the timed region
+        net.use_graph = False
+        wrap.on = True
+        for i in range(5):
+            net.train_step_async(blobs[i % 4], 0, optim)
+        barrier()
+        wrap.on = False
     if world > 1:
         tt = torch.tensor([dt], device='cuda')
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

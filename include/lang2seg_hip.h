@@ -96,8 +96,11 @@ int l2s_adaptive_pool_bwd(const void* dy, int lddy, int off_all, int off_mask, c
                           const void* relu_ref, int H, int W, int C, int OH, int OW, int dtype, hipStream_t s);
 /* gt mask (uint8 HxW) -> adaptive avg pool to (h,w) -> >= 0.5 (NET:424-428) */
 int l2s_mask_downsample(const uint8_t* mask, float* out, int H, int W, int h, int w, hipStream_t s);
-/* dropout mask (scaled by 1/(1-p)) from a counter-based hash RNG */
-int l2s_dropout_mask(float* mask, long n, float p, uint64_t seed, hipStream_t s);
+/* counter-based hash RNG: the step counter lives in DEVICE memory (so a captured hipGraph replays with fresh randomness);
+ * l2s_counter_inc bumps it once per step; `salt` separates the call sites */
+int l2s_counter_inc(uint64_t* counter_dev, hipStream_t s);
+/* dropout mask, entries 0 or 1/(1-p) */
+int l2s_dropout_mask(float* mask, long n, float p, const uint64_t* seed_dev, uint64_t salt, hipStream_t s);
 
 /* ---------------------------------------------------------------- RoI path ------------------ */
 /* RPN pair-softmax + box decode + clip (NET:242-246, proposal_layer.py:42-46, bbox_transform.py:36-80).
@@ -120,8 +123,8 @@ int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_mode, int ma
 /* gather kept proposals: rois[max_keep][5] = [0, box], roi_scores[max_keep]; rows >= *num_out are zero */
 int l2s_gather_rois(const float* sorted_boxes, const float* sorted_scores, const int* keep, const int* num, int max_keep,
                     float* rois, float* roi_scores, hipStream_t s);
-/* uint32 priority keys from a counter hash (perf mode sampling) */
-int l2s_random_keys(uint32_t* keys, long n, uint64_t seed, hipStream_t s);
+/* uint32 sampling priority keys from the same counter hash */
+int l2s_random_keys(uint32_t* keys, long n, const uint64_t* seed_dev, uint64_t salt, hipStream_t s);
 
 /* anchor_target_layer.py:19-153 on device.  gt float [n_gt][5]; keys uint32 [HWA] (smallest keys are disabled first).
  * outputs: labels int32 [A*H*W] in the (a,h,w) order of ATL:133-134 (-1,0,1), targets/inside/outside float [HW][4A].

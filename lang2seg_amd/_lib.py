@@ -58,14 +58,15 @@ SIGS = {
     'l2s_adaptive_pool_fwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_adaptive_pool_bwd': (i32, [vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_mask_downsample': (i32, [vp, vp, i32, i32, i32, i32, vp]),
-    'l2s_dropout_mask': (i32, [vp, i64, f32, u64, vp]),
+    'l2s_dropout_mask': (i32, [vp, i64, f32, vp, u64, vp]),
+    'l2s_counter_inc': (i32, [vp, vp]),
     'l2s_rpn_decode': (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]),
     'l2s_sort_topk': (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_nms_workspace_bytes': (sz, [i32]),
     'l2s_sort_ws_ints': (i64, [i32]),
     'l2s_nms': (i32, [vp, i32, f32, i32, i32, vp, vp, vp, vp]),
     'l2s_gather_rois': (i32, [vp, vp, vp, vp, i32, vp, vp, vp]),
-    'l2s_random_keys': (i32, [vp, i64, u64, vp]),
+    'l2s_random_keys': (i32, [vp, i64, vp, u64, vp]),
     'l2s_anchor_target_ws_ints': (i64, [i32]),
     'l2s_anchor_target': (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, f32, f32, i32, f32, vp, vp, vp, vp, vp, vp]),
     'l2s_proposal_target': (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, i32, i32, f32, f32, f32,

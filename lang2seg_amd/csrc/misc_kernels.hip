@@ -6,6 +6,13 @@
 
 namespace {
 
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
 inline int grid_for(long n, int block = 256, int cap = 2048) {
   long g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -229,20 +236,17 @@ __global__ void mask_downsample_kernel(const uint8_t* mask, float* out, int H, i
   if (lane == 0) out[o] = (s / (float)n >= 0.5f) ? 1.f : 0.f;
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__global__ void dropout_kernel(float* m, long n, float p, uint64_t seed) {
+__global__ void counter_inc_kernel(uint64_t* c) { *c += 1; }
+__global__ void dropout_kernel(float* m, long n, float p, const uint64_t* seed_dev, uint64_t salt) {
+  const uint64_t seed = mix64(*seed_dev * 0x9E3779B97F4A7C15ull + salt);
   const float keep = 1.f - p, inv = keep > 0.f ? 1.f / keep : 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     uint32_t r = (uint32_t)(mix64(seed * 0x100000001B3ull + (uint64_t)i) >> 40);  // 24 bits
     m[i] = ((float)r * (1.f / 16777216.f) < keep) ? inv : 0.f;
   }
 }
-__global__ void keys_kernel(uint32_t* k, long n, uint64_t seed) {
+__global__ void keys_kernel(uint32_t* k, long n, const uint64_t* seed_dev, uint64_t salt) {
+  const uint64_t seed = mix64(*seed_dev * 0x9E3779B97F4A7C15ull + salt);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     k[i] = (uint32_t)(mix64(seed * 0x100000001B3ull + (uint64_t)i) >> 32);
 }
@@ -363,12 +367,16 @@ extern "C" int l2s_mask_downsample(const uint8_t* mask, float* out, int H, int W
   hipLaunchKernelGGL(mask_downsample_kernel, dim3(cdiv(h * w, 4)), dim3(256), 0, s, mask, out, H, W, h, w);
   return l2s_check_launch();
 }
-extern "C" int l2s_dropout_mask(float* mask, long n, float p, uint64_t seed, hipStream_t s) {
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, mask, n, p, seed);
+extern "C" int l2s_counter_inc(uint64_t* counter_dev, hipStream_t s) {
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, s, counter_dev);
   return l2s_check_launch();
 }
-extern "C" int l2s_random_keys(uint32_t* keys, long n, uint64_t seed, hipStream_t s) {
-  hipLaunchKernelGGL(keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, keys, n, seed);
+extern "C" int l2s_dropout_mask(float* mask, long n, float p, const uint64_t* seed_dev, uint64_t salt, hipStream_t s) {
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, mask, n, p, seed_dev, salt);
+  return l2s_check_launch();
+}
+extern "C" int l2s_random_keys(uint32_t* keys, long n, const uint64_t* seed_dev, uint64_t salt, hipStream_t s) {
+  hipLaunchKernelGGL(keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, keys, n, seed_dev, salt);
   return l2s_check_launch();
 }
 extern "C" int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,

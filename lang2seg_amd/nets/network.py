@@ -182,6 +182,38 @@ class Network(object):
             t.zero_()
         return t
 
+    def seed_counter(self):
+        c = getattr(self, '_seed_counter', None)
+        if c is None:
+            c = self._seed_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        return c
+
+    # ------------------------------------------------------------------ hipGraph replay of the whole step
+    def graph_step(self, dev, train_op):
+        """forward + backward + optimiser as ONE captured graph per (image size, token counts, lr): ~1100 kernel launches
+        collapse into one hipGraphLaunch.  Inputs are copied into static buffers; randomness comes from the device-side
+        step counter, so every replay draws new sampling keys / dropout masks."""
+        key = (tuple(dev['data'].shape), dev['T'], dev['S'], float(train_op.lr), float(train_op.grad_scale))
+        ent = self._graphs.get(key) if hasattr(self, '_graphs') else None
+        if not hasattr(self, '_graphs'):
+            self._graphs = {}
+        if ent is None:
+            st = {k: dev[k].clone() for k in ('data', 'gt_boxes', 'gt_masks', 'labels', 'cap_in', 'cap_tgt', 'cap_mask')}
+            d = dict(dev); d.update(st)
+            # warm-up on the static buffers (allocates the activation plan), then capture
+            loss = self.forward_backward(d); train_op.step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self.forward_backward(d); train_op.step()
+            ent = self._graphs[key] = (g, st, loss)
+        g, st, loss = ent
+        for k, v in st.items():
+            if v.data_ptr() != dev[k].data_ptr():
+                v.copy_(dev[k])
+        g.replay()
+        return loss
+
     def splitk_ws(self, need):
         """shared all-zero fp32 workspace for split-K partial sums (every launch hands it back zeroed)."""
         if need > 4 * 1024 * 1024:          # only small-M problems are split
@@ -270,22 +302,20 @@ class Network(object):
 
     # ------------------------------------------------------------------ train step (NET:702-719)
     def train_step(self, blobs, idx, train_op):
-        dev = self.upload_blob(blobs, idx)
-        loss = self.forward_backward(dev)
-        if self.dp is not None:
-            self.dp.finish()
-        train_op.step()
+        loss = self.train_step_async(blobs, idx, train_op)
         vals = loss.cpu().numpy()          # the single host sync of the step (the reference does seven, NET:704-710)
-        self._step += 1
         return tuple(float(vals[i]) for i in (0, 1, 2, 3, 4, 5, 6))
 
     def train_step_async(self, blobs, idx, train_op):
         """same as train_step without the loss read-back; returns the device loss[8] buffer."""
         dev = self.upload_blob(blobs, idx)
-        loss = self.forward_backward(dev)
-        if self.dp is not None:
-            self.dp.finish()
-        train_op.step()
+        if getattr(self, 'use_graph', False) and self.dp is None and self.parity is None:
+            loss = self.graph_step(dev, train_op)
+        else:
+            loss = self.forward_backward(dev)
+            if self.dp is not None:
+                self.dp.finish()
+            train_op.step()
         self._step += 1
         return loss
 

@@ -129,14 +129,14 @@ class resnetv1(Network):
             m = (self.parity.get('drops') or {}).get(name)
             return m
         m = self.buf('drop.' + name, shape, f32)
-        O.dropout_mask(m, p, (self._step * 16 + sum(map(ord, name)) % 16) * 2654435761 % (1 << 62) + 12345 + getattr(self, 'rank_seed', 0))
+        O.dropout_mask(m, p, self.seed_counter(), 1000003 * sum(map(ord, name)) + getattr(self, 'rank_seed', 0))
         return m
 
     def _keys(self, name, n):
         if self.parity is not None and self.parity.get(name) is not None:
             return self.parity[name]
         k = self.buf('keys.' + name, (n,), torch.int32)
-        O.random_keys(k, (self._step * 64 + sum(map(ord, name)) % 64) * 0x9E3779B1 % (1 << 62) + 777 + getattr(self, 'rank_seed', 0))
+        O.random_keys(k, self.seed_counter(), 7777 + 1000003 * sum(map(ord, name)) + getattr(self, 'rank_seed', 0))
         return k
 
     # ------------------------------------------------------------------ language encoder (ENC:27-82)
@@ -305,6 +305,7 @@ class resnetv1(Network):
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
         im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
         P.grad.zero_()
+        O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
         loss = self.buf('loss', (8,), f32, zero=True)
         # ---- head: conv1/bn1/relu/maxpool/layer1-3 (RES:261-265,309-310) ----
         OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1

@@ -126,12 +126,16 @@ def mask_downsample(mask_u8, out, H, W, h, w):
     call('l2s_mask_downsample', ptr(mask_u8), ptr(out), H, W, h, w, stream())
 
 
-def dropout_mask(mask, p, seed):
-    call('l2s_dropout_mask', ptr(mask), mask.numel(), float(p), int(seed), stream())
+def counter_inc(counter):
+    call('l2s_counter_inc', ptr(counter), stream())
 
 
-def random_keys(keys, seed):
-    call('l2s_random_keys', ptr(keys), keys.numel(), int(seed), stream())
+def dropout_mask(mask, p, seed_dev, salt):
+    call('l2s_dropout_mask', ptr(mask), mask.numel(), float(p), ptr(seed_dev), int(salt), stream())
+
+
+def random_keys(keys, seed_dev, salt):
+    call('l2s_random_keys', ptr(keys), keys.numel(), ptr(seed_dev), int(salt), stream())
 
 
 # ------------------------------------------------------------------ RoI path

@@ -611,9 +611,13 @@ def test_sgd_and_misc():
     sref = pref.clone(); sref[n1:n1 + rows * rl] = (sref[n1:n1 + rows * rl].view(rows, rl) * rowscale.view(-1, 1)).view(-1)
     assert rel_err(shadow.float(), sref) < 1e-2
     # dropout mask statistics + determinism, random keys
-    mk = torch.empty(100000, device=DEV); O.dropout_mask(mk, 0.5, 42)
-    mk2 = torch.empty(100000, device=DEV); O.dropout_mask(mk2, 0.5, 42)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    mk = torch.empty(100000, device=DEV); O.dropout_mask(mk, 0.5, ctr, 42)
+    mk2 = torch.empty(100000, device=DEV); O.dropout_mask(mk2, 0.5, ctr, 42)
+    O.counter_inc(ctr)
+    mk3 = torch.empty(100000, device=DEV); O.dropout_mask(mk3, 0.5, ctr, 42)
     torch.cuda.synchronize()
+    assert int(ctr.item()) == 1 and not torch.equal(mk, mk3)
     assert torch.equal(mk, mk2) and abs((mk > 0).float().mean().item() - 0.5) < 0.01 and set(mk.unique().tolist()) == {0.0, 2.0}
     a = torch.randn(1000, generator=g); b = torch.randn(1000, generator=g); c = torch.randn(1000, generator=g)
     out = torch.empty(1000, device=DEV); O.add3(a.to(DEV), b.to(DEV), c.to(DEV), out)
