@@ -49,6 +49,7 @@ typedef struct {
   int out_h, out_w, out_stride; /* SCATTER */
   int tile;                     /* 0 = auto, 64 or 128 */
   int split_k;                  /* 0 = auto, 1 = off, n = force (needs ws) */
+  int xcd_mode;                 /* tile order over the 8 XCDs: -1 = auto, 0 = M-chunks, 1 = N-chunks (speed only) */
   float* ws;                    /* optional ALL-ZERO float workspace >= rows*Cout for split-K partial sums; returned all-zero */
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);

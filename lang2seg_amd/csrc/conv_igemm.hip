@@ -141,9 +141,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int M = p.n_img * p.OH * p.OW;
   const int K = p.KH * p.KW * p.Cin;
+  // XCD-aware tile order (1-D grid): consecutive workgroup ids are dealt round-robin over the 8 XCDs, so id % 8 labels
+  // the XCD.  The tile list is cut into 8 contiguous chunks, one per XCD, ordered so that a chunk's operands fit the
+  // XCD's 4 MiB L2 (xcd_mode 0: M-chunks, n fastest -> A tile reused across its n-tiles, all of W resident;
+  // xcd_mode 1: N-chunks, m fastest -> one W column block resident, A streamed).  Speed only, never correctness.
+  int mt, nt;
+  {
+    const int MT = (M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;
+    if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
   const T* __restrict__ X = (const T*)p.x;
   const T* __restrict__ Wt = (const T*)p.w;
 
@@ -568,7 +579,7 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
     (void)tiles; (void)KT;   // auto split-K is off: fp32 atomics cost more than the latency they hide on these shapes (profiles/r01 notes)
     if (split < 1) split = 1;
   }
-  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN), split);
+  dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN), 1, split);
   size_t lds = 2 * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) { hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
@@ -617,6 +628,15 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   // tile choice: prefer 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64
   const long t128 = (long)cdiv(M, 128) * cdiv(d->Cout, 128);
   int tile = d->tile ? d->tile : ((t128 >= 200 && d->Cout >= 96) ? 128 : 64);
+  // working-set heuristic for the XCD tile order: per-XCD chunk along M keeps all of W + 1/8 of A in L2; if that does not
+  // fit (~3 MiB), chunk along N instead (one W column block resident, A streamed)
+  l2s_conv_desc dd = *d;
+  if (dd.xcd_mode < 0 || dd.xcd_mode > 1) {
+    const double esz = dtype == L2S_BF16 ? 2.0 : 4.0;
+    const double wbytes = (double)d->Cout * K * esz, abytes = (double)d->n_img * d->IH * d->IW * d->Cin * esz;
+    dd.xcd_mode = (wbytes + abytes / 8.0 <= 3.0 * 1024 * 1024) ? 0 : 1;
+  }
+  d = &dd;
   static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 0; }();   // measured slower than the register-staged kernel at 128x128/64x64 tiles (profiles/r01_conv_bench.txt): LDS-DMA issue cost
   const bool split_req = d->ws && d->split_k > 1;
   if (use_pipe && !split_req) {

@@ -26,7 +26,7 @@ def empty(shape, dt, device='cuda'):
 # ------------------------------------------------------------------ conv / gemm
 def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
                ref=None, relu=False, out_f32=False, deconv=False, scatter=None, ldx=None, ldy=None, ldadd=None,
-               ldref=None, tile=0, dt=None, ws=None, split_k=0):
+               ldref=None, tile=0, dt=None, ws=None, split_k=0, xcd_mode=-1):
     d = ConvDesc()
     d.x, d.w, d.y = ptr(x), ptr(w), ptr(y)
     d.bias, d.add, d.ref = ptr(bias), ptr(add), ptr(ref)
@@ -50,6 +50,7 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     d.flags = fl
     d.tile = tile
     d.split_k = split_k
+    d.xcd_mode = xcd_mode
     d.ws = ptr(ws)
     call('l2s_conv_igemm', C.byref(d), dt_of(x) if dt is None else dt, stream())
     return y

@@ -39,6 +39,7 @@ def timeit(fn, iters=20):
 def main():
     dt = 1
     tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    xm = int(os.environ.get('L2S_XCD', '-1'))
     print('%-14s %8s %8s %8s | %8s %8s %8s (us | TFLOP/s)' % ('shape', 'fwd', 'dgrad', 'wgrad', 'fwd', 'dgrad', 'wgrad'))
     for name, n, H, W, Cin, Cout, k, s, p in SHAPES:
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
@@ -52,8 +53,8 @@ def main():
         dw = torch.zeros(Cout, k * k * Cin, device='cuda')
         bias = torch.randn(Cout, device='cuda')
         flop = 2.0 * M * Cout * k * k * Cin
-        tf = timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=bias, add=y, relu=True, tile=tile))
-        td = timeit(lambda: O.conv_igemm(dy, wt, dx, n, OH, OW, Cout, H, W, Cin, k, k, 1, k - 1 - p, ref=x, tile=tile))
+        tf = timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=bias, add=y, relu=True, tile=tile, xcd_mode=xm))
+        td = timeit(lambda: O.conv_igemm(dy, wt, dx, n, OH, OW, Cout, H, W, Cin, k, k, 1, k - 1 - p, ref=x, tile=tile, xcd_mode=xm))
         tw = timeit(lambda: O.conv_wgrad(dy, x, dw, n, H, W, Cin, OH, OW, Cout, k, k, s, p))
         print('%-14s %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f' % (name, tf * 1e6, td * 1e6, tw * 1e6, flop / tf / 1e12, flop / td / 1e12, flop / tw / 1e12))
 
