@@ -83,10 +83,13 @@ class ConvOp(object):
         return dx
 
     def wgrad(self, g, x, n, IH, IW):
+        """weight (+bias) gradient.  Nothing downstream in the step needs it before the optimiser, so it is forked onto the
+        weight-gradient stream and overlaps with the data-gradient chain that continues on the calling stream."""
         OH, OW = self.out_hw(IH, IW)
-        O.conv_wgrad(g, x, self.w_grad, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad)
-        if self.bias_grad is not None:
-            O.colsum(g, n * OH * OW, self.Np, self.Np, self.bias_grad)
+        with self.net.fork_wgrad():
+            O.conv_wgrad(g, x, self.w_grad, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad)
+            if self.bias_grad is not None:
+                O.colsum(g, n * OH * OW, self.Np, self.Np, self.bias_grad)
 
 
 class Bottleneck(object):
@@ -181,6 +184,30 @@ class Network(object):
         elif zero:
             t.zero_()
         return t
+
+    # ------------------------------------------------------------------ HIP streams
+    use_streams = True
+
+    def streams(self):
+        if not hasattr(self, '_streams'):
+            self._streams = dict(lang=torch.cuda.Stream(), cap=torch.cuda.Stream(), wg=torch.cuda.Stream())
+        return self._streams
+
+    def fork_wgrad(self):
+        """context: run the enclosed launches on the weight-gradient stream, ordered after everything already enqueued on
+        the current stream (event fork); joined by join_wgrad() before the optimiser / gradient all-reduce."""
+        import contextlib
+        if not self.use_streams:
+            return contextlib.nullcontext()
+        wg = self.streams()['wg']
+        ev = torch.cuda.Event()
+        ev.record()
+        wg.wait_event(ev)
+        return torch.cuda.stream(wg)
+
+    def join_wgrad(self):
+        if self.use_streams:
+            torch.cuda.current_stream().wait_stream(self.streams()['wg'])
 
     def seed_counter(self):
         c = getattr(self, '_seed_counter', None)

@@ -307,6 +307,20 @@ class resnetv1(Network):
         P.grad.zero_()
         O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
         loss = self.buf('loss', (8,), f32, zero=True)
+        main = torch.cuda.current_stream()
+        S = self.streams() if self.use_streams else None
+        import contextlib
+        def on(name):
+            return torch.cuda.stream(S[name]) if S is not None else contextlib.nullcontext()
+        # ---- expression encoding (ENC:27-82) forked onto the language stream: 80 dependent GEMV launches that overlap with the backbone
+        if S is not None:
+            S['lang'].wait_stream(main)
+        with on('lang'):
+            hidden = self._encoder_fwd(d)
+            HD = hidden.numel()
+            NF = 7 * C4 + 7
+            filt = self.buf('dyn.filt', (NF,), f32)
+            O.linear_fwd(hidden, P.gview('dyn_w', NF * HD), P.gview('dyn_b', NF), filt, 1, NF, HD, act=2)
         # ---- head: conv1/bn1/relu/maxpool/layer1-3 (RES:261-265,309-310) ----
         OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         c1 = self.buf('stem.c1', (OH1 * OW1, 64))
@@ -323,15 +337,41 @@ class resnetv1(Network):
         base, Hc, Wc = x, h, w
         HW = Hc * Wc
         t['net_conv_base'] = base
-        # ---- expression encoding + dynamic filters (NET:501-562) ----
-        hidden = self._encoder_fwd(d)
-        HD = hidden.numel()
-        NF = 7 * C4 + 7
-        filt = self.buf('dyn.filt', (NF,), f32)
-        O.linear_fwd(hidden, P.gview('dyn_w', NF * HD), P.gview('dyn_b', NF), filt, 1, NF, HD, act=2)
+        # ---- dynamic filters (NET:504-562) ----
+        if S is not None:
+            main.wait_stream(S['lang'])
         net_conv = self.buf('dyn.y', (HW, C4)); resp = self.buf('dyn.resp', (HW,), f32); respk = self.buf('dyn.respk', (HW, 7), f32)
         O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4)
         t['net_conv'], t['response'] = net_conv, resp
+        # ---- caption-cycle branch (NET:415-439), forward AND backward, forked onto the caption stream: it needs only net_conv
+        # and rejoins at d(net_conv); layer4's weight gradients from both branches accumulate atomically.
+        AF = self.opt['att_feat_size']
+
+        def caption_branch():
+            x, hh, ww = net_conv, Hc, Wc
+            for b, blk in enumerate(self.layers[4]):
+                x, hh, ww, sv = blk.fwd(x, 1, hh, ww, 'l4m.%d' % b)
+                saved[('4m', b)] = sv
+            feats = x
+            gm = self.buf('cap.gm', (HW,), f32)
+            O.mask_downsample(d['gt_masks'], gm, H, W, Hc, Wc)
+            att = self.buf('cap.att', (196, AF))
+            O.adaptive_pool_fwd(feats, None, att, Hc, Wc, 2048, 14, 14, AF)
+            O.adaptive_pool_fwd(feats, gm, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
+            t.update({'feats_all': feats, 'att_feats': att, 'gt_mask_small': gm})
+            self._caption_fwd(d, att, loss)
+            if not backward:
+                return None
+            datt = self._caption_bwd(d, att)
+            g = self.buf('l4m.g', (HW, 2048))
+            O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
+            for b in reversed(range(len(self.layers[4]))):
+                g = self.layers[4][b].bwd(g, saved[('4m', b)], 'l4m.%d' % b, x_is_relu_out=(b > 0))
+            return g
+        if S is not None:
+            S['cap'].wait_stream(main)
+        with on('cap'):
+            d_nc_cap = caption_branch()
         # ---- RPN (NET:235-275) ----
         rpn = self.buf('rpn.a', (HW, 512))
         self.rpn_conv.fwd(net_conv, 1, Hc, Wc, rpn, relu=True)
@@ -399,34 +439,14 @@ class resnetv1(Network):
         O.rpn_loss(rheads, NPR, rl, rt, ri, ro, Hc, Wc, A, 3.0, 1.0, loss, d_rheads, NPR)
         O.rcnn_loss(cheads, NPC, labels, bt, bi, bo, R, nc, 1.0, loss, d_cheads, NPC)
         O.mask_loss(mscore, nc, labels, mt, counts, FGM, MS * MS, 1.0, loss, dscore)
-        # ---- caption-cycle branch (NET:415-439) ----
-        x, hh, ww = net_conv, Hc, Wc
-        for b, blk in enumerate(self.layers[4]):
-            x, hh, ww, sv = blk.fwd(x, 1, hh, ww, 'l4m.%d' % b)
-            saved[('4m', b)] = sv
-        feats = x
-        gm = self.buf('cap.gm', (HW,), f32)
-        O.mask_downsample(d['gt_masks'], gm, H, W, Hc, Wc)
-        AF = self.opt['att_feat_size']
-        att = self.buf('cap.att', (196, AF))
-        O.adaptive_pool_fwd(feats, None, att, Hc, Wc, 2048, 14, 14, AF)
-        O.adaptive_pool_fwd(feats, gm, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
-        t.update({'feats_all': feats, 'att_feats': att, 'gt_mask_small': gm})
-        self._caption_fwd(d, att, loss)
-        O.total_loss(loss, self._cap_loss_weight)
-        t['loss'] = loss
-        if not backward:
-            return loss
-        # =================================== backward ===================================
+        # =================================== backward (detection side, main stream) ===================================
         dp = self.dp
-        datt = self._caption_bwd(d, att)
-        g = self.buf('l4m.g', (HW, 2048))
-        O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
-        for b in reversed(range(len(self.layers[4]))):
-            g = self.layers[4][b].bwd(g, saved[('4m', b)], 'l4m.%d' % b, x_is_relu_out=(b > 0))
-        d_nc_cap = g
-        if dp is not None:
-            dp.ready('caption')
+        if not backward:
+            if S is not None:
+                main.wait_stream(S['cap'])
+            O.total_loss(loss, self._cap_loss_weight)
+            t['loss'] = loss
+            return loss
         # rcnn heads -> fc7 -> spatial_fc7
         self.rcnn_heads.wgrad(d_cheads, fc7, R, 1, 1)
         dfc7 = self.buf('roi.dfc7', (R, 2048))
@@ -435,8 +455,9 @@ class resnetv1(Network):
         dup = self.buf('mask.dup', (FGM * MS * MS, 256))
         O.maskpred_bwd(dscore, labels, counts, FGM, MS * MS, 256, P.view('mask_pred_net.weight'), up, up, dup,
                        P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad))
-        O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
-        O.conv_wgrad(fc7s, dup, P.view('mask_up_sampling.weight', P.grad), FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0)
+        with self.fork_wgrad():
+            O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
+            O.conv_wgrad(fc7s, dup, P.view('mask_up_sampling.weight', P.grad), FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0)
         dmask_fc7 = self.buf('mask.dfc7s', (FGM * PS * PS, 2048))
         O.conv_igemm(dup, P.view('mask_up_sampling.weight', P.shadow), dmask_fc7, FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0, dt=dt)
         g = self.buf('l4r.g', (R * PS * PS, 2048))
@@ -448,8 +469,6 @@ class resnetv1(Network):
             g = self.layers[4][b].bwd(g, saved[('4r', b)], 'l4r.%d' % b, x_is_relu_out=(b > 0))
         d_nc_roi = self.buf('roi.dfeat', (HW, C4), f32, zero=True)
         O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
-        if dp is not None:
-            dp.ready('heads')
         # rpn
         self.rpn_heads.wgrad(d_rheads, rpn, 1, Hc, Wc)
         drpn = self.buf('rpn.da', (HW, 512))
@@ -457,6 +476,12 @@ class resnetv1(Network):
         self.rpn_conv.wgrad(drpn, net_conv, 1, Hc, Wc)
         d_nc_rpn = self.buf('rpn.dnc', (HW, C4))
         self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
+        if S is not None:
+            main.wait_stream(S['cap'])                     # join the caption branch
+        O.total_loss(loss, self._cap_loss_weight)
+        t['loss'] = loss
+        if dp is not None:
+            dp.ready('heads')                              # caption + layer4 + RoI/mask heads are final here
         d_nc = self.buf('dyn.dy', (HW, C4))
         O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)
         # dynamic filters (NET:504-562)

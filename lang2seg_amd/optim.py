@@ -16,6 +16,8 @@ class SGD(object):
 
     def step(self):
         P = self.net.P
+        if hasattr(self.net, 'join_wgrad'):
+            self.net.join_wgrad()                   # weight-gradient stream -> current stream
         O.sgd_momentum(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay,
                        self.grad_scale, shadow=P.shadow)
         self.net.refresh_weights()
