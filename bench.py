@@ -50,7 +50,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', type=int, default=1, help='replay the step as one captured hipGraph (single GPU)')
+    ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
     args = ap.parse_args()

@@ -125,7 +125,13 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_FN = {}
+
+
 def call(name, *args):
-    r = getattr(load(), name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    r = fn(*args)
     if r != 0:
         raise L2SError('%s returned error %d' % (name, r))

@@ -487,13 +487,16 @@ class resnetv1(Network):
         # dynamic filters (NET:504-562)
         dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (HW,), f32)
         O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4)
-        O.act_bwd(dfilt, filt, 2)
-        O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NF * HD, P.grad), P.gview('dyn_b', NF, P.grad), 1, NF, HD)
-        dhidden = self.buf('enc.dhidden', (HD,), f32)
-        self.bwd_x(dfilt, 'dyn_w', dhidden, 1)
-        self._encoder_bwd(d, dhidden)
-        if dp is not None:
-            dp.ready('language')
+        # language-side backward (dynamic FCs, bi-LSTM, embedding: ~170 small dependent launches) forked onto the language
+        # stream; the backbone backward below does not depend on it.  Joined by the optimiser (join_side()).
+        if S is not None:
+            S['lang'].wait_stream(main)
+        with on('lang'):
+            O.act_bwd(dfilt, filt, 2)
+            O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NF * HD, P.grad), P.gview('dyn_b', NF, P.grad), 1, NF, HD)
+            dhidden = self.buf('enc.dhidden', (HD,), f32)
+            self.bwd_x(dfilt, 'dyn_w', dhidden, 1)
+            self._encoder_bwd(d, dhidden)
         # backbone layer3, layer2 (layer1 and the stem are frozen: RES:290-299)
         g = dbase
         fb = cfg.RESNET.FIXED_BLOCKS
@@ -502,8 +505,12 @@ class resnetv1(Network):
                 break
             for b in reversed(range(len(self.layers[li]))):
                 g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
-            if dp is not None:
-                dp.ready('layer%d' % li)
+            if dp is not None and li == 3:
+                if S is not None:
+                    main.wait_stream(S['lang'])
+                dp.ready('layer3')                        # everything except layer2 is final
+        if S is not None:
+            main.wait_stream(S['lang'])
         return loss
 
     def _consts(self):
