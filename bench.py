@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
@@ -78,6 +79,7 @@ def main():
     net.train()
     net.rank_seed = rank * 1000003
     net.use_graph = bool(args.graph) and world == 1
+    net.use_tape = bool(args.tape) and world == 1
     if world > 1:
         from lang2seg_amd.parallel import GradReducer
         net.dp = GradReducer(net, world)
@@ -110,16 +112,17 @@ def main():
     for i in range(args.warmup):
         net.train_step_async(blobs[i % 4], 0, optim)
     barrier()
-    wrap.on = not net.use_graph        # HIP events cannot bracket kernels inside a captured graph
+    replay = net.use_graph or net.use_tape
+    wrap.on = not replay               # HIP events cannot bracket kernels inside a replayed graph / tape
     t0 = time.time()
     for i in range(args.steps):
         loss = net.train_step_async(blobs[i % 4], 0, optim)
     barrier()
     dt = time.time() - t0
     wrap.on = False
-    if net.use_graph:
+    if replay:
         # dominant-kernel timing: the same launches, bracketed by HIP events, in eager steps right after the timed region
-        net.use_graph = False
+        net.use_graph = False; net.use_tape = False
         wrap.on = True
         for i in range(5):
             net.train_step_async(blobs[i % 4], 0, optim)

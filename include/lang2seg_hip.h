@@ -218,6 +218,19 @@ int l2s_cap_gates_bwd(const float* dh, const float* dc_in, const float* save, co
 int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale, float* loss_slot,
                        float* dlogits, float* logprobs_opt, hipStream_t s);
 
+/* ---------------------------------------------------------------- launch tape / streams ----- */
+/* `to` waits (device side) for everything enqueued so far on `from`; fork or join of the step's branches */
+int l2s_stream_fork(hipStream_t from, hipStream_t to);
+int l2s_memset_async(void* p, int value, size_t bytes, hipStream_t s);
+int l2s_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t s);
+/* record every launch / fork / memset issued through this ABI on the registered streams (they still execute), then replay
+ * the whole multi-stream step from one call.  Valid while the recorded pointers, shapes and scalars stay the same. */
+void* l2s_tape_begin(const hipStream_t* streams, int n);
+int l2s_tape_end(void* tape);
+long l2s_tape_size(void* tape);
+int l2s_tape_run(void* tape, const hipStream_t* streams, int n);
+int l2s_tape_destroy(void* tape);
+
 /* ---------------------------------------------------------------- optimizer ---------------- */
 /* torch.optim.SGD with momentum as configured at train_val_cycle.py:194-220, fused over a flat parameter buffer.
  * seg table (device): per segment {offset, count, rows, wd_flag}; rowscale (optional, per segment offset into a float array,

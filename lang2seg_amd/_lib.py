@@ -95,6 +95,14 @@ SIGS = {
     'l2s_logsoftmax_nll': (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp]),
     'l2s_mul_f32': (i32, [vp, vp, vp, i64, vp]),
+    'l2s_stream_fork': (i32, [vp, vp]),
+    'l2s_memset_async': (i32, [vp, i32, sz, vp]),
+    'l2s_memcpy_d2d_async': (i32, [vp, vp, sz, vp]),
+    'l2s_tape_begin': (vp, [vp, i32]),
+    'l2s_tape_end': (i32, [vp]),
+    'l2s_tape_size': (i64, [vp]),
+    'l2s_tape_run': (i32, [vp, vp, i32]),
+    'l2s_tape_destroy': (i32, [vp]),
 }
 
 _lib = None

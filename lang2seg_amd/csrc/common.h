@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 
 #define L2S_OK 0
 #define L2S_EINVAL 1
@@ -77,6 +78,17 @@ __device__ __forceinline__ int fast_div(int a, int b, float rb) {
   if (r < 0) --q; else if (r >= b) ++q;
   return q;
 }
+
+// Launch tape (tape.hip): while recording, every launch site also appends a replayable closure (argument copies by value).
+namespace l2s {
+bool recording();
+void record(hipStream_t s, std::function<void(hipStream_t)> fn);
+}
+#define L2S_LAUNCH(kern, grid, block, shmem, stream, ...)                                                              \
+  do {                                                                                                                \
+    if (l2s::recording()) l2s::record((stream), [=](hipStream_t s_) { hipLaunchKernelGGL(kern, grid, block, shmem, s_, __VA_ARGS__); }); \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                                                 \
+  } while (0)
 
 static inline int l2s_check_launch() {
   hipError_t e = hipGetLastError();

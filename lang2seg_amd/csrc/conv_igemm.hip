@@ -583,11 +583,11 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   size_t lds = 2 * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) { hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, OUTF32>), grid, dim3(256), lds, st, d);
+  L2S_LAUNCH((igemm_kernel<T, BM, BN, OUTF32>), grid, dim3(256), lds, st, d);
   if (split > 1) {
     const long total = (long)M * d.Cout;
     long g = (total / 4 + 255) / 256; if (g > 2048) g = 2048;
-    hipLaunchKernelGGL((splitk_epilogue_kernel<T, OUTF32>), dim3((int)g), dim3(256), 0, st, d, total);
+    L2S_LAUNCH((splitk_epilogue_kernel<T, OUTF32>), dim3((int)g), dim3(256), 0, st, d, total);
   }
   return l2s_check_launch();
 }
@@ -599,7 +599,7 @@ int launch_igemm_pipe(const l2s_conv_desc& d, hipStream_t st) {
   size_t lds = (size_t)STAGES * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) { hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  hipLaunchKernelGGL((igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>), grid, dim3(256), lds, st, d);
+  L2S_LAUNCH((igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>), grid, dim3(256), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -610,7 +610,7 @@ int launch_wgrad(const l2s_wgrad_desc& d, int split, hipStream_t st) {
   constexpr int LRA = BM * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
   constexpr int LRB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
   size_t lds = 2 * WG<T>::BKP * (LRA + LRB);
-  hipLaunchKernelGGL((wgrad_kernel<T, BM, BN>), grid, dim3(256), lds, st, d);
+  L2S_LAUNCH((wgrad_kernel<T, BM, BN>), grid, dim3(256), lds, st, d);
   return l2s_check_launch();
 }
 

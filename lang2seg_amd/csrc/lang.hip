@@ -387,8 +387,8 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw,
   for (int m0 = 0; m0 < M; m0 += MAXM) {
     const int rem = M - m0;
     dim3 grid(cdiv(N, 4));
-#define LF(MT) do { if (vec) hipLaunchKernelGGL((linear_fwd_kernel<MT, true>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
-                    else hipLaunchKernelGGL((linear_fwd_kernel<MT, false>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); } while (0)
+#define LF(MT) do { if (vec) L2S_LAUNCH((linear_fwd_kernel<MT, true>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
+                    else L2S_LAUNCH((linear_fwd_kernel<MT, false>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); } while (0)
     if (rem <= 1) LF(1); else if (rem <= 8) LF(8); else LF(MAXM);
 #undef LF
   }
@@ -397,46 +397,46 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw,
 extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate, hipStream_t s) {
   if (M <= 0) return L2S_OK;
   dim3 grid(cdiv(K, 64));
-  if (M == 1) hipLaunchKernelGGL(gemvT_kernel<1>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, 0, M, N, K, accumulate);
-  else for (int m0 = 0; m0 < M; m0 += 8) hipLaunchKernelGGL(gemvT_kernel<8>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, m0, M, N, K, accumulate);
+  if (M == 1) L2S_LAUNCH(gemvT_kernel<1>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, 0, M, N, K, accumulate);
+  else for (int m0 = 0; m0 < M; m0 += 8) L2S_LAUNCH(gemvT_kernel<8>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, m0, M, N, K, accumulate);
   return l2s_check_launch();
 }
 extern "C" int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx_, float* dw, float* db, int M, int N, int K, hipStream_t s) {
   if (M <= 0) return L2S_OK;
-  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
+  L2S_LAUNCH(linear_bwd_w_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
   return l2s_check_launch();
 }
 extern "C" int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream_t s) {
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, s, dy, y, n, act);
+  L2S_LAUNCH(act_bwd_kernel, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, s, dy, y, n, act);
   return l2s_check_launch();
 }
 extern "C" int l2s_embed_fwd(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu, hipStream_t s) {
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(T), dim3(256), 0, s, table, ids, mask, out, T, D, relu);
+  L2S_LAUNCH(embed_fwd_kernel, dim3(T), dim3(256), 0, s, table, ids, mask, out, T, D, relu);
   return l2s_check_launch();
 }
 extern "C" int l2s_embed_bwd(const float* dout, const float* out, const int64_t* ids, const float* mask, float* dtable, int T, int D, int relu, hipStream_t s) {
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(T), dim3(256), 0, s, dout, out, ids, mask, dtable, T, D, relu);
+  L2S_LAUNCH(embed_bwd_kernel, dim3(T), dim3(256), 0, s, dout, out, ids, mask, dtable, T, D, relu);
   return l2s_check_launch();
 }
 extern "C" int l2s_lstm_cell_fwd(const float* gates, const float* c_prev, float* c, float* h, float* act, int Hh, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv(Hh, 256)), dim3(256), 0, s, gates, c_prev, c, h, act, Hh);
+  L2S_LAUNCH(lstm_cell_fwd_kernel, dim3(cdiv(Hh, 256)), dim3(256), 0, s, gates, c_prev, c, h, act, Hh);
   return l2s_check_launch();
 }
 extern "C" int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const float* act, const float* c_prev, const float* c,
                                  float* dgates, float* dc_prev, int Hh, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv(Hh, 256)), dim3(256), 0, s, dh, dc_in, act, c_prev, c, dgates, dc_prev, Hh);
+  L2S_LAUNCH(lstm_cell_bwd_kernel, dim3(cdiv(Hh, 256)), dim3(256), 0, s, dh, dc_in, act, c_prev, c, dgates, dc_prev, Hh);
   return l2s_check_launch();
 }
 extern "C" int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,
                                  int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype);
+  L2S_LAUNCH(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
                                  void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype);
+  L2S_LAUNCH(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype);
   const int pchunk = 64;
-  hipLaunchKernelGGL(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), cdiv(H * W, pchunk)), dim3(256), 0, s, dy, x, filt, r, resp, dresp_ws, dx, relu_ref,
+  L2S_LAUNCH(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), cdiv(H * W, pchunk)), dim3(256), 0, s, dy, x, filt, r, resp, dresp_ws, dx, relu_ref,
                      dfilt, H, W, C, dtype, pchunk);
   return l2s_check_launch();
 }
@@ -444,28 +444,28 @@ extern "C" int l2s_cap_attention_fwd(const float* patt, const float* att, const 
                                      float* tanh_ws, float* weight, float* att_res, hipStream_t s) {
   if (L > 256) return L2S_EINVAL;
   // the softmax weights buffer doubles as the raw-dot scratch between the two launches
-  hipLaunchKernelGGL(cap_att_dots_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, patt, att_h, aw, ab, L, D, tanh_ws, att_res + D);
-  hipLaunchKernelGGL(cap_att_apply_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, att, att_res + D, L, D, weight, att_res);
+  L2S_LAUNCH(cap_att_dots_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, patt, att_h, aw, ab, L, D, tanh_ws, att_res + D);
+  L2S_LAUNCH(cap_att_apply_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, att, att_res + D, L, D, weight, att_res);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_attention_bwd(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
                                      float* dpatt, float* datt, float* datt_h, float* daw, float* dab, hipStream_t s) {
   if (L > 256) return L2S_EINVAL;
-  hipLaunchKernelGGL(cap_att_bwd_dw_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, datt_res, att, L, D, datt_h + D);
-  hipLaunchKernelGGL(cap_att_bwd_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, datt_res, datt_h + D, tanh_ws, weight, aw, L, D, dpatt, datt, datt_h, daw, dab);
+  L2S_LAUNCH(cap_att_bwd_dw_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, datt_res, att, L, D, datt_h + D);
+  L2S_LAUNCH(cap_att_bwd_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, datt_res, datt_h + D, tanh_ws, weight, aw, L, D, dpatt, datt, datt_h, daw, dab);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save, int R, hipStream_t s) {
-  hipLaunchKernelGGL(cap_gates_fwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, sums, a2c, c_prev, c, h, save, R);
+  L2S_LAUNCH(cap_gates_fwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, sums, a2c, c_prev, c, h, save, R);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_gates_bwd(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* dsums, float* da2c,
                                  float* dc_prev, int R, hipStream_t s) {
-  hipLaunchKernelGGL(cap_gates_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, dh, dc_in, save, c_prev, dsums, da2c, dc_prev, R);
+  L2S_LAUNCH(cap_gates_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, dh, dc_in, save, c_prev, dsums, da2c, dc_prev, R);
   return l2s_check_launch();
 }
 extern "C" int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale, float* loss_slot,
                                   float* dlogits, float* logprobs_opt, hipStream_t s) {
-  hipLaunchKernelGGL(lsm_nll_kernel, dim3(S), dim3(1024), 0, s, logits, target, mask, S, V1, gscale, loss_slot, dlogits, logprobs_opt);
+  L2S_LAUNCH(lsm_nll_kernel, dim3(S), dim3(1024), 0, s, logits, target, mask, S, V1, gscale, loss_slot, dlogits, logprobs_opt);
   return l2s_check_launch();
 }

@@ -154,25 +154,25 @@ __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, 
 extern "C" int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
                             const float* outside_w, int H, int W, int A, float sigma, float gscale, float* loss, void* dheads, int ldd,
                             int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(1024), 0, s, heads, ldh, labels, targets, inside_w, outside_w, H, W, A, sigma, gscale, loss, dheads, ldd, dtype);
+  L2S_LAUNCH(rpn_loss_kernel, dim3(1), dim3(1024), 0, s, heads, ldh, labels, targets, inside_w, outside_w, H, W, A, sigma, gscale, loss, dheads, ldd, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_rcnn_loss(const float* heads, int ldh, const int* labels, const float* bbox_targets, const float* inside_w,
                              const float* outside_w, int R, int ncls, float gscale, float* loss, void* dheads, int ldd, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(rcnn_loss_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, heads, ldh, labels, bbox_targets, inside_w, outside_w, R, ncls, gscale, loss, dheads, ldd, dtype);
+  L2S_LAUNCH(rcnn_loss_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, heads, ldh, labels, bbox_targets, inside_w, outside_w, R, ncls, gscale, loss, dheads, ldd, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_mask_loss(const float* score, int ldsc, const int* labels, const float* mask_targets, const int* num_fg, int fg_max,
                              int ms2, float gscale, float* loss, float* dscore, hipStream_t s) {
-  hipLaunchKernelGGL(mask_loss_kernel, dim3(cdiv(fg_max * ms2, 256)), dim3(256), 0, s, score, ldsc, labels, mask_targets, num_fg, fg_max, ms2, gscale, loss, dscore);
+  L2S_LAUNCH(mask_loss_kernel, dim3(cdiv(fg_max * ms2, 256)), dim3(256), 0, s, score, ldsc, labels, mask_targets, num_fg, fg_max, ms2, gscale, loss, dscore);
   return l2s_check_launch();
 }
 extern "C" int l2s_total_loss(float* loss, float cap_w, hipStream_t s) {
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, s, loss, cap_w);
+  L2S_LAUNCH(total_loss_kernel, dim3(1), dim3(1), 0, s, loss, cap_w);
   return l2s_check_launch();
 }
 extern "C" int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C, const float* w,
                                 const void* x, const void* relu_ref, void* dx, float* dw, float* db, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(maskpred_bwd_kernel, dim3(fg_max), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, dw, db, dtype);
+  L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, dw, db, dtype);
   return l2s_check_launch();
 }

@@ -301,87 +301,87 @@ extern "C" int l2s_version(void) { return 100; }
 
 extern "C" int l2s_weight_cast(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s) {
   long per_row = (long)taps * Cin, total = per_row * Cout;
-  hipLaunchKernelGGL(weight_cast_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, scale, dst, per_row, total, dtype);
+  L2S_LAUNCH(weight_cast_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, scale, dst, per_row, total, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s) {
   dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), taps);
-  hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, s, src, scale, dst, Cout, taps, Cin, dtype);
+  L2S_LAUNCH(weight_transpose_kernel, grid, dim3(256), 0, s, src, scale, dst, Cout, taps, Cin, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int dtype, hipStream_t s) {
   if (n <= 0) return L2S_OK;
-  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3(48, n), dim3(256), 0, s, table_dev, dtype);
+  L2S_LAUNCH(weight_transpose_batched_kernel, dim3(48, n), dim3(256), 0, s, table_dev, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s) {
   dim3 grid(cdiv(cols, 64), cdiv(rows, 256));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, a, rows, cols, lda, out, dtype);
+  L2S_LAUNCH(colsum_kernel, grid, dim3(256), 0, s, a, rows, cols, lda, out, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_stem_conv(const float* img, const float* w, const float* scale, const float* bias, void* y, int H, int W,
                              int OH, int OW, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(stem_kernel, dim3(cdiv((long)OH * OW, 64)), dim3(256), 0, s, img, w, scale, bias, y, H, W, OH, OW, dtype);
+  L2S_LAUNCH(stem_kernel, dim3(cdiv((long)OH * OW, 64)), dim3(256), 0, s, img, w, scale, bias, y, H, W, OH, OW, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_maxpool3x3s2(const void* x, void* y, int IH, int IW, int C, int OH, int OW, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((long)OH * OW * C)), dim3(256), 0, s, x, y, IH, IW, C, OH, OW, dtype);
+  L2S_LAUNCH(maxpool_kernel, dim3(grid_for((long)OH * OW * C)), dim3(256), 0, s, x, y, IH, IW, C, OH, OW, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_fill_f32(float* p, float v, long n, hipStream_t s) {
   if (n <= 0) return L2S_OK;
-  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, v, n);
+  L2S_LAUNCH(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, v, n);
   return l2s_check_launch();
 }
 extern "C" int l2s_cast(const void* src, int sd, void* dst, int dd, long n, hipStream_t s) {
-  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, sd, dst, dd, n);
+  L2S_LAUNCH(cast_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, sd, dst, dd, n);
   return l2s_check_launch();
 }
 extern "C" int l2s_mul_f32(const float* a, const float* b, float* out, long n, hipStream_t s) {
-  hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
+  L2S_LAUNCH(mul_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
   return l2s_check_launch();
 }
 extern "C" int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(add3_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, dst, n, dtype);
+  L2S_LAUNCH(add3_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, dst, n, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_avgpool_fwd(const void* x, void* y, int n_img, int hw, int C, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv(C, 256), n_img), dim3(256), 0, s, x, y, hw, C, dtype);
+  L2S_LAUNCH(avgpool_fwd_kernel, dim3(cdiv(C, 256), n_img), dim3(256), 0, s, x, y, hw, C, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_avgpool_bwd(const void* dy, void* dx, const void* addend, const void* ref, int n_img, int hw, int C, int dtype, hipStream_t s) {
   long total = (long)n_img * hw * C;
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, dx, addend, ref, hw, C, total, dtype);
+  L2S_LAUNCH(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, dx, addend, ref, hw, C, total, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_adaptive_pool_fwd(const void* x, const float* pm, void* y, int H, int W, int C, int OH, int OW, int ldy, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(adaptive_pool_fwd_kernel, dim3(cdiv(C, 256), OH * OW), dim3(256), 0, s, x, pm, y, H, W, C, OH, OW, ldy, dtype);
+  L2S_LAUNCH(adaptive_pool_fwd_kernel, dim3(cdiv(C, 256), OH * OW), dim3(256), 0, s, x, pm, y, H, W, C, OH, OW, ldy, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_adaptive_pool_bwd(const void* dy, int lddy, int off_all, int off_mask, const float* pm, void* dx, const void* ref,
                                      int H, int W, int C, int OH, int OW, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(adaptive_pool_bwd_kernel, dim3(cdiv(C, 256), H * W), dim3(256), 0, s, dy, lddy, off_all, off_mask, pm, dx, ref, H, W, C, OH, OW, dtype);
+  L2S_LAUNCH(adaptive_pool_bwd_kernel, dim3(cdiv(C, 256), H * W), dim3(256), 0, s, dy, lddy, off_all, off_mask, pm, dx, ref, H, W, C, OH, OW, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_mask_downsample(const uint8_t* mask, float* out, int H, int W, int h, int w, hipStream_t s) {
-  hipLaunchKernelGGL(mask_downsample_kernel, dim3(cdiv(h * w, 4)), dim3(256), 0, s, mask, out, H, W, h, w);
+  L2S_LAUNCH(mask_downsample_kernel, dim3(cdiv(h * w, 4)), dim3(256), 0, s, mask, out, H, W, h, w);
   return l2s_check_launch();
 }
 extern "C" int l2s_counter_inc(uint64_t* counter_dev, hipStream_t s) {
-  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, s, counter_dev);
+  L2S_LAUNCH(counter_inc_kernel, dim3(1), dim3(1), 0, s, counter_dev);
   return l2s_check_launch();
 }
 extern "C" int l2s_dropout_mask(float* mask, long n, float p, const uint64_t* seed_dev, uint64_t salt, hipStream_t s) {
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, mask, n, p, seed_dev, salt);
+  L2S_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, s, mask, n, p, seed_dev, salt);
   return l2s_check_launch();
 }
 extern "C" int l2s_random_keys(uint32_t* keys, long n, const uint64_t* seed_dev, uint64_t salt, hipStream_t s) {
-  hipLaunchKernelGGL(keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, keys, n, seed_dev, salt);
+  L2S_LAUNCH(keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, keys, n, seed_dev, salt);
   return l2s_check_launch();
 }
 extern "C" int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
                                 float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, hipStream_t s) {
   if (nseg <= 0) return L2S_OK;
-  hipLaunchKernelGGL(sgd_kernel, dim3(64, nseg), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype);
+  L2S_LAUNCH(sgd_kernel, dim3(64, nseg), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype);
   return l2s_check_launch();
 }

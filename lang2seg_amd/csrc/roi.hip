@@ -536,7 +536,7 @@ __global__ void roialign_bwd_kernel(const void* dout, int H, int W, int C, const
 extern "C" int l2s_rpn_decode(const float* heads, int ldh, const float* base_anchors, int H, int W, int A, int feat_stride,
                               float im_h, float im_w, float* prob, float* boxes, float* scores, hipStream_t s) {
   const int n = H * W * A;
-  hipLaunchKernelGGL(rpn_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, heads, ldh, base_anchors, H, W, A, feat_stride, im_h, im_w, prob, boxes, scores);
+  L2S_LAUNCH(rpn_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, heads, ldh, base_anchors, H, W, A, feat_stride, im_h, im_w, prob, boxes, scores);
   return l2s_check_launch();
 }
 extern "C" long l2s_sort_ws_ints(int n) { return 4L * n + 256L * cdiv(n, 256) + 64; }
@@ -545,15 +545,15 @@ extern "C" int l2s_sort_topk(const float* scores, const float* boxes, int n, int
   if (!ws || n <= 0 || k > n) return L2S_EINVAL;
   const int nblk = cdiv(n, 256);
   RsWs w = rs_ws(ws, n);
-  hipLaunchKernelGGL(rs_init_kernel, dim3(nblk), dim3(256), 0, s, scores, n, ws);
+  L2S_LAUNCH(rs_init_kernel, dim3(nblk), dim3(256), 0, s, scores, n, ws);
   unsigned int* kin = w.kA; int* iin = w.iA; unsigned int* kout = w.kB; int* iout = w.iB;
   for (int pass = 0; pass < 4; ++pass) {
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, n, 8 * pass, nblk, w.hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, w.hist, 256 * nblk);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, (const int*)iin, kout, iout, n, 8 * pass, nblk, (const int*)w.hist);
+    L2S_LAUNCH(rs_hist_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, n, 8 * pass, nblk, w.hist);
+    L2S_LAUNCH(rs_scan_kernel, dim3(1), dim3(1024), 0, s, w.hist, 256 * nblk);
+    L2S_LAUNCH(rs_scatter_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, (const int*)iin, kout, iout, n, 8 * pass, nblk, (const int*)w.hist);
     unsigned int* tk = kin; kin = kout; kout = tk; int* ti = iin; iin = iout; iout = ti;
   }
-  hipLaunchKernelGGL(rs_gather_kernel, dim3(cdiv(k, 256)), dim3(256), 0, s, (const int*)iin, scores, boxes, k, sorted_boxes, sorted_scores, sorted_idx);
+  L2S_LAUNCH(rs_gather_kernel, dim3(cdiv(k, 256)), dim3(256), 0, s, (const int*)iin, scores, boxes, k, sorted_boxes, sorted_scores, sorted_idx);
   return l2s_check_launch();
 }
 extern "C" size_t l2s_nms_workspace_bytes(int n) { return (size_t)n * (size_t)cdiv(n, 64) * 8; }
@@ -562,13 +562,13 @@ extern "C" int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_m
   if (n <= 0) return L2S_EINVAL;
   const int cb = cdiv(n, 64);
   if ((size_t)(cb + 2) * 8 > 60000) return L2S_EINVAL;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, cb, mask_ws);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(1024), (size_t)(cb + 2) * 8, s, (const uint64_t*)mask_ws, n, cb, max_keep, keep_out, num_out);
+  L2S_LAUNCH(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, cb, mask_ws);
+  L2S_LAUNCH(nms_reduce_kernel, dim3(1), dim3(1024), (size_t)(cb + 2) * 8, s, (const uint64_t*)mask_ws, n, cb, max_keep, keep_out, num_out);
   return l2s_check_launch();
 }
 extern "C" int l2s_gather_rois(const float* sorted_boxes, const float* sorted_scores, const int* keep, const int* num, int max_keep,
                                float* rois, float* roi_scores, hipStream_t s) {
-  hipLaunchKernelGGL(gather_rois_kernel, dim3(cdiv(max_keep, 256)), dim3(256), 0, s, sorted_boxes, sorted_scores, keep, num, max_keep, rois, roi_scores);
+  L2S_LAUNCH(gather_rois_kernel, dim3(cdiv(max_keep, 256)), dim3(256), 0, s, sorted_boxes, sorted_scores, keep, num, max_keep, rois, roi_scores);
   return l2s_check_launch();
 }
 extern "C" long l2s_anchor_target_ws_ints(int hwa) { return 16 + 64 + 4L * hwa + 16; }
@@ -578,11 +578,11 @@ extern "C" int l2s_anchor_target(const float* gt, int n_gt, const float* base_an
                                  int* labels, float* targets, float* inside_w, float* outside_w, int* ws, hipStream_t s) {
   if (n_gt < 1 || n_gt > 32) return L2S_EINVAL;
   const int n = H * W * A;
-  hipLaunchKernelGGL(atl_init_kernel, dim3(1), dim3(128), 0, s, ws);
-  hipLaunchKernelGGL(atl_iou_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, im_h, im_w, ws);
-  hipLaunchKernelGGL(atl_label_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, neg_ov, pos_ov, ws);
-  hipLaunchKernelGGL(atl_sample_kernel, dim3(1), dim3(1024), 0, s, fg_keys, bg_keys, n, batch, fg_frac, ws);
-  hipLaunchKernelGGL(atl_out_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, base_anchors, n, H, W, A, feat_stride, (const int*)ws, labels, targets, inside_w, outside_w);
+  L2S_LAUNCH(atl_init_kernel, dim3(1), dim3(128), 0, s, ws);
+  L2S_LAUNCH(atl_iou_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, im_h, im_w, ws);
+  L2S_LAUNCH(atl_label_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, neg_ov, pos_ov, ws);
+  L2S_LAUNCH(atl_sample_kernel, dim3(1), dim3(1024), 0, s, fg_keys, bg_keys, n, batch, fg_frac, ws);
+  L2S_LAUNCH(atl_out_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, base_anchors, n, H, W, A, feat_stride, (const int*)ws, labels, targets, inside_w, outside_w);
   return l2s_check_launch();
 }
 extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, const int* n_rois, int n_max, const float* gt, int n_gt,
@@ -592,18 +592,18 @@ extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, c
                                    float* out_rois, int* labels, float* bbox_targets, float* bbox_inside, float* bbox_outside,
                                    float* mask_targets, int* counts, int* ws, hipStream_t s) {
   if (n_gt < 1 || R < 1) return L2S_EINVAL;
-  hipLaunchKernelGGL(ptl_kernel, dim3(1), dim3(1024), 0, s, rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w,
+  L2S_LAUNCH(ptl_kernel, dim3(1), dim3(1024), 0, s, rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w,
                      fg_keys, bg_keys, bg_rand, R, fg_max, fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms,
                      out_rois, labels, bbox_targets, bbox_inside, bbox_outside, mask_targets, counts, ws);
   return l2s_check_launch();
 }
 extern "C" int l2s_roialign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                                 void* out, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(roialign_fwd_kernel, dim3(R * P * P), dim3(256), 0, s, feat, H, W, C, rois, P, spatial_scale, out, dtype);
+  L2S_LAUNCH(roialign_fwd_kernel, dim3(R * P * P), dim3(256), 0, s, feat, H, W, C, rois, P, spatial_scale, out, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                                 float* dfeat, int dtype, hipStream_t s) {
-  hipLaunchKernelGGL(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, spatial_scale, dfeat, dtype);
+  L2S_LAUNCH(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, spatial_scale, dfeat, dtype);
   return l2s_check_launch();
 }

@@ -1,0 +1,104 @@
+// Launch tape: a recorded multi-stream replay of one train step.
+//
+// The step is ~800 kernel launches sequenced by Python over four HIP streams (main, language, caption, weight-gradient).
+// Issuing them from Python costs ~13 us each (10.5 ms per step, more than the GPU needs).  hipGraph capture removes the
+// host cost but, on this ROCm, replays the forked branches serially.  The tape keeps both: while `recording`, every
+// L2S_LAUNCH site (common.h) also appends a closure {logical stream, kernel, launch geometry, argument copies} and every
+// l2s_stream_fork appends an event record/wait pair; l2s_tape_run replays the closures from one tight C++ loop onto the
+// caller's streams, so the branches still overlap on the GPU.  All arguments are persistent device pointers / sizes, so a
+// tape stays valid for as long as the shapes (and scalar hyper-parameters) it was recorded with.
+#include "common.h"
+#include "../../include/lang2seg_hip.h"
+#include <vector>
+#include <mutex>
+
+namespace l2s {
+
+struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };   // kind 0 launch, 1 record ev, 2 wait ev
+struct Tape { std::vector<Op> ops; int n_events = 0; std::vector<hipEvent_t> events; };
+
+static Tape* g_rec = nullptr;
+static hipStream_t g_streams[8];
+static int g_nstreams = 0;
+static std::vector<hipEvent_t> g_pool;     // events for eager forks
+static size_t g_pool_next = 0;
+
+static int stream_id(hipStream_t s) {
+  for (int i = 0; i < g_nstreams; ++i) if (g_streams[i] == s) return i;
+  return -1;
+}
+bool recording() { return g_rec != nullptr; }
+void record(hipStream_t s, std::function<void(hipStream_t)> fn) {
+  if (!g_rec) return;
+  g_rec->ops.push_back(Op{0, stream_id(s), -1, std::move(fn)});
+}
+
+}  // namespace l2s
+
+using namespace l2s;
+
+extern "C" void* l2s_tape_begin(const hipStream_t* streams, int n) {
+  if (g_rec || n < 1 || n > 8) return nullptr;
+  for (int i = 0; i < n; ++i) g_streams[i] = streams[i];
+  g_nstreams = n;
+  g_rec = new Tape();
+  return g_rec;
+}
+extern "C" int l2s_tape_end(void* tape) {
+  if (g_rec != (Tape*)tape || !tape) return L2S_EINVAL;
+  Tape* t = g_rec;
+  g_rec = nullptr;
+  for (const Op& o : t->ops) if (o.sid < 0) return L2S_EINVAL;     // a launch went to an unregistered stream
+  t->events.resize(t->n_events);
+  for (int i = 0; i < t->n_events; ++i)
+    if (hipEventCreateWithFlags(&t->events[i], hipEventDisableTiming) != hipSuccess) return L2S_ELAUNCH;
+  return L2S_OK;
+}
+extern "C" long l2s_tape_size(void* tape) { return tape ? (long)((Tape*)tape)->ops.size() : -1; }
+extern "C" int l2s_tape_run(void* tape, const hipStream_t* streams, int n) {
+  Tape* t = (Tape*)tape;
+  if (!t || g_rec) return L2S_EINVAL;
+  for (const Op& o : t->ops) {
+    if (o.sid >= n) return L2S_EINVAL;
+    hipStream_t s = streams[o.sid];
+    if (o.kind == 0) o.fn(s);
+    else if (o.kind == 1) { if (hipEventRecord(t->events[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
+    else { if (hipStreamWaitEvent(s, t->events[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
+  }
+  return l2s_check_launch();
+}
+extern "C" int l2s_tape_destroy(void* tape) {
+  Tape* t = (Tape*)tape;
+  if (!t) return L2S_OK;
+  if (g_rec == t) g_rec = nullptr;
+  for (hipEvent_t e : t->events) hipEventDestroy(e);
+  delete t;
+  return L2S_OK;
+}
+// `to` waits for everything enqueued so far on `from` (fork or join, depending on which side continues)
+extern "C" int l2s_stream_fork(hipStream_t from, hipStream_t to) {
+  if (from == to) return L2S_OK;
+  if (g_pool.empty()) {
+    g_pool.resize(256);
+    for (auto& e : g_pool) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return L2S_ELAUNCH;
+  }
+  hipEvent_t e = g_pool[g_pool_next++ % g_pool.size()];
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) return L2S_ELAUNCH;
+  if (g_rec) {
+    const int a = stream_id(from), b = stream_id(to);
+    const int ev = g_rec->n_events++;
+    g_rec->ops.push_back(Op{1, a, ev, nullptr});
+    g_rec->ops.push_back(Op{2, b, ev, nullptr});
+  }
+  return L2S_OK;
+}
+extern "C" int l2s_memset_async(void* p, int value, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return L2S_OK;
+  if (recording()) record(s, [=](hipStream_t s_) { (void)hipMemsetAsync(p, value, bytes, s_); });
+  return hipMemsetAsync(p, value, bytes, s) == hipSuccess ? L2S_OK : L2S_ELAUNCH;
+}
+extern "C" int l2s_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return L2S_OK;
+  if (recording()) record(s, [=](hipStream_t s_) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s_); });
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? L2S_OK : L2S_ELAUNCH;
+}

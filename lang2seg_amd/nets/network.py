@@ -138,7 +138,7 @@ class Bottleneck(object):
         ref = x if x_is_relu_out else None
         if self.down is not None:
             if self.stride != 1:
-                dx.zero_()                                    # scatter writes only the strided positions
+                O.memset_zero(dx)                             # scatter writes only the strided positions
             self.c1.dgrad(dz1, n, IH, IW, dx)
             self.down.dgrad(g, n, IH, IW, dx, add=dx, ref=ref)
         else:
@@ -182,7 +182,7 @@ class Network(object):
             t = torch.zeros(tuple(shape), dtype=td, device=self.device)
             self._bufs[key] = t
         elif zero:
-            t.zero_()
+            O.memset_zero(t)
         return t
 
     # ------------------------------------------------------------------ HIP streams
@@ -193,6 +193,10 @@ class Network(object):
             self._streams = dict(lang=torch.cuda.Stream(), cap=torch.cuda.Stream(), wg=torch.cuda.Stream())
         return self._streams
 
+    def sfork(self, from_stream, to_stream):
+        """device-side ordering edge between two streams (recorded on the launch tape when one is being recorded)."""
+        O.stream_fork(from_stream, to_stream)
+
     def fork_wgrad(self):
         """context: run the enclosed launches on the weight-gradient stream, ordered after everything already enqueued on
         the current stream (event fork); joined by join_wgrad() before the optimiser / gradient all-reduce."""
@@ -200,14 +204,44 @@ class Network(object):
         if not self.use_streams:
             return contextlib.nullcontext()
         wg = self.streams()['wg']
-        ev = torch.cuda.Event()
-        ev.record()
-        wg.wait_event(ev)
+        self.sfork(torch.cuda.current_stream(), wg)
         return torch.cuda.stream(wg)
 
     def join_wgrad(self):
         if self.use_streams:
-            torch.cuda.current_stream().wait_stream(self.streams()['wg'])
+            self.sfork(self.streams()['wg'], torch.cuda.current_stream())
+
+    # ------------------------------------------------------------------ launch-tape replay of the whole step
+    def tape_step(self, dev, train_op):
+        """forward + backward + optimiser replayed from a recorded launch tape (csrc/tape.hip): the ~800 launches and the
+        stream forks/joins of the step are issued by one C call instead of ~10 ms of Python; the branches still run on
+        their own HIP streams.  One tape per (image size, token counts, lr, grad scale); inputs go through static buffers;
+        randomness comes from the device-side step counter."""
+        key = (tuple(dev['data'].shape), dev['T'], dev['S'], float(train_op.lr), float(train_op.grad_scale), self.training)
+        if not hasattr(self, '_tapes'):
+            self._tapes = {}
+        ent = self._tapes.get(key)
+        main = torch.cuda.current_stream()
+        S = self.streams()
+        slist = [main, S['lang'], S['cap'], S['wg']]
+        if ent is None:
+            st = {k: dev[k].clone() for k in ('data', 'gt_boxes', 'gt_masks', 'labels', 'cap_in', 'cap_tgt', 'cap_mask')}
+            d = dict(dev); d.update(st)
+            loss = self.forward_backward(d); train_op.step()          # allocates the activation plan for this shape
+            torch.cuda.synchronize()
+            h = O.tape_begin(slist)
+            try:
+                loss = self.forward_backward(d); train_op.step()
+            finally:
+                O.tape_end(h)
+            self._tapes[key] = (h, st, loss)
+            return loss
+        h, st, loss = ent
+        for k, v in st.items():
+            if v.data_ptr() != dev[k].data_ptr():
+                v.copy_(dev[k], non_blocking=True)
+        O.tape_run(h, slist)
+        return loss
 
     def seed_counter(self):
         c = getattr(self, '_seed_counter', None)
@@ -336,7 +370,9 @@ class Network(object):
     def train_step_async(self, blobs, idx, train_op):
         """same as train_step without the loss read-back; returns the device loss[8] buffer."""
         dev = self.upload_blob(blobs, idx)
-        if getattr(self, 'use_graph', False) and self.dp is None and self.parity is None:
+        if getattr(self, 'use_tape', False) and self.use_streams and self.dp is None and self.parity is None:
+            loss = self.tape_step(dev, train_op)
+        elif getattr(self, 'use_graph', False) and self.dp is None and self.parity is None:
             loss = self.graph_step(dev, train_op)
         else:
             loss = self.forward_backward(dev)

@@ -162,7 +162,7 @@ class resnetv1(Network):
                 cur, prev = (tt + 1, tt) if di == 0 else (tt, tt + 1)
                 O.linear_fwd(hs[prev], whh, bhh, g[tt], 1, 4 * Hh, Hh, accumulate=True)
                 O.lstm_cell_fwd(g[tt], cs[prev], cs[cur], hs[cur], act[tt], Hh)
-            hidden[di * Hh:(di + 1) * Hh].copy_(hs[T] if di == 0 else hs[0])      # ENC:76-80
+            O.memcpy(hidden[di * Hh:(di + 1) * Hh], hs[T] if di == 0 else hs[0])      # ENC:76-80
         t['enc.emb'], t['enc.x'], t['hidden'] = emb, x, hidden
         return hidden
 
@@ -175,7 +175,7 @@ class resnetv1(Network):
             act = self.buf('enc.act' + sfx, (T, 4 * Hh), f32)
             dg = self.buf('enc.dg' + sfx, (T, 4 * Hh), f32)
             dh = self.buf('enc.dh' + sfx, (2, Hh), f32); dc = self.buf('enc.dc' + sfx, (2, Hh), f32, zero=True)
-            dh[0].copy_(dhidden[di * Hh:(di + 1) * Hh])
+            O.memcpy(dh[0], dhidden[di * Hh:(di + 1) * Hh])
             k = 0
             whh = P.view('rnn_encoder.rnn.weight_hh_l0' + sfx)
             for tt in (range(T - 1, -1, -1) if di == 0 else range(T)):
@@ -304,7 +304,7 @@ class resnetv1(Network):
         C4 = self._C4_feat_dim
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
         im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
-        P.grad.zero_()
+        O.memset_zero(P.grad)
         O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
         loss = self.buf('loss', (8,), f32, zero=True)
         main = torch.cuda.current_stream()
@@ -314,7 +314,7 @@ class resnetv1(Network):
             return torch.cuda.stream(S[name]) if S is not None else contextlib.nullcontext()
         # ---- expression encoding (ENC:27-82) forked onto the language stream: 80 dependent GEMV launches that overlap with the backbone
         if S is not None:
-            S['lang'].wait_stream(main)
+            self.sfork(main, S['lang'])
         with on('lang'):
             hidden = self._encoder_fwd(d)
             HD = hidden.numel()
@@ -339,7 +339,7 @@ class resnetv1(Network):
         t['net_conv_base'] = base
         # ---- dynamic filters (NET:504-562) ----
         if S is not None:
-            main.wait_stream(S['lang'])
+            self.sfork(S['lang'], main)
         net_conv = self.buf('dyn.y', (HW, C4)); resp = self.buf('dyn.resp', (HW,), f32); respk = self.buf('dyn.respk', (HW, 7), f32)
         O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4)
         t['net_conv'], t['response'] = net_conv, resp
@@ -369,7 +369,7 @@ class resnetv1(Network):
                 g = self.layers[4][b].bwd(g, saved[('4m', b)], 'l4m.%d' % b, x_is_relu_out=(b > 0))
             return g
         if S is not None:
-            S['cap'].wait_stream(main)
+            self.sfork(main, S['cap'])
         with on('cap'):
             d_nc_cap = caption_branch()
         # ---- RPN (NET:235-275) ----
@@ -443,7 +443,7 @@ class resnetv1(Network):
         dp = self.dp
         if not backward:
             if S is not None:
-                main.wait_stream(S['cap'])
+                self.sfork(S['cap'], main)
             O.total_loss(loss, self._cap_loss_weight)
             t['loss'] = loss
             return loss
@@ -477,7 +477,7 @@ class resnetv1(Network):
         d_nc_rpn = self.buf('rpn.dnc', (HW, C4))
         self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
         if S is not None:
-            main.wait_stream(S['cap'])                     # join the caption branch
+            self.sfork(S['cap'], main)                     # join the caption branch
         O.total_loss(loss, self._cap_loss_weight)
         t['loss'] = loss
         if dp is not None:
@@ -490,7 +490,7 @@ class resnetv1(Network):
         # language-side backward (dynamic FCs, bi-LSTM, embedding: ~170 small dependent launches) forked onto the language
         # stream; the backbone backward below does not depend on it.  Joined by the optimiser (join_side()).
         if S is not None:
-            S['lang'].wait_stream(main)
+            self.sfork(main, S['lang'])
         with on('lang'):
             O.act_bwd(dfilt, filt, 2)
             O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NF * HD, P.grad), P.gview('dyn_b', NF, P.grad), 1, NF, HD)
@@ -507,10 +507,10 @@ class resnetv1(Network):
                 g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
             if dp is not None and li == 3:
                 if S is not None:
-                    main.wait_stream(S['lang'])
+                    self.sfork(S['lang'], main)
                 dp.ready('layer3')                        # everything except layer2 is final
         if S is not None:
-            main.wait_stream(S['lang'])
+            self.sfork(S['lang'], main)
         return loss
 
     def _consts(self):

@@ -23,6 +23,41 @@ def empty(shape, dt, device='cuda'):
     return torch.empty(shape, dtype=TORCH_DT[dt], device=device)
 
 
+# ------------------------------------------------------------------ streams / tape
+def stream_fork(from_stream, to_stream):
+    """`to_stream` waits for everything enqueued so far on `from_stream` (torch.cuda.Stream objects)."""
+    call('l2s_stream_fork', from_stream.cuda_stream, to_stream.cuda_stream)
+
+
+def memset_zero(t):
+    call('l2s_memset_async', ptr(t), 0, t.numel() * t.element_size(), stream())
+
+
+def memcpy(dst, src):
+    call('l2s_memcpy_d2d_async', ptr(dst), ptr(src), src.numel() * src.element_size(), stream())
+
+
+def tape_begin(streams):
+    arr = (C.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+    h = _lib.load().l2s_tape_begin(arr, len(streams))
+    if not h:
+        raise _lib.L2SError('l2s_tape_begin failed')
+    return h
+
+
+def tape_end(h):
+    call('l2s_tape_end', h)
+
+
+def tape_run(h, streams):
+    arr = (C.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+    call('l2s_tape_run', h, arr, len(streams))
+
+
+def tape_size(h):
+    return int(_lib.load().l2s_tape_size(h))
+
+
 # ------------------------------------------------------------------ conv / gemm
 def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
                ref=None, relu=False, out_f32=False, deconv=False, scatter=None, ldx=None, ldy=None, ldadd=None,
