@@ -440,30 +440,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p) {
   const int s_end = min(nslices, s_begin + per);
   if (s_begin >= s_end) return;
 
+  // per-thread loader rows are fixed inside a slice; their pixel (n, oy, ox) is advanced by BKP pixels per slice with
+  // add/compare arithmetic (BKP = sa*OH*OW + sb*OW + sc) instead of two integer divisions per vector per slice.
+  const int sa = BKP / ohw, sb = (BKP - sa * ohw) / p.OW, sc = BKP - sa * ohw - sb * p.OW;
+  int xn[NVB], xoy[NVB], xox[NVB], xci[NVB], xr[NVB];
+  long ya[NVA]; int yr[NVA]; bool yc[NVA];
+  {
+    const int pb0 = s_begin * BKP;
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + j * 256; const int r = v / VPB, c = v - r * VPB;
+      const int pix = pb0 + r;
+      xr[j] = r; xci[j] = ci0 + c * VE;
+      xn[j] = pix / ohw; const int rem = pix - xn[j] * ohw; xoy[j] = rem / p.OW; xox[j] = rem - xoy[j] * p.OW;
+    }
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + j * 256; const int r = v / VPA, c = v - r * VPA;
+      yr[j] = r; yc[j] = (co0 + c * VE) < p.Cout;
+      ya[j] = (long)(pb0 + r) * p.lddy + co0 + c * VE;
+    }
+  }
   uint4 ra[NVA], rb[NVB];
   auto load_slice = [&](int s) {
     const int pb = s * BKP;
 #pragma unroll
     for (int j = 0; j < NVA; ++j) {
-      int v = tid + j * 256; int r = v / VPA, c = v - r * VPA;
-      int pix = pb + r, co = co0 + c * VE;
       uint4 val = make_uint4(0, 0, 0, 0);
-      if (pix < M && co < p.Cout) val = *(const uint4*)(DY + (long)pix * p.lddy + co);
+      if (pb + yr[j] < M && yc[j]) val = *(const uint4*)(DY + ya[j]);
       ra[j] = val;
+      ya[j] += (long)BKP * p.lddy;
     }
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
-      int v = tid + j * 256; int r = v / VPB, c = v - r * VPB;
-      int pix = pb + r, ci = ci0 + c * VE;
       uint4 val = make_uint4(0, 0, 0, 0);
-      if (pix < M && ci < p.Cin) {
-        int n_img = fast_div(pix, ohw, r_ohw); int rem = pix - n_img * ohw;
-        int oy = fast_div(rem, p.OW, r_ow), ox = rem - oy * p.OW;
-        int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-        if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-          val = *(const uint4*)(X + (((long)n_img * p.IH + iy) * p.IW + ix) * p.ldx + ci);
-      }
+      const int iy = xoy[j] * p.stride - p.pad + ky, ix = xox[j] * p.stride - p.pad + kx;
+      if (pb + xr[j] < M && xci[j] < p.Cin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+        val = *(const uint4*)(X + (((long)xn[j] * p.IH + iy) * p.IW + ix) * p.ldx + xci[j]);
       rb[j] = val;
+      // advance this row by BKP pixels
+      xox[j] += sc; if (xox[j] >= p.OW) { xox[j] -= p.OW; ++xoy[j]; }
+      xoy[j] += sb; if (xoy[j] >= p.OH) { xoy[j] -= p.OH; ++xn[j]; }
+      xn[j] += sa;
     }
   };
   auto store_slice = [&](int buf) {

@@ -190,7 +190,8 @@ class Network(object):
 
     def streams(self):
         if not hasattr(self, '_streams'):
-            self._streams = dict(lang=torch.cuda.Stream(), cap=torch.cuda.Stream(), wg=torch.cuda.Stream())
+            self._streams = dict(lang=torch.cuda.Stream(), cap=torch.cuda.Stream(), wg=torch.cuda.Stream(), wg2=torch.cuda.Stream())
+            self._wg_flip = 0
         return self._streams
 
     def sfork(self, from_stream, to_stream):
@@ -203,13 +204,16 @@ class Network(object):
         import contextlib
         if not self.use_streams:
             return contextlib.nullcontext()
-        wg = self.streams()['wg']
+        S = self.streams()
+        self._wg_flip ^= 1                                   # two weight-gradient streams, alternated: the small late-layer
+        wg = S['wg2'] if self._wg_flip else S['wg']          # GEMMs do not fill the chip on their own
         self.sfork(torch.cuda.current_stream(), wg)
         return torch.cuda.stream(wg)
 
     def join_wgrad(self):
         if self.use_streams:
             self.sfork(self.streams()['wg'], torch.cuda.current_stream())
+            self.sfork(self.streams()['wg2'], torch.cuda.current_stream())
 
     # ------------------------------------------------------------------ launch-tape replay of the whole step
     def tape_step(self, dev, train_op):
@@ -223,7 +227,7 @@ class Network(object):
         ent = self._tapes.get(key)
         main = torch.cuda.current_stream()
         S = self.streams()
-        slist = [main, S['lang'], S['cap'], S['wg']]
+        slist = [main, S['lang'], S['cap'], S['wg'], S['wg2']]
         if ent is None:
             st = {k: dev[k].clone() for k in ('data', 'gt_boxes', 'gt_masks', 'labels', 'cap_in', 'cap_tgt', 'cap_mask')}
             d = dict(dev); d.update(st)

@@ -45,7 +45,8 @@ class GradReducer(object):
         if self.on_gpu:
             self.side.wait_stream(torch.cuda.current_stream())
             if getattr(self.net, 'use_streams', False) and hasattr(self.net, '_streams'):
-                self.side.wait_stream(self.net._streams['wg'])      # weight gradients are produced on their own stream
+                self.side.wait_stream(self.net._streams['wg'])      # weight gradients are produced on their own streams
+                self.side.wait_stream(self.net._streams['wg2'])
             with torch.cuda.stream(self.side):
                 dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         else:                                   # CPU/gloo path (tests)
