@@ -166,8 +166,11 @@ int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, i
 /* RPN CE over anchors with label != -1 (NET:377-382) + smooth-L1 sigma=3 (NET:385-390).
  * heads as in l2s_rpn_decode; labels in (a,h,w) order.  dheads(dtype) [HW][ldd] receives d(loss)/d(heads)*gscale. */
 int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
-                 const float* outside_w, int H, int W, int A, float sigma, float gscale, float* loss, void* dheads, int ldd,
-                 int dtype, hipStream_t s);
+                 const float* outside_w, int H, int W, int A, float sigma, float gscale, float* loss /* += */, void* dheads, int ldd,
+                 int dtype, const int* count_dev /* #labels != -1 (l2s_anchor_target_count) or NULL */, int* count_ws /* 1 int, used when count_dev is NULL */,
+                 hipStream_t s);
+/* device pointer to the number of sampled anchors inside an l2s_anchor_target workspace */
+const int* l2s_anchor_target_count(const int* ws);
 /* RCNN CE mean over R (NET:393-395) + smooth-L1 sigma=1 (NET:398-402). heads float [R][ldh]: [0,ncls) cls, [ncls,5ncls) bbox */
 int l2s_rcnn_loss(const float* heads, int ldh, const int* labels, const float* bbox_targets, const float* inside_w,
                   const float* outside_w, int R, int ncls, float gscale, float* loss, void* dheads, int ldd, int dtype, hipStream_t s);

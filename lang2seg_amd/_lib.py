@@ -73,7 +73,8 @@ SIGS = {
                                   vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'l2s_roialign_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, i32, vp]),
     'l2s_roialign_bwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, i32, vp]),
-    'l2s_rpn_loss': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp]),
+    'l2s_rpn_loss': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp, vp, vp]),
+    'l2s_anchor_target_count': (vp, [vp]),
     'l2s_rcnn_loss': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, f32, vp, vp, i32, i32, vp]),
     'l2s_mask_loss': (i32, [vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     'l2s_total_loss': (i32, [vp, f32, vp]),

@@ -14,19 +14,17 @@ __device__ __forceinline__ float smooth_l1(float d, float s2, float& grad) {
   return ad - 0.5f / s2;
 }
 
-__global__ __launch_bounds__(1024) void rpn_loss_kernel(const float* heads, int ldh, const int* labels, const float* tgt, const float* inw,
-                                                       const float* outw, int H, int W, int A, float sigma, float gscale, float* loss,
-                                                       void* dheads, int ldd, int dt) {
-  __shared__ float red[16];
-  const int tid = threadIdx.x, nt = blockDim.x;
+// multi-workgroup: the number of sampled anchors comes from the anchor-target kernel (device int), so no counting pass
+__global__ __launch_bounds__(256) void rpn_loss_kernel(const float* heads, int ldh, const int* labels, const float* tgt, const float* inw,
+                                                      const float* outw, int H, int W, int A, float sigma, float gscale, float* loss,
+                                                      void* dheads, int ldd, int dt, const int* count_dev) {
+  __shared__ float red[4];
   const int n = H * W * A;
-  float cnt = 0.f;
-  for (int i = tid; i < n; i += nt) cnt += (labels[i] != -1) ? 1.f : 0.f;
-  cnt = block_sum(cnt, red);
+  const float cnt = (float)(*count_dev);
   const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
   const float s2 = sigma * sigma;
   float lce = 0.f, lbox = 0.f;
-  for (int i = tid; i < n; i += nt) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     // i enumerates (h, w, a); the label array is laid out (a, h, w)
     const int a = i % A, pix = i / A, w = pix % W, h = pix / W;
     const int l = labels[(a * H + h) * W + w];
@@ -52,15 +50,19 @@ __global__ __launch_bounds__(1024) void rpn_loss_kernel(const float* heads, int 
       lbox += ow * v;
       stx(dheads, (long)pix * ldd + 2 * A + a * 4 + k, dt, ow * iw * g * gscale);
     }
+    // padding columns of dheads (so the dgrad GEMM can run over ldd columns): written by the a == 0 thread of the pixel
+    if (a == 0) for (int c = 6 * A; c < ldd; ++c) stx(dheads, (long)pix * ldd + c, dt, 0.f);
   }
   lce = block_sum(lce, red);
   lbox = block_sum(lbox, red);
-  if (tid == 0) { loss[L2S_LOSS_RPN_CLS] = lce * inv; loss[L2S_LOSS_RPN_BOX] = lbox; }
-  // zero the padding columns of dheads so the dgrad GEMM can run over ldd columns
-  for (long e = tid; e < (long)H * W * (ldd - 6 * A); e += nt) {
-    const long pix = e / (ldd - 6 * A); const int c = 6 * A + (int)(e % (ldd - 6 * A));
-    stx(dheads, pix * ldd + c, dt, 0.f);
-  }
+  if (threadIdx.x == 0) { atomicAdd(loss + L2S_LOSS_RPN_CLS, lce * inv); atomicAdd(loss + L2S_LOSS_RPN_BOX, lbox); }
+}
+__global__ void count_labels_kernel(const int* labels, int n, int* out) {   // fallback when no device count is supplied
+  __shared__ float red[16];
+  float c = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) c += labels[i] != -1 ? 1.f : 0.f;
+  c = block_sum(c, red);
+  if (threadIdx.x == 0) *out = (int)c;
 }
 
 // one wave per roi
@@ -153,8 +155,14 @@ __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, 
 
 extern "C" int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
                             const float* outside_w, int H, int W, int A, float sigma, float gscale, float* loss, void* dheads, int ldd,
-                            int dtype, hipStream_t s) {
-  L2S_LAUNCH(rpn_loss_kernel, dim3(1), dim3(1024), 0, s, heads, ldh, labels, targets, inside_w, outside_w, H, W, A, sigma, gscale, loss, dheads, ldd, dtype);
+                            int dtype, const int* count_dev, int* count_ws, hipStream_t s) {
+  const int n = H * W * A;
+  if (!count_dev) {
+    if (!count_ws) return L2S_EINVAL;
+    L2S_LAUNCH(count_labels_kernel, dim3(1), dim3(1024), 0, s, labels, n, count_ws);
+    count_dev = count_ws;
+  }
+  L2S_LAUNCH(rpn_loss_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, heads, ldh, labels, targets, inside_w, outside_w, H, W, A, sigma, gscale, loss, dheads, ldd, dtype, count_dev);
   return l2s_check_launch();
 }
 extern "C" int l2s_rcnn_loss(const float* heads, int ldh, const int* labels, const float* bbox_targets, const float* inside_w,

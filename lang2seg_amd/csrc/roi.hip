@@ -571,6 +571,7 @@ extern "C" int l2s_gather_rois(const float* sorted_boxes, const float* sorted_sc
   L2S_LAUNCH(gather_rois_kernel, dim3(cdiv(max_keep, 256)), dim3(256), 0, s, sorted_boxes, sorted_scores, keep, num, max_keep, rois, roi_scores);
   return l2s_check_launch();
 }
+extern "C" const int* l2s_anchor_target_count(const int* ws) { return ws + 2; }
 extern "C" long l2s_anchor_target_ws_ints(int hwa) { return 16 + 64 + 4L * hwa + 16; }
 extern "C" int l2s_anchor_target(const float* gt, int n_gt, const float* base_anchors, int H, int W, int A, int feat_stride,
                                  float im_h, float im_w, const uint32_t* fg_keys, const uint32_t* bg_keys,

@@ -190,7 +190,8 @@ class Network(object):
 
     def streams(self):
         if not hasattr(self, '_streams'):
-            self._streams = dict(lang=torch.cuda.Stream(), cap=torch.cuda.Stream(), wg=torch.cuda.Stream(), wg2=torch.cuda.Stream())
+            self._streams = dict(lang=torch.cuda.Stream(), cap=torch.cuda.Stream(), wg=torch.cuda.Stream(), wg2=torch.cuda.Stream(),
+                                 tr=torch.cuda.Stream())
             self._wg_flip = 0
         return self._streams
 
@@ -227,7 +228,7 @@ class Network(object):
         ent = self._tapes.get(key)
         main = torch.cuda.current_stream()
         S = self.streams()
-        slist = [main, S['lang'], S['cap'], S['wg'], S['wg2']]
+        slist = [main, S['lang'], S['cap'], S['wg'], S['wg2'], S['tr']]
         if ent is None:
             st = {k: dev[k].clone() for k in ('data', 'gt_boxes', 'gt_masks', 'labels', 'cap_in', 'cap_tgt', 'cap_mask')}
             d = dict(dev); d.update(st)
@@ -331,7 +332,21 @@ class Network(object):
                 arr[i].Cout, arr[i].taps, arr[i].Cin, arr[i].force_f32 = c.Np, c.k * c.k, c.Cin, int(getattr(c, 'force_f32', 0))
             self._tr_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             self._tr_n = len(items)
-        O.weight_transpose_batched(self._tr_table, self._tr_n, self.dt)
+        if self.use_streams and not full:
+            # the transposed copies are first read by the NEXT step's mask head / backward: rebuild them on a side stream that
+            # overlaps with the next step's backbone forward (joined by join_transposes())
+            S = self.streams()
+            self.sfork(torch.cuda.current_stream(), S['tr'])
+            with torch.cuda.stream(S['tr']):
+                O.weight_transpose_batched(self._tr_table, self._tr_n, self.dt)
+            self._tr_pending = True
+        else:
+            O.weight_transpose_batched(self._tr_table, self._tr_n, self.dt)
+
+    def join_transposes(self):
+        if self.use_streams and getattr(self, '_tr_pending', False):
+            self.sfork(self.streams()['tr'], torch.cuda.current_stream())
+            self._tr_pending = False
 
     # ------------------------------------------------------------------ blobs
     def upload_blob(self, blobs, idx):

@@ -338,6 +338,7 @@ class resnetv1(Network):
         HW = Hc * Wc
         t['net_conv_base'] = base
         # ---- dynamic filters (NET:504-562) ----
+        self.join_transposes()       # last step's transposed weight copies (first readers: caption / RoI branches below)
         if S is not None:
             self.sfork(S['lang'], main)
         net_conv = self.buf('dyn.y', (HW, C4)); resp = self.buf('dyn.resp', (HW,), f32); respk = self.buf('dyn.respk', (HW, 7), f32)
@@ -399,13 +400,17 @@ class resnetv1(Network):
             rois_all[:fr.shape[0]].copy_(fr); rsc_all[:fs.shape[0]].copy_(fs)
             nkeep = torch.tensor([fr.shape[0]], dtype=torch.int32, device=self.device)
         # ---- targets (ATL:19-153, PTL:22-204) ----
+        # anchor targets only need the gt box: they run on the language stream, beside the proposal chain
         rl = self.buf('atl.labels', (nA,), torch.int32); rt = self.buf('atl.t', (HW, 4 * A), f32)
         ri = self.buf('atl.i', (HW, 4 * A), f32); ro = self.buf('atl.o', (HW, 4 * A), f32)
         aws = self.buf('atl.ws', (O.anchor_target_ws_ints(nA),), torch.int32)
         n_gt = int(d['gt_boxes'].shape[0])
-        O.anchor_target(d['gt_boxes'], n_gt, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, self._keys('rpn_fg_keys', nA),
-                        self._keys('rpn_bg_keys', nA), TR.RPN_NEGATIVE_OVERLAP, TR.RPN_POSITIVE_OVERLAP, int(TR.RPN_BATCHSIZE),
-                        TR.RPN_FG_FRACTION, rl, rt, ri, ro, aws)
+        if S is not None:
+            self.sfork(main, S['lang'])
+        with on('lang'):
+            O.anchor_target(d['gt_boxes'], n_gt, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, self._keys('rpn_fg_keys', nA),
+                            self._keys('rpn_bg_keys', nA), TR.RPN_NEGATIVE_OVERLAP, TR.RPN_POSITIVE_OVERLAP, int(TR.RPN_BATCHSIZE),
+                            TR.RPN_FG_FRACTION, rl, rt, ri, ro, aws)
         t.update({'rpn_labels': rl, 'rpn_bbox_targets': rt, 'rpn_bbox_inside': ri, 'rpn_bbox_outside': ro})
         rois = self.buf('ptl.rois', (R, 5), f32); labels = self.buf('ptl.labels', (R,), torch.int32)
         bt = self.buf('ptl.bt', (R, 4 * nc), f32); bi = self.buf('ptl.bi', (R, 4 * nc), f32); bo = self.buf('ptl.bo', (R, 4 * nc), f32)
@@ -436,7 +441,9 @@ class resnetv1(Network):
         t.update({'pool5': pool5, 'spatial_fc7': fc7s, 'rcnn_heads': cheads, 'mask_score': mscore})
         # ---- detection losses + head gradients (NET:375-413) ----
         d_rheads = self.buf('rpn.dheads', (HW, NPR)); d_cheads = self.buf('roi.dheads', (R, NPC)); dscore = self.buf('mask.dscore', (FGM * MS * MS,), f32)
-        O.rpn_loss(rheads, NPR, rl, rt, ri, ro, Hc, Wc, A, 3.0, 1.0, loss, d_rheads, NPR)
+        if S is not None:
+            self.sfork(S['lang'], main)                    # anchor targets
+        O.rpn_loss(rheads, NPR, rl, rt, ri, ro, Hc, Wc, A, 3.0, 1.0, loss, d_rheads, NPR, atl_ws=aws)
         O.rcnn_loss(cheads, NPC, labels, bt, bi, bo, R, nc, 1.0, loss, d_cheads, NPC)
         O.mask_loss(mscore, nc, labels, mt, counts, FGM, MS * MS, 1.0, loss, dscore)
         # =================================== backward (detection side, main stream) ===================================

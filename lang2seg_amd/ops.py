@@ -228,9 +228,15 @@ def roialign_bwd(dout, H, W, Cc, rois, R, P, sscale, dfeat):
 
 
 # ------------------------------------------------------------------ losses
-def rpn_loss(heads, ldh, labels, targets, inw, outw, H, W, A, sigma, gscale, loss, dheads, ldd):
+def rpn_loss(heads, ldh, labels, targets, inw, outw, H, W, A, sigma, gscale, loss, dheads, ldd, atl_ws=None):
+    """atl_ws: the anchor-target workspace (its sampled-anchor count is reused); otherwise the labels are counted."""
+    if atl_ws is not None:
+        cnt, cws = ptr(atl_ws) + 8, None
+    else:
+        cws = torch.zeros(1, dtype=torch.int32, device=heads.device)
+        cnt, cws = None, ptr(cws)
     call('l2s_rpn_loss', ptr(heads), ldh, ptr(labels), ptr(targets), ptr(inw), ptr(outw), H, W, A, float(sigma), float(gscale),
-         ptr(loss), ptr(dheads), ldd, dt_of(dheads), stream())
+         ptr(loss), ptr(dheads), ldd, dt_of(dheads), cnt, cws, stream())
 
 
 def rcnn_loss(heads, ldh, labels, bt, bi, bo, R, ncls, gscale, loss, dheads, ldd):
