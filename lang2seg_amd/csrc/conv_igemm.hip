@@ -44,8 +44,8 @@ constexpr int ROWB = 128;        // bytes of K per LDS row per slice
 constexpr int LROW = ROWB + 16;  // padded LDS row
 
 // ---- shared epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 accumulator tile ----
-template <typename T, int TM, int TN, int WM, int WN, bool OUTF32>
-__device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M) {
+template <typename T, int TM, int TN, int WM, int WN, bool OUTF32, int KS = 1>
+__device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, int grp = 0) {
   const int ohw = p.OH * p.OW;
   const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
   const bool vec_ok = ((p.ldy & 3) == 0) && ((p.ldadd & 3) == 0) && ((p.ldref & 3) == 0) && ((Cq & 3) == 0);
@@ -61,6 +61,7 @@ __device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&a
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+      if (KS > 1 && ((i * TN + j) % KS) != grp) continue;   // in-workgroup split-K: K-group grp finishes these sub-tiles
       const int n = n0 + wn * WN + j * 16 + fg * 4;
       if (n >= p.Cout) continue;
       int oc = n; long orow2 = orow;
@@ -270,6 +271,195 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 
   if (gridDim.z > 1) { igemm_splitk_atomics<T, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, fr, fg, M); return; }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring variant (the default): same tiling / LDS image / epilogue as igemm_kernel, but the operands are fetched with
+// buffer_load_dwordx4 through two wave-uniform buffer descriptors into a ring of D register sets, D slices ahead of
+// the MFMAs.  Per load the address is descriptor + 32-bit per-row voffset (rebuilt only when the filter tap changes)
+// + scalar slice offset, so the K loop carries no per-load address arithmetic; out-of-image taps, rows >= M and
+// channels >= Cout get voffset = 0x80000000, which the descriptor's range check turns into zeros without a branch
+// (branch-free loads are what lets hipcc keep D slices in flight with counted vmcnt instead of draining at every use).
+// Iteration t:  barrier -> ds_write slice t+1 (issued D iterations ago) -> issue slice t+1+D -> MFMAs on slice t.
+// Requires Cin % BK == 0 for every tap (no K tail) and operand extents < 2 GiB; the launcher falls back otherwise.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned OOR = 0x80000000u;
+
+template <typename T, int BM, int BN, int D, bool OUTF32, int KS>
+__global__ __launch_bounds__(256 * KS) void igemm_ring_kernel(const l2s_conv_desc p) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int NA = BM / 32, NB = BN / 32;
+  constexpr int BUF = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+
+  // KS > 1: in-workgroup split-K.  The workgroup holds KS K-groups of 4 waves; group g runs the loop below over slices
+  // [g KT/KS, (g+1) KT/KS) (KT % KS == 0, so every group executes the same barriers) in its own LDS double buffer, then
+  // the partial accumulators are exchanged through LDS and each group finishes 1/KS of the 16x16 sub-tiles.
+  const int grp = KS > 1 ? (int)(threadIdx.x >> 8) : 0;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  int mt, nt;
+  {
+    const int MT = (M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;
+    if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  char* smem = smem_all + grp * (2 * BUF);
+  const long xpix = (long)p.n_img * p.IH * p.IW;
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((xpix - 1) * p.ldx + p.Cin) * (long)sizeof(T)), 0x00020000);
+  const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * K * (long)sizeof(T)), 0x00020000);
+
+  const int lrow = tid >> 3, cv = tid & 7;
+  const int wchunk = ((cv ^ (lrow & 7)) << 4);
+  int a_iy0[NA], a_ix0[NA], a_base[NA]; bool a_ok[NA];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    int m = m0 + lrow + 32 * j;
+    a_ok[j] = m < M;
+    int mm = a_ok[j] ? m : 0;
+    int n_img = mm / ohw, rem = mm - n_img * ohw;
+    int oy = rem / p.OW, ox = rem - oy * p.OW;
+    a_iy0[j] = oy * p.stride - p.pad;
+    a_ix0[j] = ox * p.stride - p.pad;
+    a_base[j] = n_img * p.IH * p.IW;
+  }
+  unsigned voffB[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + lrow + 32 * j;
+    voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + cv * VE) * (long)sizeof(T)) : OOR;
+  }
+  // issue-side state (uniform): slice index, tap, channel offset inside the tap
+  const int KT = K / BK / KS;                   // slices of this K-group
+  const int taps = p.KH * p.KW;
+  int it = grp * KT, c0 = it * BK, tap = 0;
+  if (KS > 1 && taps > 1) { tap = c0 / p.Cin; c0 -= tap * p.Cin; }
+  unsigned voffA[NA];
+  auto set_tap = [&](int t) {
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+      const bool v = a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      voffA[j] = v ? (unsigned)(((long)(a_base[j] + iy * p.IW + ix) * p.ldx + cv * VE) * (long)sizeof(T)) : OOR;
+    }
+  };
+  set_tap(tap);
+  auto issue = [&](uint4 (&a)[NA], uint4 (&b)[NB]) {
+    const int sa = c0 * (int)sizeof(T), sb = it * (BK * (int)sizeof(T));
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, voffA[j], sa, 0));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, voffB[j], sb, 0));
+    ++it; c0 += BK;
+    if (c0 >= p.Cin && taps > 1) { c0 = 0; ++tap; if (tap < taps) set_tap(tap); }
+  };
+  auto store_slice = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
+    char* a = smem + buf * BUF + lrow * ROWB + wchunk;
+    char* b = a + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *(uint4*)(a + 32 * j * ROWB) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *(uint4*)(b + 32 * j * ROWB) = rb[j];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ring set s holds slice k with k % D == s.  Prologue: slices 0..D-1 issued; slice 0 to LDS; slice D re-issued into set 0.
+  uint4 ra[D][NA], rb[D][NB];
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < KT) issue(ra[s], rb[s]);
+  store_slice(0, ra[0], rb[0]);
+  if (D < KT) issue(ra[0], rb[0]);
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = fr & 7;
+  const int offa = (wm * WM + fr) * ROWB, offb = BM * ROWB + (wn * WN + fr) * ROWB;
+  auto compute = [&](int t) {
+    const char* base = smem + (t & 1) * BUF;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int ch = ((kg * 4 + fg) ^ swz) << 4;
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * ROWB + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * ROWB + ch);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
+    }
+  };
+  // steady state: every iteration stores slice t+1 and issues slice t+1+D, no conditions (so the compiler's vmcnt is the
+  // exact count of the D-1 younger sets); unrolled by D so that the ring set index is a compile-time constant.
+  int t0 = 0;
+  for (; t0 + 2 * D <= KT; t0 += D) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      const int t = t0 + s;
+      const int nxt = (s + 1) % D;
+      __syncthreads();
+      store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
+      issue(ra[nxt], rb[nxt]);
+      compute(t);
+    }
+  }
+  // tail: fewer than 2 D slices left
+#pragma unroll
+  for (int s = 0; s < 2 * D; ++s) {
+    const int t = t0 + s;
+    if (t < KT) {
+      const int nxt = (s + 1) % D;
+      __syncthreads();
+      if (t + 1 < KT) {
+        store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
+        if (t + 1 + D < KT) issue(ra[nxt], rb[nxt]);
+      }
+      compute(t);
+    }
+  }
+  if (KS > 1) {
+    // exchange: slot [(owner group)][(source group)][sub-tile rank][thread] float4; a group keeps the sub-tiles it owns
+    __syncthreads();
+    constexpr int NSUB = TM * TN, PER = (NSUB + KS - 1) / KS;
+    float4* xch = (float4*)smem_all;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int sub = i * TN + j, owner = sub % KS;
+        if (owner != grp) xch[((owner * KS + grp) * PER + sub / KS) * 256 + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int sub = i * TN + j;
+        if (sub % KS == grp) {
+#pragma unroll
+          for (int g = 0; g < KS; ++g)
+            if (g != grp) {
+              const float4 v = xch[((grp * KS + g) * PER + sub / KS) * 256 + tid];
+              acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+            }
+        }
+      }
+  }
+  igemm_epilogue<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -600,7 +790,7 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN), 1, split);
   size_t lds = 2 * (BM + BN) * ROWB;
   static bool attr_done = false;
-  if (!attr_done) { hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   L2S_LAUNCH((igemm_kernel<T, BM, BN, OUTF32>), grid, dim3(256), lds, st, d);
   if (split > 1) {
     const long total = (long)M * d.Cout;
@@ -610,13 +800,24 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
+template <typename T, int BM, int BN, int D, bool OUTF32, int KS = 1>
+int launch_igemm_ring(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN));
+  size_t lds = (size_t)KS * 2 * (BM + BN) * ROWB;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ring_kernel<T, BM, BN, D, OUTF32, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_ring_kernel<T, BM, BN, D, OUTF32, KS>), grid, dim3(256 * KS), lds, st, d);
+  return l2s_check_launch();
+}
+
 template <typename T, int BM, int BN, int STAGES, bool OUTF32>
 int launch_igemm_pipe(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN));
   size_t lds = (size_t)STAGES * (BM + BN) * ROWB;
   static bool attr_done = false;
-  if (!attr_done) { hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   L2S_LAUNCH((igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>), grid, dim3(256), lds, st, d);
   return l2s_check_launch();
 }
@@ -655,6 +856,40 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     dd.xcd_mode = (wbytes + abytes / 8.0 <= 3.0 * 1024 * 1024) ? 0 : 1;
   }
   d = &dd;
+  // ring kernel (default): needs whole 128-byte K slices per tap and 31-bit operand extents
+  static const int ring_d = [] { const char* e = getenv("L2S_IGEMM_RING"); return e ? atoi(e) : -1; }();   // 0 = off
+  static const int ring_ks = [] { const char* e = getenv("L2S_IGEMM_KS"); return e ? atoi(e) : 0; }();     // 0 = auto, 1 = off, 2/4 = forced
+  {
+    const int bk = dtype == L2S_BF16 ? 64 : 32;
+    const long esz = dtype == L2S_BF16 ? 2 : 4;
+    const long xb = (long)d->n_img * d->IH * d->IW * d->ldx * esz, wb = (long)d->Cout * K * esz;
+    const bool ok = ring_d != 0 && (d->Cin % bk == 0) && xb < (1L << 31) && wb < (1L << 31) && !(d->ws && d->split_k > 1);
+    if (ok) {
+#define GR(T, BM, BN, DD, KS) (f32o ? launch_igemm_ring<T, BM, BN, DD, true, KS>(*d, stream) : launch_igemm_ring<T, BM, BN, DD, false, KS>(*d, stream))
+      // in-workgroup split-K for the 64x64 tile when the tile grid cannot fill the chip with several workgroups per CU
+      const int KT = K / bk;
+      const long tiles64 = (long)cdiv(M, 64) * cdiv(d->Cout, 64);
+      int ks = 1;
+      if (tile == 64 && ring_ks != 1) {
+        if (ring_ks > 1) ks = ring_ks;
+        else if (tiles64 <= 768) ks = KT >= 16 ? 4 : (KT >= 8 ? 2 : 1);
+        while (ks > 1 && (KT % ks)) ks >>= 1;
+      }
+      if (dtype == L2S_BF16) {
+        if (tile == 128) return GR(bf16_t, 128, 128, 2, 1);
+        if (ks == 4) return GR(bf16_t, 64, 64, 3, 4);
+        if (ks == 2) return GR(bf16_t, 64, 64, 3, 2);
+        return GR(bf16_t, 64, 64, 4, 1);
+      }
+      if (dtype == L2S_F32) {
+        if (tile == 128) return GR(float, 128, 128, 2, 1);
+        if (ks == 4) return GR(float, 64, 64, 3, 4);
+        if (ks == 2) return GR(float, 64, 64, 3, 2);
+        return GR(float, 64, 64, 4, 1);
+      }
+#undef GR
+    }
+  }
   static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 0; }();   // measured slower than the register-staged kernel at 128x128/64x64 tiles (profiles/r01_conv_bench.txt): LDS-DMA issue cost
   const bool split_req = d->ws && d->split_k > 1;
   if (use_pipe && !split_req) {

@@ -248,6 +248,12 @@ class Network(object):
         O.tape_run(h, slist)
         return loss
 
+    def _mark(self, name):
+        """optional phase marker (tools/phase_times.py): a timing event on the current stream."""
+        pe = getattr(self, 'phase_events', None)
+        if pe is not None:
+            e = torch.cuda.Event(enable_timing=True); e.record(); pe.append((name, e))
+
     def seed_counter(self):
         c = getattr(self, '_seed_counter', None)
         if c is None:

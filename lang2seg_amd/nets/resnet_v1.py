@@ -321,6 +321,7 @@ class resnetv1(Network):
             NF = 7 * C4 + 7
             filt = self.buf('dyn.filt', (NF,), f32)
             O.linear_fwd(hidden, P.gview('dyn_w', NF * HD), P.gview('dyn_b', NF), filt, 1, NF, HD, act=2)
+        self._mark('encoder_fwd(lang)')
         # ---- head: conv1/bn1/relu/maxpool/layer1-3 (RES:261-265,309-310) ----
         OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         c1 = self.buf('stem.c1', (OH1 * OW1, 64))
@@ -329,11 +330,13 @@ class resnetv1(Network):
         h, w = (OH1 + 2 - 3) // 2 + 1, (OW1 + 2 - 3) // 2 + 1
         x = self.buf('stem.pool', (h * w, 64))
         O.maxpool(c1, x, OH1, OW1, 64, h, w)
+        self._mark('stem')
         saved = {}
         for li in (1, 2, 3):
             for b, blk in enumerate(self.layers[li]):
                 x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
                 saved[(li, b)] = sv
+        self._mark('layer1-3 fwd')
         base, Hc, Wc = x, h, w
         HW = Hc * Wc
         t['net_conv_base'] = base
@@ -373,6 +376,7 @@ class resnetv1(Network):
             self.sfork(main, S['cap'])
         with on('cap'):
             d_nc_cap = caption_branch()
+        self._mark('dyn + caption branch (cap)')
         # ---- RPN (NET:235-275) ----
         rpn = self.buf('rpn.a', (HW, 512))
         self.rpn_conv.fwd(net_conv, 1, Hc, Wc, rpn, relu=True)
@@ -383,6 +387,7 @@ class resnetv1(Network):
         prob = self.buf('rpn.prob', (HW, 2 * A), f32); boxes = self.buf('rpn.boxes', (nA, 4), f32); scores = self.buf('rpn.scores', (nA,), f32)
         O.rpn_decode(rheads, NPR, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, prob, boxes, scores)
         t['rpn_heads'], t['rpn_cls_prob'] = rheads, prob
+        self._mark('rpn conv+heads+decode')
         key = 'TRAIN' if self._mode == 'TRAIN' else 'TEST'
         pre = int(cfg[key].RPN_PRE_NMS_TOP_N); post = int(cfg[key].RPN_POST_NMS_TOP_N)
         pre = nA if pre <= 0 else min(pre, nA)
@@ -399,6 +404,7 @@ class resnetv1(Network):
             rois_all = self.buf('prop.rois_forced', (post, 5), f32, zero=True); rsc_all = self.buf('prop.rsc_forced', (post,), f32, zero=True)
             rois_all[:fr.shape[0]].copy_(fr); rsc_all[:fs.shape[0]].copy_(fs)
             nkeep = torch.tensor([fr.shape[0]], dtype=torch.int32, device=self.device)
+        self._mark('sort+nms+gather')
         # ---- targets (ATL:19-153, PTL:22-204) ----
         # anchor targets only need the gt box: they run on the language stream, beside the proposal chain
         rl = self.buf('atl.labels', (nA,), torch.int32); rt = self.buf('atl.t', (HW, 4 * A), f32)
@@ -421,6 +427,7 @@ class resnetv1(Network):
                           self._keys('roi_bg_keys', post + n_gt), self._keys('roi_bg_rand', R), R, FGM, TR.FG_THRESH, TR.BG_THRESH_HI,
                           TR.BG_THRESH_LO, cst['means'], cst['stds'], cst['inw'], nc, MS, rois, labels, bt, bi, bo, mt, counts, pws)
         t.update({'rois': rois, 'labels': labels, 'bbox_targets': bt, 'bbox_inside': bi, 'bbox_outside': bo, 'mask_targets': mt, 'counts': counts})
+        self._mark('targets')
         # ---- RoI head (NET:572-586) ----
         pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
         O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5)
@@ -439,6 +446,7 @@ class resnetv1(Network):
         mscore = self.buf('mask.score', (FGM * MS * MS, nc), f32)
         self.mask_pred.fwd(up, FGM, MS, MS, mscore, out_f32=True)
         t.update({'pool5': pool5, 'spatial_fc7': fc7s, 'rcnn_heads': cheads, 'mask_score': mscore})
+        self._mark('roi head fwd')
         # ---- detection losses + head gradients (NET:375-413) ----
         d_rheads = self.buf('rpn.dheads', (HW, NPR)); d_cheads = self.buf('roi.dheads', (R, NPC)); dscore = self.buf('mask.dscore', (FGM * MS * MS,), f32)
         if S is not None:
@@ -454,6 +462,7 @@ class resnetv1(Network):
             O.total_loss(loss, self._cap_loss_weight)
             t['loss'] = loss
             return loss
+        self._mark('losses')
         # rcnn heads -> fc7 -> spatial_fc7
         self.rcnn_heads.wgrad(d_cheads, fc7, R, 1, 1)
         dfc7 = self.buf('roi.dfc7', (R, 2048))
@@ -474,8 +483,10 @@ class resnetv1(Network):
             O.avgpool_bwd(dfc7[FGM:], g[off:], None, fc7s[off:], R - FGM, PS * PS, 2048)
         for b in reversed(range(len(self.layers[4]))):
             g = self.layers[4][b].bwd(g, saved[('4r', b)], 'l4r.%d' % b, x_is_relu_out=(b > 0))
+        self._mark('roi head bwd')
         d_nc_roi = self.buf('roi.dfeat', (HW, C4), f32, zero=True)
         O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
+        self._mark('roialign bwd')
         # rpn
         self.rpn_heads.wgrad(d_rheads, rpn, 1, Hc, Wc)
         drpn = self.buf('rpn.da', (HW, 512))
@@ -491,6 +502,7 @@ class resnetv1(Network):
             dp.ready('heads')                              # caption + layer4 + RoI/mask heads are final here
         d_nc = self.buf('dyn.dy', (HW, C4))
         O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)
+        self._mark('rpn bwd + add3')
         # dynamic filters (NET:504-562)
         dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (HW,), f32)
         O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4)
@@ -504,6 +516,7 @@ class resnetv1(Network):
             dhidden = self.buf('enc.dhidden', (HD,), f32)
             self.bwd_x(dfilt, 'dyn_w', dhidden, 1)
             self._encoder_bwd(d, dhidden)
+        self._mark('dyn bwd + language bwd(lang)')
         # backbone layer3, layer2 (layer1 and the stem are frozen: RES:290-299)
         g = dbase
         fb = cfg.RESNET.FIXED_BLOCKS
@@ -516,6 +529,7 @@ class resnetv1(Network):
                 if S is not None:
                     self.sfork(S['lang'], main)
                 dp.ready('layer3')                        # everything except layer2 is final
+        self._mark('layer3-2 bwd')
         if S is not None:
             self.sfork(S['lang'], main)
         return loss
