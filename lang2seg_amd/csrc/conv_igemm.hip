@@ -43,12 +43,115 @@ template <> struct Mma<float> {
 constexpr int ROWB = 128;        // bytes of K per LDS row per slice
 constexpr int LROW = ROWB + 16;  // padded LDS row
 
+// ---- branch-free epilogue (all row pitches and Cout multiples of 4, extents < 2 GiB): every bias / residual / mask
+// operand of the wave's TM x TN sub-tiles is requested before the first use (buffer loads; out-of-range rows and
+// channels carry offset 0x80000000, so loads return 0 and stores are dropped), instead of one dependent HBM round trip
+// per sub-tile ----
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+template <typename T, int TM, int TN, int WM, int WN, bool OUTF32, int KS>
+__device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, int grp) {
+  constexpr unsigned NOPE = 0x80000000u;
+  constexpr int ES = (int)sizeof(T), OS = (OUTF32 || sizeof(T) == 4) ? 4 : 2;
+  const int ohw = p.OH * p.OW;
+  const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
+  const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFFFF, 0x00020000);
+  const auto radd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add ? p.add : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref ? p.ref : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const auto rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.y), 0, 0x7FFFFFFF, 0x00020000);
+  int orow[TM][TN], ocol[TM][TN]; bool ok[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + fr;
+    int n_img = 0, oy = 0, ox = 0, r0 = m;
+    if (p.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) {
+      n_img = m / ohw; const int rem = m - n_img * ohw; oy = rem / p.OW; ox = rem - oy * p.OW;
+      if (p.flags & L2S_CONV_SCATTER) r0 = (n_img * p.out_h + oy * p.out_stride) * p.out_w + ox * p.out_stride;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fg * 4;
+      int oc = n, r2 = r0;
+      if (p.flags & L2S_CONV_DECONV2X2) {
+        const int tap = n / Cq; oc = n - tap * Cq;
+        r2 = (n_img * 2 * p.OH + 2 * oy + (tap >> 1)) * (2 * p.OW) + 2 * ox + (tap & 1);
+      }
+      orow[i][j] = r2; ocol[i][j] = oc;
+      ok[i][j] = (m < M) && (n < p.Cout) && (KS == 1 || ((i * TN + j) % KS) == grp);
+    }
+  }
+  f32x4 bv[TN];
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fg * 4;
+      const unsigned o = n < p.Cout ? (unsigned)(ocol[0][j] * 4) : NOPE;
+      bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, o, 0, 0));
+    }
+  }
+  // residual and ReLU-mask operands: 4 channels = 8 bytes (bf16) or 16 bytes (f32) per lane and sub-tile
+  u32x4v av[TM][TN], rv[TM][TN];
+  if (p.add) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned o = ok[i][j] ? (unsigned)((orow[i][j] * p.ldadd + ocol[i][j]) * ES) : NOPE;
+        if (ES == 4) av[i][j] = __builtin_amdgcn_raw_buffer_load_b128(radd, o, 0, 0);
+        else { const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(radd, o, 0, 0); av[i][j] = (u32x4v){t.x, t.y, 0u, 0u}; }
+      }
+  }
+  if (p.ref) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned o = ok[i][j] ? (unsigned)((orow[i][j] * p.ldref + ocol[i][j]) * ES) : NOPE;
+        if (ES == 4) rv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rref, o, 0, 0);
+        else { const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rref, o, 0, 0); rv[i][j] = (u32x4v){t.x, t.y, 0u, 0u}; }
+      }
+  }
+  auto unpack = [](const u32x4v& q, float (&f)[4]) {
+    if (ES == 4) { f[0] = __uint_as_float(q.x); f[1] = __uint_as_float(q.y); f[2] = __uint_as_float(q.z); f[3] = __uint_as_float(q.w); }
+    else { f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xFFFF0000u); f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xFFFF0000u); }
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) { v[0] += bv[j][0]; v[1] += bv[j][1]; v[2] += bv[j][2]; v[3] += bv[j][3]; }
+      if (p.add) { float a[4]; unpack(av[i][j], a); v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3]; }
+      if (p.flags & L2S_CONV_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (p.ref) {
+        float r[4]; unpack(rv[i][j], r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!(r[e] > 0.f)) v[e] = 0.f;
+      }
+      const unsigned o = ok[i][j] ? (unsigned)((orow[i][j] * p.ldy + ocol[i][j]) * OS) : NOPE;
+      if (OS == 4) {
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4v){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ry, o, 0, 0);
+      } else {
+        u32x2 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        __builtin_amdgcn_raw_buffer_store_b64(pk, ry, o, 0, 0);
+      }
+    }
+}
+
 // ---- shared epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 accumulator tile ----
 template <typename T, int TM, int TN, int WM, int WN, bool OUTF32, int KS = 1>
 __device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, int grp = 0) {
   const int ohw = p.OH * p.OW;
   const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
   const bool vec_ok = ((p.ldy & 3) == 0) && ((p.ldadd & 3) == 0) && ((p.ldref & 3) == 0) && ((Cq & 3) == 0);
+  {
+    const long orows = (p.flags & L2S_CONV_SCATTER) ? (long)p.n_img * p.out_h * p.out_w : ((p.flags & L2S_CONV_DECONV2X2) ? 4L * M : (long)M);
+    const long lim = 1L << 31;
+    const bool small = orows * p.ldy * 4 < lim && (!p.add || orows * p.ldadd * 4 < lim) && (!p.ref || orows * p.ldref * 4 < lim);
+    if (vec_ok && small) { igemm_epilogue_fast<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp); return; }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WM + i * 16 + fr;
@@ -285,21 +388,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned OOR = 0x80000000u;
 
-template <typename T, int BM, int BN, int D, bool OUTF32, int KS>
-__global__ __launch_bounds__(256 * KS) void igemm_ring_kernel(const l2s_conv_desc p) {
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS>
+__global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void igemm_ring_kernel(const l2s_conv_desc p) {
   constexpr int VE = 16 / (int)sizeof(T);
   constexpr int BK = ROWB / (int)sizeof(T);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int NA = BM / 32, NB = BN / 32;
+  constexpr int NTG = 64 * WGM * WGN;           // threads of one K-group: WGM x WGN waves, wave tile WM x WN
+  constexpr int LR = NTG / 8;                   // rows covered by one loader pass (8 threads x 16 B per 128-byte row)
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  constexpr int NA = BM / LR, NB = BN / LR;
   constexpr int BUF = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
   // KS > 1: in-workgroup split-K.  The workgroup holds KS K-groups of 4 waves; group g runs the loop below over slices
   // [g KT/KS, (g+1) KT/KS) (KT % KS == 0, so every group executes the same barriers) in its own LDS double buffer, then
   // the partial accumulators are exchanged through LDS and each group finishes 1/KS of the 16x16 sub-tiles.
-  const int grp = KS > 1 ? (int)(threadIdx.x >> 8) : 0;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = KS > 1 ? (int)(threadIdx.x / NTG) : 0;
+  const int tid = KS > 1 ? (int)(threadIdx.x % NTG) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int M = p.n_img * p.OH * p.OW;
   const int K = p.KH * p.KW * p.Cin;
   int mt, nt;
@@ -321,7 +426,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_ring_kernel(const l2s_conv_des
   const int ohw = p.OH * p.OW;
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    int m = m0 + lrow + 32 * j;
+    int m = m0 + lrow + LR * j;
     a_ok[j] = m < M;
     int mm = a_ok[j] ? m : 0;
     int n_img = mm / ohw, rem = mm - n_img * ohw;
@@ -333,7 +438,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_ring_kernel(const l2s_conv_des
   unsigned voffB[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    const int n = n0 + lrow + 32 * j;
+    const int n = n0 + lrow + LR * j;
     voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + cv * VE) * (long)sizeof(T)) : OOR;
   }
   // issue-side state (uniform): slice index, tap, channel offset inside the tap
@@ -365,9 +470,9 @@ __global__ __launch_bounds__(256 * KS) void igemm_ring_kernel(const l2s_conv_des
     char* a = smem + buf * BUF + lrow * ROWB + wchunk;
     char* b = a + BM * ROWB;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *(uint4*)(a + 32 * j * ROWB) = ra[j];
+    for (int j = 0; j < NA; ++j) *(uint4*)(a + LR * j * ROWB) = ra[j];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) *(uint4*)(b + 32 * j * ROWB) = rb[j];
+    for (int j = 0; j < NB; ++j) *(uint4*)(b + LR * j * ROWB) = rb[j];
   };
 
   f32x4 acc[TM][TN];
@@ -441,7 +546,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_ring_kernel(const l2s_conv_des
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int sub = i * TN + j, owner = sub % KS;
-        if (owner != grp) xch[((owner * KS + grp) * PER + sub / KS) * 256 + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (owner != grp) xch[((owner * KS + grp) * PER + sub / KS) * NTG + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     __syncthreads();
 #pragma unroll
@@ -453,13 +558,180 @@ __global__ __launch_bounds__(256 * KS) void igemm_ring_kernel(const l2s_conv_des
 #pragma unroll
           for (int g = 0; g < KS; ++g)
             if (g != grp) {
-              const float4 v = xch[((grp * KS + g) * PER + sub / KS) * 256 + tid];
+              const float4 v = xch[((grp * KS + g) * PER + sub / KS) * NTG + tid];
               acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
             }
         }
       }
   }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined large-tile variant (256x128 tile, 8 waves = 2 per SIMD, one workgroup per CU): the ring loader of
+// igemm_ring_kernel plus THREE LDS slice buffers, so that slice t+1 is already complete in LDS while slice t is being
+// multiplied.  Iteration t (one barrier):
+//   phase A: ds_read the second-half fragments (k 32..63) of slice t | ds_write slice t+2 | issue loads of slice t+2+D |
+//            16 MFMAs on the first-half fragments (read during the previous iteration)
+//   phase B: ds_read the first-half fragments of slice t+1 (visible since this iteration's barrier) | 16 MFMAs on the
+//            second-half fragments
+// so no MFMA ever waits for an LDS read issued after the barrier, and the LDS fill of slice t+2 hides under the MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32>
+__global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv_desc p) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int NTG = 64 * WGM * WGN, LR = NTG / 8;
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+  constexpr int NA = BM / LR, NB = BN / LR;
+  constexpr int BUF = (BM + BN) * ROWB;
+  static_assert(D >= 2, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  int mt, nt;
+  {
+    const int MT = (M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;
+    if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const long xpix = (long)p.n_img * p.IH * p.IW;
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((xpix - 1) * p.ldx + p.Cin) * (long)sizeof(T)), 0x00020000);
+  const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * K * (long)sizeof(T)), 0x00020000);
+
+  const int lrow = tid >> 3, cv = tid & 7;
+  const int wchunk = ((cv ^ (lrow & 7)) << 4);
+  int a_iy0[NA], a_ix0[NA], a_base[NA]; bool a_ok[NA];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    int m = m0 + lrow + LR * j;
+    a_ok[j] = m < M;
+    int mm = a_ok[j] ? m : 0;
+    int n_img = mm / ohw, rem = mm - n_img * ohw;
+    int oy = rem / p.OW, ox = rem - oy * p.OW;
+    a_iy0[j] = oy * p.stride - p.pad;
+    a_ix0[j] = ox * p.stride - p.pad;
+    a_base[j] = n_img * p.IH * p.IW;
+  }
+  unsigned voffB[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + lrow + LR * j;
+    voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + cv * VE) * (long)sizeof(T)) : OOR;
+  }
+  const int KT = K / BK;
+  const int taps = p.KH * p.KW;
+  int it = 0, c0 = 0, tap = 0;
+  unsigned voffA[NA];
+  auto set_tap = [&](int t) {
+    const int ky = t / p.KW, kx = t - ky * p.KW;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+      const bool v = a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      voffA[j] = v ? (unsigned)(((long)(a_base[j] + iy * p.IW + ix) * p.ldx + cv * VE) * (long)sizeof(T)) : OOR;
+    }
+  };
+  set_tap(0);
+  auto issue = [&](uint4 (&a)[NA], uint4 (&b)[NB]) {
+    const int sa = c0 * (int)sizeof(T), sb = it * (BK * (int)sizeof(T));
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, voffA[j], sa, 0));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, voffB[j], sb, 0));
+    ++it; c0 += BK;
+    if (c0 >= p.Cin && taps > 1) { c0 = 0; ++tap; if (tap < taps) set_tap(tap); }
+  };
+  auto store_slice = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
+    char* a = smem + buf * BUF + lrow * ROWB + wchunk;
+    char* b = a + BM * ROWB;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *(uint4*)(a + LR * j * ROWB) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *(uint4*)(b + LR * j * ROWB) = rb[j];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = fr & 7;
+  const int offa = (wm * WM + fr) * ROWB, offb = BM * ROWB + (wn * WN + fr) * ROWB;
+  const int ch0 = ((0 * 4 + fg) ^ swz) << 4, ch1 = ((1 * 4 + fg) ^ swz) << 4;
+  auto read_frags = [&](int buf, int ch, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
+    const char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * ROWB + ch);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * ROWB + ch);
+  };
+  auto mma = [&](const uint4 (&fa)[TM], const uint4 (&fb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
+  };
+
+  // prologue: slices 0..D-1 in flight; slices 0 and 1 to LDS (their sets re-issued with slices D, D+1); first-half fragments of slice 0
+  uint4 ra[D][NA], rb[D][NB];
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < KT) issue(ra[s], rb[s]);
+  store_slice(0, ra[0], rb[0]);
+  if (D < KT) issue(ra[0], rb[0]);
+  if (1 < KT) {
+    store_slice(1, ra[1], rb[1]);
+    if (D + 1 < KT) issue(ra[1], rb[1]);
+  }
+  __syncthreads();
+  uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  read_frags(0, ch0, fa0, fb0);
+
+  int t0 = 0, b0 = 0;                        // b0 = t0 % 3
+  for (; t0 + 2 * D + 2 <= KT; t0 += D) {    // steady state: t + 2 + D < KT for every t in the body
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      const int set = (s + 2) % D;           // t0 % D == 0
+      const int bt = b0, bt1 = b0 == 2 ? 0 : b0 + 1, bt2 = bt1 == 2 ? 0 : bt1 + 1;
+      if (s > 0 || t0 > 0) __syncthreads();
+      read_frags(bt, ch1, fa1, fb1);
+      store_slice(bt2, ra[set], rb[set]);
+      issue(ra[set], rb[set]);
+      mma(fa0, fb0);
+      read_frags(bt1, ch0, fa0, fb0);
+      mma(fa1, fb1);
+      b0 = bt1;
+    }
+  }
+  // tail
+#pragma unroll
+  for (int s = 0; s < 2 * D + 2; ++s) {
+    const int t = t0 + s;
+    if (t < KT) {
+      const int set = (s + 2) % D;
+      const int bt = b0, bt1 = b0 == 2 ? 0 : b0 + 1, bt2 = bt1 == 2 ? 0 : bt1 + 1;
+      if (t > 0) __syncthreads();
+      read_frags(bt, ch1, fa1, fb1);
+      if (t + 2 < KT) {
+        store_slice(bt2, ra[set], rb[set]);
+        if (t + 2 + D < KT) issue(ra[set], rb[set]);
+      }
+      mma(fa0, fb0);
+      if (t + 1 < KT) read_frags(bt1, ch0, fa0, fb0);
+      mma(fa1, fb1);
+      b0 = bt1;
+    }
+  }
+  igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -800,14 +1072,25 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <typename T, int BM, int BN, int D, bool OUTF32, int KS = 1>
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS = 1>
 int launch_igemm_ring(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN));
   size_t lds = (size_t)KS * 2 * (BM + BN) * ROWB;
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ring_kernel<T, BM, BN, D, OUTF32, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  L2S_LAUNCH((igemm_ring_kernel<T, BM, BN, D, OUTF32, KS>), grid, dim3(256 * KS), lds, st, d);
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS>), grid, dim3(64 * WGM * WGN * KS), lds, st, d);
+  return l2s_check_launch();
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32>
+int launch_igemm_sp(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN));
+  size_t lds = (size_t)3 * (BM + BN) * ROWB;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32>), grid, dim3(64 * WGM * WGN), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -847,6 +1130,12 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   // tile choice: prefer 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64
   const long t128 = (long)cdiv(M, 128) * cdiv(d->Cout, 128);
   int tile = d->tile ? d->tile : ((t128 >= 200 && d->Cout >= 96) ? 128 : 64);
+  // 256x128 (8 waves, software pipelined, one workgroup per CU) when its grid is one round over most of the 256 CUs and
+  // the K loop is long enough to pay for the prologue; measured on the layer4@RoIs shapes (profiles/r01_conv_bench.txt)
+  if (!d->tile) {
+    const long t256 = (long)cdiv(M, 256) * cdiv(d->Cout, 128);
+    if (t256 >= 160 && t256 <= 256 && K >= 1024) tile = 256;
+  }
   // working-set heuristic for the XCD tile order: per-XCD chunk along M keeps all of W + 1/8 of A in L2; if that does not
   // fit (~3 MiB), chunk along N instead (one W column block resident, A streamed)
   l2s_conv_desc dd = *d;
@@ -858,6 +1147,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   d = &dd;
   // ring kernel (default): needs whole 128-byte K slices per tap and 31-bit operand extents
   static const int ring_d = [] { const char* e = getenv("L2S_IGEMM_RING"); return e ? atoi(e) : -1; }();   // 0 = off
+  static const int sp_on = [] { const char* e = getenv("L2S_IGEMM_SP"); return e ? atoi(e) : 1; }();          // 256x128 tile: software-pipelined kernel (1) or plain ring (0)
   static const int ring_ks = [] { const char* e = getenv("L2S_IGEMM_KS"); return e ? atoi(e) : 0; }();     // 0 = auto, 1 = off, 2/4 = forced
   {
     const int bk = dtype == L2S_BF16 ? 64 : 32;
@@ -865,31 +1155,38 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     const long xb = (long)d->n_img * d->IH * d->IW * d->ldx * esz, wb = (long)d->Cout * K * esz;
     const bool ok = ring_d != 0 && (d->Cin % bk == 0) && xb < (1L << 31) && wb < (1L << 31) && !(d->ws && d->split_k > 1);
     if (ok) {
-#define GR(T, BM, BN, DD, KS) (f32o ? launch_igemm_ring<T, BM, BN, DD, true, KS>(*d, stream) : launch_igemm_ring<T, BM, BN, DD, false, KS>(*d, stream))
+#define GR(T, BM, BN, DD, KS) (f32o ? launch_igemm_ring<T, BM, BN, 2, 2, DD, true, KS>(*d, stream) : launch_igemm_ring<T, BM, BN, 2, 2, DD, false, KS>(*d, stream))
+#define GR8(T, BM, BN, DD) (f32o ? launch_igemm_ring<T, BM, BN, 4, 2, DD, true, 1>(*d, stream) : launch_igemm_ring<T, BM, BN, 4, 2, DD, false, 1>(*d, stream))
+#define GSP(T, BM, BN, DD) (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false>(*d, stream))
       // in-workgroup split-K for the 64x64 tile when the tile grid cannot fill the chip with several workgroups per CU
       const int KT = K / bk;
       const long tiles64 = (long)cdiv(M, 64) * cdiv(d->Cout, 64);
       int ks = 1;
       if (tile == 64 && ring_ks != 1) {
         if (ring_ks > 1) ks = ring_ks;
-        else if (tiles64 <= 768) ks = KT >= 16 ? 4 : (KT >= 8 ? 2 : 1);
+        else if (tiles64 <= 192) ks = KT >= 16 ? 4 : (KT >= 8 ? 2 : 1);   // measured: no gain once the 64x64 grid has more tiles (LDS fill bound)
         while (ks > 1 && (KT % ks)) ks >>= 1;
       }
       if (dtype == L2S_BF16) {
+        if (tile == 256) return sp_on ? GSP(bf16_t, 256, 128, 2) : GR8(bf16_t, 256, 128, 2);
         if (tile == 128) return GR(bf16_t, 128, 128, 2, 1);
         if (ks == 4) return GR(bf16_t, 64, 64, 3, 4);
         if (ks == 2) return GR(bf16_t, 64, 64, 3, 2);
         return GR(bf16_t, 64, 64, 4, 1);
       }
       if (dtype == L2S_F32) {
+        if (tile == 256) return sp_on ? GSP(float, 256, 128, 2) : GR8(float, 256, 128, 2);
         if (tile == 128) return GR(float, 128, 128, 2, 1);
         if (ks == 4) return GR(float, 64, 64, 3, 4);
         if (ks == 2) return GR(float, 64, 64, 3, 2);
         return GR(float, 64, 64, 4, 1);
       }
 #undef GR
+#undef GR8
+#undef GSP
     }
   }
+  if (tile == 256) tile = 128;   // the 256x128 tile exists only in the ring kernel
   static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 0; }();   // measured slower than the register-staged kernel at 128x128/64x64 tiles (profiles/r01_conv_bench.txt): LDS-DMA issue cost
   const bool split_req = d->ws && d->split_k > 1;
   if (use_pipe && !split_req) {
