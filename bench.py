@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
+    ap.add_argument('--main-prio', type=int, default=0, help='run the main queue on a high-priority HIP stream instead of the null stream')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
     args = ap.parse_args()
@@ -67,6 +68,8 @@ def main():
     from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
     from lang2seg_amd import ops as O
 
+    if args.main_prio:
+        torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     T, V = 20, 3349
     cfg.COMPUTE_DTYPE = args.dtype
     opt = dict(vocab_size=V, word_embedding_size=512, word_vec_size=512, rnn_hidden_size=512, bidirectional=1, word_drop_out=0.5,

@@ -1209,13 +1209,26 @@ extern "C" int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t st
   const long M = (long)d->n_img * d->OH * d->OW;
   if (M >= (1 << 24)) return L2S_EINVAL;
   const int taps = d->KH * d->KW;
-  int tile = d->tile ? d->tile : ((d->Cout >= 128 && d->Cin >= 128) ? 128 : 64);
+  // tile / split-K heuristics from tools/wgrad_sweep.py (profiles/r01_wgrad_sweep.txt).  The kernel is bound by operand
+  // staging (pixel-major operands, 32-pixel slices), not by MFMA: 128x128 tiles pay off only for the 1x1 layers over the
+  // RoI batch (M >= 8192, wide channels); everything else runs 64x64 tiles with ~40 pixel slices per workgroup and at
+  // least ~512 workgroups, the fp32 atomics of the split-K partial sums being the other cost (split x |dW| bytes).
+  const bool big = M >= 8192 && taps == 1 && d->Cout >= 512 && d->Cin >= 512;
+  int tile = d->tile ? d->tile : (big ? 128 : 64);
   const long tiles = (long)cdiv(d->Cout, tile) * taps * cdiv(d->Cin, tile);
   const int bkp = dtype == L2S_BF16 ? 32 : 16;
+  const int slices = cdiv(M, bkp);
   int split = d->split_k;
   if (split <= 0) {
-    split = (int)((512 + tiles - 1) / tiles);          // aim at ~2 workgroups per CU
-    int maxs = cdiv(M, bkp * 8);                       // at least 8 slices per split
+    if (tile == 128) {
+      split = (int)((512 + tiles - 1) / tiles);        // aim at ~2 workgroups per CU
+    } else {
+      split = slices / 40;
+      int p2 = 1; while (p2 * 2 <= split) p2 *= 2; split = p2;
+      const int fill = (int)((512 + tiles - 1) / tiles);
+      if (split < fill) split = fill;
+    }
+    int maxs = cdiv(slices, 8);                        // at least 8 slices per split
     if (split > maxs) split = maxs;
     if (split < 1) split = 1;
     if (split > 64) split = 64;

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
                                                         int act, int accumulate) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
+  m0 += blockIdx.y * MT;                       // row chunks of one launch
   float acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
@@ -384,12 +385,12 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw,
                               int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0) return L2S_OK;
   const bool vec = !((K & 3) || (ldx_ & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15));
-  for (int m0 = 0; m0 < M; m0 += MAXM) {
-    const int rem = M - m0;
-    dim3 grid(cdiv(N, 4));
-#define LF(MT) do { if (vec) L2S_LAUNCH((linear_fwd_kernel<MT, true>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
+  {
+    const int m0 = 0;
+#define LF(MT) do { dim3 grid(cdiv(N, 4), cdiv(M, MT)); \
+                    if (vec) L2S_LAUNCH((linear_fwd_kernel<MT, true>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
                     else L2S_LAUNCH((linear_fwd_kernel<MT, false>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); } while (0)
-    if (rem <= 1) LF(1); else if (rem <= 8) LF(8); else LF(MAXM);
+    if (M <= 1) LF(1); else if (M <= 8) LF(8); else if (M <= 16) LF(16); else LF(MAXM);
 #undef LF
   }
   return l2s_check_launch();

@@ -202,13 +202,16 @@ __global__ void adaptive_pool_bwd_kernel(const void* dy, int lddy, int off_all, 
   const int pix = blockIdx.y, yy = pix / W, xx = pix - yy * W;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  // bins whose [lo,hi) range contains the pixel
+  // bins whose [lo,hi) range contains the pixel: only the bins around floor(yy OH / H) can (bins overlap by at most one pixel)
   float g = 0.f;
   const float m = pm ? pm[pix] : 0.f;
-  for (int oy = 0; oy < OH; ++oy) {
+  const int oyc = (yy * OH) / H, oxc = (xx * OW) / W;
+  const int oya = OH <= H ? max(0, oyc - 1) : 0, oyb = OH <= H ? min(OH - 1, oyc + 1) : OH - 1;
+  const int oxa = OW <= W ? max(0, oxc - 1) : 0, oxb = OW <= W ? min(OW - 1, oxc + 1) : OW - 1;
+  for (int oy = oya; oy <= oyb; ++oy) {
     int y0 = bin_lo(oy, H, OH), y1 = bin_hi(oy, H, OH);
     if (yy < y0 || yy >= y1) continue;
-    for (int ox = 0; ox < OW; ++ox) {
+    for (int ox = oxa; ox <= oxb; ++ox) {
       int x0 = bin_lo(ox, W, OW), x1 = bin_hi(ox, W, OW);
       if (xx < x0 || xx >= x1) continue;
       float inv = 1.f / (float)((y1 - y0) * (x1 - x0));

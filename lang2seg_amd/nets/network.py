@@ -9,6 +9,7 @@ NMS, target assignment and sampling stay on device, see csrc/roi.hip).
 Forward/backward structure follows NET:488-593 (_predict), NET:375-454 (_add_losses) and
 NET:702-719 (train_step); the manual backward is the adjoint of exactly those ops."""
 import numpy as np
+import os
 import torch
 
 from .. import ops as O
@@ -86,6 +87,8 @@ class ConvOp(object):
         """weight (+bias) gradient.  Nothing downstream in the step needs it before the optimiser, so it is forked onto the
         weight-gradient stream and overlaps with the data-gradient chain that continues on the calling stream."""
         OH, OW = self.out_hw(IH, IW)
+        if 'wgrad' in os.environ.get('L2S_SKIP', ''):
+            return
         with self.net.fork_wgrad():
             O.conv_wgrad(g, x, self.w_grad, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad)
             if self.bias_grad is not None:

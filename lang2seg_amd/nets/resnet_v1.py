@@ -352,6 +352,9 @@ class resnetv1(Network):
         AF = self.opt['att_feat_size']
 
         def caption_branch():
+            import os
+            if 'cap' in os.environ.get('L2S_SKIP', ''):
+                return self.buf('l4m.skip', (HW, C4))
             x, hh, ww = net_conv, Hc, Wc
             for b, blk in enumerate(self.layers[4]):
                 x, hh, ww, sv = blk.fwd(x, 1, hh, ww, 'l4m.%d' % b)
