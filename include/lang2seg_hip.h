@@ -215,8 +215,26 @@ int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_
 int l2s_cap_attention_bwd(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
                           float* dpatt /*[L][D] +=*/, float* datt /*[L][D] +=*/, float* datt_h /*[D + 256] = (tail: scratch)*/, float* daw /*[D] +=*/, float* dab /*+=*/, hipStream_t s);
 /* att2in2 core gates (AttModel.py:446-466): s[5R] = i2h+h2h, a2c[2R]; maxout candidate, no tanh */
+/* Fused per-step launches of the att2in2 recurrence (AttModel.py:406-466): the recurrence is a chain of dependent launches on
+ * the caption stream, so the per-step work is packed into as few launches as the data dependencies allow.
+ *   l2s_linear2_fwd        : h2att(h) and h2h(h) (+= into the i2h sums) from one read of h            (ATT:425,453)
+ *   l2s_cap_a2c_gates_fwd  : a2c Linear + sigmoid / maxout / cell update of l2s_cap_gates_fwd          (ATT:449-462)
+ *   l2s_linear_sum2_fwd    : dh = W_h2h^T dsums + W_h2att^T datt_h (transposed copies, one launch)
+ *   l2s_cap_attention_bwd_step / _batched : the attention backward split into what the recurrence needs at step t
+ *       (ddot[L], datt_h[D]) and the step-summed parameter / feature gradients computed once after the loop. */
+int l2s_linear2_fwd(const float* x, int K, const float* w1, const float* b1, float* y1, int N1, int acc1, const float* w2, const float* b2,
+                    float* y2, int N2, int acc2, hipStream_t s);
+int l2s_linear_sum2_fwd(const float* x1, const float* w1 /*[N][K1]*/, int K1, const float* x2, const float* w2 /*[N][K2]*/, int K2, float* y, int N,
+                        int accumulate, hipStream_t s);
+int l2s_cap_a2c_gates_fwd(const float* att_res, const float* w_a2c /*[2R][K]*/, const float* b_a2c, int K, const float* sums /*[5R]*/,
+                          const float* c_prev, float* c, float* h, float* save /*[6R]*/, int R, hipStream_t s);
+int l2s_cap_attention_bwd_step(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
+                               float* ddot /*[L]*/, float* datt_h /*[D]*/, hipStream_t s);
+int l2s_cap_attention_bwd_batched(const float* ddot /*[S][L]*/, const float* weight /*[S][L]*/, const float* datt_res /*[S][ldr]*/, int ldr,
+                                  const float* tanh_ws /*[S][L][D]*/, const float* aw, int S, int L, int D, float* dpatt /*+=*/, float* datt /*+=*/,
+                                  float* daw /*+=*/, float* dab /*+=*/, hipStream_t s);
 int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save /*[6R]: sig(3R), sel(R), cand(R), tanh(c)(R)*/, int R, hipStream_t s);
-int l2s_cap_gates_bwd(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* dsums /*[5R]*/, float* da2c /*[2R]*/, float* dc_prev, int R, hipStream_t s);
+int l2s_cap_gates_bwd(const float* dh, const float* dh2 /*nullable: dh = dh + dh2*/, const float* dc_in, const float* save, const float* c_prev, float* dsums /*[5R]*/, float* da2c /*[2R]*/, float* dc_prev, int R, hipStream_t s);
 /* log_softmax + masked NLL (AttModel.py:98, misc/utils.py:43-53): logits [S][V1]; dlogits = gscale*(softmax - onehot)*mask/sum(mask) */
 int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale, float* loss_slot,
                        float* dlogits, float* logprobs_opt, hipStream_t s);

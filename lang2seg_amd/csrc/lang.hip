@@ -337,16 +337,17 @@ __global__ void cap_gates_fwd_kernel(const float* s, const float* a2c, const flo
   save[j] = ig; save[R + j] = fg; save[2 * R + j] = og; save[3 * R + j] = (t0 >= t1) ? 0.f : 1.f;  // torch.max(a,b): first wins ties
   save[4 * R + j] = it; save[5 * R + j] = tc;
 }
-__global__ void cap_gates_bwd_kernel(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* ds, float* da2c,
+__global__ void cap_gates_bwd_kernel(const float* dh_a, const float* dh_b, const float* dc_in, const float* save, const float* c_prev, float* ds, float* da2c,
                                      float* dc_prev, int R) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= R) return;
   const float ig = save[j], fg = save[R + j], og = save[2 * R + j], sel = save[3 * R + j], it = save[4 * R + j];
   const float tc = save[5 * R + j];
-  const float dcn = (dc_in ? dc_in[j] : 0.f) + dh[j] * og * (1.f - tc * tc);
+  const float dhj = dh_a[j] + (dh_b ? dh_b[j] : 0.f);      // recurrent part + this step's output gradient
+  const float dcn = (dc_in ? dc_in[j] : 0.f) + dhj * og * (1.f - tc * tc);
   ds[j] = dcn * it * ig * (1.f - ig);
   ds[R + j] = dcn * c_prev[j] * fg * (1.f - fg);
-  ds[2 * R + j] = dh[j] * tc * og * (1.f - og);
+  ds[2 * R + j] = dhj * tc * og * (1.f - og);
   const float dit = dcn * ig;
   const float d0 = sel == 0.f ? dit : 0.f, d1 = sel == 0.f ? 0.f : dit;
   ds[3 * R + j] = d0; ds[4 * R + j] = d1;
@@ -379,6 +380,148 @@ __global__ __launch_bounds__(1024) void lsm_nll_kernel(const float* logits, cons
   if (tid == 0) atomicAdd(loss_slot, -(lr[tg] - lse) * mk / msum);
 }
 
+
+// ---- fused per-step kernels of the att2in2 recurrence (one launch each; the recurrence is a chain of dependent launches,
+// so every launch removed is a few microseconds off the caption branch's critical path) ----
+
+// two GEMVs over the same input: y1 = w1 x + b1 (blocks [0, nb1)),  y2 (+)= w2 x + b2 (the rest).  One wave per output.
+__global__ __launch_bounds__(256) void linear2_fwd_kernel(const float* __restrict__ x, int K, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         float* y1, int N1, int acc1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* y2, int N2, int acc2, int nb1) {
+  const bool second = (int)blockIdx.x >= nb1;
+  const int n = ((int)blockIdx.x - (second ? nb1 : 0)) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int N = second ? N2 : N1;
+  if (n >= N) return;
+  const float* wr = (second ? w2 : w1) + (long)n * K;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 wv = *(const float4*)(wr + k), xv = *(const float4*)(x + k);
+    acc = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc))));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float* b = second ? b2 : b1;
+    float* o = (second ? y2 : y1) + n;
+    float v = acc + (b ? b[n] : 0.f);
+    if (second ? acc2 : acc1) v += *o;
+    *o = v;
+  }
+}
+// y[n] (+)= w1[n] . x1 + w2[n] . x2   (two inputs, one output vector; one wave per n)
+__global__ __launch_bounds__(256) void linear_sum2_kernel(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
+                                                         const float* __restrict__ w2, int K2, float* y, int N, int accumulate) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float a1 = 0.f, a2 = 0.f;
+  const float* r1 = w1 + (long)n * K1; const float* r2 = w2 + (long)n * K2;
+  for (int k = lane * 4; k < K1; k += 256) {
+    const float4 wv = *(const float4*)(r1 + k), xv = *(const float4*)(x1 + k);
+    a1 = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, a1))));
+  }
+  for (int k = lane * 4; k < K2; k += 256) {
+    const float4 wv = *(const float4*)(r2 + k), xv = *(const float4*)(x2 + k);
+    a2 = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, a2))));
+  }
+  a1 = wave_sum(a1); a2 = wave_sum(a2);
+  if (lane == 0) { float v = a1 + a2; if (accumulate) v += y[n]; y[n] = v; }
+}
+// a2c Linear (rows j and R + j) fused with the gate nonlinearity of unit j (ATT:449-462): one wave per unit
+__global__ __launch_bounds__(256) void cap_a2c_gates_kernel(const float* __restrict__ ares, const float* __restrict__ w, const float* __restrict__ b, int K,
+                                                           const float* __restrict__ s, const float* __restrict__ c_prev, float* c, float* h,
+                                                           float* save, int R) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= R) return;
+  const float* r0 = w + (long)j * K; const float* r1 = w + (long)(R + j) * K;
+  float a0 = 0.f, a1 = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 xv = *(const float4*)(ares + k), w0 = *(const float4*)(r0 + k), w1 = *(const float4*)(r1 + k);
+    a0 = fmaf(w0.x, xv.x, fmaf(w0.y, xv.y, fmaf(w0.z, xv.z, fmaf(w0.w, xv.w, a0))));
+    a1 = fmaf(w1.x, xv.x, fmaf(w1.y, xv.y, fmaf(w1.z, xv.z, fmaf(w1.w, xv.w, a1))));
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1);
+  if (lane == 0) {
+    a0 += b[j]; a1 += b[R + j];
+    const float ig = sigm(s[j]), fg = sigm(s[R + j]), og = sigm(s[2 * R + j]);
+    const float t0 = s[3 * R + j] + a0, t1 = s[4 * R + j] + a1;
+    const float it = fmaxf(t0, t1);
+    const float cn = fg * c_prev[j] + ig * it;
+    const float tc = tanhf(cn);
+    c[j] = cn; h[j] = og * tc;
+    save[j] = ig; save[R + j] = fg; save[2 * R + j] = og; save[3 * R + j] = (t0 >= t1) ? 0.f : 1.f;
+    save[4 * R + j] = it; save[5 * R + j] = tc;
+  }
+}
+// attention backward, the part the recurrence needs at step t: ddot[l] (softmax backward of dweight[l] = dres . att[l],
+// recomputed by every workgroup) and datt_h[d] = sum_l ddot[l] aw[d] (1 - tanh^2).  Workgroup = 16 channels x 16 l-groups.
+__global__ __launch_bounds__(256) void cap_att_bwd_step_kernel(const float* __restrict__ dres, const float* __restrict__ att, const float* __restrict__ tanh_ws,
+                                                              const float* __restrict__ weight, const float* __restrict__ aw, int L, int D,
+                                                              float* ddot_out, float* datt_h) {
+  __shared__ float dwl[256];
+  __shared__ float ddot[256];
+  __shared__ float red[4];
+  __shared__ float part[16][16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int l = wv; l < L; l += 4) {
+    float sdot = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const float4 a = *(const float4*)(att + (long)l * D + d), r = *(const float4*)(dres + d);
+      sdot = fmaf(a.x, r.x, fmaf(a.y, r.y, fmaf(a.z, r.z, fmaf(a.w, r.w, sdot))));
+    }
+    sdot = wave_sum(sdot);
+    if (lane == 0) dwl[l] = sdot;
+  }
+  __syncthreads();
+  const float wl = tid < L ? weight[tid] : 0.f;
+  const float dw = tid < L ? dwl[tid] : 0.f;
+  const float dot = block_sum(wl * dw, red);
+  const float dd = wl * (dw - dot);
+  ddot[tid] = tid < L ? dd : 0.f;
+  if (blockIdx.x == 0 && tid < L) ddot_out[tid] = dd;
+  __syncthreads();
+  const int dl = tid & 15, lg = tid >> 4;
+  const int d = blockIdx.x * 16 + dl;
+  float sah = 0.f;
+  if (d < D) {
+    const float a = aw[d];
+    for (int l = lg; l < L; l += 16) {
+      const float t = tanh_ws[(long)l * D + d];
+      sah = fmaf(ddot[l] * a, 1.f - t * t, sah);
+    }
+  }
+  part[lg][dl] = sah;
+  __syncthreads();
+  if (lg == 0 && d < D) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += part[g][dl];
+    datt_h[d] = v;
+  }
+}
+// after the loop: everything the per-step kernel left out, summed over the S steps in one launch (workgroup = one row l)
+__global__ __launch_bounds__(256) void cap_att_bwd_batched_kernel(const float* __restrict__ ddot, const float* __restrict__ weight, const float* __restrict__ dres,
+                                                                 int ldr, const float* __restrict__ tanh_ws, const float* __restrict__ aw, int S, int L, int D,
+                                                                 float* dpatt, float* datt, float* daw, float* dab) {
+  const int l = blockIdx.x, tid = threadIdx.x;
+  for (int d = tid; d < D; d += blockDim.x) {
+    const float a = aw[d];
+    float dp = 0.f, da = 0.f, dw = 0.f;
+    for (int t = 0; t < S; ++t) {
+      const float dd = ddot[(long)t * L + l], w = weight[(long)t * L + l];
+      const float th = tanh_ws[((long)t * L + l) * D + d];
+      dp = fmaf(dd * a, 1.f - th * th, dp);
+      da = fmaf(w, dres[(long)t * ldr + d], da);
+      dw = fmaf(dd, th, dw);
+    }
+    dpatt[(long)l * D + d] += dp;
+    datt[(long)l * D + d] += da;
+    atomicAdd(daw + d, dw);
+  }
+  if (tid == 0) {
+    float sb = 0.f;
+    for (int t = 0; t < S; ++t) sb += ddot[(long)t * L + l];
+    atomicAdd(dab, sb);
+  }
+}
 }  // namespace
 
 extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw, const float* b, float* y, int ldy, int M, int N, int K, int act,
@@ -456,13 +599,43 @@ extern "C" int l2s_cap_attention_bwd(const float* datt_res, const float* att, co
   L2S_LAUNCH(cap_att_bwd_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, datt_res, datt_h + D, tanh_ws, weight, aw, L, D, dpatt, datt, datt_h, daw, dab);
   return l2s_check_launch();
 }
+extern "C" int l2s_linear2_fwd(const float* x, int K, const float* w1, const float* b1, float* y1, int N1, int acc1, const float* w2,
+                               const float* b2, float* y2, int N2, int acc2, hipStream_t s) {
+  if ((K & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15)) return L2S_EINVAL;
+  const int nb1 = cdiv(N1, 4);
+  L2S_LAUNCH(linear2_fwd_kernel, dim3(nb1 + cdiv(N2, 4)), dim3(256), 0, s, x, K, w1, b1, y1, N1, acc1, w2, b2, y2, N2, acc2, nb1);
+  return l2s_check_launch();
+}
+extern "C" int l2s_linear_sum2_fwd(const float* x1, const float* w1, int K1, const float* x2, const float* w2, int K2, float* y, int N,
+                                   int accumulate, hipStream_t s) {
+  if ((K1 & 3) || (K2 & 3) || ((uintptr_t)x1 & 15) || ((uintptr_t)x2 & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15)) return L2S_EINVAL;
+  L2S_LAUNCH(linear_sum2_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, x1, w1, K1, x2, w2, K2, y, N, accumulate);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_a2c_gates_fwd(const float* att_res, const float* w_a2c, const float* b_a2c, int K, const float* sums, const float* c_prev,
+                                     float* c, float* h, float* save, int R, hipStream_t s) {
+  if ((K & 3) || ((uintptr_t)att_res & 15) || ((uintptr_t)w_a2c & 15)) return L2S_EINVAL;
+  L2S_LAUNCH(cap_a2c_gates_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, att_res, w_a2c, b_a2c, K, sums, c_prev, c, h, save, R);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_attention_bwd_step(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L,
+                                          int D, float* ddot, float* datt_h, hipStream_t s) {
+  if (L > 256 || (D & 3)) return L2S_EINVAL;
+  L2S_LAUNCH(cap_att_bwd_step_kernel, dim3(cdiv(D, 16)), dim3(256), 0, s, datt_res, att, tanh_ws, weight, aw, L, D, ddot, datt_h);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_attention_bwd_batched(const float* ddot, const float* weight, const float* datt_res, int ldr, const float* tanh_ws,
+                                             const float* aw, int S, int L, int D, float* dpatt, float* datt, float* daw, float* dab, hipStream_t s) {
+  L2S_LAUNCH(cap_att_bwd_batched_kernel, dim3(L), dim3(256), 0, s, ddot, weight, datt_res, ldr, tanh_ws, aw, S, L, D, dpatt, datt, daw, dab);
+  return l2s_check_launch();
+}
 extern "C" int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save, int R, hipStream_t s) {
   L2S_LAUNCH(cap_gates_fwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, sums, a2c, c_prev, c, h, save, R);
   return l2s_check_launch();
 }
-extern "C" int l2s_cap_gates_bwd(const float* dh, const float* dc_in, const float* save, const float* c_prev, float* dsums, float* da2c,
+extern "C" int l2s_cap_gates_bwd(const float* dh, const float* dh2, const float* dc_in, const float* save, const float* c_prev, float* dsums, float* da2c,
                                  float* dc_prev, int R, hipStream_t s) {
-  L2S_LAUNCH(cap_gates_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, dh, dc_in, save, c_prev, dsums, da2c, dc_prev, R);
+  L2S_LAUNCH(cap_gates_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, dh, dh2, dc_in, save, c_prev, dsums, da2c, dc_prev, R);
   return l2s_check_launch();
 }
 extern "C" int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale, float* loss_slot,

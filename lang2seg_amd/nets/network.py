@@ -193,8 +193,9 @@ class Network(object):
 
     def streams(self):
         if not hasattr(self, '_streams'):
-            self._streams = dict(lang=torch.cuda.Stream(), cap=torch.cuda.Stream(), wg=torch.cuda.Stream(), wg2=torch.cuda.Stream(),
-                                 tr=torch.cuda.Stream())
+            hp = os.environ.get('L2S_HIPRIO', '').split(',')
+            mk = lambda n: torch.cuda.Stream(priority=-1) if n in hp else torch.cuda.Stream()
+            self._streams = dict(lang=mk('lang'), cap=mk('cap'), wg=mk('wg'), wg2=mk('wg2'), tr=mk('tr'))
             self._wg_flip = 0
         return self._streams
 

@@ -221,12 +221,12 @@ class resnetv1(Network):
         att_h = self.buf('cap.att_h', (S, AH), f32); tanh_ws = self.buf('cap.tanh', (S, L, AH), f32)
         wgt = self.buf('cap.wgt', (S, L), f32); ares = self.buf('cap.ares', (S, R + SC), f32); a2c = self.buf('cap.a2c', (S, 2 * R), f32)
         for i in range(S):
-            O.linear_fwd(hs[i], pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), att_h[i], 1, AH, R)
+            # h2att(h) and h2h(h) (+= i2h sums) in one launch; attention; a2c Linear fused with the gates (4 launches per step)
+            O.linear2_fwd(hs[i], R, pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), att_h[i], AH, False,
+                          pv('core.h2h.weight'), pv('core.h2h.bias'), sums[i], 5 * R, True)
             O.cap_attention_fwd(patt, ad, att_h[i], pv('core.attention.alpha_net.weight'), pv('core.attention.alpha_net.bias'), L, AH,
                                 tanh_ws[i], wgt[i], ares[i])
-            O.linear_fwd(hs[i], pv('core.h2h.weight'), pv('core.h2h.bias'), sums[i], 1, 5 * R, R, accumulate=True)
-            O.linear_fwd(ares[i], pv('core.a2c.weight'), pv('core.a2c.bias'), a2c[i], 1, 2 * R, R)
-            O.cap_gates_fwd(sums[i], a2c[i], cs[i], cs[i + 1], hs[i + 1], save[i], R)
+            O.cap_a2c_gates_fwd(ares[i], pv('core.a2c.weight'), pv('core.a2c.bias'), R, sums[i], cs[i], cs[i + 1], hs[i + 1], save[i], R)
         t['cap.drop_out'] = self._drop('out', (S, R), self.opt['drop_prob_lm'])
         if t['cap.drop_out'] is not None:
             ho = self.buf('cap.ho', (S, R), f32); O.mul(hs[1:], t['cap.drop_out'], ho)
@@ -257,19 +257,21 @@ class resnetv1(Network):
         if t['cap.drop_out'] is not None:
             O.mul(dho, t['cap.drop_out'], dho)
         dsums = self.buf('cap.dsums', (S, 5 * R), f32); da2c = self.buf('cap.da2c', (S, 2 * R), f32)
-        datt_h = self.buf('cap.datt_h', (S, AH + SC), f32); dares = self.buf('cap.dares', (R,), f32)
+        datt_h = self.buf('cap.datt_h', (S, AH + SC), f32); dares = self.buf('cap.dares', (S, R), f32); ddot = self.buf('cap.ddot', (S, L), f32)
         dpatt = self.buf('cap.dpatt', (L, AH), f32, zero=True); dad = self.buf('cap.dad', (L, R), f32, zero=True)
         dh = self.buf('cap.dh', (2, R), f32, zero=True); dc = self.buf('cap.dc', (2, R), f32, zero=True)
+        wT_h2h = self.wT['caption_model.core.h2h.weight'][0]; wT_h2att = self.wT['caption_model.core.attention.h2att.weight'][0]
         k = 0
         for i in range(S - 1, -1, -1):
-            O.add3(dh[k], dho[i], None, dh[k])                       # recurrent part + this step's output gradient
-            O.cap_gates_bwd(dh[k], dc[k], save[i], cs[i], dsums[i], da2c[i], dc[1 - k], R)
-            self.bwd_x(da2c[i], 'caption_model.core.a2c.weight', dares, 1)
-            O.cap_attention_bwd(dares, ad, tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, dpatt, dad, datt_h[i],
-                                gv('core.attention.alpha_net.weight'), gv('core.attention.alpha_net.bias'))
-            self.bwd_x(dsums[i], 'caption_model.core.h2h.weight', dh[1 - k], 1)
-            self.bwd_x(datt_h[i], 'caption_model.core.attention.h2att.weight', dh[1 - k], 1, accumulate=True)
+            # 4 launches per step: gates (dh = recurrent part + this step's output gradient), a2c^T, the attention pieces the
+            # recurrence needs, and dh(i-1) = W_h2h^T dsums + W_h2att^T datt_h
+            O.cap_gates_bwd(dh[k], dc[k], save[i], cs[i], dsums[i], da2c[i], dc[1 - k], R, dh2=dho[i])
+            self.bwd_x(da2c[i], 'caption_model.core.a2c.weight', dares[i], 1)
+            O.cap_attention_bwd_step(dares[i], ad, tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, ddot[i], datt_h[i])
+            O.linear_sum2_fwd(dsums[i], wT_h2h, 5 * R, datt_h[i], wT_h2att, AH, dh[1 - k], R)
             k = 1 - k
+        O.cap_attention_bwd_batched(ddot, wgt, dares, R, tanh_ws, pv('core.attention.alpha_net.weight'), S, L, AH, dpatt, dad,
+                                    gv('core.attention.alpha_net.weight'), gv('core.attention.alpha_net.bias'))
         hprev = hs[0:S]
         O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R, ldx=R + SC)
         O.linear_bwd_w(dsums, hprev, gv('core.h2h.weight'), gv('core.h2h.bias'), S, 5 * R, R)

@@ -317,8 +317,29 @@ def cap_gates_fwd(sums, a2c, c_prev, c, h, save, R):
     call('l2s_cap_gates_fwd', ptr(sums), ptr(a2c), ptr(c_prev), ptr(c), ptr(h), ptr(save), R, stream())
 
 
-def cap_gates_bwd(dh, dc_in, save, c_prev, dsums, da2c, dc_prev, R):
-    call('l2s_cap_gates_bwd', ptr(dh), ptr(dc_in), ptr(save), ptr(c_prev), ptr(dsums), ptr(da2c), ptr(dc_prev), R, stream())
+def cap_gates_bwd(dh, dc_in, save, c_prev, dsums, da2c, dc_prev, R, dh2=None):
+    call('l2s_cap_gates_bwd', ptr(dh), ptr(dh2), ptr(dc_in), ptr(save), ptr(c_prev), ptr(dsums), ptr(da2c), ptr(dc_prev), R, stream())
+
+
+def linear2_fwd(x, K, w1, b1, y1, N1, acc1, w2, b2, y2, N2, acc2):
+    call('l2s_linear2_fwd', ptr(x), K, ptr(w1), ptr(b1), ptr(y1), N1, int(acc1), ptr(w2), ptr(b2), ptr(y2), N2, int(acc2), stream())
+
+
+def linear_sum2_fwd(x1, w1, K1, x2, w2, K2, y, N, accumulate=False):
+    call('l2s_linear_sum2_fwd', ptr(x1), ptr(w1), K1, ptr(x2), ptr(w2), K2, ptr(y), N, int(accumulate), stream())
+
+
+def cap_a2c_gates_fwd(att_res, w_a2c, b_a2c, K, sums, c_prev, c, h, save, R):
+    call('l2s_cap_a2c_gates_fwd', ptr(att_res), ptr(w_a2c), ptr(b_a2c), K, ptr(sums), ptr(c_prev), ptr(c), ptr(h), ptr(save), R, stream())
+
+
+def cap_attention_bwd_step(datt_res, att, tanh_ws, weight, aw, L, D, ddot, datt_h):
+    call('l2s_cap_attention_bwd_step', ptr(datt_res), ptr(att), ptr(tanh_ws), ptr(weight), ptr(aw), L, D, ptr(ddot), ptr(datt_h), stream())
+
+
+def cap_attention_bwd_batched(ddot, weight, datt_res, ldr, tanh_ws, aw, S, L, D, dpatt, datt, daw, dab):
+    call('l2s_cap_attention_bwd_batched', ptr(ddot), ptr(weight), ptr(datt_res), ldr, ptr(tanh_ws), ptr(aw), S, L, D, ptr(dpatt), ptr(datt),
+         ptr(daw), ptr(dab), stream())
 
 
 def logsoftmax_nll(logits, target, mask, S, V1, gscale, loss_slot, dlogits, logprobs=None):

@@ -558,6 +558,26 @@ def test_captioner_pieces():
     assert rel_err(wd, wgt) < 1e-5 and rel_err(rd[:D], res) < 1e-5
     assert rel_err(dpatt, pr.grad) < 1e-4 and rel_err(datt, ar.grad) < 1e-4 and rel_err(dah[:D], hr.grad) < 1e-4
     assert rel_err(daw, wr.grad) < 1e-4 and abs(dab.item() - br.grad.item()) < 1e-5
+    # the split form used inside the recurrence: per-step (ddot, datt_h) + one batched launch for the step sums
+    S2 = 3
+    dres2 = torch.randn(S2, D, generator=g); ah2 = torch.randn(S2, D, generator=g)
+    pr, ar, wr, br = [t.clone().requires_grad_(True) for t in (patt, att, aw, ab)]
+    hr2 = ah2.clone().requires_grad_(True)
+    tot = 0
+    for i in range(S2):
+        wgt_i = F.softmax(torch.tanh(pr + hr2[i]) @ wr + br, 0)
+        tot = tot + ((wgt_i @ ar) * dres2[i]).sum()
+    tot.backward()
+    tws2 = torch.empty(S2, L, D, device=DEV); wd2 = torch.empty(S2, L, device=DEV); rd2 = torch.empty(S2, D + 256, device=DEV)
+    ddot = torch.empty(S2, L, device=DEV); dah2 = torch.empty(S2, D + 256, device=DEV); dr2 = dres2.to(DEV)
+    for i in range(S2):
+        O.cap_attention_fwd(patt.to(DEV), att.to(DEV), ah2[i].to(DEV), aw.to(DEV), ab.to(DEV), L, D, tws2[i], wd2[i], rd2[i])
+        O.cap_attention_bwd_step(dr2[i], att.to(DEV), tws2[i], wd2[i], aw.to(DEV), L, D, ddot[i], dah2[i])
+    dpatt = torch.zeros(L, D, device=DEV); datt = torch.zeros(L, D, device=DEV); daw = torch.zeros(D, device=DEV); dab = torch.zeros(1, device=DEV)
+    O.cap_attention_bwd_batched(ddot, wd2, dr2, D, tws2, aw.to(DEV), S2, L, D, dpatt, datt, daw, dab)
+    torch.cuda.synchronize()
+    assert rel_err(dah2[:, :D], hr2.grad) < 1e-4 and rel_err(dpatt, pr.grad) < 1e-4 and rel_err(datt, ar.grad) < 1e-4
+    assert rel_err(daw, wr.grad) < 1e-4 and abs(dab.item() - br.grad.item()) < 1e-4
     # gates (maxout candidate, AttModel.py:449-462)
     R = 512
     s = torch.randn(5 * R, generator=g); a2c = torch.randn(2 * R, generator=g); c0 = torch.randn(R, generator=g)
@@ -573,6 +593,29 @@ def test_captioner_pieces():
     torch.cuda.synchronize()
     assert rel_err(h, h1) < 1e-5 and rel_err(c, c1) < 1e-5
     assert rel_err(ds, sr.grad) < 1e-4 and rel_err(da, a2r.grad) < 1e-4 and rel_err(dcp, cr.grad) < 1e-4
+    # dh given as two addends
+    ds2 = torch.empty(5 * R, device=DEV); da2 = torch.empty(2 * R, device=DEV); dcp2 = torch.empty(R, device=DEV)
+    O.cap_gates_bwd((dh * 0.25).to(DEV), dc.to(DEV), save, c0.to(DEV), ds2, da2, dcp2, R, dh2=(dh * 0.75).to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(ds2, sr.grad) < 1e-4 and rel_err(dcp2, cr.grad) < 1e-4
+    # a2c Linear fused with the gates; two GEMVs from one input; two-input GEMV
+    K = 512
+    ares = torch.randn(K, generator=g); wa = torch.randn(2 * R, K, generator=g) / 22; ba = torch.randn(2 * R, generator=g)
+    a2c_ref = wa @ ares + ba
+    itr = s[3 * R:] + a2c_ref; itr = torch.max(itr[:R], itr[R:]); sgr = torch.sigmoid(s[:3 * R])
+    c1r = sgr[R:2 * R] * c0 + sgr[:R] * itr; h1r = sgr[2 * R:] * torch.tanh(c1r)
+    c = torch.empty(R, device=DEV); h = torch.empty(R, device=DEV); save2 = torch.empty(6 * R, device=DEV)
+    O.cap_a2c_gates_fwd(ares.to(DEV), wa.to(DEV), ba.to(DEV), K, s.to(DEV), c0.to(DEV), c, h, save2, R)
+    x = torch.randn(K, generator=g); w1 = torch.randn(300, K, generator=g) / 22; b1 = torch.randn(300, generator=g)
+    w2 = torch.randn(1030, K, generator=g) / 22; b2 = torch.randn(1030, generator=g); y2_0 = torch.randn(1030, generator=g)
+    y1 = torch.empty(300, device=DEV); y2 = y2_0.to(DEV)
+    O.linear2_fwd(x.to(DEV), K, w1.to(DEV), b1.to(DEV), y1, 300, False, w2.to(DEV), b2.to(DEV), y2, 1030, True)
+    x2 = torch.randn(256, generator=g); w3 = torch.randn(300, 256, generator=g) / 16
+    y3 = torch.empty(300, device=DEV)
+    O.linear_sum2_fwd(x.to(DEV), w1.to(DEV), K, x2.to(DEV), w3.to(DEV), 256, y3, 300)
+    torch.cuda.synchronize()
+    assert rel_err(h, h1r) < 1e-5 and rel_err(c, c1r) < 1e-5
+    assert rel_err(y1, w1 @ x + b1) < 1e-5 and rel_err(y2, w2 @ x + b2 + y2_0) < 1e-5 and rel_err(y3, w1 @ x + w3 @ x2) < 1e-5
     # log-softmax + masked NLL
     S, V1 = 7, 1200
     lg = torch.randn(S, V1, generator=g) * 3; tgt = torch.randint(0, V1, (S,), generator=g); msk = torch.tensor([1, 1, 1, 1, 1, 0.0, 1])
