@@ -453,37 +453,43 @@ __global__ __launch_bounds__(256) void cap_a2c_gates_kernel(const float* __restr
 }
 // attention backward, the part the recurrence needs at step t: ddot[l] (softmax backward of dweight[l] = dres . att[l],
 // recomputed by every workgroup) and datt_h[d] = sum_l ddot[l] aw[d] (1 - tanh^2).  Workgroup = 16 channels x 16 l-groups.
-__global__ __launch_bounds__(256) void cap_att_bwd_step_kernel(const float* __restrict__ dres, const float* __restrict__ att, const float* __restrict__ tanh_ws,
-                                                              const float* __restrict__ weight, const float* __restrict__ aw, int L, int D,
-                                                              float* ddot_out, float* datt_h) {
+__global__ __launch_bounds__(1024) void cap_att_bwd_step_kernel(const float* __restrict__ dres, const float* __restrict__ att, const float* __restrict__ tanh_ws,
+                                                               const float* __restrict__ weight, const float* __restrict__ aw, int L, int D,
+                                                               float* ddot_out, float* datt_h) {
   __shared__ float dwl[256];
   __shared__ float ddot[256];
-  __shared__ float red[4];
-  __shared__ float part[16][16];
+  __shared__ float red[16];
+  __shared__ float part[64][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int l = wv; l < L; l += 4) {
-    float sdot = 0.f;
+  // dweight[l] = dres . att[l]: 16 waves x (L / 16) rows, two rows per trip so that four 16-byte loads are in flight per lane
+  for (int l = wv; l < L; l += 32) {
+    const int l2 = l + 16;
+    float s0 = 0.f, s1 = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
-      const float4 a = *(const float4*)(att + (long)l * D + d), r = *(const float4*)(dres + d);
-      sdot = fmaf(a.x, r.x, fmaf(a.y, r.y, fmaf(a.z, r.z, fmaf(a.w, r.w, sdot))));
+      const float4 r = *(const float4*)(dres + d);
+      const float4 a = *(const float4*)(att + (long)l * D + d);
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l2 < L) b = *(const float4*)(att + (long)l2 * D + d);
+      s0 = fmaf(a.x, r.x, fmaf(a.y, r.y, fmaf(a.z, r.z, fmaf(a.w, r.w, s0))));
+      s1 = fmaf(b.x, r.x, fmaf(b.y, r.y, fmaf(b.z, r.z, fmaf(b.w, r.w, s1))));
     }
-    sdot = wave_sum(sdot);
-    if (lane == 0) dwl[l] = sdot;
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if (lane == 0) { dwl[l] = s0; if (l2 < L) dwl[l2] = s1; }
   }
   __syncthreads();
   const float wl = tid < L ? weight[tid] : 0.f;
   const float dw = tid < L ? dwl[tid] : 0.f;
   const float dot = block_sum(wl * dw, red);
   const float dd = wl * (dw - dot);
-  ddot[tid] = tid < L ? dd : 0.f;
+  if (tid < 256) ddot[tid] = tid < L ? dd : 0.f;
   if (blockIdx.x == 0 && tid < L) ddot_out[tid] = dd;
   __syncthreads();
-  const int dl = tid & 15, lg = tid >> 4;
+  const int dl = tid & 15, lg = tid >> 4;            // 16 channels x 64 l-groups
   const int d = blockIdx.x * 16 + dl;
   float sah = 0.f;
   if (d < D) {
     const float a = aw[d];
-    for (int l = lg; l < L; l += 16) {
+    for (int l = lg; l < L; l += 64) {
       const float t = tanh_ws[(long)l * D + d];
       sah = fmaf(ddot[l] * a, 1.f - t * t, sah);
     }
@@ -492,8 +498,7 @@ __global__ __launch_bounds__(256) void cap_att_bwd_step_kernel(const float* __re
   __syncthreads();
   if (lg == 0 && d < D) {
     float v = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) v += part[g][dl];
+    for (int g = 0; g < 64; ++g) v += part[g][dl];
     datt_h[d] = v;
   }
 }
@@ -621,7 +626,7 @@ extern "C" int l2s_cap_a2c_gates_fwd(const float* att_res, const float* w_a2c, c
 extern "C" int l2s_cap_attention_bwd_step(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L,
                                           int D, float* ddot, float* datt_h, hipStream_t s) {
   if (L > 256 || (D & 3)) return L2S_EINVAL;
-  L2S_LAUNCH(cap_att_bwd_step_kernel, dim3(cdiv(D, 16)), dim3(256), 0, s, datt_res, att, tanh_ws, weight, aw, L, D, ddot, datt_h);
+  L2S_LAUNCH(cap_att_bwd_step_kernel, dim3(cdiv(D, 16)), dim3(1024), 0, s, datt_res, att, tanh_ws, weight, aw, L, D, ddot, datt_h);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_attention_bwd_batched(const float* ddot, const float* weight, const float* datt_res, int ldr, const float* tanh_ws,

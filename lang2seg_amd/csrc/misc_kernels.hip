@@ -50,28 +50,60 @@ __global__ void weight_transpose_kernel(const float* __restrict__ src, const flo
 }
 
 // batched variant: one launch rebuilds every data-gradient weight copy of the step (descriptor table in device memory)
-__global__ void weight_transpose_batched_kernel(const l2s_transpose_desc* __restrict__ table, int dt) {
-  __shared__ float tile[32][33];
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const l2s_transpose_desc* __restrict__ table, int dt) {
+  // 64 (co) x 64 (ci) tiles through LDS: 16-byte reads along ci, 16-byte (bf16 x 8) / 32-byte (f32 x 8) writes along co
+  __shared__ float tile[64][65];
   const l2s_transpose_desc d = table[blockIdx.y];
   if (d.force_f32) dt = L2S_F32;
-  const int tci = (d.Cin + 31) / 32, tco = (d.Cout + 31) / 32;
+  const int tci = (d.Cin + 63) / 64, tco = (d.Cout + 63) / 64;
   const int ntiles = tci * tco * d.taps;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tid = threadIdx.x;
+  const bool vec_in = (d.Cin & 3) == 0, vec_out = (d.Cout & 7) == 0;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int tap = t / (tci * tco), rem = t - tap * (tci * tco);
-    const int co0 = (rem / tci) * 32, ci0 = (rem % tci) * 32;
+    const int co0 = (rem / tci) * 64, ci0 = (rem % tci) * 64;
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-      int co = co0 + r, ci = ci0 + tx;
-      float v = 0.f;
-      if (co < d.Cout && ci < d.Cin) { v = d.src[((long)co * d.taps + tap) * d.Cin + ci]; if (d.scale) v *= d.scale[co]; }
-      tile[r][tx] = v;
+    {
+      const int c4 = (tid & 15) * 4;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int r = (tid >> 4) + pass * 16;
+        const int co = co0 + r, ci = ci0 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < d.Cout) {
+          const float* sp = d.src + ((long)co * d.taps + tap) * d.Cin + ci;
+          if (vec_in && ci + 3 < d.Cin) v = *(const float4*)sp;
+          else { if (ci < d.Cin) v.x = sp[0]; if (ci + 1 < d.Cin) v.y = sp[1]; if (ci + 2 < d.Cin) v.z = sp[2]; if (ci + 3 < d.Cin) v.w = sp[3]; }
+          if (d.scale) { const float sc = d.scale[co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        }
+        tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+      }
     }
     __syncthreads();
     const int otap = d.taps - 1 - tap;
-    for (int r = ty; r < 32; r += 8) {
-      int ci = ci0 + r, co = co0 + tx;
-      if (co < d.Cout && ci < d.Cin) stx(d.dst, ((long)ci * d.taps + otap) * d.Cout + co, dt, tile[tx][r]);
+    const int cg = (tid & 7) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = (tid >> 3) + pass * 32;
+      const int ci = ci0 + r, co = co0 + cg;
+      if (ci >= d.Cin || co >= d.Cout) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[cg + e][r];
+      const long o = ((long)ci * d.taps + otap) * d.Cout + co;
+      if (vec_out && co + 7 < d.Cout) {
+        if (dt == L2S_BF16) {
+          uint4 pk;
+          pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+          *(uint4*)((bf16_t*)d.dst + o) = pk;
+        } else {
+          *(float4*)((float*)d.dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)((float*)d.dst + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      } else {
+        for (int e = 0; e < 8 && co + e < d.Cout; ++e) stx(d.dst, o + e, dt, v[e]);
+      }
     }
   }
 }

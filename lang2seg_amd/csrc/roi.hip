@@ -70,16 +70,28 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned int* keys, 
   hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 __global__ __launch_bounds__(1024) void rs_scan_kernel(int* hist, int total) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int per = (total + 1023) / 1024, lo = t * per, hi = min(total, lo + per);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += hist[i];
-  part[t] = s;
+  // exclusive scan of `total` counters by one workgroup: each wave owns a contiguous chunk and walks it 64 counters at a
+  // time (coalesced loads, wave prefix by DPP-style shuffles), then the 16 wave totals are scanned and added back
+  __shared__ int wtot[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int per = ((total + 15) / 16 + 63) & ~63;            // counters per wave, multiple of 64
+  const int lo = wv * per, hi = min(total, lo + per);
+  int run = 0;
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const int v = i < hi ? hist[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (i < hi) hist[i] = run + x - v;                       // exclusive, relative to the wave's chunk
+    run += __shfl(x, 63, 64);
+  }
+  if (lane == 0) wtot[wv] = run;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) { int x = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += x; __syncthreads(); }
-  int run = part[t] - s;
-  for (int i = lo; i < hi; ++i) { int v = hist[i]; hist[i] = run; run += v; }
+  int base = 0;
+  for (int w = 0; w < wv; ++w) base += wtot[w];
+  if (base)
+    for (int i = lo + lane; i < hi; i += 64) hist[i] += base;
 }
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned int* kin, const int* iin, unsigned int* kout, int* iout, int n, int shift,
                                                         int nblk, const int* hist) {
@@ -147,13 +159,17 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
   if (tid == 0) { nk_sh[0] = nk_sh[1] = 0; kept_sh[0] = kept_sh[1] = 0ull; }
   int nk = 0;   // running keep count (wave 0)
   __syncthreads();
-  unsigned long long dnext = 0ull;
-  if (wave == 0) dnext = lane < n ? mask[(long)lane * cb] : 0ull;
+  unsigned long long dnext = 0ull, cnext = 0ull;
+  if (wave == 0) { dnext = lane < n ? mask[(long)lane * cb] : 0ull; cnext = (lane < n && cb > 1) ? mask[(long)lane * cb + 1] : 0ull; }
   for (int b = 0; b < cb; ++b) {
     if (wave == 0) {
       const int row = b * 64 + lane;
-      const unsigned long long d = dnext;
-      if (b + 1 < cb) { const int r2 = row + 64; dnext = r2 < n ? mask[(long)r2 * cb + b + 1] : 0ull; }   // prefetch next diagonal
+      const unsigned long long d = dnext, ccol = cnext;      // this block's diagonal word and its column b+1 word (prefetched)
+      if (b + 1 < cb) {                                      // prefetch both words of the next block: off the phase's latency chain
+        const int r2 = row + 64;
+        dnext = r2 < n ? mask[(long)r2 * cb + b + 1] : 0ull;
+        cnext = (r2 < n && b + 2 < cb) ? mask[(long)r2 * cb + b + 2] : 0ull;
+      }
       unsigned long long rbv = remv[b];
       unsigned long long rb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(rbv >> 32)) << 32) |
                               (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)rbv);
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
       if (mine) { const int pos = nk + __popcll(K & ((1ull << lane) - 1ull)); if (pos < max_keep) keep[pos] = row; }
       // direct OR of column b+1 (needed by the very next phase)
       if (b + 1 < cb) {
-        unsigned long long v = mine ? mask[(long)row * cb + b + 1] : 0ull;
+        unsigned long long v = mine ? ccol : 0ull;
         for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
         if (lane == 0 && v) atomicOr(&remv[b + 1], v);
       }
