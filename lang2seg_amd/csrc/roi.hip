@@ -69,29 +69,26 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned int* keys, 
   __syncthreads();
   hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(1024) void rs_scan_kernel(int* hist, int total) {
-  // exclusive scan of `total` counters by one workgroup: each wave owns a contiguous chunk and walks it 64 counters at a
-  // time (coalesced loads, wave prefix by DPP-style shuffles), then the 16 wave totals are scanned and added back
-  __shared__ int wtot[16];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int per = ((total + 15) / 16 + 63) & ~63;            // counters per wave, multiple of 64
-  const int lo = wv * per, hi = min(total, lo + per);
-  int run = 0;
-  for (int i0 = lo; i0 < hi; i0 += 64) {
-    const int i = i0 + lane;
-    const int v = i < hi ? hist[i] : 0;
-    int x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (i < hi) hist[i] = run + x - v;                       // exclusive, relative to the wave's chunk
-    run += __shfl(x, 63, 64);
-  }
-  if (lane == 0) wtot[wv] = run;
+__global__ __launch_bounds__(1024) void rs_scan_kernel(int* hist, int total, int use_lds) {
+  // exclusive scan of `total` counters by one workgroup, staged through LDS when they fit (dynamic, total ints): all loads
+  // are issued before any dependent work, the serial part runs on LDS (thread-contiguous chunks, odd stride -> no bank
+  // conflicts); larger inputs run the same code in place on global memory
+  extern __shared__ int shl[];
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  int* sh = use_lds ? shl : hist;
+  if (use_lds) for (int i = t; i < total; i += 1024) sh[i] = hist[i];
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wv; ++w) base += wtot[w];
-  if (base)
-    for (int i = lo + lane; i < hi; i += 64) hist[i] += base;
+  const int per = ((total + 1023) / 1024) | 1, lo = t * per, hi = min(total, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += sh[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) { int x = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += x; __syncthreads(); }
+  int run = part[t] - s;
+  for (int i = lo; i < hi; ++i) { const int v = sh[i]; sh[i] = run; run += v; }
+  __syncthreads();
+  if (use_lds) for (int i = t; i < total; i += 1024) hist[i] = sh[i];
 }
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned int* kin, const int* iin, unsigned int* kout, int* iout, int n, int shift,
                                                         int nblk, const int* hist) {
@@ -146,29 +143,41 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 }
 // Greedy scan over the bitmask, one 64-box block per phase, single workgroup of 16 waves:
 //   wave 0 (critical path): scans block j against remv[j] (only the kept boxes cost an iteration), then ORs the kept rows'
-//           words of column j+1 straight into remv[j+1];
-//   waves 1..15 (bulk, one phase behind): OR the kept rows of block j-1 into every column >= j+1 with fire-and-forget LDS
-//           atomics (coalesced along the row), overlapping wave 0's latency chain.
+//           words of columns j+1 and j+2 (prefetched one phase ahead) straight into remv;
+//   waves 1..15 (bulk, software pipelined): in phase j+1 they LOAD the kept rows of block j for every column >= j+3 into
+//           registers, in phase j+2 they OR them into remv with fire-and-forget LDS atomics -- so the HBM/L2 latency of the
+//           bulk rows spans a whole phase instead of sitting in front of every barrier.
 // One barrier per phase; stops as soon as max_keep boxes are kept (RPN_POST_NMS_TOP_N).
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out) {
   extern __shared__ unsigned long long remv[];   // cb words
   __shared__ unsigned long long kept_sh[2];
   __shared__ int nk_sh[2];
+  constexpr int NQ = 13, BULK = 960;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < cb; c += 1024) remv[c] = 0ull;
   if (tid == 0) { nk_sh[0] = nk_sh[1] = 0; kept_sh[0] = kept_sh[1] = 0ull; }
   int nk = 0;   // running keep count (wave 0)
   __syncthreads();
-  unsigned long long dnext = 0ull, cnext = 0ull;
-  if (wave == 0) { dnext = lane < n ? mask[(long)lane * cb] : 0ull; cnext = (lane < n && cb > 1) ? mask[(long)lane * cb + 1] : 0ull; }
+  unsigned long long dnext = 0ull, c1next = 0ull, c2next = 0ull;
+  if (wave == 0 && lane < n) {
+    dnext = mask[(long)lane * cb];
+    if (cb > 1) c1next = mask[(long)lane * cb + 1];
+    if (cb > 2) c2next = mask[(long)lane * cb + 2];
+  }
+  unsigned long long pv[NQ]; int pc[NQ];      // bulk values loaded in the previous phase and their columns
+  const int brow = (tid - 64) / 15, bcl = (tid - 64) - brow * 15;   // bulk threads: row of the block, column lane
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { pv[q] = 0ull; pc[q] = 0; }
   for (int b = 0; b < cb; ++b) {
     if (wave == 0) {
       const int row = b * 64 + lane;
-      const unsigned long long d = dnext, ccol = cnext;      // this block's diagonal word and its column b+1 word (prefetched)
-      if (b + 1 < cb) {                                      // prefetch both words of the next block: off the phase's latency chain
+      const unsigned long long d = dnext, col1 = c1next, col2 = c2next;
+      if (b + 1 < cb) {                                      // prefetch the next block's words: off this phase's latency chain
         const int r2 = row + 64;
-        dnext = r2 < n ? mask[(long)r2 * cb + b + 1] : 0ull;
-        cnext = (r2 < n && b + 2 < cb) ? mask[(long)r2 * cb + b + 2] : 0ull;
+        const bool v = r2 < n;
+        dnext = v ? mask[(long)r2 * cb + b + 1] : 0ull;
+        c1next = (v && b + 2 < cb) ? mask[(long)r2 * cb + b + 2] : 0ull;
+        c2next = (v && b + 3 < cb) ? mask[(long)r2 * cb + b + 3] : 0ull;
       }
       unsigned long long rbv = remv[b];
       unsigned long long rb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(rbv >> 32)) << 32) |
@@ -185,30 +194,42 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
       }
       const bool mine = (K >> lane) & 1ull;
       if (mine) { const int pos = nk + __popcll(K & ((1ull << lane) - 1ull)); if (pos < max_keep) keep[pos] = row; }
-      // direct OR of column b+1 (needed by the very next phase)
-      if (b + 1 < cb) {
-        unsigned long long v = mine ? ccol : 0ull;
-        for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-        if (lane == 0 && v) atomicOr(&remv[b + 1], v);
+      // direct OR of columns b+1 (needed by the very next phase) and b+2
+      // (every kept lane ORs its own words: a few same-address LDS atomics cost less than a 64-lane shuffle reduction)
+      if (mine && b + 1 < cb) {
+        if (col1) atomicOr(&remv[b + 1], col1);
+        if (col2 && b + 2 < cb) atomicOr(&remv[b + 2], col2);
       }
       nk += __popcll(K);
       if (lane == 0) { kept_sh[b & 1] = K; nk_sh[b & 1] = nk; }
-    } else if (b > 0) {
-      // bulk: block b-1's kept rows into columns >= b+1
-      const unsigned long long Kp = kept_sh[(b - 1) & 1];
-      const int c0 = b + 1, ncol = cb - c0;
-      if (Kp && ncol > 0) {
-        const int total = ncol * 64;
-        for (int idx = tid - 64; idx < total; idx += 960) {
-          const int r = idx / ncol, c = c0 + (idx - r * ncol);
-          if ((Kp >> r) & 1ull) {
-            const unsigned long long v = mask[(long)((b - 1) * 64 + r) * cb + c];
-            if (v) atomicOr(&remv[c], v);
+    } else {
+      // (2) apply what was loaded in the previous phase (block b-2 -> columns >= b+1)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { if (pv[q]) atomicOr(&remv[pc[q]], pv[q]); pv[q] = 0ull; }
+      // (1) load block b-1's kept rows for columns >= b+2.  Fixed thread -> (row, column lane) map: 64 rows x 15 lanes,
+      //     lane cl covers columns c0 + cl + 15 q (no per-phase index division; a row's 15 lanes read 120 contiguous bytes)
+      if (b > 0) {
+        const unsigned long long Kp = kept_sh[(b - 1) & 1];
+        const int c0 = b + 2;
+        if ((Kp >> brow) & 1ull) {
+          const uint64_t* mr = mask + (long)((b - 1) * 64 + brow) * cb;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const int c = c0 + bcl + 15 * q;
+            pc[q] = c;
+            if (c < cb) pv[q] = mr[c];
+          }
+          for (int c = c0 + bcl + 15 * NQ; c < cb; c += 15) {                   // larger problems: the rest synchronously
+            const unsigned long long v = mr[c]; if (v) atomicOr(&remv[c], v);
           }
         }
       }
     }
-    __syncthreads();
+    // raw barrier: LDS traffic (atomics, kept_sh / nk_sh) is drained, but the bulk waves' global loads stay in flight across
+    // it (__syncthreads() would wait for vmcnt(0) and put their latency back in front of every phase)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (nk_sh[b & 1] >= max_keep) break;
   }
   if (tid == 0) *num_out = min(nk, max_keep);
@@ -560,12 +581,15 @@ extern "C" int l2s_sort_topk(const float* scores, const float* boxes, int n, int
                              float* sorted_scores, int* sorted_idx, hipStream_t s) {
   if (!ws || n <= 0 || k > n) return L2S_EINVAL;
   const int nblk = cdiv(n, 256);
+  const int scan_lds = (size_t)256 * nblk * 4 <= 150 * 1024;     // the counter scan is staged in LDS when it fits (n <= 38400)
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)rs_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done = true; }
   RsWs w = rs_ws(ws, n);
   L2S_LAUNCH(rs_init_kernel, dim3(nblk), dim3(256), 0, s, scores, n, ws);
   unsigned int* kin = w.kA; int* iin = w.iA; unsigned int* kout = w.kB; int* iout = w.iB;
   for (int pass = 0; pass < 4; ++pass) {
     L2S_LAUNCH(rs_hist_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, n, 8 * pass, nblk, w.hist);
-    L2S_LAUNCH(rs_scan_kernel, dim3(1), dim3(1024), 0, s, w.hist, 256 * nblk);
+    L2S_LAUNCH(rs_scan_kernel, dim3(1), dim3(1024), scan_lds ? (size_t)256 * nblk * 4 : 0, s, w.hist, 256 * nblk, scan_lds);
     L2S_LAUNCH(rs_scatter_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, (const int*)iin, kout, iout, n, 8 * pass, nblk, (const int*)w.hist);
     unsigned int* tk = kin; kin = kout; kout = tk; int* ti = iin; iin = iout; iout = ti;
   }
