@@ -41,7 +41,9 @@ def spatial_masks(H, W):
 
 
 class OracleNet(object):
-    def __init__(self, sd, opt, cfg=None, num_layers=101, num_classes=81):
+    def __init__(self, sd, opt, cfg=None, num_layers=101, num_classes=81, variant='cycle'):
+        from .weights import VARIANTS
+        self.variant = variant; self.var = VARIANTS[variant]
         self.cfg = DEFAULT_CFG if cfg is None else cfg
         self.opt = opt
         self.num_classes = num_classes
@@ -123,14 +125,20 @@ class OracleNet(object):
     # ---- dynamic filters (NET:504-562) ------------------------------------
     def dynamic_filter(self, net_conv, hidden):
         H, W = net_conv.shape[2], net_conv.shape[3]
-        masks = torch.from_numpy(spatial_masks(H, W))
-        resp = []
-        for k in range(7):
-            f = torch.tanh(F.linear(hidden, self.p['dynamic_fc_%d.weight' % k], self.p['dynamic_fc_%d.bias' % k]))
-            resp.append(F.conv2d(net_conv * masks[k][None, None], f.view(1, -1, 1, 1)))
-        r = torch.tanh(F.linear(hidden, self.p['response_fc.weight'], self.p['response_fc.bias']))
-        response = F.conv2d(torch.cat(resp, 1), r.view(1, 7, 1, 1))
+        if self.var['nfilt'] == 1:                                          # network.py:475-479
+            f = torch.tanh(F.linear(hidden, self.p['dynamic_fc.weight'], self.p['dynamic_fc.bias']))
+            response = F.conv2d(net_conv, f.view(1, -1, 1, 1))
+        else:
+            masks = torch.from_numpy(spatial_masks(H, W))
+            resp = []
+            for k in range(7):
+                f = torch.tanh(F.linear(hidden, self.p['dynamic_fc_%d.weight' % k], self.p['dynamic_fc_%d.bias' % k]))
+                resp.append(F.conv2d(net_conv * masks[k][None, None], f.view(1, -1, 1, 1)))
+            r = torch.tanh(F.linear(hidden, self.p['response_fc.weight'], self.p['response_fc.bias']))
+            response = F.conv2d(torch.cat(resp, 1), r.view(1, 7, 1, 1))
         self.t_response = response
+        if self.var['gate'] == 'sigmoid':                                   # network_7f_response.py:543-545
+            return net_conv * torch.sigmoid(response)
         return net_conv * response
 
     # ---- crop pool (NET:107-149, max_pool False via RES:258-259) -----------
@@ -264,24 +272,39 @@ class OracleNet(object):
         L['loss_box'] = self.smooth_l1(bbox_pred, torch.from_numpy(bt), torch.from_numpy(bi), torch.from_numpy(bo), 1.0, [1])
         fgl = label[:nfg].view(nfg, 1, 1, 1).expand(nfg, 1, cfg['MASK_SIZE'], cfg['MASK_SIZE'])
         L['loss_mask'] = F.binary_cross_entropy_with_logits(torch.gather(mscore, 1, fgl).squeeze(1), torch.from_numpy(mt))
-        # ---- caption features (NET:415-435) ----
-        feats = self.head_to_tail(net_conv)
-        T['feats_all'] = feats
-        att_all = F.adaptive_avg_pool2d(feats, [14, 14]).permute(0, 2, 3, 1)
-        gm = torch.from_numpy(blob['gt_masks']).unsqueeze(1).float()
-        gm = F.adaptive_avg_pool2d(gm, [feats.shape[2], feats.shape[3]])
-        gm = (gm >= 0.5).float()
-        T['gt_mask_small'] = gm
-        att_mask = F.adaptive_avg_pool2d(feats * gm, [14, 14]).permute(0, 2, 3, 1)
-        att = torch.cat((att_all, att_mask), 3).contiguous().view(1, 196, -1)
-        T['att_feats'] = att
-        logp = self.caption(att, torch.from_numpy(blob['cap_labels']), drops)
-        T['cap_logprobs'] = logp
-        tgt = torch.from_numpy(blob['cap_labels'])[:, 1:][:, :logp.shape[1]]
-        msk = torch.from_numpy(blob['cap_masks'])[:, 1:][:, :logp.shape[1]]
-        L['loss_caption'] = (-logp.gather(2, tgt.unsqueeze(2)).squeeze(2) * msk).sum() / msk.sum()   # CRIT:43-53
-        L['total_loss'] = (L['cross_entropy'] + L['loss_box'] + L['rpn_cross_entropy'] + L['rpn_loss_box'] +
-                           L['loss_mask'] + self.opt['cap_loss_weight'] * L['loss_caption'])            # NET:448
+        total = L['cross_entropy'] + L['loss_box'] + L['rpn_cross_entropy'] + L['rpn_loss_box'] + L['loss_mask']
+        if self.var['gate'] == 'sigmoid':
+            # response loss (network_cycle_response.py:415-423): PIL-NEAREST resize of the uint8 GT mask to the C4 map
+            rp = self.t_response[0, 0]
+            rt = B.imresize_nearest_u8(blob['gt_masks'][0], (rp.shape[0], rp.shape[1])).astype(np.float32)
+            T['response_targets'] = rt
+            L['loss_response'] = F.binary_cross_entropy_with_logits(rp, torch.from_numpy(rt))
+            total = total + L['loss_response']
+        if self.var['cap'] is not None:
+            # ---- caption features (NET:415-435; network_cycle_response.py:425-439) ----
+            feats = self.head_to_tail(net_conv)
+            T['feats_all'] = feats
+            att_all = F.adaptive_avg_pool2d(feats, [14, 14]).permute(0, 2, 3, 1)
+            if self.var['cap'] == 'mask':
+                gm = torch.from_numpy(blob['gt_masks']).unsqueeze(1).float()
+                gm = F.adaptive_avg_pool2d(gm, [feats.shape[2], feats.shape[3]])
+                gm = (gm >= 0.5).float()
+                T['gt_mask_small'] = gm
+                att_mask = F.adaptive_avg_pool2d(feats * gm, [14, 14]).permute(0, 2, 3, 1)
+                att = torch.cat((att_all, att_mask), 3).contiguous().view(1, 196, -1)
+            else:
+                feats_b = self.head_to_tail(base)
+                T['feats_before_all'] = feats_b
+                att_b = F.adaptive_avg_pool2d(feats_b, [14, 14]).permute(0, 2, 3, 1)
+                att = torch.cat((att_b, att_all), 3).contiguous().view(1, 196, -1)
+            T['att_feats'] = att
+            logp = self.caption(att, torch.from_numpy(blob['cap_labels']), drops)
+            T['cap_logprobs'] = logp
+            tgt = torch.from_numpy(blob['cap_labels'])[:, 1:][:, :logp.shape[1]]
+            msk = torch.from_numpy(blob['cap_masks'])[:, 1:][:, :logp.shape[1]]
+            L['loss_caption'] = (-logp.gather(2, tgt.unsqueeze(2)).squeeze(2) * msk).sum() / msk.sum()   # CRIT:43-53
+            total = total + self.opt['cap_loss_weight'] * L['loss_caption']                                # NET:448
+        L['total_loss'] = total
         self.t = T; self.losses = L
         return T, L
 
@@ -311,5 +334,5 @@ class OracleNet(object):
         _, L = self.forward_train(blob, samp, drops)
         self.backward()
         self.sgd_step(lr)
-        return tuple(float(L[k]) for k in ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box',
-                                           'loss_mask', 'loss_caption', 'total_loss'])
+        from .weights import loss_keys
+        return tuple(float(L[k]) for k in loss_keys(self.variant))

@@ -10,6 +10,26 @@ import numpy as np
 
 RESNET_LAYERS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
 
+# The reference's ResNet network variants (one nets/network_*.py + nets/resnet_v1_*.py pair each):
+#   nfilt: 1 = dynamic_fc (network.py:475-479), 7 = dynamic_fc_0..6 + response_fc (network_7f.py:475-534)
+#   gate : 'linear'  net_conv * response, 'sigmoid' net_conv * sigmoid(response) + response BCE loss
+#          (network_7f_response.py:411-419,543-545; network_cycle_response.py:415-423,568-570)
+#   cap  : None, 'mask' (network_cycle_res5_2.py:415-440), 'before_after' (network_cycle_response.py:425-439)
+VARIANTS = {
+    'baseline': dict(nfilt=1, gate='linear', cap=None, module='resnet_v1', net='network'),
+    'spatial': dict(nfilt=7, gate='linear', cap=None, module='resnet_v1_7f', net='network_7f'),
+    'response': dict(nfilt=7, gate='sigmoid', cap=None, module='resnet_v1_7f_response', net='network_7f_response'),
+    'cycle': dict(nfilt=7, gate='linear', cap='mask', module='resnet_v1_cycle_res5_2', net='network_cycle_res5_2'),
+    'cycle_response': dict(nfilt=7, gate='sigmoid', cap='before_after', module='resnet_v1_cycle_response', net='network_cycle_response'),
+}
+LOSS_KEYS = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_response', 'loss_caption', 'total_loss']
+
+
+def loss_keys(variant):
+    """order of the floats Network.train_step returns (NET:702-719 and its variants)."""
+    v = VARIANTS[variant]
+    return [k for k in LOSS_KEYS if not (k == 'loss_response' and v['gate'] != 'sigmoid') and not (k == 'loss_caption' and v['cap'] is None)]
+
 
 def default_opt(vocab_size=1999, seq_length=10, cap_loss_weight=1.0):
     """tools/opt_cycle_2.py:4-128 effective defaults."""
@@ -22,9 +42,10 @@ def default_opt(vocab_size=1999, seq_length=10, cap_loss_weight=1.0):
                 att_hid_size=512, start_from=None, dataset_splitBy='refcoco_unc')
 
 
-def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12):
+def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12, variant='cycle'):
     """Ordered {name: shape} for every tensor the hot path reads."""
     s = {}
+    var = VARIANTS[variant]
     V = opt['vocab_size']; E = opt['word_embedding_size']; WV = opt['word_vec_size']
     Hh = opt['rnn_hidden_size']
     s['rnn_encoder.embedding.weight'] = (V, E)
@@ -35,6 +56,7 @@ def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12):
         s['rnn_encoder.rnn.bias_ih_l0' + sfx] = (4 * Hh,)
         s['rnn_encoder.rnn.bias_hh_l0' + sfx] = (4 * Hh,)
     R = opt['rnn_size']; IE = opt['input_encoding_size']; AH = opt['att_hid_size']
+    cap_keys_from = len(s)
     s['caption_model.embed.0.weight'] = (V + 1, IE)
     s['caption_model.att_embed.0.weight'] = (R, opt['att_feat_size']); s['caption_model.att_embed.0.bias'] = (R,)
     s['caption_model.logit.weight'] = (V + 1, R); s['caption_model.logit.bias'] = (V + 1,)
@@ -44,6 +66,9 @@ def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12):
     s['caption_model.core.h2h.weight'] = (5 * R, R); s['caption_model.core.h2h.bias'] = (5 * R,)
     s['caption_model.core.attention.h2att.weight'] = (AH, R); s['caption_model.core.attention.h2att.bias'] = (AH,)
     s['caption_model.core.attention.alpha_net.weight'] = (1, AH); s['caption_model.core.attention.alpha_net.bias'] = (1,)
+    if var['cap'] is None:
+        for k in list(s.keys())[cap_keys_from:]:
+            del s[k]
 
     def bn(p, c):
         for k in ['weight', 'bias', 'running_mean', 'running_var']:
@@ -60,9 +85,12 @@ def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12):
                 s[p + '.downsample.0.weight'] = (planes * 4, inpl, 1, 1); bn(p + '.downsample.1', planes * 4)
             inpl = planes * 4
     C4 = opt['C4_feat_dim']; HD = opt['rnn_num_layers'] * (2 if opt['bidirectional'] else 1) * Hh
-    for k in range(7):
-        s['dynamic_fc_%d.weight' % k] = (C4, HD); s['dynamic_fc_%d.bias' % k] = (C4,)
-    s['response_fc.weight'] = (7, HD); s['response_fc.bias'] = (7,)
+    if var['nfilt'] == 1:
+        s['dynamic_fc.weight'] = (C4, HD); s['dynamic_fc.bias'] = (C4,)
+    else:
+        for k in range(7):
+            s['dynamic_fc_%d.weight' % k] = (C4, HD); s['dynamic_fc_%d.bias' % k] = (C4,)
+        s['response_fc.weight'] = (7, HD); s['response_fc.bias'] = (7,)
     s['rpn_net.weight'] = (512, C4, 3, 3); s['rpn_net.bias'] = (512,)
     s['rpn_cls_score_net.weight'] = (2 * num_anchors, 512, 1, 1); s['rpn_cls_score_net.bias'] = (2 * num_anchors,)
     s['rpn_bbox_pred_net.weight'] = (4 * num_anchors, 512, 1, 1); s['rpn_bbox_pred_net.bias'] = (4 * num_anchors,)
@@ -73,13 +101,13 @@ def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12):
     return s
 
 
-def make_state_dict(opt, seed=3, num_layers=101, num_classes=81, num_anchors=12, head_gain=1.0):
+def make_state_dict(opt, seed=3, num_layers=101, num_classes=81, num_anchors=12, head_gain=1.0, variant='cycle'):
     """name -> float32 ndarray.  One RandomState stream consumed in param_shapes order.
     `head_gain` > 1 scales the N(0,0.01) head initialisers so scores/deltas are not
     degenerate in parity fixtures (the reference init makes every RPN score ~0.5)."""
     rs = np.random.RandomState(seed)
     sd = {}
-    for name, shp in param_shapes(opt, num_layers, num_classes, num_anchors).items():
+    for name, shp in param_shapes(opt, num_layers, num_classes, num_anchors, variant).items():
         n = int(np.prod(shp))
         if name.endswith('running_mean'):
             a = rs.normal(0, 0.1, n)

@@ -18,7 +18,7 @@ this harness only restores the environment it expects, in-process (SURVEY.md §8
 sets the same attributes forward() sets (NET:632-648) and calls `_predict()` /
 `_add_losses()` / backward / torch.optim.SGD exactly as NET:650-662,712-715, TV:194-220.
 
-Usage: python tests/golden/make_golden.py [tiny|full|leaf|all]
+Usage: python tests/golden/make_golden.py [tiny|full|leaf|variants|all]
 """
 import os
 import sys
@@ -162,10 +162,12 @@ def keys_from_log(n_total, cand, drawn, disable_mode):
     return keys
 
 
-def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain=4.0, full_tensors=True):
+def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain=4.0, full_tensors=True, variant='cycle'):
     from model.config import cfg
-    import nets.resnet_v1_cycle_res5_2 as RESM
-    import nets.network_cycle_res5_2 as NETM
+    import importlib
+    var = OW.VARIANTS[variant]
+    RESM = importlib.import_module('nets.' + var['module'])
+    NETM = importlib.import_module('nets.' + var['net'])
     from oracle.net import DEFAULT_CFG
     import copy
     ocfg = copy.deepcopy(DEFAULT_CFG)
@@ -174,7 +176,7 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
         setattr(cfg.TRAIN, k, v)
     cfg.ANCHOR_SCALES = list(ocfg['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(ocfg['ANCHOR_RATIOS'])
     opt = OW.default_opt(vocab_size=V, seq_length=T)
-    sd = OW.make_state_dict(opt, seed=seed_w, head_gain=head_gain)
+    sd = OW.make_state_dict(opt, seed=seed_w, head_gain=head_gain, variant=variant)
     blob = OS.make_blob(H, W, T, V, seed=seed_blob)
 
     torch.manual_seed(0)
@@ -220,7 +222,7 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
     optimizer.step()
 
     out = dict(meta_H=H, meta_W=W, meta_T=T, meta_V=V, meta_seed_w=seed_w, meta_seed_blob=seed_blob,
-               meta_head_gain=head_gain)
+               meta_head_gain=head_gain, meta_variant=variant)
     for k, v in cfg_over.items():
         out['cfg.' + k] = v
     for k, v in L.items():
@@ -264,9 +266,15 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
     bg_inds = np.where((mx < cfg.TRAIN.BG_THRESH_HI) & (mx >= cfg.TRAIN.BG_THRESH_LO))[0]
     n_prop = all_rois.shape[0]
     print('n_prop', n_prop, 'fg', len(fg_inds), 'bg', len(bg_inds), 'log', [(len(e['a']), e['size'], e['replace']) for e in log])
-    assert len(ptl_fg['a']) == len(fg_inds) and len(ptl_bg['a']) == len(bg_inds), (len(ptl_fg['a']), len(fg_inds), len(ptl_bg['a']), len(bg_inds))
+    if len(fg_inds) == 0:
+        # PTL:159-167: no proposal overlaps the GT box -> the reference appends the GT boxes to the roi list and retries; the
+        # only fg candidates are the appended rows (the oracle / kernels give them key 0), proposals keep their bg draws
+        assert len(ptl_fg['a']) == blob['gt_boxes'].shape[0] and len(ptl_bg['a']) == len(bg_inds)
+        out['samp.roi_fg_keys'] = np.full(n_prop, 0xFFFFFFFF, np.uint32)
+    else:
+        assert len(ptl_fg['a']) == len(fg_inds) and len(ptl_bg['a']) == len(bg_inds), (len(ptl_fg['a']), len(fg_inds), len(ptl_bg['a']), len(bg_inds))
+        out['samp.roi_fg_keys'] = keys_from_log(n_prop, fg_inds, fg_inds[ptl_fg['result']], False)
     assert not ptl_bg['replace'], 'fixture expects the without-replacement path'
-    out['samp.roi_fg_keys'] = keys_from_log(n_prop, fg_inds, fg_inds[ptl_fg['result']], False)
     out['samp.roi_bg_keys'] = keys_from_log(n_prop, bg_inds, bg_inds[ptl_bg['result']], False)
     out['int.proposal_rois'] = all_rois
     out['int.proposal_scores'] = PROPOSALS['scores']
@@ -275,7 +283,7 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
     out['int.labels'] = prop['labels'].numpy().astype(np.int64).reshape(-1)
     out['int.mask_targets'] = prop['mask_targets'].numpy().astype(np.uint8)
     out['int.num_fg'] = prop['mask_targets'].shape[0]
-    tens = dict(net_conv=net_conv, response=None, rpn_cls_prob=net._predictions['rpn_cls_prob'],
+    tens = dict(net_conv=net_conv, response=net._predictions.get('response'), rpn_cls_prob=net._predictions['rpn_cls_prob'],
                 rpn_bbox_pred=net._predictions['rpn_bbox_pred'], rpn_bbox_targets=net._anchor_targets['rpn_bbox_targets'],
                 rpn_bbox_outside=net._anchor_targets['rpn_bbox_outside_weights'],
                 bbox_targets=prop['bbox_targets'], cls_score=net._predictions['cls_score'],
@@ -293,6 +301,10 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
             'rnn_encoder.mlp.0.bias', 'caption_model.att_embed.0.weight', 'caption_model.logit.weight',
             'caption_model.core.h2h.weight', 'caption_model.core.a2c.bias', 'caption_model.core.attention.alpha_net.weight',
             'caption_model.embed.0.weight', 'caption_model.ctx2att.weight']
+    if var['nfilt'] == 1:
+        gsel = [k for k in gsel if not k.startswith(('dynamic_fc_', 'response_fc'))] + ['dynamic_fc.weight', 'dynamic_fc.bias']
+    if var['cap'] is None:
+        gsel = [k for k in gsel if not k.startswith('caption_model.')]
     for k in gsel:
         g = grads[k]
         flat('g.' + k, digest(g if g is not None else torch.zeros(1)), out)
@@ -305,9 +317,13 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
 PROPOSALS = {}
 
 
-def hook_proposals():
+def hook_proposals(variant='cycle'):
     """Record what proposal_layer returned (its output is consumed, not stored, by NET:256-259)."""
-    import nets.network_cycle_res5_2 as NETM
+    import importlib
+    NETM = importlib.import_module('nets.' + OW.VARIANTS[variant]['net'])
+    if getattr(NETM, '_l2s_hooked', False):
+        return
+    NETM._l2s_hooked = True
     orig = NETM.proposal_layer
 
     def rec(*a, **k):
@@ -376,6 +392,12 @@ if __name__ == '__main__':
         hook_proposals()
         run_reference('tiny', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,
                                                     RPN_BATCHSIZE=64), head_gain=float(os.environ.get('HG', '4')))
+    if what in ('variants', 'all'):
+        # the other ResNet network variants of the reference (BASELINE.json configs 0, 1, 3 + train_response.sh), tiny size
+        for v in ['baseline', 'spatial', 'response', 'cycle_response']:
+            hook_proposals(v)
+            run_reference('tiny_' + v, 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,
+                                                             RPN_BATCHSIZE=64), head_gain=4.0, variant=v)
     if what in ('full', 'all'):
         hook_proposals()
         run_reference('full', 600, 1000, 20, 3349, dict(BATCH_SIZE=256, RPN_PRE_NMS_TOP_N=12000,

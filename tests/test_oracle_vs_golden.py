@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import boxes as OB, weights as OW, net as ON
-from golden_util import load, check_digest, setup_from_fixture
+from golden_util import load, check_digest, setup_from_fixture, variant_of
 
 
 def test_anchor_known_answer():
@@ -44,7 +44,7 @@ def test_leaf_language():
 def _run_e2e(tag):
     g = load(tag)
     opt, sd, blob, cfg, samp = setup_from_fixture(g)
-    net = ON.OracleNet(sd, opt, cfg)
+    net = ON.OracleNet(sd, opt, cfg, variant=variant_of(g))
     # proposal order / NMS keeps are discontinuous in fp32 scores (near-ties swap rows): compare the
     # oracle's own proposals as a SET with tolerance, then teacher-force the reference's list so that
     # everything downstream (sampling, targets, heads, losses, grads) can be compared tightly.
@@ -54,10 +54,11 @@ def _run_e2e(tag):
     key = lambda r: r[np.lexsort(np.round(r[:, ::-1] * 8).T)]
     assert np.allclose(key(T['proposal_rois']), key(g['int.proposal_rois']), atol=2e-3)
     assert np.array_equal(T['rpn_labels'].astype(np.int8), g['int.rpn_labels'])
-    assert np.allclose(T['rois'], g['int.rois'], atol=2e-3)
+    # column 0 (batch index) of a GT row appended by PTL:159-167 is uninitialised memory in the reference (`.new()`); nothing reads it
+    assert np.allclose(T['rois'][:, 1:], g['int.rois'][:, 1:], atol=2e-3)
     assert np.array_equal(T['labels'].reshape(-1).astype(np.int64), g['int.labels'])
     assert np.array_equal(T['mask_targets'].astype(np.uint8), g['int.mask_targets'])
-    for k in ['net_conv', 'rpn_cls_prob', 'rpn_bbox_pred', 'cls_score', 'bbox_pred', 'mask_score']:
+    for k in ['net_conv', 'rpn_cls_prob', 'rpn_bbox_pred', 'cls_score', 'bbox_pred', 'mask_score'] + (['response'] if 't.response.sum' in g else []):
         check_digest(g, 't.' + k, T[k].detach().numpy())
     check_digest(g, 't.rpn_bbox_targets', T['rpn_bbox_targets'])
     check_digest(g, 't.rpn_bbox_outside', T['rpn_bbox_outside'])
@@ -74,3 +75,10 @@ def _run_e2e(tag):
 
 def test_train_step_tiny():
     _run_e2e('tiny')
+
+
+@pytest.mark.parametrize('variant', ['baseline', 'spatial', 'response', 'cycle_response'])
+def test_train_step_tiny_variants(variant):
+    """the reference's other ResNet network variants (network.py, network_7f.py, network_7f_response.py,
+    network_cycle_response.py): losses (incl. the response BCE), targets, gradients, post-SGD weights."""
+    _run_e2e('tiny_' + variant)
