@@ -163,6 +163,7 @@ int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, i
 #define L2S_LOSS_MASK 4
 #define L2S_LOSS_CAP 5
 #define L2S_LOSS_TOTAL 6
+#define L2S_LOSS_RESPONSE 7   /* network_7f_response.py:411-419 / network_cycle_response.py:415-423; 0 in the other variants */
 /* RPN CE over anchors with label != -1 (NET:377-382) + smooth-L1 sigma=3 (NET:385-390).
  * heads as in l2s_rpn_decode; labels in (a,h,w) order.  dheads(dtype) [HW][ldd] receives d(loss)/d(heads)*gscale. */
 int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
@@ -178,6 +179,10 @@ int l2s_rcnn_loss(const float* heads, int ldh, const int* labels, const float* b
 int l2s_mask_loss(const float* score, int ldsc, const int* labels, const float* mask_targets, const int* num_fg, int fg_max,
                   int ms2, float gscale, float* loss, float* dscore /*[fg_max*ms2]*/, hipStream_t s);
 /* total = cls + box + rpn_cls + rpn_box + mask + w*cap (NET:448) */
+/* response BCE loss of the *_response variants: target = GT mask [mask_h][mask_w] u8 {0,1} resized PIL-NEAREST to [H][W];
+ * loss[L2S_LOSS_RESPONSE] += mean BCE; dresp[HW] = gscale * d loss / d response */
+int l2s_response_loss(const float* resp, const uint8_t* gt_mask, int mask_h, int mask_w, int H, int W, float gscale, float* loss,
+                      float* dresp, hipStream_t s);
 int l2s_total_loss(float* loss, float cap_w, hipStream_t s);
 /* mask_pred_net backward (only the label channel carries gradient): dx(dtype)[fg_max*ms2][C] = dscore[p]*W[label][:],
  * dW[label][:] += sum dscore[p]*x[p][:], db[label] += sum dscore[p] */
@@ -204,10 +209,11 @@ int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const float* act, con
 /* dynamic-filter correlation (NET:504-562): filt float [7][C] (tanh'ed), r float [7].
  * y(dtype)[HW][C] = x * resp, resp float [HW], respk float [HW][7] (masked per-filter responses) */
 int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,
-                      int dtype, hipStream_t s);
+                      int dtype, int gate /*0: y = x*response, 1: y = x*sigmoid(response) (the *_response variants)*/, hipStream_t s);
 /* dy(dtype) -> dx(dtype), dfilt float [7][C] (+=), dr float [7] (+=); dresp_ws float [HW] */
 int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
-                      void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype, hipStream_t s);
+                      void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype,
+                      int gate, const float* dresp_extra /*nullable [HW]: d(response loss)/d(response)*/, hipStream_t s);
 /* att2in2 attention (AttModel.py:406-423): patt [L][D], att [L][D] float; att_h [D]; alpha w[D], b.
  * out: weight [L] (softmax), att_res [D + 256] (the tail is scratch for the raw dots) */
 int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,

@@ -37,7 +37,7 @@ class SgdSeg(C.Structure):
 
 
 CONV_RELU, CONV_OUT_F32, CONV_DECONV2X2, CONV_SCATTER = 1, 4, 8, 16
-LOSS_RPN_CLS, LOSS_RPN_BOX, LOSS_CLS, LOSS_BOX, LOSS_MASK, LOSS_CAP, LOSS_TOTAL = range(7)
+LOSS_RPN_CLS, LOSS_RPN_BOX, LOSS_CLS, LOSS_BOX, LOSS_MASK, LOSS_CAP, LOSS_TOTAL, LOSS_RESPONSE = range(8)
 
 # name -> (restype, argtypes); the stream is always the last argument
 SIGS = {
@@ -87,8 +87,9 @@ SIGS = {
     'l2s_embed_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'l2s_lstm_cell_fwd': (i32, [vp, vp, vp, vp, vp, i32, vp]),
     'l2s_lstm_cell_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
-    'l2s_dynfilter_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    'l2s_dynfilter_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    'l2s_dynfilter_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'l2s_dynfilter_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'l2s_response_loss': (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     'l2s_cap_attention_fwd': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     'l2s_cap_attention_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     'l2s_cap_gates_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -11,6 +11,8 @@ namespace {
 
 constexpr int MAXM = 24;   // rows handled per wave pass in the skinny kernels
 
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 2) return tanhf(v);
@@ -144,7 +146,6 @@ __global__ void embed_bwd_kernel(const float* dout, const float* out, const int6
   }
 }
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ void lstm_cell_fwd_kernel(const float* g, const float* c_prev, float* c, float* h, float* act, int Hh) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,8 +181,9 @@ __device__ __forceinline__ void spatial_mask7(int y, int x, int H, int W, float 
   m[6] = (x >= (int)(W / 4.0) && x < (int)(W * 3 / 4.0)) ? 1.f : 0.f;
 }
 // one wave per pixel: 7 masked channel dot products, 7->1 mix, modulate
+// gate 0: y = x * response (NET:562); gate 1: y = x * sigmoid(response) (network_cycle_response.py:568-570).  resp keeps the raw response.
 __global__ __launch_bounds__(256) void dynfilter_fwd_kernel(const void* x, const float* __restrict__ filt, const float* __restrict__ r, void* y,
-                                                           float* resp, float* respk, int H, int W, int C, int dt) {
+                                                           float* resp, float* respk, int H, int W, int C, int dt, int gate) {
   const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (pix >= H * W) return;
   float d[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -196,15 +198,20 @@ __global__ __launch_bounds__(256) void dynfilter_fwd_kernel(const void* x, const
   for (int k = 0; k < 7; ++k) { d[k] = wave_sum(d[k]) * m[k]; rs = fmaf(r[k], d[k], rs); }
   if (lane < 7) respk[(long)pix * 7 + lane] = d[lane];
   if (lane == 0) resp[pix] = rs;
-  for (int c = lane; c < C; c += 64) stx(y, (long)pix * C + c, dt, ldx(x, (long)pix * C + c, dt) * rs);
+  const float mult = gate ? sigm(rs) : rs;
+  for (int c = lane; c < C; c += 64) stx(y, (long)pix * C + c, dt, ldx(x, (long)pix * C + c, dt) * mult);
 }
 // pass 1: dresp[p] = sum_c dy[p][c] x[p][c]; dr[k] += sum_p dresp[p]*respk[p][k]
-__global__ __launch_bounds__(256) void dynfilter_bwd1_kernel(const void* dy, const void* x, const float* respk, float* dresp, float* dr, int HW, int C, int dt) {
+// (sigmoid gate: times sigma'(response); dresp_extra = gradient of the response BCE loss w.r.t. the raw response)
+__global__ __launch_bounds__(256) void dynfilter_bwd1_kernel(const void* dy, const void* x, const float* respk, float* dresp, float* dr, int HW, int C, int dt,
+                                                            int gate, const float* resp, const float* dresp_extra) {
   const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (pix >= HW) return;
   float s = 0.f;
   for (int c = lane; c < C; c += 64) s = fmaf(ldx(dy, (long)pix * C + c, dt), ldx(x, (long)pix * C + c, dt), s);
   s = wave_sum(s);
+  if (gate) { const float sg = sigm(resp[pix]); s *= sg * (1.f - sg); }
+  if (dresp_extra) s += dresp_extra[pix];
   if (lane == 0) dresp[pix] = s;
   if (lane < 7) atomicAdd(dr + lane, s * respk[(long)pix * 7 + lane]);
 }
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void dynfilter_bwd1_kernel(const void* dy, con
 // block = 64 channels x 4 pixel lanes, grid.y over pixel chunks
 __global__ __launch_bounds__(256) void dynfilter_bwd2_kernel(const void* dy, const void* x, const float* __restrict__ filt, const float* __restrict__ r,
                                                             const float* __restrict__ resp, const float* __restrict__ dresp, void* dx, const void* ref,
-                                                            float* dfilt, int H, int W, int C, int dt, int pchunk) {
+                                                            float* dfilt, int H, int W, int C, int dt, int pchunk, int gate) {
   __shared__ float red[4][7][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
   const int p0 = blockIdx.y * pchunk, p1 = min(H * W, p0 + pchunk);
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void dynfilter_bwd2_kernel(const void* dy, con
     float m[7]; spatial_mask7(p / W, p % W, H, W, m);
     const float dr_ = dresp[p];
     const float xv = ldx(x, (long)p * C + c, dt);
-    float g = ldx(dy, (long)p * C + c, dt) * resp[p];
+    float g = ldx(dy, (long)p * C + c, dt) * (gate ? sigm(resp[p]) : resp[p]);
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) { t = fmaf(m[k], fk[k], t); acc[k] = fmaf(dr_ * m[k], xv, acc[k]); }
@@ -577,16 +584,17 @@ extern "C" int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const floa
   return l2s_check_launch();
 }
 extern "C" int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,
-                                 int dtype, hipStream_t s) {
-  L2S_LAUNCH(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype);
+                                 int dtype, int gate, hipStream_t s) {
+  L2S_LAUNCH(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype, gate);
   return l2s_check_launch();
 }
 extern "C" int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
-                                 void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype, hipStream_t s) {
-  L2S_LAUNCH(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype);
+                                 void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype,
+                                 int gate, const float* dresp_extra, hipStream_t s) {
+  L2S_LAUNCH(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype, gate, resp, dresp_extra);
   const int pchunk = 64;
   L2S_LAUNCH(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), cdiv(H * W, pchunk)), dim3(256), 0, s, dy, x, filt, r, resp, dresp_ws, dx, relu_ref,
-                     dfilt, H, W, C, dtype, pchunk);
+                     dfilt, H, W, C, dtype, pchunk, gate);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,

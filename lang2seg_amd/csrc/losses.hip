@@ -120,7 +120,33 @@ __global__ __launch_bounds__(256) void mask_loss_kernel(const float* score, int 
 
 __global__ void total_loss_kernel(float* loss, float cap_w) {
   loss[L2S_LOSS_TOTAL] = loss[L2S_LOSS_CLS] + loss[L2S_LOSS_BOX] + loss[L2S_LOSS_RPN_CLS] + loss[L2S_LOSS_RPN_BOX] +
-                         loss[L2S_LOSS_MASK] + cap_w * loss[L2S_LOSS_CAP];
+                         loss[L2S_LOSS_MASK] + loss[L2S_LOSS_RESPONSE] + cap_w * loss[L2S_LOSS_CAP];
+}
+
+// response loss (network_cycle_response.py:415-423): BCE-with-logits between the raw response map [H][W] and the GT mask
+// resized to it by scipy.misc.imresize(..., interp='nearest') = PIL NEAREST: source index (int)xo with xo = 0.5 s, += s in
+// float64 (sequential adds, as in the mask targets of proposal_target_layer.py:196)
+__device__ __forceinline__ int pil_nearest_index(int n_in, int n_out, int k) {
+  const double s = (double)n_in / (double)n_out;
+  double xo = 0.5 * s;
+  for (int i = 0; i < k; ++i) xo += s;
+  return min((int)xo, n_in - 1);
+}
+__global__ __launch_bounds__(256) void response_loss_kernel(const float* resp, const uint8_t* mask, int MH, int MW, int H, int W, float gscale,
+                                                           float* loss, float* dresp) {
+  __shared__ float red[4];
+  const int n = H * W;
+  const float inv = 1.f / (float)n;
+  float l = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const float t = (float)mask[(long)pil_nearest_index(MH, H, y) * MW + pil_nearest_index(MW, W, x)];
+    const float v = resp[p];
+    l += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+    dresp[p] = (1.f / (1.f + expf(-v)) - t) * inv * gscale;
+  }
+  l = block_sum(l, red);
+  if (threadIdx.x == 0) atomicAdd(loss + L2S_LOSS_RESPONSE, l * inv);
 }
 
 // block per roi: dx[p][c] = dscore[p] * W[label][c] (ReLU-masked by x); dW[label][c] += sum_p dscore[p] x[p][c]
@@ -173,6 +199,11 @@ extern "C" int l2s_rcnn_loss(const float* heads, int ldh, const int* labels, con
 extern "C" int l2s_mask_loss(const float* score, int ldsc, const int* labels, const float* mask_targets, const int* num_fg, int fg_max,
                              int ms2, float gscale, float* loss, float* dscore, hipStream_t s) {
   L2S_LAUNCH(mask_loss_kernel, dim3(cdiv(fg_max * ms2, 256)), dim3(256), 0, s, score, ldsc, labels, mask_targets, num_fg, fg_max, ms2, gscale, loss, dscore);
+  return l2s_check_launch();
+}
+extern "C" int l2s_response_loss(const float* resp, const uint8_t* gt_mask, int mask_h, int mask_w, int H, int W, float gscale, float* loss,
+                                 float* dresp, hipStream_t s) {
+  L2S_LAUNCH(response_loss_kernel, dim3(cdiv(H * W, 256)), dim3(256), 0, s, resp, gt_mask, mask_h, mask_w, H, W, gscale, loss, dresp);
   return l2s_check_launch();
 }
 extern "C" int l2s_total_loss(float* loss, float cap_w, hipStream_t s) {

@@ -394,7 +394,15 @@ class Network(object):
     def train_step(self, blobs, idx, train_op):
         loss = self.train_step_async(blobs, idx, train_op)
         vals = loss.cpu().numpy()          # the single host sync of the step (the reference does seven, NET:704-710)
-        return tuple(float(vals[i]) for i in (0, 1, 2, 3, 4, 5, 6))
+        return tuple(float(vals[i]) for i in self._loss_slots())
+
+    def _loss_slots(self):
+        from .variants import loss_names, SLOT
+        return [SLOT[k] for k in loss_names(getattr(self, 'variant', 'cycle'))]
+
+    def _loss_names(self):
+        from .variants import loss_names
+        return loss_names(getattr(self, 'variant', 'cycle'))
 
     def train_step_async(self, blobs, idx, train_op):
         """same as train_step without the loss read-back; returns the device loss[8] buffer."""
@@ -413,8 +421,7 @@ class Network(object):
 
     def train_step_with_summary(self, blobs, idx, train_op):
         r = self.train_step(blobs, idx, train_op)
-        names = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_caption', 'total_loss']
-        return r + ([(n, v) for n, v in zip(names, r)],)
+        return r + ([(n, v) for n, v in zip(self._loss_names(), r)],)
 
     def get_summary(self, blobs, idx):
         was = self.training
@@ -422,5 +429,4 @@ class Network(object):
         dev = self.upload_blob(blobs, idx)
         loss = self.forward_backward(dev, backward=False).cpu().numpy()
         self.train(was)
-        names = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_caption', 'total_loss']
-        return [(n, float(loss[i])) for i, n in enumerate(names)]
+        return [(n, float(loss[i])) for n, i in zip(self._loss_names(), self._loss_slots())]

@@ -37,8 +37,10 @@ def from_internal(name, t, ref_shape):
 
 
 class ParamStore(object):
-    def __init__(self, opt, num_layers, num_classes, num_anchors, fixed_blocks, device, dt):
+    def __init__(self, opt, num_layers, num_classes, num_anchors, fixed_blocks, device, dt, variant='cycle'):
+        from .variants import VARIANTS
         self.opt, self.device, self.dt = opt, device, dt
+        self.variant, self.var = variant, VARIANTS[variant]
         self.num_classes, self.A = num_classes, num_anchors
         self.nblocks = RESNET_LAYERS[num_layers]
         self.fixed_blocks = fixed_blocks
@@ -56,16 +58,17 @@ class ParamStore(object):
             s['rnn_encoder.rnn.weight_hh_l0' + sfx] = (4 * Hh, Hh)
             s['rnn_encoder.rnn.bias_ih_l0' + sfx] = (4 * Hh,)
             s['rnn_encoder.rnn.bias_hh_l0' + sfx] = (4 * Hh,)
-        R, IE, AH = o['rnn_size'], o['input_encoding_size'], o['att_hid_size']
-        s['caption_model.embed.0.weight'] = (V + 1, IE)
-        s['caption_model.att_embed.0.weight'] = (R, o['att_feat_size']); s['caption_model.att_embed.0.bias'] = (R,)
-        s['caption_model.logit.weight'] = (V + 1, R); s['caption_model.logit.bias'] = (V + 1,)
-        s['caption_model.ctx2att.weight'] = (AH, R); s['caption_model.ctx2att.bias'] = (AH,)
-        s['caption_model.core.a2c.weight'] = (2 * R, R); s['caption_model.core.a2c.bias'] = (2 * R,)
-        s['caption_model.core.i2h.weight'] = (5 * R, IE); s['caption_model.core.i2h.bias'] = (5 * R,)
-        s['caption_model.core.h2h.weight'] = (5 * R, R); s['caption_model.core.h2h.bias'] = (5 * R,)
-        s['caption_model.core.attention.h2att.weight'] = (AH, R); s['caption_model.core.attention.h2att.bias'] = (AH,)
-        s['caption_model.core.attention.alpha_net.weight'] = (1, AH); s['caption_model.core.attention.alpha_net.bias'] = (1,)
+        if self.var['cap'] is not None:
+            R, IE, AH = o['rnn_size'], o['input_encoding_size'], o['att_hid_size']
+            s['caption_model.embed.0.weight'] = (V + 1, IE)
+            s['caption_model.att_embed.0.weight'] = (R, o['att_feat_size']); s['caption_model.att_embed.0.bias'] = (R,)
+            s['caption_model.logit.weight'] = (V + 1, R); s['caption_model.logit.bias'] = (V + 1,)
+            s['caption_model.ctx2att.weight'] = (AH, R); s['caption_model.ctx2att.bias'] = (AH,)
+            s['caption_model.core.a2c.weight'] = (2 * R, R); s['caption_model.core.a2c.bias'] = (2 * R,)
+            s['caption_model.core.i2h.weight'] = (5 * R, IE); s['caption_model.core.i2h.bias'] = (5 * R,)
+            s['caption_model.core.h2h.weight'] = (5 * R, R); s['caption_model.core.h2h.bias'] = (5 * R,)
+            s['caption_model.core.attention.h2att.weight'] = (AH, R); s['caption_model.core.attention.h2att.bias'] = (AH,)
+            s['caption_model.core.attention.alpha_net.weight'] = (1, AH); s['caption_model.core.attention.alpha_net.bias'] = (1,)
 
         def bn(p, c):
             for k in ['weight', 'bias', 'running_mean', 'running_var']:
@@ -83,9 +86,12 @@ class ParamStore(object):
                 inpl = planes * 4
         s['resnet.fc.weight'] = (1000, 2048); s['resnet.fc.bias'] = (1000,)     # present in the module, never used (RES:133)
         C4 = o['C4_feat_dim']; HD = o['rnn_num_layers'] * (2 if o['bidirectional'] else 1) * Hh
-        for k in range(7):
-            s['dynamic_fc_%d.weight' % k] = (C4, HD); s['dynamic_fc_%d.bias' % k] = (C4,)
-        s['response_fc.weight'] = (7, HD); s['response_fc.bias'] = (7,)
+        if self.var['nfilt'] == 1:
+            s['dynamic_fc.weight'] = (C4, HD); s['dynamic_fc.bias'] = (C4,)
+        else:
+            for k in range(7):
+                s['dynamic_fc_%d.weight' % k] = (C4, HD); s['dynamic_fc_%d.bias' % k] = (C4,)
+            s['response_fc.weight'] = (7, HD); s['response_fc.bias'] = (7,)
         A, nc = self.A, self.num_classes
         s['rpn_net.weight'] = (512, C4, 3, 3); s['rpn_net.bias'] = (512,)
         s['rpn_cls_score_net.weight'] = (2 * A, 512, 1, 1); s['rpn_cls_score_net.bias'] = (2 * A,)
@@ -136,8 +142,8 @@ class ParamStore(object):
             'rcnn_w': ['cls_score_net.weight', 'bbox_pred_net.weight'], 'rcnn_b': ['cls_score_net.bias', 'bbox_pred_net.bias'],
             'rpn_head_w': ['rpn_cls_score_net.weight', 'rpn_bbox_pred_net.weight'],
             'rpn_head_b': ['rpn_cls_score_net.bias', 'rpn_bbox_pred_net.bias'],
-            'dyn_w': ['dynamic_fc_%d.weight' % k for k in range(7)] + ['response_fc.weight'],
-            'dyn_b': ['dynamic_fc_%d.bias' % k for k in range(7)] + ['response_fc.bias'],
+            'dyn_w': ['dynamic_fc.weight'] if self.var['nfilt'] == 1 else ['dynamic_fc_%d.weight' % k for k in range(7)] + ['response_fc.weight'],
+            'dyn_b': ['dynamic_fc.bias'] if self.var['nfilt'] == 1 else ['dynamic_fc_%d.bias' % k for k in range(7)] + ['response_fc.bias'],
         }
         plan = ['@rcnn_w', '@rcnn_b', 'mask_up_sampling.weight', 'mask_up_sampling.bias', 'mask_pred_net.weight', 'mask_pred_net.bias',
                 'rpn_net.weight', 'rpn_net.bias', '@rpn_head_w', '@rpn_head_b', '@dyn_w', '@dyn_b']

@@ -19,13 +19,20 @@ f32 = torch.float32
 
 
 class resnetv1(Network):
-    def __init__(self, opt, batch_size=1, num_layers=50):
+    variant = 'cycle'        # nets/variants.py; the sibling modules resnet_v1_{baseline,7f,7f_response,cycle_response}.py subclass this
+
+    def __init__(self, opt, batch_size=1, num_layers=50, variant=None):
         Network.__init__(self, batch_size=batch_size)
+        from .variants import VARIANTS
+        if variant is not None:
+            self.variant = variant
+        self.var = VARIANTS[self.variant]
         self._num_layers = num_layers
         self.opt = dict(opt)
         assert self.opt.get('rnn_type', 'lstm') == 'lstm' and self.opt.get('rnn_num_layers', 1) == 1 and self.opt.get('bidirectional', 1) > 0
-        assert self.opt.get('caption_model', 'att2in2') == 'att2in2', 'only the att2in2 captioner is on the hot path'
-        self._cap_loss_weight = float(self.opt['cap_loss_weight'])          # RES:253
+        if self.var['cap'] is not None:
+            assert self.opt.get('caption_model', 'att2in2') == 'att2in2', 'only the att2in2 captioner is on the hot path'
+        self._cap_loss_weight = float(self.opt.get('cap_loss_weight', 0.0)) if self.var['cap'] is not None else 0.0   # RES:253
         self._C4_feat_dim = self.opt['C4_feat_dim']
 
     # ------------------------------------------------------------------ RES:275-337
@@ -33,7 +40,7 @@ class resnetv1(Network):
         assert self._num_layers in (50, 101, 152)
         assert 0 <= cfg.RESNET.FIXED_BLOCKS < 4
         fb = cfg.RESNET.FIXED_BLOCKS
-        self.P = ParamStore(self.opt, self._num_layers, self._num_classes, self._num_anchors, fb, self.device, self.dt)
+        self.P = ParamStore(self.opt, self._num_layers, self._num_classes, self._num_anchors, fb, self.device, self.dt, self.variant)
         P = self.P
         nb = P.nblocks
         self.layers = {}
@@ -51,8 +58,11 @@ class resnetv1(Network):
         self.rpn_heads = ConvOp(self, None, 512, 6 * A, group=('rpn_head_w', 'rpn_head_b'), Cout_pad=P.rpn_npad)
         self.rcnn_heads = ConvOp(self, None, 2048, 5 * nc, group=('rcnn_w', 'rcnn_b'), Cout_pad=P.rcnn_npad)
         self.mask_pred = ConvOp(self, 'mask_pred_net.weight', 256, nc, bias_key='mask_pred_net.bias', need_dgrad=False)
-        self.att_embed = ConvOp(self, 'caption_model.att_embed.0.weight', self.opt['att_feat_size'], self.opt['rnn_size'],
-                                bias_key='caption_model.att_embed.0.bias')
+        if self.var['cap'] is not None:
+            self.att_embed = ConvOp(self, 'caption_model.att_embed.0.weight', self.opt['att_feat_size'], self.opt['rnn_size'],
+                                    bias_key='caption_model.att_embed.0.bias')
+        # number of dynamic-FC outputs: 7 filters + 7 mixing weights, or the single filter of the baseline network
+        self._NFP = 7 * C4 + 7 if self.var['nfilt'] == 7 else C4
         self.up_wT = O.empty((4 * 256 * 2048,), self.dt)     # ConvTranspose forward operand [(dy,dx,co)][ci]
         self.base_anchors = torch.from_numpy(ANC.base_anchors(self._anchor_scales, self._anchor_ratios)).to(self.device)
         self.init_weights()
@@ -102,10 +112,11 @@ class resnetv1(Network):
         for sfx in ['', '_reverse']:
             for w in ['rnn_encoder.rnn.weight_hh_l0', 'rnn_encoder.rnn.weight_ih_l0']:
                 add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
-        for k in ['rnn_encoder.mlp.0.weight', 'caption_model.logit.weight', 'caption_model.core.a2c.weight', 'caption_model.core.h2h.weight',
-                  'caption_model.core.attention.h2att.weight', 'caption_model.core.i2h.weight', 'caption_model.ctx2att.weight']:
+        capk = ['caption_model.logit.weight', 'caption_model.core.a2c.weight', 'caption_model.core.h2h.weight',
+                'caption_model.core.attention.h2att.weight', 'caption_model.core.i2h.weight', 'caption_model.ctx2att.weight']
+        for k in ['rnn_encoder.mlp.0.weight'] + (capk if self.var['cap'] is not None else []):
             add(k, P.view(k), *P.shapes[k])
-        NF, HD = 7 * self._C4_feat_dim + 7, P.shapes['response_fc.weight'][1]
+        NF, HD = self._NFP, P.shapes['rnn_encoder.rnn.weight_hh_l0'][1] * 2
         add('dyn_w', P.gview('dyn_w', NF * HD), NF, HD)
         # 2x2 deconv: its forward operand [(dy,dx,co)][ci] is the transpose of the master [ci][(dy,dx,co)] (activation dtype)
         add('mask_up', P.view('mask_up_sampling.weight'), 2048, 4 * 256, dst=self.up_wT, f32=0)
@@ -320,9 +331,15 @@ class resnetv1(Network):
         with on('lang'):
             hidden = self._encoder_fwd(d)
             HD = hidden.numel()
-            NF = 7 * C4 + 7
-            filt = self.buf('dyn.filt', (NF,), f32)
-            O.linear_fwd(hidden, P.gview('dyn_w', NF * HD), P.gview('dyn_b', NF), filt, 1, NF, HD, act=2)
+            NF = 7 * C4 + 7                      # layout the correlation kernels read: 7 filters [C4] + 7 mixing weights
+            NFP = self._NFP
+            filt = self.buf('dyn.filt', (NF,), f32, zero=(NFP != NF))
+            O.linear_fwd(hidden, P.gview('dyn_w', NFP * HD), P.gview('dyn_b', NFP), filt, 1, NFP, HD, act=2)
+            if NFP != NF:
+                # baseline network (network.py:475-479): one filter, response = its correlation -> mixing weights (1,0,..,0)
+                if not hasattr(self, '_r_one'):
+                    self._r_one = torch.tensor([1.0, 0, 0, 0, 0, 0, 0], dtype=f32, device=self.device)
+                O.memcpy(filt[7 * C4:], self._r_one)
         self._mark('encoder_fwd(lang)')
         # ---- head: conv1/bn1/relu/maxpool/layer1-3 (RES:261-265,309-310) ----
         OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
@@ -347,40 +364,69 @@ class resnetv1(Network):
         if S is not None:
             self.sfork(S['lang'], main)
         net_conv = self.buf('dyn.y', (HW, C4)); resp = self.buf('dyn.resp', (HW,), f32); respk = self.buf('dyn.respk', (HW, 7), f32)
-        O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4)
+        gate = 1 if self.var['gate'] == 'sigmoid' else 0
+        O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4, gate=gate)
         t['net_conv'], t['response'] = net_conv, resp
+        dresp_extra = None
+        if gate:
+            # response loss (network_cycle_response.py:415-423) and its gradient w.r.t. the raw response
+            dresp_extra = self.buf('dyn.dresp_loss', (HW,), f32)
+            O.response_loss(resp, d['gt_masks'], H, W, Hc, Wc, 1.0, loss, dresp_extra)
         # ---- caption-cycle branch (NET:415-439), forward AND backward, forked onto the caption stream: it needs only net_conv
         # and rejoins at d(net_conv); layer4's weight gradients from both branches accumulate atomically.
         AF = self.opt['att_feat_size']
 
+        def l4_on_map(xin, tag):
+            x, hh, ww = xin, Hc, Wc
+            for b, blk in enumerate(self.layers[4]):
+                x, hh, ww, sv = blk.fwd(x, 1, hh, ww, '%s.%d' % (tag, b))
+                saved[(tag, b)] = sv
+            return x
+
+        def l4_on_map_bwd(g, tag, in_relu=False):
+            # in_relu: the map that was fed in is itself a ReLU output (layer3's), so its gradient is masked here
+            for b in reversed(range(len(self.layers[4]))):
+                g = self.layers[4][b].bwd(g, saved[(tag, b)], '%s.%d' % (tag, b), x_is_relu_out=(b > 0 or in_relu))
+            return g
+
         def caption_branch():
+            """returns (d net_conv, d base or None) contributed by the caption loss"""
             import os
             if 'cap' in os.environ.get('L2S_SKIP', ''):
-                return self.buf('l4m.skip', (HW, C4))
-            x, hh, ww = net_conv, Hc, Wc
-            for b, blk in enumerate(self.layers[4]):
-                x, hh, ww, sv = blk.fwd(x, 1, hh, ww, 'l4m.%d' % b)
-                saved[('4m', b)] = sv
-            feats = x
-            gm = self.buf('cap.gm', (HW,), f32)
-            O.mask_downsample(d['gt_masks'], gm, H, W, Hc, Wc)
+                return self.buf('l4m.skip', (HW, C4)), None
+            feats = l4_on_map(net_conv, 'l4m')
             att = self.buf('cap.att', (196, AF))
-            O.adaptive_pool_fwd(feats, None, att, Hc, Wc, 2048, 14, 14, AF)
-            O.adaptive_pool_fwd(feats, gm, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
-            t.update({'feats_all': feats, 'att_feats': att, 'gt_mask_small': gm})
+            if self.var['cap'] == 'mask':
+                gm = self.buf('cap.gm', (HW,), f32)
+                O.mask_downsample(d['gt_masks'], gm, H, W, Hc, Wc)
+                O.adaptive_pool_fwd(feats, None, att, Hc, Wc, 2048, 14, 14, AF)
+                O.adaptive_pool_fwd(feats, gm, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
+                t.update({'feats_all': feats, 'att_feats': att, 'gt_mask_small': gm})
+            else:
+                # cycle_response: [layer4(map before the gating) ; layer4(gated map)] (network_cycle_response.py:425-439)
+                feats_b = l4_on_map(base, 'l4b')
+                O.adaptive_pool_fwd(feats_b, None, att, Hc, Wc, 2048, 14, 14, AF)
+                O.adaptive_pool_fwd(feats, None, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
+                t.update({'feats_all': feats, 'feats_before_all': feats_b, 'att_feats': att})
             self._caption_fwd(d, att, loss)
             if not backward:
-                return None
+                return None, None
             datt = self._caption_bwd(d, att)
             g = self.buf('l4m.g', (HW, 2048))
-            O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
-            for b in reversed(range(len(self.layers[4]))):
-                g = self.layers[4][b].bwd(g, saved[('4m', b)], 'l4m.%d' % b, x_is_relu_out=(b > 0))
-            return g
-        if S is not None:
-            self.sfork(main, S['cap'])
-        with on('cap'):
-            d_nc_cap = caption_branch()
+            if self.var['cap'] == 'mask':
+                O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
+                return l4_on_map_bwd(g, 'l4m'), None
+            gb = self.buf('l4b.g', (HW, 2048))
+            O.adaptive_pool_bwd(datt, AF, 0, 0, None, gb, feats_b, Hc, Wc, 2048, 14, 14)
+            O.adaptive_pool_bwd(datt, AF, 2048, 0, None, g, feats, Hc, Wc, 2048, 14, 14)
+            d_base_cap = l4_on_map_bwd(gb, 'l4b', in_relu=True)
+            return l4_on_map_bwd(g, 'l4m'), d_base_cap
+        d_nc_cap = d_base_cap = None
+        if self.var['cap'] is not None:
+            if S is not None:
+                self.sfork(main, S['cap'])
+            with on('cap'):
+                d_nc_cap, d_base_cap = caption_branch()
         self._mark('dyn + caption branch (cap)')
         # ---- RPN (NET:235-275) ----
         rpn = self.buf('rpn.a', (HW, 512))
@@ -462,7 +508,7 @@ class resnetv1(Network):
         # =================================== backward (detection side, main stream) ===================================
         dp = self.dp
         if not backward:
-            if S is not None:
+            if S is not None and self.var['cap'] is not None:
                 self.sfork(S['cap'], main)
             O.total_loss(loss, self._cap_loss_weight)
             t['loss'] = loss
@@ -499,25 +545,31 @@ class resnetv1(Network):
         self.rpn_conv.wgrad(drpn, net_conv, 1, Hc, Wc)
         d_nc_rpn = self.buf('rpn.dnc', (HW, C4))
         self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
-        if S is not None:
+        if S is not None and self.var['cap'] is not None:
             self.sfork(S['cap'], main)                     # join the caption branch
         O.total_loss(loss, self._cap_loss_weight)
         t['loss'] = loss
         if dp is not None:
             dp.ready('heads')                              # caption + layer4 + RoI/mask heads are final here
         d_nc = self.buf('dyn.dy', (HW, C4))
-        O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)
+        if d_nc_cap is not None:
+            O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)
+        else:
+            O.add3(d_nc_rpn, None, d_nc_roi, d_nc)        # (dtype, -, fp32) operands
         self._mark('rpn bwd + add3')
         # dynamic filters (NET:504-562)
         dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (HW,), f32)
-        O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4)
+        O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4,
+                        gate=gate, dresp_extra=dresp_extra)
+        if d_base_cap is not None:
+            O.add3(dbase, d_base_cap, None, dbase)         # cycle_response: layer4 also ran on the map before the gating
         # language-side backward (dynamic FCs, bi-LSTM, embedding: ~170 small dependent launches) forked onto the language
         # stream; the backbone backward below does not depend on it.  Joined by the optimiser (join_side()).
         if S is not None:
             self.sfork(main, S['lang'])
         with on('lang'):
             O.act_bwd(dfilt, filt, 2)
-            O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NF * HD, P.grad), P.gview('dyn_b', NF, P.grad), 1, NF, HD)
+            O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NFP * HD, P.grad), P.gview('dyn_b', NFP, P.grad), 1, NFP, HD)
             dhidden = self.buf('enc.dhidden', (HD,), f32)
             self.bwd_x(dfilt, 'dyn_w', dhidden, 1)
             self._encoder_bwd(d, dhidden)

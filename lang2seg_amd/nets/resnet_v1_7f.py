@@ -1,0 +1,7 @@
+"""resnetv1 of the reference's nets/resnet_v1_7f.py + nets/network_7f.py (train_spatial.sh): 7 spatial dynamic filters, 6 losses.
+Same constructor / create_architecture / train_step as every variant; see nets/variants.py and nets/resnet_v1.py."""
+from .resnet_v1 import resnetv1 as _Base
+
+
+class resnetv1(_Base):
+    variant = 'spatial'

@@ -1,0 +1,7 @@
+"""resnetv1 of the reference's nets/resnet_v1_cycle_res5_2.py + nets/network_cycle_res5_2.py (train_cycle.sh): caption-cycle loss, 7 losses.
+Same constructor / create_architecture / train_step as every variant; see nets/variants.py and nets/resnet_v1.py."""
+from .resnet_v1 import resnetv1 as _Base
+
+
+class resnetv1(_Base):
+    variant = 'cycle'

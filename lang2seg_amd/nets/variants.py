@@ -1,0 +1,27 @@
+"""The reference's ResNet network variants: one nets/network_*.py + nets/resnet_v1_*.py pair each
+(pyutils/mask-faster-rcnn/lib/nets).  They differ in three places only:
+
+  nfilt : 1 = one dynamic filter `dynamic_fc`                     (network.py:475-479)
+          7 = `dynamic_fc_0..6` on spatial masks + `response_fc`  (network_7f.py:475-534)
+  gate  : 'linear'  net_conv * response                           (NET:562)
+          'sigmoid' net_conv * sigmoid(response) + response BCE   (network_7f_response.py:411-419,543-545;
+                                                                    network_cycle_response.py:415-423,568-570)
+  cap   : None | 'mask' (layer4 on the map, all + GT-masked pools, NET:415-440)
+               | 'before_after' (layer4 on the map before and after the gating, network_cycle_response.py:425-439)
+"""
+VARIANTS = {
+    'baseline': dict(nfilt=1, gate='linear', cap=None),            # nets/resnet_v1.py            train_baseline.sh
+    'spatial': dict(nfilt=7, gate='linear', cap=None),             # nets/resnet_v1_7f.py         train_spatial.sh
+    'response': dict(nfilt=7, gate='sigmoid', cap=None),           # nets/resnet_v1_7f_response.py train_response.sh
+    'cycle': dict(nfilt=7, gate='linear', cap='mask'),             # nets/resnet_v1_cycle_res5_2.py train_cycle.sh
+    'cycle_response': dict(nfilt=7, gate='sigmoid', cap='before_after'),   # nets/resnet_v1_cycle_response.py train_cycle_response.sh
+}
+_ALL = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_response', 'loss_caption', 'total_loss']
+# slot of each loss in the device loss[8] buffer (include/lang2seg_hip.h L2S_LOSS_*)
+SLOT = dict(rpn_cross_entropy=0, rpn_loss_box=1, cross_entropy=2, loss_box=3, loss_mask=4, loss_caption=5, total_loss=6, loss_response=7)
+
+
+def loss_names(variant):
+    """order of the floats `train_step` returns in that variant (NET:702-719 and its siblings)."""
+    v = VARIANTS[variant]
+    return [k for k in _ALL if not (k == 'loss_response' and v['gate'] != 'sigmoid') and not (k == 'loss_caption' and v['cap'] is None)]

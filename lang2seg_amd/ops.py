@@ -294,13 +294,17 @@ def lstm_cell_bwd(dh, dc_in, act, c_prev, c, dgates, dc_prev, Hh):
     call('l2s_lstm_cell_bwd', ptr(dh), ptr(dc_in), ptr(act), ptr(c_prev), ptr(c), ptr(dgates), ptr(dc_prev), Hh, stream())
 
 
-def dynfilter_fwd(x, filt, r, y, resp, respk, H, W, Cc):
-    call('l2s_dynfilter_fwd', ptr(x), ptr(filt), ptr(r), ptr(y), ptr(resp), ptr(respk), H, W, Cc, dt_of(x), stream())
+def dynfilter_fwd(x, filt, r, y, resp, respk, H, W, Cc, gate=0):
+    call('l2s_dynfilter_fwd', ptr(x), ptr(filt), ptr(r), ptr(y), ptr(resp), ptr(respk), H, W, Cc, dt_of(x), int(gate), stream())
 
 
-def dynfilter_bwd(dy, x, filt, r, resp, respk, dx, ref, dfilt, dr, dresp_ws, H, W, Cc):
+def dynfilter_bwd(dy, x, filt, r, resp, respk, dx, ref, dfilt, dr, dresp_ws, H, W, Cc, gate=0, dresp_extra=None):
     call('l2s_dynfilter_bwd', ptr(dy), ptr(x), ptr(filt), ptr(r), ptr(resp), ptr(respk), ptr(dx), ptr(ref), ptr(dfilt),
-         ptr(dr), ptr(dresp_ws), H, W, Cc, dt_of(x), stream())
+         ptr(dr), ptr(dresp_ws), H, W, Cc, dt_of(x), int(gate), ptr(dresp_extra), stream())
+
+
+def response_loss(resp, gt_mask_u8, mask_h, mask_w, H, W, gscale, loss, dresp):
+    call('l2s_response_loss', ptr(resp), ptr(gt_mask_u8), mask_h, mask_w, H, W, float(gscale), ptr(loss), ptr(dresp), stream())
 
 
 def cap_attention_fwd(patt, att, att_h, aw, ab, L, D, tanh_ws, weight, att_res):

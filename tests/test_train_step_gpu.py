@@ -7,27 +7,31 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-from golden_util import load, check_digest, setup_from_fixture
+from golden_util import load, check_digest, setup_from_fixture, variant_of
 
 NAMES = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_caption', 'total_loss']
 
 
-def _setup(dtype):
+def _setup(dtype, tag='tiny'):
     from lang2seg_amd import selftest
-    g = load('tiny')
+    g = load(tag)
     opt, sd, blob, ocfg, samp = setup_from_fixture(g)
     samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
     over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
-    net = selftest.build_net(opt, over, dtype, sd)
+    net = selftest.build_net(opt, over, dtype, sd, variant=variant_of(g))
     net.parity = selftest.parity_from_samp(samp)
     return g, opt, sd, blob, ocfg, samp, net
 
 
-def test_train_step_f32_vs_fixture_and_oracle():
+@pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response'])
+def test_train_step_f32_vs_fixture_and_oracle(tag):
+    """every ResNet network variant of the reference (cycle = the benchmarked one; baseline / spatial / response /
+    cycle_response are BASELINE.json configs 0, 1, 3 + train_response.sh) against a fixture produced by the reference itself."""
     from oracle import net as ON
     from lang2seg_amd.optim import SGD
     from lang2seg_amd.nets.params import from_internal
-    g, opt, sd, blob, ocfg, samp, net = _setup('f32')
+    from lang2seg_amd.nets.variants import loss_names, SLOT
+    g, opt, sd, blob, ocfg, samp, net = _setup('f32', tag)
     dev = net.upload_blob(blob, 0)
     loss = net.forward_backward(dev)
     torch.cuda.synchronize()
@@ -38,18 +42,22 @@ def test_train_step_f32_vs_fixture_and_oracle():
     mine = t['proposal_rois'].cpu().numpy()[:n]
     ref = g['int.proposal_rois']
     assert mine.shape == ref.shape
-    key = lambda r: r[np.lexsort(np.round(r[:, ::-1] * 8).T)]
-    assert np.allclose(key(mine), key(ref), atol=5e-3)
+    # set comparison by nearest neighbour (sorting rows is not stable under 1e-4 px perturbations)
+    D = np.abs(mine[:, None, 1:] - ref[None, :, 1:]).max(-1)
+    assert D.min(1).max() < 2e-2 and D.min(0).max() < 2e-2, (D.min(1).max(), D.min(0).max())
     # integer outputs: bit-exact
     assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
     assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
     nfg = int(t['counts'][0].item())
     assert nfg == int(g['int.num_fg'])
     assert np.array_equal(t['mask_targets'].cpu().numpy()[:nfg].reshape(nfg, 14, 14).astype(np.uint8), g['int.mask_targets'])
-    assert np.allclose(t['rois'].cpu().numpy(), g['int.rois'], atol=1e-4)
+    # (column 0 of a GT row appended by PTL:159-167 is uninitialised memory in the reference)
+    assert np.allclose(t['rois'].cpu().numpy()[:, 1:], g['int.rois'][:, 1:], atol=1e-4)
     # losses vs the reference run (fixture) within 1e-4
-    for i, k in enumerate(NAMES):
+    for k in loss_names(variant_of(g)):
+        i = SLOT[k]
         assert abs(lv[i] - float(g['loss.' + k])) < 1e-4 * max(1.0, abs(float(g['loss.' + k]))), (k, lv[i], g['loss.' + k])
+    assert len(net._loss_slots()) == len(loss_names(variant_of(g)))
     Hc, Wc = 20, 26
     nc = t['net_conv'].float().cpu().view(1, Hc, Wc, -1).permute(0, 3, 1, 2)
     check_digest(g, 't.net_conv', nc.numpy())
