@@ -171,13 +171,15 @@ class SolverWrapper(object):
                     lr *= cfg.TRAIN.GAMMA
                     scale_lr(self.optimizer, cfg.TRAIN.GAMMA)
                     next_stepsize = stepsizes.pop()
-                rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, loss_mask, loss_caption, total_loss = \
-                    self.net.train_step(blobs, int(arr[idx]), self.optimizer)
+                vals = self.net.train_step(blobs, int(arr[idx]), self.optimizer)      # 6, 7 or 8 floats depending on the network variant
                 timer.toc()
                 if it % cfg.TRAIN.DISPLAY == 0 and self.rank == 0:
-                    print('iter: %d / %d, total loss: %.6f\n >>> rpn_loss_cls: %.6f\n >>> rpn_loss_box: %.6f\n >>> loss_cls: %.6f\n'
-                          ' >>> loss_box: %.6f\n >>> loss_mask: %.6f\n >>> loss_caption: %.6f\n >>> lr: %f' %
-                          (it, max_iters, total_loss, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, loss_mask, loss_caption, lr))
+                    short = dict(rpn_cross_entropy='rpn_loss_cls', cross_entropy='loss_cls')
+                    names = self.net._loss_names()
+                    print('iter: %d / %d, total loss: %.6f' % (it, max_iters, vals[-1]))
+                    for n, v in zip(names[:-1], vals[:-1]):
+                        print(' >>> %s: %.6f' % (short.get(n, n), v))
+                    print(' >>> lr: %f' % lr)
                     print('speed: {:.3f}s / iter'.format(timer.average_time()))
                 if it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
                     last_snapshot_iter = it

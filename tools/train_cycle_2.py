@@ -1,58 +1,11 @@
 #!/usr/bin/env python
-"""Entry point of `experiments/scripts/train_cycle.sh` (reference: tools/train_cycle_2.py:37-111):
-build loader + resnetv1 (ResNet-101, 7 spatial dynamic filters, att2in2 cycle loss) and call train_net.
-Launch with torchrun for data-parallel training (one process per GPU)."""
-import os
+"""Entry point of `experiments/scripts/train_cycle.sh` (reference: tools/train_cycle_2.py:37-111): the 'cycle' network variant (lang2seg_amd/nets/variants.py)."""
 import os.path as osp
-import random
 import sys
 
-ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, osp.join(ROOT, 'tools'))
-
-import numpy as np
-import torch
-
+sys.path.insert(0, osp.dirname(osp.abspath(__file__)))
 from opt import parse_opt
-
-
-def main(args):
-    from lang2seg_amd.model.config import cfg, cfg_from_file, cfg_from_list
-    from lang2seg_amd.model.train_val import train_net
-    from lang2seg_amd.nets.resnet_v1 import resnetv1
-    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
-    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(local)
-    if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
-    torch.manual_seed(args['seed']); random.seed(args['seed'])
-    T = 20 if args['dataset'] == 'refcocog' else 10
-    V = 3349 if args['dataset'] == 'refcocog' else 1999
-    loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V, rank=rank)
-    opt = dict(args)
-    opt['vocab_size'] = loader.vocab_size
-    opt['C4_feat_dim'] = 1024
-    opt['use_att'] = True
-    opt['seq_length'] = loader.label_length
-    opt['dataset_splitBy'] = args['dataset'] + '_' + args['splitBy']
-    if args['cfg_file'] and osp.exists(osp.join(ROOT, args['cfg_file'])):
-        cfg_from_file(osp.join(ROOT, args['cfg_file']))
-    if args['set_cfgs']:
-        cfg_from_list(args['set_cfgs'])
-    cfg.COMPUTE_DTYPE = args['dtype']
-    net = resnetv1(opt, batch_size=1, num_layers=101)
-    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
-    net.rank_seed = rank * 1000003
-    if world > 1:
-        from lang2seg_amd.parallel import GradReducer
-        net.dp = GradReducer(net, world)
-    output_dir = osp.join(ROOT, opt['dataset_splitBy'], 'output_{}'.format(args['output_postfix']))
-    tb_dir = osp.join(ROOT, opt['dataset_splitBy'], 'tb_{}'.format(args['output_postfix']))
-    pretrained = osp.join(ROOT, 'pyutils/mask-faster-rcnn/output/%s/%s_2014_train_minus_refer_valtest+%s_2014_valminusminival/%s/%s_mask_rcnn_iter_%s.pth' % (
-        args['net_name'], args['imdb_name'], args['imdb_name'], args['tag'], args['net_name'], args['iters']))
-    train_net(net, loader, output_dir, tb_dir, pretrained_model=pretrained, max_iters=args['max_iters'], rank=rank, world=world)
-
+from train_common import main
 
 if __name__ == '__main__':
-    main(parse_opt())
+    main(parse_opt(), variant='cycle')
