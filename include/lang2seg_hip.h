@@ -183,6 +183,13 @@ int l2s_mask_loss(const float* score, int ldsc, const int* labels, const float* 
  * loss[L2S_LOSS_RESPONSE] += mean BCE; dresp[HW] = gscale * d loss / d response */
 int l2s_response_loss(const float* resp, const uint8_t* gt_mask, int mask_h, int mask_w, int H, int W, float gscale, float* loss,
                       float* dresp, hipStream_t s);
+/* TEST mode (NET:277-307, 650-658; test_image NET:684-699): heads [R][ldh] = (cls scores | box deltas) ->
+ * cls_prob [R][ncls] (softmax), bbox_pred [R][4 ncls] de-normalised with TRAIN.BBOX_NORMALIZE_STDS / MEANS (4 floats each) */
+int l2s_rcnn_predict(const float* heads, int ldh, int R, int ncls, const float* stds4, const float* means4, float* cls_prob,
+                     float* bbox_pred, hipStream_t s);
+/* mask probabilities: score [n_elem][ldsc] (n_elem = n_roi * ms2 mask pixels); labels == NULL -> out [n_elem][ncls] = sigmoid(score)
+ * (NET:292-307); labels [n_roi] -> out [n_elem] = sigmoid of the labelled class only (NET:620-624) */
+int l2s_mask_prob(const float* score, int ldsc, int ncls, const int* labels, int ms2, long n_elem, float* out, hipStream_t s);
 int l2s_total_loss(float* loss, float cap_w, hipStream_t s);
 /* mask_pred_net backward (only the label channel carries gradient): dx(dtype)[fg_max*ms2][C] = dscore[p]*W[label][:],
  * dW[label][:] += sum dscore[p]*x[p][:], db[label] += sum dscore[p] */

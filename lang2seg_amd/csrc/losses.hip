@@ -177,6 +177,34 @@ __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, 
   }
 }
 
+
+// ---- TEST-mode heads (NET:277-307, 650-658): class probabilities, de-normalised box deltas, mask probabilities ----
+// one wave per roi
+__global__ __launch_bounds__(256) void rcnn_predict_kernel(const float* heads, int ldh, int R, int ncls, const float* stds, const float* means,
+                                                          float* cls_prob, float* bbox_pred) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* hr = heads + (long)r * ldh;
+  float mx = -INFINITY;
+  for (int c = lane; c < ncls; c += 64) mx = fmaxf(mx, hr[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < ncls; c += 64) se += expf(hr[c] - mx);
+  se = wave_sum(se);
+  for (int c = lane; c < ncls; c += 64) cls_prob[(long)r * ncls + c] = expf(hr[c] - mx) / se;
+  for (int c = lane; c < 4 * ncls; c += 64) bbox_pred[(long)r * 4 * ncls + c] = hr[ncls + c] * stds[c & 3] + means[c & 3];
+}
+// labels == nullptr: out[e][c] = sigmoid(score[e][c]) for every class; else out[e] = sigmoid(score[e][labels[e / ms2]])
+__global__ void mask_prob_kernel(const float* score, int ldsc, int ncls, const int* labels, int ms2, long n_elem, float* out) {
+  const long total = labels ? n_elem : n_elem * ncls;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v;
+    if (labels) v = score[i * ldsc + labels[i / ms2]];
+    else { const long e = i / ncls; v = score[e * ldsc + (i - e * ncls)]; }
+    out[i] = 1.f / (1.f + expf(-v));
+  }
+}
+
 }  // namespace
 
 extern "C" int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
@@ -213,5 +241,16 @@ extern "C" int l2s_total_loss(float* loss, float cap_w, hipStream_t s) {
 extern "C" int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C, const float* w,
                                 const void* x, const void* relu_ref, void* dx, float* dw, float* db, int dtype, hipStream_t s) {
   L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, dw, db, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_rcnn_predict(const float* heads, int ldh, int R, int ncls, const float* stds4, const float* means4, float* cls_prob,
+                                float* bbox_pred, hipStream_t s) {
+  L2S_LAUNCH(rcnn_predict_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, heads, ldh, R, ncls, stds4, means4, cls_prob, bbox_pred);
+  return l2s_check_launch();
+}
+extern "C" int l2s_mask_prob(const float* score, int ldsc, int ncls, const int* labels, int ms2, long n_elem, float* out, hipStream_t s) {
+  const long total = labels ? n_elem : n_elem * ncls;
+  long g = (total + 255) / 256; if (g > 4096) g = 4096;
+  L2S_LAUNCH(mask_prob_kernel, dim3((int)g), dim3(256), 0, s, score, ldsc, ncls, labels, ms2, n_elem, out);
   return l2s_check_launch();
 }

@@ -373,12 +373,15 @@ class Network(object):
             lab = labels[idx:idx + 1]
             max_len = int((lab != 0).sum(1).max())                          # NET:629-630
             lab = np.ascontiguousarray(lab[:, :max_len]).astype(np.int64)
-            cap = np.ascontiguousarray(blobs['cap_labels'][idx:idx + 1]).astype(np.int64)
-            # AttModel.py:75-93: steps i = 0.. until seq[:, i] == 0 for i >= 1
-            S = 1
-            while S < cap.shape[1] - 1 and cap[0, S] != 0:
-                S += 1
-            cm = np.ascontiguousarray(blobs['cap_masks'][idx:idx + 1]).astype(np.float32)
+            if blobs.get('cap_labels') is not None:
+                cap = np.ascontiguousarray(blobs['cap_labels'][idx:idx + 1]).astype(np.int64)
+                # AttModel.py:75-93: steps i = 0.. until seq[:, i] == 0 for i >= 1
+                S = 1
+                while S < cap.shape[1] - 1 and cap[0, S] != 0:
+                    S += 1
+                cm = np.ascontiguousarray(blobs['cap_masks'][idx:idx + 1]).astype(np.float32)
+            else:                                               # TEST mode / variants without a captioner
+                cap = np.zeros((1, 2), np.int64); cm = np.zeros((1, 2), np.float32); S = 1
             cache[key] = dict(
                 gt_boxes=torch.from_numpy(np.ascontiguousarray(blobs['gt_boxes'][idx:idx + 1], dtype=np.float32)).to(dev),
                 gt_masks=torch.from_numpy(np.ascontiguousarray(blobs['gt_masks'][idx:idx + 1], dtype=np.uint8)).to(dev),

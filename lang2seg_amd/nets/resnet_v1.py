@@ -591,6 +591,125 @@ class resnetv1(Network):
             self.sfork(S['lang'], main)
         return loss
 
+
+    # ------------------------------------------------------------------ TEST mode (NET:488-593 mode == 'TEST', 595-626, 650-658)
+    def _backbone_and_filter(self, d):
+        """conv1..layer3, expression encoding, dynamic filters -> (net_conv, base, Hc, Wc); single stream (inference)."""
+        P = self.P
+        C4 = self._C4_feat_dim
+        H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
+        hidden = self._encoder_fwd(d)
+        HD = hidden.numel()
+        NF, NFP = 7 * C4 + 7, self._NFP
+        filt = self.buf('dyn.filt', (NF,), f32, zero=(NFP != NF))
+        O.linear_fwd(hidden, P.gview('dyn_w', NFP * HD), P.gview('dyn_b', NFP), filt, 1, NFP, HD, act=2)
+        if NFP != NF:
+            if not hasattr(self, '_r_one'):
+                self._r_one = torch.tensor([1.0, 0, 0, 0, 0, 0, 0], dtype=f32, device=self.device)
+            O.memcpy(filt[7 * C4:], self._r_one)
+        OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        c1 = self.buf('stem.c1', (OH1 * OW1, 64))
+        O.stem_conv(d['data'], P.frozen['resnet.conv1.weight'], P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'],
+                    c1, H, W, OH1, OW1)
+        h, w = (OH1 + 2 - 3) // 2 + 1, (OW1 + 2 - 3) // 2 + 1
+        x = self.buf('stem.pool', (h * w, 64))
+        O.maxpool(c1, x, OH1, OW1, 64, h, w)
+        for li in (1, 2, 3):
+            for b, blk in enumerate(self.layers[li]):
+                x, h, w, _ = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
+        base, Hc, Wc = x, h, w
+        net_conv = self.buf('dyn.y', (Hc * Wc, C4)); resp = self.buf('dyn.resp', (Hc * Wc,), f32); respk = self.buf('dyn.respk', (Hc * Wc, 7), f32)
+        O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4, gate=1 if self.var['gate'] == 'sigmoid' else 0)
+        return net_conv, base, resp, Hc, Wc
+
+    def _roi_heads_test(self, net_conv, Hc, Wc, rois, n, labels=None):
+        """crop-pool -> layer4 -> (cls scores, cls prob, de-normalised deltas) and mask probabilities for `n` rois [n][5]."""
+        P, dt = self.P, self.dt
+        C4, nc = self._C4_feat_dim, self._num_classes
+        PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
+        pool5 = self.buf('roi.pool5', (n * PS * PS, C4))
+        O.roialign_fwd(net_conv, Hc, Wc, C4, rois, n, PS, 1.0 / 16.0, pool5)
+        x, hh, ww = pool5, PS, PS
+        for b, blk in enumerate(self.layers[4]):
+            x, hh, ww, _ = blk.fwd(x, n, hh, ww, 'l4t.%d' % b)
+        fc7s = x
+        fc7 = self.buf('roi.fc7', (n, 2048))
+        O.avgpool_fwd(fc7s, fc7, n, PS * PS, 2048)
+        NPC = P.rcnn_npad
+        cheads = self.buf('roi.heads', (n, NPC), f32)
+        self.rcnn_heads.fwd(fc7, n, 1, 1, cheads, out_f32=True)
+        cst = self._consts()
+        cls_prob = self.buf('test.cls_prob', (n, nc), f32); bbox_pred = self.buf('test.bbox_pred', (n, 4 * nc), f32)
+        O.rcnn_predict(cheads, NPC, n, nc, cst['stds'], cst['means'], cls_prob, bbox_pred)
+        up = self.buf('mask.up', (n * MS * MS, 256))
+        O.conv_igemm(fc7s, self.up_wT, up, n, PS, PS, 2048, PS, PS, 4 * 256, bias=P.view('mask_up_sampling.bias'), relu=True, deconv=True, dt=dt)
+        mscore = self.buf('mask.score', (n * MS * MS, nc), f32)
+        self.mask_pred.fwd(up, n, MS, MS, mscore, out_f32=True)
+        if labels is None:
+            mprob = self.buf('test.mask_prob', (n * MS * MS, nc), f32)
+            O.mask_prob(mscore, nc, nc, None, MS * MS, n * MS * MS, mprob)
+        else:
+            mprob = self.buf('test.mask_prob_l', (n, MS, MS), f32)
+            O.mask_prob(mscore, nc, nc, labels, MS * MS, n * MS * MS, mprob)
+        return cheads, cls_prob, bbox_pred, mprob
+
+    def forward_test(self, d):
+        """NET:628-662 with mode == 'TEST'.  Fills self._predictions like the reference (device tensors, NHWC / row-major)."""
+        self.join_transposes()
+        self.t = {}
+        A = self._num_anchors
+        im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
+        net_conv, base, resp, Hc, Wc = self._backbone_and_filter(d)
+        HW = Hc * Wc
+        P = self.P
+        rpn = self.buf('rpn.a', (HW, 512))
+        self.rpn_conv.fwd(net_conv, 1, Hc, Wc, rpn, relu=True)
+        NPR = P.rpn_npad
+        rheads = self.buf('rpn.heads', (HW, NPR), f32)
+        self.rpn_heads.fwd(rpn, 1, Hc, Wc, rheads, out_f32=True)
+        nA = HW * A
+        prob = self.buf('rpn.prob', (HW, 2 * A), f32); boxes = self.buf('rpn.boxes', (nA, 4), f32); scores = self.buf('rpn.scores', (nA,), f32)
+        O.rpn_decode(rheads, NPR, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, prob, boxes, scores)
+        pre = int(cfg.TEST.RPN_PRE_NMS_TOP_N); post = int(cfg.TEST.RPN_POST_NMS_TOP_N)
+        pre = nA if pre <= 0 else min(pre, nA)
+        sb = self.buf('tprop.sb', (pre, 4), f32); ss = self.buf('tprop.ss', (pre,), f32); si = self.buf('tprop.si', (pre,), torch.int32)
+        O.sort_topk(scores, boxes, nA, pre, self.buf('prop.sortws', (O.sort_ws_ints(nA),), torch.int32), sb, ss, si)
+        nms_ws = self.buf('tprop.nmsws', (O.nms_workspace_bytes(pre) // 8 + 8,), torch.int64)
+        keep = self.buf('tprop.keep', (post,), torch.int32); nkeep = self.buf('tprop.nkeep', (1,), torch.int32)
+        O.nms(sb, pre, float(cfg.TEST.RPN_NMS_THRESH), 0 if cfg.NMS_CMP == 'ge' else 1, post, nms_ws, keep, nkeep)
+        rois = self.buf('tprop.rois', (post, 5), f32, zero=True); rsc = self.buf('tprop.rsc', (post,), f32)
+        O.gather_rois(sb, ss, keep, nkeep, post, rois, rsc)
+        n = int(nkeep.item())                               # TEST mode returns host arrays anyway (NET:691-697)
+        own = rois
+        if self.parity is not None and self.parity.get('forced_proposals') is not None:
+            fr, _ = self.parity['forced_proposals']
+            rois = self.buf('tprop.rois_forced', (post, 5), f32, zero=True)
+            rois[:fr.shape[0]].copy_(fr); n = int(fr.shape[0])
+        # heads run on all `post` slots (static shapes); rows >= n are padding and sliced off
+        cheads, cls_prob, bbox_pred, mprob = self._roi_heads_test(net_conv, Hc, Wc, rois, post)
+        nc = self._num_classes; MS = int(cfg.MASK_SIZE)
+        self._predictions = dict(net_conv=net_conv, net_conv_hw=(Hc, Wc), response=resp, rois=rois[:n], own_rois=own[:int(nkeep.item())],
+                                 cls_score=cheads[:n, :nc], cls_prob=cls_prob[:n], bbox_pred=bbox_pred[:n],
+                                 mask_prob=mprob.view(post, MS, MS, nc)[:n], rpn_cls_prob=prob)
+        return self._predictions
+
+    def test_image(self, blobs):
+        """NET:684-699: (cls_score, cls_prob, bbox_pred, rois) as float32 ndarrays + net_conv (device tensor [H*W][1024], see
+        self._predictions['net_conv_hw']), for the single expression in `blobs`."""
+        self.eval()
+        p = self.forward_test(self.upload_blob(blobs, 0))
+        return (p['cls_score'].float().cpu().numpy().copy(), p['cls_prob'].cpu().numpy().copy(), p['bbox_pred'].cpu().numpy().copy(),
+                p['rois'].cpu().numpy().copy(), p['net_conv'])
+
+    def _predict_masks_from_boxes_and_labels(self, net_conv, boxes, labels):
+        """NET:595-626: boxes ndarray (n,4) in the scaled image, labels ndarray (n,) -> device tensor (n,14,14) in [0,1]."""
+        assert not self.training, 'only support testing mode'
+        Hc, Wc = self._predictions['net_conv_hw']
+        n = int(boxes.shape[0])
+        rois = torch.from_numpy(np.hstack([np.zeros((n, 1)), boxes]).astype(np.float32)).to(self.device)
+        lab = torch.from_numpy(np.asarray(labels).astype(np.int32)).to(self.device)
+        return self._roi_heads_test(net_conv, Hc, Wc, rois, n, labels=lab)[3]
+
     def _consts(self):
         if not hasattr(self, '_cst'):
             TR = cfg.TRAIN

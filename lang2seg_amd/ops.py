@@ -303,6 +303,14 @@ def dynfilter_bwd(dy, x, filt, r, resp, respk, dx, ref, dfilt, dr, dresp_ws, H, 
          ptr(dr), ptr(dresp_ws), H, W, Cc, dt_of(x), int(gate), ptr(dresp_extra), stream())
 
 
+def rcnn_predict(heads, ldh, R, ncls, stds4, means4, cls_prob, bbox_pred):
+    call('l2s_rcnn_predict', ptr(heads), ldh, R, ncls, ptr(stds4), ptr(means4), ptr(cls_prob), ptr(bbox_pred), stream())
+
+
+def mask_prob(score, ldsc, ncls, labels, ms2, n_elem, out):
+    call('l2s_mask_prob', ptr(score), ldsc, ncls, ptr(labels), ms2, n_elem, ptr(out), stream())
+
+
 def response_loss(resp, gt_mask_u8, mask_h, mask_w, H, W, gscale, loss, dresp):
     call('l2s_response_loss', ptr(resp), ptr(gt_mask_u8), mask_h, mask_w, H, W, float(gscale), ptr(loss), ptr(dresp), stream())
 

@@ -308,6 +308,54 @@ class OracleNet(object):
         self.t = T; self.losses = L
         return T, L
 
+
+    # ---- TEST mode (NET:488-593 with mode == 'TEST', NET:650-658, test_image NET:684-699) ----
+    def forward_test(self, blob, forced_proposals=None):
+        """returns dict(cls_score, cls_prob, bbox_pred (de-normalised, NET:655-658), rois, net_conv, mask_prob)."""
+        cfg = self.cfg
+        with torch.no_grad():
+            image = torch.from_numpy(blob['data'].transpose(0, 3, 1, 2).copy())
+            im_info = blob['im_info']
+            base = self.image_to_head(image)
+            hidden = self.rnn_encoder(torch.from_numpy(blob['labels']))
+            net_conv = self.dynamic_filter(base, hidden)
+            H, W = net_conv.shape[2], net_conv.shape[3]
+            anchors, _ = B.generate_anchors_pre(H, W, 16, cfg['ANCHOR_SCALES'], cfg['ANCHOR_RATIOS'])
+            rpn = F.relu(F.conv2d(net_conv, self.p['rpn_net.weight'], self.p['rpn_net.bias'], padding=1))
+            cls = F.conv2d(rpn, self.p['rpn_cls_score_net.weight'], self.p['rpn_cls_score_net.bias'])
+            prob = F.softmax(cls.view(1, 2, -1, W), 1).view_as(cls).permute(0, 2, 3, 1)
+            bbp = F.conv2d(rpn, self.p['rpn_bbox_pred_net.weight'], self.p['rpn_bbox_pred_net.bias']).permute(0, 2, 3, 1).contiguous()
+            ct = cfg['TEST']
+            rois, rscores, order, keep = B.proposal_layer(prob.numpy(), bbp.numpy(), im_info[0], anchors, self.A, ct['RPN_PRE_NMS_TOP_N'],
+                                                          ct['RPN_POST_NMS_TOP_N'], ct['RPN_NMS_THRESH'], cfg['NMS_CMP'])
+            own = rois
+            if forced_proposals is not None:
+                rois = forced_proposals
+            out = self.roi_heads_test(net_conv, rois)
+            out.update(rois=rois, own_rois=own, net_conv=net_conv, response=self.t_response)
+        return out
+
+    def roi_heads_test(self, net_conv, rois):
+        pool5 = self.crop_pool(net_conv, torch.from_numpy(np.ascontiguousarray(rois, dtype=np.float32)))
+        fc7s = self.head_to_tail(pool5)
+        fc7 = fc7s.mean(3).mean(2)
+        cls_score = F.linear(fc7, self.p['cls_score_net.weight'], self.p['cls_score_net.bias'])
+        bbox_pred = F.linear(fc7, self.p['bbox_pred_net.weight'], self.p['bbox_pred_net.bias'])
+        ct = self.cfg['TRAIN']
+        stds = torch.tensor(ct['BBOX_NORMALIZE_STDS'], dtype=torch.float32).repeat(self.num_classes)
+        means = torch.tensor(ct['BBOX_NORMALIZE_MEANS'], dtype=torch.float32).repeat(self.num_classes)
+        up = F.relu(F.conv_transpose2d(fc7s, self.p['mask_up_sampling.weight'], self.p['mask_up_sampling.bias'], stride=2))
+        mask_prob = torch.sigmoid(F.conv2d(up, self.p['mask_pred_net.weight'], self.p['mask_pred_net.bias']))
+        return dict(cls_score=cls_score, cls_prob=F.softmax(cls_score, 1), bbox_pred=bbox_pred * stds + means, mask_prob=mask_prob)
+
+    def predict_masks_from_boxes_and_labels(self, net_conv, boxes, labels):
+        """NET:595-626: (n,4) boxes + (n,) labels -> (n,14,14) mask probabilities of the labelled class."""
+        with torch.no_grad():
+            rois = np.hstack([np.zeros((boxes.shape[0], 1)), boxes]).astype(np.float32)
+            mp = self.roi_heads_test(net_conv, rois)['mask_prob']
+            idx = torch.from_numpy(np.asarray(labels)).long().view(-1, 1, 1, 1).expand(-1, 1, mp.shape[2], mp.shape[3])
+            return torch.gather(mp, 1, idx).squeeze(1)
+
     def backward(self):
         for k in self.trainable:
             self.p[k].grad = None

@@ -18,7 +18,7 @@ this harness only restores the environment it expects, in-process (SURVEY.md §8
 sets the same attributes forward() sets (NET:632-648) and calls `_predict()` /
 `_add_losses()` / backward / torch.optim.SGD exactly as NET:650-662,712-715, TV:194-220.
 
-Usage: python tests/golden/make_golden.py [tiny|full|leaf|variants|all]
+Usage: python tests/golden/make_golden.py [tiny|full|leaf|variants|test|all]
 """
 import os
 import sys
@@ -314,6 +314,61 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
     return out
 
 
+def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0, variant='cycle'):
+    """TEST mode (test_image, NET:684-699; _predict_masks_from_boxes_and_labels, NET:595-626) of the reference."""
+    from model.config import cfg
+    import importlib
+    var = OW.VARIANTS[variant]
+    RESM = importlib.import_module('nets.' + var['module'])
+    opt = OW.default_opt(vocab_size=V, seq_length=T)
+    sd = OW.make_state_dict(opt, seed=seed_w, head_gain=head_gain, variant=variant)
+    blob = OS.make_blob(H, W, T, V, seed=seed_blob)
+    from oracle.net import DEFAULT_CFG
+    for k, v in DEFAULT_CFG['TEST'].items():
+        setattr(cfg.TEST, k, v)
+    for k in ['BATCH_SIZE', 'RPN_PRE_NMS_TOP_N', 'RPN_POST_NMS_TOP_N', 'RPN_BATCHSIZE']:
+        setattr(cfg.TRAIN, k, DEFAULT_CFG['TRAIN'][k])
+    cfg.ANCHOR_SCALES = list(DEFAULT_CFG['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(DEFAULT_CFG['ANCHOR_RATIOS'])
+    torch.manual_seed(0)
+    net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
+    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    ref_sd = net.state_dict()
+    for k, v in sd.items():
+        ref_sd[k].copy_(torch.from_numpy(v))
+    net.eval()
+    # NET:632-662 with mode == 'TEST' (forward() itself is bypassed: `.data[0]` on a 0-dim tensor)
+    net._image = torch.from_numpy(blob['data'].transpose([0, 3, 1, 2]).copy())
+    net._im_info = blob['im_info']
+    net._gt_boxes = torch.from_numpy(blob['gt_boxes'])
+    net._gt_masks = blob['gt_masks']
+    net._labels = torch.from_numpy(blob['labels'])
+    net._cap_labels = None; net._cap_masks = None
+    net._mode = 'TEST'
+    net._image_gt_summaries = {}
+    with torch.no_grad():
+        net_conv, rois, cls_prob, bbox_pred, mask_prob = net._predict()
+        stds = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_STDS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
+        means = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_MEANS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
+        bbox_pred = bbox_pred.mul(stds).add(means)
+        boxes = rois.numpy()[:5, 1:5].copy()
+        labels = np.array([3, 17, 1, 80, 42])
+        masks = net._predict_masks_from_boxes_and_labels(net_conv, boxes, labels)
+    out = dict(meta_H=H, meta_W=W, meta_T=T, meta_V=V, meta_seed_w=seed_w, meta_seed_blob=seed_blob, meta_head_gain=head_gain,
+               meta_variant=variant)
+    out['int.rois'] = rois.numpy()
+    out['x.cls_score'] = net._predictions['cls_score'].numpy()
+    out['x.cls_prob'] = cls_prob.numpy()
+    out['x.bbox_pred'] = bbox_pred.numpy()[:, :24]
+    flat('t.bbox_pred', digest(bbox_pred), out)
+    flat('t.mask_prob', digest(mask_prob), out)
+    flat('t.net_conv', digest(net_conv), out)
+    out['x.mask_prob_0'] = mask_prob.numpy()[:4, :6]
+    out['pm.boxes'] = boxes; out['pm.labels'] = labels; out['pm.masks'] = masks.numpy()
+    np.savez_compressed(os.path.join(HERE, 'ref_%s.npz' % tag), **out)
+    print(tag, 'rois', rois.shape, 'cls_prob max', float(cls_prob.max()))
+    return out
+
+
 PROPOSALS = {}
 
 
@@ -398,6 +453,9 @@ if __name__ == '__main__':
             hook_proposals(v)
             run_reference('tiny_' + v, 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,
                                                              RPN_BATCHSIZE=64), head_gain=4.0, variant=v)
+    if what in ('test', 'all'):
+        run_reference_test('test_tiny', 320, 416, 6, 60)
+        run_reference_test('test_tiny_cycle_response', 320, 416, 6, 60, variant='cycle_response')
     if what in ('full', 'all'):
         hook_proposals()
         run_reference('full', 600, 1000, 20, 3349, dict(BATCH_SIZE=256, RPN_PRE_NMS_TOP_N=12000,

@@ -40,3 +40,12 @@ def setup_from_fixture(g):
     samp = dict(rpn_fg_keys=g['samp.rpn_fg_keys'], rpn_bg_keys=g['samp.rpn_bg_keys'],
                 roi_fg_keys=g['samp.roi_fg_keys'], roi_bg_keys=g['samp.roi_bg_keys'])
     return opt, sd, blob, cfg, samp
+
+
+def setup_from_fixture_test(g):
+    """inputs of a TEST-mode fixture (default TEST proposal settings, no sampling keys)."""
+    from oracle import weights as OW, synth as OS, net as ON
+    opt = OW.default_opt(vocab_size=int(g['meta_V']), seq_length=int(g['meta_T']))
+    sd = OW.make_state_dict(opt, seed=int(g['meta_seed_w']), head_gain=float(g['meta_head_gain']), variant=variant_of(g))
+    blob = OS.make_blob(int(g['meta_H']), int(g['meta_W']), int(g['meta_T']), int(g['meta_V']), seed=int(g['meta_seed_blob']))
+    return opt, sd, blob, copy.deepcopy(ON.DEFAULT_CFG), None

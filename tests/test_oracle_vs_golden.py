@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import boxes as OB, weights as OW, net as ON
-from golden_util import load, check_digest, setup_from_fixture, variant_of
+from golden_util import load, check_digest, setup_from_fixture, setup_from_fixture_test, variant_of
 
 
 def test_anchor_known_answer():
@@ -82,3 +82,23 @@ def test_train_step_tiny_variants(variant):
     """the reference's other ResNet network variants (network.py, network_7f.py, network_7f_response.py,
     network_cycle_response.py): losses (incl. the response BCE), targets, gradients, post-SGD weights."""
     _run_e2e('tiny_' + variant)
+
+
+@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response'])
+def test_test_mode(tag):
+    """TEST mode of the reference (test_image NET:684-699 + _predict_masks_from_boxes_and_labels NET:595-626):
+    300 TEST proposals, class scores / probabilities, de-normalised box deltas, mask probabilities."""
+    g = load(tag)
+    opt, sd, blob, cfg, _ = setup_from_fixture_test(g)
+    net = ON.OracleNet(sd, opt, cfg, variant=variant_of(g))
+    out = net.forward_test(blob, forced_proposals=g['int.rois'])
+    D = np.abs(out['own_rois'][:, None, 1:] - g['int.rois'][None, :, 1:]).max(-1)
+    assert out['own_rois'].shape == g['int.rois'].shape and D.min(1).max() < 5e-3 and D.min(0).max() < 5e-3
+    assert np.allclose(out['cls_score'].numpy(), g['x.cls_score'], atol=1e-4)
+    assert np.allclose(out['cls_prob'].numpy(), g['x.cls_prob'], atol=1e-6)
+    assert np.allclose(out['bbox_pred'].numpy()[:, :24], g['x.bbox_pred'], atol=1e-5)
+    check_digest(g, 't.bbox_pred', out['bbox_pred'].numpy())
+    check_digest(g, 't.mask_prob', out['mask_prob'].numpy())
+    check_digest(g, 't.net_conv', out['net_conv'].numpy())
+    pm = net.predict_masks_from_boxes_and_labels(out['net_conv'], g['pm.boxes'], g['pm.labels'])
+    assert np.allclose(pm.numpy(), g['pm.masks'], atol=1e-5)

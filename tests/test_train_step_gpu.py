@@ -121,3 +121,32 @@ def test_train_step_bf16_close():
 def test_smoke_entry():
     from lang2seg_amd import selftest
     selftest.smoke()
+
+
+@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response'])
+def test_test_mode(tag):
+    """TEST mode (test_image, _predict_masks_from_boxes_and_labels) against the reference's own TEST-mode outputs."""
+    from golden_util import setup_from_fixture_test
+    from lang2seg_amd import selftest
+    g = load(tag)
+    opt, sd, blob, ocfg, _ = setup_from_fixture_test(g)
+    net = selftest.build_net(opt, {}, 'f32', sd, variant=variant_of(g))
+    from lang2seg_amd.model.config import cfg
+    for k, v in ocfg['TEST'].items():
+        cfg.TEST[k] = v
+    net.parity = dict(forced_proposals=(torch.from_numpy(g['int.rois']).cuda(), None))
+    tb = {k: blob[k] for k in ('data', 'im_info', 'gt_boxes', 'gt_masks', 'labels')}
+    cls_score, cls_prob, bbox_pred, rois, net_conv = net.test_image(tb)
+    own = net._predictions['own_rois'].cpu().numpy()
+    D = np.abs(own[:, None, 1:] - g['int.rois'][None, :, 1:]).max(-1)
+    assert own.shape == g['int.rois'].shape and D.min(1).max() < 2e-2 and D.min(0).max() < 2e-2
+    assert np.allclose(rois, g['int.rois'], atol=1e-5)
+    assert np.allclose(cls_score, g['x.cls_score'], atol=2e-4)
+    assert np.allclose(cls_prob, g['x.cls_prob'], atol=1e-5)
+    assert np.allclose(bbox_pred[:, :24], g['x.bbox_pred'], atol=1e-4)
+    check_digest(g, 't.bbox_pred', bbox_pred, rtol=2e-4)
+    mp = net._predictions['mask_prob'].cpu().numpy().transpose(0, 3, 1, 2)      # (n, 81, 14, 14) like the reference
+    check_digest(g, 't.mask_prob', mp, rtol=2e-4)
+    assert np.allclose(mp[:4, :6], g['x.mask_prob_0'], atol=1e-4)
+    pm = net._predict_masks_from_boxes_and_labels(net_conv, g['pm.boxes'], g['pm.labels']).cpu().numpy()
+    assert np.allclose(pm, g['pm.masks'], atol=1e-4)
