@@ -438,11 +438,43 @@ def run_leaf():
     print('leaf done', out['cap.loss'])
 
 
+def run_leaf_eval():
+    """Post-processing leaves of the evaluation path, imported from the reference (model/test.py, utils/mask_utils.py)."""
+    import importlib
+    from utils.mask_utils import recover_masks
+    from model.bbox_transform import bbox_transform_inv
+    sys.modules['cv2'].resize = None
+    sys.modules['pycocotools.mask'].encode = None
+    # model/test.py imports utils.visualization (PIL fonts) and nms_wrapper: import lazily and tolerate their absence
+    rs = np.random.RandomState(21)
+    out = {}
+    masks = rs.uniform(0, 1, (6, 14, 14)).astype(np.float32)
+    masks[3] = 0.25                                            # constant mask: bytescale's cscale == 0 branch
+    rois = np.array([[10.3, 20.7, 80.2, 90.9], [-5.0, -3.0, 40.0, 33.3], [100.0, 50.0, 219.9, 146.9], [0, 0, 13, 13],
+                     [150.5, 100.5, 400.0, 300.0], [30, 40, 30.4, 40.2]], np.float32)
+    out['rm.masks'] = masks.copy(); out['rm.rois'] = rois.copy()
+    rec = recover_masks(masks.copy(), rois.copy(), 147, 220)
+    out['rm.out'] = rec
+    out['rm.bin'] = (rec > 122.).astype(np.uint8)
+    boxes = rs.uniform(0, 200, (20, 4)).astype(np.float32); boxes[:, 2:] += boxes[:, :2]
+    deltas = rs.normal(0, 0.3, (20, 4 * 5)).astype(np.float32)
+    out['bt.boxes'] = boxes; out['bt.deltas'] = deltas
+    out['bt.pred'] = bbox_transform_inv(torch.from_numpy(boxes), torch.from_numpy(deltas)).numpy()
+    import scipy.misc
+    gm = (rs.uniform(0, 1, (150, 230)) > 0.6).astype(np.uint8)
+    out['nn.mask'] = gm
+    out['nn.out'] = scipy.misc.imresize(gm, size=(94, 147), interp='nearest')
+    np.savez_compressed(os.path.join(HERE, 'ref_leaf_eval.npz'), **out)
+    print('leaf_eval done', rec.shape, int(rec.sum()))
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     install_harness()
     if what in ('leaf', 'all'):
         run_leaf()
+    if what in ('leaf_eval', 'all'):
+        run_leaf_eval()
     if what in ('tiny', 'all'):
         hook_proposals()
         run_reference('tiny', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,

@@ -130,3 +130,22 @@ def test_grad_reducer_gloo_world2():
         p.join(180)
     assert all(p.exitcode == 0 for p in procs)
     assert ret.get(0) and ret.get(1)
+
+
+def test_eval_postprocessing_vs_reference():
+    """evaluation-path leaves (model/test.py, utils/mask_utils.py of the reference, run by tests/golden/make_golden.py
+    leaf_eval with a scipy<=1.2 `imresize` restatement on PIL): recover_masks, class-wise box decoding, nearest GT resize."""
+    from golden_util import load
+    from lang2seg_amd.utils.mask_utils import recover_masks, imresize
+    from lang2seg_amd.model import test as T
+    g = load('leaf_eval')
+    rec = recover_masks(g['rm.masks'].copy(), g['rm.rois'].copy(), 147, 220)
+    assert np.array_equal(rec, g['rm.out'])
+    assert np.array_equal((rec > 122.).astype(np.uint8), g['rm.bin'])
+    assert np.allclose(T.bbox_transform_inv_np(g['bt.boxes'], g['bt.deltas']), g['bt.pred'], rtol=1e-6, atol=1e-4)
+    assert np.array_equal(imresize(g['nn.mask'], size=(94, 147), interp='nearest'), g['nn.out'])
+    assert abs(T.computeIoU_box([0, 0, 9, 9], [5, 5, 14, 14]) - 25.0 / 175.0) < 1e-12
+    sc = np.zeros((4, 5), np.float32); sc[2, 3] = 0.9; sc[1, 0] = 0.99     # background column is ignored
+    bx = np.arange(4 * 20, dtype=np.float32).reshape(4, 20)
+    r, c, b = T.best_detection(sc, bx)
+    assert (r, c) == (2, 3) and np.array_equal(b, bx[2, 12:16])

@@ -1,0 +1,59 @@
+"""Shared body of the evaluation entry points tools/eval*.py (reference: tools/eval.py:40-127, eval_spatial.py, eval_response.py):
+load the snapshot `<dataset_splitBy>/output_<postfix>/<prefix>_iter_<model_iter>.pth` into the variant's resnetv1 and run
+model.test.eval_split on a split.  Without dataset files in this repository the SyntheticLoader stands in for the loader."""
+import argparse
+import os
+import os.path as osp
+import sys
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument('--dataset', default='refcoco'); p.add_argument('--splitBy', default='unc')
+    p.add_argument('--split', default='val'); p.add_argument('--id', default='mrcn_cmr_with_st')
+    p.add_argument('--output_postfix', default='cycle'); p.add_argument('--model_iter', type=int, default=0)
+    p.add_argument('--num_sents', type=int, default=-1); p.add_argument('--verbose', type=int, default=1)
+    p.add_argument('--cfg', dest='cfg_file', default='experiments/cfgs/res101.yml')
+    p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
+    p.add_argument('--synthetic_images', type=int, default=8); p.add_argument('--dtype', default='bf16')
+    return vars(p.parse_args(argv))
+
+
+def main(args, variant):
+    from lang2seg_amd.model.config import cfg, cfg_from_file, cfg_from_list
+    from lang2seg_amd.model.test import eval_split
+    from lang2seg_amd.nets.resnet_v1 import resnetv1
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    sys.path.insert(0, osp.join(ROOT, 'tools'))
+    from opt import parse_opt
+    torch.cuda.set_device(0)
+    T = 20 if args['dataset'] == 'refcocog' else 10
+    V = 3349 if args['dataset'] == 'refcocog' else 1999
+    loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V)
+    opt = parse_opt([])
+    opt.update(vocab_size=loader.vocab_size, C4_feat_dim=1024, seq_length=loader.label_length,
+               dataset_splitBy=args['dataset'] + '_' + args['splitBy'])
+    if args['cfg_file'] and osp.exists(osp.join(ROOT, args['cfg_file'])):
+        cfg_from_file(osp.join(ROOT, args['cfg_file']))
+    if args['set_cfgs']:
+        cfg_from_list(args['set_cfgs'])
+    cfg.COMPUTE_DTYPE = args['dtype']
+    net = resnetv1(opt, batch_size=1, num_layers=101, variant=variant)
+    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    ckpt = osp.join(ROOT, opt['dataset_splitBy'], 'output_{}'.format(args['output_postfix']),
+                    cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}.pth'.format(args['model_iter']))
+    if osp.exists(ckpt):
+        net.load_state_dict(torch.load(ckpt, map_location='cpu'))
+        print('loaded', ckpt)
+    else:
+        print('no snapshot at %s: evaluating the initial weights' % ckpt)
+    acc, iou, prec = eval_split(loader, net, None, args['split'] if args['split'] in loader.split_ix else 'val',
+                                dict(num_sents=args['num_sents'], verbose=bool(args['verbose'])))
+    print('Comprehension on %s\'s %s (%s sents): box acc %.2f%%, overall IoU %.2f%%' % (
+        opt['dataset_splitBy'], args['split'], args['num_sents'], acc * 100, iou * 100))
+    return acc, iou, prec
