@@ -58,7 +58,9 @@ class OracleNet(object):
         self.momentum = {k: torch.zeros_like(self.p[k]) for k in self.trainable}
 
     def _is_trainable(self, k):
-        """RES:290-306: conv1/bn1/layer1 (FIXED_BLOCKS=1) and every BN tensor are frozen."""
+        """RES:290-306: conv1/bn1/layer1 (FIXED_BLOCKS=1) and every BN tensor are frozen; vgg16.py:49-51: features[0..9]."""
+        if k.startswith('vgg.features.'):
+            return int(k.split('.')[2]) >= 10
         if k.startswith('resnet.'):
             if '.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1') or k.startswith('resnet.conv1'):
                 return False
@@ -87,7 +89,18 @@ class OracleNet(object):
         return x
 
     def image_to_head(self, image_nchw):
-        """RES:261-265,309-310."""
+        """RES:261-265,309-310; VGG: vgg16.py:53-54,78-82 (features without the last max-pool)."""
+        if self.var.get('backbone') == 'vgg':
+            from .weights import vgg_feature_indices
+            convs, pools = vgg_feature_indices()
+            x = image_nchw
+            ci = {i: None for i, _, _ in convs}
+            for i in range(30):
+                if i in ci:
+                    x = F.relu(F.conv2d(x, self.p['vgg.features.%d.weight' % i], self.p['vgg.features.%d.bias' % i], padding=1))
+                elif i in pools:
+                    x = F.max_pool2d(x, 2, 2)
+            return x
         x = F.relu(self._bn(F.conv2d(image_nchw, self.p['resnet.conv1.weight'], stride=2, padding=3), 'resnet.bn1'))
         x = F.max_pool2d(x, 3, 2, 1)
         self.t_stem = x
@@ -97,7 +110,15 @@ class OracleNet(object):
         self.t_layer2 = x
         return self._layer(x, 3, 2)
 
-    def head_to_tail(self, x):
+    def head_to_tail(self, x, drops=None):
+        if self.var.get('backbone') == 'vgg':                     # vgg16.py:84-88: fc6 / fc7 (+ReLU, dropout)
+            h = F.relu(F.linear(x.reshape(x.shape[0], -1), self.p['vgg.classifier.0.weight'], self.p['vgg.classifier.0.bias']))
+            if drops is not None and drops.get('fc6') is not None:
+                h = h * drops['fc6']
+            h = F.relu(F.linear(h, self.p['vgg.classifier.3.weight'], self.p['vgg.classifier.3.bias']))
+            if drops is not None and drops.get('fc7') is not None:
+                h = h * drops['fc7']
+            return h
         return self._layer(x, 4, 1)       # RES:271-273, layer4 stride 1 (RES:131)
 
     # ---- language encoder (ENC:27-82), batch 1 ----------------------------
@@ -151,6 +172,9 @@ class OracleNet(object):
         zero = torch.zeros(rois.shape[0], 1)
         theta = torch.cat([(x2 - x1) / (width - 1), zero, (x1 + x2 - width + 1) / (width - 1),
                            zero, (y2 - y1) / (height - 1), (y1 + y2 - height + 1) / (height - 1)], 1).view(-1, 2, 3)
+        if self.var.get('backbone') == 'vgg':                     # network_vgg.py:139-143: 14x14 crop + 2x2 max pool
+            grid = F.affine_grid(theta, (rois.shape[0], 1, 2 * size, 2 * size), align_corners=True)
+            return F.max_pool2d(F.grid_sample(bottom.expand(rois.shape[0], -1, -1, -1), grid, align_corners=True), 2, 2)
         grid = F.affine_grid(theta, (rois.shape[0], 1, size, size), align_corners=True)
         return F.grid_sample(bottom.expand(rois.shape[0], -1, -1, -1), grid, align_corners=True)
 
@@ -251,16 +275,21 @@ class OracleNet(object):
         T['bbox_outside'] = bo; T['mask_targets'] = mt; T['roi_keep'] = skeep
         pool5 = self.crop_pool(net_conv, torch.from_numpy(srois))
         T['pool5'] = pool5
-        fc7s = self.head_to_tail(pool5)
-        T['spatial_fc7'] = fc7s
-        fc7 = fc7s.mean(3).mean(2)
+        has_mask = self.var.get('mask', True)
+        if self.var.get('backbone') == 'vgg':
+            fc7 = self.head_to_tail(pool5, drops)
+        else:
+            fc7s = self.head_to_tail(pool5)
+            T['spatial_fc7'] = fc7s
+            fc7 = fc7s.mean(3).mean(2)
         cls_score = F.linear(fc7, self.p['cls_score_net.weight'], self.p['cls_score_net.bias'])
         bbox_pred = F.linear(fc7, self.p['bbox_pred_net.weight'], self.p['bbox_pred_net.bias'])
         T['cls_score'] = cls_score; T['bbox_pred'] = bbox_pred
         nfg = mt.shape[0]
-        up = F.relu(F.conv_transpose2d(fc7s[:nfg], self.p['mask_up_sampling.weight'], self.p['mask_up_sampling.bias'], stride=2))
-        mscore = F.conv2d(up, self.p['mask_pred_net.weight'], self.p['mask_pred_net.bias'])
-        T['mask_score'] = mscore
+        if has_mask:
+            up = F.relu(F.conv_transpose2d(fc7s[:nfg], self.p['mask_up_sampling.weight'], self.p['mask_up_sampling.bias'], stride=2))
+            mscore = F.conv2d(up, self.p['mask_pred_net.weight'], self.p['mask_pred_net.bias'])
+            T['mask_score'] = mscore
         # ---- losses (NET:375-413) ----
         L = {}
         rl = torch.from_numpy(lab).view(-1).long()
@@ -270,9 +299,11 @@ class OracleNet(object):
         label = torch.from_numpy(slabels).view(-1).long()
         L['cross_entropy'] = F.cross_entropy(cls_score, label)
         L['loss_box'] = self.smooth_l1(bbox_pred, torch.from_numpy(bt), torch.from_numpy(bi), torch.from_numpy(bo), 1.0, [1])
-        fgl = label[:nfg].view(nfg, 1, 1, 1).expand(nfg, 1, cfg['MASK_SIZE'], cfg['MASK_SIZE'])
-        L['loss_mask'] = F.binary_cross_entropy_with_logits(torch.gather(mscore, 1, fgl).squeeze(1), torch.from_numpy(mt))
-        total = L['cross_entropy'] + L['loss_box'] + L['rpn_cross_entropy'] + L['rpn_loss_box'] + L['loss_mask']
+        total = L['cross_entropy'] + L['loss_box'] + L['rpn_cross_entropy'] + L['rpn_loss_box']
+        if has_mask:
+            fgl = label[:nfg].view(nfg, 1, 1, 1).expand(nfg, 1, cfg['MASK_SIZE'], cfg['MASK_SIZE'])
+            L['loss_mask'] = F.binary_cross_entropy_with_logits(torch.gather(mscore, 1, fgl).squeeze(1), torch.from_numpy(mt))
+            total = total + L['loss_mask']
         if self.var['gate'] == 'sigmoid':
             # response loss (network_cycle_response.py:415-423): PIL-NEAREST resize of the uint8 GT mask to the C4 map
             rp = self.t_response[0, 0]

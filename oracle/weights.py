@@ -21,14 +21,30 @@ VARIANTS = {
     'response': dict(nfilt=7, gate='sigmoid', cap=None, module='resnet_v1_7f_response', net='network_7f_response'),
     'cycle': dict(nfilt=7, gate='linear', cap='mask', module='resnet_v1_cycle_res5_2', net='network_cycle_res5_2'),
     'cycle_response': dict(nfilt=7, gate='sigmoid', cap='before_after', module='resnet_v1_cycle_response', net='network_cycle_response'),
+    # VGG16 / Faster R-CNN variant (nets/vgg16.py + nets/network_vgg.py, train_vgg.sh): conv5_3 map (512 ch), 14x14 crop +
+    # 2x2 max pool, fc6/fc7, no mask branch, sigmoid gating + response loss
+    'vgg': dict(nfilt=7, gate='sigmoid', cap=None, module='vgg16', net='network_vgg', backbone='vgg', mask=False),
 }
+VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]   # torchvision cfg 'D' minus the last pool
 LOSS_KEYS = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_response', 'loss_caption', 'total_loss']
 
 
 def loss_keys(variant):
     """order of the floats Network.train_step returns (NET:702-719 and its variants)."""
     v = VARIANTS[variant]
-    return [k for k in LOSS_KEYS if not (k == 'loss_response' and v['gate'] != 'sigmoid') and not (k == 'loss_caption' and v['cap'] is None)]
+    return [k for k in LOSS_KEYS if not (k == 'loss_response' and v['gate'] != 'sigmoid') and not (k == 'loss_caption' and v['cap'] is None)
+            and not (k == 'loss_mask' and not v.get('mask', True))]
+
+
+def vgg_feature_indices():
+    """[(index in vgg.features, Cin, Cout)] of the 13 convolutions and the indices of the 4 max-pools that are kept."""
+    convs, pools, i, cin = [], [], 0, 3
+    for v in VGG_CFG:
+        if v == 'M':
+            pools.append(i); i += 1
+        else:
+            convs.append((i, cin, v)); cin = v; i += 2
+    return convs, pools
 
 
 def default_opt(vocab_size=1999, seq_length=10, cap_loss_weight=1.0):
@@ -73,6 +89,8 @@ def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12, variant='c
     def bn(p, c):
         for k in ['weight', 'bias', 'running_mean', 'running_var']:
             s[p + '.' + k] = (c,)
+    if var.get('backbone') == 'vgg':
+        return _vgg_shapes(s, opt, num_classes, num_anchors)
     s['resnet.conv1.weight'] = (64, 3, 7, 7); bn('resnet.bn1', 64)
     inpl = 64
     for li, (planes, nb) in enumerate(zip([64, 128, 256, 512], RESNET_LAYERS[num_layers]), 1):
@@ -101,6 +119,24 @@ def param_shapes(opt, num_layers=101, num_classes=81, num_anchors=12, variant='c
     return s
 
 
+def _vgg_shapes(s, opt, num_classes, num_anchors):
+    convs, _ = vgg_feature_indices()
+    for i, cin, cout in convs:
+        s['vgg.features.%d.weight' % i] = (cout, cin, 3, 3); s['vgg.features.%d.bias' % i] = (cout,)
+    s['vgg.classifier.0.weight'] = (4096, 512 * 7 * 7); s['vgg.classifier.0.bias'] = (4096,)
+    s['vgg.classifier.3.weight'] = (4096, 4096); s['vgg.classifier.3.bias'] = (4096,)
+    C4 = opt['C4_feat_dim']; HD = opt['rnn_num_layers'] * (2 if opt['bidirectional'] else 1) * opt['rnn_hidden_size']
+    for k in range(7):
+        s['dynamic_fc_%d.weight' % k] = (C4, HD); s['dynamic_fc_%d.bias' % k] = (C4,)
+    s['response_fc.weight'] = (7, HD); s['response_fc.bias'] = (7,)
+    s['rpn_net.weight'] = (512, C4, 3, 3); s['rpn_net.bias'] = (512,)
+    s['rpn_cls_score_net.weight'] = (2 * num_anchors, 512, 1, 1); s['rpn_cls_score_net.bias'] = (2 * num_anchors,)
+    s['rpn_bbox_pred_net.weight'] = (4 * num_anchors, 512, 1, 1); s['rpn_bbox_pred_net.bias'] = (4 * num_anchors,)
+    s['cls_score_net.weight'] = (num_classes, 4096); s['cls_score_net.bias'] = (num_classes,)
+    s['bbox_pred_net.weight'] = (4 * num_classes, 4096); s['bbox_pred_net.bias'] = (4 * num_classes,)
+    return s
+
+
 def make_state_dict(opt, seed=3, num_layers=101, num_classes=81, num_anchors=12, head_gain=1.0, variant='cycle'):
     """name -> float32 ndarray.  One RandomState stream consumed in param_shapes order.
     `head_gain` > 1 scales the N(0,0.01) head initialisers so scores/deltas are not
@@ -117,6 +153,14 @@ def make_state_dict(opt, seed=3, num_layers=101, num_classes=81, num_anchors=12,
             a = rs.uniform(0.8, 1.2, n) if name.endswith('weight') else rs.normal(0, 0.1, n)
             if name.endswith('bn3.weight') or name.endswith('downsample.1.weight'):
                 a = a * (0.15 if name.endswith('bn3.weight') else 0.7)   # keep the residual stream's variance flat through 33 blocks
+        elif name.startswith('vgg.features.') and len(shp) == 4:
+            a = rs.normal(0, np.sqrt(2.0 / (shp[1] * 9)), n)                            # He fan-in keeps 13 ReLU layers at O(1)
+            if name == 'vgg.features.0.weight':
+                a = a * 0.02                                                           # inputs are pixel-scale (sigma 50)
+        elif name.startswith('vgg.features.') and name.endswith('bias'):
+            a = rs.normal(0, 0.05, n)
+        elif name.startswith('vgg.classifier.') and name.endswith('weight'):
+            a = rs.normal(0, np.sqrt(2.0 / shp[1]), n)
         elif name.startswith('resnet.') and len(shp) == 4:
             a = rs.normal(0, np.sqrt(2.0 / (shp[2] * shp[3] * shp[0])), n)            # RES:137-138
             if name == 'resnet.conv1.weight':

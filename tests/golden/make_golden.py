@@ -104,6 +104,26 @@ def install_harness():
     ext.roi_pooling = types.SimpleNamespace()
     sys.modules['_ext'] = ext
 
+    # --- torchvision.models.vgg16 (not installed here): the standard configuration-D module tree (features / classifier) ---
+    tv = types.ModuleType('torchvision'); tvm = types.ModuleType('torchvision.models')
+
+    class _VGG(nn.Module):
+        def __init__(self):
+            nn.Module.__init__(self)
+            layers, cin = [], 3
+            for v in [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']:
+                if v == 'M':
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                else:
+                    layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                    cin = v
+            self.features = nn.Sequential(*layers)
+            self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 4096), nn.ReLU(True),
+                                            nn.Dropout(), nn.Linear(4096, 1000))
+    tvm.vgg16 = lambda pretrained=False: _VGG()
+    tv.models = tvm
+    sys.modules['torchvision'] = tv; sys.modules['torchvision.models'] = tvm
+
     np.float = float
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
@@ -176,11 +196,14 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
         setattr(cfg.TRAIN, k, v)
     cfg.ANCHOR_SCALES = list(ocfg['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(ocfg['ANCHOR_RATIOS'])
     opt = OW.default_opt(vocab_size=V, seq_length=T)
+    is_vgg = var.get('backbone') == 'vgg'
+    if is_vgg:
+        opt['C4_feat_dim'] = 512
     sd = OW.make_state_dict(opt, seed=seed_w, head_gain=head_gain, variant=variant)
     blob = OS.make_blob(H, W, T, V, seed=seed_blob)
 
     torch.manual_seed(0)
-    net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
+    net = RESM.vgg16(opt, batch_size=1) if is_vgg else RESM.resnetv1(opt, batch_size=1, num_layers=101)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     ref_sd = net.state_dict()
     for k, v in sd.items():
@@ -212,7 +235,8 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
     net._cap_labels = blob['cap_labels']; net._cap_masks = blob['cap_masks']
     net._mode = 'TRAIN'
     net._image_gt_summaries = {}
-    net_conv, rois, cls_prob, bbox_pred, mask_prob = net._predict()
+    pred_out = net._predict()
+    net_conv = pred_out[0]
     net._predictions['net_conv'] = net_conv
     net._add_losses()
     L = {k: float(v) for k, v in net._losses.items()}
@@ -287,7 +311,7 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
                 rpn_bbox_pred=net._predictions['rpn_bbox_pred'], rpn_bbox_targets=net._anchor_targets['rpn_bbox_targets'],
                 rpn_bbox_outside=net._anchor_targets['rpn_bbox_outside_weights'],
                 bbox_targets=prop['bbox_targets'], cls_score=net._predictions['cls_score'],
-                bbox_pred=net._predictions['bbox_pred'], mask_score=net._predictions['mask_score'])
+                bbox_pred=net._predictions['bbox_pred'], mask_score=net._predictions.get('mask_score'))
     for k, v in tens.items():
         if v is not None:
             flat('t.' + k, digest(v), out)
@@ -301,6 +325,10 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
             'rnn_encoder.mlp.0.bias', 'caption_model.att_embed.0.weight', 'caption_model.logit.weight',
             'caption_model.core.h2h.weight', 'caption_model.core.a2c.bias', 'caption_model.core.attention.alpha_net.weight',
             'caption_model.embed.0.weight', 'caption_model.ctx2att.weight']
+    if is_vgg:
+        gsel = ['vgg.features.10.weight', 'vgg.features.17.bias', 'vgg.features.28.weight', 'vgg.classifier.0.weight', 'vgg.classifier.3.bias',
+                'rpn_net.weight', 'rpn_cls_score_net.bias', 'cls_score_net.weight', 'bbox_pred_net.bias', 'dynamic_fc_3.weight', 'response_fc.weight',
+                'rnn_encoder.embedding.weight', 'rnn_encoder.rnn.weight_hh_l0_reverse', 'rnn_encoder.mlp.0.bias']
     if var['nfilt'] == 1:
         gsel = [k for k in gsel if not k.startswith(('dynamic_fc_', 'response_fc'))] + ['dynamic_fc.weight', 'dynamic_fc.bias']
     if var['cap'] is None:
@@ -481,7 +509,7 @@ if __name__ == '__main__':
                                                     RPN_BATCHSIZE=64), head_gain=float(os.environ.get('HG', '4')))
     if what in ('variants', 'all'):
         # the other ResNet network variants of the reference (BASELINE.json configs 0, 1, 3 + train_response.sh), tiny size
-        for v in ['baseline', 'spatial', 'response', 'cycle_response']:
+        for v in (sys.argv[2:] or ['baseline', 'spatial', 'response', 'cycle_response', 'vgg']):
             hook_proposals(v)
             run_reference('tiny_' + v, 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,
                                                              RPN_BATCHSIZE=64), head_gain=4.0, variant=v)

@@ -58,7 +58,7 @@ def _run_e2e(tag):
     assert np.allclose(T['rois'][:, 1:], g['int.rois'][:, 1:], atol=2e-3)
     assert np.array_equal(T['labels'].reshape(-1).astype(np.int64), g['int.labels'])
     assert np.array_equal(T['mask_targets'].astype(np.uint8), g['int.mask_targets'])
-    for k in ['net_conv', 'rpn_cls_prob', 'rpn_bbox_pred', 'cls_score', 'bbox_pred', 'mask_score'] + (['response'] if 't.response.sum' in g else []):
+    for k in ['net_conv', 'rpn_cls_prob', 'rpn_bbox_pred', 'cls_score', 'bbox_pred'] + [k for k in ('mask_score', 'response') if 't.%s.sum' % k in g]:
         check_digest(g, 't.' + k, T[k].detach().numpy())
     check_digest(g, 't.rpn_bbox_targets', T['rpn_bbox_targets'])
     check_digest(g, 't.rpn_bbox_outside', T['rpn_bbox_outside'])
@@ -77,7 +77,7 @@ def test_train_step_tiny():
     _run_e2e('tiny')
 
 
-@pytest.mark.parametrize('variant', ['baseline', 'spatial', 'response', 'cycle_response'])
+@pytest.mark.parametrize('variant', ['baseline', 'spatial', 'response', 'cycle_response', 'vgg'])
 def test_train_step_tiny_variants(variant):
     """the reference's other ResNet network variants (network.py, network_7f.py, network_7f_response.py,
     network_cycle_response.py): losses (incl. the response BCE), targets, gradients, post-SGD weights."""
