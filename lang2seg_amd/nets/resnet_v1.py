@@ -304,6 +304,97 @@ class resnetv1(Network):
         self.att_embed.dgrad(dadT, L, 1, 1, datt)
         return datt
 
+    # ------------------------------------------------------------------ backbone / RoI-head hooks (overridden by the VGG variant)
+    def _backbone_fwd(self, d, saved):
+        """conv1/bn1/relu/maxpool/layer1-3 (RES:261-265,309-310) -> (C4 map [H*W][1024], Hc, Wc)."""
+        P = self.P
+        H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
+        OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        c1 = self.buf('stem.c1', (OH1 * OW1, 64))
+        O.stem_conv(d['data'], P.frozen['resnet.conv1.weight'], P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'],
+                    c1, H, W, OH1, OW1)
+        h, w = (OH1 + 2 - 3) // 2 + 1, (OW1 + 2 - 3) // 2 + 1
+        x = self.buf('stem.pool', (h * w, 64))
+        O.maxpool(c1, x, OH1, OW1, 64, h, w)
+        self._mark('stem')
+        for li in (1, 2, 3):
+            for b, blk in enumerate(self.layers[li]):
+                x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
+                saved[(li, b)] = sv
+        return x, h, w
+
+    def _backbone_bwd(self, dbase, saved, S, main, dp):
+        """layer3, layer2 (layer1 and the stem are frozen: RES:290-299)"""
+        g = dbase
+        fb = cfg.RESNET.FIXED_BLOCKS
+        for li in (3, 2, 1):
+            if li <= fb:
+                break
+            for b in reversed(range(len(self.layers[li]))):
+                g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
+            if dp is not None and li == 3:
+                if S is not None:
+                    self.sfork(S['lang'], main)
+                dp.ready('layer3')                        # everything except layer2 is final
+
+    def _roi_head_fwd(self, net_conv, Hc, Wc, rois, R, FGM, saved):
+        """RoI head (NET:572-586): crop-pool -> layer4 -> average -> (cls | bbox) heads, mask head on the first FGM RoI slots.
+        Returns (heads [R][NPC] f32, NPC, mask scores or None)."""
+        P, dt, t = self.P, self.dt, self.t
+        C4, nc = self._C4_feat_dim, self._num_classes
+        PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
+        pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
+        O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5)
+        x, hh, ww = pool5, PS, PS
+        for b, blk in enumerate(self.layers[4]):
+            x, hh, ww, sv = blk.fwd(x, R, hh, ww, 'l4r.%d' % b)
+            saved[('4r', b)] = sv
+        fc7s = x
+        fc7 = self.buf('roi.fc7', (R, 2048))
+        O.avgpool_fwd(fc7s, fc7, R, PS * PS, 2048)
+        NPC = P.rcnn_npad
+        cheads = self.buf('roi.heads', (R, NPC), f32)
+        self.rcnn_heads.fwd(fc7, R, 1, 1, cheads, out_f32=True)
+        up = self.buf('mask.up', (FGM * MS * MS, 256))
+        O.conv_igemm(fc7s, self.up_wT, up, FGM, PS, PS, 2048, PS, PS, 4 * 256, bias=P.view('mask_up_sampling.bias'), relu=True, deconv=True, dt=dt)
+        mscore = self.buf('mask.score', (FGM * MS * MS, nc), f32)
+        self.mask_pred.fwd(up, FGM, MS, MS, mscore, out_f32=True)
+        t.update({'pool5': pool5, 'spatial_fc7': fc7s, 'rcnn_heads': cheads, 'mask_score': mscore})
+        saved['roi'] = (fc7s, fc7, up)
+        return cheads, NPC, mscore
+
+    def _roi_head_bwd(self, d_cheads, dscore, labels, counts, rois, Hc, Wc, R, FGM, saved):
+        """adjoint of _roi_head_fwd -> d(net_conv) [H*W][C4] f32 (RoIAlign scatter)."""
+        P, dt = self.P, self.dt
+        C4 = self._C4_feat_dim
+        PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
+        fc7s, fc7, up = saved['roi']
+        HW = Hc * Wc
+        # rcnn heads -> fc7 -> spatial_fc7
+        self.rcnn_heads.wgrad(d_cheads, fc7, R, 1, 1)
+        dfc7 = self.buf('roi.dfc7', (R, 2048))
+        self.rcnn_heads.dgrad(d_cheads, R, 1, 1, dfc7)
+        # mask head
+        dup = self.buf('mask.dup', (FGM * MS * MS, 256))
+        O.maskpred_bwd(dscore, labels, counts, FGM, MS * MS, 256, P.view('mask_pred_net.weight'), up, up, dup,
+                       P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad))
+        with self.fork_wgrad():
+            O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
+            O.conv_wgrad(fc7s, dup, P.view('mask_up_sampling.weight', P.grad), FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0)
+        dmask_fc7 = self.buf('mask.dfc7s', (FGM * PS * PS, 2048))
+        O.conv_igemm(dup, P.view('mask_up_sampling.weight', P.shadow), dmask_fc7, FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0, dt=dt)
+        g = self.buf('l4r.g', (R * PS * PS, 2048))
+        O.avgpool_bwd(dfc7, g, dmask_fc7, fc7s, FGM, PS * PS, 2048)
+        if R > FGM:
+            off = FGM * PS * PS
+            O.avgpool_bwd(dfc7[FGM:], g[off:], None, fc7s[off:], R - FGM, PS * PS, 2048)
+        for b in reversed(range(len(self.layers[4]))):
+            g = self.layers[4][b].bwd(g, saved[('4r', b)], 'l4r.%d' % b, x_is_relu_out=(b > 0))
+        self._mark('roi head bwd')
+        d_nc_roi = self.buf('roi.dfeat', (HW, C4), f32, zero=True)
+        O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
+        return d_nc_roi
+
     # ------------------------------------------------------------------ the step
     keep_logprobs = False
 
@@ -341,22 +432,9 @@ class resnetv1(Network):
                     self._r_one = torch.tensor([1.0, 0, 0, 0, 0, 0, 0], dtype=f32, device=self.device)
                 O.memcpy(filt[7 * C4:], self._r_one)
         self._mark('encoder_fwd(lang)')
-        # ---- head: conv1/bn1/relu/maxpool/layer1-3 (RES:261-265,309-310) ----
-        OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        c1 = self.buf('stem.c1', (OH1 * OW1, 64))
-        O.stem_conv(d['data'], P.frozen['resnet.conv1.weight'], P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'],
-                    c1, H, W, OH1, OW1)
-        h, w = (OH1 + 2 - 3) // 2 + 1, (OW1 + 2 - 3) // 2 + 1
-        x = self.buf('stem.pool', (h * w, 64))
-        O.maxpool(c1, x, OH1, OW1, 64, h, w)
-        self._mark('stem')
         saved = {}
-        for li in (1, 2, 3):
-            for b, blk in enumerate(self.layers[li]):
-                x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
-                saved[(li, b)] = sv
+        base, Hc, Wc = self._backbone_fwd(d, saved)
         self._mark('layer1-3 fwd')
-        base, Hc, Wc = x, h, w
         HW = Hc * Wc
         t['net_conv_base'] = base
         # ---- dynamic filters (NET:504-562) ----
@@ -479,24 +557,7 @@ class resnetv1(Network):
                           TR.BG_THRESH_LO, cst['means'], cst['stds'], cst['inw'], nc, MS, rois, labels, bt, bi, bo, mt, counts, pws)
         t.update({'rois': rois, 'labels': labels, 'bbox_targets': bt, 'bbox_inside': bi, 'bbox_outside': bo, 'mask_targets': mt, 'counts': counts})
         self._mark('targets')
-        # ---- RoI head (NET:572-586) ----
-        pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
-        O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5)
-        x, hh, ww = pool5, PS, PS
-        for b, blk in enumerate(self.layers[4]):
-            x, hh, ww, sv = blk.fwd(x, R, hh, ww, 'l4r.%d' % b)
-            saved[('4r', b)] = sv
-        fc7s = x
-        fc7 = self.buf('roi.fc7', (R, 2048))
-        O.avgpool_fwd(fc7s, fc7, R, PS * PS, 2048)
-        NPC = P.rcnn_npad
-        cheads = self.buf('roi.heads', (R, NPC), f32)
-        self.rcnn_heads.fwd(fc7, R, 1, 1, cheads, out_f32=True)
-        up = self.buf('mask.up', (FGM * MS * MS, 256))
-        O.conv_igemm(fc7s, self.up_wT, up, FGM, PS, PS, 2048, PS, PS, 4 * 256, bias=P.view('mask_up_sampling.bias'), relu=True, deconv=True, dt=dt)
-        mscore = self.buf('mask.score', (FGM * MS * MS, nc), f32)
-        self.mask_pred.fwd(up, FGM, MS, MS, mscore, out_f32=True)
-        t.update({'pool5': pool5, 'spatial_fc7': fc7s, 'rcnn_heads': cheads, 'mask_score': mscore})
+        cheads, NPC, mscore = self._roi_head_fwd(net_conv, Hc, Wc, rois, R, FGM, saved)
         self._mark('roi head fwd')
         # ---- detection losses + head gradients (NET:375-413) ----
         d_rheads = self.buf('rpn.dheads', (HW, NPR)); d_cheads = self.buf('roi.dheads', (R, NPC)); dscore = self.buf('mask.dscore', (FGM * MS * MS,), f32)
@@ -504,7 +565,8 @@ class resnetv1(Network):
             self.sfork(S['lang'], main)                    # anchor targets
         O.rpn_loss(rheads, NPR, rl, rt, ri, ro, Hc, Wc, A, 3.0, 1.0, loss, d_rheads, NPR, atl_ws=aws)
         O.rcnn_loss(cheads, NPC, labels, bt, bi, bo, R, nc, 1.0, loss, d_cheads, NPC)
-        O.mask_loss(mscore, nc, labels, mt, counts, FGM, MS * MS, 1.0, loss, dscore)
+        if mscore is not None:
+            O.mask_loss(mscore, nc, labels, mt, counts, FGM, MS * MS, 1.0, loss, dscore)
         # =================================== backward (detection side, main stream) ===================================
         dp = self.dp
         if not backward:
@@ -514,29 +576,7 @@ class resnetv1(Network):
             t['loss'] = loss
             return loss
         self._mark('losses')
-        # rcnn heads -> fc7 -> spatial_fc7
-        self.rcnn_heads.wgrad(d_cheads, fc7, R, 1, 1)
-        dfc7 = self.buf('roi.dfc7', (R, 2048))
-        self.rcnn_heads.dgrad(d_cheads, R, 1, 1, dfc7)
-        # mask head
-        dup = self.buf('mask.dup', (FGM * MS * MS, 256))
-        O.maskpred_bwd(dscore, labels, counts, FGM, MS * MS, 256, P.view('mask_pred_net.weight'), up, up, dup,
-                       P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad))
-        with self.fork_wgrad():
-            O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
-            O.conv_wgrad(fc7s, dup, P.view('mask_up_sampling.weight', P.grad), FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0)
-        dmask_fc7 = self.buf('mask.dfc7s', (FGM * PS * PS, 2048))
-        O.conv_igemm(dup, P.view('mask_up_sampling.weight', P.shadow), dmask_fc7, FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0, dt=dt)
-        g = self.buf('l4r.g', (R * PS * PS, 2048))
-        O.avgpool_bwd(dfc7, g, dmask_fc7, fc7s, FGM, PS * PS, 2048)
-        if R > FGM:
-            off = FGM * PS * PS
-            O.avgpool_bwd(dfc7[FGM:], g[off:], None, fc7s[off:], R - FGM, PS * PS, 2048)
-        for b in reversed(range(len(self.layers[4]))):
-            g = self.layers[4][b].bwd(g, saved[('4r', b)], 'l4r.%d' % b, x_is_relu_out=(b > 0))
-        self._mark('roi head bwd')
-        d_nc_roi = self.buf('roi.dfeat', (HW, C4), f32, zero=True)
-        O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
+        d_nc_roi = self._roi_head_bwd(d_cheads, dscore, labels, counts, rois, Hc, Wc, R, FGM, saved)
         self._mark('roialign bwd')
         # rpn
         self.rpn_heads.wgrad(d_rheads, rpn, 1, Hc, Wc)
@@ -574,18 +614,7 @@ class resnetv1(Network):
             self.bwd_x(dfilt, 'dyn_w', dhidden, 1)
             self._encoder_bwd(d, dhidden)
         self._mark('dyn bwd + language bwd(lang)')
-        # backbone layer3, layer2 (layer1 and the stem are frozen: RES:290-299)
-        g = dbase
-        fb = cfg.RESNET.FIXED_BLOCKS
-        for li in (3, 2, 1):
-            if li <= fb:
-                break
-            for b in reversed(range(len(self.layers[li]))):
-                g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
-            if dp is not None and li == 3:
-                if S is not None:
-                    self.sfork(S['lang'], main)
-                dp.ready('layer3')                        # everything except layer2 is final
+        self._backbone_bwd(dbase, saved, S, main, dp)
         self._mark('layer3-2 bwd')
         if S is not None:
             self.sfork(S['lang'], main)
