@@ -79,6 +79,14 @@ int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype
 /* stem: conv 7x7 s2 p3 (3->64) + frozen-BN affine + ReLU (RES:121-124), input float NHWC; then maxpool k3 s2 p1 (RES:126) */
 int l2s_stem_conv(const float* img, const float* w /*[64][7][7][3]*/, const float* scale, const float* bias,
                   void* y, int H, int W, int OH, int OW, int dtype, hipStream_t s);
+/* VGG16 variant (nets/vgg16.py:43-54, network_vgg.py:139-143): conv1_1 (3 -> 64, 3x3, pad 1, bias, ReLU) on the fp32 NHWC image with
+ * weights [64][3][3][3]; 2x2 / stride-2 max pooling (floor mode) forward / backward over n_img NHWC maps [IH][IW][C] (also the
+ * 14x14 -> 7x7 pool behind the crop-pool).  relu_out != 0: x is a ReLU output, dx is the gradient of its pre-activation. */
+/* out = x * mask (fp32 scaled dropout mask), zero where relu_ref <= 0 (nullable): dropout forward / backward of fc6 and fc7 */
+int l2s_scale_mask(const void* x, const float* mask, const void* relu_ref, void* out, long n, int dtype, hipStream_t s);
+int l2s_conv3x3_c3(const float* img, const float* w, const float* bias, void* y, int H, int W, int dtype, hipStream_t s);
+int l2s_maxpool2x2_fwd(const void* x, void* y, int n_img, int IH, int IW, int C, int dtype, hipStream_t s);
+int l2s_maxpool2x2_bwd(const void* dy, const void* x, void* dx, int n_img, int IH, int IW, int C, int relu_out, int dtype, hipStream_t s);
 int l2s_maxpool3x3s2(const void* x, void* y, int IH, int IW, int C, int OH, int OW, int dtype, hipStream_t s);
 
 /* ---------------------------------------------------------------- pooling / elementwise ---- */

@@ -89,6 +89,10 @@ SIGS = {
     'l2s_lstm_cell_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_dynfilter_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_dynfilter_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'l2s_scale_mask': (i32, [vp, vp, vp, vp, C.c_long, i32, vp]),
+    'l2s_conv3x3_c3': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    'l2s_maxpool2x2_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'l2s_maxpool2x2_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_rcnn_predict': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_mask_prob': (i32, [vp, i32, i32, vp, i32, C.c_long, vp, vp]),
     'l2s_response_loss': (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),

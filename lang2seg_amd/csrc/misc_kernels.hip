@@ -158,6 +158,77 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   }
 }
 
+
+// ---- VGG16 variant (nets/vgg16.py:43-54): first convolution (3 -> 64, 3x3, pad 1, bias, ReLU; frozen, forward only) on the
+// fp32 NHWC image, same layout trick as the stem kernel (weights [64][3][3][3] staged as [tap*3+c][64]) ----
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        void* y, int H, int W, int dt) {
+  __shared__ float ws[27 * 64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) { int k = i >> 6, co = i & 63; ws[i] = w[co * 27 + k]; }
+  __syncthreads();
+  const int cg = threadIdx.x & 3;
+  const long pix = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (pix >= (long)H * W) return;
+  const int oy = (int)(pix / W), ox = (int)(pix - (long)oy * W);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      const float* px = img + ((long)iy * W + ix) * 3;
+      const float* wk = ws + ((ky * 3 + kx) * 3) * 64 + cg * 16;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = px[c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(v, wk[c * 64 + i], acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int co = cg * 16 + i; stx(y, pix * 64 + co, dt, fmaxf(acc[i] + bias[co], 0.f)); }
+}
+// 2x2 / stride 2 max pooling, floor mode (nn.MaxPool2d(2, 2)), NHWC, n_img images
+__global__ void maxpool2x2_fwd_kernel(const void* x, void* y, int n_img, int IH, int IW, int C, int OH, int OW, int dt) {
+  const long total = (long)n_img * OH * OW * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long p = i / C; const int ox = (int)(p % OW); p /= OW; const int oy = (int)(p % OH); const long n = p / OH;
+    const long b = ((n * IH + 2 * oy) * IW + 2 * ox) * C + c;
+    const float m = fmaxf(fmaxf(ldx(x, b, dt), ldx(x, b + C, dt)), fmaxf(ldx(x, b + (long)IW * C, dt), ldx(x, b + (long)IW * C + C, dt)));
+    stx(y, i, dt, m);
+  }
+}
+// backward: the whole gradient goes to the first maximum of the window in (row, column) order (ATen max_pool2d backward);
+// relu != 0: x is a ReLU output and dx is the gradient w.r.t. its pre-activation (zero where the maximum is 0).
+// Rows / columns not covered by a window (odd sizes) get 0.
+__global__ void maxpool2x2_bwd_kernel(const void* dy, const void* x, void* dx, int n_img, int IH, int IW, int C, int OH, int OW, int dt, int relu) {
+  const int WH = (IH + 1) / 2, WW = (IW + 1) / 2;         // windows incl. the partial ones at the odd border
+  const long total = (long)n_img * WH * WW * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long p = i / C; const int wx = (int)(p % WW); p /= WW; const int wy = (int)(p % WH); const long n = p / WH;
+    const long b = ((n * IH + 2 * wy) * IW + 2 * wx) * C + c;
+    const bool full = wy < OH && wx < OW;
+    if (!full) {                                           // border strip outside every pooling window
+      stx(dx, b, dt, 0.f);
+      if (2 * wx + 1 < IW) stx(dx, b + C, dt, 0.f);
+      if (2 * wy + 1 < IH) { stx(dx, b + (long)IW * C, dt, 0.f); if (2 * wx + 1 < IW) stx(dx, b + (long)IW * C + C, dt, 0.f); }
+      continue;
+    }
+    const long o[4] = {b, b + C, b + (long)IW * C, b + (long)IW * C + C};
+    float m = ldx(x, o[0], dt); int am = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const float v = ldx(x, o[k], dt); if (v > m) { m = v; am = k; } }
+    float g = ldx(dy, ((n * OH + wy) * OW + wx) * C + c, dt);
+    if (relu && !(m > 0.f)) g = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stx(dx, o[k], dt, k == am ? g : 0.f);
+  }
+}
+
 __global__ void maxpool_kernel(const void* x, void* y, int IH, int IW, int C, int OH, int OW, int dt) {
   const long total = (long)OH * OW * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -182,6 +253,14 @@ __global__ void cast_kernel(const void* s, int sd, void* d, int dd, long n) {
 }
 __global__ void mul_kernel(const float* a, const float* b, float* o, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
+}
+// out = x * mask (fp32 dropout mask), zeroed where relu_ref <= 0 when relu_ref is given (dropout forward / backward of fc6, fc7)
+__global__ void scale_mask_kernel(const void* x, const float* mask, const void* ref, void* out, long n, int dt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = ldx(x, i, dt) * mask[i];
+    if (ref && !(ldx(ref, i, dt) > 0.f)) v = 0.f;
+    stx(out, i, dt, v);
+  }
 }
 __global__ void add3_kernel(const void* a, const void* b, const float* c, void* d, long n, int dt) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -359,6 +438,21 @@ extern "C" int l2s_stem_conv(const float* img, const float* w, const float* scal
   L2S_LAUNCH(stem_kernel, dim3(cdiv((long)OH * OW, 64)), dim3(256), 0, s, img, w, scale, bias, y, H, W, OH, OW, dtype);
   return l2s_check_launch();
 }
+extern "C" int l2s_conv3x3_c3(const float* img, const float* w, const float* bias, void* y, int H, int W, int dtype, hipStream_t s) {
+  L2S_LAUNCH(conv3x3_c3_kernel, dim3(cdiv((long)H * W, 64)), dim3(256), 0, s, img, w, bias, y, H, W, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_maxpool2x2_fwd(const void* x, void* y, int n_img, int IH, int IW, int C, int dtype, hipStream_t s) {
+  const int OH = IH / 2, OW = IW / 2;
+  L2S_LAUNCH(maxpool2x2_fwd_kernel, dim3(grid_for((long)n_img * OH * OW * C)), dim3(256), 0, s, x, y, n_img, IH, IW, C, OH, OW, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_maxpool2x2_bwd(const void* dy, const void* x, void* dx, int n_img, int IH, int IW, int C, int relu_out, int dtype, hipStream_t s) {
+  const int OH = IH / 2, OW = IW / 2;
+  L2S_LAUNCH(maxpool2x2_bwd_kernel, dim3(grid_for((long)n_img * ((IH + 1) / 2) * ((IW + 1) / 2) * C)), dim3(256), 0, s, dy, x, dx, n_img, IH, IW, C, OH, OW,
+             dtype, relu_out);
+  return l2s_check_launch();
+}
 extern "C" int l2s_maxpool3x3s2(const void* x, void* y, int IH, int IW, int C, int OH, int OW, int dtype, hipStream_t s) {
   L2S_LAUNCH(maxpool_kernel, dim3(grid_for((long)OH * OW * C)), dim3(256), 0, s, x, y, IH, IW, C, OH, OW, dtype);
   return l2s_check_launch();
@@ -374,6 +468,10 @@ extern "C" int l2s_cast(const void* src, int sd, void* dst, int dd, long n, hipS
 }
 extern "C" int l2s_mul_f32(const float* a, const float* b, float* out, long n, hipStream_t s) {
   L2S_LAUNCH(mul_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
+  return l2s_check_launch();
+}
+extern "C" int l2s_scale_mask(const void* x, const float* mask, const void* relu_ref, void* out, long n, int dtype, hipStream_t s) {
+  L2S_LAUNCH(scale_mask_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, mask, relu_ref, out, n, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s) {

@@ -46,8 +46,10 @@ class ConvOp(object):
                 self.w_master = P.frozen[wkey].view(-1)
                 self.w_grad = None
                 self.wf = O.empty((cnt,), net.dt)
-            if bias_key is not None:
+            if bias_key is not None and bias_key in P.offsets:
                 self.bias = P.view(bias_key); self.bias_grad = P.view(bias_key, P.grad)
+            elif bias_key is not None:                      # frozen layer with a plain bias (VGG conv1_1 .. conv2_2)
+                self.bias = P.frozen[bias_key]; self.bias_grad = None
             else:
                 self.bias = P.bn_bias.get(wkey); self.bias_grad = None
         self.wb = O.empty((cnt,), net.dt) if (need_dgrad and self.trainable) else None

@@ -19,6 +19,10 @@ BN_EPS = 1e-5
 
 
 def to_internal(name, t):
+    if name == 'vgg.classifier.0.weight':
+        # fc6 reads pool5.view(n, -1) of an NCHW tensor (vgg16.py:84-86): columns (c, y, x) -> the NHWC order (y, x, c), i.e. the
+        # weight of a 7x7 'valid' convolution [O][KH][KW][I]
+        return t.view(t.shape[0], 512, 7, 7).permute(0, 2, 3, 1).contiguous().view(t.shape[0], -1)
     if t.dim() == 4 and name == 'mask_up_sampling.weight':
         return t.permute(0, 2, 3, 1).contiguous()          # (Cin,Cout,2,2) -> [ci][dy][dx][co]
     if t.dim() == 4:
@@ -27,6 +31,8 @@ def to_internal(name, t):
 
 
 def from_internal(name, t, ref_shape):
+    if name == 'vgg.classifier.0.weight':
+        return t.view(ref_shape[0], 7, 7, 512).permute(0, 3, 1, 2).contiguous().view(ref_shape)
     if len(ref_shape) == 4 and name == 'mask_up_sampling.weight':
         ci, co, kh, kw = ref_shape
         return t.view(ci, kh, kw, co).permute(0, 3, 1, 2).contiguous()
@@ -43,6 +49,8 @@ class ParamStore(object):
         self.variant, self.var = variant, VARIANTS[variant]
         self.num_classes, self.A = num_classes, num_anchors
         self.nblocks = RESNET_LAYERS[num_layers]
+        self.is_vgg = self.var.get('backbone') == 'vgg'
+        self.fc7_dim = 4096 if self.is_vgg else 2048
         self.fixed_blocks = fixed_blocks
         self.shapes = self._shapes()
         self._layout()
@@ -73,6 +81,8 @@ class ParamStore(object):
         def bn(p, c):
             for k in ['weight', 'bias', 'running_mean', 'running_var']:
                 s[p + '.' + k] = (c,)
+        if self.is_vgg:
+            return self._shapes_vgg(s)
         s['resnet.conv1.weight'] = (64, 3, 7, 7); bn('resnet.bn1', 64)
         inpl = 64
         for li, (planes, nb) in enumerate(zip([64, 128, 256, 512], self.nblocks), 1):
@@ -102,7 +112,41 @@ class ParamStore(object):
         s['mask_pred_net.weight'] = (nc, 256, 1, 1); s['mask_pred_net.bias'] = (nc,)
         return s
 
+    VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]   # torchvision 'D' minus the last pool
+
+    @classmethod
+    def vgg_layers(cls):
+        """[('conv', index in vgg.features, Cin, Cout) | ('pool', index)] in execution order (vgg16.py:53-54)."""
+        out, i, cin = [], 0, 3
+        for v in cls.VGG_CFG:
+            if v == 'M':
+                out.append(('pool', i)); i += 1
+            else:
+                out.append(('conv', i, cin, v)); cin = v; i += 2
+        return out
+
+    def _shapes_vgg(self, s):
+        o = self.opt
+        for l in self.vgg_layers():
+            if l[0] == 'conv':
+                s['vgg.features.%d.weight' % l[1]] = (l[3], l[2], 3, 3); s['vgg.features.%d.bias' % l[1]] = (l[3],)
+        s['vgg.classifier.0.weight'] = (4096, 512 * 7 * 7); s['vgg.classifier.0.bias'] = (4096,)
+        s['vgg.classifier.3.weight'] = (4096, 4096); s['vgg.classifier.3.bias'] = (4096,)
+        C4 = o['C4_feat_dim']; HD = o['rnn_num_layers'] * (2 if o['bidirectional'] else 1) * o['rnn_hidden_size']
+        for k in range(7):
+            s['dynamic_fc_%d.weight' % k] = (C4, HD); s['dynamic_fc_%d.bias' % k] = (C4,)
+        s['response_fc.weight'] = (7, HD); s['response_fc.bias'] = (7,)
+        A, nc = self.A, self.num_classes
+        s['rpn_net.weight'] = (512, C4, 3, 3); s['rpn_net.bias'] = (512,)
+        s['rpn_cls_score_net.weight'] = (2 * A, 512, 1, 1); s['rpn_cls_score_net.bias'] = (2 * A,)
+        s['rpn_bbox_pred_net.weight'] = (4 * A, 512, 1, 1); s['rpn_bbox_pred_net.bias'] = (4 * A,)
+        s['cls_score_net.weight'] = (nc, 4096); s['cls_score_net.bias'] = (nc,)
+        s['bbox_pred_net.weight'] = (4 * nc, 4096); s['bbox_pred_net.bias'] = (4 * nc,)
+        return s
+
     def is_trainable(self, k):
+        if k.startswith('vgg.features.'):
+            return int(k.split('.')[2]) >= 10              # vgg16.py:49-51: layers before conv3 are fixed
         """RES:290-306: conv1/bn1, layer1..FIXED_BLOCKS and every BN tensor are frozen; resnet.fc never gets a gradient."""
         if k.startswith('resnet.'):
             if '.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1') or k.startswith('resnet.conv1') or k.startswith('resnet.fc'):
@@ -135,6 +179,8 @@ class ParamStore(object):
             sel = [k for k in tr if pred(k) and k not in order]
             order.extend(sel)
         take(lambda k: k.startswith('caption_model.'))
+        take(lambda k: k.startswith('vgg.classifier.3.'))
+        take(lambda k: k.startswith('vgg.classifier.0.'))
         for b in reversed(range(self.nblocks[3])):
             take(lambda k: k.startswith('resnet.layer4.%d.' % b))
         # grouped heads (contiguous on purpose: they are used as one concatenated GEMM operand)
@@ -145,8 +191,8 @@ class ParamStore(object):
             'dyn_w': ['dynamic_fc.weight'] if self.var['nfilt'] == 1 else ['dynamic_fc_%d.weight' % k for k in range(7)] + ['response_fc.weight'],
             'dyn_b': ['dynamic_fc.bias'] if self.var['nfilt'] == 1 else ['dynamic_fc_%d.bias' % k for k in range(7)] + ['response_fc.bias'],
         }
-        plan = ['@rcnn_w', '@rcnn_b', 'mask_up_sampling.weight', 'mask_up_sampling.bias', 'mask_pred_net.weight', 'mask_pred_net.bias',
-                'rpn_net.weight', 'rpn_net.bias', '@rpn_head_w', '@rpn_head_b', '@dyn_w', '@dyn_b']
+        plan = ['@rcnn_w', '@rcnn_b'] + ([] if self.is_vgg else ['mask_up_sampling.weight', 'mask_up_sampling.bias', 'mask_pred_net.weight', 'mask_pred_net.bias']) + \
+               ['rpn_net.weight', 'rpn_net.bias', '@rpn_head_w', '@rpn_head_b', '@dyn_w', '@dyn_b']
         self.offsets, self.group_off = {}, {}
         off = 0
         def place(k, align=True):
@@ -168,7 +214,7 @@ class ParamStore(object):
                 for k in self.groups[g]:
                     place(k, align=False)        # members of a group are back to back
                 if g == 'rcnn_w':
-                    off += (self.rcnn_npad - self.rcnn_n) * 2048
+                    off += (self.rcnn_npad - self.rcnn_n) * self.fc7_dim
                 elif g == 'rcnn_b':
                     off += self.rcnn_npad - self.rcnn_n
                 elif g == 'rpn_head_w':
@@ -182,6 +228,10 @@ class ParamStore(object):
         rest_pred = [lambda k: k.startswith('rnn_encoder.')]
         for p in rest_pred:
             for k in [k for k in tr if p(k) and k not in self.offsets]:
+                off = (off + 63) // 64 * 64
+                place(k)
+        for i in reversed(range(31)):
+            for k in [k for k in tr if k.startswith('vgg.features.%d.' % i) and k not in self.offsets]:
                 off = (off + 63) // 64 * 64
                 place(k)
         for li in (3, 2, 1):
@@ -243,7 +293,7 @@ class ParamStore(object):
             if k in self.offsets:
                 self.view(k).copy_(ti)
             else:
-                self.frozen[k].copy_(ti.view(self.frozen[k].shape) if k != 'resnet.conv1.weight' else ti.view(64, 7, 7, 3).reshape(self.frozen[k].shape))
+                self.frozen[k].copy_(ti.view(self.frozen[k].shape))
         self._fold_bn()
         self.refresh_shadow_full()
 
@@ -253,10 +303,8 @@ class ParamStore(object):
             if k in self.offsets:
                 out[k] = from_internal(k, self.view(k).detach().clone(), shp).cpu()
             else:
-                t = self.frozen[k].detach().clone()
-                if k == 'resnet.conv1.weight':
-                    t = t.view(64, 7, 7, 3).permute(0, 3, 1, 2).contiguous()
-                out[k] = t.cpu()
+                # frozen tensors hold the internal (OHWI) order inside a reference-shaped allocation
+                out[k] = from_internal(k, self.frozen[k].detach().clone().reshape(-1), shp).cpu()
         return out
 
     def _fold_bn(self):

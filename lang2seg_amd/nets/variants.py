@@ -15,6 +15,9 @@ VARIANTS = {
     'response': dict(nfilt=7, gate='sigmoid', cap=None),           # nets/resnet_v1_7f_response.py train_response.sh
     'cycle': dict(nfilt=7, gate='linear', cap='mask'),             # nets/resnet_v1_cycle_res5_2.py train_cycle.sh
     'cycle_response': dict(nfilt=7, gate='sigmoid', cap='before_after'),   # nets/resnet_v1_cycle_response.py train_cycle_response.sh
+    # VGG16 / Faster R-CNN variant (nets/vgg16.py + nets/network_vgg.py, train_vgg.sh): conv5_3 map, 14x14 crop + 2x2 max pool,
+    # fc6 / fc7, no mask branch, sigmoid gating + response loss
+    'vgg': dict(nfilt=7, gate='sigmoid', cap=None, backbone='vgg', mask=False),
 }
 _ALL = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_response', 'loss_caption', 'total_loss']
 # slot of each loss in the device loss[8] buffer (include/lang2seg_hip.h L2S_LOSS_*)
@@ -24,4 +27,5 @@ SLOT = dict(rpn_cross_entropy=0, rpn_loss_box=1, cross_entropy=2, loss_box=3, lo
 def loss_names(variant):
     """order of the floats `train_step` returns in that variant (NET:702-719 and its siblings)."""
     v = VARIANTS[variant]
-    return [k for k in _ALL if not (k == 'loss_response' and v['gate'] != 'sigmoid') and not (k == 'loss_caption' and v['cap'] is None)]
+    return [k for k in _ALL if not (k == 'loss_response' and v['gate'] != 'sigmoid') and not (k == 'loss_caption' and v['cap'] is None)
+            and not (k == 'loss_mask' and not v.get('mask', True))]

@@ -124,6 +124,22 @@ def stem_conv(img, w, scale, bias, y, H, W, OH, OW):
     call('l2s_stem_conv', ptr(img), ptr(w), ptr(scale), ptr(bias), ptr(y), H, W, OH, OW, dt_of(y), stream())
 
 
+def scale_mask(x, mask, relu_ref, out):
+    call('l2s_scale_mask', ptr(x), ptr(mask), ptr(relu_ref), ptr(out), x.numel(), dt_of(x), stream())
+
+
+def conv3x3_c3(img, w, bias, y, H, W):
+    call('l2s_conv3x3_c3', ptr(img), ptr(w), ptr(bias), ptr(y), H, W, dt_of(y), stream())
+
+
+def maxpool2x2_fwd(x, y, n_img, IH, IW, Cc):
+    call('l2s_maxpool2x2_fwd', ptr(x), ptr(y), n_img, IH, IW, Cc, dt_of(x), stream())
+
+
+def maxpool2x2_bwd(dy, x, dx, n_img, IH, IW, Cc, relu_out):
+    call('l2s_maxpool2x2_bwd', ptr(dy), ptr(x), ptr(dx), n_img, IH, IW, Cc, int(relu_out), dt_of(x), stream())
+
+
 def maxpool(x, y, IH, IW, Cc, OH, OW):
     call('l2s_maxpool3x3s2', ptr(x), ptr(y), IH, IW, Cc, OH, OW, dt_of(x), stream())
 

@@ -11,7 +11,11 @@ def build_net(opt, cfg_train, dtype='f32', sd=None, num_layers=101, variant='cyc
     for k, v in cfg_train.items():
         cfg.TRAIN[k] = v
     cfg.COMPUTE_DTYPE = dtype
-    net = resnetv1(opt, batch_size=1, num_layers=num_layers, variant=variant)
+    if variant == 'vgg':
+        from .nets.vgg16 import vgg16
+        net = vgg16(opt, batch_size=1)
+    else:
+        net = resnetv1(opt, batch_size=1, num_layers=num_layers, variant=variant)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     if sd is not None:
         net.load_state_dict(sd)

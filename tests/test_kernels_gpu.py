@@ -372,7 +372,7 @@ def test_roialign(dt):
     rois[0, 1:] = [0, 0, 415, 319]
     fd = to_dev(nhwc(feat), dt)
     fr = fd.float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
-    net = ON.OracleNet.__new__(ON.OracleNet); net.cfg = ON.DEFAULT_CFG
+    net = ON.OracleNet.__new__(ON.OracleNet); net.cfg = ON.DEFAULT_CFG; net.var = {}
     ref = net.crop_pool(fr, torch.from_numpy(rois))
     out = O.empty((R * 49, Cc), dt)
     O.roialign_fwd(fd, H, W, Cc, torch.from_numpy(rois).to(DEV), R, 7, 1.0 / 16.0, out)
@@ -668,3 +668,81 @@ def test_sgd_and_misc():
     ob = torch.empty(1000, dtype=torch.bfloat16, device=DEV); O.cast(out, ob)
     torch.cuda.synchronize()
     assert rel_err(out, a + b + c) < 1e-6 and rel_err(ob.float(), (a + b + c)) < 1e-2
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+def test_vgg_kernels(dt):
+    """conv1_1 (3 -> 64), 2x2 max pooling forward / backward (odd sizes, first-maximum rule, ReLU mask), dropout scale-mask."""
+    O = ops()
+    g = torch.Generator().manual_seed(21)
+    H, W = 37, 45
+    img = torch.randn(1, 3, H, W, generator=g) * 30
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.02; b = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(img, w, b, padding=1))
+    y = O.empty((H * W, 64), dt)
+    O.conv3x3_c3(nhwc(img).contiguous().to(DEV), ohwi(w).to(DEV), b.to(DEV), y, H, W)
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(1, H, W, 64), nhwc(ref)) < (1e-5 if dt == 0 else 1e-2)
+    # max pool: quantised inputs so that ties occur and are resolved like ATen (first maximum in scan order)
+    C, n = 24, 3
+    x = (torch.randint(-2, 3, (n, C, H, W), generator=g).float() * 0.5)
+    xd = to_dev(nhwc(x), dt)
+    xr = xd.float().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    pr = F.max_pool2d(xr, 2, 2)
+    OH, OW = H // 2, W // 2
+    yd = O.empty((n * OH * OW, C), dt)
+    O.maxpool2x2_fwd(xd, yd, n, H, W, C)
+    torch.cuda.synchronize()
+    assert torch.equal(yd.float().cpu().view(n, OH, OW, C), nhwc(pr.detach()))
+    dy = torch.randn(n, C, OH, OW, generator=g)
+    dyd = to_dev(nhwc(dy), dt)
+    pr.backward(dyd.float().cpu().permute(0, 3, 1, 2))
+    dxd = torch.full((n * H * W, C), 7.0, device=DEV).to(O.TORCH_DT[dt])
+    O.maxpool2x2_bwd(dyd, xd, dxd, n, H, W, C, False)
+    torch.cuda.synchronize()
+    assert torch.equal(dxd.float().cpu().view(n, H, W, C), nhwc(xr.grad))
+    O.maxpool2x2_bwd(dyd, xd, dxd, n, H, W, C, True)          # x taken as a ReLU output: no gradient where the maximum is <= 0
+    torch.cuda.synchronize()
+    pooled = F.max_pool2d(xd.float().cpu().permute(0, 3, 1, 2), 2, 2)
+    up = F.interpolate((pooled > 0).float(), scale_factor=2, mode='nearest')
+    exp = xr.grad.clone(); exp[:, :, :2 * OH, :2 * OW] *= up
+    assert torch.equal(dxd.float().cpu().view(n, H, W, C), nhwc(exp))
+    # dropout scale / mask
+    v = torch.randn(500, generator=g); m = (torch.rand(500, generator=g) > 0.5).float() * 2; r = torch.randn(500, generator=g)
+    vd, rd = to_dev(v, dt), to_dev(r, dt)
+    out = O.empty((500,), dt)
+    O.scale_mask(vd, m.to(DEV), rd, out)
+    torch.cuda.synchronize()
+    exp = vd.float().cpu() * m * (rd.float().cpu() > 0).float()
+    assert rel_err(out.float(), exp) < (1e-6 if dt == 0 else 1e-2)
+
+
+def test_response_loss_and_test_heads():
+    O = ops()
+    from oracle import boxes as OB
+    g = torch.Generator().manual_seed(22)
+    MH, MW, H, W = 320, 416, 20, 26
+    mask = (torch.rand(MH, MW, generator=g) > 0.6).to(torch.uint8)
+    resp = torch.randn(H, W, generator=g)
+    tgt = torch.from_numpy(OB.imresize_nearest_u8(mask.numpy(), (H, W)).astype(np.float32))
+    rr = resp.clone().requires_grad_(True)
+    l = F.binary_cross_entropy_with_logits(rr, tgt); (l * 0.7).backward()
+    loss = torch.zeros(8, device=DEV); dresp = torch.empty(H * W, device=DEV)
+    O.response_loss(resp.to(DEV).view(-1), mask.to(DEV), MH, MW, H, W, 0.7, loss, dresp)
+    torch.cuda.synchronize()
+    assert abs(loss[7].item() - l.item()) < 1e-6 and rel_err(dresp.view(H, W), rr.grad) < 1e-5
+    # TEST-mode heads
+    R, nc = 37, 81
+    heads = torch.randn(R, 408, generator=g)
+    stds = torch.tensor([0.1, 0.1, 0.2, 0.2]); means = torch.tensor([0.0, 0.01, 0.0, -0.02])
+    cp = torch.empty(R, nc, device=DEV); bp = torch.empty(R, 4 * nc, device=DEV)
+    O.rcnn_predict(heads.to(DEV), 408, R, nc, stds.to(DEV), means.to(DEV), cp, bp)
+    sc = torch.randn(5 * 196, nc, generator=g); lab = torch.tensor([3, 80, 0, 17, 42], dtype=torch.int32)
+    mp_all = torch.empty(5 * 196, nc, device=DEV); mp_l = torch.empty(5 * 196, device=DEV)
+    O.mask_prob(sc.to(DEV), nc, nc, None, 196, 5 * 196, mp_all)
+    O.mask_prob(sc.to(DEV), nc, nc, lab.to(DEV), 196, 5 * 196, mp_l)
+    torch.cuda.synchronize()
+    assert rel_err(cp, F.softmax(heads[:, :nc], 1)) < 1e-6
+    assert rel_err(bp, heads[:, nc:5 * nc] * stds.repeat(nc) + means.repeat(nc)) < 1e-6
+    assert rel_err(mp_all, torch.sigmoid(sc)) < 1e-6
+    assert rel_err(mp_l, torch.sigmoid(sc.view(5, 196, nc)[torch.arange(5), :, lab.long()]).reshape(-1)) < 1e-6

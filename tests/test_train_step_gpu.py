@@ -23,7 +23,7 @@ def _setup(dtype, tag='tiny'):
     return g, opt, sd, blob, ocfg, samp, net
 
 
-@pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response'])
+@pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg'])
 def test_train_step_f32_vs_fixture_and_oracle(tag):
     """every ResNet network variant of the reference (cycle = the benchmarked one; baseline / spatial / response /
     cycle_response are BASELINE.json configs 0, 1, 3 + train_response.sh) against a fixture produced by the reference itself."""
@@ -71,7 +71,8 @@ def test_train_step_f32_vs_fixture_and_oracle(tag):
         gr = from_internal(nme, P.view(nme, P.grad).clone(), P.shapes[nme])
         if nme in P.rowscale_off:                       # stored gradient is w.r.t. the BN-folded weight
             gr = gr * P.bn_scale[nme].view(-1, *([1] * (gr.dim() - 1)))
-        check_digest(g, 'g.' + nme, gr.cpu().numpy(), rtol=5e-4, atol=1e-7)
+        # (the VGG trunk's gradients cross 9 un-normalised 3x3 convolutions and two max-pools: 1e-3 like the full-size test)
+        check_digest(g, 'g.' + nme, gr.cpu().numpy(), rtol=1e-3 if tag == 'tiny_vgg' else 5e-4, atol=1e-7)
     SGD(net, 1e-4).step()
     torch.cuda.synchronize()
     sd1 = net.state_dict()

@@ -32,7 +32,7 @@ def main(args, variant='cycle'):
     loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V, rank=rank)
     opt = dict(args)
     opt['vocab_size'] = loader.vocab_size
-    opt['C4_feat_dim'] = 1024
+    opt['C4_feat_dim'] = 512 if variant == 'vgg' else 1024
     opt['use_att'] = True
     opt['seq_length'] = loader.label_length
     opt['dataset_splitBy'] = args['dataset'] + '_' + args['splitBy']
@@ -41,7 +41,11 @@ def main(args, variant='cycle'):
     if args['set_cfgs']:
         cfg_from_list(args['set_cfgs'])
     cfg.COMPUTE_DTYPE = args['dtype']
-    net = resnetv1(opt, batch_size=1, num_layers=101, variant=variant)
+    if variant == 'vgg':
+        from lang2seg_amd.nets.vgg16 import vgg16
+        net = vgg16(opt, batch_size=1)
+    else:
+        net = resnetv1(opt, batch_size=1, num_layers=101, variant=variant)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.rank_seed = rank * 1000003
     if world > 1:
