@@ -43,6 +43,16 @@ def cpu_baseline(H, W, T, V):
             'sample': '1 train step (600x1000 image, 20 tokens, 256 RoIs, fp32) = %.1f s' % dt}
 
 
+def _pmc_traffic():
+    """PMC counters cannot be read inside the timed run; the committed measurement of the same launch is reported."""
+    import json
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        return float(json.load(open(f))['traffic_bytes'])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -152,7 +162,7 @@ def main():
                        'parallelism': 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12},
             'step_tflops_per_gpu': STEP_FLOP / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': STEP_FLOP / (ms * 1e-3) / PEAK_BF16,
             'roofline': {'bound': 'mfma', 'kernel': 'igemm_sp_kernel<bf16,256,128> on layer4@RoIs conv3x3 (M=%d,N=512,K=4608)' % (R * 49),
-                         'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': None,
+                         'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': _pmc_traffic(), 'traffic_note': 'HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes 30.4 MB',
                          'avg_launch_ms': kms, 'launches_timed': len(evs)},
             'final_losses': [float(x) for x in lv[:7]],
         }

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
 //            second-half fragments
 // so no MFMA ever waits for an LDS read issued after the barrier, and the LDS fill of slice t+2 hides under the MFMAs.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32>
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, bool TAPIN>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv_desc p) {
   constexpr int VE = 16 / (int)sizeof(T);
   constexpr int BK = ROWB / (int)sizeof(T);
@@ -629,6 +629,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
   const int taps = p.KH * p.KW;
   int it = 0, c0 = 0, tap = 0;
   unsigned voffA[NA];
+  // TAPIN (filters with 2..32 taps): K is walked channel-chunk-major, taps innermost, so the 9 taps of a 3x3 filter re-read the
+  // same 128-byte lines of the input within 9 consecutive slices (they hit in L2 / L1) instead of once per full pass over the
+  // channels.  Measured on the dominant launch: the fabric-side read traffic was 21x the algorithmic bytes with the tap-major
+  // walk (profiles/r01_pmc_traffic_before_tap_inner.json).  Per row: byte offset of tap (0,0) + a bit mask of the in-image taps.
+  int vbase[NA]; unsigned tmask[NA];
   auto set_tap = [&](int t) {
     const int ky = t / p.KW, kx = t - ky * p.KW;
 #pragma unroll
@@ -638,15 +643,43 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
       voffA[j] = v ? (unsigned)(((long)(a_base[j] + iy * p.IW + ix) * p.ldx + cv * VE) * (long)sizeof(T)) : OOR;
     }
   };
-  set_tap(0);
+  if (TAPIN) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      vbase[j] = ((a_base[j] + a_iy0[j] * p.IW + a_ix0[j]) * p.ldx + cv * VE) * (int)sizeof(T);
+      unsigned m = 0;
+      for (int t = 0; t < taps; ++t) {
+        const int ky = t / p.KW, kx = t - ky * p.KW;
+        const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+        if (a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) m |= 1u << t;
+      }
+      tmask[j] = m;
+    }
+  } else {
+    set_tap(0);
+  }
   auto issue = [&](uint4 (&a)[NA], uint4 (&b)[NB]) {
-    const int sa = c0 * (int)sizeof(T), sb = it * (BK * (int)sizeof(T));
+    int sa, sb;
+    if (TAPIN) {
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const int toff = (ky * p.IW + kx) * p.ldx * (int)sizeof(T);
+      sa = c0 * (int)sizeof(T); sb = (tap * p.Cin + c0) * (int)sizeof(T);
+#pragma unroll
+      for (int j = 0; j < NA; ++j) voffA[j] = ((tmask[j] >> tap) & 1u) ? (unsigned)(vbase[j] + toff) : OOR;
+    } else {
+      sa = c0 * (int)sizeof(T); sb = it * (BK * (int)sizeof(T));
+    }
 #pragma unroll
     for (int j = 0; j < NA; ++j) a[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, voffA[j], sa, 0));
 #pragma unroll
     for (int j = 0; j < NB; ++j) b[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, voffB[j], sb, 0));
-    ++it; c0 += BK;
-    if (c0 >= p.Cin && taps > 1) { c0 = 0; ++tap; if (tap < taps) set_tap(tap); }
+    ++it;
+    if (TAPIN) {
+      if (++tap == taps) { tap = 0; c0 += BK; }
+    } else {
+      c0 += BK;
+      if (c0 >= p.Cin && taps > 1) { c0 = 0; ++tap; if (tap < taps) set_tap(tap); }
+    }
   };
   auto store_slice = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
     char* a = smem + buf * BUF + lrow * ROWB + wchunk;
@@ -1267,14 +1300,14 @@ int launch_igemm_ring(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32>
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, bool TAPIN>
 int launch_igemm_sp(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN));
   size_t lds = (size_t)3 * (BM + BN) * ROWB;
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  L2S_LAUNCH((igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32>), grid, dim3(64 * WGM * WGN), lds, st, d);
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32, TAPIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32, TAPIN>), grid, dim3(64 * WGM * WGN), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -1352,8 +1385,12 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     if (ok) {
 #define GR(T, BM, BN, DD, KS) (f32o ? launch_igemm_ring<T, BM, BN, 2, 2, DD, true, KS>(*d, stream) : launch_igemm_ring<T, BM, BN, 2, 2, DD, false, KS>(*d, stream))
 #define GR8(T, BM, BN, DD) (f32o ? launch_igemm_ring<T, BM, BN, 4, 2, DD, true, 1>(*d, stream) : launch_igemm_ring<T, BM, BN, 4, 2, DD, false, 1>(*d, stream))
-#define GSP(T, BM, BN, DD) (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false>(*d, stream))
+#define GSP(T, BM, BN, DD) (tapin ? (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true, true>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false, true>(*d, stream)) \
+                                  : (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true, false>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false, false>(*d, stream)))
       // in-workgroup split-K for the 64x64 tile when the tile grid cannot fill the chip with several workgroups per CU
+      static const int tapin_on = [] { const char* e = getenv("L2S_IGEMM_TAPIN"); return e ? atoi(e) : 1; }();
+      const int ntaps = d->KH * d->KW;
+      const bool tapin = tapin_on && ntaps > 1 && ntaps <= 32 && xb < (1L << 30);
       const int KT = K / bk;
       const long tiles64 = (long)cdiv(M, 64) * cdiv(d->Cout, 64);
       int ks = 1;
