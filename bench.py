@@ -53,6 +53,12 @@ def _pmc_traffic():
         return None
 
 
+# Native libraries print to fd 1 (RCCL writes a five-line version banner there): the contract is ONE JSON line on stdout, so fd 1 is
+# pointed at stderr for the whole run and the JSON line goes to a saved duplicate of the real stdout.
+_REAL_STDOUT = os.dup(1)
+os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -63,15 +69,17 @@ def main():
     ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
     ap.add_argument('--main-prio', type=int, default=0, help='run the main queue on a high-priority HIP stream instead of the null stream')
+    ap.add_argument('--force-dp', type=int, default=0, help='(testing) build the data-parallel reducer even for one rank')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     from lang2seg_amd.model.config import cfg
     from lang2seg_amd.nets.resnet_v1 import resnetv1
     from lang2seg_amd.optim import SGD
@@ -92,8 +100,8 @@ def main():
     net.train()
     net.rank_seed = rank * 1000003
     net.use_graph = bool(args.graph) and world == 1
-    net.use_tape = bool(args.tape) and world == 1
-    if world > 1:
+    net.use_tape = bool(args.tape)          # N > 1: the tape is cut at the gradient-bucket hand-offs (Network.tape_step)
+    if world > 1 or args.force_dp:
         from lang2seg_amd.parallel import GradReducer
         net.dp = GradReducer(net, world)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
@@ -168,8 +176,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.height, args.width, T, V)
-        print(json.dumps(out))
-    if world > 1:
+        os.write(_REAL_STDOUT, (json.dumps(out) + '\n').encode())
+    if world > 1 or args.force_dp:
         torch.distributed.destroy_process_group()
 
 

@@ -271,6 +271,11 @@ void* l2s_tape_begin(const hipStream_t* streams, int n);
 int l2s_tape_end(void* tape);
 long l2s_tape_size(void* tape);
 int l2s_tape_run(void* tape, const hipStream_t* streams, int n);
+/* segments: l2s_tape_mark() (while recording) cuts the tape where the host must act between launches (RCCL all-reduce of a finished
+ * gradient bucket); l2s_tape_run_segment replays segment `seg` in [0, l2s_tape_segments) */
+int l2s_tape_mark(void);
+int l2s_tape_segments(void* tape);
+int l2s_tape_run_segment(void* tape, const hipStream_t* streams, int n, int seg);
 int l2s_tape_destroy(void* tape);
 
 /* ---------------------------------------------------------------- optimizer ---------------- */

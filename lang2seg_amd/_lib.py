@@ -116,6 +116,9 @@ SIGS = {
     'l2s_tape_size': (i64, [vp]),
     'l2s_tape_run': (i32, [vp, vp, i32]),
     'l2s_tape_destroy': (i32, [vp]),
+    'l2s_tape_mark': (i32, []),
+    'l2s_tape_segments': (i32, [vp]),
+    'l2s_tape_run_segment': (i32, [vp, vp, i32, i32]),
 }
 
 _lib = None

@@ -14,8 +14,8 @@
 
 namespace l2s {
 
-struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };   // kind 0 launch, 1 record ev, 2 wait ev
-struct Tape { std::vector<Op> ops; int n_events = 0; std::vector<hipEvent_t> events; };
+struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };   // kind 0 launch, 1 record ev, 2 wait ev, 3 segment mark
+struct Tape { std::vector<Op> ops; int n_events = 0; std::vector<hipEvent_t> events; std::vector<size_t> marks; };
 
 static Tape* g_rec = nullptr;
 static hipStream_t g_streams[8];
@@ -48,17 +48,43 @@ extern "C" int l2s_tape_end(void* tape) {
   if (g_rec != (Tape*)tape || !tape) return L2S_EINVAL;
   Tape* t = g_rec;
   g_rec = nullptr;
-  for (const Op& o : t->ops) if (o.sid < 0) return L2S_EINVAL;     // a launch went to an unregistered stream
+  for (size_t i = 0; i < t->ops.size(); ++i) {
+    if (t->ops[i].kind == 3) t->marks.push_back(i);
+    else if (t->ops[i].sid < 0) return L2S_EINVAL;                  // a launch went to an unregistered stream
+  }
   t->events.resize(t->n_events);
   for (int i = 0; i < t->n_events; ++i)
     if (hipEventCreateWithFlags(&t->events[i], hipEventDisableTiming) != hipSuccess) return L2S_ELAUNCH;
   return L2S_OK;
 }
 extern "C" long l2s_tape_size(void* tape) { return tape ? (long)((Tape*)tape)->ops.size() : -1; }
+// Segments: l2s_tape_mark() splits a tape at the points where the host has to act between launches (the data-parallel
+// gradient all-reduce of a finished bucket goes through torch.distributed / RCCL, which cannot be recorded): segment k is
+// everything between mark k-1 and mark k.
+extern "C" int l2s_tape_mark(void) {
+  if (g_rec) g_rec->ops.push_back(Op{3, 0, -1, nullptr});
+  return L2S_OK;
+}
+extern "C" int l2s_tape_segments(void* tape) { return tape ? (int)((Tape*)tape)->marks.size() + 1 : -1; }
+extern "C" int l2s_tape_run_segment(void* tape, const hipStream_t* streams, int n, int seg) {
+  Tape* t = (Tape*)tape;
+  if (!t || g_rec || seg < 0 || seg > (int)t->marks.size()) return L2S_EINVAL;
+  const size_t lo = seg == 0 ? 0 : t->marks[seg - 1] + 1, hi = seg == (int)t->marks.size() ? t->ops.size() : t->marks[seg];
+  for (size_t i = lo; i < hi; ++i) {
+    const Op& o = t->ops[i];
+    if (o.sid >= n) return L2S_EINVAL;
+    hipStream_t s = streams[o.sid];
+    if (o.kind == 0) o.fn(s);
+    else if (o.kind == 1) { if (hipEventRecord(t->events[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 2) { if (hipStreamWaitEvent(s, t->events[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
+  }
+  return l2s_check_launch();
+}
 extern "C" int l2s_tape_run(void* tape, const hipStream_t* streams, int n) {
   Tape* t = (Tape*)tape;
   if (!t || g_rec) return L2S_EINVAL;
   for (const Op& o : t->ops) {
+    if (o.kind == 3) continue;
     if (o.sid >= n) return L2S_EINVAL;
     hipStream_t s = streams[o.sid];
     if (o.kind == 0) o.fn(s);

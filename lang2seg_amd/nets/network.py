@@ -235,24 +235,50 @@ class Network(object):
         main = torch.cuda.current_stream()
         S = self.streams()
         slist = [main, S['lang'], S['cap'], S['wg'], S['wg2'], S['tr']]
+        dp = self.dp
         if ent is None:
             st = {k: dev[k].clone() for k in ('data', 'gt_boxes', 'gt_masks', 'labels', 'cap_in', 'cap_tgt', 'cap_mask')}
             d = dict(dev); d.update(st)
-            loss = self.forward_backward(d); train_op.step()          # allocates the activation plan for this shape
+            loss = self.forward_backward(d)                           # allocates the activation plan for this shape
+            if dp is not None:
+                dp.finish()
+            train_op.step()
             torch.cuda.synchronize()
             h = O.tape_begin(slist)
+            self._tape_stages = []
             try:
-                loss = self.forward_backward(d); train_op.step()
+                loss = self.forward_backward(d)                       # dp_ready() cuts the tape at every bucket hand-off
+                if dp is not None:
+                    O.tape_mark(); self._tape_stages.append('finish'); dp.finish()
+                train_op.step()
             finally:
                 O.tape_end(h)
-            self._tapes[key] = (h, st, loss)
+            stages, self._tape_stages = self._tape_stages, None
+            self._tapes[key] = (h, st, loss, stages)
             return loss
-        h, st, loss = ent
+        h, st, loss, stages = ent
         for k, v in st.items():
             if v.data_ptr() != dev[k].data_ptr():
                 v.copy_(dev[k], non_blocking=True)
-        O.tape_run(h, slist)
+        if not stages:
+            O.tape_run(h, slist)
+            return loss
+        # data parallel: replay segment by segment; between segments the finished gradient bucket goes to RCCL on the
+        # reducer's stream (torch.distributed cannot be recorded), overlapping with the rest of the backward pass
+        for i, stage in enumerate(stages):
+            O.tape_run_segment(h, slist, i)
+            if stage == 'finish':
+                dp.finish()
+            else:
+                dp.ready(stage)
+        O.tape_run_segment(h, slist, len(stages))
         return loss
+
+    def dp_ready(self, stage):
+        """a gradient bucket is final: hand it to the data-parallel reducer (and cut the launch tape there while recording)."""
+        if getattr(self, '_tape_stages', None) is not None:
+            O.tape_mark(); self._tape_stages.append(stage)
+        self.dp.ready(stage)
 
     def _mark(self, name):
         """optional phase marker (tools/phase_times.py): a timing event on the current stream."""
@@ -412,7 +438,7 @@ class Network(object):
     def train_step_async(self, blobs, idx, train_op):
         """same as train_step without the loss read-back; returns the device loss[8] buffer."""
         dev = self.upload_blob(blobs, idx)
-        if getattr(self, 'use_tape', False) and self.use_streams and self.dp is None and self.parity is None:
+        if getattr(self, 'use_tape', False) and self.use_streams and self.parity is None:
             loss = self.tape_step(dev, train_op)
         elif getattr(self, 'use_graph', False) and self.dp is None and self.parity is None:
             loss = self.graph_step(dev, train_op)

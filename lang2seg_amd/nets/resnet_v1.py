@@ -335,7 +335,7 @@ class resnetv1(Network):
             if dp is not None and li == 3:
                 if S is not None:
                     self.sfork(S['lang'], main)
-                dp.ready('layer3')                        # everything except layer2 is final
+                self.dp_ready('layer3')                        # everything except layer2 is final
 
     def _roi_head_fwd(self, net_conv, Hc, Wc, rois, R, FGM, saved):
         """RoI head (NET:572-586): crop-pool -> layer4 -> average -> (cls | bbox) heads, mask head on the first FGM RoI slots.
@@ -590,7 +590,7 @@ class resnetv1(Network):
         O.total_loss(loss, self._cap_loss_weight)
         t['loss'] = loss
         if dp is not None:
-            dp.ready('heads')                              # caption + layer4 + RoI/mask heads are final here
+            self.dp_ready('heads')                              # caption + layer4 + RoI/mask heads are final here
         d_nc = self.buf('dyn.dy', (HW, C4))
         if d_nc_cap is not None:
             O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)

@@ -154,7 +154,7 @@ class vgg16(resnetv1):
         if dp is not None:
             if S is not None:
                 self.sfork(S['lang'], main)
-            dp.ready('layer3')
+            self.dp_ready('layer3')
 
     # ------------------------------------------------------------------ RoI head (NETV:139-143, VGG:84-88, NETV:274-288)
     def _roi_head_fwd(self, net_conv, Hc, Wc, rois, R, FGM, saved):

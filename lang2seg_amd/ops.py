@@ -54,6 +54,15 @@ def tape_run(h, streams):
     call('l2s_tape_run', h, arr, len(streams))
 
 
+def tape_mark():
+    call('l2s_tape_mark')
+
+
+def tape_run_segment(h, streams, seg):
+    arr = (C.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+    call('l2s_tape_run_segment', h, arr, len(streams), seg)
+
+
 def tape_size(h):
     return int(_lib.load().l2s_tape_size(h))
 

@@ -28,7 +28,7 @@ class GradReducer(object):
         self.bounds = {
             'caption': end_of(lambda k: k.startswith('caption_model.')),
             'heads': end_of(lambda k: k.startswith(('caption_model.', 'resnet.layer4.', 'cls_score', 'bbox_pred', 'mask_'))),
-            'language': end_of(lambda k: not k.startswith(('resnet.layer3.', 'resnet.layer2.', 'resnet.layer1.'))),
+            'language': end_of(lambda k: not k.startswith(('resnet.layer3.', 'resnet.layer2.', 'resnet.layer1.', 'vgg.features.'))),
             'layer3': end_of(lambda k: not k.startswith(('resnet.layer2.', 'resnet.layer1.'))),
             'layer2': end_of(lambda k: not k.startswith('resnet.layer1.')),
             'layer1': P.total,
