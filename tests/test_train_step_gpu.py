@@ -168,6 +168,10 @@ def test_eval_split_runs():
     assert 0.0 <= acc <= 1.0 and 0.0 <= iou <= 1.0 and len(prec) == 5 and all(0.0 <= p <= 1.0 for p in prec)
 
 
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
 def test_dp_tape_segments_match_eager():
     """data-parallel replay: the launch tape cut at the gradient-bucket hand-offs (l2s_tape_mark / l2s_tape_run_segment) with a
     one-rank RCCL reducer must train exactly like the eager data-parallel step (same device RNG counter, same inputs)."""
@@ -189,13 +193,15 @@ def test_dp_tape_segments_match_eager():
         net = selftest.build_net(opt, over, 'f32', sd)
         net.dp = GradReducer(net, 1)
         net.use_tape = tape
-        sgd = SGD(net, 1e-3)
+        sgd = SGD(net, 0.0)            # lr 0: the weights stay put, so the steps are comparable one by one (the proposal list is
+                                       # discontinuous in the weights; any update would let fp32 atomic-order noise pick different RoIs)
         # the first tape call runs the step twice (shape warm-up + recording), so 4 tape calls = 5 eager steps
         vals = [net.train_step(dict(blob), 0, sgd) for _ in range(4 if tape else 5)]
         if not tape:
             vals = vals[1:]
         torch.cuda.synchronize()
-        res.append((vals, net.state_dict()['resnet.layer3.5.conv2.weight'].clone(), net.state_dict()['cls_score_net.weight'].clone()))
+        res.append((vals, net.P.view('resnet.layer3.5.conv2.weight', net.P.grad).clone(), net.P.view('cls_score_net.weight', net.P.grad).clone()))
     for a, b in zip(res[0][0], res[1][0]):
-        assert np.allclose(a, b, rtol=3e-3, atol=1e-5), (a, b)        # fp32 atomic-order noise through 5 SGD steps at lr 1e-3
-    assert torch.allclose(res[0][1], res[1][1], rtol=1e-2, atol=1e-5) and torch.allclose(res[0][2], res[1][2], rtol=1e-2, atol=1e-5)
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)
+    # all-reduced gradients of the last step (fp32 atomics: order noise only)
+    assert rel(res[0][1], res[1][1]) < 1e-3 and rel(res[0][2], res[1][2]) < 1e-3
