@@ -149,17 +149,18 @@ __global__ __launch_bounds__(256) void response_loss_kernel(const float* resp, c
   if (threadIdx.x == 0) atomicAdd(loss + L2S_LOSS_RESPONSE, l * inv);
 }
 
-// block per roi: dx[p][c] = dscore[p] * W[label][c] (ReLU-masked by x); dW[label][c] += sum_p dscore[p] x[p][c]
+// grid (roi, pixel chunk): dx[p][c] = dscore[p] * W[label][c] (ReLU-masked by x); dW[label][c] += sum_p dscore[p] x[p][c]
 __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C,
                                                           const float* w, const void* x, const void* ref, void* dx, float* dw, float* db, int dt) {
   const int s = blockIdx.x;
+  const int pc = (ms2 + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * pc, p1 = min(ms2, p0 + pc);
   const int nfg = min(*num_fg, fg_max);
   const bool valid = s < nfg;
   const int lab = valid ? labels[s] : 0;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float wv = w[(long)lab * C + c];
     float acc = 0.f;
-    for (int p = 0; p < ms2; ++p) {
+    for (int p = p0; p < p1; ++p) {
       const long o = ((long)s * ms2 + p) * C + c;
       const float d = valid ? dscore[s * ms2 + p] : 0.f;
       const float xv = ldx(x, o, dt);
@@ -172,11 +173,10 @@ __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, 
   }
   if (valid && threadIdx.x == 0) {
     float sb = 0.f;
-    for (int p = 0; p < ms2; ++p) sb += dscore[s * ms2 + p];
+    for (int p = p0; p < p1; ++p) sb += dscore[s * ms2 + p];
     atomicAdd(db + lab, sb);
   }
 }
-
 
 // ---- TEST-mode heads (NET:277-307, 650-658): class probabilities, de-normalised box deltas, mask probabilities ----
 // one wave per roi
@@ -240,7 +240,7 @@ extern "C" int l2s_total_loss(float* loss, float cap_w, hipStream_t s) {
 }
 extern "C" int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C, const float* w,
                                 const void* x, const void* relu_ref, void* dx, float* dw, float* db, int dtype, hipStream_t s) {
-  L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, dw, db, dtype);
+  L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max, 14), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, dw, db, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_rcnn_predict(const float* heads, int ldh, int R, int ncls, const float* stds4, const float* means4, float* cls_prob,

@@ -289,6 +289,29 @@ __global__ void avgpool_bwd_kernel(const void* dy, void* dx, const void* addend,
     stx(dx, i, dt, v);
   }
 }
+// bf16, C % 8 == 0: 8 channels (16 bytes) per thread
+__global__ void avgpool_bwd_bf16x8_kernel(const bf16_t* dy, bf16_t* dx, const bf16_t* addend, const bf16_t* ref, int hw, int C, long total8) {
+  const float inv = 1.f / (float)hw;
+  const int C8 = C >> 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8); const long n = i / ((long)hw * C8);
+    const uint4 g = *(const uint4*)(dy + n * C + (long)c8 * 8);
+    uint4 a = make_uint4(0, 0, 0, 0), r = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    if (addend) a = *(const uint4*)(addend + i * 8);
+    if (ref) r = *(const uint4*)(ref + i * 8);
+    const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, aw[4] = {a.x, a.y, a.z, a.w}, rw[4] = {r.x, r.y, r.z, r.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v0 = __uint_as_float(gw[k] << 16) * inv, v1 = __uint_as_float(gw[k] & 0xFFFF0000u) * inv;
+      if (addend) { v0 += __uint_as_float(aw[k] << 16); v1 += __uint_as_float(aw[k] & 0xFFFF0000u); }
+      if (!(__uint_as_float(rw[k] << 16) > 0.f)) v0 = 0.f;
+      if (!(__uint_as_float(rw[k] & 0xFFFF0000u) > 0.f)) v1 = 0.f;
+      ow[k] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+    }
+    *(uint4*)(dx + i * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
 
 __device__ __forceinline__ int bin_lo(int i, int n_in, int n_out) { return (i * n_in) / n_out; }
 __device__ __forceinline__ int bin_hi(int i, int n_in, int n_out) { return ((i + 1) * n_in + n_out - 1) / n_out; }
@@ -484,6 +507,10 @@ extern "C" int l2s_avgpool_fwd(const void* x, void* y, int n_img, int hw, int C,
 }
 extern "C" int l2s_avgpool_bwd(const void* dy, void* dx, const void* addend, const void* ref, int n_img, int hw, int C, int dtype, hipStream_t s) {
   long total = (long)n_img * hw * C;
+  if (dtype == L2S_BF16 && (C & 7) == 0) {
+    L2S_LAUNCH(avgpool_bwd_bf16x8_kernel, dim3(grid_for(total / 8)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, (const bf16_t*)addend, (const bf16_t*)ref, hw, C, total / 8);
+    return l2s_check_launch();
+  }
   L2S_LAUNCH(avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, dx, addend, ref, hw, C, total, dtype);
   return l2s_check_launch();
 }

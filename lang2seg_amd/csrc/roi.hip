@@ -471,9 +471,7 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
   __syncthreads();
   if (tid == 0) { counts[0] = min(nfg_sel, fg_max); counts[1] = n_fg; counts[2] = n_bg; counts[3] = appended; }
   // outputs
-  const int W4 = 4 * ncls;
-  for (long e = tid; e < (long)R * W4; e += nt) { bt[e] = 0.f; bi[e] = 0.f; bo[e] = 0.f; }
-  __syncthreads();
+  const int W4 = 4 * ncls;          // bt / bi / bo arrive zeroed (l2s_proposal_target)
   for (int s = tid; s < R; s += nt) {
     const int i = slot[s];
     float b[4] = {0, 0, 0, 0}; int lab = 0;
@@ -633,6 +631,10 @@ extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, c
                                    float* out_rois, int* labels, float* bbox_targets, float* bbox_inside, float* bbox_outside,
                                    float* mask_targets, int* counts, int* ws, hipStream_t s) {
   if (n_gt < 1 || R < 1) return L2S_EINVAL;
+  // the three [R][4 ncls] target arrays are sparse (4 floats per foreground row): cleared by the copy engine / fill kernel
+  // instead of 730 stores per thread of the single-workgroup kernel
+  const size_t tb = (size_t)R * 4 * ncls * sizeof(float);
+  if (l2s_memset_async(bbox_targets, 0, tb, s) || l2s_memset_async(bbox_inside, 0, tb, s) || l2s_memset_async(bbox_outside, 0, tb, s)) return L2S_ELAUNCH;
   L2S_LAUNCH(ptl_kernel, dim3(1), dim3(1024), 0, s, rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w,
                      fg_keys, bg_keys, bg_rand, R, fg_max, fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms,
                      out_rois, labels, bbox_targets, bbox_inside, bbox_outside, mask_targets, counts, ws);
