@@ -120,8 +120,8 @@ def test_train_step_bf16_close():
 
 
 def test_smoke_entry():
-    from lang2seg_amd import selftest
-    selftest.smoke()
+    import __graft_entry__
+    __graft_entry__.smoke()
 
 
 @pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response'])
