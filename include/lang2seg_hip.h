@@ -174,6 +174,12 @@ int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, i
 #define L2S_LOSS_RESPONSE 7   /* network_7f_response.py:411-419 / network_cycle_response.py:415-423; 0 in the other variants */
 /* RPN CE over anchors with label != -1 (NET:377-382) + smooth-L1 sigma=3 (NET:385-390).
  * heads as in l2s_rpn_decode; labels in (a,h,w) order.  dheads(dtype) [HW][ldd] receives d(loss)/d(heads)*gscale. */
+/* RoI max pooling, POOLING_MODE == 'pool' (layer_utils/roi_pooling/roi_pool.py:19-50 -> src/cuda/roi_pooling_kernel.cu:15-70,104-180;
+ * the reference's second native FFI besides NMS).  feat NHWC [H*W][C]; out [R*P*P][C]; argmax [R*P*P][C] int32 = h*W + w of the
+ * maximum (-1: empty bin); backward adds dout into dfeat [H*W][C] f32 through the recorded argmax (dfeat is not cleared). */
+int l2s_roipool_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale, void* out, int* argmax,
+                    int dtype, hipStream_t s);
+int l2s_roipool_bwd(const void* dout, const int* argmax, int R, int P, int C, float* dfeat, int dtype, hipStream_t s);
 int l2s_rpn_loss(const float* heads, int ldh, const int* labels, const float* targets, const float* inside_w,
                  const float* outside_w, int H, int W, int A, float sigma, float gscale, float* loss /* += */, void* dheads, int ldd,
                  int dtype, const int* count_dev /* #labels != -1 (l2s_anchor_target_count) or NULL */, int* count_ws /* 1 int, used when count_dev is NULL */,

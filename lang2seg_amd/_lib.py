@@ -93,6 +93,8 @@ SIGS = {
     'l2s_conv3x3_c3': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'l2s_maxpool2x2_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_maxpool2x2_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'l2s_roipool_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, i32, vp]),
+    'l2s_roipool_bwd': (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
     'l2s_rcnn_predict': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_mask_prob': (i32, [vp, i32, i32, vp, i32, C.c_long, vp, vp]),
     'l2s_response_loss': (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -369,6 +369,42 @@ __global__ void atl_out_kernel(const float* gt, const float* base, int n, int H,
   for (int k = 0; k < 4; ++k) { targets[(long)i * 4 + k] = t[k]; inw[(long)i * 4 + k] = iw; outw[(long)i * 4 + k] = ow; }
 }
 
+
+// ------------------------------------------------------------------ RoI max pooling (POOLING_MODE == 'pool')
+// layer_utils/roi_pooling/src/cuda/roi_pooling_kernel.cu:15-70 (forward + argmax) and :104-180 (backward), on NHWC maps.
+// One thread per (roi, bin, channel); the bin geometry is uniform across the channel lanes of a wave.
+__global__ __launch_bounds__(256) void roipool_fwd_kernel(const void* feat, int H, int W, int C, const float* rois, int P, float scale,
+                                                         void* out, int* argmax, int dt) {
+  const int bin = blockIdx.x;                       // roi * P * P + ph * P + pw
+  const int n = bin / (P * P), r = bin - n * P * P, ph = r / P, pw = r - ph * P;
+  const float* roi = rois + (long)n * 5;
+  const int sw = (int)roundf(roi[1] * scale), sh = (int)roundf(roi[2] * scale);
+  const int ew = (int)roundf(roi[3] * scale), eh = (int)roundf(roi[4] * scale);
+  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+  const float bh = (float)rh / (float)P, bw = (float)rw / (float)P;
+  int hs = (int)floorf((float)ph * bh), ws = (int)floorf((float)pw * bw);
+  int he = (int)ceilf((float)(ph + 1) * bh), we = (int)ceilf((float)(pw + 1) * bw);
+  hs = min(max(hs + sh, 0), H); he = min(max(he + sh, 0), H);
+  ws = min(max(ws + sw, 0), W); we = min(max(we + sw, 0), W);
+  const bool empty = (he <= hs) || (we <= ws);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mx = empty ? 0.f : -3.402823466e+38f; int mi = -1;
+    for (int h = hs; h < he; ++h)
+      for (int w = ws; w < we; ++w) {
+        const float v = ldx(feat, ((long)h * W + w) * C + c, dt);
+        if (v > mx) { mx = v; mi = h * W + w; }
+      }
+    stx(out, (long)bin * C + c, dt, mx);
+    argmax[(long)bin * C + c] = mi;
+  }
+}
+__global__ __launch_bounds__(256) void roipool_bwd_kernel(const void* dout, const int* argmax, long n_elem, int C, float* dfeat, int dt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_elem; i += (long)gridDim.x * blockDim.x) {
+    const int a = argmax[i];
+    if (a >= 0) atomicAdd(dfeat + (long)a * C + (int)(i % C), ldx(dout, i, dt));
+  }
+}
+
 // ------------------------------------------------------------------ proposal targets (single workgroup)
 __device__ __forceinline__ float iou32(const float* b, const float* q) {   // utils/bbox.py:21-29 in fp32
   const float ba = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f), qa = (q[2] - q[0] + 1.f) * (q[3] - q[1] + 1.f);
@@ -648,5 +684,16 @@ extern "C" int l2s_roialign_fwd(const void* feat, int H, int W, int C, const flo
 extern "C" int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                                 float* dfeat, int dtype, hipStream_t s) {
   L2S_LAUNCH(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, spatial_scale, dfeat, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_roipool_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale, void* out,
+                               int* argmax, int dtype, hipStream_t s) {
+  L2S_LAUNCH(roipool_fwd_kernel, dim3(R * P * P), dim3(256), 0, s, feat, H, W, C, rois, P, spatial_scale, out, argmax, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_roipool_bwd(const void* dout, const int* argmax, int R, int P, int C, float* dfeat, int dtype, hipStream_t s) {
+  const long n = (long)R * P * P * C;
+  long g = (n + 255) / 256; if (g > 8192) g = 8192;
+  L2S_LAUNCH(roipool_bwd_kernel, dim3((int)g), dim3(256), 0, s, dout, argmax, n, C, dfeat, dtype);
   return l2s_check_launch();
 }

@@ -344,7 +344,11 @@ class resnetv1(Network):
         C4, nc = self._C4_feat_dim, self._num_classes
         PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
         pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
-        O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5)
+        if cfg.POOLING_MODE == 'crop':
+            O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5)           # NET:107-149
+        else:                                                                             # NET:104-105 RoIPoolFunction
+            saved['roi_argmax'] = self.buf('roi.argmax', (R * PS * PS, C4), torch.int32)
+            O.roipool_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5, saved['roi_argmax'])
         x, hh, ww = pool5, PS, PS
         for b, blk in enumerate(self.layers[4]):
             x, hh, ww, sv = blk.fwd(x, R, hh, ww, 'l4r.%d' % b)
@@ -392,7 +396,10 @@ class resnetv1(Network):
             g = self.layers[4][b].bwd(g, saved[('4r', b)], 'l4r.%d' % b, x_is_relu_out=(b > 0))
         self._mark('roi head bwd')
         d_nc_roi = self.buf('roi.dfeat', (HW, C4), f32, zero=True)
-        O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
+        if cfg.POOLING_MODE == 'crop':
+            O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
+        else:
+            O.roipool_bwd(g, saved['roi_argmax'], R, PS, C4, d_nc_roi)
         return d_nc_roi
 
     # ------------------------------------------------------------------ the step

@@ -328,6 +328,14 @@ def dynfilter_bwd(dy, x, filt, r, resp, respk, dx, ref, dfilt, dr, dresp_ws, H, 
          ptr(dr), ptr(dresp_ws), H, W, Cc, dt_of(x), int(gate), ptr(dresp_extra), stream())
 
 
+def roipool_fwd(feat, H, W, Cc, rois, R, P, scale, out, argmax):
+    call('l2s_roipool_fwd', ptr(feat), H, W, Cc, ptr(rois), R, P, float(scale), ptr(out), ptr(argmax), dt_of(feat), stream())
+
+
+def roipool_bwd(dout, argmax, R, P, Cc, dfeat):
+    call('l2s_roipool_bwd', ptr(dout), ptr(argmax), R, P, Cc, ptr(dfeat), dt_of(dout), stream())
+
+
 def rcnn_predict(heads, ldh, R, ncls, stds4, means4, cls_prob, bbox_pred):
     call('l2s_rcnn_predict', ptr(heads), ldh, R, ncls, ptr(stds4), ptr(means4), ptr(cls_prob), ptr(bbox_pred), stream())
 

@@ -341,3 +341,51 @@ def proposal_target_layer(rois, scores, gt_boxes, gt_masks, num_classes, cfgt, m
         crop = gt_masks[gt_assign[i], int(roi[2]):int(roi[4]) + 1, int(roi[1]):int(roi[3]) + 1]
         mt[mix] = imresize_nearest_u8(crop, (mask_size, mask_size)).astype(np.float32)
     return (out_rois, out_scores, labels.reshape(-1, 1), bt, bi, bo, mt, keep)
+
+
+# ----------------------------------------------------------------------------
+# RoI max pooling (POOLING_MODE == 'pool'): restates the reference's CUDA kernels
+# layer_utils/roi_pooling/src/cuda/roi_pooling_kernel.cu:15-70 (forward, argmax) and :104-180 (backward)
+# ----------------------------------------------------------------------------
+
+def _c_round(x):
+    """C round(): half away from zero, on the float32 product as the kernel computes it."""
+    x = np.float32(x)
+    return int(np.floor(x + np.float32(0.5))) if x >= 0 else -int(np.floor(-x + np.float32(0.5)))
+
+
+def roi_pool_fwd(feat_chw, rois, P, spatial_scale):
+    """feat (C,H,W) f32, rois (R,5) -> out (R,C,P,P) f32, argmax (R,C,P,P) int32 (index h*W+w, -1 if empty)."""
+    C, H, W = feat_chw.shape
+    R = rois.shape[0]
+    out = np.zeros((R, C, P, P), np.float32)
+    arg = np.full((R, C, P, P), -1, np.int32)
+    for n in range(R):
+        sw, sh = _c_round(rois[n, 1] * np.float32(spatial_scale)), _c_round(rois[n, 2] * np.float32(spatial_scale))
+        ew, eh = _c_round(rois[n, 3] * np.float32(spatial_scale)), _c_round(rois[n, 4] * np.float32(spatial_scale))
+        rw, rh = max(ew - sw + 1, 1), max(eh - sh + 1, 1)
+        bh, bw = np.float32(rh) / np.float32(P), np.float32(rw) / np.float32(P)
+        for ph in range(P):
+            for pw in range(P):
+                hs = int(np.floor(np.float32(ph) * bh)); ws = int(np.floor(np.float32(pw) * bw))
+                he = int(np.ceil(np.float32(ph + 1) * bh)); we = int(np.ceil(np.float32(pw + 1) * bw))
+                hs = min(max(hs + sh, 0), H); he = min(max(he + sh, 0), H)
+                ws = min(max(ws + sw, 0), W); we = min(max(we + sw, 0), W)
+                if he <= hs or we <= ws:
+                    continue                                  # empty bin: 0, argmax -1
+                win = feat_chw[:, hs:he, ws:we].reshape(C, -1)
+                k = win.argmax(1)                             # first maximum in (h, w) scan order, like the strict '>' loop
+                out[n, :, ph, pw] = win[np.arange(C), k]
+                arg[n, :, ph, pw] = (hs + k // (we - ws)) * W + (ws + k % (we - ws))
+    return out, arg
+
+
+def roi_pool_bwd(dout, arg, H, W):
+    """dout (R,C,P,P), argmax -> dfeat (C,H,W): every pooled element sends its gradient to its argmax."""
+    R, C = dout.shape[:2]
+    df = np.zeros((C, H * W), np.float32)
+    for c in range(C):
+        a = arg[:, c].reshape(-1); g = dout[:, c].reshape(-1)
+        m = a >= 0
+        np.add.at(df[c], a[m], g[m])
+    return df.reshape(C, H, W)

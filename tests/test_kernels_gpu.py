@@ -746,3 +746,31 @@ def test_response_loss_and_test_heads():
     assert rel_err(bp, heads[:, nc:5 * nc] * stds.repeat(nc) + means.repeat(nc)) < 1e-6
     assert rel_err(mp_all, torch.sigmoid(sc)) < 1e-6
     assert rel_err(mp_l, torch.sigmoid(sc.view(5, 196, nc)[torch.arange(5), :, lab.long()]).reshape(-1)) < 1e-6
+
+
+@pytest.mark.parametrize('dt', [0, 1])
+def test_roipool(dt):
+    """RoI max pooling (POOLING_MODE == 'pool') vs the numpy restatement of roi_pooling_kernel.cu: values and argmax exact."""
+    O = ops()
+    g = torch.Generator().manual_seed(31)
+    H, W, Cc, R, P = 20, 26, 40, 11, 7
+    feat = torch.randint(-8, 9, (Cc, H, W), generator=g).float() * 0.25      # ties on purpose
+    rs = np.random.RandomState(4)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 1] = rs.uniform(0, 300, R); rois[:, 2] = rs.uniform(0, 200, R)
+    rois[:, 3] = np.minimum(rois[:, 1] + rs.uniform(2, 250, R), 415); rois[:, 4] = np.minimum(rois[:, 2] + rs.uniform(2, 250, R), 319)
+    rois[0, 1:] = [0, 0, 415, 319]; rois[1, 1:] = [100.0, 90.0, 103.0, 92.0]            # full image, tiny roi (bins share pixels)
+    rois[2, 1:] = [400.0, 300.0, 500.0, 400.0]                                           # partly outside: empty bins
+    fd = to_dev(feat.permute(1, 2, 0).contiguous().view(H * W, Cc), dt)
+    ref, arg = OB.roi_pool_fwd(fd.float().cpu().view(H, W, Cc).permute(2, 0, 1).numpy(), rois, P, 1.0 / 16.0)
+    out = O.empty((R * P * P, Cc), dt); am = torch.empty((R * P * P, Cc), dtype=torch.int32, device=DEV)
+    O.roipool_fwd(fd, H, W, Cc, torch.from_numpy(rois).to(DEV), R, P, 1.0 / 16.0, out, am)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.float().cpu().view(R, P, P, Cc).permute(0, 3, 1, 2).numpy(), ref)
+    assert np.array_equal(am.cpu().view(R, P, P, Cc).permute(0, 3, 1, 2).numpy(), arg)
+    dout = to_dev(torch.randn(R * P * P, Cc, generator=g), dt)
+    dfeat = torch.zeros(H * W, Cc, device=DEV)
+    O.roipool_bwd(dout, am, R, P, Cc, dfeat)
+    torch.cuda.synchronize()
+    dref = OB.roi_pool_bwd(dout.float().cpu().view(R, P, P, Cc).permute(0, 3, 1, 2).numpy(), arg, H, W)
+    assert rel_err(dfeat.view(H, W, Cc).permute(2, 0, 1), torch.from_numpy(dref)) < 1e-5
