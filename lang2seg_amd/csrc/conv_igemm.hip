@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int NTG = 64 * WGM * WGN, LR = NTG / 8;
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
-  constexpr int NA = BM / LR, NB = BN / LR;
+  constexpr int NA = (BM + LR - 1) / LR, NB = BN / LR;      // BM need not be a multiple of the loader pass (224 = 3.5 passes)
   constexpr int BUF = (BM + BN) * ROWB;
   static_assert(D >= 2, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     int m = m0 + lrow + LR * j;
-    a_ok[j] = m < M;
+    a_ok[j] = m < M && (lrow + LR * j) < BM;
     int mm = a_ok[j] ? m : 0;
     int n_img = mm / ohw, rem = mm - n_img * ohw;
     int oy = rem / p.OW, ox = rem - oy * p.OW;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
     char* a = smem + buf * BUF + lrow * ROWB + wchunk;
     char* b = a + BM * ROWB;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *(uint4*)(a + LR * j * ROWB) = ra[j];
+    for (int j = 0; j < NA; ++j) if ((BM % LR) == 0 || j < NA - 1 || lrow < (BM % LR)) *(uint4*)(a + LR * j * ROWB) = ra[j];
 #pragma unroll
     for (int j = 0; j < NB; ++j) *(uint4*)(b + LR * j * ROWB) = rb[j];
   };
@@ -1362,7 +1362,12 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   // the K loop is long enough to pay for the prologue; measured on the layer4@RoIs shapes (profiles/r01_conv_bench.txt)
   if (!d->tile) {
     const long t256 = (long)cdiv(M, 256) * cdiv(d->Cout, 128);
-    if (t256 >= 160 && t256 <= 256 && K >= 1024) tile = 256;
+    if (t256 >= 160 && t256 <= 256 && K >= 1024) {
+      tile = 256;
+      // one round either way: the 224-row tile puts 224 instead of 196 workgroups on the 256 CUs (12 % less work per CU)
+      static const int t224 = [] { const char* e = getenv("L2S_IGEMM_T224"); return e ? atoi(e) : 1; }();
+      if (t224 && (long)cdiv(M, 224) * cdiv(d->Cout, 128) <= 256) tile = 224;
+    }
   }
   // working-set heuristic for the XCD tile order: per-XCD chunk along M keeps all of W + 1/8 of A in L2; if that does not
   // fit (~3 MiB), chunk along N instead (one W column block resident, A streamed)
@@ -1385,6 +1390,8 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     if (ok) {
 #define GR(T, BM, BN, DD, KS) (f32o ? launch_igemm_ring<T, BM, BN, 2, 2, DD, true, KS>(*d, stream) : launch_igemm_ring<T, BM, BN, 2, 2, DD, false, KS>(*d, stream))
 #define GR8(T, BM, BN, DD) (f32o ? launch_igemm_ring<T, BM, BN, 4, 2, DD, true, 1>(*d, stream) : launch_igemm_ring<T, BM, BN, 4, 2, DD, false, 1>(*d, stream))
+#define GSP7(T, DD) (tapin ? (f32o ? launch_igemm_sp<T, 224, 128, 2, 4, DD, true, true>(*d, stream) : launch_igemm_sp<T, 224, 128, 2, 4, DD, false, true>(*d, stream)) \
+                          : (f32o ? launch_igemm_sp<T, 224, 128, 2, 4, DD, true, false>(*d, stream) : launch_igemm_sp<T, 224, 128, 2, 4, DD, false, false>(*d, stream)))
 #define GSP(T, BM, BN, DD) (tapin ? (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true, true>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false, true>(*d, stream)) \
                                   : (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true, false>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false, false>(*d, stream)))
       // in-workgroup split-K for the 64x64 tile when the tile grid cannot fill the chip with several workgroups per CU
@@ -1400,6 +1407,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
         while (ks > 1 && (KT % ks)) ks >>= 1;
       }
       if (dtype == L2S_BF16) {
+        if (tile == 224) return GSP7(bf16_t, 2);
         if (tile == 256) return sp_on ? GSP(bf16_t, 256, 128, 2) : GR8(bf16_t, 256, 128, 2);
         if (tile == 128) return GR(bf16_t, 128, 128, 2, 1);
         if (ks == 4) return GR(bf16_t, 64, 64, 3, 4);
@@ -1407,6 +1415,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
         return GR(bf16_t, 64, 64, 4, 1);
       }
       if (dtype == L2S_F32) {
+        if (tile == 224) return GSP7(float, 2);
         if (tile == 256) return sp_on ? GSP(float, 256, 128, 2) : GR8(float, 256, 128, 2);
         if (tile == 128) return GR(float, 128, 128, 2, 1);
         if (ks == 4) return GR(float, 64, 64, 3, 4);
@@ -1416,9 +1425,10 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
 #undef GR
 #undef GR8
 #undef GSP
+#undef GSP7
     }
   }
-  if (tile == 256) tile = 128;   // the 256x128 tile exists only in the ring kernel
+  if (tile == 256 || tile == 224) tile = 128;   // the large tiles exist only in the ring / software-pipelined kernels
   static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 0; }();   // measured slower than the register-staged kernel at 128x128/64x64 tiles (profiles/r01_conv_bench.txt): LDS-DMA issue cost
   const bool split_req = d->ws && d->split_k > 1;
   if (use_pipe && !split_req) {

@@ -49,6 +49,7 @@ TOL = {0: 2e-5, 1: 2e-2}
     dict(n=1, H=20, W=26, Cin=256, Cout=128, k=1, s=2, p=0),
     dict(n=40, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1, tile=128),
     dict(n=21, H=7, W=7, Cin=128, Cout=200, k=3, s=1, p=1, tile=256),
+    dict(n=23, H=7, W=7, Cin=128, Cout=136, k=3, s=1, p=1, tile=224),
     dict(n=1, H=9, W=11, Cin=96, Cout=40, k=1, s=1, p=0),
 ])
 def test_conv_fwd(cfg, dt):
