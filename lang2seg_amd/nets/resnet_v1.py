@@ -333,9 +333,8 @@ class resnetv1(Network):
             for b in reversed(range(len(self.layers[li]))):
                 g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
             if dp is not None and li == 3:
-                if S is not None:
-                    self.sfork(S['lang'], main)
-                self.dp_ready('layer3')                        # everything except layer2 is final
+                self.dp_ready('layer3')                        # everything except layer2 is final (the reducer's stream waits for
+                                                               # the language / weight-gradient streams itself)
 
     def _roi_head_fwd(self, net_conv, Hc, Wc, rois, R, FGM, saved):
         """RoI head (NET:572-586): crop-pool -> layer4 -> average -> (cls | bbox) heads, mask head on the first FGM RoI slots.

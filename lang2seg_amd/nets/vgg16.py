@@ -152,8 +152,6 @@ class vgg16(resnetv1):
             op.dgrad(g, 1, h, w, dx, ref=None if prev_is_pool else xin)
             g = dx; k -= 1
         if dp is not None:
-            if S is not None:
-                self.sfork(S['lang'], main)
             self.dp_ready('layer3')
 
     # ------------------------------------------------------------------ RoI head (NETV:139-143, VGG:84-88, NETV:274-288)

@@ -11,6 +11,10 @@ import torch
 import torch.distributed as dist
 
 
+import os
+_SKIP_AR = int(os.environ.get('L2S_DP_SKIP_ALLREDUCE', '0'))     # experiment knob: keep the stream structure, skip RCCL
+
+
 class GradReducer(object):
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
 
@@ -38,6 +42,8 @@ class GradReducer(object):
         self.side = torch.cuda.Stream() if self.on_gpu else None
 
     def ready(self, stage):
+        if _SKIP_AR == 2:
+            return
         end = min(self.bounds[stage], self.net.P.total)
         if end <= self.done:
             return
@@ -45,15 +51,18 @@ class GradReducer(object):
         if self.on_gpu:
             self.side.wait_stream(torch.cuda.current_stream())
             if getattr(self.net, 'use_streams', False) and hasattr(self.net, '_streams'):
-                self.side.wait_stream(self.net._streams['wg'])      # weight gradients are produced on their own streams
-                self.side.wait_stream(self.net._streams['wg2'])
+                for name in ('wg', 'wg2', 'lang', 'cap'):           # gradients are also produced on the side streams: the reducer
+                    self.side.wait_stream(self.net._streams[name])  # waits for them, the main stream does not have to
             with torch.cuda.stream(self.side):
-                dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+                if not _SKIP_AR:
+                    dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         else:                                   # CPU/gloo path (tests)
             dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         self.done = end
 
     def finish(self):
+        if _SKIP_AR == 2:
+            return
         P = self.net.P
         if self.done < P.total:
             self.ready('layer1')

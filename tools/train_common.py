@@ -25,7 +25,7 @@ def main(args, variant='cycle'):
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        torch.distributed.init_process_group('nccl')        # lazy communicator (see bench.py)
     torch.manual_seed(args['seed']); random.seed(args['seed'])
     T = 20 if args['dataset'] == 'refcocog' else 10
     V = 3349 if args['dataset'] == 'refcocog' else 1999
