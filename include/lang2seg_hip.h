@@ -224,6 +224,16 @@ int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream_t s);
 int l2s_embed_fwd(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu, hipStream_t s);
 int l2s_embed_bwd(const float* dout, const float* out, const int64_t* ids, const float* mask, float* dtable, int T, int D, int relu, hipStream_t s);
 /* nn.LSTM cell (gate order i,f,g,o; lang_encoder.py:21-24): gates[4H] pre-activations (already x-proj + h-proj + biases) */
+/* Fused bi-LSTM time step (lang_encoder.py:62; nn.LSTM gate order i,f,g,o), one launch for up to two directions.
+ * forward : gates_out[4H] = gates_in[4H] (x W_ih^T + b_ih, precomputed) + W_hh h_prev + b_hh; cell update -> c, h, act[4H] (gate activations)
+ * backward: dh = w_hh_T[H][4H] . dgates_next (NULL at the first step) + dh_ext (NULL or the gradient of the final hidden state);
+ *           then the cell backward of this step: dgates[4H], dc_prev[H] */
+typedef struct { const float* w_hh; const float* b_hh; const float* gates_in; const float* h_prev; const float* c_prev;
+                 float* c; float* h; float* act; float* gates_out; } l2s_lstm_fwd_dir;
+typedef struct { const float* w_hh_T; const float* dgates_next; const float* dh_ext; const float* dc_in; const float* act;
+                 const float* c_prev; const float* c; float* dgates; float* dc_prev; } l2s_lstm_bwd_dir;
+int l2s_lstm_step_fwd(const l2s_lstm_fwd_dir* dirs, int ndir, int Hh, hipStream_t s);
+int l2s_lstm_step_bwd(const l2s_lstm_bwd_dir* dirs, int ndir, int Hh, hipStream_t s);
 int l2s_lstm_cell_fwd(const float* gates, const float* c_prev, float* c, float* h, float* act /*[4H] saved*/, int Hh, hipStream_t s);
 int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const float* act, const float* c_prev, const float* c,
                       float* dgates, float* dc_prev, int Hh, hipStream_t s);

@@ -31,6 +31,14 @@ class TransposeDesc(C.Structure):
     _fields_ = [('src', vp), ('scale', vp), ('dst', vp), ('Cout', i32), ('taps', i32), ('Cin', i32), ('force_f32', i32)]
 
 
+class LstmFwdDir(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('w_hh', 'b_hh', 'gates_in', 'h_prev', 'c_prev', 'c', 'h', 'act', 'gates_out')]
+
+
+class LstmBwdDir(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('w_hh_T', 'dgates_next', 'dh_ext', 'dc_in', 'act', 'c_prev', 'c', 'dgates', 'dc_prev')]
+
+
 class SgdSeg(C.Structure):
     _fields_ = [('offset', i64), ('count', i64), ('row_len', i32), ('weight_decay', i32), ('rowscale_off', i64),
                 ('lr_mult', f32), ('pad', i32)]
@@ -95,6 +103,8 @@ SIGS = {
     'l2s_maxpool2x2_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_roipool_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, i32, vp]),
     'l2s_roipool_bwd': (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
+    'l2s_lstm_step_fwd': (i32, [vp, i32, i32, vp]),
+    'l2s_lstm_step_bwd': (i32, [vp, i32, i32, vp]),
     'l2s_rcnn_predict': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_mask_prob': (i32, [vp, i32, i32, vp, i32, C.c_long, vp, vp]),
     'l2s_response_loss': (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),

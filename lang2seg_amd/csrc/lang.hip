@@ -169,6 +169,64 @@ __global__ void lstm_cell_bwd_kernel(const float* dh, const float* dc_in, const 
   dc_prev[j] = dcn * f;
 }
 
+
+// ---- fused bi-LSTM steps (ENC:62, nn.LSTM gate order i,f,g,o).  One launch per time step for BOTH directions (grid.y = direction):
+// forward : gates = g_in (x W_ih + b_ih, precomputed for all steps) + W_hh h_prev + b_hh, then the cell update; one wave per unit.
+// backward: dh = W_hh^T dg_next (through the [Hh][4Hh] transposed copy; skipped at the first step, where dh is the gradient of the
+//           final hidden state) and then the cell backward of this step for the same unit -- both are per-unit once dg_next is known.
+struct LstmDir { const float* w; const float* b; const float* g_in; const float* h_prev; const float* c_prev; float* c; float* h; float* act; float* g_out; };
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmDir d0, LstmDir d1, int Hh) {
+  const LstmDir d = blockIdx.y ? d1 : d0;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= Hh) return;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane * 4; k < Hh; k += 256) {
+    const float4 hv = *(const float4*)(d.h_prev + k);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 wv = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
+      a[q] = fmaf(wv.x, hv.x, fmaf(wv.y, hv.y, fmaf(wv.z, hv.z, fmaf(wv.w, hv.w, a[q]))));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] = wave_sum(a[q]);
+  if (lane == 0) {
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { g[q] = d.g_in[q * Hh + j] + a[q] + d.b[q * Hh + j]; d.g_out[q * Hh + j] = g[q]; }
+    const float i = sigm(g[0]), f = sigm(g[1]), gg = tanhf(g[2]), o = sigm(g[3]);
+    const float cn = f * d.c_prev[j] + i * gg;
+    d.c[j] = cn; d.h[j] = o * tanhf(cn);
+    d.act[j] = i; d.act[Hh + j] = f; d.act[2 * Hh + j] = gg; d.act[3 * Hh + j] = o;
+  }
+}
+struct LstmBDir { const float* wT; const float* dg_next; const float* dh_ext; const float* dc_in; const float* act; const float* c_prev; const float* c; float* dg; float* dc_prev; };
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBDir d0, LstmBDir d1, int Hh) {
+  const LstmBDir d = blockIdx.y ? d1 : d0;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= Hh) return;
+  float dh = 0.f;
+  if (d.dg_next) {
+    const float* wr = d.wT + (long)j * 4 * Hh;
+    for (int k = lane * 4; k < 4 * Hh; k += 256) {
+      const float4 wv = *(const float4*)(wr + k), gv = *(const float4*)(d.dg_next + k);
+      dh = fmaf(wv.x, gv.x, fmaf(wv.y, gv.y, fmaf(wv.z, gv.z, fmaf(wv.w, gv.w, dh))));
+    }
+    dh = wave_sum(dh);
+  }
+  if (lane == 0) {
+    if (d.dh_ext) dh += d.dh_ext[j];
+    const float i = d.act[j], f = d.act[Hh + j], gg = d.act[2 * Hh + j], o = d.act[3 * Hh + j];
+    const float tc = tanhf(d.c[j]);
+    const float dcn = (d.dc_in ? d.dc_in[j] : 0.f) + dh * o * (1.f - tc * tc);
+    d.dg[j] = dcn * gg * i * (1.f - i);
+    d.dg[Hh + j] = dcn * d.c_prev[j] * f * (1.f - f);
+    d.dg[2 * Hh + j] = dcn * i * (1.f - gg * gg);
+    d.dg[3 * Hh + j] = dh * tc * o * (1.f - o);
+    d.dc_prev[j] = dcn * f;
+  }
+}
+
 // ---------------------------------------------------------------- dynamic filter correlation
 __device__ __forceinline__ void spatial_mask7(int y, int x, int H, int W, float m[7]) {
   // NET:530-557 (python-2 true division then int())
@@ -581,6 +639,20 @@ extern "C" int l2s_lstm_cell_fwd(const float* gates, const float* c_prev, float*
 extern "C" int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const float* act, const float* c_prev, const float* c,
                                  float* dgates, float* dc_prev, int Hh, hipStream_t s) {
   L2S_LAUNCH(lstm_cell_bwd_kernel, dim3(cdiv(Hh, 256)), dim3(256), 0, s, dh, dc_in, act, c_prev, c, dgates, dc_prev, Hh);
+  return l2s_check_launch();
+}
+extern "C" int l2s_lstm_step_fwd(const l2s_lstm_fwd_dir* dirs, int ndir, int Hh, hipStream_t s) {
+  if (!dirs || ndir < 1 || ndir > 2 || (Hh & 3)) return L2S_EINVAL;
+  LstmDir a[2];
+  for (int i = 0; i < 2; ++i) { const l2s_lstm_fwd_dir& q = dirs[i < ndir ? i : 0]; a[i] = LstmDir{q.w_hh, q.b_hh, q.gates_in, q.h_prev, q.c_prev, q.c, q.h, q.act, q.gates_out}; }
+  L2S_LAUNCH(lstm_step_fwd_kernel, dim3(cdiv(Hh, 4), ndir), dim3(256), 0, s, a[0], a[1], Hh);
+  return l2s_check_launch();
+}
+extern "C" int l2s_lstm_step_bwd(const l2s_lstm_bwd_dir* dirs, int ndir, int Hh, hipStream_t s) {
+  if (!dirs || ndir < 1 || ndir > 2 || (Hh & 3)) return L2S_EINVAL;
+  LstmBDir a[2];
+  for (int i = 0; i < 2; ++i) { const l2s_lstm_bwd_dir& q = dirs[i < ndir ? i : 0]; a[i] = LstmBDir{q.w_hh_T, q.dgates_next, q.dh_ext, q.dc_in, q.act, q.c_prev, q.c, q.dgates, q.dc_prev}; }
+  L2S_LAUNCH(lstm_step_bwd_kernel, dim3(cdiv(Hh, 4), ndir), dim3(256), 0, s, a[0], a[1], Hh);
   return l2s_check_launch();
 }
 extern "C" int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,

@@ -163,17 +163,23 @@ class resnetv1(Network):
         x = self.buf('enc.x', (T, Hh), f32)
         O.linear_fwd(emb, P.view('rnn_encoder.mlp.0.weight'), P.view('rnn_encoder.mlp.0.bias'), x, T, Hh, E, act=1)
         hidden = self.buf('enc.hidden', (2 * Hh,), f32)
+        st = []
         for di, sfx in enumerate(['', '_reverse']):
             g = self.buf('enc.gates' + sfx, (T, 4 * Hh), f32)
             O.linear_fwd(x, P.view('rnn_encoder.rnn.weight_ih_l0' + sfx), P.view('rnn_encoder.rnn.bias_ih_l0' + sfx), g, T, 4 * Hh, Hh)
-            hs = self.buf('enc.hfull' + sfx, (T + 1, Hh), f32); cs = self.buf('enc.cfull' + sfx, (T + 1, Hh), f32)
-            act = self.buf('enc.act' + sfx, (T, 4 * Hh), f32)
-            whh, bhh = P.view('rnn_encoder.rnn.weight_hh_l0' + sfx), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx)
-            for tt in (range(T) if di == 0 else range(T - 1, -1, -1)):
+            st.append(dict(g=g, hs=self.buf('enc.hfull' + sfx, (T + 1, Hh), f32), cs=self.buf('enc.cfull' + sfx, (T + 1, Hh), f32),
+                           act=self.buf('enc.act' + sfx, (T, 4 * Hh), f32), whh=P.view('rnn_encoder.rnn.weight_hh_l0' + sfx),
+                           bhh=P.view('rnn_encoder.rnn.bias_hh_l0' + sfx)))
+        # one launch per time step for both directions (h2h GEMV + cell update fused): T launches instead of 4 T
+        for s_ in range(T):
+            dirs = []
+            for di, q in enumerate(st):
+                tt = s_ if di == 0 else T - 1 - s_
                 cur, prev = (tt + 1, tt) if di == 0 else (tt, tt + 1)
-                O.linear_fwd(hs[prev], whh, bhh, g[tt], 1, 4 * Hh, Hh, accumulate=True)
-                O.lstm_cell_fwd(g[tt], cs[prev], cs[cur], hs[cur], act[tt], Hh)
-            O.memcpy(hidden[di * Hh:(di + 1) * Hh], hs[T] if di == 0 else hs[0])      # ENC:76-80
+                dirs.append(dict(w_hh=q['whh'], b_hh=q['bhh'], gates_in=q['g'][tt], h_prev=q['hs'][prev], c_prev=q['cs'][prev],
+                                 c=q['cs'][cur], h=q['hs'][cur], act=q['act'][tt], gates_out=q['g'][tt]))
+            O.lstm_step_fwd(dirs, Hh)
+        O.memcpy(hidden[0:Hh], st[0]['hs'][T]); O.memcpy(hidden[Hh:2 * Hh], st[1]['hs'][0])      # ENC:76-80
         t['enc.emb'], t['enc.x'], t['hidden'] = emb, x, hidden
         return hidden
 
@@ -181,19 +187,26 @@ class resnetv1(Network):
         P, T, t = self.P, d['T'], self.t
         Hh, E = self.opt['rnn_hidden_size'], self.opt['word_embedding_size']
         dx = self.buf('enc.dx', (T, Hh), f32, zero=True)
+        st = []
         for di, sfx in enumerate(['', '_reverse']):
-            hs = self.buf('enc.hfull' + sfx, (T + 1, Hh), f32); cs = self.buf('enc.cfull' + sfx, (T + 1, Hh), f32)
-            act = self.buf('enc.act' + sfx, (T, 4 * Hh), f32)
-            dg = self.buf('enc.dg' + sfx, (T, 4 * Hh), f32)
-            dh = self.buf('enc.dh' + sfx, (2, Hh), f32); dc = self.buf('enc.dc' + sfx, (2, Hh), f32, zero=True)
-            O.memcpy(dh[0], dhidden[di * Hh:(di + 1) * Hh])
-            k = 0
-            whh = P.view('rnn_encoder.rnn.weight_hh_l0' + sfx)
-            for tt in (range(T - 1, -1, -1) if di == 0 else range(T)):
+            st.append(dict(hs=self.buf('enc.hfull' + sfx, (T + 1, Hh), f32), cs=self.buf('enc.cfull' + sfx, (T + 1, Hh), f32),
+                           act=self.buf('enc.act' + sfx, (T, 4 * Hh), f32), dg=self.buf('enc.dg' + sfx, (T, 4 * Hh), f32),
+                           dc=self.buf('enc.dc' + sfx, (2, Hh), f32, zero=True), wT=self.wT['rnn_encoder.rnn.weight_hh_l0' + sfx][0], sfx=sfx))
+        # one launch per time step for both directions: dh = W_hh^T dg(next step) fused with this step's cell backward
+        k = 0
+        for s_ in range(T):
+            dirs = []
+            for di, q in enumerate(st):
+                tt = T - 1 - s_ if di == 0 else s_
+                nxt = tt + 1 if di == 0 else tt - 1               # the step processed just before this one
                 cur, prev = (tt + 1, tt) if di == 0 else (tt, tt + 1)
-                O.lstm_cell_bwd(dh[k], dc[k], act[tt], cs[prev], cs[cur], dg[tt], dc[1 - k], Hh)
-                self.bwd_x(dg[tt], 'rnn_encoder.rnn.weight_hh_l0' + sfx, dh[1 - k], 1)
-                k = 1 - k
+                dirs.append(dict(w_hh_T=q['wT'], dgates_next=(q['dg'][nxt] if s_ > 0 else None),
+                                 dh_ext=(dhidden[di * Hh:(di + 1) * Hh] if s_ == 0 else None), dc_in=q['dc'][k], act=q['act'][tt],
+                                 c_prev=q['cs'][prev], c=q['cs'][cur], dgates=q['dg'][tt], dc_prev=q['dc'][1 - k]))
+            O.lstm_step_bwd(dirs, Hh)
+            k = 1 - k
+        for di, q in enumerate(st):
+            sfx, dg, hs = q['sfx'], q['dg'], q['hs']
             hprev = hs[0:T] if di == 0 else hs[1:T + 1]
             O.linear_bwd_w(dg, hprev, P.view('rnn_encoder.rnn.weight_hh_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_hh_l0' + sfx, P.grad), T, 4 * Hh, Hh)
             O.linear_bwd_w(dg, t['enc.x'], P.view('rnn_encoder.rnn.weight_ih_l0' + sfx, P.grad), P.view('rnn_encoder.rnn.bias_ih_l0' + sfx, P.grad), T, 4 * Hh, Hh)

@@ -319,6 +319,23 @@ def lstm_cell_bwd(dh, dc_in, act, c_prev, c, dgates, dc_prev, Hh):
     call('l2s_lstm_cell_bwd', ptr(dh), ptr(dc_in), ptr(act), ptr(c_prev), ptr(c), ptr(dgates), ptr(dc_prev), Hh, stream())
 
 
+def lstm_step_fwd(dirs, Hh):
+    """dirs: list (1 or 2) of dicts with the l2s_lstm_fwd_dir fields (tensors)."""
+    arr = (_lib.LstmFwdDir * len(dirs))()
+    for i, d in enumerate(dirs):
+        for k, _ in _lib.LstmFwdDir._fields_:
+            setattr(arr[i], k, ptr(d[k]))
+    call('l2s_lstm_step_fwd', arr, len(dirs), Hh, stream())
+
+
+def lstm_step_bwd(dirs, Hh):
+    arr = (_lib.LstmBwdDir * len(dirs))()
+    for i, d in enumerate(dirs):
+        for k, _ in _lib.LstmBwdDir._fields_:
+            setattr(arr[i], k, ptr(d.get(k)))
+    call('l2s_lstm_step_bwd', arr, len(dirs), Hh, stream())
+
+
 def dynfilter_fwd(x, filt, r, y, resp, respk, H, W, Cc, gate=0):
     call('l2s_dynfilter_fwd', ptr(x), ptr(filt), ptr(r), ptr(y), ptr(resp), ptr(respk), H, W, Cc, dt_of(x), int(gate), stream())
 
