@@ -345,6 +345,8 @@ class resnetv1(Network):
                 break
             for b in reversed(range(len(self.layers[li]))):
                 g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
+                if dp is not None and li == 3 and b in (16, 8) and len(self.layers[3]) > 16:
+                    self.dp_ready('layer3:%d' % b)             # hand the finished third of layer3 to the reducer
             if dp is not None and li == 3:
                 self.dp_ready('layer3')                        # everything except layer2 is final (the reducer's stream waits for
                                                                # the language / weight-gradient streams itself)

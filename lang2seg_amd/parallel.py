@@ -37,6 +37,11 @@ class GradReducer(object):
             'layer2': end_of(lambda k: not k.startswith('resnet.layer1.')),
             'layer1': P.total,
         }
+        # layer3 is the largest stage (23 blocks, ~100 MB of gradients): it is handed over in three pieces so that its all-reduce
+        # overlaps with the rest of its own backward pass.  'layer3:b' = everything down to (and including) block b.
+        for b in (16, 8):
+            self.bounds['layer3:%d' % b] = end_of(lambda k, b=b: not k.startswith(('resnet.layer2.', 'resnet.layer1.')) and
+                                                  not (k.startswith('resnet.layer3.') and int(k.split('.')[2]) < b))
         self.done = 0
         self.on_gpu = P.grad.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None
