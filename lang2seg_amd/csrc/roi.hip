@@ -602,6 +602,86 @@ __global__ void roialign_bwd_kernel(const void* dout, int H, int W, int C, const
   }
 }
 
+
+// Gather form of the backward: one workgroup owns one feature pixel, lists the (RoI, bin) samples whose bilinear footprint
+// touches it (the sample rows / columns of a RoI are separable, so a thread tests P rows + P columns of its RoI), and sums
+// weight * dout over the list with vector loads — no atomics, one read-modify-write of the pixel's C floats, and a fixed
+// summation order.  4 channels per thread-iteration (C % 4 == 0).
+__device__ __forceinline__ void ra_load4(const float* p, float v[4]) {
+  const float4 q = *(const float4*)p; v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ __forceinline__ void ra_load4(const bf16_t* p, float v[4]) {
+  const uint2 q = *(const uint2*)p;
+  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const T* dout, int H, int W, int C, const float* rois, int R, int P,
+                                                                  float sscale, float* dfeat) {
+  constexpr int CAP = 2048;
+  __shared__ int e_cell[CAP];
+  __shared__ float e_w[CAP];
+  __shared__ int sc[256];
+  const int pix = blockIdx.x, y = pix / W, x = pix - y * W, t = threadIdx.x, nv = C >> 2;
+  for (int r0 = 0; r0 < R; r0 += 256) {
+    const int r = r0 + t;
+    unsigned my = 0, mx = 0;
+    if (r < R) {
+      for (int i = 0; i < P; ++i) {
+        const Samp s = roi_sample(rois + r * 5, H, W, P, i, i, sscale);
+        const float wyv = (s.y0 == y ? 1.f - s.wy1 : 0.f) + (s.y0 + 1 == y ? s.wy1 : 0.f);
+        const float wxv = (s.x0 == x ? 1.f - s.wx1 : 0.f) + (s.x0 + 1 == x ? s.wx1 : 0.f);
+        if (wyv != 0.f) my |= 1u << i;
+        if (wxv != 0.f) mx |= 1u << i;
+      }
+    }
+    const int n = __popc(my) * __popc(mx);
+    // inclusive scan of the 256 counts
+    sc[t] = n;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int v = t >= o ? sc[t - o] : 0;
+      __syncthreads();
+      sc[t] += v;
+      __syncthreads();
+    }
+    const int total = sc[255], off = sc[t] - n;
+    __syncthreads();
+    for (int wb = 0; wb < total; wb += CAP) {
+      if (n && off < wb + CAP && off + n > wb) {
+        int k = off;
+        for (unsigned a = my; a; a &= a - 1) {
+          const int py = __ffs(a) - 1;
+          for (unsigned b = mx; b; b &= b - 1, ++k) {
+            if (k < wb || k >= wb + CAP) continue;
+            const int px = __ffs(b) - 1;
+            const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale);
+            const float wyv = s.y0 == y ? 1.f - s.wy1 : s.wy1, wxv = s.x0 == x ? 1.f - s.wx1 : s.wx1;
+            e_cell[k - wb] = (r * P + py) * P + px;
+            e_w[k - wb] = wxv * wyv;
+          }
+        }
+      }
+      __syncthreads();
+      const int ne = min(CAP, total - wb);
+      for (int v = t; v < nv; v += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const T* base = dout + v * 4;
+#pragma unroll 4
+        for (int e = 0; e < ne; ++e) {
+          float g[4];
+          ra_load4(base + (long)e_cell[e] * C, g);
+          const float w = e_w[e];
+          a0 += w * g[0]; a1 += w * g[1]; a2 += w * g[2]; a3 += w * g[3];
+        }
+        float4* d = (float4*)(dfeat + (long)pix * C + v * 4);
+        float4 q = *d; q.x += a0; q.y += a1; q.z += a2; q.w += a3; *d = q;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int l2s_rpn_decode(const float* heads, int ldh, const float* base_anchors, int H, int W, int A, int feat_stride,
@@ -683,6 +763,12 @@ extern "C" int l2s_roialign_fwd(const void* feat, int H, int W, int C, const flo
 }
 extern "C" int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                                 float* dfeat, int dtype, hipStream_t s) {
+  static const bool gather = !(getenv("L2S_ROIALIGN_ATOMIC") && atoi(getenv("L2S_ROIALIGN_ATOMIC")));
+  if (gather && C % 4 == 0 && P <= 32) {
+    if (dtype) L2S_LAUNCH(roialign_bwd_gather_kernel<bf16_t>, dim3(H * W), dim3(256), 0, s, (const bf16_t*)dout, H, W, C, rois, R, P, spatial_scale, dfeat);
+    else L2S_LAUNCH(roialign_bwd_gather_kernel<float>, dim3(H * W), dim3(256), 0, s, (const float*)dout, H, W, C, rois, R, P, spatial_scale, dfeat);
+    return l2s_check_launch();
+  }
   L2S_LAUNCH(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, spatial_scale, dfeat, dtype);
   return l2s_check_launch();
 }

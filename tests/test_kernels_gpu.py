@@ -387,6 +387,32 @@ def test_roialign(dt):
     assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
 
 
+def test_roialign_bwd_clustered_rois():
+    """the gather-form backward on 300 RoIs, 200 of them tiny boxes on one spot (every bin of a RoI lands on the same pixel and the
+    per-pixel sample list overflows its LDS window) plus duplicates, against autograd of the oracle's crop_pool"""
+    O = ops()
+    g = torch.Generator().manual_seed(17)
+    H, W, Cc, R = 20, 26, 64, 300
+    rs = np.random.RandomState(5)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 1] = rs.uniform(0, 300, R); rois[:, 2] = rs.uniform(0, 200, R)
+    rois[:, 3] = np.minimum(rois[:, 1] + rs.uniform(10, 200, R), 415); rois[:, 4] = np.minimum(rois[:, 2] + rs.uniform(10, 200, R), 319)
+    rois[:200, 1] = 100.0 + rs.uniform(0, 2, 200); rois[:200, 2] = 84.0 + rs.uniform(0, 2, 200)
+    rois[:200, 3] = rois[:200, 1] + rs.uniform(1, 10, 200); rois[:200, 4] = rois[:200, 2] + rs.uniform(1, 10, 200)
+    rois[200:210] = rois[210:220]
+    rois[220, 1:] = [0, 0, 415, 319]
+    rois[221, 1:] = [64, 32, 64, 32]                      # degenerate: integer sample coordinates, zero-weight corners
+    fr = torch.randn(1, Cc, H, W, generator=g).requires_grad_(True)
+    net = ON.OracleNet.__new__(ON.OracleNet); net.cfg = ON.DEFAULT_CFG; net.var = {}
+    ref = net.crop_pool(fr, torch.from_numpy(rois))
+    dout = torch.randn(R, 7, 7, Cc, generator=g)
+    ref.backward(dout.permute(0, 3, 1, 2))
+    dfeat = torch.zeros(H * W, Cc, device=DEV)
+    O.roialign_bwd(dout.to(DEV), H, W, Cc, torch.from_numpy(rois).to(DEV), R, 7, 1.0 / 16.0, dfeat)
+    torch.cuda.synchronize()
+    assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
+
+
 def test_losses():
     O = ops()
     g = torch.Generator().manual_seed(8)
