@@ -167,6 +167,7 @@ class Network(object):
         self._step = 0
         self.parity = None          # dict of injected sampling keys / dropout masks (tests); None = production RNG
         self.dp = None              # data-parallel gradient reducer (lang2seg_amd/parallel.py)
+        self._early_op = None       # optimiser taking early partial updates during backward (optim.SGD.partial)
 
     # ------------------------------------------------------------------ construction
     def create_architecture(self, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
@@ -276,6 +277,9 @@ class Network(object):
 
     def dp_ready(self, stage):
         """a gradient bucket is final: hand it to the data-parallel reducer (and cut the launch tape there while recording)."""
+        if self.dp is None:
+            self._early_op.partial(stage)                        # single process: the optimiser updates the finished prefix early
+            return
         if getattr(self, '_tape_stages', None) is not None:
             O.tape_mark(); self._tape_stages.append(stage)
         self.dp.ready(stage)
@@ -438,6 +442,8 @@ class Network(object):
     def train_step_async(self, blobs, idx, train_op):
         """same as train_step without the loss read-back; returns the device loss[8] buffer."""
         dev = self.upload_blob(blobs, idx)
+        self._early_op = train_op if (self.dp is None and self.use_streams and self.parity is None
+                                      and getattr(train_op, 'early', False) and str(self.device).startswith('cuda')) else None
         if getattr(self, 'use_tape', False) and self.use_streams and self.parity is None:
             loss = self.tape_step(dev, train_op)
         elif getattr(self, 'use_graph', False) and self.dp is None and self.parity is None:
@@ -447,6 +453,7 @@ class Network(object):
             if self.dp is not None:
                 self.dp.finish()
             train_op.step()
+        self._early_op = None
         self._step += 1
         return loss
 

@@ -336,6 +336,8 @@ class ParamStore(object):
             segs.append(sg)
         arr = (SgdSeg * len(segs))(*segs)
         self.nseg = len(segs)
+        self.seg_ends = [int(g.offset + g.count) for g in segs]      # host copy: the optimiser's partial updates split here
+        self.seg_size = C.sizeof(SgdSeg)
         self.segs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         return self.nseg
 

@@ -589,7 +589,7 @@ class resnetv1(Network):
         if mscore is not None:
             O.mask_loss(mscore, nc, labels, mt, counts, FGM, MS * MS, 1.0, loss, dscore)
         # =================================== backward (detection side, main stream) ===================================
-        dp = self.dp
+        dp = self.dp if self.dp is not None else self._early_op     # either one takes the finished gradient prefixes
         if not backward:
             if S is not None and self.var['cap'] is not None:
                 self.sfork(S['cap'], main)

@@ -2,6 +2,11 @@
 pyutils/mask-faster-rcnn/lib/model/train_val_cycle.py:194-220 (one param group per tensor, weight decay on
 non-bias tensors, optional DOUBLE_BIAS), fused into one HIP launch that also rewrites the dtype
 shadow weights; the data-gradient (transposed) weight copies are refreshed right after."""
+import bisect
+import os
+
+import torch
+
 from . import ops as O
 
 
@@ -14,12 +19,49 @@ class SGD(object):
     def zero_grad(self):
         pass                                        # gradients are zeroed at the start of forward_backward
 
+    # Early partial updates: the flat buffer is in reverse execution order, so once a backward stage has finished a prefix of
+    # it is final (parallel.bucket_bounds).  `partial(stage)` applies the update to that prefix on the idle transpose stream
+    # while the earlier layers are still back-propagating (the update is HBM-bound, the convolutions are not); `step()` then
+    # only has the last layers left.  Single-process only: with a gradient reducer the prefix still has to be all-reduced.
+    # Measured on MI355X (bench.py, A/B in one box): 122.4 / 123.6 img/s with it vs 123.1 without — the update competes for HBM with
+    # the layer3 backward it overlaps, so it is off by default (L2S_EARLY_SGD=1 turns it on; tests cover it).
+    early = os.environ.get('L2S_EARLY_SGD', '0') == '1'
+    _seg_done = 0
+
+    def _launch(self, s0, s1):
+        P = self.net.P
+        if s1 > s0:
+            O.sgd_momentum(P.param, P.grad, P.mom, P.segs_dev[s0 * P.seg_size:], s1 - s0, P.rowscale, self.lr, self.momentum,
+                           self.weight_decay, self.grad_scale, shadow=P.shadow)
+
+    def partial(self, stage):
+        net = self.net
+        P = net.P
+        if not hasattr(self, '_bounds'):
+            from .parallel import bucket_bounds
+            self._bounds = bucket_bounds(P)
+            assert all(a <= b for a, b in zip(P.seg_ends, P.seg_ends[1:]))
+        hi = bisect.bisect_right(P.seg_ends, self._bounds[stage])
+        if hi <= self._seg_done:
+            return
+        S = net.streams()
+        tr = S[os.environ.get('L2S_EARLY_SGD_STREAM', 'tr')]
+        net.join_transposes()                                    # (already joined at the start of the step; keeps `tr` ordered)
+        net.sfork(torch.cuda.current_stream(), tr)
+        for name in ('wg', 'wg2', 'lang', 'cap'):                # gradients are also produced on the side streams
+            net.sfork(S[name], tr)
+        with torch.cuda.stream(tr):
+            self._launch(self._seg_done, hi)
+        self._seg_done = hi
+
     def step(self):
         P = self.net.P
         if hasattr(self.net, 'join_wgrad'):
             self.net.join_wgrad()                   # weight-gradient stream -> current stream
-        O.sgd_momentum(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay,
-                       self.grad_scale, shadow=P.shadow)
+        if self._seg_done:
+            self.net.sfork(self.net.streams()[os.environ.get('L2S_EARLY_SGD_STREAM', 'tr')], torch.cuda.current_stream())
+        self._launch(self._seg_done, P.nseg)
+        self._seg_done = 0
         self.net.refresh_weights()
 
     def state_dict(self):

@@ -15,33 +15,39 @@ import os
 _SKIP_AR = int(os.environ.get('L2S_DP_SKIP_ALLREDUCE', '0'))     # experiment knob: keep the stream structure, skip RCCL
 
 
+def bucket_bounds(P):
+    """prefix of the flat parameter / gradient buffer that is final after each backward stage (the buffer is laid out in
+    reverse execution order, nets/params.py).  Used by the gradient reducer and by the optimiser's early partial updates."""
+    def end_of(pred):
+        e = 0
+        for k in P.trainable:
+            if pred(k):
+                e = max(e, P.offsets[k] + int(np.prod(P.shapes[k])))
+        return (e + 63) // 64 * 64
+    # layer4 weights get gradient from both the caption pass and the RoI pass -> final only after 'heads'
+    bounds = {
+        'caption': end_of(lambda k: k.startswith('caption_model.')),
+        'heads': end_of(lambda k: k.startswith(('caption_model.', 'resnet.layer4.', 'cls_score', 'bbox_pred', 'mask_'))),
+        'language': end_of(lambda k: not k.startswith(('resnet.layer3.', 'resnet.layer2.', 'resnet.layer1.', 'vgg.features.'))),
+        'layer3': end_of(lambda k: not k.startswith(('resnet.layer2.', 'resnet.layer1.'))),
+        'layer2': end_of(lambda k: not k.startswith('resnet.layer1.')),
+        'layer1': P.total,
+    }
+    # layer3 is the largest stage (23 blocks, ~100 MB of gradients): it is handed over in three pieces so that its all-reduce
+    # overlaps with the rest of its own backward pass.  'layer3:b' = everything down to (and including) block b.
+    for b in (16, 8):
+        bounds['layer3:%d' % b] = end_of(lambda k, b=b: not k.startswith(('resnet.layer2.', 'resnet.layer1.')) and
+                                         not (k.startswith('resnet.layer3.') and int(k.split('.')[2]) < b))
+    return bounds
+
+
 class GradReducer(object):
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
 
     def __init__(self, net, world, backend_stream=True):
         self.net, self.world = net, world
         P = net.P
-        # bucket boundaries: prefix of the flat buffer that is final after each backward stage
-        def end_of(pred):
-            e = 0
-            for k in P.trainable:
-                if pred(k):
-                    e = max(e, P.offsets[k] + int(np.prod(P.shapes[k])))
-            return (e + 63) // 64 * 64
-        # layer4 weights get gradient from both the caption pass and the RoI pass -> final only after 'heads'
-        self.bounds = {
-            'caption': end_of(lambda k: k.startswith('caption_model.')),
-            'heads': end_of(lambda k: k.startswith(('caption_model.', 'resnet.layer4.', 'cls_score', 'bbox_pred', 'mask_'))),
-            'language': end_of(lambda k: not k.startswith(('resnet.layer3.', 'resnet.layer2.', 'resnet.layer1.', 'vgg.features.'))),
-            'layer3': end_of(lambda k: not k.startswith(('resnet.layer2.', 'resnet.layer1.'))),
-            'layer2': end_of(lambda k: not k.startswith('resnet.layer1.')),
-            'layer1': P.total,
-        }
-        # layer3 is the largest stage (23 blocks, ~100 MB of gradients): it is handed over in three pieces so that its all-reduce
-        # overlaps with the rest of its own backward pass.  'layer3:b' = everything down to (and including) block b.
-        for b in (16, 8):
-            self.bounds['layer3:%d' % b] = end_of(lambda k, b=b: not k.startswith(('resnet.layer2.', 'resnet.layer1.')) and
-                                                  not (k.startswith('resnet.layer3.') and int(k.split('.')[2]) < b))
+        self.bounds = bucket_bounds(P)
         self.done = 0
         self.on_gpu = P.grad.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None

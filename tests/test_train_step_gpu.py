@@ -205,3 +205,38 @@ def test_dp_tape_segments_match_eager():
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)
     # all-reduced gradients of the last step (fp32 atomics: order noise only)
     assert rel(res[0][1], res[1][1]) < 1e-3 and rel(res[0][2], res[1][2]) < 1e-3
+
+
+def test_early_partial_sgd_matches_single_update():
+    """optim.SGD.partial: the optimiser updates each finished prefix of the flat buffer during backward (on a side stream).  Every
+    segment must be updated exactly once per step: momentum buffers after two lr=0 steps and the weight change of one lr=1e-3 step
+    equal those of the single end-of-step launch (up to fp32 atomic-order noise in the gradients), eager and replayed from the tape."""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    blob = OS.make_blob(320, 416, 6, 60, seed=5)
+    over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
+
+    def run(early, tape, lr, calls):
+        net = selftest.build_net(opt, over, 'f32', sd)
+        net.use_tape = tape
+        sgd = SGD(net, lr)
+        sgd.early = early
+        w0 = net.P.param.clone()
+        for _ in range(calls):
+            net.train_step(dict(blob), 0, sgd)
+        torch.cuda.synchronize()
+        assert sgd._seg_done == 0
+        return net.P.mom.clone(), net.P.param - w0
+
+    m_ref, _ = run(False, False, 0.0, 2)
+    assert float(m_ref.abs().max()) > 0
+    for early, tape, calls in ((True, False, 2), (True, True, 1)):       # the first tape call runs the step twice
+        m, dw = run(early, tape, 0.0, calls)
+        assert rel(m, m_ref) < 1e-3, (early, tape)
+        assert float(dw.abs().max()) == 0.0
+    _, d_ref = run(False, False, 1e-3, 1)
+    _, d = run(True, False, 1e-3, 1)
+    assert float(d_ref.abs().max()) > 0 and rel(d, d_ref) < 1e-3
