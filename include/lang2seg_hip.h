@@ -276,6 +276,25 @@ int l2s_cap_gates_bwd(const float* dh, const float* dh2 /*nullable: dh = dh + dh
 int l2s_logsoftmax_nll(const float* logits, const int64_t* target, const float* mask, int S, int V1, float gscale, float* loss_slot,
                        float* dlogits, float* logprobs_opt, hipStream_t s);
 
+/* ---------------------------------------------------------------- input side ----- */
+/* Host. COCO compressed run-length string -> run lengths; replaces rleFrString, pyutils/refer/external/maskApi.c:217-231
+ * (reached through external/mask.py decode <- lib/loaders/cycle_loader.py:199).  Returns the number of runs written to
+ * cnts[0..max_counts), or -1 for a truncated string / too small a buffer. */
+int l2s_rle_from_string(const char* s, uint32_t* cnts, int max_counts);
+/* Host. prep_im_for_blob's scale (pyutils/mask-faster-rcnn/lib/utils/blob.py:35-43: target_size / short side, capped so that
+ * round(scale * long side) <= max_size) and cv2.resize's output size (round-half-even of h * scale, w * scale). */
+int l2s_prep_geometry(int h, int w, int target_size, int max_size, double* scale, int* oh, int* ow);
+/* Device. blob.py:32-47 on one image: uint8 BGR [h][w][3] -> float32 [oh][ow][3] = cv2.resize(float32(img) - means, fx = fy =
+ * scale, INTER_LINEAR); the result is the `data` blob of cycle_loader.py:119-138 for a batch of one image. */
+int l2s_prep_image(const uint8_t* img_bgr, int h, int w, double mean_b, double mean_g, double mean_r, double scale,
+                   int oh, int ow, float* out, hipStream_t s);
+/* Device. The gt mask of one referred object (cycle_loader.py:198-210): rleDecode (maskApi.c:43-47) of its n run-length objects
+ * (column-major runs, concatenated in cnts, object r = cnts[offs[r]..offs[r+1])), union over the objects (sum > 0), PIL-nearest
+ * resize from [h][w] to [oh][ow] (scipy.misc.imresize 'nearest'); out uint8 {0,1} row-major.  ws: l2s_rle_ws_words() uint32. */
+long l2s_rle_ws_words(int total_counts, int oh, int ow);
+int l2s_rle_to_mask(const uint32_t* cnts, const int* offs, int n, int total_counts, int h, int w, int oh, int ow,
+                    uint32_t* ws, uint8_t* out, hipStream_t s);
+
 /* ---------------------------------------------------------------- launch tape / streams ----- */
 /* `to` waits (device side) for everything enqueued so far on `from`; fork or join of the step's branches */
 int l2s_stream_fork(hipStream_t from, hipStream_t to);

@@ -103,6 +103,11 @@ SIGS = {
     'l2s_maxpool2x2_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_roipool_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, i32, vp]),
     'l2s_roipool_bwd': (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
+    'l2s_rle_from_string': (i32, [C.c_char_p, vp, i32]),
+    'l2s_prep_geometry': (i32, [i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(i32)]),
+    'l2s_prep_image': (i32, [vp, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, i32, i32, vp, vp]),
+    'l2s_rle_ws_words': (i64, [i32, i32, i32]),
+    'l2s_rle_to_mask': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'l2s_lstm_step_fwd': (i32, [vp, i32, i32, vp]),
     'l2s_lstm_step_bwd': (i32, [vp, i32, i32, vp]),
     'l2s_rcnn_predict': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -414,9 +414,14 @@ class Network(object):
                 cm = np.ascontiguousarray(blobs['cap_masks'][idx:idx + 1]).astype(np.float32)
             else:                                               # TEST mode / variants without a captioner
                 cap = np.zeros((1, 2), np.int64); cm = np.zeros((1, 2), np.float32); S = 1
+            if '_gt_masks_ref' in cache:                        # loaders/cycle_loader.py: one device mask per referred object
+                r = cache['_sent_ref_host'][idx]
+                gm = cache['_gt_masks_ref'][r:r + 1]
+            else:
+                gm = torch.from_numpy(np.ascontiguousarray(blobs['gt_masks'][idx:idx + 1], dtype=np.uint8)).to(dev)
             cache[key] = dict(
                 gt_boxes=torch.from_numpy(np.ascontiguousarray(blobs['gt_boxes'][idx:idx + 1], dtype=np.float32)).to(dev),
-                gt_masks=torch.from_numpy(np.ascontiguousarray(blobs['gt_masks'][idx:idx + 1], dtype=np.uint8)).to(dev),
+                gt_masks=gm,
                 labels=torch.from_numpy(lab[0]).to(dev), T=max_len, S=S,
                 cap_in=torch.from_numpy(cap[0, :S].copy()).to(dev), cap_tgt=torch.from_numpy(cap[0, 1:S + 1].copy()).to(dev),
                 cap_mask=torch.from_numpy(cm[0, 1:S + 1].copy()).to(dev))

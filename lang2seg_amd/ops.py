@@ -353,6 +353,41 @@ def roipool_bwd(dout, argmax, R, P, Cc, dfeat):
     call('l2s_roipool_bwd', ptr(dout), ptr(argmax), R, P, Cc, ptr(dfeat), dt_of(dout), stream())
 
 
+# ------------------------------------------------------------------ input side (loaders)
+def rle_from_string(s):
+    """COCO compressed RLE string -> uint32 run lengths (host; maskApi.c:217-231)."""
+    import numpy as np
+    b = s.encode('ascii') if isinstance(s, str) else bytes(s)
+    buf = np.empty(max(len(b), 1), np.uint32)
+    m = _lib.load().l2s_rle_from_string(b, buf.ctypes.data, buf.size)
+    if m < 0:
+        raise ValueError('malformed run-length string')
+    return buf[:m].copy()
+
+
+def prep_geometry(h, w, target_size, max_size):
+    """(im_scale, out_h, out_w) of prep_im_for_blob (host; blob.py:35-45)."""
+    sc, oh, ow = C.c_double(), C.c_int(), C.c_int()
+    call('l2s_prep_geometry', int(h), int(w), int(target_size), int(max_size), C.byref(sc), C.byref(oh), C.byref(ow))
+    return sc.value, oh.value, ow.value
+
+
+def prep_image(img_u8, means, scale, out):
+    """img_u8 uint8 [h][w][3] BGR (device) -> out float32 [oh][ow][3]."""
+    h, w = img_u8.shape[0], img_u8.shape[1]
+    call('l2s_prep_image', ptr(img_u8), h, w, float(means[0]), float(means[1]), float(means[2]), float(scale),
+         out.shape[0], out.shape[1], ptr(out), stream())
+
+
+def rle_ws_words(total_counts, oh, ow):
+    return int(_lib.load().l2s_rle_ws_words(total_counts, oh, ow))
+
+
+def rle_to_mask(cnts, offs, n, total, h, w, ws, out):
+    """cnts uint32 / offs int32 (device) -> out uint8 [oh][ow]."""
+    call('l2s_rle_to_mask', ptr(cnts), ptr(offs), n, total, h, w, out.shape[0], out.shape[1], ptr(ws), ptr(out), stream())
+
+
 def rcnn_predict(heads, ldh, R, ncls, stds4, means4, cls_prob, bbox_pred):
     call('l2s_rcnn_predict', ptr(heads), ldh, R, ncls, ptr(stds4), ptr(means4), ptr(cls_prob), ptr(bbox_pred), stream())
 
