@@ -112,8 +112,13 @@ def eval_split(loader, model, crit, split, opt, max_per_image=100, thresh=0.):
         for i in range(labels.shape[0]):
             label = labels[i:i + 1, :]
             max_len = int((label != 0).sum())
-            blobs = dict(data=data['data'], im_info=data['im_info'], file_name=data.get('file_name'), bounds=data.get('bounds'),
+            blobs = dict(im_info=data['im_info'], file_name=data.get('file_name'), bounds=data.get('bounds'),
                          gt_boxes=data['gt_boxes'][i:i + 1, :], gt_masks=data['gt_masks'][i:i + 1, :, :], labels=label[:, :max_len], sent_id=i)
+            dev = dict.get(data, '_device', None)
+            if dev is not None and 'data' in dev:
+                blobs['_device'] = {'data': dev['data']}          # loaders/cycle_loader.py keeps the image blob in HBM: no host round trip
+            else:
+                blobs['data'] = data['data']
             scores, boxes, net_conv, im_scale = im_detect(model, blobs)
             pred_roi, pred_class, pred_box = best_detection(scores, boxes)
             gt_box = blobs['gt_boxes'][0, :4] / im_scale

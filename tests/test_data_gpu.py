@@ -151,3 +151,36 @@ def test_train_step_on_loader_blobs(tmp_path):
             assert np.allclose(a, c, rtol=1e-5, atol=1e-6), (a, c)
     finally:
         cfg.TRAIN.SCALES, cfg.TRAIN.MAX_SIZE = old
+
+
+def test_eval_split_on_loader(tmp_path):
+    """model/test.py eval_split driven by GtMRCNLoader.getTestBatch on the tiny on-disk dataset: same metrics whether the loop reads the
+    loader's device-resident blobs or host arrays of the same batch (the reference's contract)."""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.loaders.cycle_loader import GtMRCNLoader
+    from lang2seg_amd.model.config import cfg
+    from lang2seg_amd.model.test import eval_split
+    from oracle import weights as OW
+    root = str(tmp_path)
+    write_tiny_dataset(root, sizes=((120, 160), (90, 150), (100, 140), (128, 128)))
+    old = (cfg.TRAIN.SCALES, cfg.TRAIN.MAX_SIZE)
+    cfg.TRAIN.SCALES, cfg.TRAIN.MAX_SIZE = (240,), 400
+    try:
+        mk = lambda: GtMRCNLoader(os.path.join(root, 'data.json'), os.path.join(root, 'data.h5'), image_root=os.path.join(root, 'images'),
+                                  image_pattern='img_{:0>12d}.png', verbose=False)
+        ld = mk()
+        opt = OW.default_opt(vocab_size=ld.vocab_size, seq_length=ld.label_length)
+        net = selftest.build_net(opt, {}, 'f32', OW.make_state_dict(opt, seed=3, head_gain=4.0))
+        r_dev = eval_split(ld, net, None, 'val', dict(verbose=False))
+
+        class HostView(object):            # the same batches as plain host dicts
+            def __init__(self, inner):
+                self.inner, self.split_ix = inner, inner.split_ix
+            def getTestBatch(self, split):
+                b = self.inner.getTestBatch(split)
+                return {k: b[k] for k in ('data', 'gt_masks', 'im_info', 'gt_boxes', 'labels', 'file_name', 'bounds')}
+        r_host = eval_split(HostView(mk()), net, None, 'val', dict(verbose=False))
+        assert r_dev[0] == r_host[0] and abs(r_dev[1] - r_host[1]) < 1e-6 and list(r_dev[2]) == list(r_host[2])
+        assert 0.0 <= r_dev[1] <= 1.0
+    finally:
+        cfg.TRAIN.SCALES, cfg.TRAIN.MAX_SIZE = old

@@ -34,7 +34,13 @@ def main(args, variant):
     torch.cuda.set_device(0)
     T = 20 if args['dataset'] == 'refcocog' else 10
     V = 3349 if args['dataset'] == 'refcocog' else 1999
-    loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V)
+    data_json = osp.join(ROOT, 'cache/prepro', args['dataset'] + '_' + args['splitBy'], 'data.json')       # eval_cycle.py:45-48
+    data_h5 = osp.join(ROOT, 'cache/prepro', args['dataset'] + '_' + args['splitBy'], 'data.h5')
+    if osp.exists(data_json):
+        from lang2seg_amd.loaders.cycle_loader import GtMRCNLoader
+        loader = GtMRCNLoader(data_json, data_h5, image_root=osp.join(ROOT, 'pyutils/mask-faster-rcnn/data/coco/images/train2014'))
+    else:
+        loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V)
     opt = parse_opt([])
     opt.update(vocab_size=loader.vocab_size, C4_feat_dim=1024, seq_length=loader.label_length,
                dataset_splitBy=args['dataset'] + '_' + args['splitBy'])

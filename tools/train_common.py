@@ -29,7 +29,19 @@ def main(args, variant='cycle'):
     torch.manual_seed(args['seed']); random.seed(args['seed'])
     T = 20 if args['dataset'] == 'refcocog' else 10
     V = 3349 if args['dataset'] == 'refcocog' else 1999
-    loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V, rank=rank)
+    # the reference's dataset files (train_cycle_2.py:50-53) when they are present, else the synthetic stand-in of the same contract
+    data_json = osp.join(ROOT, 'cache/prepro', args['dataset'] + '_' + args['splitBy'], 'data.json')
+    data_h5 = osp.join(ROOT, 'cache/prepro', args['dataset'] + '_' + args['splitBy'], 'data.h5')
+    if osp.exists(data_json):
+        from lang2seg_amd.loaders.cycle_loader import CycleLoader, GtMRCNLoader
+        cls = CycleLoader if variant in ('cycle', 'cycle_response') else GtMRCNLoader      # tools/train.py etc. use GtMRCNLoader
+        loader = cls(data_json, data_h5, image_root=osp.join(ROOT, 'pyutils/mask-faster-rcnn/data/coco/images/train2014'))
+        if world > 1:                                            # one (image, expression) stream per rank: rank-strided image list
+            for k in loader.split_ix:
+                loader.split_ix[k] = loader.split_ix[k][rank::world]
+                loader.perm[k] = np.arange(len(loader.split_ix[k]))
+    else:
+        loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V, rank=rank)
     opt = dict(args)
     opt['vocab_size'] = loader.vocab_size
     opt['C4_feat_dim'] = 512 if variant == 'vgg' else 1024
