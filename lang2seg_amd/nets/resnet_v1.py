@@ -720,16 +720,34 @@ class resnetv1(Network):
         nA = HW * A
         prob = self.buf('rpn.prob', (HW, 2 * A), f32); boxes = self.buf('rpn.boxes', (nA, 4), f32); scores = self.buf('rpn.scores', (nA,), f32)
         O.rpn_decode(rheads, NPR, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, prob, boxes, scores)
-        pre = int(cfg.TEST.RPN_PRE_NMS_TOP_N); post = int(cfg.TEST.RPN_POST_NMS_TOP_N)
-        pre = nA if pre <= 0 else min(pre, nA)
-        sb = self.buf('tprop.sb', (pre, 4), f32); ss = self.buf('tprop.ss', (pre,), f32); si = self.buf('tprop.si', (pre,), torch.int32)
-        O.sort_topk(scores, boxes, nA, pre, self.buf('prop.sortws', (O.sort_ws_ints(nA),), torch.int32), sb, ss, si)
-        nms_ws = self.buf('tprop.nmsws', (O.nms_workspace_bytes(pre) // 8 + 8,), torch.int64)
-        keep = self.buf('tprop.keep', (post,), torch.int32); nkeep = self.buf('tprop.nkeep', (1,), torch.int32)
-        O.nms(sb, pre, float(cfg.TEST.RPN_NMS_THRESH), 0 if cfg.NMS_CMP == 'ge' else 1, post, nms_ws, keep, nkeep)
-        rois = self.buf('tprop.rois', (post, 5), f32, zero=True); rsc = self.buf('tprop.rsc', (post,), f32)
-        O.gather_rois(sb, ss, keep, nkeep, post, rois, rsc)
-        n = int(nkeep.item())                               # TEST mode returns host arrays anyway (NET:691-697)
+        if str(cfg.TEST.MODE) == 'top':
+            # NET:263-264 -> proposal_top_layer.py:18-67: the RPN_TOP_N best anchors, decoded + clipped (rpn_decode did both), no NMS
+            post = int(cfg.TEST.RPN_TOP_N)
+            rois = self.buf('tprop.rois_top', (post, 5), f32, zero=True)
+            if nA >= post:
+                sb = self.buf('tprop.sb_top', (post, 4), f32); ss = self.buf('tprop.ss_top', (post,), f32); si = self.buf('tprop.si_top', (post,), torch.int32)
+                O.sort_topk(scores, boxes, nA, post, self.buf('prop.sortws', (O.sort_ws_ints(nA),), torch.int32), sb, ss, si)
+                rois[:, 1:].copy_(sb)
+            else:
+                # fewer anchors than RPN_TOP_N (:44-49): drawn with replacement from numpy's generator, as the reference does
+                idx = torch.from_numpy(np.random.choice(nA, size=post, replace=True)).to(self.device)
+                rois[:, 1:].copy_(boxes[idx])
+            n = post
+            nkeep = None
+        elif str(cfg.TEST.MODE) == 'nms':
+            pre = int(cfg.TEST.RPN_PRE_NMS_TOP_N); post = int(cfg.TEST.RPN_POST_NMS_TOP_N)
+            pre = nA if pre <= 0 else min(pre, nA)
+            sb = self.buf('tprop.sb', (pre, 4), f32); ss = self.buf('tprop.ss', (pre,), f32); si = self.buf('tprop.si', (pre,), torch.int32)
+            O.sort_topk(scores, boxes, nA, pre, self.buf('prop.sortws', (O.sort_ws_ints(nA),), torch.int32), sb, ss, si)
+            nms_ws = self.buf('tprop.nmsws', (O.nms_workspace_bytes(pre) // 8 + 8,), torch.int64)
+            keep = self.buf('tprop.keep', (post,), torch.int32); nkeep = self.buf('tprop.nkeep', (1,), torch.int32)
+            O.nms(sb, pre, float(cfg.TEST.RPN_NMS_THRESH), 0 if cfg.NMS_CMP == 'ge' else 1, post, nms_ws, keep, nkeep)
+            rois = self.buf('tprop.rois', (post, 5), f32, zero=True); rsc = self.buf('tprop.rsc', (post,), f32)
+            O.gather_rois(sb, ss, keep, nkeep, post, rois, rsc)
+            n = int(nkeep.item())                               # TEST mode returns host arrays anyway (NET:691-697)
+        else:
+            raise NotImplementedError(cfg.TEST.MODE)            # NET:265-266
+        n_own = n
         own = rois
         if self.parity is not None and self.parity.get('forced_proposals') is not None:
             fr, _ = self.parity['forced_proposals']
@@ -738,7 +756,7 @@ class resnetv1(Network):
         # heads run on all `post` slots (static shapes); rows >= n are padding and sliced off
         cheads, cls_prob, bbox_pred, mprob = self._roi_heads_test(net_conv, Hc, Wc, rois, post)
         nc = self._num_classes; MS = int(cfg.MASK_SIZE)
-        self._predictions = dict(net_conv=net_conv, net_conv_hw=(Hc, Wc), response=resp, rois=rois[:n], own_rois=own[:int(nkeep.item())],
+        self._predictions = dict(net_conv=net_conv, net_conv_hw=(Hc, Wc), response=resp, rois=rois[:n], own_rois=own[:n_own],
                                  cls_score=cheads[:n, :nc], cls_prob=cls_prob[:n], bbox_pred=bbox_pred[:n],
                                  mask_prob=mprob.view(post, MS, MS, nc)[:n], rpn_cls_prob=prob)
         return self._predictions

@@ -170,6 +170,20 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_info, anchors, num_anchors,
     rois = np.hstack((np.zeros((props.shape[0], 1), np.float32), props)).astype(np.float32)
     return rois, sc, order, keep
 
+def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_info, anchors, num_anchors, rpn_top_n, rng=None):
+    """layer_utils/proposal_top_layer.py:18-67 (TEST.MODE == 'top'): the rpn_top_n best-scoring anchors, decoded and clipped, no NMS.
+    Fewer anchors than rpn_top_n: sampled WITH replacement (npr.choice, :46-49) — `rng` supplies the draw."""
+    A = num_anchors
+    scores = rpn_cls_prob[:, :, :, A:].reshape(-1).astype(np.float32)
+    deltas = rpn_bbox_pred.reshape(-1, 4)
+    if scores.shape[0] < rpn_top_n:
+        top = (rng or np.random).choice(scores.shape[0], size=rpn_top_n, replace=True)
+    else:
+        top = stable_desc_order(scores)[:rpn_top_n]
+    props = clip_boxes(bbox_transform_inv(anchors[top], deltas[top]), im_info[:2])
+    rois = np.hstack((np.zeros((props.shape[0], 1), np.float32), props)).astype(np.float32)
+    return rois, scores[top]
+
 # ----------------------------------------------------------------------------
 # sampling helper: "keep the k smallest keys" == npr.choice(..., replace=False)
 # when key[cand[perm[j]]] = j (numpy legacy choice = permutation(n)[:k]).

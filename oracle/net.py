@@ -357,8 +357,11 @@ class OracleNet(object):
             prob = F.softmax(cls.view(1, 2, -1, W), 1).view_as(cls).permute(0, 2, 3, 1)
             bbp = F.conv2d(rpn, self.p['rpn_bbox_pred_net.weight'], self.p['rpn_bbox_pred_net.bias']).permute(0, 2, 3, 1).contiguous()
             ct = cfg['TEST']
-            rois, rscores, order, keep = B.proposal_layer(prob.numpy(), bbp.numpy(), im_info[0], anchors, self.A, ct['RPN_PRE_NMS_TOP_N'],
-                                                          ct['RPN_POST_NMS_TOP_N'], ct['RPN_NMS_THRESH'], cfg['NMS_CMP'])
+            if ct.get('MODE', 'nms') == 'top':
+                rois, rscores = B.proposal_top_layer(prob.numpy(), bbp.numpy(), im_info[0], anchors, self.A, ct['RPN_TOP_N'])
+            else:
+                rois, rscores, order, keep = B.proposal_layer(prob.numpy(), bbp.numpy(), im_info[0], anchors, self.A, ct['RPN_PRE_NMS_TOP_N'],
+                                                              ct['RPN_POST_NMS_TOP_N'], ct['RPN_NMS_THRESH'], cfg['NMS_CMP'])
             own = rois
             if forced_proposals is not None:
                 rois = forced_proposals

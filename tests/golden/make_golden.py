@@ -342,7 +342,7 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
     return out
 
 
-def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0, variant='cycle'):
+def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0, variant='cycle', test_mode='nms', top_n=0):
     """TEST mode (test_image, NET:684-699; _predict_masks_from_boxes_and_labels, NET:595-626) of the reference."""
     from model.config import cfg
     import importlib
@@ -357,6 +357,9 @@ def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0,
     for k in ['BATCH_SIZE', 'RPN_PRE_NMS_TOP_N', 'RPN_POST_NMS_TOP_N', 'RPN_BATCHSIZE']:
         setattr(cfg.TRAIN, k, DEFAULT_CFG['TRAIN'][k])
     cfg.ANCHOR_SCALES = list(DEFAULT_CFG['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(DEFAULT_CFG['ANCHOR_RATIOS'])
+    cfg.TEST.MODE = test_mode                       # 'top': proposal_top_layer instead of proposal_layer (NET:261-266)
+    if top_n:
+        cfg.TEST.RPN_TOP_N = top_n
     torch.manual_seed(0)
     net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
@@ -382,7 +385,8 @@ def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0,
         labels = np.array([3, 17, 1, 80, 42])
         masks = net._predict_masks_from_boxes_and_labels(net_conv, boxes, labels)
     out = dict(meta_H=H, meta_W=W, meta_T=T, meta_V=V, meta_seed_w=seed_w, meta_seed_blob=seed_blob, meta_head_gain=head_gain,
-               meta_variant=variant)
+               meta_variant=variant, meta_test_mode=test_mode, meta_top_n=top_n)
+    cfg.TEST.MODE = 'nms'
     out['int.rois'] = rois.numpy()
     out['x.cls_score'] = net._predictions['cls_score'].numpy()
     out['x.cls_prob'] = cls_prob.numpy()
@@ -516,6 +520,8 @@ if __name__ == '__main__':
     if what in ('test', 'all'):
         run_reference_test('test_tiny', 320, 416, 6, 60)
         run_reference_test('test_tiny_cycle_response', 320, 416, 6, 60, variant='cycle_response')
+    if what in ('test_top', 'all'):
+        run_reference_test('test_tiny_top', 320, 416, 6, 60, test_mode='top', top_n=200)
     if what in ('full', 'all'):
         hook_proposals()
         run_reference('full', 600, 1000, 20, 3349, dict(BATCH_SIZE=256, RPN_PRE_NMS_TOP_N=12000,

@@ -50,4 +50,9 @@ def setup_from_fixture_test(g):
     opt = OW.default_opt(vocab_size=int(g['meta_V']), seq_length=int(g['meta_T']))
     sd = OW.make_state_dict(opt, seed=int(g['meta_seed_w']), head_gain=float(g['meta_head_gain']), variant=variant_of(g))
     blob = OS.make_blob(int(g['meta_H']), int(g['meta_W']), int(g['meta_T']), int(g['meta_V']), seed=int(g['meta_seed_blob']))
-    return opt, sd, blob, copy.deepcopy(ON.DEFAULT_CFG), None
+    cfg = copy.deepcopy(ON.DEFAULT_CFG)
+    if 'meta_test_mode' in g:
+        cfg['TEST']['MODE'] = str(g['meta_test_mode'])
+        if int(g['meta_top_n']):
+            cfg['TEST']['RPN_TOP_N'] = int(g['meta_top_n'])
+    return opt, sd, blob, cfg, None

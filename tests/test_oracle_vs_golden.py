@@ -84,7 +84,7 @@ def test_train_step_tiny_variants(variant):
     _run_e2e('tiny_' + variant)
 
 
-@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response'])
+@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top'])
 def test_test_mode(tag):
     """TEST mode of the reference (test_image NET:684-699 + _predict_masks_from_boxes_and_labels NET:595-626):
     300 TEST proposals, class scores / probabilities, de-normalised box deltas, mask probabilities."""

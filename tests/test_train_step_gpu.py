@@ -124,7 +124,7 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response'])
+@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top'])
 def test_test_mode(tag):
     """TEST mode (test_image, _predict_masks_from_boxes_and_labels) against the reference's own TEST-mode outputs."""
     from golden_util import setup_from_fixture_test
@@ -133,11 +133,16 @@ def test_test_mode(tag):
     opt, sd, blob, ocfg, _ = setup_from_fixture_test(g)
     net = selftest.build_net(opt, {}, 'f32', sd, variant=variant_of(g))
     from lang2seg_amd.model.config import cfg
+    saved_test = {k: cfg.TEST[k] for k in list(ocfg['TEST']) + ['MODE', 'RPN_TOP_N']}
     for k, v in ocfg['TEST'].items():
-        cfg.TEST[k] = v
+        cfg.TEST[k] = v                 # 'test_tiny_top': TEST.MODE = 'top' (proposal_top_layer.py), RPN_TOP_N = 200
     net.parity = dict(forced_proposals=(torch.from_numpy(g['int.rois']).cuda(), None))
     tb = {k: blob[k] for k in ('data', 'im_info', 'gt_boxes', 'gt_masks', 'labels')}
-    cls_score, cls_prob, bbox_pred, rois, net_conv = net.test_image(tb)
+    try:
+        cls_score, cls_prob, bbox_pred, rois, net_conv = net.test_image(tb)
+    finally:
+        for k, v in saved_test.items():
+            cfg.TEST[k] = v
     own = net._predictions['own_rois'].cpu().numpy()
     D = np.abs(own[:, None, 1:] - g['int.rois'][None, :, 1:]).max(-1)
     assert own.shape == g['int.rois'].shape and D.min(1).max() < 2e-2 and D.min(0).max() < 2e-2
