@@ -162,6 +162,13 @@ int l2s_roialign_fwd(const void* feat, int H, int W, int C, const float* rois, i
 int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                      float* dfeat, int dtype, hipStream_t s);
 
+/* _crop_pool_layer_align (NET:151-182, selected by cfg.POOLING_ALIGN at NET:569-570,610-611): the same sampler with the affine
+ * grid computed from the RoI in image pixels over the image size (im_info) instead of roi/16 over the map size */
+int l2s_cropalign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float im_h, float im_w,
+                      void* out, int dtype, hipStream_t s);
+int l2s_cropalign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float im_h, float im_w,
+                      float* dfeat, int dtype, hipStream_t s);
+
 /* ---------------------------------------------------------------- losses -------------------- */
 /* loss slots in the float loss[8] buffer */
 #define L2S_LOSS_RPN_CLS 0

@@ -101,6 +101,8 @@ SIGS = {
     'l2s_conv3x3_c3': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'l2s_maxpool2x2_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_maxpool2x2_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'l2s_cropalign_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, f32, vp, i32, vp]),
+    'l2s_cropalign_bwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, f32, vp, i32, vp]),
     'l2s_roipool_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, vp, i32, vp]),
     'l2s_roipool_bwd': (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
     'l2s_rle_from_string': (i32, [C.c_char_p, vp, i32]),

@@ -558,11 +558,12 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
 
 // ------------------------------------------------------------------ RoIAlign (crop-and-resize)
 struct Samp { int x0, y0; float wx1, wy1; };
-__device__ __forceinline__ Samp roi_sample(const float* roi, int H, int W, int P, int py, int px, float sscale) {
-  // NET:122-147: theta from roi/16, affine_grid + grid_sample, align_corners = True
+__device__ __forceinline__ Samp roi_sample(const float* roi, int H, int W, int P, int py, int px, float sscale, float TH, float TW) {
+  // NET:122-147: theta from roi/16 over the map size, (TH, TW) = (H, W); NET:151-182 (_crop_pool_layer_align): theta from the roi in
+  // image pixels over the image size, (TH, TW) = im_info and sscale = 1; affine_grid + grid_sample, align_corners = True
   const float x1 = roi[1] * sscale, y1 = roi[2] * sscale, x2 = roi[3] * sscale, y2 = roi[4] * sscale;
-  const float t00 = (x2 - x1) / (float)(W - 1), t02 = (x1 + x2 - (float)W + 1.f) / (float)(W - 1);
-  const float t11 = (y2 - y1) / (float)(H - 1), t12 = (y1 + y2 - (float)H + 1.f) / (float)(H - 1);
+  const float t00 = (x2 - x1) / (TW - 1.f), t02 = (x1 + x2 - TW + 1.f) / (TW - 1.f);
+  const float t11 = (y2 - y1) / (TH - 1.f), t12 = (y1 + y2 - TH + 1.f) / (TH - 1.f);
   const float step = 2.f / (float)(P - 1);
   // torch.linspace(-1, 1, P): start-based for i < P/2, end-based otherwise
   const float bx = (px < P / 2) ? (-1.f + step * (float)px) : (1.f - step * (float)(P - 1 - px));
@@ -574,9 +575,9 @@ __device__ __forceinline__ Samp roi_sample(const float* roi, int H, int W, int P
   s.x0 = (int)fx; s.y0 = (int)fy; s.wx1 = ix - fx; s.wy1 = iy - fy;
   return s;
 }
-__global__ void roialign_fwd_kernel(const void* feat, int H, int W, int C, const float* rois, int P, float sscale, void* out, int dt) {
+__global__ void roialign_fwd_kernel(const void* feat, int H, int W, int C, const float* rois, int P, float sscale, float TH, float TW, void* out, int dt) {
   const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
-  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale);
+  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW);
   const float w00 = (1.f - s.wx1) * (1.f - s.wy1), w01 = s.wx1 * (1.f - s.wy1), w10 = (1.f - s.wx1) * s.wy1, w11 = s.wx1 * s.wy1;
   const bool vx0 = s.x0 >= 0 && s.x0 < W, vx1 = s.x0 + 1 >= 0 && s.x0 + 1 < W, vy0 = s.y0 >= 0 && s.y0 < H, vy1 = s.y0 + 1 >= 0 && s.y0 + 1 < H;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -588,9 +589,9 @@ __global__ void roialign_fwd_kernel(const void* feat, int H, int W, int C, const
     stx(out, (long)cell * C + c, dt, v);
   }
 }
-__global__ void roialign_bwd_kernel(const void* dout, int H, int W, int C, const float* rois, int P, float sscale, float* dfeat, int dt) {
+__global__ void roialign_bwd_kernel(const void* dout, int H, int W, int C, const float* rois, int P, float sscale, float TH, float TW, float* dfeat, int dt) {
   const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
-  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale);
+  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW);
   const float w00 = (1.f - s.wx1) * (1.f - s.wy1), w01 = s.wx1 * (1.f - s.wy1), w10 = (1.f - s.wx1) * s.wy1, w11 = s.wx1 * s.wy1;
   const bool vx0 = s.x0 >= 0 && s.x0 < W, vx1 = s.x0 + 1 >= 0 && s.x0 + 1 < W, vy0 = s.y0 >= 0 && s.y0 < H, vy1 = s.y0 + 1 >= 0 && s.y0 + 1 < H;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -617,7 +618,7 @@ __device__ __forceinline__ void ra_load4(const bf16_t* p, float v[4]) {
 }
 template <typename T>
 __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const T* dout, int H, int W, int C, const float* rois, int R, int P,
-                                                                  float sscale, float* dfeat) {
+                                                                  float sscale, float TH, float TW, float* dfeat) {
   constexpr int CAP = 2048;
   __shared__ int e_cell[CAP];
   __shared__ float e_w[CAP];
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const T* dout,
     unsigned my = 0, mx = 0;
     if (r < R) {
       for (int i = 0; i < P; ++i) {
-        const Samp s = roi_sample(rois + r * 5, H, W, P, i, i, sscale);
+        const Samp s = roi_sample(rois + r * 5, H, W, P, i, i, sscale, TH, TW);
         const float wyv = (s.y0 == y ? 1.f - s.wy1 : 0.f) + (s.y0 + 1 == y ? s.wy1 : 0.f);
         const float wxv = (s.x0 == x ? 1.f - s.wx1 : 0.f) + (s.x0 + 1 == x ? s.wx1 : 0.f);
         if (wyv != 0.f) my |= 1u << i;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const T* dout,
           for (unsigned b = mx; b; b &= b - 1, ++k) {
             if (k < wb || k >= wb + CAP) continue;
             const int px = __ffs(b) - 1;
-            const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale);
+            const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW);
             const float wyv = s.y0 == y ? 1.f - s.wy1 : s.wy1, wxv = s.x0 == x ? 1.f - s.wx1 : s.wx1;
             e_cell[k - wb] = (r * P + py) * P + px;
             e_w[k - wb] = wxv * wyv;
@@ -756,21 +757,37 @@ extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, c
                      out_rois, labels, bbox_targets, bbox_inside, bbox_outside, mask_targets, counts, ws);
   return l2s_check_launch();
 }
+static int roialign_fwd_launch(const void* feat, int H, int W, int C, const float* rois, int R, int P, float sscale, float TH, float TW,
+                               void* out, int dtype, hipStream_t s) {
+  L2S_LAUNCH(roialign_fwd_kernel, dim3(R * P * P), dim3(256), 0, s, feat, H, W, C, rois, P, sscale, TH, TW, out, dtype);
+  return l2s_check_launch();
+}
+static int roialign_bwd_launch(const void* dout, int H, int W, int C, const float* rois, int R, int P, float sscale, float TH, float TW,
+                               float* dfeat, int dtype, hipStream_t s) {
+  static const bool gather = !(getenv("L2S_ROIALIGN_ATOMIC") && atoi(getenv("L2S_ROIALIGN_ATOMIC")));
+  if (gather && C % 4 == 0 && P <= 32) {
+    if (dtype) L2S_LAUNCH(roialign_bwd_gather_kernel<bf16_t>, dim3(H * W), dim3(256), 0, s, (const bf16_t*)dout, H, W, C, rois, R, P, sscale, TH, TW, dfeat);
+    else L2S_LAUNCH(roialign_bwd_gather_kernel<float>, dim3(H * W), dim3(256), 0, s, (const float*)dout, H, W, C, rois, R, P, sscale, TH, TW, dfeat);
+    return l2s_check_launch();
+  }
+  L2S_LAUNCH(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, sscale, TH, TW, dfeat, dtype);
+  return l2s_check_launch();
+}
 extern "C" int l2s_roialign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                                 void* out, int dtype, hipStream_t s) {
-  L2S_LAUNCH(roialign_fwd_kernel, dim3(R * P * P), dim3(256), 0, s, feat, H, W, C, rois, P, spatial_scale, out, dtype);
-  return l2s_check_launch();
+  return roialign_fwd_launch(feat, H, W, C, rois, R, P, spatial_scale, (float)H, (float)W, out, dtype, s);
 }
 extern "C" int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                                 float* dfeat, int dtype, hipStream_t s) {
-  static const bool gather = !(getenv("L2S_ROIALIGN_ATOMIC") && atoi(getenv("L2S_ROIALIGN_ATOMIC")));
-  if (gather && C % 4 == 0 && P <= 32) {
-    if (dtype) L2S_LAUNCH(roialign_bwd_gather_kernel<bf16_t>, dim3(H * W), dim3(256), 0, s, (const bf16_t*)dout, H, W, C, rois, R, P, spatial_scale, dfeat);
-    else L2S_LAUNCH(roialign_bwd_gather_kernel<float>, dim3(H * W), dim3(256), 0, s, (const float*)dout, H, W, C, rois, R, P, spatial_scale, dfeat);
-    return l2s_check_launch();
-  }
-  L2S_LAUNCH(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, spatial_scale, dfeat, dtype);
-  return l2s_check_launch();
+  return roialign_bwd_launch(dout, H, W, C, rois, R, P, spatial_scale, (float)H, (float)W, dfeat, dtype, s);
+}
+extern "C" int l2s_cropalign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float im_h, float im_w,
+                                 void* out, int dtype, hipStream_t s) {
+  return roialign_fwd_launch(feat, H, W, C, rois, R, P, 1.f, im_h, im_w, out, dtype, s);
+}
+extern "C" int l2s_cropalign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float im_h, float im_w,
+                                 float* dfeat, int dtype, hipStream_t s) {
+  return roialign_bwd_launch(dout, H, W, C, rois, R, P, 1.f, im_h, im_w, dfeat, dtype, s);
 }
 extern "C" int l2s_roipool_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale, void* out,
                                int* argmax, int dtype, hipStream_t s) {

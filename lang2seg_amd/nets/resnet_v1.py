@@ -351,18 +351,63 @@ class resnetv1(Network):
                 self.dp_ready('layer3')                        # everything except layer2 is final (the reducer's stream waits for
                                                                # the language / weight-gradient streams itself)
 
+    # ------------------------------------------------------------------ RoI feature extraction (NET:566-574, 607-615)
+    def _crop_max_pool(self):
+        return bool(cfg.RESNET.MAX_POOL)                 # RES:252-253 (the VGG network keeps Network._crop_pool_layer's default, True)
+
+    def _pool_mode(self):
+        """(kind, crop size, 2x2 max pool after the crop) for cfg.POOLING_MODE / POOLING_ALIGN / RESNET.MAX_POOL"""
+        PS = int(cfg.POOLING_SIZE)
+        if cfg.POOLING_MODE != 'crop':
+            return 'pool', PS, False                     # NET:104-105 RoIPoolFunction
+        if cfg.POOLING_ALIGN:
+            return 'align', 2 * PS, True                 # NET:569-570: _crop_pool_layer_align(net_conv, rois, im_info), max_pool defaults to True
+        mp = self._crop_max_pool()
+        return 'crop', (2 * PS if mp else PS), mp        # NET:107-149
+
+    def _rois_pool_fwd(self, net_conv, Hc, Wc, rois, R, saved):
+        C4, PS = self._C4_feat_dim, int(cfg.POOLING_SIZE)
+        kind, CS, mp = self._pool_mode()
+        pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
+        if kind == 'pool':
+            saved['roi_argmax'] = self.buf('roi.argmax', (R * PS * PS, C4), torch.int32)
+            O.roipool_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5, saved['roi_argmax'])
+            return pool5
+        crop = self.buf('roi.crop', (R * CS * CS, C4)) if mp else pool5
+        if kind == 'align':
+            O.cropalign_fwd(net_conv, Hc, Wc, C4, rois, R, CS, self._im_hw[0], self._im_hw[1], crop)
+        else:
+            O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, CS, 1.0 / 16.0, crop)
+        if mp:
+            O.maxpool2x2_fwd(crop, pool5, R, CS, CS, C4)
+            saved['roi_crop'] = crop
+        return pool5
+
+    def _rois_pool_bwd(self, g, Hc, Wc, rois, R, saved):
+        """g = d(pool5) [R*PS*PS][C4] -> d(net_conv) float [H*W][C4]"""
+        C4, PS = self._C4_feat_dim, int(cfg.POOLING_SIZE)
+        kind, CS, mp = self._pool_mode()
+        d_nc_roi = self.buf('roi.dfeat', (Hc * Wc, C4), f32, zero=True)
+        if kind == 'pool':
+            O.roipool_bwd(g, saved['roi_argmax'], R, PS, C4, d_nc_roi)
+            return d_nc_roi
+        if mp:
+            dcrop = self.buf('roi.dcrop', (R * CS * CS, C4))
+            O.maxpool2x2_bwd(g, saved['roi_crop'], dcrop, R, CS, CS, C4, False)
+            g = dcrop
+        if kind == 'align':
+            O.cropalign_bwd(g, Hc, Wc, C4, rois, R, CS, self._im_hw[0], self._im_hw[1], d_nc_roi)
+        else:
+            O.roialign_bwd(g, Hc, Wc, C4, rois, R, CS, 1.0 / 16.0, d_nc_roi)
+        return d_nc_roi
+
     def _roi_head_fwd(self, net_conv, Hc, Wc, rois, R, FGM, saved):
         """RoI head (NET:572-586): crop-pool -> layer4 -> average -> (cls | bbox) heads, mask head on the first FGM RoI slots.
         Returns (heads [R][NPC] f32, NPC, mask scores or None)."""
         P, dt, t = self.P, self.dt, self.t
         C4, nc = self._C4_feat_dim, self._num_classes
         PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
-        pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
-        if cfg.POOLING_MODE == 'crop':
-            O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5)           # NET:107-149
-        else:                                                                             # NET:104-105 RoIPoolFunction
-            saved['roi_argmax'] = self.buf('roi.argmax', (R * PS * PS, C4), torch.int32)
-            O.roipool_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, pool5, saved['roi_argmax'])
+        pool5 = self._rois_pool_fwd(net_conv, Hc, Wc, rois, R, saved)
         x, hh, ww = pool5, PS, PS
         for b, blk in enumerate(self.layers[4]):
             x, hh, ww, sv = blk.fwd(x, R, hh, ww, 'l4r.%d' % b)
@@ -409,12 +454,7 @@ class resnetv1(Network):
         for b in reversed(range(len(self.layers[4]))):
             g = self.layers[4][b].bwd(g, saved[('4r', b)], 'l4r.%d' % b, x_is_relu_out=(b > 0))
         self._mark('roi head bwd')
-        d_nc_roi = self.buf('roi.dfeat', (HW, C4), f32, zero=True)
-        if cfg.POOLING_MODE == 'crop':
-            O.roialign_bwd(g, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, d_nc_roi)
-        else:
-            O.roipool_bwd(g, saved['roi_argmax'], R, PS, C4, d_nc_roi)
-        return d_nc_roi
+        return self._rois_pool_bwd(g, Hc, Wc, rois, R, saved)
 
     # ------------------------------------------------------------------ the step
     keep_logprobs = False
@@ -429,6 +469,7 @@ class resnetv1(Network):
         C4 = self._C4_feat_dim
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
         im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
+        self._im_hw = (im_h, im_w)
         O.memset_zero(P.grad)
         O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
         loss = self.buf('loss', (8,), f32, zero=True)
@@ -677,8 +718,7 @@ class resnetv1(Network):
         P, dt = self.P, self.dt
         C4, nc = self._C4_feat_dim, self._num_classes
         PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
-        pool5 = self.buf('roi.pool5', (n * PS * PS, C4))
-        O.roialign_fwd(net_conv, Hc, Wc, C4, rois, n, PS, 1.0 / 16.0, pool5)
+        pool5 = self._rois_pool_fwd(net_conv, Hc, Wc, rois, n, {})
         x, hh, ww = pool5, PS, PS
         for b, blk in enumerate(self.layers[4]):
             x, hh, ww, _ = blk.fwd(x, n, hh, ww, 'l4t.%d' % b)
@@ -709,6 +749,7 @@ class resnetv1(Network):
         self.t = {}
         A = self._num_anchors
         im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
+        self._im_hw = (im_h, im_w)
         net_conv, base, resp, Hc, Wc = self._backbone_and_filter(d)
         HW = Hc * Wc
         P = self.P

@@ -155,14 +155,14 @@ class vgg16(resnetv1):
             self.dp_ready('layer3')
 
     # ------------------------------------------------------------------ RoI head (NETV:139-143, VGG:84-88, NETV:274-288)
+    def _crop_max_pool(self):
+        return True                                       # network_vgg.py:139 _crop_pool_layer(bottom, rois, max_pool=True)
+
     def _roi_head_fwd(self, net_conv, Hc, Wc, rois, R, FGM, saved):
         P, t = self.P, self.t
         C4, nc = self._C4_feat_dim, self._num_classes
         PS = int(cfg.POOLING_SIZE)
-        crop = self.buf('roi.crop', (R * 4 * PS * PS, C4))
-        O.roialign_fwd(net_conv, Hc, Wc, C4, rois, R, 2 * PS, 1.0 / 16.0, crop)
-        pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
-        O.maxpool2x2_fwd(crop, pool5, R, 2 * PS, 2 * PS, C4)
+        pool5 = self._rois_pool_fwd(net_conv, Hc, Wc, rois, R, saved)      # 14x14 crop + 2x2 max pool (Network._crop_pool_layer default)
         h6 = self.buf('roi.fc6', (R, 4096))
         self.fc6.fwd(pool5, R, PS, PS, h6, relu=True)
         d6 = self._drop('fc6', (R, 4096), 0.5)
@@ -179,13 +179,13 @@ class vgg16(resnetv1):
         cheads = self.buf('roi.heads', (R, NPC), f32)
         self.rcnn_heads.fwd(h7d, R, 1, 1, cheads, out_f32=True)
         t.update({'pool5': pool5, 'rcnn_heads': cheads})
-        saved['roi'] = (crop, pool5, h6, h6d, d6, h7, h7d, d7)
+        saved['roi'] = (pool5, h6, h6d, d6, h7, h7d, d7)
         return cheads, NPC, None
 
     def _roi_head_bwd(self, d_cheads, dscore, labels, counts, rois, Hc, Wc, R, FGM, saved):
         C4 = self._C4_feat_dim
         PS = int(cfg.POOLING_SIZE)
-        crop, pool5, h6, h6d, d6, h7, h7d, d7 = saved['roi']
+        pool5, h6, h6d, d6, h7, h7d, d7 = saved['roi']
         self.rcnn_heads.wgrad(d_cheads, h7d, R, 1, 1)
         g7 = self.buf('roi.dfc7', (R, 4096))
         if d7 is None:
@@ -203,9 +203,5 @@ class vgg16(resnetv1):
         self.fc6.wgrad(g6, pool5, R, PS, PS)
         dpool5 = self.buf('roi.dpool5', (R * PS * PS, C4))
         self.fc6.dgrad(g6, R, PS, PS, dpool5)
-        dcrop = self.buf('roi.dcrop', (R * 4 * PS * PS, C4))
-        O.maxpool2x2_bwd(dpool5, crop, dcrop, R, 2 * PS, 2 * PS, C4, False)
         self._mark('roi head bwd')
-        d_nc_roi = self.buf('roi.dfeat', (Hc * Wc, C4), f32, zero=True)
-        O.roialign_bwd(dcrop, Hc, Wc, C4, rois, R, 2 * PS, 1.0 / 16.0, d_nc_roi)
-        return d_nc_roi
+        return self._rois_pool_bwd(dpool5, Hc, Wc, rois, R, saved)

@@ -349,6 +349,14 @@ def roipool_fwd(feat, H, W, Cc, rois, R, P, scale, out, argmax):
     call('l2s_roipool_fwd', ptr(feat), H, W, Cc, ptr(rois), R, P, float(scale), ptr(out), ptr(argmax), dt_of(feat), stream())
 
 
+def cropalign_fwd(feat, H, W, Cc, rois, R, P, im_h, im_w, out):
+    call('l2s_cropalign_fwd', ptr(feat), H, W, Cc, ptr(rois), R, P, float(im_h), float(im_w), ptr(out), dt_of(feat), stream())
+
+
+def cropalign_bwd(dout, H, W, Cc, rois, R, P, im_h, im_w, dfeat):
+    call('l2s_cropalign_bwd', ptr(dout), H, W, Cc, ptr(rois), R, P, float(im_h), float(im_w), ptr(dfeat), dt_of(dout), stream())
+
+
 def roipool_bwd(dout, argmax, R, P, Cc, dfeat):
     call('l2s_roipool_bwd', ptr(dout), ptr(argmax), R, P, Cc, ptr(dfeat), dt_of(dout), stream())
 

@@ -163,16 +163,25 @@ class OracleNet(object):
         return net_conv * response
 
     # ---- crop pool (NET:107-149, max_pool False via RES:258-259) -----------
-    def crop_pool(self, bottom, rois, size=None):
+    def crop_pool(self, bottom, rois, size=None, im_info=None):
+        """NET:107-149 (_crop_pool_layer) and, with cfg POOLING_ALIGN, NET:151-182 (_crop_pool_layer_align: theta from the RoI in image
+        pixels over im_info's size, always followed by the 2x2 max pool).  cfg RESNET_MAX_POOL = RES:252-253."""
         size = size or self.cfg['POOLING_SIZE']
         rois = rois.detach()
-        x1 = rois[:, 1:2] / 16.0; y1 = rois[:, 2:3] / 16.0
-        x2 = rois[:, 3:4] / 16.0; y2 = rois[:, 4:5] / 16.0
-        height, width = bottom.shape[2], bottom.shape[3]
+        align = bool(self.cfg.get('POOLING_ALIGN', False))
+        if align:
+            im_info = self._im_info if im_info is None else im_info
+            x1 = rois[:, 1:2]; y1 = rois[:, 2:3]; x2 = rois[:, 3:4]; y2 = rois[:, 4:5]
+            height, width = float(im_info[0][0]), float(im_info[0][1])
+        else:
+            x1 = rois[:, 1:2] / 16.0; y1 = rois[:, 2:3] / 16.0
+            x2 = rois[:, 3:4] / 16.0; y2 = rois[:, 4:5] / 16.0
+            height, width = bottom.shape[2], bottom.shape[3]
         zero = torch.zeros(rois.shape[0], 1)
         theta = torch.cat([(x2 - x1) / (width - 1), zero, (x1 + x2 - width + 1) / (width - 1),
                            zero, (y2 - y1) / (height - 1), (y1 + y2 - height + 1) / (height - 1)], 1).view(-1, 2, 3)
-        if self.var.get('backbone') == 'vgg':                     # network_vgg.py:139-143: 14x14 crop + 2x2 max pool
+        # network_vgg.py:139-143: 14x14 crop + 2x2 max pool
+        if align or self.var.get('backbone') == 'vgg' or self.cfg.get('RESNET_MAX_POOL', False):
             grid = F.affine_grid(theta, (rois.shape[0], 1, 2 * size, 2 * size), align_corners=True)
             return F.max_pool2d(F.grid_sample(bottom.expand(rois.shape[0], -1, -1, -1), grid, align_corners=True), 2, 2)
         grid = F.affine_grid(theta, (rois.shape[0], 1, size, size), align_corners=True)
@@ -238,6 +247,7 @@ class OracleNet(object):
         cfg = self.cfg; T = {}
         image = torch.from_numpy(blob['data'].transpose(0, 3, 1, 2).copy())
         im_info = blob['im_info']
+        self._im_info = im_info
         base = self.image_to_head(image)
         T['net_conv_base'] = base
         hidden = self.rnn_encoder(torch.from_numpy(blob['labels']), None if drops is None else drops.get('word'))
@@ -347,6 +357,7 @@ class OracleNet(object):
         with torch.no_grad():
             image = torch.from_numpy(blob['data'].transpose(0, 3, 1, 2).copy())
             im_info = blob['im_info']
+            self._im_info = im_info
             base = self.image_to_head(image)
             hidden = self.rnn_encoder(torch.from_numpy(blob['labels']))
             net_conv = self.dynamic_filter(base, hidden)

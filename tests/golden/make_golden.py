@@ -182,7 +182,7 @@ def keys_from_log(n_total, cand, drawn, disable_mode):
     return keys
 
 
-def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain=4.0, full_tensors=True, variant='cycle'):
+def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain=4.0, full_tensors=True, variant='cycle', top_over=None):
     from model.config import cfg
     import importlib
     var = OW.VARIANTS[variant]
@@ -195,6 +195,9 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
         ocfg['TRAIN'][k] = v
         setattr(cfg.TRAIN, k, v)
     cfg.ANCHOR_SCALES = list(ocfg['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(ocfg['ANCHOR_RATIOS'])
+    top_saved = {}
+    for k, v in (top_over or {}).items():            # top-level switches, e.g. POOLING_ALIGN (NET:569-570)
+        top_saved[k] = getattr(cfg, k); setattr(cfg, k, v); ocfg[k] = v
     opt = OW.default_opt(vocab_size=V, seq_length=T)
     is_vgg = var.get('backbone') == 'vgg'
     if is_vgg:
@@ -337,6 +340,10 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
         g = grads[k]
         flat('g.' + k, digest(g if g is not None else torch.zeros(1)), out)
         flat('w1.' + k, digest(dict(net.named_parameters())[k]), out)
+    for k, v in (top_over or {}).items():
+        out['top.' + k] = int(v)
+    for k, v in top_saved.items():
+        setattr(cfg, k, v)
     np.savez_compressed(os.path.join(HERE, 'ref_%s.npz' % tag), **out)
     print(tag, 'losses', L, 'num_fg', out['int.num_fg'], 'n_prop', n_prop, 'choices', [(len(e['a']), e['size']) for e in log])
     return out
@@ -517,6 +524,11 @@ if __name__ == '__main__':
             hook_proposals(v)
             run_reference('tiny_' + v, 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,
                                                              RPN_BATCHSIZE=64), head_gain=4.0, variant=v)
+    if what in ('align', 'all'):
+        # cfg.POOLING_ALIGN: _crop_pool_layer_align (NET:151-182) = image-space affine grid, 14x14 crop + 2x2 max pool
+        hook_proposals()
+        run_reference('tiny_align', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64),
+                      head_gain=4.0, top_over=dict(POOLING_ALIGN=True))
     if what in ('test', 'all'):
         run_reference_test('test_tiny', 320, 416, 6, 60)
         run_reference_test('test_tiny_cycle_response', 320, 416, 6, 60, variant='cycle_response')

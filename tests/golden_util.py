@@ -39,6 +39,8 @@ def setup_from_fixture(g):
     for k in g:
         if k.startswith('cfg.'):
             cfg['TRAIN'][k[4:]] = int(g[k])
+        if k.startswith('top.'):                     # top-level switches of the reference's cfg (POOLING_ALIGN, ...)
+            cfg[k[4:]] = bool(int(g[k]))
     samp = dict(rpn_fg_keys=g['samp.rpn_fg_keys'], rpn_bg_keys=g['samp.rpn_bg_keys'],
                 roi_fg_keys=g['samp.roi_fg_keys'], roi_bg_keys=g['samp.roi_bg_keys'])
     return opt, sd, blob, cfg, samp

@@ -387,6 +387,41 @@ def test_roialign(dt):
     assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
 
 
+def test_cropalign_with_max_pool():
+    """_crop_pool_layer_align (NET:151-182): l2s_cropalign_fwd/bwd (grid from the RoI in image pixels over im_info) + the 2x2 max pool,
+    against autograd of the oracle's crop_pool with POOLING_ALIGN"""
+    import copy
+    O = ops()
+    g = torch.Generator().manual_seed(9)
+    H, W, Cc, R = 20, 26, 64, 11
+    im_h, im_w = 317.0, 409.0                             # not a multiple of 16: the two parameterisations differ
+    rs = np.random.RandomState(4)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 1] = rs.uniform(0, 300, R); rois[:, 2] = rs.uniform(0, 200, R)
+    rois[:, 3] = np.minimum(rois[:, 1] + rs.uniform(10, 200, R), im_w - 1); rois[:, 4] = np.minimum(rois[:, 2] + rs.uniform(10, 200, R), im_h - 1)
+    rois[0, 1:] = [0, 0, im_w - 1, im_h - 1]
+    fr = torch.randn(1, Cc, H, W, generator=g).requires_grad_(True)
+    net = ON.OracleNet.__new__(ON.OracleNet); net.cfg = copy.deepcopy(ON.DEFAULT_CFG); net.cfg['POOLING_ALIGN'] = True; net.var = {}
+    net._im_info = np.array([[im_h, im_w, 1.0]], np.float32)
+    ref = net.crop_pool(fr, torch.from_numpy(rois))        # (R, C, 7, 7)
+    fd = nhwc(fr.detach()).to(DEV).contiguous().view(H * W, Cc)
+    rd = torch.from_numpy(rois).to(DEV)
+    crop = torch.empty(R * 14 * 14, Cc, device=DEV)
+    O.cropalign_fwd(fd, H, W, Cc, rd, R, 14, im_h, im_w, crop)
+    pool = torch.empty(R * 49, Cc, device=DEV)
+    O.maxpool2x2_fwd(crop, pool, R, 14, 14, Cc)
+    torch.cuda.synchronize()
+    assert rel_err(pool.view(R, 7, 7, Cc), ref.permute(0, 2, 3, 1)) < 2e-5
+    dout = torch.randn(R, 7, 7, Cc, generator=g)
+    ref.backward(dout.permute(0, 3, 1, 2))
+    dcrop = torch.empty(R * 14 * 14, Cc, device=DEV)
+    O.maxpool2x2_bwd(dout.to(DEV).view(R * 49, Cc).contiguous(), crop, dcrop, R, 14, 14, Cc, False)
+    dfeat = torch.zeros(H * W, Cc, device=DEV)
+    O.cropalign_bwd(dcrop, H, W, Cc, rd, R, 14, im_h, im_w, dfeat)
+    torch.cuda.synchronize()
+    assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
+
+
 def test_roialign_bwd_clustered_rois():
     """the gather-form backward on 300 RoIs, 200 of them tiny boxes on one spot (every bin of a RoI lands on the same pixel and the
     per-pixel sample list overflows its LDS window) plus duplicates, against autograd of the oracle's crop_pool"""

@@ -77,6 +77,12 @@ def test_train_step_tiny():
     _run_e2e('tiny')
 
 
+def test_train_step_tiny_pooling_align():
+    """cfg.POOLING_ALIGN = True in the reference: _crop_pool_layer_align (NET:151-182) — affine grid from the RoI in image pixels over
+    im_info's size, 14x14 crop + 2x2 max pool — in the RoI head, forward and backward."""
+    _run_e2e('tiny_align')
+
+
 @pytest.mark.parametrize('variant', ['baseline', 'spatial', 'response', 'cycle_response', 'vgg'])
 def test_train_step_tiny_variants(variant):
     """the reference's other ResNet network variants (network.py, network_7f.py, network_7f_response.py,

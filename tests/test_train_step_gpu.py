@@ -19,11 +19,15 @@ def _setup(dtype, tag='tiny'):
     samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
     over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
     net = selftest.build_net(opt, over, dtype, sd, variant=variant_of(g))
+    from lang2seg_amd.model.config import cfg
+    for k in g:
+        if k.startswith('top.'):                 # e.g. POOLING_ALIGN (reset by conftest after the test)
+            cfg[k[4:]] = bool(int(g[k]))
     net.parity = selftest.parity_from_samp(samp)
     return g, opt, sd, blob, ocfg, samp, net
 
 
-@pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg'])
+@pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align'])
 def test_train_step_f32_vs_fixture_and_oracle(tag):
     """every ResNet network variant of the reference (cycle = the benchmarked one; baseline / spatial / response /
     cycle_response are BASELINE.json configs 0, 1, 3 + train_response.sh) against a fixture produced by the reference itself."""
