@@ -698,17 +698,7 @@ class resnetv1(Network):
             if not hasattr(self, '_r_one'):
                 self._r_one = torch.tensor([1.0, 0, 0, 0, 0, 0, 0], dtype=f32, device=self.device)
             O.memcpy(filt[7 * C4:], self._r_one)
-        OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        c1 = self.buf('stem.c1', (OH1 * OW1, 64))
-        O.stem_conv(d['data'], P.frozen['resnet.conv1.weight'], P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'],
-                    c1, H, W, OH1, OW1)
-        h, w = (OH1 + 2 - 3) // 2 + 1, (OW1 + 2 - 3) // 2 + 1
-        x = self.buf('stem.pool', (h * w, 64))
-        O.maxpool(c1, x, OH1, OW1, 64, h, w)
-        for li in (1, 2, 3):
-            for b, blk in enumerate(self.layers[li]):
-                x, h, w, _ = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
-        base, Hc, Wc = x, h, w
+        base, Hc, Wc = self._backbone_fwd(d, {})
         net_conv = self.buf('dyn.y', (Hc * Wc, C4)); resp = self.buf('dyn.resp', (Hc * Wc,), f32); respk = self.buf('dyn.respk', (Hc * Wc, 7), f32)
         O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4, gate=1 if self.var['gate'] == 'sigmoid' else 0)
         return net_conv, base, resp, Hc, Wc
@@ -797,6 +787,10 @@ class resnetv1(Network):
         # heads run on all `post` slots (static shapes); rows >= n are padding and sliced off
         cheads, cls_prob, bbox_pred, mprob = self._roi_heads_test(net_conv, Hc, Wc, rois, post)
         nc = self._num_classes; MS = int(cfg.MASK_SIZE)
+        if mprob is None:                                   # VGG16 / Faster R-CNN network: no mask branch (network_vgg.py:614)
+            self._predictions = dict(net_conv=net_conv, net_conv_hw=(Hc, Wc), response=resp, rois=rois[:n], own_rois=own[:n_own],
+                                     cls_score=cheads[:n, :nc], cls_prob=cls_prob[:n], bbox_pred=bbox_pred[:n], rpn_cls_prob=prob)
+            return self._predictions
         self._predictions = dict(net_conv=net_conv, net_conv_hw=(Hc, Wc), response=resp, rois=rois[:n], own_rois=own[:n_own],
                                  cls_score=cheads[:n, :nc], cls_prob=cls_prob[:n], bbox_pred=bbox_pred[:n],
                                  mask_prob=mprob.view(post, MS, MS, nc)[:n], rpn_cls_prob=prob)

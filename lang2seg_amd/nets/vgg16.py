@@ -182,6 +182,26 @@ class vgg16(resnetv1):
         saved['roi'] = (pool5, h6, h6d, d6, h7, h7d, d7)
         return cheads, NPC, None
 
+    def _roi_heads_test(self, net_conv, Hc, Wc, rois, n, labels=None):
+        """TEST mode (network_vgg.py:588-614): crop-pool -> fc6 -> fc7 -> class scores / probabilities / de-normalised deltas; no masks."""
+        P = self.P
+        nc, PS = self._num_classes, int(cfg.POOLING_SIZE)
+        pool5 = self._rois_pool_fwd(net_conv, Hc, Wc, rois, n, {})
+        h6 = self.buf('roi.fc6', (n, 4096))
+        self.fc6.fwd(pool5, n, PS, PS, h6, relu=True)
+        h7 = self.buf('roi.fc7', (n, 4096))
+        self.fc7.fwd(h6, n, 1, 1, h7, relu=True)
+        NPC = P.rcnn_npad
+        cheads = self.buf('roi.heads', (n, NPC), f32)
+        self.rcnn_heads.fwd(h7, n, 1, 1, cheads, out_f32=True)
+        cst = self._consts()
+        cls_prob = self.buf('test.cls_prob', (n, nc), f32); bbox_pred = self.buf('test.bbox_pred', (n, 4 * nc), f32)
+        O.rcnn_predict(cheads, NPC, n, nc, cst['stds'], cst['means'], cls_prob, bbox_pred)
+        return cheads, cls_prob, bbox_pred, None
+
+    def _predict_masks_from_boxes_and_labels(self, net_conv, boxes, labels):
+        raise NotImplementedError('the VGG16 / Faster R-CNN network has no mask branch (network_vgg.py:614; model/test_vgg.py evaluates boxes only)')
+
     def _roi_head_bwd(self, d_cheads, dscore, labels, counts, rois, Hc, Wc, R, FGM, saved):
         C4 = self._C4_feat_dim
         PS = int(cfg.POOLING_SIZE)

@@ -382,13 +382,16 @@ class OracleNet(object):
 
     def roi_heads_test(self, net_conv, rois):
         pool5 = self.crop_pool(net_conv, torch.from_numpy(np.ascontiguousarray(rois, dtype=np.float32)))
+        vgg = self.var.get('backbone') == 'vgg'
         fc7s = self.head_to_tail(pool5)
-        fc7 = fc7s.mean(3).mean(2)
+        fc7 = fc7s if vgg else fc7s.mean(3).mean(2)
         cls_score = F.linear(fc7, self.p['cls_score_net.weight'], self.p['cls_score_net.bias'])
         bbox_pred = F.linear(fc7, self.p['bbox_pred_net.weight'], self.p['bbox_pred_net.bias'])
         ct = self.cfg['TRAIN']
         stds = torch.tensor(ct['BBOX_NORMALIZE_STDS'], dtype=torch.float32).repeat(self.num_classes)
         means = torch.tensor(ct['BBOX_NORMALIZE_MEANS'], dtype=torch.float32).repeat(self.num_classes)
+        if vgg:                                               # network_vgg.py:604-614: no mask branch
+            return dict(cls_score=cls_score, cls_prob=F.softmax(cls_score, 1), bbox_pred=bbox_pred * stds + means)
         up = F.relu(F.conv_transpose2d(fc7s, self.p['mask_up_sampling.weight'], self.p['mask_up_sampling.bias'], stride=2))
         mask_prob = torch.sigmoid(F.conv2d(up, self.p['mask_pred_net.weight'], self.p['mask_pred_net.bias']))
         return dict(cls_score=cls_score, cls_prob=F.softmax(cls_score, 1), bbox_pred=bbox_pred * stds + means, mask_prob=mask_prob)

@@ -356,6 +356,8 @@ def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0,
     var = OW.VARIANTS[variant]
     RESM = importlib.import_module('nets.' + var['module'])
     opt = OW.default_opt(vocab_size=V, seq_length=T)
+    if var.get('backbone') == 'vgg':
+        opt['C4_feat_dim'] = 512
     sd = OW.make_state_dict(opt, seed=seed_w, head_gain=head_gain, variant=variant)
     blob = OS.make_blob(H, W, T, V, seed=seed_blob)
     from oracle.net import DEFAULT_CFG
@@ -368,7 +370,8 @@ def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0,
     if top_n:
         cfg.TEST.RPN_TOP_N = top_n
     torch.manual_seed(0)
-    net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
+    is_vgg = var.get('backbone') == 'vgg'
+    net = RESM.vgg16(opt, batch_size=1) if is_vgg else RESM.resnetv1(opt, batch_size=1, num_layers=101)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     ref_sd = net.state_dict()
     for k, v in sd.items():
@@ -384,13 +387,15 @@ def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0,
     net._mode = 'TEST'
     net._image_gt_summaries = {}
     with torch.no_grad():
-        net_conv, rois, cls_prob, bbox_pred, mask_prob = net._predict()
+        pr = net._predict()
+        net_conv, rois, cls_prob, bbox_pred = pr[:4]
+        mask_prob = pr[4] if len(pr) > 4 else None          # network_vgg.py:614 returns no mask_prob
         stds = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_STDS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
         means = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_MEANS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
         bbox_pred = bbox_pred.mul(stds).add(means)
         boxes = rois.numpy()[:5, 1:5].copy()
         labels = np.array([3, 17, 1, 80, 42])
-        masks = net._predict_masks_from_boxes_and_labels(net_conv, boxes, labels)
+        masks = net._predict_masks_from_boxes_and_labels(net_conv, boxes, labels) if mask_prob is not None else None
     out = dict(meta_H=H, meta_W=W, meta_T=T, meta_V=V, meta_seed_w=seed_w, meta_seed_blob=seed_blob, meta_head_gain=head_gain,
                meta_variant=variant, meta_test_mode=test_mode, meta_top_n=top_n)
     cfg.TEST.MODE = 'nms'
@@ -399,10 +404,11 @@ def run_reference_test(tag, H, W, T, V, seed_w=3, seed_blob=1234, head_gain=4.0,
     out['x.cls_prob'] = cls_prob.numpy()
     out['x.bbox_pred'] = bbox_pred.numpy()[:, :24]
     flat('t.bbox_pred', digest(bbox_pred), out)
-    flat('t.mask_prob', digest(mask_prob), out)
     flat('t.net_conv', digest(net_conv), out)
-    out['x.mask_prob_0'] = mask_prob.numpy()[:4, :6]
-    out['pm.boxes'] = boxes; out['pm.labels'] = labels; out['pm.masks'] = masks.numpy()
+    if mask_prob is not None:
+        flat('t.mask_prob', digest(mask_prob), out)
+        out['x.mask_prob_0'] = mask_prob.numpy()[:4, :6]
+        out['pm.boxes'] = boxes; out['pm.labels'] = labels; out['pm.masks'] = masks.numpy()
     np.savez_compressed(os.path.join(HERE, 'ref_%s.npz' % tag), **out)
     print(tag, 'rois', rois.shape, 'cls_prob max', float(cls_prob.max()))
     return out
@@ -532,6 +538,8 @@ if __name__ == '__main__':
     if what in ('test', 'all'):
         run_reference_test('test_tiny', 320, 416, 6, 60)
         run_reference_test('test_tiny_cycle_response', 320, 416, 6, 60, variant='cycle_response')
+    if what in ('test_vgg', 'all'):
+        run_reference_test('test_tiny_vgg', 320, 416, 6, 60, variant='vgg')
     if what in ('test_top', 'all'):
         run_reference_test('test_tiny_top', 320, 416, 6, 60, test_mode='top', top_n=200)
     if what in ('full', 'all'):

@@ -50,6 +50,8 @@ def setup_from_fixture_test(g):
     """inputs of a TEST-mode fixture (default TEST proposal settings, no sampling keys)."""
     from oracle import weights as OW, synth as OS, net as ON
     opt = OW.default_opt(vocab_size=int(g['meta_V']), seq_length=int(g['meta_T']))
+    if OW.VARIANTS[variant_of(g)].get('backbone') == 'vgg':
+        opt['C4_feat_dim'] = 512
     sd = OW.make_state_dict(opt, seed=int(g['meta_seed_w']), head_gain=float(g['meta_head_gain']), variant=variant_of(g))
     blob = OS.make_blob(int(g['meta_H']), int(g['meta_W']), int(g['meta_T']), int(g['meta_V']), seed=int(g['meta_seed_blob']))
     cfg = copy.deepcopy(ON.DEFAULT_CFG)

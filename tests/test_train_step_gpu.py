@@ -128,7 +128,7 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top'])
+@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top', 'test_tiny_vgg'])
 def test_test_mode(tag):
     """TEST mode (test_image, _predict_masks_from_boxes_and_labels) against the reference's own TEST-mode outputs."""
     from golden_util import setup_from_fixture_test
@@ -155,6 +155,11 @@ def test_test_mode(tag):
     assert np.allclose(cls_prob, g['x.cls_prob'], atol=1e-5)
     assert np.allclose(bbox_pred[:, :24], g['x.bbox_pred'], atol=1e-4)
     check_digest(g, 't.bbox_pred', bbox_pred, rtol=2e-4)
+    if 't.mask_prob.sum' not in g:          # VGG16 / Faster R-CNN network: boxes only (network_vgg.py:614)
+        assert 'mask_prob' not in net._predictions
+        with pytest.raises(NotImplementedError):
+            net._predict_masks_from_boxes_and_labels(net_conv, g['int.rois'][:2, 1:], np.array([1, 2]))
+        return
     mp = net._predictions['mask_prob'].cpu().numpy().transpose(0, 3, 1, 2)      # (n, 81, 14, 14) like the reference
     check_digest(g, 't.mask_prob', mp, rtol=2e-4)
     assert np.allclose(mp[:4, :6], g['x.mask_prob_0'], atol=1e-4)
@@ -175,6 +180,20 @@ def test_eval_split_runs():
     loader = SyntheticLoader(num_images=2, sents_per_image=2, H=320, W=416, T=6, vocab_size=60)
     acc, iou, prec = eval_split(loader, net, None, 'val', dict(verbose=False))
     assert 0.0 <= acc <= 1.0 and 0.0 <= iou <= 1.0 and len(prec) == 5 and all(0.0 <= p <= 1.0 for p in prec)
+
+
+def test_eval_split_vgg_runs():
+    """model/test_vgg.py (boxes only) on the VGG16 / Faster R-CNN network in TEST mode"""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.model.test_vgg import eval_split
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    from oracle import weights as OW
+    opt = OW.default_opt(vocab_size=60, seq_length=6); opt['C4_feat_dim'] = 512
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant='vgg')
+    net = selftest.build_net(opt, {}, 'bf16', sd, variant='vgg')
+    loader = SyntheticLoader(num_images=2, sents_per_image=2, H=320, W=416, T=6, vocab_size=60)
+    acc, n = eval_split(loader, net, None, 'val', dict(verbose=False))
+    assert n == 4 and 0.0 <= acc <= 1.0
 
 
 def rel(a, b):

@@ -49,7 +49,12 @@ def main(args, variant):
     if args['set_cfgs']:
         cfg_from_list(args['set_cfgs'])
     cfg.COMPUTE_DTYPE = args['dtype']
-    net = resnetv1(opt, batch_size=1, num_layers=101, variant=variant)
+    if variant == 'vgg':
+        from lang2seg_amd.nets.vgg16 import vgg16
+        opt['C4_feat_dim'] = 512
+        net = vgg16(opt, batch_size=1)
+    else:
+        net = resnetv1(opt, batch_size=1, num_layers=101, variant=variant)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     ckpt = osp.join(ROOT, opt['dataset_splitBy'], 'output_{}'.format(args['output_postfix']),
                     cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}.pth'.format(args['model_iter']))
@@ -58,8 +63,13 @@ def main(args, variant):
         print('loaded', ckpt)
     else:
         print('no snapshot at %s: evaluating the initial weights' % ckpt)
-    acc, iou, prec = eval_split(loader, net, None, args['split'] if args['split'] in loader.split_ix else 'val',
-                                dict(num_sents=args['num_sents'], verbose=bool(args['verbose'])))
+    split = args['split'] if args['split'] in loader.split_ix else 'val'
+    if variant == 'vgg':                                     # tools/eval_vgg.py: boxes only (model/test_vgg.py)
+        from lang2seg_amd.model.test_vgg import eval_split as eval_split_vgg
+        acc, n = eval_split_vgg(loader, net, None, split, dict(num_sents=args['num_sents'], verbose=bool(args['verbose'])))
+        print('Comprehension on %s\'s %s (%s sents): box acc %.2f%%' % (opt['dataset_splitBy'], args['split'], n, acc * 100))
+        return acc, None, None
+    acc, iou, prec = eval_split(loader, net, None, split, dict(num_sents=args['num_sents'], verbose=bool(args['verbose'])))
     print('Comprehension on %s\'s %s (%s sents): box acc %.2f%%, overall IoU %.2f%%' % (
         opt['dataset_splitBy'], args['split'], args['num_sents'], acc * 100, iou * 100))
     return acc, iou, prec
