@@ -1461,13 +1461,15 @@ extern "C" int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t st
   const int bkp = dtype == L2S_BF16 ? 32 : 16;
   const int slices = cdiv(M, bkp);
   int split = d->split_k;
+  static const int min_wg = [] { const char* e = getenv("L2S_WGRAD_MINWG"); return e ? atoi(e) : 512; }();   // experiment knob
+  static const int per_split = [] { const char* e = getenv("L2S_WGRAD_SLICES"); return e ? atoi(e) : 40; }();
   if (split <= 0) {
     if (tile == 128) {
-      split = (int)((512 + tiles - 1) / tiles);        // aim at ~2 workgroups per CU
+      split = (int)((min_wg + tiles - 1) / tiles);        // aim at ~2 workgroups per CU
     } else {
-      split = slices / 40;
+      split = slices / per_split;
       int p2 = 1; while (p2 * 2 <= split) p2 *= 2; split = p2;
-      const int fill = (int)((512 + tiles - 1) / tiles);
+      const int fill = (int)((min_wg + tiles - 1) / tiles);
       if (split < fill) split = fill;
     }
     int maxs = cdiv(slices, 8);                        // at least 8 slices per split

@@ -421,8 +421,8 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
                                                    float* out_rois, int* labels, float* bt, float* bi, float* bo, float* mt,
                                                    int* counts, int* ws) {
   __shared__ int sh_cnt[4];
-  __shared__ unsigned int s_key[4096];
-  __shared__ int s_idx[4096];
+  __shared__ int sh_wc[16][2];
+  __shared__ unsigned long long s_ki[4096];         // (key << 32) | index: the rank order is one 64-bit compare
   const int tid = threadIdx.x, nt = blockDim.x;
   const int cap = n_max + n_gt;
   int* fg_list = ws; int* bg_list = ws + cap; int* argm = ws + 2 * cap; int* cls = ws + 3 * cap; int* slot = ws + 4 * cap;  // slot[R]
@@ -450,16 +450,22 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
         else if (best < bg_hi && best >= bg_lo) kind = 2;                 // PTL:146 (byte add == 2)
         cls[i] = kind;
       }
-      // ordered compaction: per-wave ballots + serial wave order via shared counters
-      for (int wv = 0; wv < (nt >> 6); ++wv) {
-        if ((tid >> 6) == wv) {
-          unsigned long long mf = __ballot(kind == 1), mb = __ballot(kind == 2);
-          const int lane = tid & 63;
-          const int bf = sh_cnt[0], bb = sh_cnt[1];
-          if (kind == 1) fg_list[bf + __popcll(mf & ((1ull << lane) - 1ull))] = i;
-          if (kind == 2) bg_list[bb + __popcll(mb & ((1ull << lane) - 1ull))] = i;
-          if (lane == 0) { sh_cnt[0] = bf + __popcll(mf); sh_cnt[1] = bb + __popcll(mb); }
+      // ordered compaction: per-wave ballots, wave bases from the 16 wave counts (index order is kept)
+      {
+        const unsigned long long mf = __ballot(kind == 1), mb = __ballot(kind == 2);
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane == 0) { sh_wc[wv][0] = __popcll(mf); sh_wc[wv][1] = __popcll(mb); }
+        __syncthreads();
+        int bf = sh_cnt[0], bb = sh_cnt[1], tf = 0, tb = 0;
+        for (int w2 = 0; w2 < (nt >> 6); ++w2) {
+          const int cf = sh_wc[w2][0], cb = sh_wc[w2][1];
+          if (w2 < wv) { bf += cf; bb += cb; }
+          tf += cf; tb += cb;
         }
+        if (kind == 1) fg_list[bf + __popcll(mf & ((1ull << lane) - 1ull))] = i;
+        if (kind == 2) bg_list[bb + __popcll(mb & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) { sh_cnt[0] += tf; sh_cnt[1] += tb; }
         __syncthreads();
       }
     }
@@ -475,34 +481,41 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
   for (int s = tid; s < R; s += nt) slot[s] = -1;
   __syncthreads();
   // rank by key inside each list; the k smallest keys are emitted in key order (= fg_inds[npr.choice(n,k,False)])
-  if (!fg_repl) {
-    const bool lds = n_fg <= 4096;
-    if (lds) { for (int a = tid; a < n_fg; a += nt) { const int i = fg_list[a]; s_idx[a] = i; s_key[a] = fkey(i); } }
-    __syncthreads();
-    for (int a = tid; a < n_fg; a += nt) {
-      const int i = fg_list[a]; const uint32_t ki = fkey(i); int rank = 0;
-      if (lds) for (int b = 0; b < n_fg; ++b) { const int j = s_idx[b]; const uint32_t kj = s_key[b]; rank += (kj < ki) || (kj == ki && j < i); }
-      else for (int b = 0; b < n_fg; ++b) { const int j = fg_list[b]; const uint32_t kj = fkey(j); rank += (kj < ki) || (kj == ki && j < i); }
-      if (rank < nfg_sel) slot[rank] = i;
-    }
-    __syncthreads();
-  } else {
-    for (int s = tid; s < nfg_sel; s += nt) slot[s] = fg_list[bg_rand[s] % (uint32_t)n_fg];
-  }
-  if (nbg_sel > 0) {
-    if (!bg_repl) {
-      const bool lds = n_bg <= 4096;
-      if (lds) { for (int a = tid; a < n_bg; a += nt) { const int i = bg_list[a]; s_idx[a] = i; s_key[a] = bkey(i); } }
-      __syncthreads();
-      for (int a = tid; a < n_bg; a += nt) {
-        const int i = bg_list[a]; const uint32_t ki = bkey(i); int rank = 0;
-        if (lds) for (int b = 0; b < n_bg; ++b) { const int j = s_idx[b]; const uint32_t kj = s_key[b]; rank += (kj < ki) || (kj == ki && j < i); }
-        else for (int b = 0; b < n_bg; ++b) { const int j = bg_list[b]; const uint32_t kj = bkey(j); rank += (kj < ki) || (kj == ki && j < i); }
-        if (rank < nbg_sel) slot[nfg_sel + rank] = i;
+  // LDS path (up to 4096 candidates): bitonic sort of the packed (key, index) words — the O(n^2) rank count of ~1900 background
+  // candidates is ~3.6 M compares on ONE compute unit (80+ us); the sort is 66 compare-exchange steps
+  auto rank_list = [&](const int* list, int cnt, bool is_fg, int nsel, int slot0) {
+    if (cnt <= 4096) {
+      int N2 = 2; while (N2 < cnt) N2 <<= 1;
+      for (int a = tid; a < N2; a += nt) {
+        unsigned long long v = ~0ull;
+        if (a < cnt) { const int i = list[a]; v = ((unsigned long long)(is_fg ? fkey(i) : bkey(i)) << 32) | (unsigned int)i; }
+        s_ki[a] = v;
       }
+      __syncthreads();
+      for (int k = 2; k <= N2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = tid; t < (N2 >> 1); t += nt) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+            const unsigned long long x = s_ki[i], y = s_ki[p];
+            if ((x > y) == ((i & k) == 0)) { s_ki[i] = y; s_ki[p] = x; }
+          }
+          __syncthreads();
+        }
+      for (int r = tid; r < min(nsel, cnt); r += nt) slot[slot0 + r] = (int)(unsigned int)s_ki[r];
     } else {
-      for (int s = tid; s < nbg_sel; s += nt) slot[nfg_sel + s] = bg_list[bg_rand[s] % (uint32_t)n_bg];
+      for (int a = tid; a < cnt; a += nt) {
+        const int i = list[a]; const uint32_t ki = is_fg ? fkey(i) : bkey(i); int rank = 0;
+        for (int b = 0; b < cnt; ++b) { const int j = list[b]; const uint32_t kj = is_fg ? fkey(j) : bkey(j); rank += (kj < ki) || (kj == ki && j < i); }
+        if (rank < nsel) slot[slot0 + rank] = i;
+      }
     }
+    __syncthreads();
+  };
+  if (!fg_repl) rank_list(fg_list, n_fg, true, nfg_sel, 0);
+  else for (int s = tid; s < nfg_sel; s += nt) slot[s] = fg_list[bg_rand[s] % (uint32_t)n_fg];
+  if (nbg_sel > 0) {
+    if (!bg_repl) rank_list(bg_list, n_bg, false, nbg_sel, nfg_sel);
+    else for (int s = tid; s < nbg_sel; s += nt) slot[nfg_sel + s] = bg_list[bg_rand[s] % (uint32_t)n_bg];
   }
   __syncthreads();
   if (tid == 0) { counts[0] = min(nfg_sel, fg_max); counts[1] = n_fg; counts[2] = n_bg; counts[3] = appended; }
@@ -530,29 +543,53 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
     for (int k = 0; k < 4; ++k) out_rois[s * 5 + 1 + k] = b[k];
     labels[s] = lab;
   }
-  // mask targets (PTL:193-201): crop gt mask to the roi, PIL-NEAREST resize to ms x ms
+  // mask targets (PTL:193-201): crop gt mask to the roi, PIL-NEAREST resize to ms x ms.  The per-RoI crop geometry goes through
+  // LDS first, so that an element costs one global load (issued four at a time) instead of a chain of four dependent ones.
   const int nm = min(nfg_sel, fg_max);
-  for (int e = tid; e < fg_max * ms * ms; e += nt) {
-    const int s = e / (ms * ms), r = e - s * ms * ms, py = r / ms, px = r - py * ms;
-    float v = 0.f;
-    if (s < nm && slot[s] >= 0) {
+  int* s_geo = (int*)s_ki;                               // [fg_max][6]: x1, y1, cw, ch, gt index, valid   (the sort buffer is free now)
+  __syncthreads();
+  for (int s = tid; s < fg_max; s += nt) {
+    int x1 = 0, y1 = 0, cw = 0, ch = 0, ga = 0, ok = 0;
+    if (s < nm && slot[s] >= 0 && fg_max * 6 <= 8192) {
       const int i = slot[s];
       float b[4]; roi_ptr(i, b);
-      const int x1 = (int)b[0], y1 = (int)b[1];
+      x1 = (int)b[0]; y1 = (int)b[1];
       int x2 = (int)b[2] + 1, y2 = (int)b[3] + 1;                       // python slice end, clipped by numpy
       x2 = min(x2, im_w); y2 = min(y2, im_h);
-      const int cw = x2 - x1, ch = y2 - y1;
-      if (cw > 0 && ch > 0) {
-        // PIL nearest: xo = 0.5*s; idx_k = (int)xo; xo += s  (float64, sequential adds)
-        const double sx = (double)cw / (double)ms, sy = (double)ch / (double)ms;
-        double xo = 0.5 * sx, yo = 0.5 * sy;
-        for (int k = 0; k < px; ++k) xo += sx;
-        for (int k = 0; k < py; ++k) yo += sy;
-        const int ix = min((int)xo, cw - 1), iy = min((int)yo, ch - 1);
-        v = (float)gt_masks[((long)argm[i] * im_h + (y1 + iy)) * im_w + (x1 + ix)];
+      cw = x2 - x1; ch = y2 - y1; ga = argm[i]; ok = cw > 0 && ch > 0;
+    }
+    int* g6 = s_geo + s * 6;
+    g6[0] = x1; g6[1] = y1; g6[2] = cw; g6[3] = ch; g6[4] = ga; g6[5] = ok;
+  }
+  __syncthreads();
+  const int ms2 = ms * ms, total = fg_max * ms2;
+  for (int e0 = tid; e0 < total; e0 += 4 * nt) {
+    long addr[4]; bool val[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * nt;
+      val[q] = false; addr[q] = 0;
+      if (e < total) {
+        const int s = e / ms2, r = e - s * ms2, py = r / ms, px = r - py * ms;
+        const int* g6 = s_geo + s * 6;
+        if (g6[5]) {
+          // PIL nearest: xo = 0.5*s; idx_k = (int)xo; xo += s  (float64, sequential adds)
+          const int cw = g6[2], ch = g6[3];
+          const double sx = (double)cw / (double)ms, sy = (double)ch / (double)ms;
+          double xo = 0.5 * sx, yo = 0.5 * sy;
+          for (int k = 0; k < px; ++k) xo += sx;
+          for (int k = 0; k < py; ++k) yo += sy;
+          const int ix = min((int)xo, cw - 1), iy = min((int)yo, ch - 1);
+          addr[q] = ((long)g6[4] * im_h + (g6[1] + iy)) * im_w + (g6[0] + ix);
+          val[q] = true;
+        }
       }
     }
-    mt[e] = v;
+    uint8_t m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = val[q] ? gt_masks[addr[q]] : (uint8_t)0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int e = e0 + q * nt; if (e < total) mt[e] = (float)m[q]; }
   }
 }
 
