@@ -171,7 +171,7 @@ def main():
                                    '20-token expression (V=3349), 12000->2000 proposals, 256 RoIs, per-GPU batch 1' % (args.height, args.width),
                        'parallelism': 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12},
             'step_tflops_per_gpu': STEP_FLOP / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': STEP_FLOP / (ms * 1e-3) / PEAK_BF16,
-            'roofline': {'bound': 'mfma', 'kernel': 'igemm_sp_kernel<bf16,256,128> on layer4@RoIs conv3x3 (M=%d,N=512,K=4608)' % (R * 49),
+            'roofline': {'bound': 'mfma', 'kernel': 'igemm_sp_kernel<bf16,224,128> on layer4@RoIs conv3x3 (M=%d,N=512,K=4608)' % (R * 49),
                          'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': _pmc_traffic(), 'traffic_note': 'HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes 30.4 MB',
                          'avg_launch_ms': kms, 'launches_timed': len(evs)},
             'final_losses': [float(x) for x in lv[:7]],
