@@ -145,14 +145,13 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 //   wave 0 (critical path): scans block j against remv[j] (only the kept boxes cost an iteration), then ORs the kept rows'
 //           words of columns j+1 and j+2 (prefetched one phase ahead) straight into remv;
 //   waves 1..15 (bulk, software pipelined): in phase j+1 they LOAD the kept rows of block j for every column >= j+3 into
-//           registers, in phase j+2 they OR them into remv with fire-and-forget LDS atomics -- so the HBM/L2 latency of the
-//           bulk rows spans a whole phase instead of sitting in front of every barrier.
+//           registers (whole rows, one wave per row: contiguous 512-byte pieces), in phase j+2 they OR them into remv with
+//           fire-and-forget LDS atomics -- so the L2 latency of the bulk rows spans a whole phase.
 // One barrier per phase; stops as soon as max_keep boxes are kept (RPN_POST_NMS_TOP_N).
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out) {
   extern __shared__ unsigned long long remv[];   // cb words
   __shared__ unsigned long long kept_sh[2];
   __shared__ int nk_sh[2];
-  constexpr int NQ = 13, BULK = 960;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < cb; c += 1024) remv[c] = 0ull;
   if (tid == 0) { nk_sh[0] = nk_sh[1] = 0; kept_sh[0] = kept_sh[1] = 0ull; }
@@ -164,10 +163,17 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
     if (cb > 1) c1next = mask[(long)lane * cb + 1];
     if (cb > 2) c2next = mask[(long)lane * cb + 2];
   }
-  unsigned long long pv[NQ]; int pc[NQ];      // bulk values loaded in the previous phase and their columns
-  const int brow = (tid - 64) / 15, bcl = (tid - 64) - brow * 15;   // bulk threads: row of the block, column lane
+  // bulk waves: wave w owns rows w-1, w-1+15, ... of a block (up to RW = 5); a lane owns columns c0 + lane + 64 k (k < CK = 3).
+  // A kept row is a wave-uniform condition and its words are read as contiguous 512-byte pieces: the kernel is bound by what ONE
+  // compute unit's L1 path can move (~9 MB of mask words per 12000 boxes at 64 B/clk), so the pieces have to be whole cache lines
+  // (a 64-rows x 15-lanes map that read 120-byte pieces took 231 us, this one 198 us; 16-byte loads of column pairs took 243 us).
+  // The rows of one phase are OR-combined when they are applied, so a lane issues at most CK LDS atomics per phase.
+  constexpr int RW = 5, CK = 3;
+  unsigned long long pv[RW][CK]; int pc0 = 0;    // bulk words requested in the previous phase and their first column
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) { pv[q] = 0ull; pc[q] = 0; }
+  for (int ri = 0; ri < RW; ++ri)
+#pragma unroll
+    for (int k = 0; k < CK; ++k) pv[ri][k] = 0ull;
   for (int b = 0; b < cb; ++b) {
     if (wave == 0) {
       const int row = b * 64 + lane;
@@ -203,24 +209,32 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
       nk += __popcll(K);
       if (lane == 0) { kept_sh[b & 1] = K; nk_sh[b & 1] = nk; }
     } else {
-      // (2) apply what was loaded in the previous phase (block b-2 -> columns >= b+1)
+      // (2) apply what was requested in the previous phase (block b-2 -> columns >= b+1)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { if (pv[q]) atomicOr(&remv[pc[q]], pv[q]); pv[q] = 0ull; }
-      // (1) load block b-1's kept rows for columns >= b+2.  Fixed thread -> (row, column lane) map: 64 rows x 15 lanes,
-      //     lane cl covers columns c0 + cl + 15 q (no per-phase index division; a row's 15 lanes read 120 contiguous bytes)
+      for (int k = 0; k < CK; ++k) {
+        unsigned long long a = 0ull;
+#pragma unroll
+        for (int ri = 0; ri < RW; ++ri) { a |= pv[ri][k]; pv[ri][k] = 0ull; }
+        if (a) atomicOr(&remv[pc0 + lane + 64 * k], a);
+      }
+      // (1) request block b-1's kept rows for columns >= b+2
       if (b > 0) {
         const unsigned long long Kp = kept_sh[(b - 1) & 1];
         const int c0 = b + 2;
-        if ((Kp >> brow) & 1ull) {
-          const uint64_t* mr = mask + (long)((b - 1) * 64 + brow) * cb;
+        pc0 = c0;
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            const int c = c0 + bcl + 15 * q;
-            pc[q] = c;
-            if (c < cb) pv[q] = mr[c];
-          }
-          for (int c = c0 + bcl + 15 * NQ; c < cb; c += 15) {                   // larger problems: the rest synchronously
-            const unsigned long long v = mr[c]; if (v) atomicOr(&remv[c], v);
+        for (int ri = 0; ri < RW; ++ri) {
+          const int r = (wave - 1) + 15 * ri;
+          if (r < 64 && ((Kp >> r) & 1ull)) {                                   // wave-uniform
+            const uint64_t* mr = mask + (long)((b - 1) * 64 + r) * cb;
+#pragma unroll
+            for (int k = 0; k < CK; ++k) {
+              const int c = c0 + lane + 64 * k;
+              if (c < cb) pv[ri][k] = mr[c];
+            }
+            for (int c = c0 + lane + 64 * CK; c < cb; c += 64) {                // larger problems: the rest synchronously
+              const unsigned long long v = mr[c]; if (v) atomicOr(&remv[c], v);
+            }
           }
         }
       }
