@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Input-side throughput: CycleLoader.getBatch on a generated COCO-sized dataset (480x640 JPEGs, 2-3 referred
+"""(Lives under tests/: it times the oracle's numpy restatement next to the loader, and only tests/ may use oracle/.)
+Input-side throughput: CycleLoader.getBatch on a generated COCO-sized dataset (480x640 JPEGs, 2-3 referred
 objects per image, polygon-like masks) against the oracle's numpy restatement of the reference's per-image CPU work
 (prep_im_for_blob + RLE decode + union + nearest resize, one thread).  Prints per-batch times and the device kernel time."""
 import os
