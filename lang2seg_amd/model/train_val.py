@@ -69,6 +69,9 @@ class SolverWrapper(object):
                 pickle.dump(self.loader.iterators[split], fid, pickle.HIGHEST_PROTOCOL)
                 pickle.dump(self.loader.perm[split], fid, pickle.HIGHEST_PROTOCOL)
             pickle.dump(it, fid, pickle.HIGHEST_PROTOCOL)
+            # after the reference's fields (a reader of its format stops above): the device-side RNG step counter, so that a resumed run
+            # draws the sampling keys / dropout masks the uninterrupted one would have
+            pickle.dump(int(self.net.seed_counter().item()), fid, pickle.HIGHEST_PROTOCOL)
         return filename, nfilename
 
     # ---- TV:106-165 ----------------------------------------------------
@@ -96,6 +99,10 @@ class SolverWrapper(object):
                 self.loader.iterators[split] = pickle.load(fid)
                 self.loader.perm[split] = pickle.load(fid)
             last_snapshot_iter = pickle.load(fid)
+            try:
+                self.net.seed_counter().fill_(int(pickle.load(fid)))
+            except EOFError:                      # a sidecar written by the reference
+                pass
         return last_snapshot_iter
 
     # ---- TV:167-225 ----------------------------------------------------

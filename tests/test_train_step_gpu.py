@@ -268,3 +268,50 @@ def test_early_partial_sgd_matches_single_update():
     _, d_ref = run(False, False, 1e-3, 1)
     _, d = run(True, False, 1e-3, 1)
     assert float(d_ref.abs().max()) > 0 and rel(d, d_ref) < 1e-3
+
+
+def test_train_net_snapshot_and_resume(tmp_path):
+    """model/train_val.py train_net (TV:327-434) end to end on the HIP step: display / LR step / snapshot cadence, the reference's
+    snapshot pair (state dict in its key + shape format, sidecar with RNG states and loader cursors), and resume from the newest
+    snapshot with the LR rescaled by the steps already passed (TV:227-310)."""
+    import glob, os, pickle
+    from lang2seg_amd import selftest
+    from lang2seg_amd.model.config import cfg
+    from lang2seg_amd.model.train_val import train_net
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    from oracle import weights as OW
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=16, RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=100, RPN_BATCHSIZE=64)
+    saved = {k: cfg.TRAIN[k] for k in ('SNAPSHOT_ITERS', 'DISPLAY', 'STEPSIZE', 'SNAPSHOT_KEPT', 'LEARNING_RATE')}
+    cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.DISPLAY, cfg.TRAIN.STEPSIZE, cfg.TRAIN.SNAPSHOT_KEPT = 2, 1, [3], 3
+    out = str(tmp_path / 'out')
+    try:
+        mk_loader = lambda: SyntheticLoader(num_images=3, sents_per_image=2, H=160, W=224, T=6, vocab_size=60)
+        net = selftest.build_net(opt, over, 'f32', sd)
+        sw = train_net(net, mk_loader(), out, str(tmp_path / 'tb'), max_iters=4)
+        pths = sorted(os.path.basename(f) for f in glob.glob(os.path.join(out, '*.pth')))
+        assert cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_4.pth' in pths and cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_2.pth' in pths
+        assert abs(sw.optimizer.lr - cfg.TRAIN.LEARNING_RATE * cfg.TRAIN.GAMMA) < 1e-12          # stepped at iter 4 = STEPSIZE + 1
+        ck = torch.load(os.path.join(out, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_4.pth'), map_location='cpu')
+        # (the reference's state dict also carries torchvision's unused resnet.fc.*; the oracle's weight set does not)
+        assert set(sd.keys()) <= set(ck.keys()) and all(tuple(ck[k].shape) == sd[k].shape for k in sd)
+        assert any(float((ck[k].float() - torch.from_numpy(sd[k])).abs().max()) > 0 for k in ('cls_score_net.weight', 'resnet.layer3.5.conv2.weight'))
+        w4 = {k: v.clone() for k, v in net.state_dict().items()}
+        for k in ck:
+            assert torch.equal(ck[k], w4[k]), k
+        with open(os.path.join(out, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_4.pkl'), 'rb') as f:
+            pickle.load(f); pickle.load(f)
+            it_train = pickle.load(f)
+        # resume: a fresh network and loader pick the newest snapshot up and continue to iteration 6
+        net2 = selftest.build_net(opt, over, 'f32', sd)
+        ld2 = mk_loader()
+        sw2 = train_net(net2, ld2, out, str(tmp_path / 'tb'), max_iters=6)
+        assert os.path.exists(os.path.join(out, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_6.pth'))
+        assert abs(sw2.optimizer.lr - cfg.TRAIN.LEARNING_RATE * cfg.TRAIN.GAMMA) < 1e-12          # rescaled on resume: 4 > STEPSIZE
+        assert isinstance(it_train, int) and int(net2.seed_counter().item()) > 0
+        d = max(float((net2.state_dict()[k].float() - w4[k].float()).abs().max()) for k in ('cls_score_net.weight', 'rpn_net.weight'))
+        assert 0 < d < 1.0                                  # moved on from the restored weights
+    finally:
+        for k, v in saved.items():
+            cfg.TRAIN[k] = v
