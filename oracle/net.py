@@ -122,6 +122,12 @@ class OracleNet(object):
         return self._layer(x, 4, 1)       # RES:271-273, layer4 stride 1 (RES:131)
 
     # ---- language encoder (ENC:27-82), batch 1 ----------------------------
+    @staticmethod
+    def trim_labels(labels):
+        """forward(), NET:629-630: `max_len = (labels != 0).sum(1).max(); labels = labels[:, :max_len]` (zero padding at the row end)"""
+        labels = np.asarray(labels)
+        return np.ascontiguousarray(labels[:, :int((labels != 0).sum(1).max())])
+
     def rnn_encoder(self, labels, word_drop=None):
         emb = self.p['rnn_encoder.embedding.weight'][labels[0]]          # (T, E)
         if word_drop is not None:
@@ -250,7 +256,7 @@ class OracleNet(object):
         self._im_info = im_info
         base = self.image_to_head(image)
         T['net_conv_base'] = base
-        hidden = self.rnn_encoder(torch.from_numpy(blob['labels']), None if drops is None else drops.get('word'))
+        hidden = self.rnn_encoder(torch.from_numpy(self.trim_labels(blob['labels'])), None if drops is None else drops.get('word'))
         T['hidden'] = hidden
         net_conv = self.dynamic_filter(base, hidden)
         T['net_conv'] = net_conv; T['response'] = self.t_response
@@ -359,7 +365,7 @@ class OracleNet(object):
             im_info = blob['im_info']
             self._im_info = im_info
             base = self.image_to_head(image)
-            hidden = self.rnn_encoder(torch.from_numpy(blob['labels']))
+            hidden = self.rnn_encoder(torch.from_numpy(self.trim_labels(blob['labels'])))
             net_conv = self.dynamic_filter(base, hidden)
             H, W = net_conv.shape[2], net_conv.shape[3]
             anchors, _ = B.generate_anchors_pre(H, W, 16, cfg['ANCHOR_SCALES'], cfg['ANCHOR_RATIOS'])

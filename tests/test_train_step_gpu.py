@@ -315,3 +315,62 @@ def test_train_net_snapshot_and_resume(tmp_path):
     finally:
         for k, v in saved.items():
             cfg.TRAIN[k] = v
+
+
+def _edge_blob(kind):
+    from oracle import synth as OS
+    V = 60
+    if kind == 'one_token':                     # shortest expression: a single token (max_len = 1), caption of one word
+        b = OS.make_blob(160, 224, 1, V, seed=21)
+    elif kind == 'padded_tokens':               # zero padding inside the label row: T = 6 columns, 3 real tokens
+        b = OS.make_blob(160, 224, 6, V, seed=22)
+        b['labels'][0, 3:] = 0
+        b['cap_labels'][0, 4:] = 0
+        b['cap_masks'][0, 5:] = 0               # 3 words + BOS + EOS positions count (cycle_loader.py:297-305)
+    elif kind == 'small_image':                 # 96x128 image: 6x8 map, 576 anchors < RPN_PRE_NMS_TOP_N, few proposals
+        b = OS.make_blob(96, 128, 4, V, seed=23)
+    elif kind == 'full_image_box':              # the referred object fills the image
+        b = OS.make_blob(160, 224, 5, V, seed=24)
+        H, W = 160, 224
+        b['gt_boxes'][0, :4] = [0, 0, W - 1, H - 1]
+        b['gt_masks'][:] = 1
+    elif kind == 'tiny_box':                    # an object smaller than one feature-map cell
+        b = OS.make_blob(160, 224, 5, V, seed=25)
+        b['gt_boxes'][0, :4] = [100, 60, 109, 70]
+        b['gt_masks'][:] = 0
+        b['gt_masks'][0, 60:71, 100:110] = 1
+    return b
+
+
+@pytest.mark.parametrize('kind', ['one_token', 'padded_tokens', 'small_image', 'full_image_box', 'tiny_box'])
+def test_edge_cases_vs_oracle(kind):
+    """ragged / extreme inputs of the blobs contract through the whole HIP step against the oracle (same recorded sampling keys, the
+    device's own proposals teacher-forced into the oracle): losses within 1e-3, integer targets exact."""
+    import copy
+    from lang2seg_amd import selftest
+    from oracle import weights as OW, net as ON
+    blob = _edge_blob(kind)
+    H, W = blob['data'].shape[1:3]
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=16, RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=100, RPN_BATCHSIZE=64)
+    ocfg = copy.deepcopy(ON.DEFAULT_CFG); ocfg['TRAIN'].update(over)
+    Hc, Wc = -(-H // 16), -(-W // 16)
+    nA = Hc * Wc * 12
+    rs = np.random.RandomState(1)
+    samp = dict(rpn_fg_keys=rs.permutation(nA).astype(np.uint32), rpn_bg_keys=rs.permutation(nA).astype(np.uint32),
+                roi_fg_keys=rs.permutation(100).astype(np.uint32), roi_bg_keys=rs.permutation(100).astype(np.uint32))
+    net = selftest.build_net(opt, over, 'f32', sd)
+    net.parity = selftest.parity_from_samp(samp)
+    lv = net.forward_backward(net.upload_blob(blob, 0)).cpu().numpy()
+    n = int(net.t['proposal_n'].item())
+    assert n > 0
+    samp['forced_proposals'] = (net.t['proposal_rois'].cpu().numpy()[:n], net.t['proposal_scores'].cpu().numpy()[:n])
+    onet = ON.OracleNet(sd, opt, ocfg)
+    T, L = onet.forward_train(blob, samp)
+    for i, k in enumerate(NAMES):
+        ref = float(L[k])
+        assert np.isfinite(lv[i]) and abs(lv[i] - ref) < 1e-3 * max(1.0, abs(ref)), (kind, k, lv[i], ref)
+    assert np.array_equal(net.t['labels'].cpu().numpy().astype(np.int64), np.asarray(T['labels']).reshape(-1).astype(np.int64))
+    assert np.array_equal(net.t['rpn_labels'].cpu().numpy().astype(np.int64), np.asarray(T['rpn_labels']).reshape(-1).astype(np.int64))
+    assert np.isfinite(net.P.grad.float().abs().sum().item())
