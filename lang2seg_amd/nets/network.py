@@ -163,6 +163,7 @@ class Network(object):
         self.training = True
         self.device = 'cuda'
         self._bufs = {}
+        self._buf_users = {}        # buffer key -> keys of the launch tapes that captured its address
         self.convs = []
         self._step = 0
         self.parity = None          # dict of injected sampling keys / dropout masks (tests); None = production RNG
@@ -183,10 +184,15 @@ class Network(object):
         """persistent activation plan: one device buffer per (site, shape), allocated on first use."""
         key = (name, tuple(shape), dtype)
         t = self._bufs.get(key)
+        rec = getattr(self, '_rec_key', None)
+        if rec is not None:
+            self._buf_users.setdefault(key, set()).add(rec)     # the tape being recorded holds this buffer's address
         if t is None:
             td = O.TORCH_DT[self.dt] if dtype is None else dtype
             t = torch.zeros(tuple(shape), dtype=td, device=self.device)
             self._bufs[key] = t
+            if zero and rec is not None:
+                O.memset_zero(t)                                 # the clear has to be ON the tape even when the buffer is new
         elif zero:
             O.memset_zero(t)
         return t
@@ -231,22 +237,23 @@ class Network(object):
         randomness comes from the device-side step counter."""
         key = (tuple(dev['data'].shape), dev['T'], dev['S'], float(train_op.lr), float(train_op.grad_scale), self.training)
         if not hasattr(self, '_tapes'):
-            self._tapes = {}
+            import collections
+            self._tapes = collections.OrderedDict()                  # least recently used first
         ent = self._tapes.get(key)
         main = torch.cuda.current_stream()
         S = self.streams()
         slist = [main, S['lang'], S['cap'], S['wg'], S['wg2'], S['tr']]
         dp = self.dp
         if ent is None:
+            # a new (image size, token counts): the step is executed once, eagerly, and recorded while it runs
+            while len(self._tapes) >= int(getattr(self, 'max_tapes', 64)):
+                self._evict_tape()
             st = {k: dev[k].clone() for k in ('data', 'gt_boxes', 'gt_masks', 'labels', 'cap_in', 'cap_tgt', 'cap_mask')}
             d = dict(dev); d.update(st)
-            loss = self.forward_backward(d)                           # allocates the activation plan for this shape
-            if dp is not None:
-                dp.finish()
-            train_op.step()
             torch.cuda.synchronize()
             h = O.tape_begin(slist)
             self._tape_stages = []
+            self._rec_key = key
             try:
                 loss = self.forward_backward(d)                       # dp_ready() cuts the tape at every bucket hand-off
                 if dp is not None:
@@ -254,9 +261,11 @@ class Network(object):
                 train_op.step()
             finally:
                 O.tape_end(h)
+                self._rec_key = None
             stages, self._tape_stages = self._tape_stages, None
             self._tapes[key] = (h, st, loss, stages)
             return loss
+        self._tapes.move_to_end(key)
         h, st, loss, stages = ent
         for k, v in st.items():
             if v.data_ptr() != dev[k].data_ptr():
@@ -274,6 +283,18 @@ class Network(object):
                 dp.ready(stage)
         O.tape_run_segment(h, slist, len(stages))
         return loss
+
+    def _evict_tape(self):
+        """drop the least recently used tape and every activation buffer only it was holding (real data: one activation plan per
+        image size would otherwise accumulate)"""
+        key, (h, st, loss, stages) = self._tapes.popitem(last=False)
+        O.tape_destroy(h)
+        for bk in [bk for bk, users in self._buf_users.items() if key in users]:
+            users = self._buf_users[bk]
+            users.discard(key)
+            if not users:
+                del self._buf_users[bk]
+                self._bufs.pop(bk, None)
 
     def dp_ready(self, stage):
         """a gradient bucket is final: hand it to the data-parallel reducer (and cut the launch tape there while recording)."""
@@ -386,7 +407,8 @@ class Network(object):
             O.weight_transpose_batched(self._tr_table, self._tr_n, self.dt)
 
     def join_transposes(self):
-        if self.use_streams and getattr(self, '_tr_pending', False):
+        # unconditional: whether a refresh is pending is host state, and a step recorded on a launch tape must contain the edge
+        if self.use_streams:
             self.sfork(self.streams()['tr'], torch.cuda.current_stream())
             self._tr_pending = False
 

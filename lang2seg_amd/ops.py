@@ -63,6 +63,11 @@ def tape_run_segment(h, streams, seg):
     call('l2s_tape_run_segment', h, arr, len(streams), seg)
 
 
+def tape_destroy(h):
+    torch.cuda.synchronize()                     # nothing of the tape may still be in flight
+    call('l2s_tape_destroy', h)
+
+
 def tape_size(h):
     return int(_lib.load().l2s_tape_size(h))
 

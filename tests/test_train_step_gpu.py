@@ -223,10 +223,8 @@ def test_dp_tape_segments_match_eager():
         net.use_tape = tape
         sgd = SGD(net, 0.0)            # lr 0: the weights stay put, so the steps are comparable one by one (the proposal list is
                                        # discontinuous in the weights; any update would let fp32 atomic-order noise pick different RoIs)
-        # the first tape call runs the step twice (shape warm-up + recording), so 4 tape calls = 5 eager steps
-        vals = [net.train_step(dict(blob), 0, sgd) for _ in range(4 if tape else 5)]
-        if not tape:
-            vals = vals[1:]
+        # (the first tape call executes the step once and records it while it runs; the later calls replay)
+        vals = [net.train_step(dict(blob), 0, sgd) for _ in range(4)]
         torch.cuda.synchronize()
         res.append((vals, net.P.view('resnet.layer3.5.conv2.weight', net.P.grad).clone(), net.P.view('cls_score_net.weight', net.P.grad).clone()))
     for a, b in zip(res[0][0], res[1][0]):
@@ -261,7 +259,7 @@ def test_early_partial_sgd_matches_single_update():
 
     m_ref, _ = run(False, False, 0.0, 2)
     assert float(m_ref.abs().max()) > 0
-    for early, tape, calls in ((True, False, 2), (True, True, 1)):       # the first tape call runs the step twice
+    for early, tape, calls in ((True, False, 2), (True, True, 2)):       # first tape call: executed + recorded, second: replayed
         m, dw = run(early, tape, 0.0, calls)
         assert rel(m, m_ref) < 1e-3, (early, tape)
         assert float(dw.abs().max()) == 0.0
@@ -374,3 +372,31 @@ def test_edge_cases_vs_oracle(kind):
     assert np.array_equal(net.t['labels'].cpu().numpy().astype(np.int64), np.asarray(T['labels']).reshape(-1).astype(np.int64))
     assert np.array_equal(net.t['rpn_labels'].cpu().numpy().astype(np.int64), np.asarray(T['rpn_labels']).reshape(-1).astype(np.int64))
     assert np.isfinite(net.P.grad.float().abs().sum().item())
+
+
+def test_tape_over_mixed_shapes_matches_eager():
+    """real data feeds a different image size / token count almost every step: the launch tape records a new shape while it executes
+    it (no extra step), replays the ones it has seen, and evicts the least recently used tape together with its activation plan.
+    Same losses as the eager step for the same sequence of inputs (lr 0: weights stay put)."""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=16, RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=100, RPN_BATCHSIZE=64)
+    blobs = [OS.make_blob(160, 224, 6, 60, seed=5), OS.make_blob(128, 256, 4, 60, seed=6), OS.make_blob(192, 160, 5, 60, seed=7)]
+    order = [0, 1, 0, 2, 1, 0, 2, 2, 1]                   # with max_tapes = 2 the third shape evicts the least recently used one
+    res = []
+    for tape in (False, True):
+        net = selftest.build_net(opt, over, 'f32', sd)
+        net.use_tape = tape
+        net.max_tapes = 2
+        sgd = SGD(net, 0.0)
+        res.append([net.train_step(dict(blobs[i]), 0, sgd) for i in order])
+        torch.cuda.synchronize()
+        if tape:
+            assert len(net._tapes) == 2
+            live = {k[0] for k in net._tapes}
+            assert all(any(t[0] in live for t in users) for users in net._buf_users.values())
+    for k, (a, b) in enumerate(zip(res[0], res[1])):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (k, order[k], a, b)
