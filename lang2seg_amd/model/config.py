@@ -56,7 +56,7 @@ __C.TRAIN.BBOX_THRESH = 0.5
 __C.TRAIN.SNAPSHOT_ITERS = 5000
 __C.TRAIN.SNAPSHOT_PREFIX = 'res101_mask_rcnn'
 # replay steps from per-shape launch tapes in train_net (see model/train_val.py)
-__C.TRAIN.USE_TAPE = False
+__C.TRAIN.USE_TAPE = True
 __C.TRAIN.BBOX_NORMALIZE_TARGETS = True
 __C.TRAIN.BBOX_INSIDE_WEIGHTS = (1.0, 1.0, 1.0, 1.0)
 __C.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = True

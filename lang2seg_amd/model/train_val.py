@@ -167,10 +167,10 @@ class SolverWrapper(object):
         next_stepsize = stepsizes.pop()
         self.net.train(); self.net.cuda()
         # TRAIN.USE_TAPE: record every (image size, token counts) on a launch tape while it first executes and replay it afterwards
-        # (Network.tape_step; least recently used tapes and their activation plans are evicted).  Off by default: on a stream of mixed
-        # sizes the eager issue path keeps up with the GPU (tools/mixed_shape_bench.py: 127.8 vs 120.0 img/s); it pays at one fixed
-        # 600x1000 shape (122 vs 102-110 img/s, bench.py --tape 0/1).
-        self.net.use_tape = bool(getattr(cfg.TRAIN, 'USE_TAPE', False))
+        # (Network.tape_step; least recently used tapes and their activation plans are evicted).  Measured: a stream of six mixed
+        # shapes 120-121 img/s against 116 img/s issued eagerly (tools/mixed_shape_bench.py); one fixed shape 122 vs 102-110 (600x1000),
+        # 127.5 vs 112-116 (600x800), 135 vs 101 (480x640) (bench.py --tape 1/0).
+        self.net.use_tape = bool(getattr(cfg.TRAIN, 'USE_TAPE', True))
         timer = Timer()
         while it < max_iters + 1:
             blobs = self.loader.getBatch('train', self.net._batch_size)

@@ -71,17 +71,28 @@ class resnetv1(Network):
         del self._initial_state
 
     def init_weights(self):
-        """NET:333-355 / RES:135-141 initialisers (host RNG, once, before the first load)."""
+        """NET:333-355 / RES:135-141 initialisers (host RNG, once, before the first load).
+        The reference never runs its ResNet from these values (the trunk always comes from the pretrained detector); a network that IS
+        run from them (bench.py, tools without a checkpoint) has frozen identity BatchNorm and pixel-scale inputs, and its activations
+        overflow bf16 / fp32 within one step (layer3 output ~1e6, NaN after the first update).  Three scale factors keep the residual
+        stream's variance flat through the 33 blocks, as oracle/weights.make_state_dict does for the parity fixtures: the last BN
+        gain of a block 0.15, the shortcut BN gain 0.7, conv1 x 0.05."""
         g = torch.Generator().manual_seed(cfg.RNG_SEED)
         sd = {}
         for k, shp in self.P.shapes.items():
             n = int(np.prod(shp))
-            if k.endswith('running_var') or (('.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1')) and k.endswith('weight')):
+            if k.endswith('bn3.weight'):
+                t = torch.full((n,), 0.15)
+            elif k.endswith('downsample.1.weight'):
+                t = torch.full((n,), 0.7)
+            elif k.endswith('running_var') or (('.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1')) and k.endswith('weight')):
                 t = torch.ones(n)
             elif k.endswith('running_mean') or '.bn' in k or 'downsample.1' in k or k.startswith('resnet.bn1'):
                 t = torch.zeros(n)
             elif k.startswith('resnet.') and len(shp) == 4:
                 t = torch.randn(n, generator=g) * float(np.sqrt(2.0 / (shp[2] * shp[3] * shp[0])))
+                if k == 'resnet.conv1.weight':
+                    t = t * 0.05                                      # inputs are pixel-scale (sigma ~50)
             elif k.startswith(('rpn_', 'cls_score', 'mask_')) and k.endswith('weight'):
                 t = torch.randn(n, generator=g) * 0.01
             elif k.startswith('bbox_pred_net') and k.endswith('weight'):

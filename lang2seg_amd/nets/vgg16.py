@@ -67,6 +67,8 @@ class vgg16(resnetv1):
             n = int(np.prod(shp))
             if k.startswith('vgg.features.') and len(shp) == 4:
                 t = torch.randn(n, generator=g) * float(np.sqrt(2.0 / (shp[1] * 9)))
+                if k == 'vgg.features.0.weight':
+                    t = t * 0.02                                      # inputs are pixel-scale (sigma ~50)
             elif k.startswith('vgg.classifier.') and len(shp) == 2:
                 t = torch.randn(n, generator=g) * 0.01
             elif k.startswith('vgg.'):
