@@ -400,3 +400,27 @@ def test_tape_over_mixed_shapes_matches_eager():
             assert all(any(t[0] in live for t in users) for users in net._buf_users.values())
     for k, (a, b) in enumerate(zip(res[0], res[1])):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (k, order[k], a, b)
+
+
+@pytest.mark.parametrize('variant', ['cycle', 'vgg'])
+def test_random_init_network_stays_finite(variant):
+    """bench.py and the tools without a checkpoint run the network from its own initialisers: the frozen-BN trunk must keep its
+    activations O(1) (a plain He-initialised ResNet-101 with identity BatchNorm on pixel-scale inputs overflows within one step and
+    every later loss sits at its all-zero-logit value)."""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    if variant == 'vgg':
+        opt['C4_feat_dim'] = 512
+    net = selftest.build_net(opt, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64), 'bf16', None, variant=variant)
+    sgd = SGD(net, 1e-4)
+    blob = OS.make_blob(320, 416, 6, 60, seed=5)
+    for step in range(4):
+        vals = net.train_step(dict(blob), 0, sgd)
+        torch.cuda.synchronize()
+        assert all(np.isfinite(v) for v in vals), (step, vals)
+        for k in ('net_conv_base', 'net_conv'):
+            a = net.t[k].float()
+            assert bool(torch.isfinite(a).all()) and 1e-4 < float(a.abs().max()) < 1e3, (step, k, float(a.abs().max()))
+    assert bool(torch.isfinite(net.P.param).all())
