@@ -169,7 +169,8 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'train_cycle.sh step: ResNet-101 C4 + 7 spatial dynamic filters + att2in2 cycle loss, %dx%d image, '
                                    '20-token expression (V=3349), 12000->2000 proposals, 256 RoIs, per-GPU batch 1' % (args.height, args.width),
-                       'parallelism': 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12},
+                       'parallelism': 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12,
+                       'weights': 'random (reference initialisers; trunk BN gains scaled so activations stay O(1)), fixed seed'},
             'step_tflops_per_gpu': STEP_FLOP / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': STEP_FLOP / (ms * 1e-3) / PEAK_BF16,
             'roofline': {'bound': 'mfma', 'kernel': 'igemm_sp_kernel<bf16,224,128> on layer4@RoIs conv3x3 (M=%d,N=512,K=4608)' % (R * 49),
                          'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': _pmc_traffic(), 'traffic_note': 'HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes 30.4 MB',
