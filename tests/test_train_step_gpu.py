@@ -424,3 +424,25 @@ def test_random_init_network_stays_finite(variant):
             a = net.t[k].float()
             assert bool(torch.isfinite(a).all()) and 1e-4 < float(a.abs().max()) < 1e3, (step, k, float(a.abs().max()))
     assert bool(torch.isfinite(net.P.param).all())
+
+
+def test_bench_json_contract():
+    """bench.py prints exactly one JSON line on stdout with the driver's keys (BASELINE.json's metric string verbatim, the roofline
+    and cpu_baseline objects); run at the full BASELINE shape with a handful of steps."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['metric'] == json.load(open(os.path.join(root, 'BASELINE.json')))['metric']
+    for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+              'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['vs_baseline'] is None and d['dtype'] == 'bf16' and d['scaling'] == 'weak'
+    assert abs(d['value'] - 1000.0 / d['ms_per_step']) < 1e-6 * d['value'] and 'workload' in d['config'] and 'model' not in d['config']
+    rf, cb = d['roofline'], d['cpu_baseline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['achieved'] > 100
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'img/s' and cb['sample']
+    assert all(np.isfinite(v) for v in d['final_losses'])
