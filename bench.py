@@ -164,6 +164,9 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     lv = loss.cpu().numpy()
+    # a run whose network went non-finite measured nothing (NaN activations are silently zeroed by the next ReLU)
+    if not (np.isfinite(lv[:7]).all() and bool(torch.isfinite(net.P.param).all())):
+        raise RuntimeError('non-finite losses or parameters after the run: %s' % lv[:7])
     if rank == 0:
         ms = dt / args.steps * 1e3
         val = world * args.steps / dt
