@@ -96,11 +96,13 @@ def segment_from_mask_prob(mask_prob, pred_box, im_info):
 
 
 def eval_split(loader, model, crit, split, opt, max_per_image=100, thresh=0.):
-    """test.py:187-420.  Returns (box accuracy @0.5, overall IoU, [prec@.5 .. prec@.9]) like the reference prints / returns."""
+    """test.py:185-450.  Returns the reference's tuple
+    (acc, eval_seg_iou_list, seg_correct, seg_total, cum_I, cum_U, num_sent): box accuracy @0.5, the precision thresholds, the
+    number of sentences whose mask IoU reaches each threshold, the number of sentences, cumulative intersection / union pixels."""
     num_sents = opt.get('num_sents', -1)
     verbose = opt.get('verbose', True)
     model.eval()
-    loss_evals, acc = 0, 0
+    loss_evals, acc, num_sent = 0, 0, 0
     cum_I, cum_U = 0, 0
     eval_seg_iou_list = [.5, .6, .7, .8, .9]
     seg_correct = np.zeros(len(eval_seg_iou_list), dtype=np.int32)
@@ -134,17 +136,24 @@ def eval_split(loader, model, crit, split, opt, max_per_image=100, thresh=0.):
             for k, t in enumerate(eval_seg_iou_list):
                 seg_correct[k] += (I * 1.0 / U >= t)
             seg_total += 1
+            num_sent += 1
             if num_sents > 0 and loss_evals >= num_sents:
                 finish = True
                 break
         if verbose:
-            print('evaluating [%s] ... sent %d, box acc %.2f%%, overall IoU %.2f%%' % (
-                split, loss_evals, acc * 100.0 / max(loss_evals, 1), cum_I * 100.0 / max(cum_U, 1)))
+            b = data['bounds']
+            print('evaluating [%s] ... image[%d/%d]\'s sents, det acc=%.2f%%, seg acc=%.2f%%, seg IoU=%.2f%%' % (
+                split, b['it_pos_now'], b['it_max'], acc * 100.0 / max(loss_evals, 1), seg_correct[0] * 100.0 / max(seg_total, 1),
+                cum_I * 100.0 / max(cum_U, 1)))
         if finish or data['bounds']['wrapped']:
             break
-    prec = [seg_correct[k] * 1.0 / max(seg_total, 1) for k in range(len(eval_seg_iou_list))]
-    if verbose:
-        for t, p in zip(eval_seg_iou_list, prec):
-            print('precision@%.1f = %.4f' % (t, p))
-        print('overall IoU = %.4f' % (cum_I * 1.0 / max(cum_U, 1)))
-    return acc * 1.0 / max(loss_evals, 1), cum_I * 1.0 / max(cum_U, 1), prec
+    return acc / loss_evals, eval_seg_iou_list, seg_correct, seg_total, cum_I, cum_U, num_sent
+
+
+def summarize(eval_seg_iou_list, seg_correct, seg_total, cum_I, cum_U):
+    """the text block of tools/eval_spatial.py:104-110 and ([prec@X], overall IoU) as fractions"""
+    s = ''
+    for k, t in enumerate(eval_seg_iou_list):
+        s += '    precision@%s = %.2f\n' % (str(t), seg_correct[k] * 100. / seg_total)
+    s += '    overall IoU = %.2f\n' % (cum_I * 100. / cum_U)
+    return s, [seg_correct[k] * 1.0 / seg_total for k in range(len(eval_seg_iou_list))], cum_I * 1.0 / cum_U

@@ -5,7 +5,9 @@ display every cfg.TRAIN.DISPLAY iters as `speed: s / iter`, snapshot every SNAPS
 files (`<prefix>_iter_N.pth` state dict in the reference's key/shape format + `.pkl` sidecar with numpy /
 python RNG state, loader cursors and iter, TV:57-104) and the same resume rules (TV:106-165,227-310:
 newest snapshot, name+shape matched copy incl. the `[:, :-1]` partial rule, LR rescaled by passed steps).
-Data parallel (not in the reference): every rank runs the same loop on its shard; rank 0 snapshots."""
+Data parallel (not in the reference): every rank runs the same loop on its shard; rank 0 writes the weights and the
+reference-format sidecar, every other rank writes its own cursor / RNG sidecar `<prefix>_iter_N.rank<r>.pkl` (the
+shards are `split_ix[rank::world]`: their lengths, permutations and per-rank RNG streams differ)."""
 import glob
 import os
 import pickle
@@ -51,17 +53,19 @@ class SolverWrapper(object):
         self.net, self.loader = network, loader
         self.output_dir, self.tbdir, self.pretrained_model = output_dir, tbdir, pretrained_model
         self.rank, self.world = rank, world
-        if rank == 0:
-            os.makedirs(output_dir, exist_ok=True)
+        os.makedirs(output_dir, exist_ok=True)
+        # experiment switches that change what is trained (bench.py --knockout / --dp-skip-allreduce) have no place in a training run
+        if getattr(network, 'knockout', None):
+            raise RuntimeError('train_net: network.knockout = %s is a benchmarking experiment, not a training mode' % sorted(network.knockout))
+        if getattr(getattr(network, 'dp', None), 'skip_allreduce', 0):
+            raise RuntimeError('train_net: the gradient reducer was built with skip_allreduce (ranks would diverge)')
 
-    # ---- TV:57-104 -----------------------------------------------------
-    def snapshot(self, it):
-        if self.rank != 0:
-            return None, None
-        filename = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it) + '.pth')
-        torch.save(self.net.state_dict(), filename)
-        print('Wrote snapshot to: {:s}'.format(filename))
-        nfilename = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it) + '.pkl')
+    def _sidecar(self, it, rank=None):
+        rank = self.rank if rank is None else rank
+        base = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it))
+        return base + ('.pkl' if rank == 0 else '.rank{:d}.pkl'.format(rank))
+
+    def _write_sidecar(self, nfilename, it):
         with open(nfilename, 'wb') as fid:
             pickle.dump(np.random.get_state(), fid, pickle.HIGHEST_PROTOCOL)
             pickle.dump(random.getstate(), fid, pickle.HIGHEST_PROTOCOL)
@@ -72,6 +76,17 @@ class SolverWrapper(object):
             # after the reference's fields (a reader of its format stops above): the device-side RNG step counter, so that a resumed run
             # draws the sampling keys / dropout masks the uninterrupted one would have
             pickle.dump(int(self.net.seed_counter().item()), fid, pickle.HIGHEST_PROTOCOL)
+
+    # ---- TV:57-104 -----------------------------------------------------
+    def snapshot(self, it):
+        nfilename = self._sidecar(it)
+        if self.rank != 0:
+            self._write_sidecar(nfilename, it)           # this rank's own loader cursor / permutation / RNG streams
+            return None, nfilename
+        filename = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it) + '.pth')
+        torch.save(self.net.state_dict(), filename)
+        print('Wrote snapshot to: {:s}'.format(filename))
+        self._write_sidecar(nfilename, it)
         return filename, nfilename
 
     # ---- TV:106-165 ----------------------------------------------------
@@ -92,12 +107,32 @@ class SolverWrapper(object):
     def from_snapshot(self, sfile, nfile):
         print('Restoring model snapshots from {:s}'.format(sfile))
         self.load_matched(torch.load(str(sfile), map_location='cpu'))
+        if self.rank != 0:
+            # data parallel: this rank's own sidecar (its shard has its own length, permutation and RNG streams); rank 0's
+            # file is the reference-format one.  Without it (a snapshot written by a single-process or a smaller run) only the
+            # iteration number is taken over and the rank keeps its freshly seeded streams and an in-range cursor.
+            own = str(nfile)[:-len('.pkl')] + '.rank{:d}.pkl'.format(self.rank)
+            if not os.path.exists(own):
+                with open(nfile, 'rb') as fid:
+                    for _ in range(6):
+                        pickle.load(fid)
+                    return pickle.load(fid)
+            nfile = own
         with open(nfile, 'rb') as fid:
-            np.random.set_state(pickle.load(fid))
-            random.setstate(pickle.load(fid))
+            np_state, py_state = pickle.load(fid), pickle.load(fid)
+            cursors = {}
             for split in ('train', 'val'):
-                self.loader.iterators[split] = pickle.load(fid)
-                self.loader.perm[split] = pickle.load(fid)
+                it_, perm_ = pickle.load(fid), pickle.load(fid)
+                n_here = len(self.loader.split_ix[split]) if split in getattr(self.loader, 'split_ix', {}) else len(perm_)
+                if len(perm_) != n_here:
+                    raise ValueError('%s: the %s permutation has %d entries, this rank\'s shard has %d images (snapshot written '
+                                     'with a different world size?)' % (nfile, split, len(perm_), n_here))
+                cursors[split] = (it_, perm_)
+            np.random.set_state(np_state)
+            random.setstate(py_state)
+            for split, (it_, perm_) in cursors.items():
+                self.loader.iterators[split] = it_
+                self.loader.perm[split] = perm_
             last_snapshot_iter = pickle.load(fid)
             try:
                 self.net.seed_counter().fill_(int(pickle.load(fid)))
@@ -122,7 +157,7 @@ class SolverWrapper(object):
         sfiles.sort(key=os.path.getmtime)
         red = [os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}.pth'.format(s + 1)) for s in cfg.TRAIN.STEPSIZE]
         sfiles = [s for s in sfiles if s not in red]
-        nfiles = glob.glob(os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pkl'))
+        nfiles = [f for f in glob.glob(os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pkl')) if '.rank' not in os.path.basename(f)]
         nfiles.sort(key=os.path.getmtime)
         red = [r.replace('.pth', '.pkl') for r in red]
         nfiles = [n for n in nfiles if n not in red]
@@ -130,7 +165,15 @@ class SolverWrapper(object):
         return len(sfiles), nfiles, sfiles
 
     def initialize(self):
-        if self.pretrained_model and os.path.exists(self.pretrained_model):
+        # TV:249-281.  pretrained_model=None is the caller's explicit choice to start from the weights the network holds
+        # (tools: --from_scratch; tests); a path that does not exist raises, as torch.load does in the reference (TV:262) — a
+        # mistyped path must not silently train from the random initialisers.
+        if self.pretrained_model is None:
+            print('No pretrained model given: training starts from the weights the network holds')
+        elif not os.path.exists(self.pretrained_model):
+            raise FileNotFoundError('pretrained model not found: %s (pass pretrained_model=None / --from_scratch to train from '
+                                    'the initialisers)' % self.pretrained_model)
+        else:
             print('Loading initial model weights from {:s}'.format(self.pretrained_model))
             self.load_matched(torch.load(self.pretrained_model, map_location='cpu'))
             print('Loaded.')
@@ -145,13 +188,16 @@ class SolverWrapper(object):
             else:
                 stepsizes.append(s)
         scale_lr(self.optimizer, lr_scale)
+        if self.rank != 0:                       # the files this rank owns (rank 0 owns the weights and the reference-format sidecar)
+            own = str(nfile)[:-len('.pkl')] + '.rank{:d}.pkl'.format(self.rank)
+            return cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [own if os.path.exists(own) else None], [None]
         return cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [nfile], [sfile]
 
     def remove_snapshot(self, np_paths, ss_paths):
         for paths in (np_paths, ss_paths):
             while len(paths) > cfg.TRAIN.SNAPSHOT_KEPT:
                 f = paths.pop(0)
-                if self.rank == 0 and os.path.exists(str(f)):
+                if f is not None and os.path.exists(str(f)):        # every rank removes the files it wrote
                     os.remove(str(f))
 
     # ---- TV:327-434 ----------------------------------------------------

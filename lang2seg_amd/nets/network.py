@@ -89,7 +89,7 @@ class ConvOp(object):
         """weight (+bias) gradient.  Nothing downstream in the step needs it before the optimiser, so it is forked onto the
         weight-gradient stream and overlaps with the data-gradient chain that continues on the calling stream."""
         OH, OW = self.out_hw(IH, IW)
-        if 'wgrad' in os.environ.get('L2S_SKIP', ''):
+        if 'wgrad' in self.net.knockout:                  # experiment only (bench.py --knockout); train_net refuses it
             return
         with self.net.fork_wgrad():
             O.conv_wgrad(g, x, self.w_grad, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad)
@@ -169,6 +169,7 @@ class Network(object):
         self.parity = None          # dict of injected sampling keys / dropout masks (tests); None = production RNG
         self.dp = None              # data-parallel gradient reducer (lang2seg_amd/parallel.py)
         self._early_op = None       # optimiser taking early partial updates during backward (optim.SGD.partial)
+        self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'cap'); set by bench.py --knockout
 
     # ------------------------------------------------------------------ construction
     def create_architecture(self, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):

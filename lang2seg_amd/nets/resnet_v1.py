@@ -69,6 +69,11 @@ class resnetv1(Network):
         P.build_segments(double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
         self.load_state_dict(self._initial_state, strict=False)
         del self._initial_state
+        # RES:256 -> caption_models.setup(opt): `--start_from` warm-starts the captioner from <dataset_splitBy>/<start_from>/model-best.pth
+        # (caption_models/__init__.py:45-51); missing directory / infos-best.pkl / mismatching keys raise, as the reference asserts
+        if self.var['cap'] is not None and self.opt.get('start_from') is not None:
+            from ..utils.caption_ckpt import load_caption_weights
+            load_caption_weights(self, self.opt, root=self.opt.get('checkpoint_root', '.'))
 
     def init_weights(self):
         """NET:333-355 / RES:135-141 initialisers (host RNG, once, before the first load).
@@ -542,8 +547,7 @@ class resnetv1(Network):
 
         def caption_branch():
             """returns (d net_conv, d base or None) contributed by the caption loss"""
-            import os
-            if 'cap' in os.environ.get('L2S_SKIP', ''):
+            if 'cap' in self.knockout:
                 return self.buf('l4m.skip', (HW, C4)), None
             feats = l4_on_map(net_conv, 'l4m')
             att = self.buf('cap.att', (196, AF))

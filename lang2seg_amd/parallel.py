@@ -11,9 +11,6 @@ import torch
 import torch.distributed as dist
 
 
-import os
-_SKIP_AR = int(os.environ.get('L2S_DP_SKIP_ALLREDUCE', '0'))     # experiment knob: keep the stream structure, skip RCCL
-
 
 def bucket_bounds(P):
     """prefix of the flat parameter / gradient buffer that is final after each backward stage (the buffer is laid out in
@@ -44,8 +41,11 @@ def bucket_bounds(P):
 class GradReducer(object):
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
 
-    def __init__(self, net, world, backend_stream=True):
+    def __init__(self, net, world, backend_stream=True, skip_allreduce=0):
         self.net, self.world = net, world
+        # experiment only (bench.py --dp-skip-allreduce): 1 = keep the stream structure but issue no collective, 2 = do nothing.
+        # Ranks diverge with either, so model/train_val.py refuses a reducer built this way.
+        self.skip_allreduce = int(skip_allreduce)
         P = net.P
         self.bounds = bucket_bounds(P)
         self.done = 0
@@ -53,7 +53,7 @@ class GradReducer(object):
         self.side = torch.cuda.Stream() if self.on_gpu else None
 
     def ready(self, stage):
-        if _SKIP_AR == 2:
+        if self.skip_allreduce == 2:
             return
         end = min(self.bounds[stage], self.net.P.total)
         if end <= self.done:
@@ -65,14 +65,14 @@ class GradReducer(object):
                 for name in ('wg', 'wg2', 'lang', 'cap'):           # gradients are also produced on the side streams: the reducer
                     self.side.wait_stream(self.net._streams[name])  # waits for them, the main stream does not have to
             with torch.cuda.stream(self.side):
-                if not _SKIP_AR:
+                if not self.skip_allreduce:
                     dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         else:                                   # CPU/gloo path (tests)
             dist.all_reduce(seg, op=dist.ReduceOp.SUM)
         self.done = end
 
     def finish(self):
-        if _SKIP_AR == 2:
+        if self.skip_allreduce == 2:
             return
         P = self.net.P
         if self.done < P.total:

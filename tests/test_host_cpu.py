@@ -149,3 +149,197 @@ def test_eval_postprocessing_vs_reference():
     bx = np.arange(4 * 20, dtype=np.float32).reshape(4, 20)
     r, c, b = T.best_detection(sc, bx)
     assert (r, c) == (2, 3) and np.array_equal(b, bx[2, 12:16])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# caption warm start (caption_models/__init__.py:45-51, train_cycle_2.py:69-76)
+def _write_infos(path, proto=0, **over):
+    import argparse, pickle
+    o = dict(caption_model='att2in2', rnn_type='lstm', rnn_size=512, num_layers=1, vocab_size=37, seq_length=6)
+    o.update(over)
+    with open(path, 'wb') as f:
+        pickle.dump({'opt': argparse.Namespace(**o), 'iter': 7, 'best_val_score': -2.5, 'perm': np.arange(5)}, f, protocol=proto)
+
+
+def test_caption_infos_reader(tmp_path):
+    """the no-import reader of infos-best.pkl: python-2 style protocol-0 pickles and newer ones, no foreign code executed,
+    and (where the reference checkout is present) the reference's own four files against tests/golden/ref_caption_infos.json"""
+    import json, pickle
+    from lang2seg_amd.utils import caption_ckpt as CK
+    for proto in (0, 2, 4):
+        f = str(tmp_path / ('infos%d.pkl' % proto))
+        _write_infos(f, proto)
+        r = CK.read_infos(f)
+        assert r['iter'] == 7 and r['best_val_score'] == -2.5 and 'perm' not in r
+        assert r['opt'] == dict(caption_model='att2in2', rnn_type='lstm', rnn_size=512, num_layers=1, vocab_size=37, seq_length=6)
+    marker = tmp_path / 'pwned'
+
+    class Evil(object):
+        def __reduce__(self):
+            return (os.system, ('touch %s' % marker,))
+    import argparse
+    f = str(tmp_path / 'evil.pkl')
+    with open(f, 'wb') as fid:
+        pickle.dump({'opt': argparse.Namespace(rnn_size=3), 'x': Evil()}, fid, protocol=0)
+    assert CK.read_infos(f)['opt'] == {'rnn_size': 3} and not marker.exists()
+    gold = json.load(open(os.path.join(ROOT, 'tests/golden/ref_caption_infos.json')))
+    assert len(gold) == 4
+    if os.path.isdir('/root/reference'):
+        for key, g in gold.items():
+            r = CK.read_infos(os.path.join('/root/reference', key, 'infos-best.pkl'))
+            assert r['iter'] == g['iter'] and r['best_val_score'] == g['best_val_score']
+            for k, v in g['opt'].items():
+                assert r['opt'][k] == v, (key, k)
+
+
+class _FakeCapNet(object):
+    def __init__(self):
+        g = torch.Generator().manual_seed(0)
+        self.sd = {'caption_model.embed.0.weight': torch.randn(5, 4, generator=g), 'caption_model.core.i2h.bias': torch.randn(6, generator=g),
+                   'resnet.conv1.weight': torch.randn(2, 3, generator=g)}
+
+    def state_dict(self):
+        return dict(self.sd)
+
+    def load_state_dict(self, sd, strict=False):
+        self.sd = dict(sd)
+
+
+def test_caption_warm_start_rules(tmp_path):
+    from lang2seg_amd.utils import caption_ckpt as CK
+    opt = dict(dataset_splitBy='refcoco_unc', start_from='caption_log_res5_2', caption_model='att2in2', rnn_type='lstm', rnn_size=512, num_layers=1)
+    root = str(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        CK.check_infos(opt, root)                                   # directory missing
+    d = tmp_path / 'refcoco_unc' / 'caption_log_res5_2'
+    d.mkdir(parents=True)
+    with pytest.raises(FileNotFoundError):
+        CK.check_infos(opt, root)                                   # infos-best.pkl missing
+    with pytest.raises(FileNotFoundError):
+        CK.load_caption_weights(_FakeCapNet(), opt, root)
+    _write_infos(str(d / 'infos-best.pkl'), 0, rnn_size=1024)
+    with pytest.raises(ValueError, match='rnn_size'):
+        CK.check_infos(opt, root)
+    _write_infos(str(d / 'infos-best.pkl'), 0)
+    assert CK.check_infos(opt, root)['iter'] == 7
+    assert CK.check_infos(dict(opt, start_from=None), root) is None
+    net = _FakeCapNet()
+    good = {'embed.0.weight': torch.full((5, 4), 2.0), 'core.i2h.bias': torch.full((6,), 3.0)}
+    torch.save(dict(good, extra=torch.zeros(1)), str(d / 'model-best.pth'))
+    with pytest.raises(KeyError, match='unexpected'):
+        CK.load_caption_weights(net, opt, root)                     # strict, like nn.Module.load_state_dict
+    torch.save({'embed.0.weight': good['embed.0.weight']}, str(d / 'model-best.pth'))
+    with pytest.raises(KeyError, match='missing'):
+        CK.load_caption_weights(net, opt, root)
+    torch.save(dict(good, **{'core.i2h.bias': torch.zeros(7)}), str(d / 'model-best.pth'))
+    with pytest.raises(ValueError, match='shape'):
+        CK.load_caption_weights(net, opt, root)
+    torch.save(good, str(d / 'model-best.pth'))
+    before = net.sd['resnet.conv1.weight'].clone()
+    assert CK.load_caption_weights(net, opt, root)
+    assert torch.equal(net.sd['caption_model.embed.0.weight'], good['embed.0.weight'])
+    assert torch.equal(net.sd['caption_model.core.i2h.bias'], good['core.i2h.bias']) and torch.equal(net.sd['resnet.conv1.weight'], before)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# solver: missing pretrained file, data-parallel resume with per-rank sidecars
+class _FakeSolverNet(object):
+    _batch_size = 1
+    knockout = frozenset()
+    dp = None
+
+    def __init__(self):
+        self.w = {'a.weight': torch.zeros(3)}
+        self.ctr = torch.zeros(1, dtype=torch.int64)
+
+    def state_dict(self):
+        return dict(self.w)
+
+    def load_state_dict(self, sd, strict=False):
+        self.w = dict(sd)
+
+    def seed_counter(self):
+        return self.ctr
+
+
+def test_initialize_raises_on_missing_pretrained(tmp_path):
+    from lang2seg_amd.model.train_val import SolverWrapper
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    ld = SyntheticLoader(num_images=2, H=32, W=32, T=3, vocab_size=10)
+    sw = SolverWrapper(_FakeSolverNet(), ld, str(tmp_path / 'o'), str(tmp_path / 't'), pretrained_model=str(tmp_path / 'nope.pth'))
+    with pytest.raises(FileNotFoundError):
+        sw.initialize()
+    SolverWrapper(_FakeSolverNet(), ld, str(tmp_path / 'o'), str(tmp_path / 't'), pretrained_model=None).initialize()
+    net = _FakeSolverNet(); net.knockout = frozenset(['wgrad'])
+    with pytest.raises(RuntimeError, match='knockout'):
+        SolverWrapper(net, ld, str(tmp_path / 'o'), str(tmp_path / 't'))
+
+
+def _resume_worker(rank, world, port, outdir, ret):
+    import random
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lang2seg_amd.model.train_val import SolverWrapper
+    from lang2seg_amd.model.config import cfg
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+
+    def shard():
+        ld = SyntheticLoader(num_images=5, H=32, W=32, T=3, vocab_size=10)     # odd image count: shards of 3 and 2 images
+        for k in ld.split_ix:
+            ld.split_ix[k] = ld.split_ix[k][rank::world]
+            ld.perm[k] = np.arange(len(ld.split_ix[k]))
+        return ld
+    np.random.seed(cfg.RNG_SEED + rank); random.seed(100 + rank)
+    ld = shard()
+    for _ in range(4 + rank):                               # the ranks' cursors and permutations drift apart
+        ld.getBatch('train', 1)
+    net = _FakeSolverNet(); net.ctr.fill_(11 + rank)
+    sw = SolverWrapper(net, ld, outdir, outdir, rank=rank, world=world)
+    sw.snapshot(8)
+    expect_next = np.random.rand()                          # the draw that follows the snapshot
+    state = (ld.iterators['train'], ld.perm['train'].copy())
+    dist.barrier()
+    n, nfiles, sfiles = sw.find_previous()
+    ok = n == 1 and all('.rank' not in f for f in nfiles)
+    # resume in a fresh loader / solver
+    np.random.seed(999); random.seed(999)
+    ld2 = shard()
+    net2 = _FakeSolverNet()
+    sw2 = SolverWrapper(net2, ld2, outdir, outdir, rank=rank, world=world)
+    last = sw2.from_snapshot(sfiles[-1], nfiles[-1])
+    ok = ok and last == 8 and ld2.iterators['train'] == state[0] and np.array_equal(ld2.perm['train'], state[1])
+    ok = ok and len(ld2.perm['train']) == len(ld2.split_ix['train']) and int(net2.ctr.item()) == 11 + rank
+    ok = ok and np.random.rand() == expect_next
+    for _ in range(7):                                      # keeps walking its own shard without running past its end
+        ld2.getBatch('train', 1)
+    if rank == 1:
+        # a snapshot written by another world size must be refused, not silently mis-indexed
+        os.replace(os.path.join(outdir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_8.pkl'), os.path.join(outdir, 'tmp.pkl'))
+        import shutil
+        shutil.copy(os.path.join(outdir, 'tmp.pkl'), os.path.join(outdir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_8.rank1.pkl'))
+        os.replace(os.path.join(outdir, 'tmp.pkl'), os.path.join(outdir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_8.pkl'))
+        try:
+            sw2.from_snapshot(sfiles[-1], nfiles[-1])
+            ok = False
+        except ValueError:
+            pass
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_resume_per_rank_sidecars(tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, str(tmp_path), ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert ret.get(0) and ret.get(1)
+    names = sorted(os.listdir(str(tmp_path)))
+    assert any(n.endswith('_iter_8.rank1.pkl') for n in names) and any(n.endswith('_iter_8.pkl') for n in names) and any(n.endswith('_iter_8.pth') for n in names)

@@ -171,15 +171,18 @@ def test_eval_split_runs():
     """evaluation loop (model/test.py eval_split) end to end on the synthetic loader: TEST-mode network on the HIP kernels +
     host post-processing; the metrics of an untrained network are only checked for sanity."""
     from lang2seg_amd import selftest
-    from lang2seg_amd.model.test import eval_split
+    from lang2seg_amd.model.test import eval_split, summarize
     from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
     from oracle import weights as OW
     opt = OW.default_opt(vocab_size=60, seq_length=6)
     sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
     net = selftest.build_net(opt, {}, 'bf16', sd)
     loader = SyntheticLoader(num_images=2, sents_per_image=2, H=320, W=416, T=6, vocab_size=60)
-    acc, iou, prec = eval_split(loader, net, None, 'val', dict(verbose=False))
+    acc, thr, seg_correct, seg_total, cum_I, cum_U, num_sent = eval_split(loader, net, None, 'val', dict(verbose=False))
+    text, prec, iou = summarize(thr, seg_correct, seg_total, cum_I, cum_U)
+    assert num_sent == seg_total == 4 and thr == [.5, .6, .7, .8, .9] and 0 <= cum_I <= cum_U
     assert 0.0 <= acc <= 1.0 and 0.0 <= iou <= 1.0 and len(prec) == 5 and all(0.0 <= p <= 1.0 for p in prec)
+    assert text.count('precision@') == 5 and 'overall IoU' in text
 
 
 def test_eval_split_vgg_runs():

@@ -21,12 +21,15 @@ def parse_args(argv=None):
     p.add_argument('--cfg', dest='cfg_file', default='experiments/cfgs/res101.yml')
     p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
     p.add_argument('--synthetic_images', type=int, default=8); p.add_argument('--dtype', default='bf16')
+    p.add_argument('--results_dir', default=None, help='where det_results.txt / mask_results.txt are appended (default: experiments/)')
+    p.add_argument('--synthetic', type=int, default=0, help='1: evaluate on the SyntheticLoader when the dataset files are absent')
+    p.add_argument('--allow_init_weights', type=int, default=0, help='1: evaluate the initial weights when the snapshot is missing (otherwise an error)')
     return vars(p.parse_args(argv))
 
 
 def main(args, variant):
     from lang2seg_amd.model.config import cfg, cfg_from_file, cfg_from_list
-    from lang2seg_amd.model.test import eval_split
+    from lang2seg_amd.model.test import eval_split, summarize
     from lang2seg_amd.nets.resnet_v1 import resnetv1
     from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
     sys.path.insert(0, osp.join(ROOT, 'tools'))
@@ -39,8 +42,10 @@ def main(args, variant):
     if osp.exists(data_json):
         from lang2seg_amd.loaders.cycle_loader import GtMRCNLoader
         loader = GtMRCNLoader(data_json, data_h5, image_root=osp.join(ROOT, 'pyutils/mask-faster-rcnn/data/coco/images/train2014'))
-    else:
+    elif args['synthetic']:
         loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V)
+    else:
+        raise FileNotFoundError('%s not found (pass --synthetic 1 to run on the synthetic stand-in)' % data_json)
     opt = parse_opt([])
     opt.update(vocab_size=loader.vocab_size, C4_feat_dim=1024, seq_length=loader.label_length,
                dataset_splitBy=args['dataset'] + '_' + args['splitBy'])
@@ -61,15 +66,28 @@ def main(args, variant):
     if osp.exists(ckpt):
         net.load_state_dict(torch.load(ckpt, map_location='cpu'))
         print('loaded', ckpt)
+    elif args['allow_init_weights']:
+        print('no snapshot at %s: evaluating the initial weights (--allow_init_weights 1)' % ckpt)
     else:
-        print('no snapshot at %s: evaluating the initial weights' % ckpt)
+        raise FileNotFoundError('no snapshot at %s (eval.py:66 torch.load would fail; --allow_init_weights 1 evaluates the initialisers)' % ckpt)
     split = args['split'] if args['split'] in loader.split_ix else 'val'
     if variant == 'vgg':                                     # tools/eval_vgg.py: boxes only (model/test_vgg.py)
         from lang2seg_amd.model.test_vgg import eval_split as eval_split_vgg
         acc, n = eval_split_vgg(loader, net, None, split, dict(num_sents=args['num_sents'], verbose=bool(args['verbose'])))
         print('Comprehension on %s\'s %s (%s sents): box acc %.2f%%' % (opt['dataset_splitBy'], args['split'], n, acc * 100))
         return acc, None, None
-    acc, iou, prec = eval_split(loader, net, None, split, dict(num_sents=args['num_sents'], verbose=bool(args['verbose'])))
-    print('Comprehension on %s\'s %s (%s sents): box acc %.2f%%, overall IoU %.2f%%' % (
-        opt['dataset_splitBy'], args['split'], args['num_sents'], acc * 100, iou * 100))
+    opt['split'], opt['id'] = args['split'], args['id']
+    acc, eval_seg_iou_list, seg_correct, seg_total, cum_I, cum_U, num_sent = eval_split(
+        loader, net, None, split, dict(num_sents=args['num_sents'], verbose=bool(args['verbose'])))
+    print('Comprehension on %s\'s %s (%s sents) is %.2f%%' % (opt['dataset_splitBy'], split, num_sent, acc * 100.))
+    results_str, prec, iou = summarize(eval_seg_iou_list, seg_correct, seg_total, cum_I, cum_U)
+    print('Segmentation results on [%s][%s]' % (opt['dataset_splitBy'], split))
+    print(results_str)
+    # tools/eval_spatial.py:95-98,121-124: the two running result logs
+    res_dir = args.get('results_dir') or osp.join(ROOT, 'experiments')
+    os.makedirs(res_dir, exist_ok=True)
+    with open(osp.join(res_dir, 'det_results.txt'), 'a') as f:
+        f.write('[%s][%s], id[%s]\'s acc is %.2f%%\n' % (opt['dataset_splitBy'], opt['split'], opt['id'], acc * 100.0))
+    with open(osp.join(res_dir, 'mask_results.txt'), 'a') as f:
+        f.write('[%s][%s]\'s iou is:\n%s' % (opt['dataset_splitBy'], split, results_str))
     return acc, iou, prec

@@ -26,7 +26,8 @@ def parse_opt(argv=None):
     p.add_argument('--att_feat_size', type=int, default=4096); p.add_argument('--drop_prob_lm', type=float, default=0.5)
     p.add_argument('--start_from', default=None); p.add_argument('--cap_loss_weight', type=float, default=1.0)
     # this implementation
-    p.add_argument('--synthetic', type=int, default=1, help='use the SyntheticLoader (no dataset files in this repo)')
+    p.add_argument('--synthetic', type=int, default=0, help='1: run on the SyntheticLoader when cache/prepro/<dataset>_<splitBy>/data.json is absent (otherwise that is an error)')
+    p.add_argument('--from_scratch', type=int, default=0, help='1: do not load the pretrained Mask R-CNN (a missing file is otherwise an error)')
     p.add_argument('--synthetic_images', type=int, default=64); p.add_argument('--dtype', default='bf16')
     args = p.parse_args(argv)
     return vars(args)

@@ -40,14 +40,24 @@ def main(args, variant='cycle'):
             for k in loader.split_ix:
                 loader.split_ix[k] = loader.split_ix[k][rank::world]
                 loader.perm[k] = np.arange(len(loader.split_ix[k]))
-    else:
+    elif args['synthetic']:
         loader = SyntheticLoader(num_images=args['synthetic_images'], sents_per_image=3, T=T, vocab_size=V, rank=rank)
+    else:
+        raise FileNotFoundError('%s not found (pass --synthetic 1 to run on the synthetic stand-in)' % data_json)
     opt = dict(args)
     opt['vocab_size'] = loader.vocab_size
     opt['C4_feat_dim'] = 512 if variant == 'vgg' else 1024
     opt['use_att'] = True
     opt['seq_length'] = loader.label_length
     opt['dataset_splitBy'] = args['dataset'] + '_' + args['splitBy']
+    opt['checkpoint_root'] = ROOT
+    if variant in ('cycle', 'cycle_response') and opt.get('start_from') is not None:
+        # train_cycle_2.py:69-76: the caption model saved under <dataset_splitBy>/<start_from> must agree with the command line
+        # (the weights themselves are loaded by the network's constructor, caption_models/__init__.py:45-51)
+        from lang2seg_amd.utils.caption_ckpt import check_infos
+        check_infos(opt, root=ROOT)
+    else:
+        opt['start_from'] = None                      # the other variants have no captioner (tools/train.py etc. never read it)
     if args['cfg_file'] and osp.exists(osp.join(ROOT, args['cfg_file'])):
         cfg_from_file(osp.join(ROOT, args['cfg_file']))
     if args['set_cfgs']:
@@ -67,5 +77,7 @@ def main(args, variant='cycle'):
     tb_dir = osp.join(ROOT, opt['dataset_splitBy'], 'tb_{}'.format(args['output_postfix']))
     pretrained = osp.join(ROOT, 'pyutils/mask-faster-rcnn/output/%s/%s_2014_train_minus_refer_valtest+%s_2014_valminusminival/%s/%s_mask_rcnn_iter_%s.pth' % (
         args['net_name'], args['imdb_name'], args['imdb_name'], args['tag'], args['net_name'], args['iters']))
+    if args['from_scratch']:
+        pretrained = None                                        # explicit: train from the initialisers (train_net raises on a missing file)
     train_net(net, loader, output_dir, tb_dir, pretrained_model=pretrained, max_iters=args['max_iters'], rank=rank, world=world)
 
