@@ -7,40 +7,104 @@ backward, SGD (the unit behind the reference's `speed: s / iter`, train_val_cycl
 Workload = BASELINE.json configs[2] (`train_cycle.sh`, bf16) with the refcocog token/vocab sizes the
 headline metric is quoted on.  Inputs are synthetic and resident in HBM before the
 timed region; weights are the reference initialisers with a fixed seed.
-N > 1: one process per GPU (torchrun), per-GPU batch 1, RCCL all-reduce of the flat gradient buffer
-overlapped with backward (weak scaling).
 
-Prints ONE JSON line (rank 0)."""
+N > 1: one process per GPU, per-GPU batch 1, RCCL all-reduce of the flat gradient buffer overlapped with
+backward (weak scaling).  The ranks come either from the driver (`python -m torch.distributed.run ... bench.py
+--gpus N`: RANK / WORLD_SIZE in the environment) or, when `--gpus N` is given without them, from this script
+itself: it starts `torch.distributed.run` as a CHILD process before anything here touches a GPU and relays
+rank 0's line.
+
+Prints ONE JSON line (rank 0).  `value` times K pipelined steps (loss read back once, after the region, as
+`train_net` does between display iterations); the JSON also carries the fully synchronous `train_step` rate
+(the reference reads its losses back every step, NET:704-710), the rate with the 7.2 MB image re-uploaded
+every step, the roofline of the dominant launch, of the whole 3x3 stack and of the time-dominant group of
+convolution launches, and the CPU restatement timed on this box's host cores."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 # algorithmic work (BASELINE.md §2): forward 321.29 GMAC, backward 2x except frozen stem+layer1 (9.40 GMAC)
 STEP_FLOP = 2.0 * (321.29e9 + 2.0 * (321.29e9 - 9.40e9))
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def cpu_baseline(H, W, T, V):
-    """The oracle's fp32 CPU restatement of the same step on this box's host cores (baseline only)."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-steps', default='1,2', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3 prescribes 3,10: ~3-5 min)')
+    ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
+    ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
+    ap.add_argument('--main-prio', type=int, default=0, help='run the main queue on a high-priority HIP stream instead of the null stream')
+    ap.add_argument('--force-dp', type=int, default=0, help='(testing) build the data-parallel reducer even for one rank')
+    ap.add_argument('--height', type=int, default=600)
+    ap.add_argument('--width', type=int, default=1000)
+    ap.add_argument('--extras', type=int, default=1, help='0: only the headline timing (no synchronous / PCIe-inclusive / per-launch legs)')
+    ap.add_argument('--knockout', default='', help='EXPERIMENT: leave parts of the step out (wgrad,cap); the line is marked invalid')
+    ap.add_argument('--dp-skip-allreduce', type=int, default=0, help='EXPERIMENT: 1 = no collective, 2 = no reducer calls, 3 = no reducer; the line is marked invalid')
+    ap.add_argument('--launcher-check', action='store_true', help='only bring the ranks up (gloo without GPUs), count them with an all-reduce, print the line')
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """`--gpus N` without a launcher: start the N ranks as children (never re-exec a process that touched a GPU; this one has not)."""
+    port = int(os.environ.get('MASTER_PORT', 29400 + os.getpid() % 500))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in r.stdout.decode(errors='replace').splitlines() if l.strip().startswith('{')]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write('bench.py: the %d-rank child run failed (exit code %d)\n' % (args.gpus, r.returncode))
+        return r.returncode or 1
+    sys.stdout.write(lines[-1] + '\n')
+    sys.stdout.flush()
+    return 0
+
+
+def cpu_model():
+    try:
+        for l in open('/proc/cpuinfo'):
+            if l.startswith('model name'):
+                return l.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(H, W, T, V, warm, timed):
+    """The oracle's fp32 CPU restatement of the same step on this box's host cores (baseline only, the checker is not shipped)."""
     import copy
+    import numpy as np
+    import torch
     from oracle import weights as OW, synth as OS, net as ON
     opt = OW.default_opt(vocab_size=V, seq_length=T)
     sd = OW.make_state_dict(opt, seed=3)
     blob = OS.make_blob(H, W, T, V, seed=1234)
     net = ON.OracleNet(sd, opt, copy.deepcopy(ON.DEFAULT_CFG))
-    t0 = time.time()
-    net.train_step(blob, dict(rng=np.random.RandomState(3)))
-    dt = time.time() - t0
-    return {'value': 1.0 / dt, 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '1 train step (600x1000 image, 20 tokens, 256 RoIs, fp32) = %.1f s' % dt}
+    rng = np.random.RandomState(3)
+    for _ in range(warm):
+        net.train_step(blob, dict(rng=rng))
+    ts = []
+    for _ in range(timed):
+        t0 = time.time()
+        net.train_step(blob, dict(rng=rng))
+        ts.append(time.time() - t0)
+    dt = float(np.mean(ts))
+    return {'value': 1.0 / dt, 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model(),
+            's_per_step': dt, 's_per_step_all': [round(t, 3) for t in ts],
+            'sample': '%d warm-up + %d timed train steps (%dx%d image, %d tokens, 256 RoIs, fp32, torch-CPU restatement in oracle/), mean %.1f s / step'
+                      % (warm, timed, H, W, T, dt)}
 
 
 def _baseline_metric():
@@ -48,45 +112,146 @@ def _baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, 'BASELINE.json')))['metric']
     except Exception:
-        return 'train images/sec (cycle loss on), 600\u00d71000 input, at 1/2/4/8 MI355X'
+        return 'train images/sec (cycle loss on), 600×1000 input, at 1/2/4/8 MI355X'
 
 
 def _pmc_traffic():
     """PMC counters cannot be read inside the timed run; the committed measurement of the same launch is reported."""
-    import json
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    try:
-        return float(json.load(open(f))['traffic_bytes'])
-    except Exception:
-        return None
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        f = os.path.join(ROOT, 'profiles', name)
+        try:
+            return float(json.load(open(f))['traffic_bytes']), name
+        except Exception:
+            continue
+    return None, None
 
 
-# Native libraries print to fd 1 (RCCL writes a five-line version banner there): the contract is ONE JSON line on stdout, so fd 1 is
-# pointed at stderr for the whole run and the JSON line goes to a saved duplicate of the real stdout.
-_REAL_STDOUT = os.dup(1)
-os.dup2(2, 1)
+class LaunchTimer(object):
+    """HIP events around every convolution launch of eager steps, recorded on the stream the launch goes to (the weight-gradient
+    launches run on their own streams; torch.cuda.Event.record() uses the current stream, which ConvOp switches before launching)."""
+
+    def __init__(self, net, torch):
+        self.torch, self.on, self.recs = torch, False, []
+        for c in net.convs:
+            self._wrap(c)
+
+    def _group(self, conv, n, IH, IW):
+        k = conv.wkey or (conv.group[0] if conv.group else '?')
+        if k.startswith('resnet.layer'):
+            li = k.split('.')[1]
+            if li == 'layer4':
+                return 'layer4@RoIs' if n > 1 else 'layer4@map'
+            return li
+        if k.startswith('rpn') or k == 'rpn_head_w':
+            return 'rpn'
+        return 'heads'
+
+    def _wrap(self, conv):
+        T = self.torch
+        for kind in ('fwd', 'dgrad', 'wgrad'):
+            orig = getattr(conv, kind)
+
+            def timed(a, b, *rest, _orig=orig, _kind=kind, **kw):
+                if not self.on:
+                    return _orig(a, b, *rest, **kw)
+                # fwd(x, n, IH, IW, y, ..), dgrad(g, n, IH, IW, dx, ..), wgrad(g, x, n, IH, IW)
+                n, IH, IW = (rest[0], rest[1], rest[2]) if _kind == 'wgrad' else (b, rest[0], rest[1])
+                OH, OW = conv.out_hw(IH, IW)
+                flop = 2.0 * n * OH * OW * conv.Np * conv.k * conv.k * conv.Cin
+                if _kind == 'wgrad':
+                    # the launch happens inside fork_wgrad() on a weight-gradient stream: bracket it there
+                    net = conv.net
+                    ctx_orig = net.fork_wgrad
+                    evs = []
+
+                    def fork():
+                        ctx = ctx_orig()
+
+                        class _C(object):
+                            def __enter__(s):
+                                r = ctx.__enter__()
+                                e0 = T.cuda.Event(enable_timing=True); e0.record(); evs.append(e0)
+                                return r
+
+                            def __exit__(s, *a3):
+                                e1 = T.cuda.Event(enable_timing=True); e1.record(); evs.append(e1)
+                                return ctx.__exit__(*a3)
+                        return _C()
+                    net.fork_wgrad = fork
+                    try:
+                        r = _orig(a, b, *rest, **kw)
+                    finally:
+                        del net.fork_wgrad
+                    if len(evs) == 2:
+                        self.recs.append((self._group(conv, n, IH, IW), _kind, conv.k, flop, evs[0], evs[1]))
+                    return r
+                e0 = T.cuda.Event(enable_timing=True); e1 = T.cuda.Event(enable_timing=True)
+                e0.record(); r = _orig(a, b, *rest, **kw); e1.record()
+                self.recs.append((self._group(conv, n, IH, IW), _kind, conv.k, flop, e0, e1))
+                return r
+            setattr(conv, kind, timed)
+
+    def summary(self, steps):
+        """(per-group table, 3x3 stack, time-dominant group); times are per step, bias column sums ride with the wgrad launches"""
+        groups, s3 = {}, [0.0, 0.0, 0]
+        for grp, kind, k, flop, e0, e1 in self.recs:
+            ms = e0.elapsed_time(e1)
+            g = groups.setdefault('%s %s' % (grp, kind), [0.0, 0.0, 0])
+            g[0] += flop; g[1] += ms; g[2] += 1
+            if k == 3:
+                s3[0] += flop; s3[1] += ms; s3[2] += 1
+        tab = {name: {'launches_per_step': v[2] / steps, 'ms_per_step': v[1] / steps, 'tflops': v[0] / (v[1] * 1e-3) / 1e12,
+                      'frac': v[0] / (v[1] * 1e-3) / PEAK_BF16} for name, v in groups.items() if v[1] > 0}
+        dom = max(tab, key=lambda n: tab[n]['ms_per_step']) if tab else None
+        stack = None
+        if s3[1] > 0:
+            ach = s3[0] / (s3[1] * 1e-3) / 1e12
+            stack = {'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12),
+                     'launches_per_step': s3[2] / steps, 'ms_per_step': s3[1] / steps, 'gflop_per_step': s3[0] / steps / 1e9,
+                     'note': 'every 3x3 convolution launch of the step (forward, data gradient, weight gradient; layer2/3/4 + RPN): '
+                             'summed algorithmic FLOPs / summed HIP-event time of the launches, eager multi-stream steps'}
+        return tab, stack, dom
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default='bf16')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
-    ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
-    ap.add_argument('--main-prio', type=int, default=0, help='run the main queue on a high-priority HIP stream instead of the null stream')
-    ap.add_argument('--force-dp', type=int, default=0, help='(testing) build the data-parallel reducer even for one rank')
-    ap.add_argument('--height', type=int, default=600)
-    ap.add_argument('--width', type=int, default=1000)
-    args = ap.parse_args()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args, argv)
+    rank = int(os.environ.get('RANK', 0)); world = int(env_world or 1); local = int(os.environ.get('LOCAL_RANK', 0))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)' % (args.gpus, world))
 
-    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
+    # Native libraries print to fd 1 (RCCL writes a five-line version banner there): the contract is ONE JSON line on stdout, so
+    # fd 1 is pointed at stderr for the whole run and the JSON line goes to a saved duplicate of the real stdout.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + '\n').encode())
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+
+    if args.launcher_check:
+        # bring the ranks up exactly as a measured run does and count them; gloo where there is no GPU (CPU test of the launcher path)
+        on_gpu = torch.cuda.device_count() >= world
+        if on_gpu:
+            torch.cuda.set_device(local)
+        dist.init_process_group('nccl' if on_gpu else 'gloo', rank=rank, world_size=world)
+        c = torch.ones(1, device='cuda' if on_gpu else 'cpu')
+        dist.all_reduce(c)
+        if rank == 0:
+            emit({'launcher_check': True, 'n_gpus': world, 'ranks_seen': int(c.item()), 'backend': 'nccl' if on_gpu else 'gloo'})
+        dist.destroy_process_group()
+        return 0
+
     torch.cuda.set_device(local)
-    if world > 1 or args.force_dp:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         # no device_id: binding the process group to the device eagerly costs 7 % of the step on this stack even when no collective
         # is ever issued (112 vs 121 img/s at one rank; DESIGN.md section 6); the communicator is created by the first all-reduce
         dist.init_process_group('nccl', rank=rank, world_size=world)
@@ -94,7 +259,6 @@ def main():
     from lang2seg_amd.nets.resnet_v1 import resnetv1
     from lang2seg_amd.optim import SGD
     from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
-    from lang2seg_amd import ops as O
 
     if args.main_prio:
         torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
@@ -111,59 +275,77 @@ def main():
     net.rank_seed = rank * 1000003
     net.use_graph = bool(args.graph) and world == 1
     net.use_tape = bool(args.tape)          # N > 1: the tape is cut at the gradient-bucket hand-offs (Network.tape_step)
-    if (world > 1 or args.force_dp) and os.environ.get('L2S_DP_SKIP_ALLREDUCE') != '3':
+    net.knockout = frozenset(x for x in args.knockout.split(',') if x)
+    experiment = bool(net.knockout) or bool(args.dp_skip_allreduce)
+    if use_dp and args.dp_skip_allreduce != 3:
         from lang2seg_amd.parallel import GradReducer
-        net.dp = GradReducer(net, world)
+        net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
     loader = SyntheticLoader(num_images=4, sents_per_image=1, H=args.height, W=args.width, T=T, vocab_size=V, rank=rank)
     blobs = [loader.getBatch('train') for _ in range(4)]
     for b in blobs:
         net.upload_blob(b, 0)          # inputs resident in HBM before the timed region
 
-    # live timing of the dominant kernel: the implicit-GEMM conv on the layer4@RoIs 3x3 (M=12544, N=512, K=4608)
-    evs = []
-    doms = [blk.c2 for blk in net.layers[4]]
-    def wrap(conv):
-        orig = conv.fwd
-        def timed(x, n, IH, IW, y, **kw):
-            if n > 1 and wrap.on:
-                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-                a.record(); r = orig(x, n, IH, IW, y, **kw); b.record(); evs.append((a, b)); return r
-            return orig(x, n, IH, IW, y, **kw)
-        conv.fwd = timed
-    wrap.on = False
-    for c in doms:
-        wrap(c)
-
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
         torch.cuda.synchronize()
 
+    def rank_max(dt):
+        if world > 1:
+            tt = torch.tensor([dt], device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return dt
+
+    lt = LaunchTimer(net, torch)
     for i in range(args.warmup):
         net.train_step_async(blobs[i % 4], 0, optim)
     barrier()
-    replay = net.use_graph or net.use_tape
-    wrap.on = not replay               # HIP events cannot bracket kernels inside a replayed graph / tape
+    # ---- the headline: K pipelined steps, one loss read-back after the region ----
     t0 = time.time()
     for i in range(args.steps):
         loss = net.train_step_async(blobs[i % 4], 0, optim)
     barrier()
-    dt = time.time() - t0
-    wrap.on = False
-    if replay:
-        # dominant-kernel timing: the same launches, bracketed by HIP events, in eager steps right after the timed region
-        net.use_graph = False; net.use_tape = False
-        wrap.on = True
-        for i in range(5):
+    dt = rank_max(time.time() - t0)
+    lv = loss.cpu().numpy()
+    ranks_seen = 1
+    if use_dp:
+        c = torch.ones(1, device='cuda'); dist.all_reduce(c); ranks_seen = int(c.item())
+        assert ranks_seen == world, (ranks_seen, world)
+    extras = {}
+    if args.extras:
+        # ---- the reference's unit as it stands: train_step() reads the losses back every step (NET:704-710: seven .data[0]) ----
+        barrier()
+        t0 = time.time()
+        for i in range(args.steps):
+            net.train_step(blobs[i % 4], 0, optim)
+        barrier()
+        dts = rank_max(time.time() - t0)
+        extras['sync_train_step'] = {'ms_per_step': dts / args.steps * 1e3, 'value': world * args.steps / dts, 'unit': 'img/s',
+                                     'note': 'Network.train_step: loss read-back (host sync) after every step'}
+        # ---- PCIe-inclusive: the 7.2 MB fp32 image goes host -> device again before every step (NET:633-636 does so per sentence) ----
+        hosts = [torch.from_numpy(np.ascontiguousarray(b['data'], dtype=np.float32)).pin_memory() for b in blobs]
+        devd = [b['_device']['data'] for b in blobs]
+        barrier()
+        t0 = time.time()
+        for i in range(args.steps):
+            devd[i % 4].copy_(hosts[i % 4], non_blocking=True)
             net.train_step_async(blobs[i % 4], 0, optim)
         barrier()
-        wrap.on = False
-    if world > 1:
-        tt = torch.tensor([dt], device='cuda')
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    lv = loss.cpu().numpy()
+        dth = rank_max(time.time() - t0)
+        extras['pcie_inclusive'] = {'ms_per_step': dth / args.steps * 1e3, 'value': world * args.steps / dth, 'unit': 'img/s',
+                                    'h2d_bytes_per_step': int(hosts[0].numel() * 4), 'note': 'image blob re-uploaded from pinned host memory before every step'}
+        # ---- per-launch HIP events (eager steps: events cannot bracket launches inside a replayed tape) ----
+        net.use_graph = False; net.use_tape = False
+        net.train_step_async(blobs[0], 0, optim)
+        barrier()
+        lt.on = True
+        NE = 5
+        for i in range(NE):
+            net.train_step_async(blobs[i % 4], 0, optim)
+        barrier()
+        lt.on = False
     # a run whose network went non-finite measured nothing (NaN activations are silently zeroed by the next ReLU)
     if not (np.isfinite(lv[:7]).all() and bool(torch.isfinite(net.P.param).all())):
         raise RuntimeError('non-finite losses or parameters after the run: %s' % lv[:7])
@@ -171,29 +353,48 @@ def main():
         ms = dt / args.steps * 1e3
         val = world * args.steps / dt
         R = int(cfg.TRAIN.BATCH_SIZE)
-        kflop = 2.0 * (R * 49) * 512 * 4608
-        kms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else float('nan')
-        ach = kflop / (kms * 1e-3) / 1e12
         out = {
-            'metric': _baseline_metric(), 'value': val, 'unit': 'img/s', 'n_gpus': world,
+            'metric': _baseline_metric(), 'value': val, 'unit': 'img/s', 'n_gpus': world, 'ranks_seen': ranks_seen,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'train_cycle.sh step: ResNet-101 C4 + 7 spatial dynamic filters + att2in2 cycle loss, %dx%d image, '
                                    '20-token expression (V=3349), 12000->2000 proposals, 256 RoIs, per-GPU batch 1' % (args.height, args.width),
                        'parallelism': 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12,
-                       'weights': 'random (reference initialisers; trunk BN gains scaled so activations stay O(1)), fixed seed'},
+                       'weights': 'random (reference initialisers; trunk BN gains scaled so activations stay O(1)), fixed seed',
+                       'timed': 'K pipelined train steps (launch tape), losses read back once after the region'},
             'step_tflops_per_gpu': STEP_FLOP / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': STEP_FLOP / (ms * 1e-3) / PEAK_BF16,
-            'roofline': {'bound': 'mfma', 'kernel': 'igemm_sp_kernel<bf16,224,128> on layer4@RoIs conv3x3 (M=%d,N=512,K=4608)' % (R * 49),
-                         'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': _pmc_traffic(), 'traffic_note': 'HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.json; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes 30.4 MB',
-                         'avg_launch_ms': kms, 'launches_timed': len(evs)},
             'final_losses': [float(x) for x in lv[:7]],
         }
+        out.update(extras)
+        if experiment:
+            out['experiment'] = 'INVALID as a measurement: knockout=%s dp_skip_allreduce=%d' % (sorted(net.knockout), args.dp_skip_allreduce)
+        if args.extras:
+            tab, stack, dom = lt.summary(NE)
+            dk = [r for r in lt.recs if r[0] == 'layer4@RoIs' and r[1] == 'fwd' and r[2] == 3]
+            kflop = 2.0 * (R * 49) * 512 * 4608
+            kms = float(np.mean([e0.elapsed_time(e1) for _, _, _, _, e0, e1 in dk])) if dk else float('nan')
+            ach = kflop / (kms * 1e-3) / 1e12
+            traffic, tfile = _pmc_traffic()
+            out['roofline'] = {
+                'bound': 'mfma', 'kernel': 'igemm_sp_kernel<bf16,224,128> on layer4@RoIs conv3x3 forward (M=%d,N=512,K=4608)' % (R * 49),
+                'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': traffic,
+                'traffic_note': 'HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (tools/pmc_traffic.sh -> '
+                                'profiles/%s; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes 30.4 MB' % tfile,
+                'avg_launch_ms': kms, 'launches_timed': len(dk),
+                'stack3x3': stack,
+                'time_dominant': dict(tab[dom], group=dom, note='the group of convolution launches with the largest summed time per step') if dom else None,
+                'groups': tab,
+            }
+        else:
+            out['roofline'] = None
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.height, args.width, T, V)
-        os.write(_REAL_STDOUT, (json.dumps(out) + '\n').encode())
-    if world > 1 or args.force_dp:
-        torch.distributed.destroy_process_group()
+            w, k = [int(x) for x in args.cpu_baseline_steps.split(',')]
+            out['cpu_baseline'] = cpu_baseline(args.height, args.width, T, V, w, k)
+        emit(out)
+    if use_dp:
+        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

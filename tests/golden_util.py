@@ -23,6 +23,20 @@ def check_digest(g, prefix, arr, rtol=1e-4, atol=1e-4):
     return err
 
 
+def digest_metrics(g, prefix, arr):
+    """(cosine, max-normalised error, relative L2 error) of `arr` against the fixture's strided sample of the same tensor"""
+    a = np.asarray(arr, dtype=np.float64).ravel()
+    assert list(g[prefix + '.shape']) == list(np.asarray(arr).shape), (prefix, g[prefix + '.shape'], np.asarray(arr).shape)
+    stride = int(g[prefix + '.stride'])
+    samp = g[prefix + '.sample'].astype(np.float64)
+    mine = a[::stride][:samp.size]
+    nrm = float(np.linalg.norm(samp))
+    if nrm == 0.0:
+        return 1.0, float(np.abs(mine).max()), float(np.linalg.norm(mine))
+    cos = float(mine @ samp / (np.linalg.norm(mine) * nrm + 1e-300))
+    return cos, float(np.abs(mine - samp).max() / np.abs(samp).max()), float(np.linalg.norm(mine - samp) / nrm)
+
+
 def variant_of(g):
     return str(g['meta_variant']) if 'meta_variant' in g else 'cycle'
 

@@ -343,3 +343,20 @@ def test_dp_resume_per_rank_sidecars(tmp_path):
     assert ret.get(0) and ret.get(1)
     names = sorted(os.listdir(str(tmp_path)))
     assert any(n.endswith('_iter_8.rank1.pkl') for n in names) and any(n.endswith('_iter_8.pkl') for n in names) and any(n.endswith('_iter_8.pth') for n in names)
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` without a launcher starts the two ranks itself (a child `torch.distributed.run`, before any GPU
+    call), the ranks find each other, and rank 0's single JSON line reports n_gpus = 2 with an all-reduced rank count of 2.
+    (--launcher-check stops after the rendezvous; gloo stands in for RCCL on this GPU-less box.)"""
+    import json, subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher-check'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d == {'launcher_check': True, 'n_gpus': 2, 'ranks_seen': 2, 'backend': 'gloo'}
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silently mislabelled line
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher-check'], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)

@@ -27,15 +27,53 @@ def _setup(dtype, tag='tiny'):
     return g, opt, sd, blob, ocfg, samp, net
 
 
-@pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align'])
-def test_train_step_f32_vs_fixture_and_oracle(tag):
-    """every ResNet network variant of the reference (cycle = the benchmarked one; baseline / spatial / response /
-    cycle_response are BASELINE.json configs 0, 1, 3 + train_response.sh) against a fixture produced by the reference itself."""
+# Tolerances.  f32 ("verification mode", exact-f32 MFMA): north_star's 1e-4 on losses and seg-logits, integer outputs bit-exact.
+# bf16 (the benchmarked mode: bf16 activations / weight shadows, fp32 accumulation, fp32 master weights): losses within 1e-2
+# relative; every checked gradient tensor has cosine >= 0.999 and max-normalised error <= 3e-2 against the reference's fp32
+# gradient; integer outputs still bit-exact (they depend on the boxes, not on the activations, once the proposals are teacher-forced).
+BF16_LOSS_RTOL, BF16_COS, BF16_MAXERR = 1e-2, 0.999, 3e-2
+VARIANT_TAGS = ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align']
+
+
+def _grad_of(net, nme):
+    from lang2seg_amd.nets.params import from_internal
+    P = net.P
+    gr = from_internal(nme, P.view(nme, P.grad).clone(), P.shapes[nme])
+    if nme in P.rowscale_off:                       # stored gradient is w.r.t. the BN-folded weight
+        gr = gr * P.bn_scale[nme].view(-1, *([1] * (gr.dim() - 1)))
+    return gr.cpu().numpy()
+
+
+def _check_grads(g, net, dtype, rtol_f32):
+    """gradients of the fixture's tensors (reference layout): f32 -> digest within rtol + relative L2 error (which, unlike the
+    max-normalised digest, weighs the small entries too); bf16 -> cosine / max-normalised error table"""
+    from golden_util import digest_metrics
+    names = sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')})
+    bad = []
+    for nme in names:
+        gr = _grad_of(net, nme)
+        cos, emax, el2 = digest_metrics(g, 'g.' + nme, gr)
+        if dtype == 'f32':
+            check_digest(g, 'g.' + nme, gr, rtol=rtol_f32, atol=1e-7)
+            if not (el2 <= 4 * rtol_f32 and cos >= 1 - 1e-5):
+                bad.append((nme, cos, emax, el2))
+        elif not (cos >= BF16_COS and emax <= BF16_MAXERR):
+            bad.append((nme, cos, emax, el2))
+    assert not bad, bad
+    return names
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('tag', VARIANT_TAGS)
+def test_train_step_vs_fixture_and_oracle(tag, dtype):
+    """every network variant of the reference (cycle = the benchmarked one; baseline / spatial / response / cycle_response / vgg /
+    POOLING_ALIGN are BASELINE.json configs 0-4 + train_response.sh) against a fixture produced by the reference itself, in the
+    exact-f32 verification mode AND in bf16, the mode bench.py measures."""
     from oracle import net as ON
     from lang2seg_amd.optim import SGD
-    from lang2seg_amd.nets.params import from_internal
     from lang2seg_amd.nets.variants import loss_names, SLOT
-    g, opt, sd, blob, ocfg, samp, net = _setup('f32', tag)
+    g, opt, sd, blob, ocfg, samp, net = _setup(dtype, tag)
+    f32 = dtype == 'f32'
     dev = net.upload_blob(blob, 0)
     loss = net.forward_backward(dev)
     torch.cuda.synchronize()
@@ -45,11 +83,16 @@ def test_train_step_f32_vs_fixture_and_oracle(tag):
     n = int(t['proposal_n'].item())
     mine = t['proposal_rois'].cpu().numpy()[:n]
     ref = g['int.proposal_rois']
-    assert mine.shape == ref.shape
-    # set comparison by nearest neighbour (sorting rows is not stable under 1e-4 px perturbations)
-    D = np.abs(mine[:, None, 1:] - ref[None, :, 1:]).max(-1)
-    assert D.min(1).max() < 2e-2 and D.min(0).max() < 2e-2, (D.min(1).max(), D.min(0).max())
-    # integer outputs: bit-exact
+    if f32:
+        assert mine.shape == ref.shape
+        # set comparison by nearest neighbour (sorting rows is not stable under 1e-4 px perturbations)
+        D = np.abs(mine[:, None, 1:] - ref[None, :, 1:]).max(-1)
+        assert D.min(1).max() < 2e-2 and D.min(0).max() < 2e-2, (D.min(1).max(), D.min(0).max())
+    else:
+        # bf16 scores reorder near-ties, so a few keeps differ; the lists must still describe the same boxes
+        D = np.abs(mine[:, None, 1:] - ref[None, :, 1:]).max(-1)
+        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and (D.min(1) < 4.0).mean() > 0.8, (n, ref.shape, float((D.min(1) < 4.0).mean()))
+    # integer outputs: bit-exact (proposals teacher-forced)
     assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
     assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
     nfg = int(t['counts'][0].item())
@@ -57,70 +100,80 @@ def test_train_step_f32_vs_fixture_and_oracle(tag):
     assert np.array_equal(t['mask_targets'].cpu().numpy()[:nfg].reshape(nfg, 14, 14).astype(np.uint8), g['int.mask_targets'])
     # (column 0 of a GT row appended by PTL:159-167 is uninitialised memory in the reference)
     assert np.allclose(t['rois'].cpu().numpy()[:, 1:], g['int.rois'][:, 1:], atol=1e-4)
-    # losses vs the reference run (fixture) within 1e-4
+    # losses vs the reference run (fixture)
+    ltol = 1e-4 if f32 else BF16_LOSS_RTOL
     for k in loss_names(variant_of(g)):
         i = SLOT[k]
-        assert abs(lv[i] - float(g['loss.' + k])) < 1e-4 * max(1.0, abs(float(g['loss.' + k]))), (k, lv[i], g['loss.' + k])
+        assert abs(lv[i] - float(g['loss.' + k])) < ltol * max(1.0, abs(float(g['loss.' + k]))), (dtype, k, lv[i], g['loss.' + k])
     assert len(net._loss_slots()) == len(loss_names(variant_of(g)))
     Hc, Wc = 20, 26
+    atol = 1e-4 if f32 else 3e-2
     nc = t['net_conv'].float().cpu().view(1, Hc, Wc, -1).permute(0, 3, 1, 2)
-    check_digest(g, 't.net_conv', nc.numpy())
+    check_digest(g, 't.net_conv', nc.numpy(), rtol=atol, atol=atol)
     heads = t['rcnn_heads'].cpu().numpy()
-    assert np.allclose(heads[:, :8], g['x.cls_score'], atol=2e-4)
-    assert np.allclose(heads[:8, 81:97], g['x.bbox_pred'], atol=2e-4)
+    # class scores / box deltas (NET:277-290): 1e-4 of the tensor's scale in f32
+    hs = max(1.0, float(np.abs(g['x.cls_score']).max()))
+    assert np.abs(heads[:, :8] - g['x.cls_score']).max() <= atol * hs, (np.abs(heads[:, :8] - g['x.cls_score']).max(), hs)
+    assert np.abs(heads[:8, 81:97] - g['x.bbox_pred']).max() <= atol * max(1.0, float(np.abs(g['x.bbox_pred']).max()))
+    check_digest(g, 't.cls_score', heads[:, :81], rtol=atol, atol=atol)
+    check_digest(g, 't.bbox_pred', heads[:, 81:81 + 324], rtol=atol, atol=atol)
+    if 't.mask_score.sum' in g and t.get('mask_score') is not None:
+        # seg-logits (NET:292-307) on the first num_fg RoIs, reference layout (nfg, 81, 14, 14)
+        ms = t['mask_score'].cpu().numpy().reshape(-1, 14, 14, 81)[:nfg].transpose(0, 3, 1, 2)
+        check_digest(g, 't.mask_score', ms, rtol=atol, atol=atol)
     # gradients (reference layout) and post-SGD weights vs the fixture
-    names = sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')})
-    P = net.P
-    for nme in names:
-        gr = from_internal(nme, P.view(nme, P.grad).clone(), P.shapes[nme])
-        if nme in P.rowscale_off:                       # stored gradient is w.r.t. the BN-folded weight
-            gr = gr * P.bn_scale[nme].view(-1, *([1] * (gr.dim() - 1)))
-        # (the VGG trunk's gradients cross 9 un-normalised 3x3 convolutions and two max-pools: 1e-3 like the full-size test)
-        check_digest(g, 'g.' + nme, gr.cpu().numpy(), rtol=1e-3 if tag == 'tiny_vgg' else 5e-4, atol=1e-7)
+    # (the VGG trunk's gradients cross 9 un-normalised 3x3 convolutions and two max-pools: 1e-3 like the full-size test)
+    names = _check_grads(g, net, dtype, 1e-3 if tag == 'tiny_vgg' else 5e-4)
     SGD(net, 1e-4).step()
     torch.cuda.synchronize()
     sd1 = net.state_dict()
     for nme in names:
+        # lr 1e-4 x a bf16-level gradient error stays far below 1e-5 of the weight scale
         check_digest(g, 'w1.' + nme, sd1[nme].numpy(), rtol=1e-5, atol=1e-7)
 
 
-def test_train_step_full_size_f32():
-    """BASELINE.json full size (600x1000, 12000->2000 proposals, 256 RoIs, 20 tokens, V=3349) vs the reference run."""
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_train_step_full_size(dtype):
+    """BASELINE.json full size (600x1000, 12000->2000 proposals, 256 RoIs, 20 tokens, V=3349) vs the reference run, f32 and bf16."""
     from lang2seg_amd import selftest
     g = load('full')
     opt, sd, blob, ocfg, samp = setup_from_fixture(g)
     samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
     over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
-    net = selftest.build_net(opt, over, 'f32', sd)
+    net = selftest.build_net(opt, over, dtype, sd)
     net.parity = selftest.parity_from_samp(samp)
     lv = net.forward_backward(net.upload_blob(blob, 0)).cpu().numpy()
     t = net.t
+    f32 = dtype == 'f32'
     n = int(t['proposal_n'].item())
-    assert n == g['int.proposal_rois'].shape[0]
+    # the device's own 28 728 -> 12 000 -> NMS -> 2000 list against the reference's, as a set (two independent fp32 conv stacks
+    # order near-tied scores differently; the bit-exact index check on identical inputs is test_kernels_gpu.py::test_sort_nms_full_size)
+    mine = t['proposal_rois'].cpu().numpy()[:n]
+    ref = g['int.proposal_rois']
+    D = np.abs(mine[:, None, 1:] - ref[None, :, 1:]).max(-1)
+    if f32:
+        assert n == ref.shape[0]
+        far_m, far_r = (D.min(1) > 2e-2), (D.min(0) > 2e-2)
+        # boxes present in one list only: a swap of two near-tied scores at the 12 000 cut or in the greedy scan changes a few keeps
+        assert far_m.sum() <= 0.01 * n and far_r.sum() <= 0.01 * n, (int(far_m.sum()), int(far_r.sum()))
+    else:
+        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and (D.min(1) < 4.0).mean() > 0.8
     assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
     assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
     nfg = int(t['counts'][0].item())
     assert nfg == int(g['int.num_fg'])
     assert np.array_equal(t['mask_targets'].cpu().numpy()[:nfg].reshape(nfg, 14, 14).astype(np.uint8), g['int.mask_targets'])
+    ltol = 1e-4 if f32 else BF16_LOSS_RTOL
     for i, k in enumerate(NAMES):
-        assert abs(lv[i] - float(g['loss.' + k])) < 1e-4 * max(1.0, abs(float(g['loss.' + k]))), (k, lv[i], g['loss.' + k])
-    from lang2seg_amd.nets.params import from_internal
-    P = net.P
-    for nme in sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')}):
-        gr = from_internal(nme, P.view(nme, P.grad).clone(), P.shapes[nme])
-        if nme in P.rowscale_off:
-            gr = gr * P.bn_scale[nme].view(-1, *([1] * (gr.dim() - 1)))
-        check_digest(g, 'g.' + nme, gr.cpu().numpy(), rtol=1e-3, atol=1e-7)
-
-
-def test_train_step_bf16_close():
-    g, opt, sd, blob, ocfg, samp, net = _setup('bf16')
-    dev = net.upload_blob(blob, 0)
-    lv = net.forward_backward(dev).cpu().numpy()
-    for i, k in enumerate(NAMES):
-        ref = float(g['loss.' + k])
-        assert abs(lv[i] - ref) < 0.05 * max(1.0, abs(ref)), (k, lv[i], ref)
-    assert np.isfinite(net.P.grad.float().abs().sum().item())
+        assert abs(lv[i] - float(g['loss.' + k])) < ltol * max(1.0, abs(float(g['loss.' + k]))), (dtype, k, lv[i], g['loss.' + k])
+    atol = 1e-4 if f32 else 3e-2
+    heads = t['rcnn_heads'].cpu().numpy()
+    check_digest(g, 't.cls_score', heads[:, :81], rtol=atol, atol=atol)
+    check_digest(g, 't.bbox_pred', heads[:, 81:81 + 324], rtol=atol, atol=atol)
+    ms = t['mask_score'].cpu().numpy().reshape(-1, 14, 14, 81)[:nfg].transpose(0, 3, 1, 2)
+    check_digest(g, 't.mask_score', ms, rtol=atol, atol=atol)
+    assert np.abs(heads[:, :8] - g['x.cls_score']).max() <= atol * max(1.0, float(np.abs(g['x.cls_score']).max()))
+    _check_grads(g, net, dtype, 1e-3)
 
 
 def test_smoke_entry():
@@ -443,9 +496,16 @@ def test_bench_json_contract():
     for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
               'roofline', 'cpu_baseline'):
         assert k in d, k
-    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['vs_baseline'] is None and d['dtype'] == 'bf16' and d['scaling'] == 'weak'
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['vs_baseline'] is None and d['dtype'] == 'bf16' and d['scaling'] == 'weak'
     assert abs(d['value'] - 1000.0 / d['ms_per_step']) < 1e-6 * d['value'] and 'workload' in d['config'] and 'model' not in d['config']
     rf, cb = d['roofline'], d['cpu_baseline']
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['achieved'] > 100
-    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'img/s' and cb['sample']
+    # the whole 3x3 stack (north_star's target is quoted on it) and the time-dominant group of convolution launches
+    st, td = rf['stack3x3'], rf['time_dominant']
+    assert abs(st['frac'] - st['achieved'] / st['peak']) < 1e-9 and 900 < st['gflop_per_step'] < 960 and st['launches_per_step'] > 90
+    assert td['group'] in rf['groups'] and td['ms_per_step'] == max(v['ms_per_step'] for v in rf['groups'].values())
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'img/s' and cb['sample'] and cb['cpu']
+    # the synchronous train_step (the reference's unit as it stands) and the PCIe-inclusive rate ride along; neither is `value`
+    assert 0 < d['sync_train_step']['value'] <= d['value'] * 1.05 and 0 < d['pcie_inclusive']['value'] <= d['value'] * 1.05
+    assert d['pcie_inclusive']['h2d_bytes_per_step'] == 600 * 1000 * 3 * 4
     assert all(np.isfinite(v) for v in d['final_losses'])
