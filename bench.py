@@ -164,8 +164,8 @@ class LaunchTimer(object):
                     ctx_orig = net.fork_wgrad
                     evs = []
 
-                    def fork():
-                        ctx = ctx_orig()
+                    def fork(*fa, **fk):
+                        ctx = ctx_orig(*fa, **fk)
 
                         class _C(object):
                             def __enter__(s):

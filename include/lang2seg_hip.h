@@ -54,7 +54,12 @@ typedef struct {
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);
 
-/* weight gradient: dw[Cout][KH*KW*Cin] (float) += sum_pixels dy[p][co] * x(p,tap)[ci]  (atomic accumulate) */
+/* weight gradient: dw[Cout][KH*KW*Cin] (float) += sum_pixels dy[p][co] * x(p,tap)[ci]
+ * (cuDNN backward-filter behind autograd in the reference: resnet_v1_cycle_res5_2.py:83-88,324-335, network_cycle_res5_2.py:236-251,279-301).
+ * No floating-point atomics: with split-K every workgroup stores its partial tile into its own slab of `ws` and a second launch on the
+ * same stream adds the slabs to dw in a fixed order, so the result is bit-identical from run to run.  Without a workspace (or when it is
+ * too small for two slabs) the pixels are not split.  The caller must not run two launches that accumulate into the SAME dw, or that
+ * share a workspace, concurrently on different streams.  l2s_wgrad_ws_bytes: workspace the automatic split of this problem would use. */
 typedef struct {
   const void* dy;  /* [n_img*OH*OW][lddy] (dtype) */
   const void* x;   /* [n_img, IH, IW, ldx] (dtype) */
@@ -62,8 +67,11 @@ typedef struct {
   int n_img, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int lddy, ldx;
   int split_k;     /* 0 = auto */
-  int tile;        /* 0 = auto */
+  int tile;        /* 0 = auto, 64 or 128 (output-channel tile) */
+  float* ws;       /* split-K slabs (device), may be NULL */
+  size_t ws_bytes;
 } l2s_wgrad_desc;
+size_t l2s_wgrad_ws_bytes(const l2s_wgrad_desc* d, int dtype);
 int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
 
 /* shadow weights: dst(dtype)[Cout][taps][Cin] = scale[co] * src[Cout][taps][Cin]  (scale may be NULL) */
@@ -93,6 +101,7 @@ int l2s_maxpool3x3s2(const void* x, void* y, int IH, int IW, int C, int OH, int 
 int l2s_fill_f32(float* p, float v, long n, hipStream_t s);
 int l2s_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, hipStream_t s);
 int l2s_mul_f32(const float* a, const float* b, float* out, long n, hipStream_t s);
+int l2s_add_f32(const float* a, const float* b, float* out, long n, hipStream_t s);   /* out = a + b (out may alias a or b) */
 /* dst(dtype) = a(dtype) + b(dtype) + c(float)   (any of b, c may be NULL) */
 int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s);
 /* spatial mean over hw pixels per image: y[n][c] = mean_p x[n][p][c]  (NET:278) and its backward */

@@ -24,7 +24,7 @@ class WgradDesc(C.Structure):
     _fields_ = [('dy', vp), ('x', vp), ('dw', vp),
                 ('n_img', i32), ('IH', i32), ('IW', i32), ('Cin', i32), ('OH', i32), ('OW', i32), ('Cout', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32), ('lddy', i32), ('ldx', i32),
-                ('split_k', i32), ('tile', i32)]
+                ('split_k', i32), ('tile', i32), ('ws', vp), ('ws_bytes', sz)]
 
 
 class TransposeDesc(C.Structure):
@@ -52,6 +52,7 @@ SIGS = {
     'l2s_version': (i32, []),
     'l2s_conv_igemm': (i32, [C.POINTER(ConvDesc), i32, vp]),
     'l2s_conv_wgrad': (i32, [C.POINTER(WgradDesc), i32, vp]),
+    'l2s_wgrad_ws_bytes': (sz, [C.POINTER(WgradDesc), i32]),
     'l2s_weight_cast': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_weight_transpose': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_colsum': (i32, [vp, i32, i32, i32, vp, i32, vp]),
@@ -127,6 +128,7 @@ SIGS = {
     'l2s_logsoftmax_nll': (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp]),
     'l2s_mul_f32': (i32, [vp, vp, vp, i64, vp]),
+    'l2s_add_f32': (i32, [vp, vp, vp, i64, vp]),
     'l2s_stream_fork': (i32, [vp, vp]),
     'l2s_memset_async': (i32, [vp, i32, sz, vp]),
     'l2s_memcpy_d2d_async': (i32, [vp, vp, sz, vp]),

@@ -3,9 +3,7 @@
 //   l2s_conv_igemm : forward conv / 1x1 / Linear / data-gradient, no im2col buffer.
 //                    C[m][n] = sum_k A(m,k) * W[n][k],  m = output pixel, n = output channel,
 //                    k = (tap, cin); A gathered on the fly from the NHWC input (zero padded).
-//   l2s_conv_wgrad : weight gradient, dW[n][tap][c] += sum_m dY[m][n] * X(m,tap)[c]
-//                    (reduction over pixels; both operands are pixel-major in HBM, so the bf16
-//                    path feeds the MFMA through ds_read_b64_tr_b16 transposed LDS reads).
+//   (the weight gradient lives in conv_wgrad.hip)
 //
 // Replaces the cuDNN calls behind nn.Conv2d / F.conv2d / nn.Linear in the reference
 // (pyutils/mask-faster-rcnn/lib/nets/resnet_v1_cycle_res5_2.py:83-88,121,147,324-335 and
@@ -891,360 +889,6 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(const l2s_conv_desc p) 
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
-// ------------------------------------------------------------------------------------------------
-// weight gradient
-// ------------------------------------------------------------------------------------------------
-template <typename T> struct WG;
-template <> struct WG<bf16_t> {
-  static constexpr int BKP = 32;  // pixels per slice (= one 16x16x32 MFMA k-step)
-  static __device__ __forceinline__ int lrow(int bm) { return bm * 2 + 32; }  // stride == 8 dwords (mod 64): tr reads conflict-free
-};
-template <> struct WG<float> {
-  static constexpr int BKP = 16;
-  static __device__ __forceinline__ int lrow(int bm) { return bm * 4 + 64; }  // stride == 16 dwords (mod 32)
-};
-
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p) {
-  constexpr int VE = 16 / (int)sizeof(T);
-  constexpr int BKP = WG<T>::BKP;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int LRA = BM * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  constexpr int LRB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  constexpr int VPA = BM / VE, VPB = BN / VE;            // vectors per row
-  constexpr int NVA = BKP * VPA / 256, NVB = BKP * VPB / 256;  // vectors per thread
-  static_assert(NVA >= 1 && NVB >= 1, "tile too small");
-  constexpr int BUF = BKP * (LRA + LRB);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int co0 = blockIdx.x * BM;
-  const int cblocks = (p.Cin + BN - 1) / BN;
-  const int tap = blockIdx.y / cblocks, ci0 = (blockIdx.y - tap * cblocks) * BN;
-  const int ky = tap / p.KW, kx = tap - ky * p.KW;
-  const int M = p.n_img * p.OH * p.OW;
-  const int ohw = p.OH * p.OW;
-  const float r_ohw = 1.0f / (float)ohw, r_ow = 1.0f / (float)p.OW;
-  const T* __restrict__ DY = (const T*)p.dy;
-  const T* __restrict__ X = (const T*)p.x;
-
-  const int nslices = (M + BKP - 1) / BKP;
-  const int per = (nslices + gridDim.z - 1) / gridDim.z;
-  const int s_begin = blockIdx.z * per;
-  const int s_end = min(nslices, s_begin + per);
-  if (s_begin >= s_end) return;
-
-  // per-thread loader rows are fixed inside a slice; their pixel (n, oy, ox) is advanced by BKP pixels per slice with
-  // add/compare arithmetic (BKP = sa*OH*OW + sb*OW + sc) instead of two integer divisions per vector per slice.
-  const int sa = BKP / ohw, sb = (BKP - sa * ohw) / p.OW, sc = BKP - sa * ohw - sb * p.OW;
-  int xn[NVB], xoy[NVB], xox[NVB], xci[NVB], xr[NVB];
-  long ya[NVA]; int yr[NVA]; bool yc[NVA];
-  {
-    const int pb0 = s_begin * BKP;
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = tid + j * 256; const int r = v / VPB, c = v - r * VPB;
-      const int pix = pb0 + r;
-      xr[j] = r; xci[j] = ci0 + c * VE;
-      xn[j] = pix / ohw; const int rem = pix - xn[j] * ohw; xoy[j] = rem / p.OW; xox[j] = rem - xoy[j] * p.OW;
-    }
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = tid + j * 256; const int r = v / VPA, c = v - r * VPA;
-      yr[j] = r; yc[j] = (co0 + c * VE) < p.Cout;
-      ya[j] = (long)(pb0 + r) * p.lddy + co0 + c * VE;
-    }
-  }
-  uint4 ra[NVA], rb[NVB];
-  auto load_slice = [&](int s) {
-    const int pb = s * BKP;
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (pb + yr[j] < M && yc[j]) val = *(const uint4*)(DY + ya[j]);
-      ra[j] = val;
-      ya[j] += (long)BKP * p.lddy;
-    }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      uint4 val = make_uint4(0, 0, 0, 0);
-      const int iy = xoy[j] * p.stride - p.pad + ky, ix = xox[j] * p.stride - p.pad + kx;
-      if (pb + xr[j] < M && xci[j] < p.Cin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-        val = *(const uint4*)(X + (((long)xn[j] * p.IH + iy) * p.IW + ix) * p.ldx + xci[j]);
-      rb[j] = val;
-      // advance this row by BKP pixels
-      xox[j] += sc; if (xox[j] >= p.OW) { xox[j] -= p.OW; ++xoy[j]; }
-      xoy[j] += sb; if (xoy[j] >= p.OH) { xoy[j] -= p.OH; ++xn[j]; }
-      xn[j] += sa;
-    }
-  };
-  auto store_slice = [&](int buf) {
-    char* a = smem + buf * BUF;
-    char* b = a + BKP * LRA;
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) { int v = tid + j * 256; int r = v / VPA, c = v - r * VPA; *(uint4*)(a + r * LRA + c * 16) = ra[j]; }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) { int v = tid + j * 256; int r = v / VPB, c = v - r * VPB; *(uint4*)(b + r * LRB + c * 16) = rb[j]; }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  load_slice(s_begin);
-  store_slice(0);
-  __syncthreads();
-  const int fr = lane & 15, fg = lane >> 4;
-  for (int s = s_begin; s < s_end; ++s) {
-    const int cur = (s - s_begin) & 1;
-    if (s + 1 < s_end) load_slice(s + 1);
-    const char* a = smem + cur * BUF;
-    const char* b = a + BKP * LRA;
-    if constexpr (sizeof(T) == 2) {
-      // k mapping inside the 32-pixel slice: lane group g, half h, element e  <->  pixel 16h + 4g + e
-      // (same map for both operands, so the contraction is consistent; chosen so a 32-lane half reads
-      // 8 consecutive LDS rows -> conflict-free with the 8-dword row skew).
-      const int trow = 4 * fg + ((lane >> 2) & 3), tcol = 8 * (lane & 3);
-      uint4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const char* q = a + trow * LRA + (wm * WM + i * 16) * 2 + tcol;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRA));
-        fa[i] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const char* q = b + trow * LRB + (wn * WN + j * 16) * 2 + tcol;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRB));
-        fb[j] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < BKP / 4; ++ks) {
-        float fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *(const float*)(a + (ks * 4 + fg) * LRA + (wm * WM + i * 16 + fr) * 4);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = *(const float*)(b + (ks * 4 + fg) * LRB + (wn * WN + j * 16 + fr) * 4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    if (s + 1 < s_end) store_slice(cur ^ 1);
-    __syncthreads();
-  }
-  // D[row = co][col = ci]: col = lane&15, row = 4*(lane>>4) + r
-  const long Kw = (long)p.KH * p.KW * p.Cin;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int ci = ci0 + wn * WN + j * 16 + fr;
-      if (ci >= p.Cin) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + wm * WM + i * 16 + fg * 4 + r;
-        if (co < p.Cout) atomicAdd(p.dw + (long)co * Kw + (long)tap * p.Cin + ci, acc[i][j][r]);
-      }
-    }
-}
-
-// Ring variant of the weight-gradient kernel (the default): the two operands of a 32-pixel slice are fetched with branch-free
-// buffer loads (pixels past M, padding taps and channels past Cin/Cout carry the out-of-range offset and read as zeros) into
-// a ring of D register sets, D slices ahead of the MFMAs, so the slice loop is no longer one exposed HBM/L2 round trip per
-// 32 pixels.  Same LDS image, fragment reads, MFMAs and atomic epilogue as wgrad_kernel.
-template <typename T, int BM, int BN, int D>
-__global__ __launch_bounds__(256) void wgrad_ring_kernel(const l2s_wgrad_desc p) {
-  constexpr int VE = 16 / (int)sizeof(T);
-  constexpr int BKP = WG<T>::BKP;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int LRA = BM * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  constexpr int LRB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  constexpr int VPA = BM / VE, VPB = BN / VE;            // vectors per row
-  constexpr int NVA = BKP * VPA / 256, NVB = BKP * VPB / 256;  // vectors per thread
-  static_assert(NVA >= 1 && NVB >= 1, "tile too small");
-  constexpr int BUF = BKP * (LRA + LRB);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int co0 = blockIdx.x * BM;
-  const int cblocks = (p.Cin + BN - 1) / BN;
-  const int tap = blockIdx.y / cblocks, ci0 = (blockIdx.y - tap * cblocks) * BN;
-  const int ky = tap / p.KW, kx = tap - ky * p.KW;
-  const int M = p.n_img * p.OH * p.OW;
-  const int ohw = p.OH * p.OW;
-  const float r_ohw = 1.0f / (float)ohw, r_ow = 1.0f / (float)p.OW;
-  const auto rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, 0x7FFFFFFF, 0x00020000);
-  const auto rxx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7FFFFFFF, 0x00020000);
-
-  const int nslices = (M + BKP - 1) / BKP;
-  const int per = (nslices + gridDim.z - 1) / gridDim.z;
-  const int s_begin = blockIdx.z * per;
-  const int s_end = min(nslices, s_begin + per);
-  if (s_begin >= s_end) return;
-
-  // per-thread loader rows are fixed inside a slice; their pixel (n, oy, ox) is advanced by BKP pixels per slice with
-  // add/compare arithmetic (BKP = sa*OH*OW + sb*OW + sc) instead of two integer divisions per vector per slice.
-  const int sa = BKP / ohw, sb = (BKP - sa * ohw) / p.OW, sc = BKP - sa * ohw - sb * p.OW;
-  int xn[NVB], xoy[NVB], xox[NVB], xci[NVB], xr[NVB];
-  int ya[NVA]; int yr[NVA]; bool yc[NVA];
-  {
-    const int pb0 = s_begin * BKP;
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = tid + j * 256; const int r = v / VPB, c = v - r * VPB;
-      const int pix = pb0 + r;
-      xr[j] = r; xci[j] = ci0 + c * VE;
-      xn[j] = pix / ohw; const int rem = pix - xn[j] * ohw; xoy[j] = rem / p.OW; xox[j] = rem - xoy[j] * p.OW;
-    }
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = tid + j * 256; const int r = v / VPA, c = v - r * VPA;
-      yr[j] = r; yc[j] = (co0 + c * VE) < p.Cout;
-      ya[j] = (pb0 + r) * p.lddy + co0 + c * VE;
-    }
-  }
-  int s_issue = s_begin;                                   // next slice to fetch
-  auto issue = [&](uint4 (&ra)[NVA], uint4 (&rb)[NVB]) {
-    const int pb = s_issue * BKP;
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const unsigned o = (pb + yr[j] < M && yc[j]) ? (unsigned)(ya[j] * (int)sizeof(T)) : OOR;
-      ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o, 0, 0));
-      ya[j] += BKP * p.lddy;
-    }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int iy = xoy[j] * p.stride - p.pad + ky, ix = xox[j] * p.stride - p.pad + kx;
-      const bool ok = pb + xr[j] < M && xci[j] < p.Cin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-      const unsigned o = ok ? (unsigned)(((((xn[j] * p.IH + iy) * p.IW + ix) * p.ldx) + xci[j]) * (int)sizeof(T)) : OOR;
-      rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxx, o, 0, 0));
-      xox[j] += sc; if (xox[j] >= p.OW) { xox[j] -= p.OW; ++xoy[j]; }
-      xoy[j] += sb; if (xoy[j] >= p.OH) { xoy[j] -= p.OH; ++xn[j]; }
-      xn[j] += sa;
-    }
-    ++s_issue;
-  };
-  auto store_slice = [&](int buf, const uint4 (&ra)[NVA], const uint4 (&rb)[NVB]) {
-    char* a = smem + buf * BUF;
-    char* b = a + BKP * LRA;
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) { int v = tid + j * 256; int r = v / VPA, c = v - r * VPA; *(uint4*)(a + r * LRA + c * 16) = ra[j]; }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) { int v = tid + j * 256; int r = v / VPB, c = v - r * VPB; *(uint4*)(b + r * LRB + c * 16) = rb[j]; }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fg = lane >> 4;
-  auto compute = [&](int cur) {
-    const char* a = smem + cur * BUF;
-    const char* b = a + BKP * LRA;
-    if constexpr (sizeof(T) == 2) {
-      // k mapping inside the 32-pixel slice: lane group g, half h, element e  <->  pixel 16h + 4g + e
-      // (same map for both operands, so the contraction is consistent; chosen so a 32-lane half reads
-      // 8 consecutive LDS rows -> conflict-free with the 8-dword row skew).
-      const int trow = 4 * fg + ((lane >> 2) & 3), tcol = 8 * (lane & 3);
-      uint4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const char* q = a + trow * LRA + (wm * WM + i * 16) * 2 + tcol;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRA));
-        fa[i] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const char* q = b + trow * LRB + (wn * WN + j * 16) * 2 + tcol;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRB));
-        fb[j] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < BKP / 4; ++ks) {
-        float fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *(const float*)(a + (ks * 4 + fg) * LRA + (wm * WM + i * 16 + fr) * 4);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = *(const float*)(b + (ks * 4 + fg) * LRB + (wn * WN + j * 16 + fr) * 4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    }
-  };
-  const int NS = s_end - s_begin;
-  uint4 qa[D][NVA], qb[D][NVB];
-#pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < NS) issue(qa[s], qb[s]);
-  store_slice(0, qa[0], qb[0]);
-  if (D < NS) issue(qa[0], qb[0]);
-  int t0 = 0;
-  for (; t0 + 2 * D <= NS; t0 += D) {
-#pragma unroll
-    for (int s = 0; s < D; ++s) {
-      const int t = t0 + s;
-      const int nxt = (s + 1) % D;
-      __syncthreads();
-      store_slice((t + 1) & 1, qa[nxt], qb[nxt]);
-      issue(qa[nxt], qb[nxt]);
-      compute(t & 1);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < 2 * D; ++s) {
-    const int t = t0 + s;
-    if (t < NS) {
-      const int nxt = (s + 1) % D;
-      __syncthreads();
-      if (t + 1 < NS) {
-        store_slice((t + 1) & 1, qa[nxt], qb[nxt]);
-        if (t + 1 + D < NS) issue(qa[nxt], qb[nxt]);
-      }
-      compute(t & 1);
-    }
-  }
-  // D[row = co][col = ci]: col = lane&15, row = 4*(lane>>4) + r
-  const long Kw = (long)p.KH * p.KW * p.Cin;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int ci = ci0 + wn * WN + j * 16 + fr;
-      if (ci >= p.Cin) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + wm * WM + i * 16 + fg * 4 + r;
-        if (co < p.Cout) atomicAdd(p.dw + (long)co * Kw + (long)tap * p.Cin + ci, acc[i][j][r]);
-      }
-    }
-}
-
 // y = epilogue(ws) and ws = 0 (so the workspace is clean for the next split-K launch)
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const l2s_conv_desc p, long total) {
@@ -1319,28 +963,6 @@ int launch_igemm_pipe(const l2s_conv_desc& d, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   L2S_LAUNCH((igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>), grid, dim3(256), lds, st, d);
-  return l2s_check_launch();
-}
-
-template <typename T, int BM, int BN, int D>
-int launch_wgrad_ring(const l2s_wgrad_desc& d, int split, hipStream_t st) {
-  const int taps = d.KH * d.KW;
-  dim3 grid(cdiv(d.Cout, BM), taps * cdiv(d.Cin, BN), split);
-  constexpr int LRA = BM * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  constexpr int LRB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  size_t lds = 2 * WG<T>::BKP * (LRA + LRB);
-  L2S_LAUNCH((wgrad_ring_kernel<T, BM, BN, D>), grid, dim3(256), lds, st, d);
-  return l2s_check_launch();
-}
-
-template <typename T, int BM, int BN>
-int launch_wgrad(const l2s_wgrad_desc& d, int split, hipStream_t st) {
-  const int taps = d.KH * d.KW;
-  dim3 grid(cdiv(d.Cout, BM), taps * cdiv(d.Cin, BN), split);
-  constexpr int LRA = BM * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  constexpr int LRB = BN * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 64);
-  size_t lds = 2 * WG<T>::BKP * (LRA + LRB);
-  L2S_LAUNCH((wgrad_kernel<T, BM, BN>), grid, dim3(256), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -1441,52 +1063,5 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   if (dtype == L2S_BF16) return tile == 128 ? GO(bf16_t, 128, 128) : GO(bf16_t, 64, 64);
   if (dtype == L2S_F32) return tile == 128 ? GO(float, 128, 128) : GO(float, 64, 64);
 #undef GO
-  return L2S_EINVAL;
-}
-
-extern "C" int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream) {
-  if (!d || !d->dy || !d->x || !d->dw) return L2S_EINVAL;
-  const int ve = dtype == L2S_BF16 ? 8 : 4;
-  if (d->lddy % ve || d->ldx % ve || d->Cin % ve || d->Cout % ve) return L2S_EINVAL;
-  const long M = (long)d->n_img * d->OH * d->OW;
-  if (M >= (1 << 24)) return L2S_EINVAL;
-  const int taps = d->KH * d->KW;
-  // tile / split-K heuristics from tools/wgrad_sweep.py (profiles/r01_wgrad_sweep.txt).  The kernel is bound by operand
-  // staging (pixel-major operands, 32-pixel slices), not by MFMA: 128x128 tiles pay off only for the 1x1 layers over the
-  // RoI batch (M >= 8192, wide channels); everything else runs 64x64 tiles with ~40 pixel slices per workgroup and at
-  // least ~512 workgroups, the fp32 atomics of the split-K partial sums being the other cost (split x |dW| bytes).
-  const bool big = M >= 8192 && taps == 1 && d->Cout >= 512 && d->Cin >= 512;
-  int tile = d->tile ? d->tile : (big ? 128 : 64);
-  const long tiles = (long)cdiv(d->Cout, tile) * taps * cdiv(d->Cin, tile);
-  const int bkp = dtype == L2S_BF16 ? 32 : 16;
-  const int slices = cdiv(M, bkp);
-  int split = d->split_k;
-  static const int min_wg = [] { const char* e = getenv("L2S_WGRAD_MINWG"); return e ? atoi(e) : 512; }();   // experiment knob
-  static const int per_split = [] { const char* e = getenv("L2S_WGRAD_SLICES"); return e ? atoi(e) : 40; }();
-  if (split <= 0) {
-    if (tile == 128) {
-      split = (int)((min_wg + tiles - 1) / tiles);        // aim at ~2 workgroups per CU
-    } else {
-      split = slices / per_split;
-      int p2 = 1; while (p2 * 2 <= split) p2 *= 2; split = p2;
-      const int fill = (int)((min_wg + tiles - 1) / tiles);
-      if (split < fill) split = fill;
-    }
-    int maxs = cdiv(slices, 8);                        // at least 8 slices per split
-    if (split > maxs) split = maxs;
-    if (split < 1) split = 1;
-    if (split > 64) split = 64;
-  }
-  static const int wring = [] { const char* e = getenv("L2S_WGRAD_RING"); return e ? atoi(e) : 1; }();
-  {
-    const long esz = dtype == L2S_BF16 ? 2 : 4;
-    const long xb = (long)d->n_img * d->IH * d->IW * d->ldx * esz, yb = M * d->lddy * esz;
-    if (wring && xb < (1L << 31) && yb < (1L << 31)) {
-      if (dtype == L2S_BF16) return tile == 128 ? launch_wgrad_ring<bf16_t, 128, 128, 3>(*d, split, stream) : launch_wgrad_ring<bf16_t, 64, 64, 4>(*d, split, stream);
-      if (dtype == L2S_F32) return tile == 128 ? launch_wgrad_ring<float, 128, 128, 2>(*d, split, stream) : launch_wgrad_ring<float, 64, 64, 4>(*d, split, stream);
-    }
-  }
-  if (dtype == L2S_BF16) return tile == 128 ? launch_wgrad<bf16_t, 128, 128>(*d, split, stream) : launch_wgrad<bf16_t, 64, 64>(*d, split, stream);
-  if (dtype == L2S_F32) return tile == 128 ? launch_wgrad<float, 128, 128>(*d, split, stream) : launch_wgrad<float, 64, 64>(*d, split, stream);
   return L2S_EINVAL;
 }

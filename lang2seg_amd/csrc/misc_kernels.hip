@@ -254,6 +254,15 @@ __global__ void cast_kernel(const void* s, int sd, void* d, int dd, long n) {
 __global__ void mul_kernel(const float* a, const float* b, float* o, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
 }
+// out = a + b, 16 bytes per lane (n % 4 == 0, 16-byte aligned) with a scalar tail otherwise
+__global__ void add_f32_kernel(const float* a, const float* b, float* o, long n) {
+  const long n4 = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)o) & 15) ? 0 : n / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = ((const float4*)a)[i], y = ((const float4*)b)[i];
+    ((float4*)o)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+  for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
+}
 // out = x * mask (fp32 dropout mask), zeroed where relu_ref <= 0 when relu_ref is given (dropout forward / backward of fc6, fc7)
 __global__ void scale_mask_kernel(const void* x, const float* mask, const void* ref, void* out, long n, int dt) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -491,6 +500,10 @@ extern "C" int l2s_cast(const void* src, int sd, void* dst, int dd, long n, hipS
 }
 extern "C" int l2s_mul_f32(const float* a, const float* b, float* out, long n, hipStream_t s) {
   L2S_LAUNCH(mul_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
+  return l2s_check_launch();
+}
+extern "C" int l2s_add_f32(const float* a, const float* b, float* out, long n, hipStream_t s) {
+  L2S_LAUNCH(add_f32_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, a, b, out, n);
   return l2s_check_launch();
 }
 extern "C" int l2s_scale_mask(const void* x, const float* mask, const void* relu_ref, void* out, long n, int dtype, hipStream_t s) {

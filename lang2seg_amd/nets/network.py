@@ -85,14 +85,18 @@ class ConvOp(object):
                          scatter=(IH, IW, self.stride), dt=self.net.dt)
         return dx
 
-    def wgrad(self, g, x, n, IH, IW):
-        """weight (+bias) gradient.  Nothing downstream in the step needs it before the optimiser, so it is forked onto the
-        weight-gradient stream and overlaps with the data-gradient chain that continues on the calling stream."""
+    def wgrad(self, g, x, n, IH, IW, alt=False):
+        """weight (+bias) gradient.  Nothing downstream in the step needs it before the optimiser, so it is forked onto a
+        weight-gradient stream and overlaps with the data-gradient chain that continues on the calling stream.
+        alt: accumulate into the caption branch's own gradient buffer (Network.merge_alt_grads adds it to the main one): the
+        layer4 weights are used by the RoI pass and by the caption pass, which run concurrently, and the weight-gradient kernels
+        add without atomics (bit-reproducible), so two passes never accumulate into the same tensor at the same time."""
         OH, OW = self.out_hw(IH, IW)
         if 'wgrad' in self.net.knockout:                  # experiment only (bench.py --knockout); train_net refuses it
             return
-        with self.net.fork_wgrad():
-            O.conv_wgrad(g, x, self.w_grad, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad)
+        dw = self.w_grad_alt if alt else self.w_grad
+        with self.net.fork_wgrad(alt):
+            O.conv_wgrad(g, x, dw, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad, ws=self.net.wgrad_ws())
             if self.bias_grad is not None:
                 O.colsum(g, n * OH * OW, self.Np, self.Np, self.bias_grad)
 
@@ -124,19 +128,20 @@ class Bottleneck(object):
             self.c3.fwd(a2, n, OH, OW, y, add=x, relu=True)
         return y, OH, OW, (x, a1, a2, IH, IW, OH, OW, n)
 
-    def bwd(self, g, saved, tag, x_is_relu_out=True):
-        """g = dL/d(pre-ReLU sum) (already masked by y > 0).  Returns dL/dx masked by x > 0 when x is a ReLU output."""
+    def bwd(self, g, saved, tag, x_is_relu_out=True, alt=False):
+        """g = dL/d(pre-ReLU sum) (already masked by y > 0).  Returns dL/dx masked by x > 0 when x is a ReLU output.
+        alt: weight gradients go to the caption branch's gradient buffer (ConvOp.wgrad)."""
         net = self.net
         x, a1, a2, IH, IW, OH, OW, n = saved
-        self.c3.wgrad(g, a2, n, OH, OW)
+        self.c3.wgrad(g, a2, n, OH, OW, alt)
         dz2 = net.buf(tag + '.dz2', (n * OH * OW, self.planes))
         self.c3.dgrad(g, n, OH, OW, dz2, ref=a2)
-        self.c2.wgrad(dz2, a1, n, OH, OW)
+        self.c2.wgrad(dz2, a1, n, OH, OW, alt)
         dz1 = net.buf(tag + '.dz1', (n * OH * OW, self.planes))
         self.c2.dgrad(dz2, n, OH, OW, dz1, ref=a1)
-        self.c1.wgrad(dz1, x, n, IH, IW)
+        self.c1.wgrad(dz1, x, n, IH, IW, alt)
         if self.down is not None:
-            self.down.wgrad(g, x, n, IH, IW)
+            self.down.wgrad(g, x, n, IH, IW, alt)
         if not self.need_dx:
             return None
         dx = net.buf(tag + '.dx', (n * IH * IW, self.inpl))
@@ -213,17 +218,51 @@ class Network(object):
         """device-side ordering edge between two streams (recorded on the launch tape when one is being recorded)."""
         O.stream_fork(from_stream, to_stream)
 
-    def fork_wgrad(self):
-        """context: run the enclosed launches on the weight-gradient stream, ordered after everything already enqueued on
-        the current stream (event fork); joined by join_wgrad() before the optimiser / gradient all-reduce."""
+    WGRAD_WS_BYTES = 64 << 20      # split-K slabs of one weight-gradient launch (the launcher splits less when they would not fit)
+
+    def fork_wgrad(self, alt=False):
+        """context: run the enclosed launches on a weight-gradient stream, ordered after everything already enqueued on
+        the current stream (event fork); joined by join_wgrad() before the optimiser / gradient all-reduce.
+        alt (the caption branch's second use of the layer4 weights): always the second stream, so that these launches are
+        ordered among themselves."""
         import contextlib
         if not self.use_streams:
+            self._wg_name = 'main'
             return contextlib.nullcontext()
         S = self.streams()
-        self._wg_flip ^= 1                                   # two weight-gradient streams, alternated: the small late-layer
-        wg = S['wg2'] if self._wg_flip else S['wg']          # GEMMs do not fill the chip on their own
-        self.sfork(torch.cuda.current_stream(), wg)
-        return torch.cuda.stream(wg)
+        if alt:
+            name = 'wg2'
+        else:
+            self._wg_flip ^= 1                               # two weight-gradient streams, alternated: the small late-layer
+            name = 'wg2' if self._wg_flip else 'wg'          # GEMMs do not fill the chip on their own
+        self._wg_name = name
+        self.sfork(torch.cuda.current_stream(), S[name])
+        return torch.cuda.stream(S[name])
+
+    def wgrad_ws(self):
+        """split-K workspace of the stream the current weight-gradient launch goes to (one per stream: launches on different
+        streams overlap)"""
+        name = getattr(self, '_wg_name', 'main')
+        d = self.__dict__.setdefault('_wg_ws', {})
+        if name not in d:
+            d[name] = torch.empty(self.WGRAD_WS_BYTES // 4, dtype=torch.float32, device=self.device)
+        return d[name]
+
+    def merge_alt_grads(self):
+        """grad[layer4] += the caption branch's layer4 gradients, on the first weight-gradient stream after everything both
+        weight-gradient streams hold so far (the RoI pass's and the caption pass's layer4 launches)."""
+        P = self.P
+        if getattr(P, 'grad_alt', None) is None:
+            return
+        lo, hi = P.alt_range
+        if not self.use_streams:
+            O.add_f32(P.grad[lo:hi], P.grad_alt, P.grad[lo:hi])
+            return
+        S = self.streams()
+        self.sfork(S['wg2'], S['wg'])
+        self.sfork(torch.cuda.current_stream(), S['wg'])
+        with torch.cuda.stream(S['wg']):
+            O.add_f32(P.grad[lo:hi], P.grad_alt, P.grad[lo:hi])
 
     def join_wgrad(self):
         if self.use_streams:

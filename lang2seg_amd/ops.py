@@ -105,8 +105,7 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     return y
 
 
-def conv_wgrad(dy, x, dw, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, lddy=None, ldx=None,
-               split_k=0, tile=0):
+def _wgrad_desc(dy, x, dw, n_img, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, lddy, ldx, split_k, tile, ws):
     d = WgradDesc()
     d.dy, d.x, d.dw = ptr(dy), ptr(x), ptr(dw)
     d.n_img, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = n_img, IH, IW, Cin, OH, OW, Cout
@@ -114,8 +113,23 @@ def conv_wgrad(dy, x, dw, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1
     d.lddy = Cout if lddy is None else lddy
     d.ldx = Cin if ldx is None else ldx
     d.split_k, d.tile = split_k, tile
+    d.ws = ptr(ws)
+    d.ws_bytes = 0 if ws is None else ws.numel() * ws.element_size()
+    return d
+
+
+def conv_wgrad(dy, x, dw, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, lddy=None, ldx=None,
+               split_k=0, tile=0, ws=None):
+    """dw += weight gradient.  `ws`: float workspace for the split-K slabs (summed in a fixed order by a second launch on the same
+    stream: no float atomics); None = pixels are not split.  One workspace per stream that runs these launches."""
+    d = _wgrad_desc(dy, x, dw, n_img, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, lddy, ldx, split_k, tile, ws)
     call('l2s_conv_wgrad', C.byref(d), dt_of(x), stream())
     return dw
+
+
+def wgrad_ws_bytes(n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, dt=BF16, split_k=0, tile=0):
+    d = _wgrad_desc(None, None, None, n_img, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, None, None, split_k, tile, None)
+    return int(_lib.load().l2s_wgrad_ws_bytes(C.byref(d), dt))
 
 
 def weight_cast(src, scale, dst, Cout, taps, Cin):
@@ -460,6 +474,10 @@ def logsoftmax_nll(logits, target, mask, S, V1, gscale, loss_slot, dlogits, logp
 def sgd_momentum(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale=1.0, shadow=None):
     call('l2s_sgd_momentum', ptr(param), ptr(grad), ptr(mom), ptr(segs_dev), nseg, ptr(rowscale), float(lr), float(momentum),
          float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, stream())
+
+
+def add_f32(a, b, out):
+    call('l2s_add_f32', ptr(a), ptr(b), ptr(out), a.numel(), stream())
 
 
 def mul(a, b, out):

@@ -131,18 +131,25 @@ def test_conv_bwd(cfg, dt):
         O.conv_igemm(dyd, wt, dx, n, OH, OW, Cout, OH, OW, Cin, 1, 1, 1, 0, scatter=(H, W, s))
     torch.cuda.synchronize()
     assert rel_err(dx.float().view(n, H, W, Cin), nhwc(xr.grad)) < TOL[dt]
-    # wgrad (accumulates on top of existing content)
-    dw = torch.ones((Cout, k * k, Cin), dtype=torch.float32, device=DEV)
-    O.conv_wgrad(dyd, xd, dw, n, H, W, Cin, OH, OW, Cout, k, k, s, p)
+    # wgrad (accumulates on top of existing content); split-K partial slabs go through the workspace and are summed in a fixed order
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    dw = torch.ones((Cout, k * k * Cin), dtype=torch.float32, device=DEV)
+    O.conv_wgrad(dyd, xd, dw, n, H, W, Cin, OH, OW, Cout, k, k, s, p, ws=ws)
     torch.cuda.synchronize()
-    refw = ohwi(weff.grad).view(Cout, k * k, Cin) + 1.0
+    refw = ohwi(weff.grad).view(Cout, k * k * Cin) + 1.0
     # fp32 accumulation of exact products of the same rounded operands in both modes
     assert rel_err(dw, refw) < 1e-4
     # the weight gradient is reproducible bit for bit from run to run (no floating-point atomics)
-    dw2 = torch.ones((Cout, k * k, Cin), dtype=torch.float32, device=DEV)
-    O.conv_wgrad(dyd, xd, dw2, n, H, W, Cin, OH, OW, Cout, k, k, s, p)
+    dw2 = torch.ones((Cout, k * k * Cin), dtype=torch.float32, device=DEV)
+    O.conv_wgrad(dyd, xd, dw2, n, H, W, Cin, OH, OW, Cout, k, k, s, p, ws=ws)
     torch.cuda.synchronize()
     assert torch.equal(dw, dw2)
+    # every tile / split choice (forced split-K, no workspace = unsplit, the other tile, per-tap tiles instead of shared filter rows)
+    for kw in (dict(split_k=3, ws=ws), dict(), dict(tile=128, ws=ws), dict(tile=64, split_k=2, ws=ws)):
+        dw3 = torch.ones((Cout, k * k * Cin), dtype=torch.float32, device=DEV)
+        O.conv_wgrad(dyd, xd, dw3, n, H, W, Cin, OH, OW, Cout, k, k, s, p, **kw)
+        torch.cuda.synchronize()
+        assert rel_err(dw3, refw) < 1e-4, kw
 
 
 @pytest.mark.parametrize('dt', [0, 1])

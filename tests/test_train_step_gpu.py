@@ -59,8 +59,23 @@ def _check_grads(g, net, dtype, rtol_f32):
                 bad.append((nme, cos, emax, el2))
         elif not (cos >= BF16_COS and emax <= BF16_MAXERR):
             bad.append((nme, cos, emax, el2))
+    _log_grad_table(g, net, dtype, names)
     assert not bad, bad
     return names
+
+
+def _log_grad_table(g, net, dtype, names):
+    """append the per-tensor gradient agreement of this run to gpurun_out/grad_agreement.jsonl (evidence for the stated tolerances)"""
+    import json, os
+    from golden_util import digest_metrics
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        rows = {n: [round(v, 6) for v in digest_metrics(g, 'g.' + n, _grad_of(net, n))] for n in names}
+        with open(os.path.join(d, 'grad_agreement.jsonl'), 'a') as f:
+            f.write(json.dumps({'variant': variant_of(g), 'H': int(g['meta_H']), 'dtype': dtype, 'cos_maxerr_l2err': rows}) + '\n')
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

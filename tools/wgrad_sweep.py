@@ -12,9 +12,10 @@ for name, n, H, W, Cin, Cout, k, s, p in SHAPES:
     x = torch.randn(n * H * W, Cin, device='cuda').bfloat16()
     dy = torch.randn(M, Cout, device='cuda').bfloat16()
     dw = torch.zeros(Cout, k * k * Cin, device='cuda')
+    ws = torch.empty(64 << 18, device='cuda')                   # 64 MiB of split-K slabs (the launcher splits less when they do not fit)
     for tile in (64, 128):
         row = []
         for sk in (0, 1, 2, 4, 8, 16, 32):
-            t = timeit(lambda: O.conv_wgrad(dy, x, dw, n, H, W, Cin, OH, OW, Cout, k, k, s, p, split_k=sk, tile=tile))
+            t = timeit(lambda: O.conv_wgrad(dy, x, dw, n, H, W, Cin, OH, OW, Cout, k, k, s, p, split_k=sk, tile=tile, ws=ws))
             row.append(t * 1e6)
         print('%-14s %-5d' % (name, tile) + ''.join('%8.1f' % v for v in row))
