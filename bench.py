@@ -134,6 +134,7 @@ class LaunchTimer(object):
         self.torch, self.on, self.recs = torch, False, []
         for c in net.convs:
             self._wrap(c)
+        net.wgq.on_launch = self.wgrad_hook
 
     def _group(self, conv, n, IH, IW):
         k = conv.wkey or (conv.group[0] if conv.group else '?')
@@ -148,48 +149,34 @@ class LaunchTimer(object):
 
     def _wrap(self, conv):
         T = self.torch
-        for kind in ('fwd', 'dgrad', 'wgrad'):
+        for kind in ('fwd', 'dgrad'):
             orig = getattr(conv, kind)
 
-            def timed(a, b, *rest, _orig=orig, _kind=kind, **kw):
+            def timed(x, n, IH, IW, *rest, _orig=orig, _kind=kind, **kw):
                 if not self.on:
-                    return _orig(a, b, *rest, **kw)
-                # fwd(x, n, IH, IW, y, ..), dgrad(g, n, IH, IW, dx, ..), wgrad(g, x, n, IH, IW)
-                n, IH, IW = (rest[0], rest[1], rest[2]) if _kind == 'wgrad' else (b, rest[0], rest[1])
+                    return _orig(x, n, IH, IW, *rest, **kw)
                 OH, OW = conv.out_hw(IH, IW)
                 flop = 2.0 * n * OH * OW * conv.Np * conv.k * conv.k * conv.Cin
-                if _kind == 'wgrad':
-                    # the launch happens inside fork_wgrad() on a weight-gradient stream: bracket it there
-                    net = conv.net
-                    ctx_orig = net.fork_wgrad
-                    evs = []
-
-                    def fork(*fa, **fk):
-                        ctx = ctx_orig(*fa, **fk)
-
-                        class _C(object):
-                            def __enter__(s):
-                                r = ctx.__enter__()
-                                e0 = T.cuda.Event(enable_timing=True); e0.record(); evs.append(e0)
-                                return r
-
-                            def __exit__(s, *a3):
-                                e1 = T.cuda.Event(enable_timing=True); e1.record(); evs.append(e1)
-                                return ctx.__exit__(*a3)
-                        return _C()
-                    net.fork_wgrad = fork
-                    try:
-                        r = _orig(a, b, *rest, **kw)
-                    finally:
-                        del net.fork_wgrad
-                    if len(evs) == 2:
-                        self.recs.append((self._group(conv, n, IH, IW), _kind, conv.k, flop, evs[0], evs[1]))
-                    return r
                 e0 = T.cuda.Event(enable_timing=True); e1 = T.cuda.Event(enable_timing=True)
-                e0.record(); r = _orig(a, b, *rest, **kw); e1.record()
+                e0.record(); r = _orig(x, n, IH, IW, *rest, **kw); e1.record()
                 self.recs.append((self._group(conv, n, IH, IW), _kind, conv.k, flop, e0, e1))
                 return r
             setattr(conv, kind, timed)
+
+    def wgrad_hook(self, tag, variant, flop, k):
+        """context around one grouped weight-gradient launch (all weight gradients of a backward stage with one tile variant)"""
+        if not self.on:
+            return None
+        T, recs = self.torch, self.recs
+
+        class _C(object):
+            def __enter__(s):
+                s.e0 = T.cuda.Event(enable_timing=True); s.e0.record()
+
+            def __exit__(s, *a):
+                e1 = T.cuda.Event(enable_timing=True); e1.record()
+                recs.append(('%s [%s]' % (tag, ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3')[variant]), 'wgrad', 3 if variant >= 2 else k, flop, s.e0, e1))
+        return _C()
 
     def summary(self, steps):
         """(per-group table, 3x3 stack, time-dominant group); times are per step, bias column sums ride with the wgrad launches"""
@@ -208,8 +195,9 @@ class LaunchTimer(object):
             ach = s3[0] / (s3[1] * 1e-3) / 1e12
             stack = {'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12),
                      'launches_per_step': s3[2] / steps, 'ms_per_step': s3[1] / steps, 'gflop_per_step': s3[0] / steps / 1e9,
-                     'note': 'every 3x3 convolution launch of the step (forward, data gradient, weight gradient; layer2/3/4 + RPN): '
-                             'summed algorithmic FLOPs / summed HIP-event time of the launches, eager multi-stream steps'}
+                     'note': 'every 3x3 convolution of the step (forward and data-gradient launches; the weight gradients as the grouped '
+                             'filter-row launches of each backward stage; layer2/3/4 + RPN): summed algorithmic FLOPs / summed HIP-event time '
+                             'of the launches, eager multi-stream steps'}
         return tab, stack, dom
 
 

@@ -72,6 +72,28 @@ typedef struct {
   size_t ws_bytes;
 } l2s_wgrad_desc;
 size_t l2s_wgrad_ws_bytes(const l2s_wgrad_desc* d, int dtype);
+
+/* Deferred, grouped weight gradients: every weight gradient of a backward stage in ONE launch (nothing needs them before the optimiser
+ * / the gradient all-reduce of that stage).  Each workgroup owns a whole output tile over all pixels: no split-K, no atomics, no partial
+ * sums, bit-reproducible, and a few thousand workgroups fill the chip where a single small layer has ~100 tiles.  A tensor that is used
+ * twice in the step (resnet.layer4 on the RoIs and on the whole map, network_cycle_res5_2.py:415-435) is one problem with two pixel
+ * segments.  All problems of a launch use the same tile variant (l2s_wgrad_variant: 0 = 64x64 tile per tap, 1 = 128x128 per tap,
+ * 2 = 64x64 x three taps of a 3x3 filter row, 3 = 128x64 x filter row); `table_dev` is the device copy of `table_host` and must stay
+ * valid until the launch has run.  dw += gradient. */
+#define L2S_WGRAD_MAX_GROUP 64
+#define L2S_WGRAD_MAX_SEG 2
+typedef struct {
+  const void* dy[L2S_WGRAD_MAX_SEG];   /* [n_img*OH*OW][lddy] (dtype) per segment */
+  const void* x[L2S_WGRAD_MAX_SEG];    /* [n_img, IH, IW, ldx] (dtype) per segment */
+  int n_img[L2S_WGRAD_MAX_SEG], IH[L2S_WGRAD_MAX_SEG], IW[L2S_WGRAD_MAX_SEG], OH[L2S_WGRAD_MAX_SEG], OW[L2S_WGRAD_MAX_SEG];
+  int lddy[L2S_WGRAD_MAX_SEG], ldx[L2S_WGRAD_MAX_SEG];
+  float* dw;                           /* [Cout][KH*KW*Cin] */
+  int nseg, Cin, Cout, KH, KW, stride, pad;
+} l2s_wgrad_prob;
+int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile);
+long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW);
+int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
+                           hipStream_t stream);
 int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
 
 /* shadow weights: dst(dtype)[Cout][taps][Cin] = scale[co] * src[Cout][taps][Cin]  (scale may be NULL) */

@@ -9,15 +9,24 @@
 // verification mode) staged global -> register ring -> LDS with rows = pixels; the bf16 MFMA fragments come out of LDS
 // through ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16 lanes, transposed by the hardware).
 //
-// Two things differ from a per-tap GEMM:
+// What shapes the design:
+//   * The layers of this network are small (a 38x63 map is 2394 pixels): one weight gradient alone has 50-150 output tiles and
+//     a pixel loop of ~75 slices, i.e. it can neither fill 256 CUs nor hide the ~2 us memory latency of its own loads, and
+//     cutting the pixels into split-K ranges pays for the parallelism with partial-sum traffic (fp32 atomics in round 1).
+//     Nothing needs a weight gradient before the optimiser, though, so the step DEFERS them: l2s_conv_wgrad_grouped runs the
+//     weight gradients of a whole backward stage (e.g. 8 bottlenecks = 24 convolutions) as ONE launch of a few thousand
+//     workgroups, each owning a full output tile over all pixels: the chip is full, several workgroups per CU hide each
+//     other's latency, there is no split-K, no atomic and no partial-sum traffic, and the result is bit-reproducible.
+//   * A tensor that is used twice in the step (layer4 on the RoIs and on the whole map, NET:415-435) is ONE problem with two
+//     pixel segments: the workgroup walks both and stores its tile once.
 //   * TX = 3 (3x3, stride 1, pad 1): a workgroup owns (co tile, ci tile, filter ROW ky) and accumulates the three taps
 //     kx = 0..2 together.  Pixels are walked in a virtual layout with one zero column appended to every image row
 //     (width OW + 1); the X image in LDS holds the slice's pixels shifted by -1 .. +32, and tap kx reads it at row offset kx:
 //     a shift that runs off a row end lands on the zero column, so no per-tap masking exists.  dY is staged once per slice
 //     instead of once per tap and X 34/32 times instead of three times: a third of the L2 -> LDS traffic per MAC.
-//   * no floating-point atomics: with split-K (pixels cut into `split` ranges so that a small-M layer still fills the chip)
-//     every workgroup stores its partial tile into its own slab of a workspace, and a second launch adds the slabs to dW in
-//     a fixed order.  The result is bit-identical from run to run.  split == 1 adds into dW directly.
+//   * l2s_conv_wgrad (one problem per launch) remains for callers outside a step; with a workspace it may split the pixels:
+//     every workgroup then stores its partial tile into its own slab and a second launch adds the slabs to dW in a fixed
+//     order (still no floating-point atomics).
 #include "common.h"
 #include "../../include/lang2seg_hip.h"
 #include <stdlib.h>
@@ -30,18 +39,12 @@ template <typename T> struct WGT;
 template <> struct WGT<bf16_t> { static constexpr int BKP = 32; static constexpr int PADB = 32; };   // row skew 8 dwords: tr reads conflict-free
 template <> struct WGT<float> { static constexpr int BKP = 16; static constexpr int PADB = 64; };
 
-struct wg_geom {
-  int Wv;            // virtual row width (OW, or OW + 1 with the zero column)
-  int Mv;            // virtual pixels
-  int sa, sb, sc;    // BKP = sa * OH * Wv + sb * Wv + sc
-  int split;         // pixel ranges
-  int cblocks;       // ci tiles
-  long slab;         // floats per slab (= Cout * KH * KW * Cin); 0: add into dW directly
-  float* ws;
-};
+typedef l2s_wgrad_prob wgp;
 
+// One output tile (co tile, ci tile, tap or filter row) of problem p over the slices [s_begin, s_end) of segment `seg`'s pixels
+// (s_end < 0: all slices of every segment).  out: where the tile goes (dW, or a split-K slab); accumulate: out += tile.
 template <typename T, int BM, int BN, int TX, int D>
-__global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p, const wg_geom g) {
+__device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int tg, int split_idx, int nsplit, float* out, bool accumulate, char* smem) {
   constexpr int ES = (int)sizeof(T);
   constexpr int VE = 16 / ES;
   constexpr int BKP = WGT<T>::BKP;
@@ -51,81 +54,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p, cons
   constexpr int VPA = BM / VE, VPB = BN / VE;            // 16-byte vectors per row
   constexpr int NVA = (BKP * VPA + 255) / 256, NVB = (RB * VPB + 255) / 256;
   constexpr int BUF = BKP * LRA + RB * LRB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int co0 = blockIdx.x * BM;
-  const int tg = blockIdx.y / g.cblocks, ci0 = (blockIdx.y - tg * g.cblocks) * BN;
   const int ky = TX == 3 ? tg : tg / p.KW, kx = TX == 3 ? 0 : tg - ky * p.KW;
-  const auto rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, 0x7FFFFFFF, 0x00020000);
-  const auto rxx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7FFFFFFF, 0x00020000);
-
-  const int nslices = (g.Mv + BKP - 1) / BKP;
-  const int per = (nslices + g.split - 1) / g.split;
-  const int s_begin = blockIdx.z * per;
-  const int s_end = min(nslices, s_begin + per);
-  const int NS = max(0, s_end - s_begin);                // (an empty range still has to write its zero slab)
-
-  // ---- loader state: every thread owns NVA vectors of dY and NVB vectors of X per slice; their (image, row, column) in the
-  // virtual layout advance by BKP pixels per slice with add / compare steps ----
-  const int ohwv = p.OH * g.Wv;
-  int an[NVA], ay[NVA], ax[NVA], ac[NVA]; bool aok[NVA];
-  int bn[NVB], by[NVB], bx[NVB], bc[NVB]; bool bok[NVB];
-  const int pb0 = s_begin * BKP;
-#pragma unroll
-  for (int j = 0; j < NVA; ++j) {
-    const int v = tid + j * 256, r = v / VPA, c = v - r * VPA;
-    aok[j] = r < BKP && (co0 + c * VE) < p.Cout;
-    ac[j] = co0 + c * VE;
-    const int pix = pb0 + min(r, BKP - 1);
-    an[j] = pix / ohwv; const int rem = pix - an[j] * ohwv; ay[j] = rem / g.Wv; ax[j] = rem - ay[j] * g.Wv;
-  }
-#pragma unroll
-  for (int j = 0; j < NVB; ++j) {
-    const int v = tid + j * 256, r = v / VPB, c = v - r * VPB;
-    bok[j] = r < RB && (ci0 + c * VE) < p.Cin;
-    bc[j] = ci0 + c * VE;
-    const int pix = pb0 + min(r, RB - 1) - (TX == 3 ? 1 : 0);       // TX == 3: image row r holds virtual pixel base - 1 + r
-    if (pix < 0) { bn[j] = 0; by[j] = 0; bx[j] = -1; }
-    else { bn[j] = pix / ohwv; const int rem = pix - bn[j] * ohwv; by[j] = rem / g.Wv; bx[j] = rem - by[j] * g.Wv; }
-  }
-  auto issue = [&](uint4 (&ra)[NVA], uint4 (&rb)[NVB]) {
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const bool ok = aok[j] && ax[j] < p.OW && an[j] < p.n_img;
-      const unsigned o = ok ? (unsigned)((((an[j] * p.OH + ay[j]) * p.OW + ax[j]) * p.lddy + ac[j]) * ES) : OOR;
-      ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o, 0, 0));
-      ax[j] += g.sc; if (ax[j] >= g.Wv) { ax[j] -= g.Wv; ++ay[j]; }
-      ay[j] += g.sb; if (ay[j] >= p.OH) { ay[j] -= p.OH; ++an[j]; }
-      an[j] += g.sa;
-    }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int iy = by[j] * p.stride - p.pad + ky;
-      const int ix = TX == 3 ? bx[j] : bx[j] * p.stride - p.pad + kx;
-      const bool ok = bok[j] && bn[j] < p.n_img && bx[j] >= 0 && bx[j] < p.OW && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-      const unsigned o = ok ? (unsigned)((((bn[j] * p.IH + iy) * p.IW + ix) * p.ldx + bc[j]) * ES) : OOR;
-      rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxx, o, 0, 0));
-      bx[j] += g.sc; if (bx[j] >= g.Wv) { bx[j] -= g.Wv; ++by[j]; }
-      by[j] += g.sb; if (by[j] >= p.OH) { by[j] -= p.OH; ++bn[j]; }
-      bn[j] += g.sa;
-    }
-  };
-  auto store_slice = [&](int buf, const uint4 (&ra)[NVA], const uint4 (&rb)[NVB]) {
-    char* a = smem + buf * BUF;
-    char* b = a + BKP * LRA;
-#pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = tid + j * 256, r = v / VPA, c = v - r * VPA;
-      if ((BKP * VPA) % 256 == 0 || r < BKP) *(uint4*)(a + r * LRA + c * 16) = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = tid + j * 256, r = v / VPB, c = v - r * VPB;
-      if ((RB * VPB) % 256 == 0 || r < RB) *(uint4*)(b + r * LRB + c * 16) = rb[j];
-    }
-  };
+  const int fr = lane & 15, fg = lane >> 4;
 
   f32x4 acc[TX][TM][TN];
 #pragma unroll
@@ -135,7 +68,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p, cons
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int fr = lane & 15, fg = lane >> 4;
   // The MFMA is issued with X as the row operand and dY as the column operand: D[row = ci][col = co], so a lane ends up
   // with 4 consecutive input channels of one output channel -> 16-byte accesses to dW[co][tap][ci .. ci+3].
   auto compute = [&](int cur) {
@@ -188,12 +120,88 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p, cons
     }
   };
 
-  // register ring: set s holds slice k with k % D == s; iteration t: barrier -> ds_write slice t+1 -> issue slice t+1+D -> MFMAs on t
-  uint4 qa[D][NVA], qb[D][NVB];
-  if (NS > 0) {
+#pragma unroll
+  for (int seg = 0; seg < L2S_WGRAD_MAX_SEG; ++seg) {    // (unrolled: the per-segment fields are read with constant indices, p stays in SGPRs)
+    if (seg >= p.nseg) break;
+    // ---- geometry of this pixel segment (uniform) ----
+    const int n_img = p.n_img[seg], IH = p.IH[seg], IW = p.IW[seg], OH = p.OH[seg], OW = p.OW[seg], lddy = p.lddy[seg], ldx = p.ldx[seg];
+    const int Wv = OW + (TX == 3 ? 1 : 0);               // virtual row width (with the zero column)
+    const int ohwv = OH * Wv;
+    const int Mv = n_img * ohwv;
+    const int sa = BKP / ohwv, sb = (BKP - sa * ohwv) / Wv, sc = BKP - sa * ohwv - sb * Wv;   // BKP = sa*OH*Wv + sb*Wv + sc
+    const int nslices = (Mv + BKP - 1) / BKP;
+    const int per = (nslices + nsplit - 1) / nsplit;
+    const int s_begin = split_idx * per;
+    const int NS = max(0, min(nslices, s_begin + per) - s_begin);
+    if (NS == 0) continue;
+    const auto rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy[seg], 0, 0x7FFFFFFF, 0x00020000);
+    const auto rxx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x[seg], 0, 0x7FFFFFFF, 0x00020000);
+
+    // ---- loader state: every thread owns NVA vectors of dY and NVB vectors of X per slice; their (image, row, column) in the
+    // virtual layout advance by BKP pixels per slice with add / compare steps ----
+    int an[NVA], ay[NVA], ax[NVA], ac[NVA]; bool aok[NVA];
+    int bn[NVB], by[NVB], bx[NVB], bc[NVB]; bool bok[NVB];
+    const int pb0 = s_begin * BKP;
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+      const int v = tid + j * 256, r = v / VPA, c = v - r * VPA;
+      aok[j] = r < BKP && (co0 + c * VE) < p.Cout;
+      ac[j] = co0 + c * VE;
+      const int pix = pb0 + min(r, BKP - 1);
+      an[j] = pix / ohwv; const int rem = pix - an[j] * ohwv; ay[j] = rem / Wv; ax[j] = rem - ay[j] * Wv;
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int v = tid + j * 256, r = v / VPB, c = v - r * VPB;
+      bok[j] = r < RB && (ci0 + c * VE) < p.Cin;
+      bc[j] = ci0 + c * VE;
+      const int pix = pb0 + min(r, RB - 1) - (TX == 3 ? 1 : 0);     // TX == 3: image row r holds virtual pixel base - 1 + r
+      if (pix < 0) { bn[j] = 0; by[j] = 0; bx[j] = -1; }
+      else { bn[j] = pix / ohwv; const int rem = pix - bn[j] * ohwv; by[j] = rem / Wv; bx[j] = rem - by[j] * Wv; }
+    }
+    auto issue = [&](uint4 (&ra)[NVA], uint4 (&rb)[NVB]) {
+#pragma unroll
+      for (int j = 0; j < NVA; ++j) {
+        const bool ok = aok[j] && ax[j] < OW && an[j] < n_img;
+        const unsigned o = ok ? (unsigned)((((an[j] * OH + ay[j]) * OW + ax[j]) * lddy + ac[j]) * ES) : OOR;
+        ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o, 0, 0));
+        ax[j] += sc; if (ax[j] >= Wv) { ax[j] -= Wv; ++ay[j]; }
+        ay[j] += sb; if (ay[j] >= OH) { ay[j] -= OH; ++an[j]; }
+        an[j] += sa;
+      }
+#pragma unroll
+      for (int j = 0; j < NVB; ++j) {
+        const int iy = by[j] * p.stride - p.pad + ky;
+        const int ix = TX == 3 ? bx[j] : bx[j] * p.stride - p.pad + kx;
+        const bool ok = bok[j] && bn[j] < n_img && bx[j] >= 0 && bx[j] < OW && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+        const unsigned o = ok ? (unsigned)((((bn[j] * IH + iy) * IW + ix) * ldx + bc[j]) * ES) : OOR;
+        rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxx, o, 0, 0));
+        bx[j] += sc; if (bx[j] >= Wv) { bx[j] -= Wv; ++by[j]; }
+        by[j] += sb; if (by[j] >= OH) { by[j] -= OH; ++bn[j]; }
+        bn[j] += sa;
+      }
+    };
+    auto store_slice = [&](int buf, const uint4 (&ra)[NVA], const uint4 (&rb)[NVB]) {
+      char* a = smem + buf * BUF;
+      char* b = a + BKP * LRA;
+#pragma unroll
+      for (int j = 0; j < NVA; ++j) {
+        const int v = tid + j * 256, r = v / VPA, c = v - r * VPA;
+        if ((BKP * VPA) % 256 == 0 || r < BKP) *(uint4*)(a + r * LRA + c * 16) = ra[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NVB; ++j) {
+        const int v = tid + j * 256, r = v / VPB, c = v - r * VPB;
+        if ((RB * VPB) % 256 == 0 || r < RB) *(uint4*)(b + r * LRB + c * 16) = rb[j];
+      }
+    };
+
+    // register ring: set s holds slice k with k % D == s; iteration t: barrier -> ds_write slice t+1 -> issue slice t+1+D -> MFMAs on t
+    uint4 qa[D][NVA], qb[D][NVB];
 #pragma unroll
     for (int s = 0; s < D; ++s)
       if (s < NS) issue(qa[s], qb[s]);
+    __syncthreads();                                     // (the previous segment's last slice may still be read)
     store_slice(0, qa[0], qb[0]);
     if (D < NS) issue(qa[0], qb[0]);
     int t0 = 0;
@@ -222,9 +230,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p, cons
       }
     }
   }
-  // ---- epilogue: partial tile -> own slab (plain stores), or dW += tile when the pixels are not split ----
+  // ---- epilogue ----
   const long Kw = (long)p.KH * p.KW * p.Cin;
-  float* out = g.slab ? g.ws + (long)blockIdx.z * g.slab : p.dw;
 #pragma unroll
   for (int t = 0; t < TX; ++t) {
     const int tap = TX == 3 ? ky * p.KW + t : tg;
@@ -237,12 +244,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const l2s_wgrad_desc p, cons
         if (co < p.Cout && ci < p.Cin) {                 // Cin % 4 == 0
           float4* q = (float4*)(out + (long)co * Kw + (long)tap * p.Cin + ci);
           float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
-          if (!g.slab) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          if (accumulate) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
           *q = v;
         }
       }
     }
   }
+}
+
+template <typename T, int BM, int BN, int TX> constexpr size_t wgrad_lds() {
+  return 2 * (size_t)(WGT<T>::BKP * (BM * sizeof(T) + WGT<T>::PADB) + (WGT<T>::BKP + TX - 1) * (BN * sizeof(T) + WGT<T>::PADB));
+}
+
+// ---- one problem per launch: grid (co tiles, taps x ci tiles, split) ----
+template <typename T, int BM, int BN, int TX, int D>
+__global__ __launch_bounds__(256) void wgrad_kernel(const wgp p, int cblocks, float* ws, long slab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tg = blockIdx.y / cblocks, ci0 = (blockIdx.y - tg * cblocks) * BN;
+  float* out = slab ? ws + (long)blockIdx.z * slab : p.dw;
+  wgrad_tile<T, BM, BN, TX, D>(p, blockIdx.x * BM, ci0, tg, blockIdx.z, gridDim.z, out, slab == 0, smem);
+}
+
+// ---- a whole backward stage per launch: problems in a device table, workgroup -> (problem, tile) through the tile prefix ----
+struct wg_prefix { int n; int tile0[L2S_WGRAD_MAX_GROUP + 1]; };
+
+template <typename T, int BM, int BN, int TX, int D>
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const wgp* __restrict__ tab, const wg_prefix pre) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = pre.n;                                // tile0[lo] <= bid < tile0[hi]
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre.tile0[mid] <= bid) lo = mid; else hi = mid; }
+  const wgp p = tab[lo];                                 // uniform: scalar loads
+  const int t = bid - pre.tile0[lo];
+  const int co_tiles = (p.Cout + BM - 1) / BM, ci_tiles = (p.Cin + BN - 1) / BN;
+  // co fastest: consecutive workgroups (dealt round-robin over the XCDs) share the X tile and the tap
+  const int cot = t % co_tiles, rest = t / co_tiles, cit = rest % ci_tiles, tg = rest / ci_tiles;
+  wgrad_tile<T, BM, BN, TX, D>(p, cot * BM, cit * BN, tg, 0, 1, p.dw, true, smem);
 }
 
 // dW[e] += slab_0[e] + slab_1[e] + ... in that order (a fixed summation tree: bit-reproducible)
@@ -259,27 +296,111 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
   }
 }
 
-struct wg_plan { int tile_m, tile_n, tx, split; };
-
-// tile / split choice.  Tiles: 3x3 stride-1 layers share the three taps of a filter row (TX = 3); the co tile is 128 wide when the
-// layer is large enough to fill the chip that way.  split: enough pixel ranges for ~2 workgroups per CU, at least 8 slices each.
-wg_plan plan_wgrad(const l2s_wgrad_desc& d, int dtype, size_t ws_bytes) {
-  const int taps = d.KH * d.KW;
-  const bool row3 = d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.OH == d.IH && d.OW == d.IW;
+// ---- variants (tile, taps per workgroup): 0 = 64x64 per tap, 1 = 128x128 per tap, 2 = 64x64 filter row, 3 = 128(co)x64 filter row ----
+int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   static const int tx_on = [] { const char* e = getenv("L2S_WGRAD_TX3"); return e ? atoi(e) : 1; }();
-  wg_plan pl;
-  pl.tx = (row3 && tx_on) ? 3 : 1;
-  const long M = (long)d.n_img * d.OH * d.OW;
-  const bool big = M >= 8192 && d.Cout >= 512 && d.Cin >= 512;
-  if (pl.tx == 3) { pl.tile_m = (d.tile == 128 || (!d.tile && big)) ? 128 : 64; pl.tile_n = 64; }
-  else { pl.tile_m = pl.tile_n = d.tile ? (d.tile == 128 ? 128 : 64) : ((big && taps == 1) ? 128 : 64); }
-  const long tiles = (long)cdiv(d.Cout, pl.tile_m) * cdiv(d.Cin, pl.tile_n) * (pl.tx == 3 ? d.KH : taps);
+  const bool row3 = tx_on && KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
+  const bool big = M >= 8192 && Cout >= 512 && Cin >= 512;
+  if (row3) return (tile == 128 || (!tile && Cout >= 512)) ? 3 : 2;
+  return (tile == 128 || (!tile && big && KH * KW == 1)) ? 1 : 0;
+}
+void variant_tile(int v, int& bm, int& bn, int& tx) {
+  bm = (v == 1 || v == 3) ? 128 : 64; bn = v == 1 ? 128 : 64; tx = v >= 2 ? 3 : 1;
+}
+long variant_tiles(int v, int Cin, int Cout, int KH, int KW) {
+  int bm, bn, tx; variant_tile(v, bm, bn, tx);
+  return (long)cdiv(Cout, bm) * cdiv(Cin, bn) * (tx == 3 ? KH : KH * KW);
+}
+
+wgp prob_of(const l2s_wgrad_desc& d) {
+  wgp p = {};
+  p.dy[0] = d.dy; p.x[0] = d.x; p.dw = d.dw;
+  p.n_img[0] = d.n_img; p.IH[0] = d.IH; p.IW[0] = d.IW; p.OH[0] = d.OH; p.OW[0] = d.OW; p.lddy[0] = d.lddy; p.ldx[0] = d.ldx;
+  p.nseg = 1; p.Cin = d.Cin; p.Cout = d.Cout; p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
+  return p;
+}
+
+template <typename T, int BM, int BN, int TX, int D>
+int launch_single(const l2s_wgrad_desc& d, int split, hipStream_t st) {
+  const wgp p = prob_of(d);
+  const int cblocks = cdiv(d.Cin, BN);
+  const long slab = split > 1 ? (long)d.Cout * d.KH * d.KW * d.Cin : 0;
+  dim3 grid(cdiv(d.Cout, BM), (TX == 3 ? d.KH : d.KH * d.KW) * cblocks, split);
+  float* ws = d.ws;
+  L2S_LAUNCH((wgrad_kernel<T, BM, BN, TX, D>), grid, dim3(256), (wgrad_lds<T, BM, BN, TX>()), st, p, cblocks, ws, slab);
+  if (split > 1) {
+    const long n4 = slab / 4;
+    long gb = (n4 + 255) / 256; if (gb > 4096) gb = 4096;
+    float* dw = d.dw; const float* wsc = d.ws;
+    L2S_LAUNCH(wgrad_reduce_kernel, dim3((int)gb), dim3(256), 0, st, dw, wsc, n4, slab, split);
+  }
+  return l2s_check_launch();
+}
+
+template <typename T, int BM, int BN, int TX, int D>
+int launch_grouped(const wgp* tab, const wg_prefix& pre, hipStream_t st) {
+  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D>), dim3(pre.tile0[pre.n]), dim3(256), (wgrad_lds<T, BM, BN, TX>()), st, tab, pre);
+  return l2s_check_launch();
+}
+
+bool prob_ok(const wgp& p, int dtype) {
+  const int ve = dtype == L2S_BF16 ? 8 : 4;
+  const long esz = dtype == L2S_BF16 ? 2 : 4;
+  if (p.nseg < 1 || p.nseg > L2S_WGRAD_MAX_SEG || p.Cin % ve || p.Cout % ve || ((long)p.Cout * p.KH * p.KW * p.Cin) % 4) return false;
+  for (int s = 0; s < p.nseg; ++s) {
+    if (p.lddy[s] % ve || p.ldx[s] % ve) return false;
+    const long M = (long)p.n_img[s] * p.OH[s] * p.OW[s];
+    if (M >= (1 << 24)) return false;
+    if ((long)p.n_img[s] * p.IH[s] * p.IW[s] * p.ldx[s] * esz >= (1L << 31) || M * p.lddy[s] * esz >= (1L << 31)) return false;   // 32-bit buffer offsets
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
+  return variant_of(Cin, Cout, KH, KW, stride, pad, same_hw, M, tile);
+}
+extern "C" long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW) { return variant_tiles(variant, Cin, Cout, KH, KW); }
+
+extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
+                                      hipStream_t stream) {
+  if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 3) return L2S_EINVAL;
+  wg_prefix pre;
+  pre.n = nprob;
+  long t = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (!prob_ok(table_host[i], dtype) || !table_host[i].dw) return L2S_EINVAL;
+    if (variant >= 2 && !(table_host[i].KH == 3 && table_host[i].KW == 3 && table_host[i].stride == 1 && table_host[i].pad == 1)) return L2S_EINVAL;
+    pre.tile0[i] = (int)t;
+    t += variant_tiles(variant, table_host[i].Cin, table_host[i].Cout, table_host[i].KH, table_host[i].KW);
+  }
+  if (t >= (1L << 30)) return L2S_EINVAL;
+  pre.tile0[nprob] = (int)t;
+  for (int i = nprob + 1; i <= L2S_WGRAD_MAX_GROUP; ++i) pre.tile0[i] = (int)t;
+  // (ring depth 2: with several workgroups per CU the other workgroups cover a load's latency; fewer registers = more of them)
+#define GO(T)                                                                                    \
+  switch (variant) {                                                                             \
+    case 0: return launch_grouped<T, 64, 64, 1, 2>(table_dev, pre, stream);                       \
+    case 1: return launch_grouped<T, 128, 128, 1, 2>(table_dev, pre, stream);                     \
+    case 2: return launch_grouped<T, 64, 64, 3, 2>(table_dev, pre, stream);                       \
+    default: return launch_grouped<T, 128, 64, 3, 2>(table_dev, pre, stream);                     \
+  }
+  if (dtype == L2S_BF16) { GO(bf16_t) }
+  if (dtype == L2S_F32) { GO(float) }
+#undef GO
+  return L2S_EINVAL;
+}
+
+static int plan_split(const l2s_wgrad_desc& d, int variant, int dtype, size_t ws_bytes) {
+  int bm, bn, tx; variant_tile(variant, bm, bn, tx);
+  const long tiles = variant_tiles(variant, d.Cin, d.Cout, d.KH, d.KW);
   const int bkp = dtype == L2S_BF16 ? 32 : 16;
-  const long Mv = (long)d.n_img * d.OH * (d.OW + (pl.tx == 3 ? 1 : 0));
+  const long Mv = (long)d.n_img * d.OH * (d.OW + (tx == 3 ? 1 : 0));
   const int slices = cdiv(Mv, bkp);
   int split = d.split_k;
   if (split <= 0) {
-    static const int min_wg = [] { const char* e = getenv("L2S_WGRAD_MINWG"); return e ? atoi(e) : 448; }();
+    static const int min_wg = [] { const char* e = getenv("L2S_WGRAD_MINWG"); return e ? atoi(e) : 256; }();
     split = (int)((min_wg + tiles - 1) / tiles);
     const int maxs = slices / 8 > 0 ? slices / 8 : 1;
     if (split > maxs) split = maxs;
@@ -287,63 +408,32 @@ wg_plan plan_wgrad(const l2s_wgrad_desc& d, int dtype, size_t ws_bytes) {
   if (split > slices) split = slices;
   if (split < 1) split = 1;
   if (split > 64) split = 64;
-  const long slab = (long)d.Cout * taps * d.Cin * 4;
+  const long slab = (long)d.Cout * d.KH * d.KW * d.Cin * 4;
   if (split > 1 && (long)split * slab > (long)ws_bytes) split = ws_bytes >= (size_t)(2 * slab) ? (int)(ws_bytes / slab) : 1;
-  pl.split = split;
-  return pl;
+  return split;
 }
-
-template <typename T, int BM, int BN, int TX, int D>
-int launch_wgrad(const l2s_wgrad_desc& d, const wg_plan& pl, hipStream_t st) {
-  constexpr int ES = (int)sizeof(T), BKP = WGT<T>::BKP, RB = BKP + TX - 1;
-  constexpr int LRA = BM * ES + WGT<T>::PADB, LRB = BN * ES + WGT<T>::PADB;
-  wg_geom g;
-  g.Wv = d.OW + (TX == 3 ? 1 : 0);
-  g.Mv = d.n_img * d.OH * g.Wv;
-  const int ohwv = d.OH * g.Wv;
-  g.sa = BKP / ohwv; g.sb = (BKP - g.sa * ohwv) / g.Wv; g.sc = BKP - g.sa * ohwv - g.sb * g.Wv;
-  g.split = pl.split;
-  g.cblocks = cdiv(d.Cin, BN);
-  g.slab = pl.split > 1 ? (long)d.Cout * d.KH * d.KW * d.Cin : 0;
-  g.ws = d.ws;
-  dim3 grid(cdiv(d.Cout, BM), (TX == 3 ? d.KH : d.KH * d.KW) * g.cblocks, pl.split);
-  const size_t lds = 2 * (size_t)(BKP * LRA + RB * LRB);
-  L2S_LAUNCH((wgrad_kernel<T, BM, BN, TX, D>), grid, dim3(256), lds, st, d, g);
-  if (pl.split > 1) {
-    const long n4 = g.slab / 4;
-    long gb = (n4 + 255) / 256; if (gb > 4096) gb = 4096;
-    float* dw = d.dw; const float* ws = d.ws; const long slab = g.slab; const int split = pl.split;
-    L2S_LAUNCH(wgrad_reduce_kernel, dim3((int)gb), dim3(256), 0, st, dw, ws, n4, slab, split);
-  }
-  return l2s_check_launch();
-}
-
-template <typename T>
-int dispatch_wgrad(const l2s_wgrad_desc& d, const wg_plan& pl, hipStream_t st) {
-  if (pl.tx == 3) return pl.tile_m == 128 ? launch_wgrad<T, 128, 64, 3, 3>(d, pl, st) : launch_wgrad<T, 64, 64, 3, 4>(d, pl, st);
-  return pl.tile_m == 128 ? launch_wgrad<T, 128, 128, 1, 3>(d, pl, st) : launch_wgrad<T, 64, 64, 1, 4>(d, pl, st);
-}
-
-}  // namespace
 
 extern "C" size_t l2s_wgrad_ws_bytes(const l2s_wgrad_desc* d, int dtype) {
   if (!d) return 0;
-  const wg_plan pl = plan_wgrad(*d, dtype, (size_t)1 << 40);
-  return pl.split > 1 ? (size_t)pl.split * d->Cout * d->KH * d->KW * d->Cin * 4 : 0;
+  const int v = variant_of(d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->OH == d->IH && d->OW == d->IW, (long)d->n_img * d->OH * d->OW, d->tile);
+  const int split = plan_split(*d, v, dtype, (size_t)1 << 40);
+  return split > 1 ? (size_t)split * d->Cout * d->KH * d->KW * d->Cin * 4 : 0;
 }
 
 extern "C" int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream) {
   if (!d || !d->dy || !d->x || !d->dw) return L2S_EINVAL;
-  const int ve = dtype == L2S_BF16 ? 8 : 4;
-  if (d->lddy % ve || d->ldx % ve || d->Cin % ve || d->Cout % ve) return L2S_EINVAL;
-  const long M = (long)d->n_img * d->OH * d->OW;
-  if (M >= (1 << 24)) return L2S_EINVAL;
-  const long esz = dtype == L2S_BF16 ? 2 : 4;
-  const long xb = (long)d->n_img * d->IH * d->IW * d->ldx * esz, yb = M * d->lddy * esz;
-  if (xb >= (1L << 31) || yb >= (1L << 31)) return L2S_EINVAL;        // 32-bit buffer offsets
-  if ((long)d->Cout * d->KH * d->KW * d->Cin % 4) return L2S_EINVAL;
-  const wg_plan pl = plan_wgrad(*d, dtype, d->ws ? d->ws_bytes : 0);
-  if (dtype == L2S_BF16) return dispatch_wgrad<bf16_t>(*d, pl, stream);
-  if (dtype == L2S_F32) return dispatch_wgrad<float>(*d, pl, stream);
+  if (!prob_ok(prob_of(*d), dtype)) return L2S_EINVAL;
+  const int v = variant_of(d->Cin, d->Cout, d->KH, d->KW, d->stride, d->pad, d->OH == d->IH && d->OW == d->IW, (long)d->n_img * d->OH * d->OW, d->tile);
+  const int split = plan_split(*d, v, dtype, d->ws ? d->ws_bytes : 0);
+#define GO(T)                                                                                    \
+  switch (v) {                                                                                   \
+    case 0: return launch_single<T, 64, 64, 1, 4>(*d, split, stream);                             \
+    case 1: return launch_single<T, 128, 128, 1, 3>(*d, split, stream);                           \
+    case 2: return launch_single<T, 64, 64, 3, 4>(*d, split, stream);                             \
+    default: return launch_single<T, 128, 64, 3, 3>(*d, split, stream);                           \
+  }
+  if (dtype == L2S_BF16) { GO(bf16_t) }
+  if (dtype == L2S_F32) { GO(float) }
+#undef GO
   return L2S_EINVAL;
 }

@@ -299,17 +299,23 @@ __global__ void atl_iou_kernel(const float* gt, int n_gt, const float* base, int
 __global__ void atl_label_kernel(const float* gt, int n_gt, const float* base, int n, int W, int A, int fs, float neg_ov, float pos_ov, int* ws) {
   AtlWs w = atl_ws(ws, n);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || w.lab[i] == -2) return;
-  float x1, y1, x2, y2; anchor_at(base, i, A, W, fs, x1, y1, x2, y2);
-  const double mo = w.maxov[i];
+  const bool live = i < n && w.lab[min(i, n - 1)] != -2;
   int l = -1;
-  if (mo < (double)neg_ov) l = 0;                               // ATL:75
-  for (int g = 0; g < n_gt; ++g)
-    if (iou64(x1, y1, x2, y2, gt + g * 5) == __longlong_as_double((long long)w.gtmax[g])) l = 1;   // ATL:70,78 (all ties)
-  if (mo >= (double)pos_ov) l = 1;                              // ATL:81
-  w.lab[i] = l;
-  if (l == 1) atomicAdd(&w.cnt[0], 1);
-  if (l == 0) atomicAdd(&w.cnt[1], 1);
+  if (live) {
+    float x1, y1, x2, y2; anchor_at(base, i, A, W, fs, x1, y1, x2, y2);
+    const double mo = w.maxov[i];
+    if (mo < (double)neg_ov) l = 0;                               // ATL:75
+    for (int g = 0; g < n_gt; ++g)
+      if (iou64(x1, y1, x2, y2, gt + g * 5) == __longlong_as_double((long long)w.gtmax[g])) l = 1;   // ATL:70,78 (all ties)
+    if (mo >= (double)pos_ov) l = 1;                              // ATL:81
+    w.lab[i] = l;
+  }
+  // one counter update per wave, not per anchor: 28 728 same-address atomics serialise at the memory side (this kernel took 157 us)
+  const unsigned long long m1 = __ballot(l == 1), m0 = __ballot(l == 0);
+  if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(1))) {
+    if (m1) atomicAdd(&w.cnt[0], __popcll(m1));
+    if (m0) atomicAdd(&w.cnt[1], __popcll(m0));
+  }
 }
 // disable the D smallest-key candidates with label == which (single workgroup, radix select on 32-bit keys)
 __device__ void select_disable(int* lab, const uint32_t* keys, int n, int which, int D, int* hist /*256*/, int* sh /*4*/) {
@@ -344,6 +350,102 @@ __device__ void select_disable(int* lab, const uint32_t* keys, int n, int which,
     __syncthreads();
   }
 }
+// On-chip variant of select_disable for n <= 31 * 1024 candidates (a 38x63 map with 12 anchors has 28 728): keys (4 B) and labels
+// (1 B) sit in LDS (<= 156 KiB), so the four radix passes and the disabling sweep never leave the CU; the looping version above
+// re-reads lab / keys from L2 in a dependent loop for every pass (28 round trips per pass on one CU: 134 us for both calls).
+__device__ __forceinline__ void select_disable_lds(signed char* lab, const uint32_t* key, int n, int which, int D, int* hist /*256*/, int* sh /*24*/) {
+  const int tid = threadIdx.x;
+  if (D <= 0) return;                                    // (uniform: D comes from the shared counters)
+  uint32_t prefix = 0, pmask = 0; int need = D;
+  for (int pass = 3; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (int i = tid; i < n; i += 1024) {
+      const uint32_t k = key[i];
+      if (lab[i] == which && (k & pmask) == prefix) atomicAdd(&hist[(k >> (8 * pass)) & 255], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // wave 0: inclusive scan of the 256 bins, 4 per lane; the bin where the running count reaches `need`
+      const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+      const int tot = c0 + c1 + c2 + c3;
+      int inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (tid >= o) inc += v; }
+      const int before = inc - tot;
+      if (before < need && inc >= need) {
+        int acc = before, b = 4 * tid;
+        if (acc + c0 < need) { acc += c0; ++b; if (acc + c1 < need) { acc += c1; ++b; if (acc + c2 < need) { acc += c2; ++b; } } }
+        sh[0] = b; sh[1] = need - acc;
+      }
+    }
+    __syncthreads();
+    prefix |= ((uint32_t)sh[0]) << (8 * pass); pmask |= 255u << (8 * pass); need = sh[1];
+    __syncthreads();
+  }
+  // disable key < prefix and the first `need` (by index) of key == prefix
+  if (tid == 0) sh[2] = 0;
+  __syncthreads();
+  int nt = 0;
+#pragma unroll 4
+  for (int i = tid; i < n; i += 1024) {
+    const uint32_t k = key[i];
+    const bool c = lab[i] == which;
+    if (c && k < prefix) lab[i] = -1;
+    nt += (c && k == prefix);
+  }
+  if (nt) atomicAdd(&sh[2], nt);
+  __syncthreads();
+  const int nties = sh[2];
+  if (nties == need) {                                   // the usual case: the threshold key occurs exactly as often as it must go
+#pragma unroll 4
+    for (int i = tid; i < n; i += 1024) if (lab[i] == which && key[i] == prefix) lab[i] = -1;
+  } else {
+    // equal keys straddle the threshold: the lowest indices go first, one chunk of 1024 at a time
+    int left = need;
+    for (int i0 = 0; i0 < n && left > 0; i0 += 1024) {   // (`left` is uniform)
+      const int i = i0 + tid;
+      const bool tie = i < n && lab[i] == which && key[i] == prefix;
+      const unsigned long long bm = __ballot(tie);
+      const int wv = tid >> 6, ln = tid & 63;
+      if (ln == 0) sh[8 + wv] = __popcll(bm);
+      __syncthreads();
+      int before = 0, total = 0;
+      for (int q = 0; q < 16; ++q) { const int c = sh[8 + q]; if (q < wv) before += c; total += c; }
+      const int rank = before + __popcll(bm & ((1ull << ln) - 1ull));
+      if (tie && rank < left) lab[i] = -1;
+      left -= total;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+}
+
+constexpr int ATL_LDS_MAX = 31 * 1024;
+__global__ __launch_bounds__(1024) void atl_sample_lds_kernel(const uint32_t* fg_keys, const uint32_t* bg_keys, int n, int npad, int batch, float fg_frac, int* ws) {
+  extern __shared__ __attribute__((aligned(16))) int lds_all[];       // [256 hist][24 misc][npad keys][npad label bytes]
+  int* hist = lds_all; int* sh = lds_all + 256; uint32_t* key = (uint32_t*)(lds_all + 256 + 24);
+  signed char* lab = (signed char*)(key + npad);
+  AtlWs w = atl_ws(ws, n);
+  const int tid = threadIdx.x;
+  const int num_fg = (int)(fg_frac * (float)batch);
+  const int nfg = w.cnt[0], nbg = w.cnt[1];
+#pragma unroll 8
+  for (int i = tid; i < n; i += 1024) { lab[i] = (signed char)w.lab[i]; key[i] = fg_keys[i]; }
+  __syncthreads();
+  select_disable_lds(lab, key, n, 1, nfg - num_fg, hist, sh);          // ATL:88-93
+  const int fg_after = min(nfg, num_fg);
+  const int num_bg = batch - fg_after;                                // ATL:96
+#pragma unroll 8
+  for (int i = tid; i < n; i += 1024) key[i] = bg_keys[i];
+  __syncthreads();
+  select_disable_lds(lab, key, n, 0, nbg - num_bg, hist, sh);         // ATL:97-101
+#pragma unroll 8
+  for (int i = tid; i < n; i += 1024) w.lab[i] = lab[i];
+  if (tid == 0) w.cnt[2] = fg_after + min(nbg, num_bg);               // num_examples = sum(labels >= 0)
+}
+
 __global__ __launch_bounds__(1024) void atl_sample_kernel(const uint32_t* fg_keys, const uint32_t* bg_keys, int n, int batch, float fg_frac, int* ws) {
   __shared__ int hist[256];
   __shared__ int sh[4];
@@ -788,7 +890,14 @@ extern "C" int l2s_anchor_target(const float* gt, int n_gt, const float* base_an
   L2S_LAUNCH(atl_init_kernel, dim3(1), dim3(128), 0, s, ws);
   L2S_LAUNCH(atl_iou_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, im_h, im_w, ws);
   L2S_LAUNCH(atl_label_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, n_gt, base_anchors, n, W, A, feat_stride, neg_ov, pos_ov, ws);
-  L2S_LAUNCH(atl_sample_kernel, dim3(1), dim3(1024), 0, s, fg_keys, bg_keys, n, batch, fg_frac, ws);
+  if (n <= ATL_LDS_MAX) {
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)atl_sample_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 24) * 4 + ATL_LDS_MAX * 5); attr_done = true; }
+    const int npad = (n + 3) / 4 * 4;
+    L2S_LAUNCH(atl_sample_lds_kernel, dim3(1), dim3(1024), (size_t)(256 + 24) * 4 + (size_t)npad * 5, s, fg_keys, bg_keys, n, npad, batch, fg_frac, ws);
+  } else {
+    L2S_LAUNCH(atl_sample_kernel, dim3(1), dim3(1024), 0, s, fg_keys, bg_keys, n, batch, fg_frac, ws);
+  }
   L2S_LAUNCH(atl_out_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, gt, base_anchors, n, H, W, A, feat_stride, (const int*)ws, labels, targets, inside_w, outside_w);
   return l2s_check_launch();
 }

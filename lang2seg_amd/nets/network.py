@@ -85,20 +85,79 @@ class ConvOp(object):
                          scatter=(IH, IW, self.stride), dt=self.net.dt)
         return dx
 
-    def wgrad(self, g, x, n, IH, IW, alt=False):
-        """weight (+bias) gradient.  Nothing downstream in the step needs it before the optimiser, so it is forked onto a
-        weight-gradient stream and overlaps with the data-gradient chain that continues on the calling stream.
-        alt: accumulate into the caption branch's own gradient buffer (Network.merge_alt_grads adds it to the main one): the
-        layer4 weights are used by the RoI pass and by the caption pass, which run concurrently, and the weight-gradient kernels
-        add without atomics (bit-reproducible), so two passes never accumulate into the same tensor at the same time."""
-        OH, OW = self.out_hw(IH, IW)
+    def wgrad(self, g, x, n, IH, IW):
+        """weight (+bias) gradient.  Nothing needs it before the optimiser (or the gradient all-reduce of its stage), so it is only
+        QUEUED here: Network.flush_wgrads launches the queued problems of a whole backward stage as one grouped launch on the
+        weight-gradient stream (csrc/conv_wgrad.hip: no split-K, no atomics, two uses of one tensor = one problem with two pixel
+        segments).  The bias gradient (a column sum) is launched right away on a weight-gradient stream."""
         if 'wgrad' in self.net.knockout:                  # experiment only (bench.py --knockout); train_net refuses it
             return
-        dw = self.w_grad_alt if alt else self.w_grad
-        with self.net.fork_wgrad(alt):
-            O.conv_wgrad(g, x, dw, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad, ws=self.net.wgrad_ws())
-            if self.bias_grad is not None:
+        OH, OW = self.out_hw(IH, IW)
+        self.net.wgq.add(self.w_grad, g, x, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.stride, self.pad)
+        if self.bias_grad is not None:
+            with self.net.fork_wgrad():
                 O.colsum(g, n * OH * OW, self.Np, self.Np, self.bias_grad)
+
+
+class WgradQueue(object):
+    """weight gradients waiting for the grouped launch of their backward stage (Network.flush_wgrads)"""
+
+    def __init__(self, net):
+        self.net, self.items, self.tables = net, [], {}
+        self.on_launch = None            # optional hook(tag, variant, flop, k) -> context manager (bench.py times the launches with it)
+
+    def add(self, dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy=None, ldx=None):
+        self.items.append((dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, Cout if lddy is None else lddy, Cin if ldx is None else ldx))
+
+    def flush(self, tag):
+        from .._lib import WgradProb, ptr, load
+        import ctypes as C
+        if not self.items:
+            return
+        lib = load()
+        net = self.net
+        items, self.items = self.items, []
+        # uses of one tensor -> pixel segments of one problem (two per problem; a third use goes to a later launch, in order)
+        by_dw = {}
+        for it in items:
+            by_dw.setdefault((it[0].data_ptr(), it[6], it[9], it[10], it[11], it[12]), []).append(it)
+        rounds = {}
+        for key, uses in by_dw.items():
+            for r in range(0, len(uses), 2):
+                seg = uses[r:r + 2]
+                dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
+                M = max(u[3] * u[7] * u[8] for u in seg)
+                same = all(u[7] == u[4] and u[8] == u[5] for u in seg)
+                v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, stride, pad, int(same), M, 0))
+                rounds.setdefault((r // 2, v), []).append(seg)
+        with net.fork_wgrad(alt=False, fixed='wg'):
+            for (rnd, v) in sorted(rounds):
+                probs = rounds[(rnd, v)]
+                for c0 in range(0, len(probs), 64):
+                    chunk = probs[c0:c0 + 64]
+                    arr = (WgradProb * len(chunk))()
+                    flop = 0.0
+                    for i, seg in enumerate(chunk):
+                        dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
+                        q = arr[i]
+                        q.dw, q.nseg, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad = dw.data_ptr(), len(seg), Cin, Cout, k, k, stride, pad
+                        for s_, u in enumerate(seg):
+                            q.dy[s_], q.x[s_] = u[1].data_ptr(), u[2].data_ptr()
+                            q.n_img[s_], q.IH[s_], q.IW[s_], q.OH[s_], q.OW[s_], q.lddy[s_], q.ldx[s_] = u[3], u[4], u[5], u[7], u[8], u[13], u[14]
+                            flop += 2.0 * u[3] * u[7] * u[8] * Cout * k * k * Cin
+                    raw = bytes(arr)
+                    ck = (tag, rnd, v, c0, getattr(net, '_rec_key', None))
+                    ent = self.tables.get(ck)
+                    if ent is None or ent[0] != raw:
+                        ent = (raw, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(net.device))
+                        self.tables[ck] = ent
+                    dt = O.dt_of(chunk[0][0][2])
+                    ctx = self.on_launch(tag, v, flop, chunk[0][0][10]) if self.on_launch is not None else None
+                    if ctx is not None:
+                        ctx.__enter__()
+                    O.call('l2s_conv_wgrad_grouped', ent[1].data_ptr(), C.cast(arr, C.c_void_p), len(chunk), v, dt, O.stream())
+                    if ctx is not None:
+                        ctx.__exit__(None, None, None)
 
 
 class Bottleneck(object):
@@ -128,20 +187,19 @@ class Bottleneck(object):
             self.c3.fwd(a2, n, OH, OW, y, add=x, relu=True)
         return y, OH, OW, (x, a1, a2, IH, IW, OH, OW, n)
 
-    def bwd(self, g, saved, tag, x_is_relu_out=True, alt=False):
-        """g = dL/d(pre-ReLU sum) (already masked by y > 0).  Returns dL/dx masked by x > 0 when x is a ReLU output.
-        alt: weight gradients go to the caption branch's gradient buffer (ConvOp.wgrad)."""
+    def bwd(self, g, saved, tag, x_is_relu_out=True):
+        """g = dL/d(pre-ReLU sum) (already masked by y > 0).  Returns dL/dx masked by x > 0 when x is a ReLU output."""
         net = self.net
         x, a1, a2, IH, IW, OH, OW, n = saved
-        self.c3.wgrad(g, a2, n, OH, OW, alt)
+        self.c3.wgrad(g, a2, n, OH, OW)
         dz2 = net.buf(tag + '.dz2', (n * OH * OW, self.planes))
         self.c3.dgrad(g, n, OH, OW, dz2, ref=a2)
-        self.c2.wgrad(dz2, a1, n, OH, OW, alt)
+        self.c2.wgrad(dz2, a1, n, OH, OW)
         dz1 = net.buf(tag + '.dz1', (n * OH * OW, self.planes))
         self.c2.dgrad(dz2, n, OH, OW, dz1, ref=a1)
-        self.c1.wgrad(dz1, x, n, IH, IW, alt)
+        self.c1.wgrad(dz1, x, n, IH, IW)
         if self.down is not None:
-            self.down.wgrad(g, x, n, IH, IW, alt)
+            self.down.wgrad(g, x, n, IH, IW)
         if not self.need_dx:
             return None
         dx = net.buf(tag + '.dx', (n * IH * IW, self.inpl))
@@ -174,6 +232,7 @@ class Network(object):
         self.parity = None          # dict of injected sampling keys / dropout masks (tests); None = production RNG
         self.dp = None              # data-parallel gradient reducer (lang2seg_amd/parallel.py)
         self._early_op = None       # optimiser taking early partial updates during backward (optim.SGD.partial)
+        self.wgq = WgradQueue(self) # weight gradients of the current backward stage, launched together by flush_wgrads()
         self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'cap'); set by bench.py --knockout
 
     # ------------------------------------------------------------------ construction
@@ -218,53 +277,30 @@ class Network(object):
         """device-side ordering edge between two streams (recorded on the launch tape when one is being recorded)."""
         O.stream_fork(from_stream, to_stream)
 
-    WGRAD_WS_BYTES = 64 << 20      # split-K slabs of one weight-gradient launch (the launcher splits less when they would not fit)
-
-    def fork_wgrad(self, alt=False):
+    def fork_wgrad(self, alt=False, fixed=None):
         """context: run the enclosed launches on a weight-gradient stream, ordered after everything already enqueued on
         the current stream (event fork); joined by join_wgrad() before the optimiser / gradient all-reduce.
-        alt (the caption branch's second use of the layer4 weights): always the second stream, so that these launches are
-        ordered among themselves."""
+        fixed: 'wg' / 'wg2' instead of alternating (the grouped weight-gradient launches all go to 'wg', in order)."""
         import contextlib
         if not self.use_streams:
-            self._wg_name = 'main'
             return contextlib.nullcontext()
         S = self.streams()
-        if alt:
-            name = 'wg2'
+        if fixed is not None:
+            name = fixed
         else:
-            self._wg_flip ^= 1                               # two weight-gradient streams, alternated: the small late-layer
-            name = 'wg2' if self._wg_flip else 'wg'          # GEMMs do not fill the chip on their own
-        self._wg_name = name
+            self._wg_flip ^= 1                               # two weight-gradient streams, alternated (small independent launches)
+            name = 'wg2' if self._wg_flip else 'wg'
         self.sfork(torch.cuda.current_stream(), S[name])
         return torch.cuda.stream(S[name])
 
-    def wgrad_ws(self):
-        """split-K workspace of the stream the current weight-gradient launch goes to (one per stream: launches on different
-        streams overlap)"""
-        name = getattr(self, '_wg_name', 'main')
-        d = self.__dict__.setdefault('_wg_ws', {})
-        if name not in d:
-            d[name] = torch.empty(self.WGRAD_WS_BYTES // 4, dtype=torch.float32, device=self.device)
-        return d[name]
-
-    def merge_alt_grads(self):
-        """grad[layer4] += the caption branch's layer4 gradients, on the first weight-gradient stream after everything both
-        weight-gradient streams hold so far (the RoI pass's and the caption pass's layer4 launches)."""
-        P = self.P
-        if getattr(P, 'grad_alt', None) is None:
-            return
-        lo, hi = P.alt_range
-        if not self.use_streams:
-            O.add_f32(P.grad[lo:hi], P.grad_alt, P.grad[lo:hi])
-            return
-        S = self.streams()
-        self.sfork(S['wg2'], S['wg'])
-        self.sfork(torch.cuda.current_stream(), S['wg'])
-        with torch.cuda.stream(S['wg']):
-            O.add_f32(P.grad[lo:hi], P.grad_alt, P.grad[lo:hi])
+    def flush_wgrads(self, tag):
+        """launch the weight gradients queued since the last flush as grouped launches (one per tile variant) on the weight-gradient
+        stream, after everything enqueued so far on the current stream.  Called at the end of every backward stage; join_wgrad()
+        flushes whatever is left, so no gradient can be missed."""
+        self.wgq.flush(tag)
 
     def join_wgrad(self):
+        self.flush_wgrads('final')
         if self.use_streams:
             self.sfork(self.streams()['wg'], torch.cuda.current_stream())
             self.sfork(self.streams()['wg2'], torch.cuda.current_stream())

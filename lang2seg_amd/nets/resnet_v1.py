@@ -65,7 +65,6 @@ class resnetv1(Network):
         self._NFP = 7 * C4 + 7 if self.var['nfilt'] == 7 else C4
         self.up_wT = O.empty((4 * 256 * 2048,), self.dt)     # ConvTranspose forward operand [(dy,dx,co)][ci]
         self.base_anchors = torch.from_numpy(ANC.base_anchors(self._anchor_scales, self._anchor_ratios)).to(self.device)
-        self._make_alt_grads()
         self.init_weights()
         P.build_segments(double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
         self.load_state_dict(self._initial_state, strict=False)
@@ -75,24 +74,6 @@ class resnetv1(Network):
         if self.var['cap'] is not None and self.opt.get('start_from') is not None:
             from ..utils.caption_ckpt import load_caption_weights
             load_caption_weights(self, self.opt, root=self.opt.get('checkpoint_root', '.'))
-
-    def _make_alt_grads(self):
-        """second accumulator for the layer4 weight gradients of the caption pass(es) (NET:415-435 runs resnet.layer4 a second time,
-        on the whole map): see ConvOp.wgrad / Network.merge_alt_grads"""
-        P = self.P
-        P.grad_alt, P.alt_range = None, None
-        if self.var['cap'] is None:
-            return
-        convs = [c for blk in self.layers[4] for c in (blk.c1, blk.c2, blk.c3, blk.down) if c is not None and c.trainable]
-        if not convs:
-            return
-        offs = [(P.offsets[c.wkey], int(np.prod(P.shapes[c.wkey]))) for c in convs]
-        lo = min(o for o, _ in offs) // 64 * 64
-        hi = (max(o + n for o, n in offs) + 63) // 64 * 64
-        P.grad_alt = torch.zeros(hi - lo, dtype=torch.float32, device=self.device)
-        P.alt_range = (lo, hi)
-        for c, (o, n) in zip(convs, offs):
-            c.w_grad_alt = P.grad_alt[o - lo:o - lo + n]
 
     def init_weights(self):
         """NET:333-355 / RES:135-141 initialisers (host RNG, once, before the first load).
@@ -380,8 +361,11 @@ class resnetv1(Network):
                 break
             for b in reversed(range(len(self.layers[li]))):
                 g = self.layers[li][b].bwd(g, saved[(li, b)], 'l%d.%d' % (li, b), x_is_relu_out=True)
-                if dp is not None and li == 3 and b in (16, 8) and len(self.layers[3]) > 16:
-                    self.dp_ready('layer3:%d' % b)             # hand the finished third of layer3 to the reducer
+                if li == 3 and b in (16, 8) and len(self.layers[3]) > 16:
+                    self.flush_wgrads('layer3:%d' % b)         # the weight gradients of the finished third of layer3, one grouped launch
+                    if dp is not None:
+                        self.dp_ready('layer3:%d' % b)         # ... and its gradients to the reducer
+            self.flush_wgrads('layer%d' % li)
             if dp is not None and li == 3:
                 self.dp_ready('layer3')                        # everything except layer2 is final (the reducer's stream waits for
                                                                # the language / weight-gradient streams itself)
@@ -478,7 +462,8 @@ class resnetv1(Network):
                        P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad))
         with self.fork_wgrad():
             O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
-            O.conv_wgrad(fc7s, dup, P.view('mask_up_sampling.weight', P.grad), FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0, ws=self.wgrad_ws())
+        # the 2x2 stride-2 transposed convolution's weight gradient = a convolution weight gradient with the roles of input and output swapped
+        self.wgq.add(P.view('mask_up_sampling.weight', P.grad), fc7s, dup, FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 0)
         dmask_fc7 = self.buf('mask.dfc7s', (FGM * PS * PS, 2048))
         O.conv_igemm(dup, P.view('mask_up_sampling.weight', P.shadow), dmask_fc7, FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 2, 0, dt=dt)
         g = self.buf('l4r.g', (R * PS * PS, 2048))
@@ -506,8 +491,6 @@ class resnetv1(Network):
         im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
         self._im_hw = (im_h, im_w)
         O.memset_zero(P.grad)
-        if getattr(P, 'grad_alt', None) is not None:
-            O.memset_zero(P.grad_alt)
         O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
         loss = self.buf('loss', (8,), f32, zero=True)
         main = torch.cuda.current_stream()
@@ -563,7 +546,7 @@ class resnetv1(Network):
         def l4_on_map_bwd(g, tag, in_relu=False):
             # in_relu: the map that was fed in is itself a ReLU output (layer3's), so its gradient is masked here
             for b in reversed(range(len(self.layers[4]))):
-                g = self.layers[4][b].bwd(g, saved[(tag, b)], '%s.%d' % (tag, b), x_is_relu_out=(b > 0 or in_relu), alt=True)
+                g = self.layers[4][b].bwd(g, saved[(tag, b)], '%s.%d' % (tag, b), x_is_relu_out=(b > 0 or in_relu))
             return g
 
         def caption_branch():
@@ -687,7 +670,9 @@ class resnetv1(Network):
             self.sfork(S['cap'], main)                     # join the caption branch
         O.total_loss(loss, self._cap_loss_weight)
         t['loss'] = loss
-        self.merge_alt_grads()                                  # layer4: RoI-pass gradients + caption-pass gradients
+        # weight gradients of the caption branch, the RoI head (layer4: RoI pass + caption pass = two pixel segments of one problem)
+        # and the RPN, as grouped launches on the weight-gradient stream
+        self.flush_wgrads('heads')
         if dp is not None:
             self.dp_ready('heads')                              # caption + layer4 + RoI/mask heads are final here
         d_nc = self.buf('dyn.dy', (HW, C4))

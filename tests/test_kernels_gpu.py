@@ -153,6 +153,58 @@ def test_conv_bwd(cfg, dt):
 
 
 @pytest.mark.parametrize('dt', [0, 1])
+def test_conv_wgrad_grouped(dt):
+    """l2s_conv_wgrad_grouped: the weight gradients of several convolutions in one launch per tile variant (what a backward stage of the
+    step issues), incl. a tensor used twice (two pixel segments of different shape, like resnet.layer4 on the RoIs and on the map);
+    against torch autograd on the same rounded operands, accumulating on top of existing content, bit-identical from run to run."""
+    import ctypes as C
+    from lang2seg_amd._lib import WgradProb, load
+    O = ops()
+    lib = load()
+    g = torch.Generator().manual_seed(5)
+    # (uses [(n, H, W)], Cin, Cout, k, stride, pad)
+    convs = [([(1, 19, 23)], 64, 128, 3, 1, 1), ([(3, 7, 7), (1, 11, 13)], 128, 64, 3, 1, 1), ([(2, 9, 9)], 256, 72, 1, 1, 0),
+             ([(40, 7, 7), (1, 10, 12)], 512, 512, 1, 1, 0), ([(1, 20, 26)], 256, 128, 1, 2, 0), ([(20, 7, 7)], 512, 512, 3, 1, 1)]
+    byv, keep = {}, []
+    for uses, Cin, Cout, k, s, p in convs:
+        dw = torch.ones((Cout, k * k * Cin), dtype=torch.float32, device=DEV)
+        ref = torch.zeros(Cout, Cin, k, k)
+        q = WgradProb()
+        q.dw, q.nseg, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad = dw.data_ptr(), len(uses), Cin, Cout, k, k, s, p
+        Mmax, same = 0, True
+        for si, (n, H, W) in enumerate(uses):
+            OH = (H + 2 * p - k) // s + 1; OW = (W + 2 * p - k) // s + 1
+            x = torch.randn(n, Cin, H, W, generator=g); dy = torch.randn(n, Cout, OH, OW, generator=g)
+            xd, dyd = to_dev(nhwc(x), dt), to_dev(nhwc(dy), dt)
+            keep += [xd, dyd]
+            w0 = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+            F.conv2d(xd.float().cpu().permute(0, 3, 1, 2), w0, None, stride=s, padding=p).backward(dyd.float().cpu().permute(0, 3, 1, 2))
+            ref += w0.grad
+            q.dy[si], q.x[si] = dyd.data_ptr(), xd.data_ptr()
+            q.n_img[si], q.IH[si], q.IW[si], q.OH[si], q.OW[si], q.lddy[si], q.ldx[si] = n, H, W, OH, OW, Cout, Cin
+            Mmax = max(Mmax, n * OH * OW); same = same and OH == H and OW == W
+        v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, s, p, int(same), Mmax, 0))
+        byv.setdefault(v, []).append((q, dw, ohwi(ref).reshape(Cout, k * k * Cin) + 1.0))
+    assert len(byv) >= 3                                        # per-tap and filter-row tiles, 64- and 128-wide
+    first = {}
+    for rep in range(2):
+        for v, lst in byv.items():
+            arr = (WgradProb * len(lst))(*[q for q, _, _ in lst])
+            if rep:
+                for _, dw, _ in lst:
+                    dw.fill_(1.0)
+            tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+            O.call('l2s_conv_wgrad_grouped', tab.data_ptr(), C.cast(arr, C.c_void_p), len(lst), v, dt, O.stream())
+            torch.cuda.synchronize()
+            for i, (_, dw, ref) in enumerate(lst):
+                assert rel_err(dw, ref) < 1e-4, (v, i)
+                if rep == 0:
+                    first[(v, i)] = dw.clone()
+                else:
+                    assert torch.equal(dw, first[(v, i)])
+
+
+@pytest.mark.parametrize('dt', [0, 1])
 def test_deconv_and_colsum(dt):
     O = ops()
     g = torch.Generator().manual_seed(3)
