@@ -79,7 +79,8 @@ size_t l2s_wgrad_ws_bytes(const l2s_wgrad_desc* d, int dtype);
  * twice in the step (resnet.layer4 on the RoIs and on the whole map, network_cycle_res5_2.py:415-435) is one problem with two pixel
  * segments.  All problems of a launch use the same tile variant (l2s_wgrad_variant: 0 = 64x64 tile per tap, 1 = 128x128 per tap,
  * 2 = 64x64 x three taps of a 3x3 filter row, 3 = 128x64 x filter row); `table_dev` is the device copy of `table_host` and must stay
- * valid until the launch has run.  dw += gradient. */
+ * valid until the launch has run.  dw += gradient.  Problems with few output tiles and many pixels (layer2: 9375 pixels, 128 channels)
+ * may still split their pixels (`split`): slabs in `ws`, no atomics either. */
 #define L2S_WGRAD_MAX_GROUP 64
 #define L2S_WGRAD_MAX_SEG 2
 typedef struct {
@@ -89,11 +90,13 @@ typedef struct {
   int lddy[L2S_WGRAD_MAX_SEG], ldx[L2S_WGRAD_MAX_SEG];
   float* dw;                           /* [Cout][KH*KW*Cin] */
   int nseg, Cin, Cout, KH, KW, stride, pad;
+  int split;                           /* <= 1: whole tiles; n: the pixels of every segment are cut into n ranges whose partial tiles go to */
+  long ws_off;                         /*       n slabs at float offset ws_off of the launch's workspace, summed in order by a second launch */
 } l2s_wgrad_prob;
 int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile);
 long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW);
 int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
-                           hipStream_t stream);
+                           float* ws, size_t ws_bytes, hipStream_t stream);
 int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
 
 /* shadow weights: dst(dtype)[Cout][taps][Cin] = scale[co] * src[Cout][taps][Cin]  (scale may be NULL) */

@@ -30,7 +30,8 @@ class WgradDesc(C.Structure):
 class WgradProb(C.Structure):
     _fields_ = [('dy', vp * 2), ('x', vp * 2), ('n_img', i32 * 2), ('IH', i32 * 2), ('IW', i32 * 2), ('OH', i32 * 2), ('OW', i32 * 2),
                 ('lddy', i32 * 2), ('ldx', i32 * 2), ('dw', vp),
-                ('nseg', i32), ('Cin', i32), ('Cout', i32), ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32)]
+                ('nseg', i32), ('Cin', i32), ('Cout', i32), ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
+                ('split', i32), ('ws_off', i64)]
 
 
 class TransposeDesc(C.Structure):
@@ -61,7 +62,7 @@ SIGS = {
     'l2s_wgrad_ws_bytes': (sz, [C.POINTER(WgradDesc), i32]),
     'l2s_wgrad_variant': (i32, [i32, i32, i32, i32, i32, i32, i32, i64, i32]),
     'l2s_wgrad_tiles': (i64, [i32, i32, i32, i32, i32]),
-    'l2s_conv_wgrad_grouped': (i32, [vp, vp, i32, i32, i32, vp]),
+    'l2s_conv_wgrad_grouped': (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),
     'l2s_weight_cast': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_weight_transpose': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_colsum': (i32, [vp, i32, i32, i32, vp, i32, vp]),

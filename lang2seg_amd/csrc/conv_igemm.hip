@@ -1025,7 +1025,10 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
       int ks = 1;
       if (tile == 64 && ring_ks != 1) {
         if (ring_ks > 1) ks = ring_ks;
-        else if (tiles64 <= 192) ks = KT >= 16 ? 4 : (KT >= 8 ? 2 : 1);   // measured: no gain once the 64x64 grid has more tiles (LDS fill bound)
+        // ring_ks == 0 (default): no in-workgroup split-K.  In isolation KS = 4 is 15 % faster on the 152-tile layer3 3x3, but its
+        // workgroups are 16 waves with 128 KiB of LDS: next to the weight-gradient launches on the other queue such a workgroup only
+        // starts once a whole CU has drained, and the step as a whole is slower (115.7 vs 123.3 img/s, round 2).  -1 = the old rule.
+        else if (ring_ks < 0 && tiles64 <= 192) ks = KT >= 16 ? 4 : (KT >= 8 ? 2 : 1);
         while (ks > 1 && (KT % ks)) ks >>= 1;
       }
       if (dtype == L2S_BF16) {

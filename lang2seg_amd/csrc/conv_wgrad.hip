@@ -269,17 +269,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const wgp p, int cblocks, fl
 struct wg_prefix { int n; int tile0[L2S_WGRAD_MAX_GROUP + 1]; };
 
 template <typename T, int BM, int BN, int TX, int D>
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const wgp* __restrict__ tab, const wg_prefix pre) {
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const wgp* __restrict__ tab, const wg_prefix pre, float* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
   int lo = 0, hi = pre.n;                                // tile0[lo] <= bid < tile0[hi]
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre.tile0[mid] <= bid) lo = mid; else hi = mid; }
   const wgp p = tab[lo];                                 // uniform: scalar loads
-  const int t = bid - pre.tile0[lo];
+  int t = bid - pre.tile0[lo];
   const int co_tiles = (p.Cout + BM - 1) / BM, ci_tiles = (p.Cin + BN - 1) / BN;
-  // co fastest: consecutive workgroups (dealt round-robin over the XCDs) share the X tile and the tap
+  const int split = p.split > 1 ? p.split : 1;
+  // split index fastest, then co: consecutive workgroups (dealt round-robin over the XCDs) share the X tile and the tap
+  const int sp = t % split; t /= split;
   const int cot = t % co_tiles, rest = t / co_tiles, cit = rest % ci_tiles, tg = rest / ci_tiles;
-  wgrad_tile<T, BM, BN, TX, D>(p, cot * BM, cit * BN, tg, 0, 1, p.dw, true, smem);
+  float* out = split > 1 ? ws + p.ws_off + (long)sp * ((long)p.Cout * p.KH * p.KW * p.Cin) : p.dw;
+  wgrad_tile<T, BM, BN, TX, D>(p, cot * BM, cit * BN, tg, sp, split, out, split == 1, smem);
+}
+
+// problems of a grouped launch whose pixels were split: dW[e] += slab_0[e] + slab_1[e] + ... (fixed order); grid (blocks, problems)
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const wgp* __restrict__ tab, const float* __restrict__ ws) {
+  const wgp p = tab[blockIdx.y];
+  if (p.split <= 1) return;
+  const long slab = (long)p.Cout * p.KH * p.KW * p.Cin, n4 = slab / 4;
+  const float* w0 = ws + p.ws_off;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+    float4 s = ((const float4*)w0)[e];
+    for (int k = 1; k < p.split; ++k) {
+      const float4 v = ((const float4*)(w0 + (long)k * slab))[e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4 o = ((float4*)p.dw)[e];
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    ((float4*)p.dw)[e] = o;
+  }
 }
 
 // dW[e] += slab_0[e] + slab_1[e] + ... in that order (a fixed summation tree: bit-reproducible)
@@ -338,8 +359,12 @@ int launch_single(const l2s_wgrad_desc& d, int split, hipStream_t st) {
 }
 
 template <typename T, int BM, int BN, int TX, int D>
-int launch_grouped(const wgp* tab, const wg_prefix& pre, hipStream_t st) {
-  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D>), dim3(pre.tile0[pre.n]), dim3(256), (wgrad_lds<T, BM, BN, TX>()), st, tab, pre);
+int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_split, hipStream_t st) {
+  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D>), dim3(pre.tile0[pre.n]), dim3(256), (wgrad_lds<T, BM, BN, TX>()), st, tab, pre, ws);
+  if (any_split) {
+    const float* wsc = ws;
+    L2S_LAUNCH(wgrad_reduce_grouped_kernel, dim3(64, pre.n), dim3(256), 0, st, tab, wsc);
+  }
   return l2s_check_launch();
 }
 
@@ -364,16 +389,24 @@ extern "C" int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, 
 extern "C" long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW) { return variant_tiles(variant, Cin, Cout, KH, KW); }
 
 extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
-                                      hipStream_t stream) {
+                                      float* ws, size_t ws_bytes, hipStream_t stream) {
   if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 3) return L2S_EINVAL;
   wg_prefix pre;
   pre.n = nprob;
   long t = 0;
+  bool any_split = false;
   for (int i = 0; i < nprob; ++i) {
-    if (!prob_ok(table_host[i], dtype) || !table_host[i].dw) return L2S_EINVAL;
-    if (variant >= 2 && !(table_host[i].KH == 3 && table_host[i].KW == 3 && table_host[i].stride == 1 && table_host[i].pad == 1)) return L2S_EINVAL;
+    const wgp& q = table_host[i];
+    if (!prob_ok(q, dtype) || !q.dw) return L2S_EINVAL;
+    if (variant >= 2 && !(q.KH == 3 && q.KW == 3 && q.stride == 1 && q.pad == 1)) return L2S_EINVAL;
+    const int split = q.split > 1 ? q.split : 1;
+    if (split > 1) {
+      const long slab = (long)q.Cout * q.KH * q.KW * q.Cin;
+      if (!ws || q.ws_off < 0 || (q.ws_off % 4) || (size_t)(q.ws_off + split * slab) * 4 > ws_bytes) return L2S_EINVAL;
+      any_split = true;
+    }
     pre.tile0[i] = (int)t;
-    t += variant_tiles(variant, table_host[i].Cin, table_host[i].Cout, table_host[i].KH, table_host[i].KW);
+    t += variant_tiles(variant, q.Cin, q.Cout, q.KH, q.KW) * split;
   }
   if (t >= (1L << 30)) return L2S_EINVAL;
   pre.tile0[nprob] = (int)t;
@@ -381,10 +414,10 @@ extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s
   // (ring depth 2: with several workgroups per CU the other workgroups cover a load's latency; fewer registers = more of them)
 #define GO(T)                                                                                    \
   switch (variant) {                                                                             \
-    case 0: return launch_grouped<T, 64, 64, 1, 2>(table_dev, pre, stream);                       \
-    case 1: return launch_grouped<T, 128, 128, 1, 2>(table_dev, pre, stream);                     \
-    case 2: return launch_grouped<T, 64, 64, 3, 2>(table_dev, pre, stream);                       \
-    default: return launch_grouped<T, 128, 64, 3, 2>(table_dev, pre, stream);                     \
+    case 0: return launch_grouped<T, 64, 64, 1, 2>(table_dev, pre, ws, any_split, stream);        \
+    case 1: return launch_grouped<T, 128, 128, 1, 2>(table_dev, pre, ws, any_split, stream);      \
+    case 2: return launch_grouped<T, 64, 64, 3, 2>(table_dev, pre, ws, any_split, stream);        \
+    default: return launch_grouped<T, 128, 64, 3, 2>(table_dev, pre, ws, any_split, stream);      \
   }
   if (dtype == L2S_BF16) { GO(bf16_t) }
   if (dtype == L2S_F32) { GO(float) }

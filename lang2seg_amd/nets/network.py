@@ -130,17 +130,32 @@ class WgradQueue(object):
                 same = all(u[7] == u[4] and u[8] == u[5] for u in seg)
                 v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, stride, pad, int(same), M, 0))
                 rounds.setdefault((r // 2, v), []).append(seg)
-        with net.fork_wgrad(alt=False, fixed='wg'):
+        bkp = 32 if net.dt == BF16 else 16
+        with net.fork_wgrad(fixed='wg'):
+            ws = net.wgrad_ws()
             for (rnd, v) in sorted(rounds):
                 probs = rounds[(rnd, v)]
                 for c0 in range(0, len(probs), 64):
                     chunk = probs[c0:c0 + 64]
+                    # few output tiles and many pixels (layer2: 128 channels, 9375 pixels): cut the pixels so that the launch still has
+                    # ~1000 workgroups, at least 16 slices each; the partial tiles go to slabs of the workspace (no atomics)
+                    tiles = [int(lib.l2s_wgrad_tiles(v, seg[0][6], seg[0][9], seg[0][10], seg[0][10])) for seg in chunk]
+                    total = sum(tiles)
+                    want = max(1, -(-self.MIN_WG // max(total, 1)))
                     arr = (WgradProb * len(chunk))()
-                    flop = 0.0
+                    flop, off = 0.0, 0
                     for i, seg in enumerate(chunk):
                         dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
                         q = arr[i]
                         q.dw, q.nseg, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad = dw.data_ptr(), len(seg), Cin, Cout, k, k, stride, pad
+                        slices = min(u[3] * u[7] * (u[8] + (1 if v >= 2 else 0)) // bkp for u in seg)
+                        split = max(1, min(want, slices // 16, 16))
+                        slab = Cout * k * k * Cin
+                        if split > 1 and (off + split * slab) * 4 <= ws.numel() * 4:
+                            q.split, q.ws_off = split, off
+                            off += split * slab
+                        else:
+                            q.split, q.ws_off = 1, 0
                         for s_, u in enumerate(seg):
                             q.dy[s_], q.x[s_] = u[1].data_ptr(), u[2].data_ptr()
                             q.n_img[s_], q.IH[s_], q.IW[s_], q.OH[s_], q.OW[s_], q.lddy[s_], q.ldx[s_] = u[3], u[4], u[5], u[7], u[8], u[13], u[14]
@@ -155,9 +170,12 @@ class WgradQueue(object):
                     ctx = self.on_launch(tag, v, flop, chunk[0][0][10]) if self.on_launch is not None else None
                     if ctx is not None:
                         ctx.__enter__()
-                    O.call('l2s_conv_wgrad_grouped', ent[1].data_ptr(), C.cast(arr, C.c_void_p), len(chunk), v, dt, O.stream())
+                    O.call('l2s_conv_wgrad_grouped', ent[1].data_ptr(), C.cast(arr, C.c_void_p), len(chunk), v, dt, ws.data_ptr(),
+                           ws.numel() * 4, O.stream())
                     if ctx is not None:
                         ctx.__exit__(None, None, None)
+
+    MIN_WG = 1024        # workgroups a grouped launch should have before its problems stop splitting their pixels
 
 
 class Bottleneck(object):
@@ -292,6 +310,15 @@ class Network(object):
             name = 'wg2' if self._wg_flip else 'wg'
         self.sfork(torch.cuda.current_stream(), S[name])
         return torch.cuda.stream(S[name])
+
+    WGRAD_WS_BYTES = 64 << 20
+
+    def wgrad_ws(self):
+        """split-K slabs of the grouped weight-gradient launches (one buffer: they all run on the 'wg' stream, in order)"""
+        ws = getattr(self, '_wg_ws', None)
+        if ws is None:
+            ws = self._wg_ws = torch.empty(self.WGRAD_WS_BYTES // 4, dtype=torch.float32, device=self.device)
+        return ws
 
     def flush_wgrads(self, tag):
         """launch the weight gradients queued since the last flush as grouped launches (one per tile variant) on the weight-gradient

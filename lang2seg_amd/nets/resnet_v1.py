@@ -699,6 +699,7 @@ class resnetv1(Network):
             self._encoder_bwd(d, dhidden)
         self._mark('dyn bwd + language bwd(lang)')
         self._backbone_bwd(dbase, saved, S, main, dp)
+        self.flush_wgrads('backbone')                           # whatever a backbone variant left queued
         self._mark('layer3-2 bwd')
         if S is not None:
             self.sfork(S['lang'], main)
