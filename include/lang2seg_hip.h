@@ -247,9 +247,11 @@ int l2s_rcnn_predict(const float* heads, int ldh, int R, int ncls, const float* 
 int l2s_mask_prob(const float* score, int ldsc, int ncls, const int* labels, int ms2, long n_elem, float* out, hipStream_t s);
 int l2s_total_loss(float* loss, float cap_w, hipStream_t s);
 /* mask_pred_net backward (only the label channel carries gradient): dx(dtype)[fg_max*ms2][C] = dscore[p]*W[label][:],
- * dW[label][:] += sum dscore[p]*x[p][:], db[label] += sum dscore[p] */
+ * dW[label][:] += sum dscore[p]*x[p][:], db[label] += sum dscore[p]; ws: fg_max*(C+1) floats of per-RoI partial sums (added in RoI
+ * order by a second launch: no atomics) */
 int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C,
-                     const float* w /*[ncls][C]*/, const void* x, const void* relu_ref, void* dx, float* dw, float* db, int dtype, hipStream_t s);
+                     const float* w /*[ncls][C]*/, const void* x, const void* relu_ref, void* dx, float* dw, float* db, float* ws, int dtype,
+                     hipStream_t s);
 
 /* ---------------------------------------------------------------- language side ------------- */
 /* small-M linear layers, fp32: y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y_in)) ; act 0 none, 1 relu, 2 tanh */
@@ -282,9 +284,11 @@ int l2s_lstm_cell_bwd(const float* dh, const float* dc_in, const float* act, con
  * y(dtype)[HW][C] = x * resp, resp float [HW], respk float [HW][7] (masked per-filter responses) */
 int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,
                       int dtype, int gate /*0: y = x*response, 1: y = x*sigmoid(response) (the *_response variants)*/, hipStream_t s);
-/* dy(dtype) -> dx(dtype), dfilt float [7][C] (+=), dr float [7] (+=); dresp_ws float [HW] */
+/* dy(dtype) -> dx(dtype), dfilt float [7][C] (+=), dr float [7] (+=); ws: l2s_dynfilter_ws_floats(H, W, C) floats (d(response) per pixel
+ * + per-pixel-chunk partial filter gradients, summed in chunk order by a third launch: no atomics) */
+long l2s_dynfilter_ws_floats(int H, int W, int C);
 int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
-                      void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype,
+                      void* dx, const void* relu_ref, float* dfilt, float* dr, float* ws, int H, int W, int C, int dtype,
                       int gate, const float* dresp_extra /*nullable [HW]: d(response loss)/d(response)*/, hipStream_t s);
 /* att2in2 attention (AttModel.py:406-423): patt [L][D], att [L][D] float; att_h [D]; alpha w[D], b.
  * out: weight [L] (softmax), att_res [D + 256] (the tail is scratch for the raw dots) */

@@ -97,7 +97,7 @@ SIGS = {
     'l2s_rcnn_loss': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, f32, vp, vp, i32, i32, vp]),
     'l2s_mask_loss': (i32, [vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     'l2s_total_loss': (i32, [vp, f32, vp]),
-    'l2s_maskpred_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_maskpred_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_linear_fwd': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_linear_bwd_x': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_linear_bwd_w': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]),
@@ -107,6 +107,7 @@ SIGS = {
     'l2s_lstm_cell_fwd': (i32, [vp, vp, vp, vp, vp, i32, vp]),
     'l2s_lstm_cell_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_dynfilter_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'l2s_dynfilter_ws_floats': (i64, [i32, i32, i32]),
     'l2s_dynfilter_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     'l2s_scale_mask': (i32, [vp, vp, vp, vp, C.c_long, i32, vp]),
     'l2s_conv3x3_c3': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -135,14 +135,23 @@ __global__ void embed_fwd_kernel(const float* table, const int64_t* ids, const f
     out[(long)t * D + d] = v;
   }
 }
+// The same token may occur more than once in an expression: the block of its FIRST occurrence adds all of them into the table row, in
+// position order (single owner per row: no atomics, bit-reproducible).
 __global__ void embed_bwd_kernel(const float* dout, const float* out, const int64_t* ids, const float* mask, float* dtable, int T, int D, int relu) {
   const int t = blockIdx.x;
-  float* row = dtable + ids[t] * (long)D;
+  const int64_t id = ids[t];
+  for (int u = 0; u < t; ++u) if (ids[u] == id) return;          // (uniform) an earlier position owns this row
+  float* row = dtable + id * (long)D;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float g = dout[(long)t * D + d];
-    if (mask) g *= mask[(long)t * D + d];
-    if (relu && out[(long)t * D + d] == 0.f) g = 0.f;   // relu killed it (or the mask did, then g is 0 already)
-    atomicAdd(row + d, g);   // the same token may occur twice in one expression
+    float acc = row[d];
+    for (int u = t; u < T; ++u) {
+      if (ids[u] != id) continue;
+      float g = dout[(long)u * D + d];
+      if (mask) g *= mask[(long)u * D + d];
+      if (relu && out[(long)u * D + d] == 0.f) g = 0.f;   // relu killed it (or the mask did, then g is 0 already)
+      acc += g;
+    }
+    row[d] = acc;
   }
 }
 
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256) void dynfilter_fwd_kernel(const void* x, const
   const float mult = gate ? sigm(rs) : rs;
   for (int c = lane; c < C; c += 64) stx(y, (long)pix * C + c, dt, ldx(x, (long)pix * C + c, dt) * mult);
 }
-// pass 1: dresp[p] = sum_c dy[p][c] x[p][c]; dr[k] += sum_p dresp[p]*respk[p][k]
+// pass 1: dresp[p] = sum_c dy[p][c] x[p][c]   (dr[k] += sum_p dresp[p]*respk[p][k] is taken by pass 3, in a fixed order)
 // (sigmoid gate: times sigma'(response); dresp_extra = gradient of the response BCE loss w.r.t. the raw response)
 __global__ __launch_bounds__(256) void dynfilter_bwd1_kernel(const void* dy, const void* x, const float* respk, float* dresp, float* dr, int HW, int C, int dt,
                                                             int gate, const float* resp, const float* dresp_extra) {
@@ -271,10 +280,9 @@ __global__ __launch_bounds__(256) void dynfilter_bwd1_kernel(const void* dy, con
   if (gate) { const float sg = sigm(resp[pix]); s *= sg * (1.f - sg); }
   if (dresp_extra) s += dresp_extra[pix];
   if (lane == 0) dresp[pix] = s;
-  if (lane < 7) atomicAdd(dr + lane, s * respk[(long)pix * 7 + lane]);
 }
-// pass 2: dx[p][c] = dy*resp + dresp[p]*sum_k r_k m_k[p] f_k[c] (ReLU-masked by relu_ref); dfilt[k][c] += sum_p dresp r_k m_k x[p][c]
-// block = 64 channels x 4 pixel lanes, grid.y over pixel chunks
+// pass 2: dx[p][c] = dy*resp + dresp[p]*sum_k r_k m_k[p] f_k[c] (ReLU-masked by relu_ref); part[chunk][k][c] = sum_{p in chunk} dresp r_k m_k x[p][c]
+// block = 64 channels x 4 pixel lanes, grid.y over pixel chunks; pass 3 adds the chunks' partial sums to dfilt in chunk order (no atomics)
 __global__ __launch_bounds__(256) void dynfilter_bwd2_kernel(const void* dy, const void* x, const float* __restrict__ filt, const float* __restrict__ r,
                                                             const float* __restrict__ resp, const float* __restrict__ dresp, void* dx, const void* ref,
                                                             float* dfilt, int H, int W, int C, int dt, int pchunk, int gate) {
@@ -304,7 +312,27 @@ __global__ __launch_bounds__(256) void dynfilter_bwd2_kernel(const void* dy, con
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       const int l = threadIdx.x;
-      atomicAdd(dfilt + k * C + c, (red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l]) * r[k]);
+      dfilt[((long)blockIdx.y * 7 + k) * C + c] = (red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l]) * r[k];
+    }
+  }
+}
+
+// pass 3: dfilt[k][c] += sum_chunk part[chunk][k][c] (chunk order); block 0 also dr[k] += sum_p dresp[p] respk[p][k] (fixed tree)
+__global__ __launch_bounds__(256) void dynfilter_bwd3_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ dresp,
+                                                            const float* __restrict__ respk, float* dfilt, float* dr, int HW, int C) {
+  __shared__ float red[4];
+  const int e = blockIdx.x * 256 + threadIdx.x;              // (k, c) flattened
+  if (e < 7 * C) {
+    float s = 0.f;
+    for (int q = 0; q < nchunk; ++q) s += part[(long)q * 7 * C + e];
+    dfilt[e] += s;
+  }
+  if (blockIdx.x == 0) {
+    for (int k = 0; k < 7; ++k) {
+      float s = 0.f;
+      for (int p = threadIdx.x; p < HW; p += 256) s = fmaf(dresp[p], respk[(long)p * 7 + k], s);
+      s = block_sum(s, red);
+      if (threadIdx.x == 0) dr[k] += s;
     }
   }
 }
@@ -567,29 +595,45 @@ __global__ __launch_bounds__(1024) void cap_att_bwd_step_kernel(const float* __r
     datt_h[d] = v;
   }
 }
-// after the loop: everything the per-step kernel left out, summed over the S steps in one launch (workgroup = one row l)
+// after the loop: everything the per-step kernel left out, summed over the S steps in one launch.  A workgroup owns 16 channels d
+// (16 location lanes x 16 channels): dpatt / datt rows are written per (l, d), the alpha_net weight gradient daw[d] is summed over all
+// locations inside the workgroup in a fixed order (no atomics); workgroup 0 also takes the bias gradient.
 __global__ __launch_bounds__(256) void cap_att_bwd_batched_kernel(const float* __restrict__ ddot, const float* __restrict__ weight, const float* __restrict__ dres,
                                                                  int ldr, const float* __restrict__ tanh_ws, const float* __restrict__ aw, int S, int L, int D,
                                                                  float* dpatt, float* datt, float* daw, float* dab) {
-  const int l = blockIdx.x, tid = threadIdx.x;
-  for (int d = tid; d < D; d += blockDim.x) {
+  __shared__ float part[16][16];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, dl = tid & 15, ll = tid >> 4;
+  const int d = blockIdx.x * 16 + dl;
+  float dwsum = 0.f;
+  if (d < D) {
     const float a = aw[d];
-    float dp = 0.f, da = 0.f, dw = 0.f;
-    for (int t = 0; t < S; ++t) {
-      const float dd = ddot[(long)t * L + l], w = weight[(long)t * L + l];
-      const float th = tanh_ws[((long)t * L + l) * D + d];
-      dp = fmaf(dd * a, 1.f - th * th, dp);
-      da = fmaf(w, dres[(long)t * ldr + d], da);
-      dw = fmaf(dd, th, dw);
+    for (int l = ll; l < L; l += 16) {
+      float dp = 0.f, da = 0.f, dw = 0.f;
+      for (int t = 0; t < S; ++t) {
+        const float dd = ddot[(long)t * L + l], w = weight[(long)t * L + l];
+        const float th = tanh_ws[((long)t * L + l) * D + d];
+        dp = fmaf(dd * a, 1.f - th * th, dp);
+        da = fmaf(w, dres[(long)t * ldr + d], da);
+        dw = fmaf(dd, th, dw);
+      }
+      dpatt[(long)l * D + d] += dp;
+      datt[(long)l * D + d] += da;
+      dwsum += dw;
     }
-    dpatt[(long)l * D + d] += dp;
-    datt[(long)l * D + d] += da;
-    atomicAdd(daw + d, dw);
   }
-  if (tid == 0) {
+  part[ll][dl] = dwsum;
+  __syncthreads();
+  if (ll == 0 && d < D) {
+    float v = 0.f;
+    for (int g = 0; g < 16; ++g) v += part[g][dl];
+    daw[d] += v;
+  }
+  if (blockIdx.x == 0) {
     float sb = 0.f;
-    for (int t = 0; t < S; ++t) sb += ddot[(long)t * L + l];
-    atomicAdd(dab, sb);
+    for (int e = tid; e < S * L; e += 256) sb += ddot[e];
+    sb = block_sum(sb, red);
+    if (tid == 0) dab[0] += sb;
   }
 }
 }  // namespace
@@ -660,13 +704,17 @@ extern "C" int l2s_dynfilter_fwd(const void* x, const float* filt, const float* 
   L2S_LAUNCH(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype, gate);
   return l2s_check_launch();
 }
+extern "C" long l2s_dynfilter_ws_floats(int H, int W, int C) { return (long)H * W + (long)cdiv(H * W, 64) * 7 * C; }
 extern "C" int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
-                                 void* dx, const void* relu_ref, float* dfilt, float* dr, float* dresp_ws, int H, int W, int C, int dtype,
+                                 void* dx, const void* relu_ref, float* dfilt, float* dr, float* ws, int H, int W, int C, int dtype,
                                  int gate, const float* dresp_extra, hipStream_t s) {
+  // ws: [H*W] d(response) followed by [chunks][7][C] partial filter gradients (l2s_dynfilter_ws_floats)
+  float* dresp_ws = ws; float* part = ws + (long)H * W;
+  const int pchunk = 64, nchunk = cdiv(H * W, pchunk);
   L2S_LAUNCH(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype, gate, resp, dresp_extra);
-  const int pchunk = 64;
-  L2S_LAUNCH(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), cdiv(H * W, pchunk)), dim3(256), 0, s, dy, x, filt, r, resp, dresp_ws, dx, relu_ref,
-                     dfilt, H, W, C, dtype, pchunk, gate);
+  L2S_LAUNCH(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, dy, x, filt, r, resp, (const float*)dresp_ws, dx, relu_ref,
+                     part, H, W, C, dtype, pchunk, gate);
+  L2S_LAUNCH(dynfilter_bwd3_kernel, dim3(cdiv(7 * C, 256)), dim3(256), 0, s, (const float*)part, nchunk, (const float*)dresp_ws, respk, dfilt, dr, H * W, C);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,
@@ -711,7 +759,7 @@ extern "C" int l2s_cap_attention_bwd_step(const float* datt_res, const float* at
 }
 extern "C" int l2s_cap_attention_bwd_batched(const float* ddot, const float* weight, const float* datt_res, int ldr, const float* tanh_ws,
                                              const float* aw, int S, int L, int D, float* dpatt, float* datt, float* daw, float* dab, hipStream_t s) {
-  L2S_LAUNCH(cap_att_bwd_batched_kernel, dim3(L), dim3(256), 0, s, ddot, weight, datt_res, ldr, tanh_ws, aw, S, L, D, dpatt, datt, daw, dab);
+  L2S_LAUNCH(cap_att_bwd_batched_kernel, dim3(cdiv(D, 16)), dim3(256), 0, s, ddot, weight, datt_res, ldr, tanh_ws, aw, S, L, D, dpatt, datt, daw, dab);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save, int R, hipStream_t s) {

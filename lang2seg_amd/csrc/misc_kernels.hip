@@ -108,17 +108,29 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const l2s
   }
 }
 
-__global__ void colsum_kernel(const void* a, int rows, int cols, int lda, float* out, int dt) {
-  // block: 64 columns x 4 row-groups
-  __shared__ float sh[4][64];
+// out[c] += sum_r a[r][c]: a workgroup owns 64 columns and walks ALL rows with 16 row lanes (coalesced 128/256-byte row pieces), then
+// adds the 16 partial sums in lane order: single owner per column, no atomics, bit-reproducible
+__global__ __launch_bounds__(1024) void colsum_kernel(const void* a, int rows, int cols, int lda, float* out, int dt) {
+  __shared__ float sh[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * 256;
   float s = 0.f;
-  if (c < cols)
-    for (int r = r0 + rg; r < min(rows, r0 + 256); r += 4) s += ldx(a, (long)r * lda + c, dt);
+  if (c < cols) {
+    int r = rg;
+    for (; r + 48 < rows; r += 64) {                     // four independent loads in flight
+      const float v0 = ldx(a, (long)r * lda + c, dt), v1 = ldx(a, (long)(r + 16) * lda + c, dt);
+      const float v2 = ldx(a, (long)(r + 32) * lda + c, dt), v3 = ldx(a, (long)(r + 48) * lda + c, dt);
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; r < rows; r += 16) s += ldx(a, (long)r * lda + c, dt);
+  }
   sh[rg][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rg == 0 && c < cols) atomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (rg == 0 && c < cols) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += sh[g][threadIdx.x];
+    out[c] += v;
+  }
 }
 
 // stem: one thread = one output pixel x 16 output channels; weights [64][7][7][3] staged in LDS as [tap*3+c][64]
@@ -461,8 +473,7 @@ extern "C" int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev,
   return l2s_check_launch();
 }
 extern "C" int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s) {
-  dim3 grid(cdiv(cols, 64), cdiv(rows, 256));
-  L2S_LAUNCH(colsum_kernel, grid, dim3(256), 0, s, a, rows, cols, lda, out, dtype);
+  L2S_LAUNCH(colsum_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, s, a, rows, cols, lda, out, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_stem_conv(const float* img, const float* w, const float* scale, const float* bias, void* y, int H, int W,

@@ -459,7 +459,7 @@ class resnetv1(Network):
         # mask head
         dup = self.buf('mask.dup', (FGM * MS * MS, 256))
         O.maskpred_bwd(dscore, labels, counts, FGM, MS * MS, 256, P.view('mask_pred_net.weight'), up, up, dup,
-                       P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad))
+                       P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad), ws=self.buf('mask.pred_ws', (FGM * 257,), f32))
         with self.fork_wgrad():
             O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
         # the 2x2 stride-2 transposed convolution's weight gradient = a convolution weight gradient with the roles of input and output swapped
@@ -682,7 +682,7 @@ class resnetv1(Network):
             O.add3(d_nc_rpn, None, d_nc_roi, d_nc)        # (dtype, -, fp32) operands
         self._mark('rpn bwd + add3')
         # dynamic filters (NET:504-562)
-        dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (HW,), f32)
+        dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (O.dynfilter_ws_floats(Hc, Wc, C4),), f32)
         O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4,
                         gate=gate, dresp_extra=dresp_extra)
         if d_base_cap is not None:

@@ -297,9 +297,11 @@ def total_loss(loss, cap_w):
     call('l2s_total_loss', ptr(loss), float(cap_w), stream())
 
 
-def maskpred_bwd(dscore, labels, num_fg, fg_max, ms2, Cc, w, x, ref, dx, dw, db):
+def maskpred_bwd(dscore, labels, num_fg, fg_max, ms2, Cc, w, x, ref, dx, dw, db, ws=None):
+    if ws is None:                                   # per-RoI partial sums (fg_max * (C + 1) floats)
+        ws = torch.empty(fg_max * (Cc + 1), dtype=torch.float32, device=dx.device)
     call('l2s_maskpred_bwd', ptr(dscore), ptr(labels), ptr(num_fg), fg_max, ms2, Cc, ptr(w), ptr(x), ptr(ref), ptr(dx),
-         ptr(dw), ptr(db), dt_of(x), stream())
+         ptr(dw), ptr(db), ptr(ws), dt_of(x), stream())
 
 
 # ------------------------------------------------------------------ language side (fp32)
@@ -359,7 +361,12 @@ def dynfilter_fwd(x, filt, r, y, resp, respk, H, W, Cc, gate=0):
     call('l2s_dynfilter_fwd', ptr(x), ptr(filt), ptr(r), ptr(y), ptr(resp), ptr(respk), H, W, Cc, dt_of(x), int(gate), stream())
 
 
+def dynfilter_ws_floats(H, W, Cc):
+    return int(_lib.load().l2s_dynfilter_ws_floats(H, W, Cc))
+
+
 def dynfilter_bwd(dy, x, filt, r, resp, respk, dx, ref, dfilt, dr, dresp_ws, H, W, Cc, gate=0, dresp_extra=None):
+    assert dresp_ws.numel() >= dynfilter_ws_floats(H, W, Cc)
     call('l2s_dynfilter_bwd', ptr(dy), ptr(x), ptr(filt), ptr(r), ptr(resp), ptr(respk), ptr(dx), ptr(ref), ptr(dfilt),
          ptr(dr), ptr(dresp_ws), H, W, Cc, dt_of(x), int(gate), ptr(dresp_extra), stream())
 

@@ -24,17 +24,21 @@ def check_digest(g, prefix, arr, rtol=1e-4, atol=1e-4):
 
 
 def digest_metrics(g, prefix, arr):
-    """(cosine, max-normalised error, relative L2 error) of `arr` against the fixture's strided sample of the same tensor"""
+    """(cosine, max-normalised error, relative L2 error, 99th-percentile error over the tensor's scale) of `arr` against the fixture's
+    strided sample of the same tensor; the tensor's scale = max(largest sample entry, mean |entry| of the whole tensor)"""
     a = np.asarray(arr, dtype=np.float64).ravel()
     assert list(g[prefix + '.shape']) == list(np.asarray(arr).shape), (prefix, g[prefix + '.shape'], np.asarray(arr).shape)
     stride = int(g[prefix + '.stride'])
     samp = g[prefix + '.sample'].astype(np.float64)
     mine = a[::stride][:samp.size]
     nrm = float(np.linalg.norm(samp))
+    mean_abs = float(g[prefix + '.abssum']) / max(1.0, float(np.prod(g[prefix + '.shape'])))
+    scale = max(float(np.abs(samp).max()), mean_abs, 1e-300)
+    p99 = float(np.percentile(np.abs(mine - samp), 99)) / scale
     if nrm == 0.0:
-        return 1.0, float(np.abs(mine).max()), float(np.linalg.norm(mine))
+        return 1.0, float(np.abs(mine).max()), float(np.linalg.norm(mine)), p99
     cos = float(mine @ samp / (np.linalg.norm(mine) * nrm + 1e-300))
-    return cos, float(np.abs(mine - samp).max() / np.abs(samp).max()), float(np.linalg.norm(mine - samp) / nrm)
+    return cos, float(np.abs(mine - samp).max() / np.abs(samp).max()), float(np.linalg.norm(mine - samp) / nrm), p99
 
 
 def variant_of(g):

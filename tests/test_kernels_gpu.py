@@ -762,7 +762,7 @@ def test_dynfilter(dt):
     assert rel_err(rs_.view(H, W), response[0, 0]) < 1e-5
     dy = to_dev(torch.randn(H * W, Cc, generator=g), dt)
     yref.backward(dy.float().cpu().view(1, H, W, Cc).permute(0, 3, 1, 2))
-    dx = O.empty((H * W, Cc), dt); dfilt = torch.zeros(7, Cc, device=DEV); dr = torch.zeros(7, device=DEV); wsd = torch.empty(H * W, device=DEV)
+    dx = O.empty((H * W, Cc), dt); dfilt = torch.zeros(7, Cc, device=DEV); dr = torch.zeros(7, device=DEV); wsd = torch.empty(O.dynfilter_ws_floats(H, W, Cc), device=DEV)
     O.dynfilter_bwd(dy, xd, filt.to(DEV), r.to(DEV), rs_, rk, dx, xd, dfilt, dr, wsd, H, W, Cc)
     torch.cuda.synchronize()
     tol = 1e-4 if dt == 0 else 2e-2
