@@ -106,8 +106,9 @@ int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Co
 /* all data-gradient copies of one step in one launch: table (DEVICE memory) of n descriptors */
 typedef struct { const float* src; const float* scale; void* dst; int Cout, taps, Cin, force_f32; } l2s_transpose_desc;
 int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int dtype, hipStream_t s);
-/* column sums: out[c] += sum_r a[r][c] (bias gradients) */
-int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s);
+/* column sums: out[c] += sum_r a[r][c] (bias gradients), no atomics; ws (nullable, 32*cols floats): partial sums of the row ranges a tall
+ * matrix is cut into, added in order by a second launch */
+int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, float* ws, long ws_floats, int dtype, hipStream_t s);
 
 /* stem: conv 7x7 s2 p3 (3->64) + frozen-BN affine + ReLU (RES:121-124), input float NHWC; then maxpool k3 s2 p1 (RES:126) */
 int l2s_stem_conv(const float* img, const float* w /*[64][7][7][3]*/, const float* scale, const float* bias,
@@ -247,8 +248,9 @@ int l2s_rcnn_predict(const float* heads, int ldh, int R, int ncls, const float* 
 int l2s_mask_prob(const float* score, int ldsc, int ncls, const int* labels, int ms2, long n_elem, float* out, hipStream_t s);
 int l2s_total_loss(float* loss, float cap_w, hipStream_t s);
 /* mask_pred_net backward (only the label channel carries gradient): dx(dtype)[fg_max*ms2][C] = dscore[p]*W[label][:],
- * dW[label][:] += sum dscore[p]*x[p][:], db[label] += sum dscore[p]; ws: fg_max*(C+1) floats of per-RoI partial sums (added in RoI
- * order by a second launch: no atomics) */
+ * dW[label][:] += sum dscore[p]*x[p][:], db[label] += sum dscore[p]; ws: l2s_maskpred_ws_floats(fg_max, C) floats of per-(RoI, pixel chunk) partial sums
+ * (added in order by a second launch: no atomics) */
+long l2s_maskpred_ws_floats(int fg_max, int C);
 int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C,
                      const float* w /*[ncls][C]*/, const void* x, const void* relu_ref, void* dx, float* dw, float* db, float* ws, int dtype,
                      hipStream_t s);

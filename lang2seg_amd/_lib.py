@@ -65,7 +65,7 @@ SIGS = {
     'l2s_conv_wgrad_grouped': (i32, [vp, vp, i32, i32, i32, vp, sz, vp]),
     'l2s_weight_cast': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_weight_transpose': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
-    'l2s_colsum': (i32, [vp, i32, i32, i32, vp, i32, vp]),
+    'l2s_colsum': (i32, [vp, i32, i32, i32, vp, vp, i64, i32, vp]),
     'l2s_weight_transpose_batched': (i32, [vp, i32, i32, vp]),
     'l2s_stem_conv': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -97,6 +97,7 @@ SIGS = {
     'l2s_rcnn_loss': (i32, [vp, i32, vp, vp, vp, vp, i32, i32, f32, vp, vp, i32, i32, vp]),
     'l2s_mask_loss': (i32, [vp, i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     'l2s_total_loss': (i32, [vp, f32, vp]),
+    'l2s_maskpred_ws_floats': (i64, [i32, i32]),
     'l2s_maskpred_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_linear_fwd': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_linear_bwd_x': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -149,20 +149,22 @@ __global__ __launch_bounds__(256) void response_loss_kernel(const float* resp, c
   if (threadIdx.x == 0) atomicAdd(loss + L2S_LOSS_RESPONSE, l * inv);
 }
 
-// grid (roi): dx[p][c] = dscore[p] * W[label][c] (ReLU-masked by x); part[roi][c] = sum_p dscore[p] x[p][c], part[roi][C] = sum_p dscore[p];
-// the second kernel adds the RoIs' partial sums into dW[label] / db[label] in RoI order (all foreground RoIs of a step usually share one
-// label: a single owner per (label, channel), no atomics, bit-reproducible)
+// grid (roi, pixel chunk): dx[p][c] = dscore[p] * W[label][c] (ReLU-masked by x); part[roi][chunk][c] = sum_{p in chunk} dscore[p] x[p][c],
+// part[roi][chunk][C] = sum_p dscore[p]; the second kernel adds the partial sums into dW[label] / db[label] in (RoI, chunk) order (all
+// foreground RoIs of a step usually share one label: a single owner per (label, channel), no atomics, bit-reproducible)
+constexpr int MPB_CHUNKS = 14;
 __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C,
                                                           const float* w, const void* x, const void* ref, void* dx, float* part, int dt) {
-  __shared__ float red[4];
   const int s = blockIdx.x;
+  const int pc = (ms2 + gridDim.y - 1) / gridDim.y, p0 = blockIdx.y * pc, p1 = min(ms2, p0 + pc);
   const int nfg = min(*num_fg, fg_max);
   const bool valid = s < nfg;
   const int lab = valid ? labels[s] : 0;
+  float* po = part + ((long)s * gridDim.y + blockIdx.y) * (C + 1);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float wv = w[(long)lab * C + c];
     float acc = 0.f;
-    for (int p = 0; p < ms2; ++p) {
+    for (int p = p0; p < p1; ++p) {
       const long o = ((long)s * ms2 + p) * C + c;
       const float d = valid ? dscore[s * ms2 + p] : 0.f;
       const float xv = ldx(x, o, dt);
@@ -171,18 +173,21 @@ __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, 
       if (ref && !(ldx(ref, o, dt) > 0.f)) g = 0.f;
       stx(dx, o, dt, g);
     }
-    part[(long)s * (C + 1) + c] = acc;
+    po[c] = acc;
   }
-  float sb = 0.f;
-  if (valid) for (int p = threadIdx.x; p < ms2; p += blockDim.x) sb += dscore[s * ms2 + p];
-  sb = block_sum(sb, red);
-  if (threadIdx.x == 0) part[(long)s * (C + 1) + C] = sb;
+  if (threadIdx.x == 0) {
+    float sb = 0.f;
+    if (valid) for (int p = p0; p < p1; ++p) sb += dscore[s * ms2 + p];
+    po[C] = sb;
+  }
 }
-__global__ __launch_bounds__(256) void maskpred_bwd_reduce_kernel(const float* part, const int* labels, const int* num_fg, int fg_max, int C, float* dw, float* db) {
+__global__ __launch_bounds__(256) void maskpred_bwd_reduce_kernel(const float* part, const int* labels, const int* num_fg, int fg_max, int C, int chunks,
+                                                                 float* dw, float* db) {
   const int nfg = min(*num_fg, fg_max);
-  for (int c = threadIdx.x; c <= C; c += blockDim.x)
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= C; c += gridDim.x * blockDim.x)
     for (int s = 0; s < nfg; ++s) {
-      const float v = part[(long)s * (C + 1) + c];
+      float v = 0.f;
+      for (int q = 0; q < chunks; ++q) v += part[((long)s * chunks + q) * (C + 1) + c];
       if (c < C) dw[(long)labels[s] * C + c] += v; else db[labels[s]] += v;
     }
 }
@@ -247,11 +252,12 @@ extern "C" int l2s_total_loss(float* loss, float cap_w, hipStream_t s) {
   L2S_LAUNCH(total_loss_kernel, dim3(1), dim3(1), 0, s, loss, cap_w);
   return l2s_check_launch();
 }
+extern "C" long l2s_maskpred_ws_floats(int fg_max, int C) { return (long)fg_max * MPB_CHUNKS * (C + 1); }
 extern "C" int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C, const float* w,
                                 const void* x, const void* relu_ref, void* dx, float* dw, float* db, float* ws, int dtype, hipStream_t s) {
-  if (!ws) return L2S_EINVAL;                            // fg_max * (C + 1) floats
-  L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, ws, dtype);
-  L2S_LAUNCH(maskpred_bwd_reduce_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, labels, num_fg, fg_max, C, dw, db);
+  if (!ws) return L2S_EINVAL;                            // l2s_maskpred_ws_floats(fg_max, C) floats
+  L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max, MPB_CHUNKS), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, ws, dtype);
+  L2S_LAUNCH(maskpred_bwd_reduce_kernel, dim3(cdiv(C + 1, 256)), dim3(256), 0, s, (const float*)ws, labels, num_fg, fg_max, C, MPB_CHUNKS, dw, db);
   return l2s_check_launch();
 }
 extern "C" int l2s_rcnn_predict(const float* heads, int ldh, int R, int ncls, const float* stds4, const float* means4, float* cls_prob,

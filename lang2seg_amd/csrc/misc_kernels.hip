@@ -108,20 +108,22 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const l2s
   }
 }
 
-// out[c] += sum_r a[r][c]: a workgroup owns 64 columns and walks ALL rows with 16 row lanes (coalesced 128/256-byte row pieces), then
-// adds the 16 partial sums in lane order: single owner per column, no atomics, bit-reproducible
-__global__ __launch_bounds__(1024) void colsum_kernel(const void* a, int rows, int cols, int lda, float* out, int dt) {
+// Column sums (bias gradients), no atomics: a workgroup owns 64 columns and a range of rows, walked with 16 row lanes (coalesced
+// 128/256-byte row pieces); the 16 partial sums are added in lane order.  One row range: out[c] += sum directly.  Tall matrices
+// (12 544 x 256 for the mask head) are cut into row ranges whose partial sums go to part[range][cols]; colsum_finish adds them in order.
+__global__ __launch_bounds__(1024) void colsum_kernel(const void* a, int rows, int cols, int lda, float* out, float* part, int rows_per, int dt) {
   __shared__ float sh[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
   float s = 0.f;
   if (c < cols) {
-    int r = rg;
-    for (; r + 48 < rows; r += 64) {                     // four independent loads in flight
+    int r = r0 + rg;
+    for (; r + 48 < r1; r += 64) {                       // four independent loads in flight
       const float v0 = ldx(a, (long)r * lda + c, dt), v1 = ldx(a, (long)(r + 16) * lda + c, dt);
       const float v2 = ldx(a, (long)(r + 32) * lda + c, dt), v3 = ldx(a, (long)(r + 48) * lda + c, dt);
       s += (v0 + v1) + (v2 + v3);
     }
-    for (; r < rows; r += 16) s += ldx(a, (long)r * lda + c, dt);
+    for (; r < r1; r += 16) s += ldx(a, (long)r * lda + c, dt);
   }
   sh[rg][threadIdx.x & 63] = s;
   __syncthreads();
@@ -129,8 +131,15 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const void* a, int rows, i
     float v = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) v += sh[g][threadIdx.x];
-    out[c] += v;
+    if (part) part[(long)blockIdx.y * cols + c] = v; else out[c] += v;
   }
+}
+__global__ void colsum_finish_kernel(const float* part, int nr, int cols, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float v = 0.f;
+  for (int q = 0; q < nr; ++q) v += part[(long)q * cols + c];
+  out[c] += v;
 }
 
 // stem: one thread = one output pixel x 16 output channels; weights [64][7][7][3] staged in LDS as [tap*3+c][64]
@@ -472,8 +481,14 @@ extern "C" int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev,
   L2S_LAUNCH(weight_transpose_batched_kernel, dim3(48, n), dim3(256), 0, s, table_dev, dtype);
   return l2s_check_launch();
 }
-extern "C" int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, int dtype, hipStream_t s) {
-  L2S_LAUNCH(colsum_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, s, a, rows, cols, lda, out, dtype);
+extern "C" int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, float* ws, long ws_floats, int dtype, hipStream_t s) {
+  int nr = (rows + 511) / 512;                           // row ranges of >= 512 rows
+  if (nr > 32) nr = 32;
+  if (!ws || ws_floats < (long)nr * cols) nr = 1;
+  const int rows_per = (rows + nr - 1) / nr;
+  float* part = nr > 1 ? ws : nullptr;
+  L2S_LAUNCH(colsum_kernel, dim3(cdiv(cols, 64), nr), dim3(1024), 0, s, a, rows, cols, lda, out, part, rows_per, dtype);
+  if (nr > 1) L2S_LAUNCH(colsum_finish_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, (const float*)ws, nr, cols, out);
   return l2s_check_launch();
 }
 extern "C" int l2s_stem_conv(const float* img, const float* w, const float* scale, const float* bias, void* y, int H, int W,

@@ -96,7 +96,7 @@ class ConvOp(object):
         self.net.wgq.add(self.w_grad, g, x, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.stride, self.pad)
         if self.bias_grad is not None:
             with self.net.fork_wgrad():
-                O.colsum(g, n * OH * OW, self.Np, self.Np, self.bias_grad)
+                O.colsum(g, n * OH * OW, self.Np, self.Np, self.bias_grad, ws=self.net.buf('colsum.ws.' + str(self.bias_key or self.group[1]), (32 * self.Np,), torch.float32))
 
 
 class WgradQueue(object):

@@ -459,9 +459,9 @@ class resnetv1(Network):
         # mask head
         dup = self.buf('mask.dup', (FGM * MS * MS, 256))
         O.maskpred_bwd(dscore, labels, counts, FGM, MS * MS, 256, P.view('mask_pred_net.weight'), up, up, dup,
-                       P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad), ws=self.buf('mask.pred_ws', (FGM * 257,), f32))
+                       P.view('mask_pred_net.weight', P.grad), P.view('mask_pred_net.bias', P.grad), ws=self.buf('mask.pred_ws', (FGM * 14 * 257,), f32))
         with self.fork_wgrad():
-            O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad))
+            O.colsum(dup, FGM * MS * MS, 256, 256, P.view('mask_up_sampling.bias', P.grad), ws=self.buf('mask.up_bias_ws', (32 * 256,), f32))
         # the 2x2 stride-2 transposed convolution's weight gradient = a convolution weight gradient with the roles of input and output swapped
         self.wgq.add(P.view('mask_up_sampling.weight', P.grad), fc7s, dup, FGM, MS, MS, 256, PS, PS, 2048, 2, 2, 0)
         dmask_fc7 = self.buf('mask.dfc7s', (FGM * PS * PS, 2048))

@@ -144,8 +144,9 @@ def weight_transpose_batched(table_dev, n, dt):
     call('l2s_weight_transpose_batched', ptr(table_dev), n, dt, stream())
 
 
-def colsum(a, rows, cols, lda, out):
-    call('l2s_colsum', ptr(a), rows, cols, lda, ptr(out), dt_of(a), stream())
+def colsum(a, rows, cols, lda, out, ws=None):
+    """out[c] += sum_r a[r][c].  ws (32 * cols floats, one per concurrent call site): tall matrices are summed in row ranges."""
+    call('l2s_colsum', ptr(a), rows, cols, lda, ptr(out), ptr(ws), 0 if ws is None else ws.numel(), dt_of(a), stream())
 
 
 def stem_conv(img, w, scale, bias, y, H, W, OH, OW):
@@ -298,8 +299,8 @@ def total_loss(loss, cap_w):
 
 
 def maskpred_bwd(dscore, labels, num_fg, fg_max, ms2, Cc, w, x, ref, dx, dw, db, ws=None):
-    if ws is None:                                   # per-RoI partial sums (fg_max * (C + 1) floats)
-        ws = torch.empty(fg_max * (Cc + 1), dtype=torch.float32, device=dx.device)
+    if ws is None:                                   # per-(RoI, pixel chunk) partial sums
+        ws = torch.empty(int(_lib.load().l2s_maskpred_ws_floats(fg_max, Cc)), dtype=torch.float32, device=dx.device)
     call('l2s_maskpred_bwd', ptr(dscore), ptr(labels), ptr(num_fg), fg_max, ms2, Cc, ptr(w), ptr(x), ptr(ref), ptr(dx),
          ptr(dw), ptr(db), ptr(ws), dt_of(x), stream())
 

@@ -29,11 +29,12 @@ def _setup(dtype, tag='tiny'):
 
 # Tolerances.  f32 ("verification mode", exact-f32 MFMA): north_star's 1e-4 on losses and seg-logits, integer outputs bit-exact.
 # bf16 (the benchmarked mode: bf16 activations / weight shadows, fp32 accumulation, fp32 master weights): losses within 1e-2
-# relative; every checked gradient tensor has cosine >= 0.99 and 99 % of its sampled entries within 0.1 of the tensor's scale of the
-# reference's fp32 gradient (measured on the MI355X, profiles/r02_bf16_grad_agreement.jsonl: full size cosine >= 0.9983, the tiny
-# fixtures with head_gain 4 >= 0.9944 on the deepest tensor, resnet.layer2.0.conv1.weight, 27 blocks of bf16 activations away from
-# the losses); integer outputs still bit-exact (they depend on the boxes, not on the activations, once the proposals are teacher-forced).
-BF16_LOSS_RTOL, BF16_COS, BF16_P99 = 1e-2, 0.99, 0.1
+# relative; EVERY trainable tensor's gradient has cosine >= 0.99 with, and a norm within 5 % of, the f32 step's gradient of the same
+# inputs on the device (which the f32 leg pins to the reference at 5e-4): measured cosine >= 0.994 on the tiny fixtures (head_gain 4;
+# the deepest tensor, resnet.layer2.0.conv1.weight, is 27 blocks of bf16 activations away from the losses) and >= 0.998 at full size
+# (profiles/r02_bf16_grad_agreement.jsonl); integer outputs still bit-exact (they depend on the boxes, not on the activations, once the
+# proposals are teacher-forced).
+BF16_LOSS_RTOL, BF16_COS, BF16_NORM = 1e-2, 0.99, 0.05
 VARIANT_TAGS = ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align']
 
 
@@ -46,45 +47,59 @@ def _grad_of(net, nme):
     return gr.cpu().numpy()
 
 
-def _check_grads(g, net, dtype, rtol_f32):
-    """gradients of the fixture's tensors (reference layout): f32 -> digest within rtol + relative L2 error (which, unlike the
-    max-normalised digest, weighs the small entries too); bf16 -> cosine / max-normalised error table"""
+def _check_grads(g, net, dtype, rtol_f32, ref_net=None):
+    """f32: gradients of the fixture's tensors (reference layout) against the reference run: digest within rtol + relative L2 error (which,
+    unlike the max-normalised digest, weighs the small entries too).
+    bf16: EVERY trainable tensor, whole, against the f32 step of the same inputs on the device (`ref_net`, itself pinned to the reference by
+    the f32 leg): cosine and norm ratio.  (The fixtures hold strided samples; a sample that happens to sit on small entries of a
+    heavy-tailed tensor measures bf16's noise floor, not the tensor.)"""
     from golden_util import digest_metrics
     names = sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')})
-    bad = []
-    for nme in names:
-        gr = _grad_of(net, nme)
-        cos, emax, el2, p99 = digest_metrics(g, 'g.' + nme, gr)
-        if dtype == 'f32':
+    bad, table = [], {}
+    if dtype == 'f32':
+        for nme in names:
+            gr = _grad_of(net, nme)
+            cos, emax, el2, p99 = digest_metrics(g, 'g.' + nme, gr)
+            table[nme] = [round(cos, 6), round(emax, 6), round(el2, 6)]
             check_digest(g, 'g.' + nme, gr, rtol=rtol_f32, atol=1e-7)
             if not (el2 <= 4 * rtol_f32 and cos >= 1 - 1e-5):
                 bad.append((nme, cos, emax, el2))
-        else:
-            # bf16: 99 % of the sampled entries within BF16_P99 of the tensor's scale (single entries can move more: a ReLU gate next to
-            # zero flips under bf16 rounding and adds / removes one pixel's contribution), and the direction agrees unless the sample holds
-            # only entries far below the tensor's mean magnitude (column 0 of layer4.2.conv3.weight at full size: a near-dead input channel)
-            numel = float(np.prod(g['g.' + nme + '.shape']))
-            mean_abs = float(g['g.' + nme + '.abssum']) / numel
-            smax = float(np.abs(g['g.' + nme + '.sample']).max())
-            if not (p99 <= BF16_P99 and (cos >= BF16_COS or smax < 0.5 * mean_abs)):
-                bad.append((nme, cos, emax, el2, p99))
-    _log_grad_table(g, net, dtype, names)
+    else:
+        P, Pr = net.P, ref_net.P
+        gmax = max(float(Pr.view(k, Pr.grad).double().norm()) for k in Pr.trainable)
+        for k in P.trainable:
+            a, b = Pr.view(k, Pr.grad).double(), P.view(k, P.grad).double()
+            na, nb = float(a.norm()), float(b.norm())
+            if na <= 1e-7 * gmax:                      # e.g. alpha_net.bias: softmax is shift-invariant, its gradient is rounding noise
+                continue
+            cos = float((a * b).sum() / (na * nb + 1e-300))
+            table[k] = [round(cos, 6), round(nb / na, 6)]
+            if not (cos >= BF16_COS and abs(nb / na - 1.0) <= BF16_NORM):
+                bad.append((k, cos, nb / na))
+    _log_grad_table(g, dtype, table)
     assert not bad, bad
     return names
 
 
-def _log_grad_table(g, net, dtype, names):
+def _log_grad_table(g, dtype, table):
     """append the per-tensor gradient agreement of this run to gpurun_out/grad_agreement.jsonl (evidence for the stated tolerances)"""
     import json, os
-    from golden_util import digest_metrics
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     try:
         os.makedirs(d, exist_ok=True)
-        rows = {n: [round(v, 6) for v in digest_metrics(g, 'g.' + n, _grad_of(net, n))[:3]] for n in names}
         with open(os.path.join(d, 'grad_agreement.jsonl'), 'a') as f:
-            f.write(json.dumps({'variant': variant_of(g), 'H': int(g['meta_H']), 'dtype': dtype, 'cos_maxerr_l2err': rows}) + '\n')
+            f.write(json.dumps({'variant': variant_of(g), 'H': int(g['meta_H']), 'dtype': dtype,
+                                ('cos_maxerr_l2err_vs_reference_sample' if dtype == 'f32' else 'cos_normratio_vs_f32_device'): table}) + '\n')
     except OSError:
         pass
+
+
+def _f32_reference_step(tag):
+    """the f32 step of the same fixture inputs on the device (gradients left in net.P.grad)"""
+    g, opt, sd, blob, ocfg, samp, net = _setup('f32', tag)
+    net.forward_backward(net.upload_blob(blob, 0))
+    torch.cuda.synchronize()
+    return net
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
@@ -147,7 +162,7 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
         check_digest(g, 't.mask_score', ms, rtol=atol, atol=atol)
     # gradients (reference layout) and post-SGD weights vs the fixture
     # (the VGG trunk's gradients cross 9 un-normalised 3x3 convolutions and two max-pools: 1e-3 like the full-size test)
-    names = _check_grads(g, net, dtype, 1e-3 if tag == 'tiny_vgg' else 5e-4)
+    names = _check_grads(g, net, dtype, 1e-3 if tag == 'tiny_vgg' else 5e-4, ref_net=None if f32 else _f32_reference_step(tag))
     SGD(net, 1e-4).step()
     torch.cuda.synchronize()
     sd1 = net.state_dict()
@@ -197,7 +212,7 @@ def test_train_step_full_size(dtype):
     ms = t['mask_score'].cpu().numpy().reshape(-1, 14, 14, 81)[:nfg].transpose(0, 3, 1, 2)
     check_digest(g, 't.mask_score', ms, rtol=atol, atol=atol)
     assert np.abs(heads[:, :8] - g['x.cls_score']).max() <= atol * max(1.0, float(np.abs(g['x.cls_score']).max()))
-    _check_grads(g, net, dtype, 1e-3)
+    _check_grads(g, net, dtype, 1e-3, ref_net=None if f32 else _f32_reference_step('full'))
 
 
 def test_gradients_are_bit_reproducible():

@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
-from golden_util import load, setup_from_fixture
+from golden_util import load, setup_from_fixture, variant_of
 from lang2seg_amd import selftest
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'full'
@@ -15,7 +15,7 @@ samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
 over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
 grads = {}
 for dt in ('f32', 'bf16'):
-    net = selftest.build_net(opt, over, dt, sd)
+    net = selftest.build_net(opt, over, dt, sd, variant=variant_of(g))
     net.parity = selftest.parity_from_samp(samp)
     net.forward_backward(net.upload_blob(blob, 0))
     torch.cuda.synchronize()
