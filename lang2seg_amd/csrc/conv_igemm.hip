@@ -1037,11 +1037,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
         if (tile == 128) return GR(bf16_t, 128, 128, 2, 1);
         if (ks == 4) return GR(bf16_t, 64, 64, 3, 4);
         if (ks == 2) return GR(bf16_t, 64, 64, 3, 2);
-        // ring depth of the 64x64 tile: these launches have ~150 workgroups of 36 K slices each, one per CU, and are bound by the latency of
-        // their own loads (depth 4 = 64 KiB in flight per CU); a wave alone on its SIMD may use up to 512 registers, so the ring can be deeper
-        static const int d64 = [] { const char* e = getenv("L2S_IGEMM_D64"); return e ? atoi(e) : 4; }();
-        if (d64 >= 12) return GR(bf16_t, 64, 64, 12, 1);
-        if (d64 >= 8) return GR(bf16_t, 64, 64, 8, 1);
+        // (ring depth 4 = 64 KiB in flight per workgroup; depths 8 and 12 were measured slower, round 2: 129 / 119 vs 136 img/s)
         return GR(bf16_t, 64, 64, 4, 1);
       }
       if (dtype == L2S_F32) {
