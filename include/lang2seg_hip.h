@@ -182,10 +182,12 @@ int l2s_anchor_target(const float* gt, int n_gt, const float* base_anchors, int 
 /* proposal_target_layer.py:22-204 on device (torch-0.3 ByteTensor semantics at :146).
  * rois [n_max][5], n_rois device int; gt [n_gt][5]; gt_masks uint8 [n_gt][im_h][im_w].
  * outputs: out_rois [R][5], labels int32 [R], bbox_targets/inside/outside [R][4*ncls], mask_targets float
- * [fg_max][ms*ms], counts int32[4] = {num_fg, n_fg_cand, n_bg_cand, appended_gt}.  ws: int32 [4*(n_max+n_gt)+16]. */
+ * [mask_slots][ms*ms], counts int32[4] = {num_fg (capped at mask_slots), n_fg_cand, n_bg_cand, appended_gt}.  ws: int32 [4*(n_max+n_gt)+16].
+ * fg_max = round(FG_FRACTION * R) caps the sampled foreground when background candidates exist; without any (PTL:155-158) all R sampled
+ * RoIs are foreground, and the mask targets cover the first mask_slots (fg_max <= mask_slots <= R) of them. */
 int l2s_proposal_target(const float* rois, const float* roi_scores, const int* n_rois, int n_max, const float* gt, int n_gt,
                         const uint8_t* gt_masks, int im_h, int im_w, const uint32_t* fg_keys, const uint32_t* bg_keys,
-                        const uint32_t* bg_rand, int R, int fg_max, float fg_thresh, float bg_hi, float bg_lo,
+                        const uint32_t* bg_rand, int R, int fg_max, int mask_slots, float fg_thresh, float bg_hi, float bg_lo,
                         const float* means4, const float* stds4, const float* inw4, int ncls, int ms,
                         float* out_rois, int* labels, float* bbox_targets, float* bbox_inside, float* bbox_outside,
                         float* mask_targets, int* counts, int* ws, hipStream_t s);

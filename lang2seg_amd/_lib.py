@@ -88,7 +88,7 @@ SIGS = {
     'l2s_random_keys': (i32, [vp, i64, vp, u64, vp]),
     'l2s_anchor_target_ws_ints': (i64, [i32]),
     'l2s_anchor_target': (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, f32, f32, i32, f32, vp, vp, vp, vp, vp, vp]),
-    'l2s_proposal_target': (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, i32, i32, f32, f32, f32,
+    'l2s_proposal_target': (i32, [vp, vp, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, f32, f32,
                                   vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'l2s_roialign_fwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, i32, vp]),
     'l2s_roialign_bwd': (i32, [vp, i32, i32, i32, vp, i32, i32, f32, vp, i32, vp]),

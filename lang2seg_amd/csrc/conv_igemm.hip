@@ -1038,6 +1038,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
         if (ks == 4) return GR(bf16_t, 64, 64, 3, 4);
         if (ks == 2) return GR(bf16_t, 64, 64, 3, 2);
         // (ring depth 4 = 64 KiB in flight per workgroup; depths 8 and 12 were measured slower, round 2: 129 / 119 vs 136 img/s)
+        // and so was the software-pipelined (three LDS buffers) form of this tile: 132-133 img/s
         return GR(bf16_t, 64, 64, 4, 1);
       }
       if (dtype == L2S_F32) {

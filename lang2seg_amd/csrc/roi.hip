@@ -532,7 +532,7 @@ __device__ __forceinline__ float iou32(const float* b, const float* q) {   // ut
 __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const float* scores_in, const int* n_rois, int n_max,
                                                    const float* gt, int n_gt, const uint8_t* gt_masks, int im_h, int im_w,
                                                    const uint32_t* fg_keys, const uint32_t* bg_keys, const uint32_t* bg_rand,
-                                                   int R, int fg_max, float fg_thresh, float bg_hi, float bg_lo,
+                                                   int R, int fg_max, int mask_slots, float fg_thresh, float bg_hi, float bg_lo,
                                                    const float* means4, const float* stds4, const float* inw4, int ncls, int ms,
                                                    float* out_rois, int* labels, float* bt, float* bi, float* bo, float* mt,
                                                    int* counts, int* ws) {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
     else for (int s = tid; s < nbg_sel; s += nt) slot[nfg_sel + s] = bg_list[bg_rand[s] % (uint32_t)n_bg];
   }
   __syncthreads();
-  if (tid == 0) { counts[0] = min(nfg_sel, fg_max); counts[1] = n_fg; counts[2] = n_bg; counts[3] = appended; }
+  if (tid == 0) { counts[0] = min(nfg_sel, mask_slots); counts[1] = n_fg; counts[2] = n_bg; counts[3] = appended; }
   // outputs
   const int W4 = 4 * ncls;          // bt / bi / bo arrive zeroed (l2s_proposal_target)
   for (int s = tid; s < R; s += nt) {
@@ -661,12 +661,12 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
   }
   // mask targets (PTL:193-201): crop gt mask to the roi, PIL-NEAREST resize to ms x ms.  The per-RoI crop geometry goes through
   // LDS first, so that an element costs one global load (issued four at a time) instead of a chain of four dependent ones.
-  const int nm = min(nfg_sel, fg_max);
-  int* s_geo = (int*)s_ki;                               // [fg_max][6]: x1, y1, cw, ch, gt index, valid   (the sort buffer is free now)
+  const int nm = min(nfg_sel, mask_slots);
+  int* s_geo = (int*)s_ki;                               // [mask_slots][6]: x1, y1, cw, ch, gt index, valid   (the sort buffer is free now)
   __syncthreads();
-  for (int s = tid; s < fg_max; s += nt) {
+  for (int s = tid; s < mask_slots; s += nt) {
     int x1 = 0, y1 = 0, cw = 0, ch = 0, ga = 0, ok = 0;
-    if (s < nm && slot[s] >= 0 && fg_max * 6 <= 8192) {
+    if (s < nm && slot[s] >= 0 && mask_slots * 6 <= 8192) {
       const int i = slot[s];
       float b[4]; roi_ptr(i, b);
       x1 = (int)b[0]; y1 = (int)b[1];
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
     g6[0] = x1; g6[1] = y1; g6[2] = cw; g6[3] = ch; g6[4] = ga; g6[5] = ok;
   }
   __syncthreads();
-  const int ms2 = ms * ms, total = fg_max * ms2;
+  const int ms2 = ms * ms, total = mask_slots * ms2;
   for (int e0 = tid; e0 < total; e0 += 4 * nt) {
     long addr[4]; bool val[4];
 #pragma unroll
@@ -903,17 +903,17 @@ extern "C" int l2s_anchor_target(const float* gt, int n_gt, const float* base_an
 }
 extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, const int* n_rois, int n_max, const float* gt, int n_gt,
                                    const uint8_t* gt_masks, int im_h, int im_w, const uint32_t* fg_keys, const uint32_t* bg_keys,
-                                   const uint32_t* bg_rand, int R, int fg_max, float fg_thresh, float bg_hi, float bg_lo,
+                                   const uint32_t* bg_rand, int R, int fg_max, int mask_slots, float fg_thresh, float bg_hi, float bg_lo,
                                    const float* means4, const float* stds4, const float* inw4, int ncls, int ms,
                                    float* out_rois, int* labels, float* bbox_targets, float* bbox_inside, float* bbox_outside,
                                    float* mask_targets, int* counts, int* ws, hipStream_t s) {
-  if (n_gt < 1 || R < 1) return L2S_EINVAL;
+  if (n_gt < 1 || R < 1 || mask_slots < 1 || mask_slots > R || mask_slots * 6 > 8192) return L2S_EINVAL;
   // the three [R][4 ncls] target arrays are sparse (4 floats per foreground row): cleared by the copy engine / fill kernel
   // instead of 730 stores per thread of the single-workgroup kernel
   const size_t tb = (size_t)R * 4 * ncls * sizeof(float);
   if (l2s_memset_async(bbox_targets, 0, tb, s) || l2s_memset_async(bbox_inside, 0, tb, s) || l2s_memset_async(bbox_outside, 0, tb, s)) return L2S_ELAUNCH;
   L2S_LAUNCH(ptl_kernel, dim3(1), dim3(1024), 0, s, rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w,
-                     fg_keys, bg_keys, bg_rand, R, fg_max, fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms,
+                     fg_keys, bg_keys, bg_rand, R, fg_max, mask_slots, fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms,
                      out_rois, labels, bbox_targets, bbox_inside, bbox_outside, mask_targets, counts, ws);
   return l2s_check_launch();
 }

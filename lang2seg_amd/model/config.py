@@ -47,6 +47,10 @@ __C.TRAIN.MAX_SIZE = 1000
 __C.TRAIN.IMS_PER_BATCH = 1
 __C.TRAIN.BATCH_SIZE = 256
 __C.TRAIN.FG_FRACTION = 0.25
+# (this implementation) size the mask head for BATCH_SIZE RoIs instead of FG_FRACTION * BATCH_SIZE: exact in the no-background case of
+# proposal_target_layer.py:155-158 (all sampled RoIs foreground) at 4x the mask-head work; off, that case trains the mask branch on the
+# first FG_FRACTION * BATCH_SIZE foreground RoIs only
+__C.TRAIN.MASK_SLOTS_ALL = False
 __C.TRAIN.FG_THRESH = 0.5
 __C.TRAIN.BG_THRESH_HI = 0.5
 __C.TRAIN.BG_THRESH_LO = 0.0

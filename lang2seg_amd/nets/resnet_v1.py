@@ -484,7 +484,10 @@ class resnetv1(Network):
         self.t = t = {}
         TR = cfg.TRAIN
         A, nc = self._num_anchors, self._num_classes
-        R = int(TR.BATCH_SIZE); FGM = int(round(TR.FG_FRACTION * R))
+        R = int(TR.BATCH_SIZE); FGS = int(round(TR.FG_FRACTION * R))       # FGS: foreground RoIs sampled when background candidates exist
+        # FGM: RoI slots the mask head runs on.  Normally FGS; TRAIN.MASK_SLOTS_ALL sizes it for the no-background case of
+        # proposal_target_layer.py:155-158, where all R sampled RoIs are foreground (4x the mask-head work for a case real data never hits)
+        FGM = R if getattr(TR, 'MASK_SLOTS_ALL', False) else FGS
         PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
         C4 = self._C4_feat_dim
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
@@ -634,7 +637,7 @@ class resnetv1(Network):
         pws = self.buf('ptl.ws', (4 * (post + n_gt) + R + 16,), torch.int32)
         cst = self._consts()
         O.proposal_target(rois_all, rsc_all, nkeep, post, d['gt_boxes'], n_gt, d['gt_masks'], H, W, self._keys('roi_fg_keys', post + n_gt),
-                          self._keys('roi_bg_keys', post + n_gt), self._keys('roi_bg_rand', R), R, FGM, TR.FG_THRESH, TR.BG_THRESH_HI,
+                          self._keys('roi_bg_keys', post + n_gt), self._keys('roi_bg_rand', R), R, FGS, FGM, TR.FG_THRESH, TR.BG_THRESH_HI,
                           TR.BG_THRESH_LO, cst['means'], cst['stds'], cst['inw'], nc, MS, rois, labels, bt, bi, bo, mt, counts, pws)
         t.update({'rois': rois, 'labels': labels, 'bbox_targets': bt, 'bbox_inside': bi, 'bbox_outside': bo, 'mask_targets': mt, 'counts': counts})
         self._mark('targets')

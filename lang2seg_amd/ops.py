@@ -256,10 +256,10 @@ def anchor_target(gt, n_gt, base_anchors, H, W, A, fs, im_h, im_w, fg_keys, bg_k
          ptr(outw), ptr(ws), stream())
 
 
-def proposal_target(rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w, fg_keys, bg_keys, bg_rand, R, fg_max,
+def proposal_target(rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w, fg_keys, bg_keys, bg_rand, R, fg_max, mask_slots,
                     fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms, out_rois, labels, bt, bi, bo, mt, counts, ws):
     call('l2s_proposal_target', ptr(rois), ptr(roi_scores), ptr(n_rois), n_max, ptr(gt), n_gt, ptr(gt_masks), im_h, im_w,
-         ptr(fg_keys), ptr(bg_keys), ptr(bg_rand), R, fg_max, float(fg_thresh), float(bg_hi), float(bg_lo), ptr(means4),
+         ptr(fg_keys), ptr(bg_keys), ptr(bg_rand), R, fg_max, mask_slots, float(fg_thresh), float(bg_hi), float(bg_lo), ptr(means4),
          ptr(stds4), ptr(inw4), ncls, ms, ptr(out_rois), ptr(labels), ptr(bt), ptr(bi), ptr(bo), ptr(mt), ptr(counts),
          ptr(ws), stream())
 

@@ -487,7 +487,7 @@ def test_anchor_target(seed):
     assert np.abs(o_.cpu().numpy() - outw.reshape(H * W, -1)).max() < 1e-8
 
 
-@pytest.mark.parametrize('case', ['normal', 'few_bg', 'no_fg'])
+@pytest.mark.parametrize('case', ['normal', 'few_bg', 'no_fg', 'only_fg', 'only_fg_few'])
 def test_proposal_target(case):
     O = ops()
     rs = np.random.RandomState(11)
@@ -497,7 +497,13 @@ def test_proposal_target(case):
     gm = ((((xx - 200) / 100.) ** 2 + ((yy - 170) / 90.) ** 2) <= 1).astype(np.uint8)[None]
     n_max, n = 300, 240
     b = rs.uniform(0, 300, (n, 4)).astype(np.float32); b[:, 2:] = np.minimum(b[:, :2] + rs.uniform(20, 200, (n, 2)), [im_w - 1, im_h - 1])
-    if case != 'no_fg':
+    if case.startswith('only_fg'):
+        # proposal_target_layer.py:155-158: every candidate overlaps the gt box by >= 0.5 -> all R sampled RoIs are foreground
+        # (without replacement from 240 candidates; with replacement when there are fewer than R)
+        b = (gt[0, :4] + rs.normal(0, 6, (n, 4))).astype(np.float32); b = np.clip(b, 0, [im_w - 1, im_h - 1, im_w - 1, im_h - 1]).astype(np.float32)
+        if case == 'only_fg_few':
+            n = 20
+    elif case != 'no_fg':
         b[:40] = gt[0, :4] + rs.normal(0, 12, (40, 4)); b[:40] = np.clip(b[:40], 0, [im_w - 1, im_h - 1, im_w - 1, im_h - 1])
     else:
         b[:, 0] = np.minimum(b[:, 0], 60); b[:, 2] = np.minimum(b[:, 2], 90)
@@ -510,19 +516,22 @@ def test_proposal_target(case):
     ct = dict(ON.DEFAULT_CFG['TRAIN']); ct['BATCH_SIZE'] = 32
     ref = OB.proposal_target_layer(rois[:n], sc[:n], gt, gm, 81, ct, 14, fgk[:n], bgk[:n], None, bgr)
     R, fg_max = 32, 8
+    slots = R if case.startswith('only_fg') else fg_max          # mask-target slots (TRAIN.MASK_SLOTS_ALL sizes them for the no-background case)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     out_rois = torch.empty(R, 5, device=DEV); labels = torch.empty(R, dtype=torch.int32, device=DEV)
     bt = torch.empty(R, 324, device=DEV); bi = torch.empty_like(bt); bo = torch.empty_like(bt)
-    mt = torch.empty(fg_max, 196, device=DEV); counts = torch.zeros(4, dtype=torch.int32, device=DEV)
+    mt = torch.empty(slots, 196, device=DEV); counts = torch.zeros(4, dtype=torch.int32, device=DEV)
     ws = torch.empty(4 * (n_max + 1) + R + 16, dtype=torch.int32, device=DEV)
     O.proposal_target(d(rois), d(sc), d(np.array([n], np.int32)), n_max, d(gt), 1, d(gm), im_h, im_w, d(fgk.view(np.int32)),
-                      d(bgk.view(np.int32)), d(bgr.view(np.int32)), R, fg_max, 0.5, 0.5, 0.0, d(np.zeros(4, np.float32)),
+                      d(bgk.view(np.int32)), d(bgr.view(np.int32)), R, fg_max, slots, 0.5, 0.5, 0.0, d(np.zeros(4, np.float32)),
                       d(np.array([.1, .1, .2, .2], np.float32)), d(np.ones(4, np.float32)), 81, 14, out_rois, labels, bt, bi, bo, mt,
                       counts, ws)
     torch.cuda.synchronize()
     r_rois, _, r_lab, r_bt, r_bi, r_bo, r_mt, _ = ref
     nfg = int(counts[0].item())
     assert nfg == r_mt.shape[0]
+    if case.startswith('only_fg'):
+        assert nfg == R and int(counts[2].item()) == 0 and (r_lab > 0).all()
     assert np.array_equal(out_rois.cpu().numpy(), r_rois)
     assert np.array_equal(labels.cpu().numpy(), r_lab.reshape(-1).astype(np.int32))
     assert np.abs(bt.cpu().numpy() - r_bt).max() < 1e-4

@@ -501,6 +501,48 @@ def test_edge_cases_vs_oracle(kind):
     assert np.isfinite(net.P.grad.float().abs().sum().item())
 
 
+def test_only_foreground_rois_through_the_step():
+    """proposal_target_layer.py:155-158: no background candidate at all -> all R sampled RoIs are foreground and the mask branch runs on
+    every one of them (NET:584-586).  TRAIN.MASK_SLOTS_ALL sizes the mask head for that; the whole step (losses, integer targets)
+    against the oracle on proposals that all hug the gt box."""
+    import copy
+    from lang2seg_amd import selftest
+    from lang2seg_amd.model.config import cfg
+    from oracle import weights as OW, net as ON, synth as OS
+    blob = OS.make_blob(160, 224, 5, 60, seed=31)
+    H, W = 160, 224
+    blob['gt_boxes'][0, :4] = [40, 30, 180, 130]
+    blob['gt_masks'][:] = 0; blob['gt_masks'][0, 30:131, 40:181] = 1
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=16, RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=100, RPN_BATCHSIZE=64)
+    ocfg = copy.deepcopy(ON.DEFAULT_CFG); ocfg['TRAIN'].update(over)
+    rs = np.random.RandomState(2)
+    nA = 10 * 14 * 12
+    props = np.zeros((40, 5), np.float32)
+    props[:, 1:] = np.clip(blob['gt_boxes'][0, :4] + rs.normal(0, 4, (40, 4)), 0, [W - 1, H - 1, W - 1, H - 1])
+    samp = dict(rpn_fg_keys=rs.permutation(nA).astype(np.uint32), rpn_bg_keys=rs.permutation(nA).astype(np.uint32),
+                roi_fg_keys=rs.permutation(100).astype(np.uint32), roi_bg_keys=rs.permutation(100).astype(np.uint32),
+                forced_proposals=(props, np.linspace(0.9, 0.5, 40).astype(np.float32)))
+    cfg.TRAIN.MASK_SLOTS_ALL = True
+    try:
+        net = selftest.build_net(opt, over, 'f32', sd)
+        net.parity = selftest.parity_from_samp(samp)
+        lv = net.forward_backward(net.upload_blob(blob, 0)).cpu().numpy()
+        torch.cuda.synchronize()
+    finally:
+        cfg.TRAIN.MASK_SLOTS_ALL = False
+    assert int(net.t['counts'][0].item()) == 16 and int(net.t['counts'][2].item()) == 0          # 16 foreground RoIs, no background candidate
+    onet = ON.OracleNet(sd, opt, ocfg)
+    T, L = onet.forward_train(blob, samp)
+    for i, k in enumerate(NAMES):
+        ref = float(L[k])
+        assert np.isfinite(lv[i]) and abs(lv[i] - ref) < 1e-3 * max(1.0, abs(ref)), (k, lv[i], ref)
+    assert np.array_equal(net.t['labels'].cpu().numpy().astype(np.int64), np.asarray(T['labels']).reshape(-1).astype(np.int64))
+    assert (net.t['labels'].cpu().numpy() > 0).all()
+    assert np.array_equal(net.t['mask_targets'].cpu().numpy().reshape(16, 14, 14), np.asarray(T['mask_targets']).reshape(16, 14, 14))
+
+
 def test_tape_over_mixed_shapes_matches_eager():
     """real data feeds a different image size / token count almost every step: the launch tape records a new shape while it executes
     it (no extra step), replays the ones it has seen, and evicts the least recently used tape together with its activation plan.
