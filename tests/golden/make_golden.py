@@ -513,6 +513,133 @@ def run_leaf_eval():
     print('leaf_eval done', rec.shape, int(rec.sum()))
 
 
+class _Labels(object):
+    """the loader hands eval_split a torch-0.3 Variable of token ids; the loop only slices it and evaluates
+    `(label != 0).sum().data[0]` (test.py:236), which has no equivalent on 0-dim tensors of a current torch: same idiom, numpy inside"""
+
+    def __init__(self, a):
+        self.a = np.asarray(a)
+        self.shape = self.a.shape
+
+    def __getitem__(self, k):
+        return _Labels(self.a[k])
+
+    def __ne__(self, v):
+        return _Labels(self.a != v)
+
+    def sum(self):
+        class _S(object):
+            pass
+        r = _S(); r.data = [int(self.a.sum())]
+        return r
+
+
+def eval_blobs(seed0=41, n_img=2, n_sent=2, H=160, W=224, T=6, V=60):
+    """the synthetic evaluation set of ref_eval_split.npz: n_img images with n_sent referred objects / expressions each"""
+    out = []
+    for i in range(n_img):
+        bl = [OS.make_blob(H, W, T, V, seed=seed0 + 10 * i + j) for j in range(n_sent)]
+        lab = np.zeros((n_sent, T), np.int64)
+        for j, b in enumerate(bl):
+            n = T - (i + j) % 3                     # ragged lengths: zero padding at the end of a row
+            lab[j, :n] = b['labels'][0, :n]
+        gtb = np.concatenate([b['gt_boxes'] for b in bl]); gtm = np.concatenate([b['gt_masks'] for b in bl])
+        # the referred objects sit where this untrained network's best anchors fall (right edge of the image), with different overlaps:
+        # the fixture is about the accumulation of box accuracy / intersection / union, which needs non-empty intersections
+        for j in range(n_sent):
+            x1, y1, x2, y2 = [(188, 90, 223, 159), (150, 60, 223, 159), (196, 100, 223, 150), (120, 0, 223, 70)][(2 * i + j) % 4]
+            gtb[j, :4] = [x1, y1, x2, y2]
+            gtm[j] = 0; gtm[j, y1 + (j % 2) * 8:y2 + 1, x1 + 4 * i:x2 + 1] = 1
+        out.append(dict(data=bl[0]['data'], im_info=bl[0]['im_info'], gt_boxes=gtb, gt_masks=gtm, labels=lab, file_name='synthetic_%d.jpg' % i))
+    return out
+
+
+def eval_state_dict(opt):
+    """weights of the eval_split fixture: the usual random set with both box-regression heads zeroed, so that the predicted box is the
+    chosen anchor itself (untrained regressors throw every box to the image border and all intersections are empty)"""
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    for k in ('bbox_pred_net', 'rpn_bbox_pred_net'):          # RoIs = anchors, predicted boxes = RoIs
+        sd[k + '.weight'] = np.zeros_like(sd[k + '.weight'])
+        sd[k + '.bias'] = np.zeros_like(sd[k + '.bias'])
+    return sd
+
+
+def run_eval_split():
+    """the reference's evaluation loop itself (model/test.py:185-450 eval_split, :97-129 im_detect, mask_utils.recover_masks, NET:595-626)
+    on a tiny synthetic split: box accuracy, precision@X counts, cumulative intersection / union.  Only Network.test_image is replaced by
+    the harness's bypass of forward() (as in run_reference_test); everything else runs as it is."""
+    import importlib
+    from model.config import cfg
+    import model.test as MT
+    from oracle.net import DEFAULT_CFG
+    sys.modules['cv2'].resize = None
+    H, W, T, V = 160, 224, 6, 60
+    opt = OW.default_opt(vocab_size=V, seq_length=T)
+    sd = eval_state_dict(opt)
+    for k, v in DEFAULT_CFG['TEST'].items():
+        setattr(cfg.TEST, k, v)
+    cfg.TEST.MODE = 'nms'
+    cfg.ANCHOR_SCALES = list(DEFAULT_CFG['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(DEFAULT_CFG['ANCHOR_RATIOS'])
+    RESM = importlib.import_module('nets.' + OW.VARIANTS['cycle']['module'])
+    torch.manual_seed(0)
+    net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
+    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    ref_sd = net.state_dict()
+    for k, v in sd.items():
+        ref_sd[k].copy_(torch.from_numpy(v))
+    net.eval()
+
+    def test_image(blobs):                      # NET:671-699 with forward() bypassed (NET:632-662, mode TEST)
+        net._image = torch.from_numpy(np.ascontiguousarray(blobs['data'].transpose([0, 3, 1, 2])))
+        net._im_info = blobs['im_info']
+        net._gt_boxes = torch.from_numpy(blobs['gt_boxes'])
+        net._gt_masks = blobs['gt_masks']
+        net._labels = torch.from_numpy(np.asarray(blobs['labels'].a))
+        net._cap_labels = None; net._cap_masks = None
+        net._mode = 'TEST'
+        net._image_gt_summaries = {}
+        with torch.no_grad():
+            net_conv, rois, cls_prob, bbox_pred, mask_prob = net._predict()
+            stds = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_STDS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
+            means = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_MEANS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
+            bbox_pred = bbox_pred.mul(stds).add(means)
+        return (net._predictions['cls_score'].numpy(), cls_prob.numpy(), bbox_pred.numpy(), rois.numpy(), net_conv)
+    net.test_image = test_image
+    pm = net._predict_masks_from_boxes_and_labels
+    net._predict_masks_from_boxes_and_labels = lambda nc, b, l: pm(nc, b, l).detach()
+
+    imgs = eval_blobs(H=H, W=W, T=T, V=V)
+
+    class Loader(object):
+        def __init__(self):
+            self.i = 0
+
+        def getTestBatch(self, split):
+            b = dict(imgs[self.i]); self.i += 1
+            b['labels'] = _Labels(b['labels'])
+            b['bounds'] = dict(it_pos_now=self.i, it_max=len(imgs), wrapped=self.i >= len(imgs))
+            return b
+    picked = []
+    orig_detect = MT.im_detect
+
+    def rec_detect(model, blobs):
+        r = orig_detect(model, blobs)
+        sc, bx = r[0], r[1]
+        pr = np.where(sc == np.max(sc[:, 1:]))
+        picked.append((int(pr[0][0]), int(pr[1][0]), bx[pr[0][0], pr[1][0] * 4:(pr[1][0] + 1) * 4].copy()))
+        return r
+    MT.im_detect = rec_detect
+    with torch.no_grad():
+        acc, thr, seg_correct, seg_total, cum_I, cum_U, num_sent = MT.eval_split(Loader(), net, None, 'val', dict(verbose=False))
+    MT.im_detect = orig_detect
+    out = dict(acc=float(acc), thr=np.asarray(thr, np.float64), seg_correct=np.asarray(seg_correct), seg_total=int(seg_total), cum_I=int(cum_I),
+               cum_U=int(cum_U), num_sent=int(num_sent), pred_roi=np.array([p[0] for p in picked]), pred_class=np.array([p[1] for p in picked]),
+               pred_box=np.stack([p[2] for p in picked]).astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, 'ref_eval_split.npz'), **out)
+    print('eval_split: acc %.3f seg_correct %s / %d  I %d U %d  sents %d' % (acc, list(seg_correct), seg_total, cum_I, cum_U, num_sent))
+    print(out['pred_class'], out['pred_box'])
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     install_harness()
@@ -520,6 +647,8 @@ if __name__ == '__main__':
         run_leaf()
     if what in ('leaf_eval', 'all'):
         run_leaf_eval()
+    if what in ('eval_split', 'all'):
+        run_eval_split()
     if what in ('tiny', 'all'):
         hook_proposals()
         run_reference('tiny', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,

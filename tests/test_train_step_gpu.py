@@ -309,6 +309,52 @@ def test_eval_split_runs():
     assert text.count('precision@') == 5 and 'overall IoU' in text
 
 
+def test_eval_split_vs_reference():
+    """model/test.py eval_split against the reference's own evaluation loop (model/test.py:185-450, run through the harness on the same
+    tiny synthetic split by tests/golden/make_golden.py eval_split -> ref_eval_split.npz): chosen (RoI, class), predicted boxes, box
+    accuracy, precision@X counts and the cumulative intersection / union pixel counts of the recovered masks."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_golden as MG
+    from lang2seg_amd import selftest
+    from lang2seg_amd.model import test as T
+    from oracle import weights as OW
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_eval_split.npz')))
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    net = selftest.build_net(opt, {}, 'f32', MG.eval_state_dict(opt))
+    imgs = MG.eval_blobs()
+
+    class Loader(object):
+        split_ix = {'val': [0, 1]}
+
+        def __init__(self):
+            self.i = 0
+
+        def getTestBatch(self, split):
+            b = dict(imgs[self.i]); self.i += 1
+            b['bounds'] = dict(it_pos_now=self.i, it_max=len(imgs), wrapped=self.i >= len(imgs))
+            return b
+    picked = []
+    orig = T.best_detection
+
+    def rec(scores, boxes):
+        r = orig(scores, boxes)
+        picked.append(r)
+        return r
+    T.best_detection = rec
+    try:
+        acc, thr, seg_correct, seg_total, cum_I, cum_U, num_sent = T.eval_split(Loader(), net, None, 'val', dict(verbose=False))
+    finally:
+        T.best_detection = orig
+    assert num_sent == int(g['num_sent']) == seg_total == int(g['seg_total']) and list(thr) == list(g['thr'])
+    assert [p[1] for p in picked] == list(g['pred_class'])
+    assert np.allclose(np.stack([p[2] for p in picked]), g['pred_box'], atol=1e-2)
+    assert acc == float(g['acc']) and list(seg_correct) == list(g['seg_correct'])
+    # masks are thresholded at 122/255 after a bilinear resize of fp32 probabilities: a last-bit difference may move a handful of pixels
+    assert abs(int(cum_I) - int(g['cum_I'])) <= 3 and abs(int(cum_U) - int(g['cum_U'])) <= 3, (cum_I, cum_U, int(g['cum_I']), int(g['cum_U']))
+    assert int(g['cum_I']) > 0
+
+
 def test_eval_split_vgg_runs():
     """model/test_vgg.py (boxes only) on the VGG16 / Faster R-CNN network in TEST mode"""
     from lang2seg_amd import selftest
