@@ -53,6 +53,9 @@ typedef struct {
   float* ws;                    /* optional ALL-ZERO float workspace >= rows*Cout for split-K partial sums; returned all-zero */
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);
+/* Direct 3x3 / stride 1 / pad 1 convolution with an LDS-staged input patch shared by the nine taps (csrc/conv3x3_patch.hip), for
+ * single-image feature maps; l2s_conv_igemm tries it first.  Returns 1 = launched, 0 = problem not eligible (nothing done), < 0 = -error. */
+int l2s_conv3x3_patch_try(const l2s_conv_desc* d, int dtype, hipStream_t stream);
 
 /* weight gradient: dw[Cout][KH*KW*Cin] (float) += sum_pixels dy[p][co] * x(p,tap)[ci]
  * (cuDNN backward-filter behind autograd in the reference: resnet_v1_cycle_res5_2.py:83-88,324-335, network_cycle_res5_2.py:236-251,279-301).

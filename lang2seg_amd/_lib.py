@@ -58,6 +58,7 @@ LOSS_RPN_CLS, LOSS_RPN_BOX, LOSS_CLS, LOSS_BOX, LOSS_MASK, LOSS_CAP, LOSS_TOTAL,
 SIGS = {
     'l2s_version': (i32, []),
     'l2s_conv_igemm': (i32, [C.POINTER(ConvDesc), i32, vp]),
+    'l2s_conv3x3_patch_try': (i32, [C.POINTER(ConvDesc), i32, vp]),
     'l2s_conv_wgrad': (i32, [C.POINTER(WgradDesc), i32, vp]),
     'l2s_wgrad_ws_bytes': (sz, [C.POINTER(WgradDesc), i32]),
     'l2s_wgrad_variant': (i32, [i32, i32, i32, i32, i32, i32, i32, i64, i32]),

@@ -386,15 +386,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned OOR = 0x80000000u;
 
-template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS>
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS, int RB = 128>
 __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void igemm_ring_kernel(const l2s_conv_desc p) {
   constexpr int VE = 16 / (int)sizeof(T);
-  constexpr int BK = ROWB / (int)sizeof(T);
+  // RB = bytes of K per LDS row per slice: 128 (64 bf16) or 256.  A wave of the 64x64 tile has only 8 MFMAs per 128-byte slice, and
+  // the LDS write -> barrier -> fragment read round trip (~600 cycles, measured: MFMA busy 13 % of the wave's cycles) is paid per slice:
+  // 256-byte rows halve the barriers per K.
+  constexpr int BK = RB / (int)sizeof(T);
+  constexpr int CPR = RB / 16;                  // 16-byte chunks (= loader threads) per row
   constexpr int NTG = 64 * WGM * WGN;           // threads of one K-group: WGM x WGN waves, wave tile WM x WN
-  constexpr int LR = NTG / 8;                   // rows covered by one loader pass (8 threads x 16 B per 128-byte row)
+  constexpr int LR = NTG / CPR;                 // rows covered by one loader pass
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int NA = BM / LR, NB = BN / LR;
-  constexpr int BUF = (BM + BN) * ROWB;
+  constexpr int BUF = (BM + BN) * RB;
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
   // KS > 1: in-workgroup split-K.  The workgroup holds KS K-groups of 4 waves; group g runs the loop below over slices
@@ -418,8 +422,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
   const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((xpix - 1) * p.ldx + p.Cin) * (long)sizeof(T)), 0x00020000);
   const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * K * (long)sizeof(T)), 0x00020000);
 
-  const int lrow = tid >> 3, cv = tid & 7;
-  const int wchunk = ((cv ^ (lrow & 7)) << 4);
+  const int lrow = tid / CPR, cv = tid % CPR;
+  const int wchunk = ((cv ^ (lrow & (CPR - 1))) << 4);      // (LR is a multiple of CPR: every row of this thread has the same low bits)
   int a_iy0[NA], a_ix0[NA], a_base[NA]; bool a_ok[NA];
   const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -465,12 +469,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
     if (c0 >= p.Cin && taps > 1) { c0 = 0; ++tap; if (tap < taps) set_tap(tap); }
   };
   auto store_slice = [&](int buf, const uint4 (&ra)[NA], const uint4 (&rb)[NB]) {
-    char* a = smem + buf * BUF + lrow * ROWB + wchunk;
-    char* b = a + BM * ROWB;
+    char* a = smem + buf * BUF + lrow * RB + wchunk;
+    char* b = a + BM * RB;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *(uint4*)(a + LR * j * ROWB) = ra[j];
+    for (int j = 0; j < NA; ++j) *(uint4*)(a + LR * j * RB) = ra[j];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) *(uint4*)(b + LR * j * ROWB) = rb[j];
+    for (int j = 0; j < NB; ++j) *(uint4*)(b + LR * j * RB) = rb[j];
   };
 
   f32x4 acc[TM][TN];
@@ -488,18 +492,18 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
   if (D < KT) issue(ra[0], rb[0]);
 
   const int fr = lane & 15, fg = lane >> 4;
-  const int swz = fr & 7;
-  const int offa = (wm * WM + fr) * ROWB, offb = BM * ROWB + (wn * WN + fr) * ROWB;
+  const int swz = fr & (CPR - 1);
+  const int offa = (wm * WM + fr) * RB, offb = BM * RB + (wn * WN + fr) * RB;
   auto compute = [&](int t) {
     const char* base = smem + (t & 1) * BUF;
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
+    for (int kg = 0; kg < RB / 64; ++kg) {
       const int ch = ((kg * 4 + fg) ^ swz) << 4;
       uint4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * ROWB + ch);
+      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * RB + ch);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * ROWB + ch);
+      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * RB + ch);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -933,14 +937,14 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS = 1>
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS = 1, int RB = 128>
 int launch_igemm_ring(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN));
-  size_t lds = (size_t)KS * 2 * (BM + BN) * ROWB;
+  size_t lds = (size_t)KS * 2 * (BM + BN) * RB;
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  L2S_LAUNCH((igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS>), grid, dim3(64 * WGM * WGN * KS), lds, st, d);
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS, RB>), grid, dim3(64 * WGM * WGN * KS), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -976,6 +980,12 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   if ((d->flags & L2S_CONV_DECONV2X2) && (d->Cout % 16)) return L2S_EINVAL;
   const long M = (long)d->n_img * d->OH * d->OW;
   if (M >= (1 << 24)) return L2S_EINVAL;
+  {
+    // 3x3 / stride 1 on a feature map: the patch kernel (one staged input patch for all nine taps) when the problem is eligible
+    const int r = l2s_conv3x3_patch_try(d, dtype, stream);
+    if (r == 1) return L2S_OK;
+    if (r < 0) return -r;
+  }
   const bool f32o = d->flags & L2S_CONV_OUT_F32;
   // tile choice: prefer 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64
   const long t128 = (long)cdiv(M, 128) * cdiv(d->Cout, 128);
@@ -1039,6 +1049,15 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
         if (ks == 2) return GR(bf16_t, 64, 64, 3, 2);
         // (ring depth 4 = 64 KiB in flight per workgroup; depths 8 and 12 were measured slower, round 2: 129 / 119 vs 136 img/s)
         // and so was the software-pipelined (three LDS buffers) form of this tile: 132-133 img/s
+        // 256-byte K rows per slice when every tap has whole 256-byte pieces of channels
+        static const int rb256 = [] { const char* e = getenv("L2S_IGEMM_RB256"); return e ? atoi(e) : 0; }();
+        if (rb256 && d->Cin % 128 == 0) {
+#define GRB(DD) (f32o ? launch_igemm_ring<bf16_t, 64, 64, 2, 2, DD, true, 1, 256>(*d, stream) : launch_igemm_ring<bf16_t, 64, 64, 2, 2, DD, false, 1, 256>(*d, stream))
+          if (rb256 == 2) return GRB(2);
+          if (rb256 == 3) return GRB(3);
+          return GRB(4);
+#undef GRB
+        }
         return GR(bf16_t, 64, 64, 4, 1);
       }
       if (dtype == L2S_F32) {

@@ -55,6 +55,9 @@ TOL = {0: 2e-5, 1: 5e-3}
     dict(n=256, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1),          # the dominant launch: layer4 @ 256 RoIs (M=12544, K=4608, 224x128 tile, tap-inner walk)
     dict(n=1, H=38, W=63, Cin=1024, Cout=512, k=3, s=1, p=1),         # RPN 3x3
     dict(n=256, H=7, W=7, Cin=1024, Cout=2048, k=1, s=1, p=0),        # layer4.0 downsample @ RoIs
+    dict(n=1, H=75, W=125, Cin=128, Cout=128, k=3, s=1, p=1),         # layer2 3x3 (patch kernel, wide rows)
+    dict(n=1, H=5, W=3, Cin=64, Cout=36, k=3, s=1, p=1),              # a map smaller than one pixel tile, ragged channel tile
+    dict(n=2, H=19, W=23, Cin=64, Cout=64, k=3, s=1, p=1),            # two images: implicit GEMM (the patch kernel takes single maps)
 ])
 def test_conv_fwd(cfg, dt):
     O = ops()
@@ -98,6 +101,7 @@ def test_conv_fwd(cfg, dt):
     dict(n=256, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1),          # dominant shape: dgrad on the 224x128 tile, wgrad over 12544 pixels
     dict(n=256, H=7, W=7, Cin=1024, Cout=512, k=1, s=1, p=0),         # layer4 1x1-in @ RoIs (the 128x128 wgrad tile)
     dict(n=1, H=38, W=63, Cin=256, Cout=1024, k=1, s=1, p=0),         # layer3 1x1-out
+    dict(n=1, H=75, W=125, Cin=128, Cout=128, k=3, s=1, p=1),         # layer2 3x3
 ])
 def test_conv_bwd(cfg, dt):
     """data gradient = igemm over dY with transposed/flipped weights; weight gradient = wgrad kernel."""
