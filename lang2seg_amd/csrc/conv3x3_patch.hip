@@ -12,6 +12,12 @@
 // fragment is ever masked.  Per 128x32 tile and 256 input channels the workgroup loads 132 KB of input + 147 KB of weights instead of
 // 590 KB + 147 KB.
 //
+// Measured (round 2, tools/conv_bench.py): layer3 3x3 14.4 us against 15.1 us for the implicit GEMM, but layer2 (21 vs 13.5 us), the RPN
+// convolution (79 vs 65 us) and layer4 on the map (45 vs 34 us) are slower, and so is the step (134.3 vs 136.1 img/s): with ~150 workgroups
+// these launches are paced by fixed latencies (a one-slice launch already takes 4 us) and by instruction issue of a single wave per SIMD
+// (PMC: 350 of a slice's 970 cycles are issue, 128 of them MFMA), not by bytes.  l2s_conv_igemm therefore uses this kernel only when
+// L2S_CONV3X3_PATCH=1; it stays in the library as a checked alternative (tests/test_kernels_gpu.py::test_conv3x3_patch).
+//
 // Pipeline step = (channel chunk, filter row ky): the three taps of the row share one barrier: 24 MFMAs per wave and step.
 // LDS: patch double-buffered per chunk, weights (3 taps x BN rows) double-buffered per step; 128-byte rows, 16-byte chunks XOR-swizzled
 // by (row & 7) (conflict-free ds_read_b128 at any row offset).  Operands are fetched one step ahead through wave-uniform buffer
@@ -240,8 +246,7 @@ int launch_patch(const l2s_conv_desc& d, hipStream_t st) {
 
 // 1: this problem is handled (launched); 0: not eligible (caller falls back to the implicit GEMM); < 0: error
 extern "C" int l2s_conv3x3_patch_try(const l2s_conv_desc* d, int dtype, hipStream_t stream) {
-  static const int on = [] { const char* e = getenv("L2S_CONV3X3_PATCH"); return e ? atoi(e) : 1; }();
-  if (!on || !d) return 0;
+  if (!d) return 0;
   const int bk = dtype == L2S_BF16 ? 64 : 32;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->OH != d->IH || d->OW != d->IW) return 0;
   if (d->Cin % bk || d->Cout % 4 || (d->flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) || d->tile) return 0;

@@ -982,7 +982,8 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   if (M >= (1 << 24)) return L2S_EINVAL;
   {
     // 3x3 / stride 1 on a feature map: the patch kernel (one staged input patch for all nine taps) when the problem is eligible
-    const int r = l2s_conv3x3_patch_try(d, dtype, stream);
+    static const int patch_on = [] { const char* e = getenv("L2S_CONV3X3_PATCH"); return e ? atoi(e) : 0; }();   // measured slower in the step: off
+    const int r = patch_on ? l2s_conv3x3_patch_try(d, dtype, stream) : 0;
     if (r == 1) return L2S_OK;
     if (r < 0) return -r;
   }

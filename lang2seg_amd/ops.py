@@ -73,6 +73,19 @@ def tape_size(h):
 
 
 # ------------------------------------------------------------------ conv / gemm
+def conv3x3_patch(x, w, y, n_img, IH, IW, Cin, Cout, bias=None, add=None, ref=None, relu=False, out_f32=False, dt=None):
+    """direct 3x3 / stride 1 / pad 1 convolution through the LDS-patch kernel; False when the problem is not eligible (nothing launched)"""
+    d = ConvDesc()
+    d.x, d.w, d.y, d.bias, d.add, d.ref = ptr(x), ptr(w), ptr(y), ptr(bias), ptr(add), ptr(ref)
+    d.n_img, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad = n_img, IH, IW, Cin, IH, IW, Cout, 3, 3, 1, 1
+    d.ldx, d.ldy, d.ldadd, d.ldref = Cin, Cout, Cout, Cout
+    d.flags = (_lib.CONV_RELU if relu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0)
+    r = _lib.load().l2s_conv3x3_patch_try(C.byref(d), dt_of(x) if dt is None else dt, stream())
+    if r < 0:
+        raise _lib.L2SError('l2s_conv3x3_patch_try returned error %d' % -r)
+    return r == 1
+
+
 def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
                ref=None, relu=False, out_f32=False, deconv=False, scatter=None, ldx=None, ldy=None, ldadd=None,
                ldref=None, tile=0, dt=None, ws=None, split_k=0, xcd_mode=-1):

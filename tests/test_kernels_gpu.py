@@ -92,6 +92,35 @@ def test_conv_fwd(cfg, dt):
 
 
 @pytest.mark.parametrize('dt', [0, 1])
+@pytest.mark.parametrize('cfg', [dict(H=19, W=23, Cin=64, Cout=64), dict(H=38, W=63, Cin=256, Cout=256), dict(H=75, W=125, Cin=128, Cout=128),
+                                 dict(H=5, W=3, Cin=64, Cout=36), dict(H=38, W=63, Cin=1024, Cout=512)])
+def test_conv3x3_patch(cfg, dt):
+    """l2s_conv3x3_patch_try (direct 3x3 with one LDS-staged input patch for the nine taps, zero-padded virtual pixel layout) against
+    torch on the same rounded operands: bias + residual + ReLU epilogue, ReLU-mask epilogue (the data-gradient form), fp32 output."""
+    O = ops()
+    g = torch.Generator().manual_seed(8)
+    H, W, Cin, Cout = cfg['H'], cfg['W'], cfg['Cin'], cfg['Cout']
+    x = torch.randn(1, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g); res = torch.randn(1, Cout, H, W, generator=g)
+    xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
+    xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
+    conv = F.conv2d(xr, wr, None, padding=1)
+    y = O.empty((H * W, Cout), dt)
+    assert O.conv3x3_patch(xd, wd, y, 1, H, W, Cin, Cout, bias=b.to(DEV), add=rd, relu=True)
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(1, H, W, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
+    y2 = O.empty((H * W, Cout), dt)
+    assert O.conv3x3_patch(xd, wd, y2, 1, H, W, Cin, Cout, ref=rd)
+    torch.cuda.synchronize()
+    assert rel_err(y2.float().view(1, H, W, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
+    y3 = torch.empty((H * W, Cout), dtype=torch.float32, device=DEV)
+    assert O.conv3x3_patch(xd, wd, y3, 1, H, W, Cin, Cout, out_f32=True)
+    torch.cuda.synchronize()
+    assert rel_err(y3.view(1, H, W, Cout), nhwc(conv)) < (2e-5 if dt == 0 else 1e-4)
+    assert not O.conv3x3_patch(xd, wd, y3, 2, H, W, Cin, Cout)          # RoI batches / several images: not eligible
+
+
+@pytest.mark.parametrize('dt', [0, 1])
 @pytest.mark.parametrize('cfg', [
     dict(n=1, H=19, W=23, Cin=64, Cout=128, k=3, s=1, p=1),
     dict(n=1, H=38, W=63, Cin=256, Cout=256, k=3, s=1, p=1),

@@ -6,7 +6,7 @@ import torch
 from lang2seg_amd import ops as O
 from tools.conv_bench import timeit
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-for name, n, H, W, Cin, Cout, k in [('l4r 1x1 out', 256, 7, 7, 512, 2048, 1), ('l4r down', 256, 7, 7, 1024, 2048, 1), ('l4r 3x3', 256, 7, 7, 512, 512, 3), ('l3 1x1 out', 1, 38, 63, 256, 1024, 1)]:
+for name, n, H, W, Cin, Cout, k in [('l4r 1x1 out', 256, 7, 7, 512, 2048, 1), ('l4r down', 256, 7, 7, 1024, 2048, 1), ('l4r 3x3', 256, 7, 7, 512, 512, 3), ('l3 1x1 out', 1, 38, 63, 256, 1024, 1), ('l3 1x1 in', 1, 38, 63, 1024, 256, 1), ('l3 3x3', 1, 38, 63, 256, 256, 3), ('l3 tiny K', 1, 38, 63, 64, 256, 1)]:
     p = k // 2
     M = n * H * W
     x = torch.randn(M, Cin, device='cuda').bfloat16()
