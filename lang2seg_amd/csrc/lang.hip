@@ -19,48 +19,61 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y[m][n]));  one wave per n, M <= MT rows per pass.
-// VEC: 16-byte loads (rows 16-byte aligned: ldw, ldx, K multiples of 4); otherwise scalar loads.
-template <int MT, bool VEC>
+// y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y[m][n]));  a wave owns NW consecutive outputs n and M <= MT rows per pass: every x
+// vector it loads is used for NW weight rows (the one-output-per-wave form re-read the whole x block per output: 144 MB of L1 traffic
+// for the 21 x 3350 x 512 logit layer, 40 us).  VW = floats per load: 4 (rows 16-byte aligned), 2 (8-byte aligned: K = 3350) or 1.
+template <int MT, int VW, int NW>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int ldx_, const float* __restrict__ w, int ldw,
                                                         const float* __restrict__ b, float* y, int ldy, int m0, int M, int N, int K,
                                                         int act, int accumulate) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NW, lane = threadIdx.x & 63;
+  if (n0 >= N) return;
   m0 += blockIdx.y * MT;                       // row chunks of one launch
-  float acc[MT];
+  float acc[MT][NW];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-  const float* wr = w + (long)n * ldw;
-  if (VEC) {
-    for (int k = lane * 4; k < K; k += 256) {
-      const float4 wv = *(const float4*)(wr + k);
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        if (m0 + m < M) {
-          const float4 xv = *(const float4*)(x + (long)(m0 + m) * ldx_ + k);
-          acc[m] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[m]))));
-        }
-      }
+    for (int j = 0; j < NW; ++j) acc[m][j] = 0.f;
+  for (int k = lane * VW; k < K; k += 64 * VW) {
+    float wv[NW][VW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const float* wr = w + (long)min(n0 + j, N - 1) * ldw + k;
+      if (VW == 4) { const float4 t = *(const float4*)wr; wv[j][0] = t.x; wv[j][1] = t.y; wv[j][VW > 2 ? 2 : 0] = t.z; wv[j][VW > 3 ? 3 : 0] = t.w; }
+      else if (VW == 2) { const float2 t = *(const float2*)wr; wv[j][0] = t.x; wv[j][VW > 1 ? 1 : 0] = t.y; }
+      else wv[j][0] = *wr;
     }
-  } else {
-    for (int k = lane; k < K; k += 64) {
-      const float wv = wr[k];
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        if (m0 + m < M) acc[m] = fmaf(wv, x[(long)(m0 + m) * ldx_ + k], acc[m]);
+    for (int m = 0; m < MT; ++m) {
+      if (m0 + m < M) {
+        const float* xr = x + (long)(m0 + m) * ldx_ + k;
+        float xv[VW];
+        if (VW == 4) { const float4 t = *(const float4*)xr; xv[0] = t.x; xv[1] = t.y; xv[VW > 2 ? 2 : 0] = t.z; xv[VW > 3 ? 3 : 0] = t.w; }
+        else if (VW == 2) { const float2 t = *(const float2*)xr; xv[0] = t.x; xv[VW > 1 ? 1 : 0] = t.y; }
+        else xv[0] = *xr;
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+          for (int e = 0; e < VW; ++e) acc[m][j] = fmaf(wv[j][e], xv[e], acc[m][j]);
+      }
     }
   }
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[m][j] = wave_sum(acc[m][j]);
   if (lane == 0) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
       if (m0 + m < M) {
-        float v = acc[m] + (b ? b[n] : 0.f);
-        float* o = y + (long)(m0 + m) * ldy + n;
-        if (accumulate) v += *o;
-        *o = act_apply(v, act);
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+          if (n0 + j < N) {
+            float v = acc[m][j] + (b ? b[n0 + j] : 0.f);
+            float* o = y + (long)(m0 + m) * ldy + n0 + j;
+            if (accumulate) v += *o;
+            *o = act_apply(v, act);
+          }
       }
   }
 }
@@ -100,20 +113,29 @@ __global__ __launch_bounds__(1024) void gemvT_kernel(const float* __restrict__ d
   }
 }
 
-// dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n]
+// dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n].  A block owns 256 columns k and NB = 8 rows n: every x value it loads is
+// used for 8 outputs (dy[m][n] is uniform: scalar loads); single owner per output, no atomics.
 __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx_,
                                                           float* dw, float* db, int M, int N, int K) {
-  const int n = blockIdx.y;
+  constexpr int NB = 8;
+  const int n0 = blockIdx.y * NB;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k < K) {
-    float acc = 0.f;
-    for (int m = 0; m < M; ++m) acc = fmaf(dy[(long)m * lddy + n], x[(long)m * ldx_ + k], acc);
-    dw[(long)n * K + k] += acc;
+    float acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float xv = x[(long)m * ldx_ + k];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = fmaf(dy[(long)m * lddy + min(n0 + j, N - 1)], xv, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) if (n0 + j < N) dw[(long)(n0 + j) * K + k] += acc[j];
   }
-  if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (db && blockIdx.x == 0 && threadIdx.x < NB && n0 + threadIdx.x < N) {
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += dy[(long)m * lddy + n];
-    db[n] += s;
+    for (int m = 0; m < M; ++m) s += dy[(long)m * lddy + n0 + threadIdx.x];
+    db[n0 + threadIdx.x] += s;
   }
 }
 
@@ -641,13 +663,16 @@ __global__ __launch_bounds__(256) void cap_att_bwd_batched_kernel(const float* _
 extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw, const float* b, float* y, int ldy, int M, int N, int K, int act,
                               int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0) return L2S_OK;
-  const bool vec = !((K & 3) || (ldx_ & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15));
+  const bool v4 = !((K & 3) || (ldx_ & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15));
+  const bool v2 = !((K & 1) || (ldx_ & 1) || (ldw & 1) || ((uintptr_t)x & 7) || ((uintptr_t)w & 7));
   {
     const int m0 = 0;
-#define LF(MT) do { dim3 grid(cdiv(N, 4), cdiv(M, MT)); \
-                    if (vec) L2S_LAUNCH((linear_fwd_kernel<MT, true>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
-                    else L2S_LAUNCH((linear_fwd_kernel<MT, false>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); } while (0)
-    if (M <= 1) LF(1); else if (M <= 8) LF(8); else if (M <= 16) LF(16); else LF(MAXM);
+    // one output per wave for a single row (GEMV: nothing to reuse), four outputs per wave for row batches
+#define LF(MT, NW) do { dim3 grid(cdiv(N, 4 * NW), cdiv(M, MT)); \
+                    if (v4) L2S_LAUNCH((linear_fwd_kernel<MT, 4, NW>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
+                    else if (v2) L2S_LAUNCH((linear_fwd_kernel<MT, 2, NW>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
+                    else L2S_LAUNCH((linear_fwd_kernel<MT, 1, NW>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); } while (0)
+    if (M <= 1) LF(1, 1); else if (M <= 8) LF(8, 4); else if (M <= 16) LF(16, 4); else LF(MAXM, 4);
 #undef LF
   }
   return l2s_check_launch();
@@ -661,7 +686,7 @@ extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float
 }
 extern "C" int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx_, float* dw, float* db, int M, int N, int K, hipStream_t s) {
   if (M <= 0) return L2S_OK;
-  L2S_LAUNCH(linear_bwd_w_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
+  L2S_LAUNCH(linear_bwd_w_kernel, dim3(cdiv(K, 256), cdiv(N, 8)), dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
   return l2s_check_launch();
 }
 extern "C" int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream_t s) {

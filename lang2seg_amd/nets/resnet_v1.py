@@ -556,7 +556,9 @@ class resnetv1(Network):
             """returns (d net_conv, d base or None) contributed by the caption loss"""
             if 'cap' in self.knockout:
                 return self.buf('l4m.skip', (HW, C4)), None
+            self._mark('dyn fwd')
             feats = l4_on_map(net_conv, 'l4m')
+            self._mark('cap: layer4 on map fwd')
             att = self.buf('cap.att', (196, AF))
             if self.var['cap'] == 'mask':
                 gm = self.buf('cap.gm', (HW,), f32)
@@ -570,14 +572,19 @@ class resnetv1(Network):
                 O.adaptive_pool_fwd(feats_b, None, att, Hc, Wc, 2048, 14, 14, AF)
                 O.adaptive_pool_fwd(feats, None, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
                 t.update({'feats_all': feats, 'feats_before_all': feats_b, 'att_feats': att})
+            self._mark('cap: pools')
             self._caption_fwd(d, att, loss)
+            self._mark('cap: captioner fwd')
             if not backward:
                 return None, None
             datt = self._caption_bwd(d, att)
+            self._mark('cap: captioner bwd')
             g = self.buf('l4m.g', (HW, 2048))
             if self.var['cap'] == 'mask':
                 O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
-                return l4_on_map_bwd(g, 'l4m'), None
+                r = l4_on_map_bwd(g, 'l4m')
+                self._mark('cap: pool bwd + layer4 on map dgrad')
+                return r, None
             gb = self.buf('l4b.g', (HW, 2048))
             O.adaptive_pool_bwd(datt, AF, 0, 0, None, gb, feats_b, Hc, Wc, 2048, 14, 14)
             O.adaptive_pool_bwd(datt, AF, 2048, 0, None, g, feats, Hc, Wc, 2048, 14, 14)
