@@ -553,7 +553,9 @@ class resnetv1(Network):
             return g
 
         def caption_branch():
-            """returns (d net_conv, d base or None) contributed by the caption loss"""
+            """generator; returns (d net_conv, d base or None) contributed by the caption loss.  It yields between its four pieces so that
+            the launches of the main path are ISSUED in between: one host thread feeds every stream, and the ~220 launches of this branch
+            in one burst would leave the main queue without work for their whole issue time."""
             if 'cap' in self.knockout:
                 return self.buf('l4m.skip', (HW, C4)), None
             self._mark('dyn fwd')
@@ -573,12 +575,15 @@ class resnetv1(Network):
                 O.adaptive_pool_fwd(feats, None, att[:, 2048:], Hc, Wc, 2048, 14, 14, AF)
                 t.update({'feats_all': feats, 'feats_before_all': feats_b, 'att_feats': att})
             self._mark('cap: pools')
+            yield
             self._caption_fwd(d, att, loss)
             self._mark('cap: captioner fwd')
             if not backward:
                 return None, None
+            yield
             datt = self._caption_bwd(d, att)
             self._mark('cap: captioner bwd')
+            yield
             g = self.buf('l4m.g', (HW, 2048))
             if self.var['cap'] == 'mask':
                 O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
@@ -590,12 +595,24 @@ class resnetv1(Network):
             O.adaptive_pool_bwd(datt, AF, 2048, 0, None, g, feats, Hc, Wc, 2048, 14, 14)
             d_base_cap = l4_on_map_bwd(gb, 'l4b', in_relu=True)
             return l4_on_map_bwd(g, 'l4m'), d_base_cap
-        d_nc_cap = d_base_cap = None
+        cap_state = dict(gen=None, out=(None, None))
         if self.var['cap'] is not None:
             if S is not None:
-                self.sfork(main, S['cap'])
-            with on('cap'):
-                d_nc_cap, d_base_cap = caption_branch()
+                self.sfork(main, S['cap'])                  # the branch needs net_conv only: ordered after the dynamic filters, whenever issued
+            cap_state['gen'] = caption_branch()
+
+        def cap_advance(finish=False):
+            """issue the next piece (or all remaining pieces) of the caption branch on its stream"""
+            while cap_state['gen'] is not None:
+                with on('cap'):
+                    try:
+                        next(cap_state['gen'])
+                    except StopIteration as e:
+                        cap_state['out'] = e.value if e.value is not None else (None, None)
+                        cap_state['gen'] = None
+                if not finish:
+                    break
+        cap_advance()                                         # layer4 on the map + pooled caption features
         self._mark('dyn + caption branch (cap)')
         # ---- RPN (NET:235-275) ----
         rpn = self.buf('rpn.a', (HW, 512))
@@ -619,6 +636,7 @@ class resnetv1(Network):
         rois_all = self.buf('prop.rois', (post, 5), f32); rsc_all = self.buf('prop.rsc', (post,), f32)
         O.gather_rois(sb, ss, keep, nkeep, post, rois_all, rsc_all)
         t['proposal_rois'], t['proposal_n'], t['proposal_scores'] = rois_all, nkeep, rsc_all
+        cap_advance()                                         # captioner forward
         if self.parity is not None and self.parity.get('forced_proposals') is not None:
             fr, fs = self.parity['forced_proposals']
             rois_all = self.buf('prop.rois_forced', (post, 5), f32, zero=True); rsc_all = self.buf('prop.rsc_forced', (post,), f32, zero=True)
@@ -650,6 +668,7 @@ class resnetv1(Network):
         self._mark('targets')
         cheads, NPC, mscore = self._roi_head_fwd(net_conv, Hc, Wc, rois, R, FGM, saved)
         self._mark('roi head fwd')
+        cap_advance()                                         # captioner backward
         # ---- detection losses + head gradients (NET:375-413) ----
         d_rheads = self.buf('rpn.dheads', (HW, NPR)); d_cheads = self.buf('roi.dheads', (R, NPC)); dscore = self.buf('mask.dscore', (FGM * MS * MS,), f32)
         if S is not None:
@@ -661,6 +680,7 @@ class resnetv1(Network):
         # =================================== backward (detection side, main stream) ===================================
         dp = self.dp if self.dp is not None else self._early_op     # either one takes the finished gradient prefixes
         if not backward:
+            cap_advance(finish=True)
             if S is not None and self.var['cap'] is not None:
                 self.sfork(S['cap'], main)
             O.total_loss(loss, self._cap_loss_weight)
@@ -669,6 +689,8 @@ class resnetv1(Network):
         self._mark('losses')
         d_nc_roi = self._roi_head_bwd(d_cheads, dscore, labels, counts, rois, Hc, Wc, R, FGM, saved)
         self._mark('roialign bwd')
+        cap_advance(finish=True)                              # layer4 on the map backward
+        d_nc_cap, d_base_cap = cap_state['out']
         # rpn
         self.rpn_heads.wgrad(d_rheads, rpn, 1, Hc, Wc)
         drpn = self.buf('rpn.da', (HW, 512))
