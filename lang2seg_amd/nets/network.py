@@ -342,15 +342,29 @@ class Network(object):
         if not hasattr(self, '_tapes'):
             import collections
             self._tapes = collections.OrderedDict()                  # least recently used first
+            self._tape_hist = collections.deque(maxlen=int(getattr(self, 'tape_window', 64)))   # hit / miss of the last steps
         ent = self._tapes.get(key)
+        # Real data feeds dozens of image sizes x 10-20 token counts: when most steps meet a new key, recording (two device syncs, an
+        # eagerly issued step, an activation plan pinned per key) costs more than replaying saves.  Below a 50 % hit rate over the last
+        # 64 steps a miss is simply run eagerly and not recorded (the keys already on tape keep replaying); recording resumes when the
+        # stream of shapes settles.
+        self._tape_hist.append(ent is not None)
+        if ent is None and len(self._tape_hist) == self._tape_hist.maxlen and sum(self._tape_hist) < self._tape_hist.maxlen // 2 \
+                and not getattr(self, 'tape_always', False):
+            loss = self.forward_backward(dev)
+            if self.dp is not None:
+                self.dp.finish()
+            train_op.step()
+            return loss
         main = torch.cuda.current_stream()
         S = self.streams()
         slist = [main, S['lang'], S['cap'], S['wg'], S['wg2'], S['tr']]
         dp = self.dp
         if ent is None:
             # a new (image size, token counts): the step is executed once, eagerly, and recorded while it runs
-            while len(self._tapes) >= int(getattr(self, 'max_tapes', 64)):
-                self._evict_tape()
+            while len(self._tapes) >= int(getattr(self, 'max_tapes', 64)) or \
+                    (self._tapes and self.plan_bytes() > int(getattr(self, 'max_plan_bytes', 96 << 30))):
+                self._evict_tape()                                   # by count and by the bytes of the activation plans the tapes pin
             st = {k: dev[k].clone() for k in ('data', 'gt_boxes', 'gt_masks', 'labels', 'cap_in', 'cap_tgt', 'cap_mask')}
             d = dict(dev); d.update(st)
             torch.cuda.synchronize()
@@ -386,6 +400,10 @@ class Network(object):
                 dp.ready(stage)
         O.tape_run_segment(h, slist, len(stages))
         return loss
+
+    def plan_bytes(self):
+        """bytes of the persistent activation buffers (one plan per image size / token count that is on a tape)"""
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
     def _evict_tape(self):
         """drop the least recently used tape and every activation buffer only it was holding (real data: one activation plan per

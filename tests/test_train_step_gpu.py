@@ -617,6 +617,30 @@ def test_tape_over_mixed_shapes_matches_eager():
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (k, order[k], a, b)
 
 
+def test_tape_stops_recording_when_shapes_keep_changing():
+    """a stream of inputs whose (image size, token count) key is new almost every step: once fewer than half of the last `tape_window`
+    steps were replays, a miss runs eagerly and is not recorded (no tape, no pinned activation plan per key); known keys keep replaying"""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=16, RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=100, RPN_BATCHSIZE=64)
+    net = selftest.build_net(opt, over, 'f32', sd)
+    net.use_tape = True
+    net.tape_window = 4
+    sgd = SGD(net, 0.0)
+    shapes = [(160, 224, 6), (128, 256, 4), (192, 160, 5), (160, 192, 3), (176, 208, 6), (144, 240, 2), (128, 224, 5)]
+    for i, (h, w, tk) in enumerate(shapes):
+        vals = net.train_step(dict(OS.make_blob(h, w, tk, 60, seed=40 + i)), 0, sgd)
+        assert all(np.isfinite(v) for v in vals)
+    torch.cuda.synchronize()
+    assert len(net._tapes) == 4                               # the window filled with misses after four steps: the rest ran eagerly
+    first = dict(OS.make_blob(160, 224, 6, 60, seed=40))
+    a = net.train_step(first, 0, sgd)                         # a key that is on tape still replays
+    assert len(net._tapes) == 4 and all(np.isfinite(v) for v in a)
+
+
 @pytest.mark.parametrize('variant', ['cycle', 'vgg'])
 def test_random_init_network_stays_finite(variant):
     """bench.py and the tools without a checkpoint run the network from its own initialisers: the frozen-BN trunk must keep its
