@@ -113,11 +113,11 @@ __global__ __launch_bounds__(1024) void gemvT_kernel(const float* __restrict__ d
   }
 }
 
-// dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n].  A block owns 256 columns k and NB = 8 rows n: every x value it loads is
-// used for 8 outputs (dy[m][n] is uniform: scalar loads); single owner per output, no atomics.
+// dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n].  A block owns 256 columns k and NB rows n (dy[m][n] is uniform: scalar
+// loads); single owner per output, no atomics.
 __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx_,
                                                           float* dw, float* db, int M, int N, int K) {
-  constexpr int NB = 8;
+  constexpr int NB = 1;                    // (8 rows per block was measured slower inside the step: 378 vs 319 us for the 12 launches)
   const int n0 = blockIdx.y * NB;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k < K) {
@@ -672,7 +672,9 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw,
                     if (v4) L2S_LAUNCH((linear_fwd_kernel<MT, 4, NW>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
                     else if (v2) L2S_LAUNCH((linear_fwd_kernel<MT, 2, NW>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); \
                     else L2S_LAUNCH((linear_fwd_kernel<MT, 1, NW>), grid, dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, m0, M, N, K, act, accumulate); } while (0)
-    if (M <= 1) LF(1, 1); else if (M <= 8) LF(8, 4); else if (M <= 16) LF(16, 4); else LF(MAXM, 4);
+    // NW = 4 (x reused for four outputs) was measured slower inside the step (635 vs 441 us for the 11 row-batch launches: four times
+    // fewer waves to hide the load latency on 512..3350 outputs), so every wave keeps one output
+    if (M <= 1) LF(1, 1); else if (M <= 8) LF(8, 1); else if (M <= 16) LF(16, 1); else LF(MAXM, 1);
 #undef LF
   }
   return l2s_check_launch();
@@ -686,7 +688,7 @@ extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float
 }
 extern "C" int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx_, float* dw, float* db, int M, int N, int K, hipStream_t s) {
   if (M <= 0) return L2S_OK;
-  L2S_LAUNCH(linear_bwd_w_kernel, dim3(cdiv(K, 256), cdiv(N, 8)), dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
+  L2S_LAUNCH(linear_bwd_w_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
   return l2s_check_launch();
 }
 extern "C" int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream_t s) {
