@@ -146,6 +146,8 @@ int l2s_mask_downsample(const uint8_t* mask, float* out, int H, int W, int h, in
 /* counter-based hash RNG: the step counter lives in DEVICE memory (so a captured hipGraph replays with fresh randomness);
  * l2s_counter_inc bumps it once per step; `salt` separates the call sites */
 int l2s_counter_inc(uint64_t* counter_dev, hipStream_t s);
+/* diagnostics (tools/step_timeline.py): one-thread launch that stores the device's constant 100 MHz clock when the stream reaches it */
+int l2s_stamp(uint64_t* slot_dev, hipStream_t s);
 /* dropout mask, entries 0 or 1/(1-p) */
 int l2s_dropout_mask(float* mask, long n, float p, const uint64_t* seed_dev, uint64_t salt, hipStream_t s);
 
@@ -264,8 +266,12 @@ int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, 
 /* small-M linear layers, fp32: y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y_in)) ; act 0 none, 1 relu, 2 tanh */
 int l2s_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* b, float* y, int ldy, int M, int N, int K, int act,
                    int accumulate, hipStream_t s);
-/* dx[m][k] (+)= sum_n dy[m][n] w[n][k] */
-int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate, hipStream_t s);
+/* dx[m][k] (+)= (sum_n dy[m][n] w[n][k]) (* mul[m][k], same leading dimension as dx; may be NULL) from the weight as stored.
+ * Row batches split the contraction over workgroups when `ws` (>= l2s_linear_bwd_x_ws_floats floats) is given: partial sums in ws,
+ * added in a fixed order by a second launch (no atomics); without ws one workgroup per 64 output columns walks all of n. */
+long l2s_linear_bwd_x_ws_floats(int M, int N, int K);
+int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate,
+                     const float* mul, float* ws, long ws_floats, hipStream_t s);
 /* dw[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n] */
 int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, hipStream_t s);
 /* activation backward in place: dy *= act'(y)  (act 1 relu, 2 tanh) */

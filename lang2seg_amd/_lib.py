@@ -80,6 +80,7 @@ SIGS = {
     'l2s_mask_downsample': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'l2s_dropout_mask': (i32, [vp, i64, f32, vp, u64, vp]),
     'l2s_counter_inc': (i32, [vp, vp]),
+    'l2s_stamp': (i32, [vp, vp]),
     'l2s_rpn_decode': (i32, [vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]),
     'l2s_sort_topk': (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_nms_workspace_bytes': (sz, [i32]),
@@ -101,7 +102,8 @@ SIGS = {
     'l2s_maskpred_ws_floats': (i64, [i32, i32]),
     'l2s_maskpred_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_linear_fwd': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    'l2s_linear_bwd_x': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    'l2s_linear_bwd_x': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, i64, vp]),
+    'l2s_linear_bwd_x_ws_floats': (i64, [i32, i32, i32]),
     'l2s_linear_bwd_w': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]),
     'l2s_act_bwd': (i32, [vp, vp, i64, i32, vp]),
     'l2s_embed_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),

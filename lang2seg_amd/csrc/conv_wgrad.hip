@@ -43,11 +43,12 @@ typedef l2s_wgrad_prob wgp;
 
 // One output tile (co tile, ci tile, tap or filter row) of problem p over the slices [s_begin, s_end) of segment `seg`'s pixels
 // (s_end < 0: all slices of every segment).  out: where the tile goes (dW, or a split-K slab); accumulate: out += tile.
-template <typename T, int BM, int BN, int TX, int D>
+template <typename T, int BM, int BN, int TX, int D, int KSTEP = 1>
 __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int tg, int split_idx, int nsplit, float* out, bool accumulate, char* smem) {
   constexpr int ES = (int)sizeof(T);
   constexpr int VE = 16 / ES;
-  constexpr int BKP = WGT<T>::BKP;
+  constexpr int BKP0 = WGT<T>::BKP;                      // pixels of one MFMA k step
+  constexpr int BKP = BKP0 * KSTEP;                      // pixels per slice (one barrier)
   constexpr int RB = BKP + TX - 1;                       // rows of the X image
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int LRA = BM * ES + WGT<T>::PADB, LRB = BN * ES + WGT<T>::PADB;
@@ -75,30 +76,34 @@ __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int t
     const char* b = a + BKP * LRA;
     if constexpr (sizeof(T) == 2) {
       // k mapping inside the 32-pixel slice: lane group g, half h, element e  <->  pixel 16 h + 4 g + e (both operands)
-      const int trow = 4 * fg + ((lane >> 2) & 3), tcol = 8 * (lane & 3);
-      uint4 fa[TM];
+      const int trow0 = 4 * fg + ((lane >> 2) & 3), tcol = 8 * (lane & 3);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const char* q = a + trow * LRA + (wm * WM + i * 16) * 2 + tcol;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRA));
-        fa[i] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-      }
+      for (int h = 0; h < KSTEP; ++h) {
+        const int trow = trow0 + h * 32;
+        uint4 fa[TM];
 #pragma unroll
-      for (int t = 0; t < TX; ++t) {
-        uint4 fb[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const char* q = b + (trow + t) * LRB + (wn * WN + j * 16) * 2 + tcol;
+        for (int i = 0; i < TM; ++i) {
+          const char* q = a + trow * LRA + (wm * WM + i * 16) * 2 + tcol;
           s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRB));
-          fb[j] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRA));
+          fa[i] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int t = 0; t < TX; ++t) {
+          uint4 fb[TN];
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[t][i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            const char* q = b + (trow + t) * LRB + (wn * WN + j * 16) * 2 + tcol;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * LRB));
+            fb[j] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[t][i][j], 0, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -252,8 +257,8 @@ __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int t
   }
 }
 
-template <typename T, int BM, int BN, int TX> constexpr size_t wgrad_lds() {
-  return 2 * (size_t)(WGT<T>::BKP * (BM * sizeof(T) + WGT<T>::PADB) + (WGT<T>::BKP + TX - 1) * (BN * sizeof(T) + WGT<T>::PADB));
+template <typename T, int BM, int BN, int TX, int KSTEP = 1> constexpr size_t wgrad_lds() {
+  return 2 * (size_t)(WGT<T>::BKP * KSTEP * (BM * sizeof(T) + WGT<T>::PADB) + (WGT<T>::BKP * KSTEP + TX - 1) * (BN * sizeof(T) + WGT<T>::PADB));
 }
 
 // ---- one problem per launch: grid (co tiles, taps x ci tiles, split) ----
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const wgp p, int cblocks, fl
 // ---- a whole backward stage per launch: problems in a device table, workgroup -> (problem, tile) through the tile prefix ----
 struct wg_prefix { int n; int tile0[L2S_WGRAD_MAX_GROUP + 1]; };
 
-template <typename T, int BM, int BN, int TX, int D>
+template <typename T, int BM, int BN, int TX, int D, int KSTEP>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const wgp* __restrict__ tab, const wg_prefix pre, float* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const wgp* __restric
   const int sp = t % split; t /= split;
   const int cot = t % co_tiles, rest = t / co_tiles, cit = rest % ci_tiles, tg = rest / ci_tiles;
   float* out = split > 1 ? ws + p.ws_off + (long)sp * ((long)p.Cout * p.KH * p.KW * p.Cin) : p.dw;
-  wgrad_tile<T, BM, BN, TX, D>(p, cot * BM, cit * BN, tg, sp, split, out, split == 1, smem);
+  wgrad_tile<T, BM, BN, TX, D, KSTEP>(p, cot * BM, cit * BN, tg, sp, split, out, split == 1, smem);
 }
 
 // problems of a grouped launch whose pixels were split: dW[e] += slab_0[e] + slab_1[e] + ... (fixed order); grid (blocks, problems)
@@ -358,9 +363,12 @@ int launch_single(const l2s_wgrad_desc& d, int split, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <typename T, int BM, int BN, int TX, int D>
+template <typename T, int BM, int BN, int TX, int D, int KSTEP>
 int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_split, hipStream_t st) {
-  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D>), dim3(pre.tile0[pre.n]), dim3(256), (wgrad_lds<T, BM, BN, TX>()), st, tab, pre, ws);
+  const size_t lds = wgrad_lds<T, BM, BN, TX, KSTEP>();
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP>), dim3(pre.tile0[pre.n]), dim3(256), lds, st, tab, pre, ws);
   if (any_split) {
     const float* wsc = ws;
     L2S_LAUNCH(wgrad_reduce_grouped_kernel, dim3(64, pre.n), dim3(256), 0, st, tab, wsc);
@@ -412,15 +420,17 @@ extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s
   pre.tile0[nprob] = (int)t;
   for (int i = nprob + 1; i <= L2S_WGRAD_MAX_GROUP; ++i) pre.tile0[i] = (int)t;
   // (ring depth 2: with several workgroups per CU the other workgroups cover a load's latency; fewer registers = more of them)
-#define GO(T)                                                                                    \
+  // KSTEP = MFMA k steps (32 pixels in bf16) per barrier: 2 (64-pixel slices) measured 137.4-139.7 vs 134.9-136.5 img/s for 1 (round 2)
+  static const int kstep = [] { const char* e = getenv("L2S_WGRAD_KSTEP"); return e ? atoi(e) : 2; }();
+#define GO(T, KS)                                                                                \
   switch (variant) {                                                                             \
-    case 0: return launch_grouped<T, 64, 64, 1, 2>(table_dev, pre, ws, any_split, stream);        \
-    case 1: return launch_grouped<T, 128, 128, 1, 2>(table_dev, pre, ws, any_split, stream);      \
-    case 2: return launch_grouped<T, 64, 64, 3, 2>(table_dev, pre, ws, any_split, stream);        \
-    default: return launch_grouped<T, 128, 64, 3, 2>(table_dev, pre, ws, any_split, stream);      \
+    case 0: return launch_grouped<T, 64, 64, 1, 2, KS>(table_dev, pre, ws, any_split, stream);    \
+    case 1: return launch_grouped<T, 128, 128, 1, 2, KS>(table_dev, pre, ws, any_split, stream);  \
+    case 2: return launch_grouped<T, 64, 64, 3, 2, KS>(table_dev, pre, ws, any_split, stream);    \
+    default: return launch_grouped<T, 128, 64, 3, 2, KS>(table_dev, pre, ws, any_split, stream);  \
   }
-  if (dtype == L2S_BF16) { GO(bf16_t) }
-  if (dtype == L2S_F32) { GO(float) }
+  if (dtype == L2S_BF16) { if (kstep == 2) { GO(bf16_t, 2) } else { GO(bf16_t, 1) } }
+  if (dtype == L2S_F32) { GO(float, 1) }
 #undef GO
   return L2S_EINVAL;
 }

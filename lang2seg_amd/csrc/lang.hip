@@ -2,14 +2,16 @@
 // the spatial dynamic-filter correlation and the att2in2 captioner core, forward + backward, fp32.
 // Reference: lib/layers/lang_encoder.py:27-82, lib/caption_models/AttModel.py:60-101,406-466,
 // lib/misc/utils.py:43-53, pyutils/mask-faster-rcnn/lib/nets/network_cycle_res5_2.py:504-562.
-// Everything here is GEMV-shaped (M = 1..21): weights are streamed once per call, one wave per output row,
-// wave-level shuffle reductions; HBM/L2-bandwidth- and latency-bound, no MFMA reshaping.
+// The recurrences are GEMV-shaped (M = 1): weights are streamed once per call, one wave per output row, wave-level shuffle
+// reductions; HBM/L2-bandwidth- and latency-bound.  The row-batch linears outside the recurrences (M = 21 tokens, 196 attention
+// locations) run on the exact-fp32 MFMA (linear_nt_mfma_kernel / linear_nn_mfma_kernel).
 #include "common.h"
 #include "../../include/lang2seg_hip.h"
 
 namespace {
 
 constexpr int MAXM = 24;   // rows handled per wave pass in the skinny kernels
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -576,20 +578,20 @@ __global__ __launch_bounds__(1024) void cap_att_bwd_step_kernel(const float* __r
   __shared__ float red[16];
   __shared__ float part[64][17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // dweight[l] = dres . att[l]: 16 waves x (L / 16) rows, two rows per trip so that four 16-byte loads are in flight per lane
-  for (int l = wv; l < L; l += 32) {
-    const int l2 = l + 16;
-    float s0 = 0.f, s1 = 0.f;
+  // dweight[l] = dres . att[l]: 16 waves x (L / 16) rows, ONE row per trip.  (Round 2: the two-rows-per-trip form -- two interleaved
+  // shuffle reductions whose results lane 0 stored with two LDS writes -- sporadically produced a wrong SECOND sum when other kernels
+  // shared the CU: the compiler consumes the last ds_bpermute of the second chain after `s_waitcnt lgkmcnt(1)` with the first
+  // ds_write already issued, i.e. it relies on a DS permute and a younger DS write retiring in order.  Found by the bit-reproducibility
+  // test; tools/scan_lgkm_order.py looks for the pattern in the generated ISA.)
+  for (int l = wv; l < L; l += 16) {
+    float s0 = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
       const float4 r = *(const float4*)(dres + d);
       const float4 a = *(const float4*)(att + (long)l * D + d);
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (l2 < L) b = *(const float4*)(att + (long)l2 * D + d);
       s0 = fmaf(a.x, r.x, fmaf(a.y, r.y, fmaf(a.z, r.z, fmaf(a.w, r.w, s0))));
-      s1 = fmaf(b.x, r.x, fmaf(b.y, r.y, fmaf(b.z, r.z, fmaf(b.w, r.w, s1))));
     }
-    s0 = wave_sum(s0); s1 = wave_sum(s1);
-    if (lane == 0) { dwl[l] = s0; if (l2 < L) dwl[l2] = s1; }
+    s0 = wave_sum(s0);
+    if (lane == 0) dwl[l] = s0;
   }
   __syncthreads();
   const float wl = tid < L ? weight[tid] : 0.f;
@@ -658,6 +660,151 @@ __global__ __launch_bounds__(256) void cap_att_bwd_batched_kernel(const float* _
     if (tid == 0) dab[0] += sb;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ void mul_inplace_kernel(float* dx, int lddx, const float* __restrict__ mul, int M, int K) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < (long)M * K) { const int m = (int)(i / K), k = (int)(i - (long)m * K); dx[(long)m * lddx + k] *= mul[(long)m * lddx + k]; }
+}
+// Row-batch linears on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: a lane holds A[l%16][l/16] and B[l/16][l%16], D rows 4(l/16)+r).
+// The wave-per-output kernels above re-read the x block per output and leave the 21 x 3350 x 512 logit layer at 40-200 us; these
+// stream every weight exactly once with 16-byte loads, 4 k (or n) per lane per load: the MFMA's k index is a permutation of memory
+// order, the same permutation on both operands.
+//
+// NT: y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y)).  Workgroup = one 16-column tile x MT 16-row tiles; its 4 waves split K.
+template <int MT>
+__global__ __launch_bounds__(256) void linear_nt_mfma_kernel(const float* __restrict__ x, int ldx_, const float* __restrict__ w, int ldw,
+                                                            const float* __restrict__ b, float* y, int ldy, int M, int N, int K,
+                                                            int act, int accumulate) {
+  __shared__ float red[4][MT][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
+  const float* wr = w + (long)min(n0 + j, N - 1) * ldw;
+  const float* xr[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) xr[t] = x + (long)min(m0 + 16 * t + j, M - 1) * ldx_;
+  floatx4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int kper = ((K + 63) / 64) * 16;                  // K range of one wave, a multiple of 16
+  const int kb = wv * kper, ke = min(K, kb + kper);
+#pragma unroll 4
+  for (int k = kb; k < ke; k += 16) {
+    const int kk = k + 4 * kq;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), av[MT];
+    const bool in = kk < ke;                              // K % 4 == 0: a lane's four k are all inside or all outside
+    if (in) bv = *(const float4*)(wr + kk);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) av[t] = in ? *(const float4*)(xr[t] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv.x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv.y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].z, bv.z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv.w, acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][t][r][lane] = acc[t][r];
+  __syncthreads();
+  // wave wv finishes register r = wv of every tile: row 4 (lane/16) + r, column lane % 16
+  const int n = n0 + j;
+  if (n < N) {
+    const float bias = b ? b[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + 16 * t + 4 * kq + wv;
+      if (m < M) {
+        float v = ((red[0][t][wv][lane] + red[1][t][wv][lane]) + red[2][t][wv][lane]) + red[3][t][wv][lane] + bias;
+        float* o = y + (long)m * ldy + n;
+        if (accumulate) v += *o;
+        *o = act_apply(v, act);
+      }
+    }
+  }
+}
+
+// NN: dx[m][k] (+)= (sum_n dy[m][n] w[n][k]) (* mul[m][k]) from the weight as stored (no transposed copy).  A wave owns 64 output columns
+// as four interleaved 16-column tiles (column k0 + 4 (lane%16) + q belongs to tile q: one 16-byte load of a weight row feeds four
+// MFMAs), MT 16-row tiles, and a share of the contraction range; workgroup = 4 waves (LDS sum), grid.y = further split of n whose
+// partial sums go to `ws` and are added in order by linear_nn_reduce_kernel (no atomics).
+template <int MT>
+__global__ __launch_bounds__(256) void linear_nn_mfma_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w, float* dx,
+                                                            int lddx, int M, int N, int K, int accumulate, const float* __restrict__ mul,
+                                                            float* ws, int nper) {
+  __shared__ float red[4][MT * 4][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+  const int k0 = blockIdx.x * 64, m0 = blockIdx.z * (16 * MT);
+  const int nb0 = blockIdx.y * nper, ne0 = min(N, nb0 + nper);
+  const int wper = ((ne0 - nb0 + 63) / 64) * 16;          // n range of one wave, a multiple of 16
+  const int nb = nb0 + wv * wper, ne = min(ne0, nb + wper);
+  const int kc = min(k0 + 4 * j, K - 4);                  // K % 4 == 0; columns past K are computed on a clamped address and not stored
+  const float* dyr[MT]; bool rv[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) { const int m = m0 + 16 * t + j; rv[t] = m < M; dyr[t] = dy + (long)min(m, M - 1) * lddy; }
+  floatx4 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[t][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int n = nb; n < ne; n += 16) {
+    float4 bv[4]; float av[MT][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int nn = n + 4 * kq + e;
+      bv[e] = *(const float4*)(w + (long)min(nn, N - 1) * K + kc);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) av[t][e] = (nn < ne && rv[t]) ? dyr[t][nn] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], bv[e].x, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], bv[e].y, acc[t][1], 0, 0, 0);
+        acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], bv[e].z, acc[t][2], 0, 0, 0);
+        acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][e], bv[e].w, acc[t][3], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wv][t * 4 + q][r][lane] = acc[t][q][r];
+  __syncthreads();
+  // wave wv finishes the (tile, column set) pairs p = wv, wv + 4, ...: row 4 (lane/16) + r, column k0 + 4 (lane%16) + q
+  const int Mpad = gridDim.z * 16 * MT;
+  for (int p = wv; p < MT * 4; p += 4) {
+    const int t = p >> 2, q = p & 3;
+    const int kcol = k0 + 4 * j + q;
+    if (kcol >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * t + 4 * kq + r;
+      if (m >= M) continue;
+      float v = ((red[0][p][r][lane] + red[1][p][r][lane]) + red[2][p][r][lane]) + red[3][p][r][lane];
+      if (gridDim.y > 1) { ws[((long)blockIdx.y * Mpad + m) * K + kcol] = v; continue; }
+      if (mul) v *= mul[(long)m * lddx + kcol];
+      float* o = dx + (long)m * lddx + kcol;
+      *o = accumulate ? *o + v : v;
+    }
+  }
+}
+__global__ void linear_nn_reduce_kernel(const float* __restrict__ ws, int nsplit, int Mpad, float* dx, int lddx, int M, int K, int accumulate,
+                                        const float* __restrict__ mul) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)M * K) return;
+  const int m = (int)(i / K), k = (int)(i - (long)m * K);
+  float v = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) v += ws[((long)sp * Mpad + m) * K + k];
+  if (mul) v *= mul[(long)m * lddx + k];
+  float* o = dx + (long)m * lddx + k;
+  *o = accumulate ? *o + v : v;
+}
 }  // namespace
 
 extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw, const float* b, float* y, int ldy, int M, int N, int K, int act,
@@ -665,6 +812,13 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw,
   if (M <= 0 || N <= 0) return L2S_OK;
   const bool v4 = !((K & 3) || (ldx_ & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15));
   const bool v2 = !((K & 1) || (ldx_ & 1) || (ldw & 1) || ((uintptr_t)x & 7) || ((uintptr_t)w & 7));
+  static const int mfma_on = [] { const char* e = getenv("L2S_LINEAR_MFMA"); return e ? atoi(e) : 1; }();
+  if (mfma_on && v4 && M >= 2) {
+    // row batches: exact-fp32 MFMA tiles, every weight read once
+    if (M <= 16) L2S_LAUNCH((linear_nt_mfma_kernel<1>), dim3(cdiv(N, 16), 1), dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, M, N, K, act, accumulate);
+    else L2S_LAUNCH((linear_nt_mfma_kernel<2>), dim3(cdiv(N, 16), cdiv(M, 32)), dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, M, N, K, act, accumulate);
+    return l2s_check_launch();
+  }
   {
     const int m0 = 0;
     // one output per wave for a single row (GEMV: nothing to reuse), four outputs per wave for row batches
@@ -679,11 +833,38 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw,
   }
   return l2s_check_launch();
 }
-extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate, hipStream_t s) {
+// n-splits of the NN kernel for (M, N, K): enough workgroups to reach ~128, at least 64 n per workgroup
+static int nn_split(int M, int N, int K) {
+  const int tiles = cdiv(K, 64) * cdiv(M, 32);
+  int sp = 128 / (tiles > 0 ? tiles : 1);
+  const int maxsp = N / 64;
+  if (sp > maxsp) sp = maxsp;
+  if (sp > 32) sp = 32;
+  return sp < 1 ? 1 : sp;
+}
+extern "C" long l2s_linear_bwd_x_ws_floats(int M, int N, int K) {
+  const int sp = nn_split(M, N, K);
+  return sp > 1 ? (long)sp * cdiv(M, 32) * 32 * K : 0;
+}
+extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate,
+                                const float* mul, float* ws, long ws_floats, hipStream_t s) {
   if (M <= 0) return L2S_OK;
+  static const int mfma_on = [] { const char* e = getenv("L2S_LINEAR_MFMA"); return e ? atoi(e) : 1; }();
+  if (mfma_on && M >= 2 && !(K & 3) && !((uintptr_t)w & 15) && K >= 4) {
+    int sp = nn_split(M, N, K);
+    const int mch = cdiv(M, 32), Mpad = mch * 32;
+    if (!ws || ws_floats < (long)sp * Mpad * K) sp = 1;
+    const int nper = cdiv(cdiv(N, sp), 16) * 16;
+    sp = cdiv(N, nper);
+    if (M <= 16 && sp == 1) L2S_LAUNCH((linear_nn_mfma_kernel<1>), dim3(cdiv(K, 64), 1, cdiv(M, 16)), dim3(256), 0, s, dy, lddy, w, dx, lddx, M, N, K, accumulate, mul, ws, nper);
+    else L2S_LAUNCH((linear_nn_mfma_kernel<2>), dim3(cdiv(K, 64), sp, mch), dim3(256), 0, s, dy, lddy, w, dx, lddx, M, N, K, accumulate, mul, ws, nper);
+    if (sp > 1) L2S_LAUNCH(linear_nn_reduce_kernel, dim3(cdiv((long)M * K, 256)), dim3(256), 0, s, (const float*)ws, sp, Mpad, dx, lddx, M, K, accumulate, mul);
+    return l2s_check_launch();
+  }
   dim3 grid(cdiv(K, 64));
   if (M == 1) L2S_LAUNCH(gemvT_kernel<1>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, 0, M, N, K, accumulate);
   else for (int m0 = 0; m0 < M; m0 += 8) L2S_LAUNCH(gemvT_kernel<8>, grid, dim3(1024), 0, s, dy, lddy, w, dx, lddx, m0, M, N, K, accumulate);
+  if (mul) L2S_LAUNCH(mul_inplace_kernel, dim3(cdiv((long)M * K, 256)), dim3(256), 0, s, dx, lddx, mul, M, K);
   return l2s_check_launch();
 }
 extern "C" int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx_, float* dw, float* db, int M, int N, int K, hipStream_t s) {
@@ -803,3 +984,4 @@ extern "C" int l2s_logsoftmax_nll(const float* logits, const int64_t* target, co
   L2S_LAUNCH(lsm_nll_kernel, dim3(S), dim3(1024), 0, s, logits, target, mask, S, V1, gscale, loss_slot, dlogits, logprobs_opt);
   return l2s_check_launch();
 }
+

@@ -404,6 +404,7 @@ __global__ void mask_downsample_kernel(const uint8_t* mask, float* out, int H, i
 }
 
 __global__ void counter_inc_kernel(uint64_t* c) { *c += 1; }
+__global__ void stamp_kernel(uint64_t* out) { *out = wall_clock64(); }   // constant 100 MHz device clock
 __global__ void dropout_kernel(float* m, long n, float p, const uint64_t* seed_dev, uint64_t salt) {
   const uint64_t seed = mix64(*seed_dev * 0x9E3779B97F4A7C15ull + salt);
   const float keep = 1.f - p, inv = keep > 0.f ? 1.f / keep : 0.f;
@@ -568,6 +569,10 @@ extern "C" int l2s_mask_downsample(const uint8_t* mask, float* out, int H, int W
 }
 extern "C" int l2s_counter_inc(uint64_t* counter_dev, hipStream_t s) {
   L2S_LAUNCH(counter_inc_kernel, dim3(1), dim3(1), 0, s, counter_dev);
+  return l2s_check_launch();
+}
+extern "C" int l2s_stamp(uint64_t* slot_dev, hipStream_t s) {
+  L2S_LAUNCH(stamp_kernel, dim3(1), dim3(1), 0, s, slot_dev);
   return l2s_check_launch();
 }
 extern "C" int l2s_dropout_mask(float* mask, long n, float p, const uint64_t* seed_dev, uint64_t salt, hipStream_t s) {

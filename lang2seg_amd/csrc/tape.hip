@@ -118,10 +118,32 @@ extern "C" int l2s_stream_fork(hipStream_t from, hipStream_t to) {
   }
   return L2S_OK;
 }
+// Clears are ordinary kernel launches (recorded on the tape like every other launch; word-aligned ranges only).
+__global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* p, size_t nwords, uint32_t v) {
+  size_t head = ((16 - ((uintptr_t)p & 15)) & 15) >> 2;
+  if (head > nwords) head = nwords;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nthreads = gridDim.x * (size_t)blockDim.x;
+  if (i < head) p[i] = v;
+  uint4* q = (uint4*)(p + head);
+  const size_t nq = (nwords - head) >> 2;
+  for (size_t j = i; j < nq; j += nthreads) q[j] = make_uint4(v, v, v, v);
+  const size_t tail0 = head + (nq << 2);
+  if (i < nwords - tail0) p[tail0 + i] = v;
+}
 extern "C" int l2s_memset_async(void* p, int value, size_t bytes, hipStream_t s) {
   if (bytes == 0) return L2S_OK;
-  if (recording()) record(s, [=](hipStream_t s_) { (void)hipMemsetAsync(p, value, bytes, s_); });
-  return hipMemsetAsync(p, value, bytes, s) == hipSuccess ? L2S_OK : L2S_ELAUNCH;
+  if (((uintptr_t)p & 3) || (bytes & 3)) {
+    // byte-granular clears (none on the train-step path) stay with the runtime
+    if (recording()) record(s, [=](hipStream_t s_) { (void)hipMemsetAsync(p, value, bytes, s_); });
+    return hipMemsetAsync(p, value, bytes, s) == hipSuccess ? L2S_OK : L2S_ELAUNCH;
+  }
+  const uint32_t b = (uint32_t)value & 0xffu, v = b | (b << 8) | (b << 16) | (b << 24);
+  const size_t nwords = bytes >> 2;
+  size_t blocks = (nwords / 4 + 255) / 256;                 // one 16-byte store per thread up to 8192 workgroups, then a grid-stride loop
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  L2S_LAUNCH(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)p, nwords, v);
+  return l2s_check_launch();
 }
 extern "C" int l2s_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
   if (bytes == 0) return L2S_OK;

@@ -329,6 +329,10 @@ class Network(object):
     def join_wgrad(self):
         self.flush_wgrads('final')
         if self.use_streams:
+            if getattr(self, 'stamp_buf', None) is not None:
+                for k in ('wg', 'wg2'):
+                    with torch.cuda.stream(self.streams()[k]):
+                        self._mark('%s stream done' % k)
             self.sfork(self.streams()['wg'], torch.cuda.current_stream())
             self.sfork(self.streams()['wg2'], torch.cuda.current_stream())
 
@@ -376,6 +380,7 @@ class Network(object):
                 if dp is not None:
                     O.tape_mark(); self._tape_stages.append('finish'); dp.finish()
                 train_op.step()
+                self._mark('optimiser')
             finally:
                 O.tape_end(h)
                 self._rec_key = None
@@ -431,6 +436,9 @@ class Network(object):
         pe = getattr(self, 'phase_events', None)
         if pe is not None:
             e = torch.cuda.Event(enable_timing=True); e.record(); pe.append((name, e))
+        sb = getattr(self, 'stamp_buf', None)                    # tools/step_timeline.py: device clock stamps, recorded on the tape like any launch
+        if sb is not None and len(self.stamp_names) < sb.numel():
+            O.stamp(sb, len(self.stamp_names)); self.stamp_names.append(name)
 
     def seed_counter(self):
         c = getattr(self, '_seed_counter', None)

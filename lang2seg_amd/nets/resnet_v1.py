@@ -5,6 +5,7 @@ nets/network_cycle_res5_2.py ("NET"), on the MI355X kernels.  Constructor, `crea
 
 Citations: ENC = lib/layers/lang_encoder.py, ATT = lib/caption_models/AttModel.py,
 CRIT = lib/misc/utils.py, PL/ATL/PTL = layer_utils/{proposal,anchor_target,proposal_target}_layer.py."""
+import os
 import numpy as np
 import torch
 
@@ -125,22 +126,32 @@ class resnetv1(Network):
             self.extra_transposes.append(e)
             if dst is None:
                 self.wT[name] = (e.wb, N, K)
+        # only the matrices whose data gradient is taken one row at a time (inside a recurrence); row batches use bwd_x's MFMA path
         for sfx in ['', '_reverse']:
-            for w in ['rnn_encoder.rnn.weight_hh_l0', 'rnn_encoder.rnn.weight_ih_l0']:
-                add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
-        capk = ['caption_model.logit.weight', 'caption_model.core.a2c.weight', 'caption_model.core.h2h.weight',
-                'caption_model.core.attention.h2att.weight', 'caption_model.core.i2h.weight', 'caption_model.ctx2att.weight']
-        for k in ['rnn_encoder.mlp.0.weight'] + (capk if self.var['cap'] is not None else []):
+            w = 'rnn_encoder.rnn.weight_hh_l0'
+            add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
+        capk = ['caption_model.core.a2c.weight', 'caption_model.core.h2h.weight', 'caption_model.core.attention.h2att.weight']
+        for k in (capk if self.var['cap'] is not None else []):
             add(k, P.view(k), *P.shapes[k])
         NF, HD = self._NFP, P.shapes['rnn_encoder.rnn.weight_hh_l0'][1] * 2
         add('dyn_w', P.gview('dyn_w', NF * HD), NF, HD)
         # 2x2 deconv: its forward operand [(dy,dx,co)][ci] is the transpose of the master [ci][(dy,dx,co)] (activation dtype)
         add('mask_up', P.view('mask_up_sampling.weight'), 2048, 4 * 256, dst=self.up_wT, f32=0)
 
-    def bwd_x(self, dy, name, dx, M, accumulate=False, lddy=None):
-        """dx[M][K] (+)= dy[M][N] . W[N][K] using the transposed copy."""
-        wT, N, K = self.wT[name]
-        O.linear_fwd(dy, wT, None, dx, M, K, N, accumulate=accumulate, ldx=N if lddy is None else lddy, ldw=N)
+    def bwd_x(self, dy, name, dx, M, accumulate=False, lddy=None, mul=None):
+        """dx[M][K] (+)= (dy[M][N] . W[N][K]) (* mul).  One row (inside the recurrences): the transposed copy through the
+        one-wave-per-output GEMV; row batches: the MFMA kernel on the weight as stored (no copy)."""
+        if M == 1 and name in self.wT:
+            assert mul is None
+            wT, N, K = self.wT[name]
+            O.linear_fwd(dy, wT, None, dx, M, K, N, accumulate=accumulate, ldx=N if lddy is None else lddy, ldw=N)
+            return
+        P = self.P
+        w = P.view(name)
+        N, K = P.shapes[name]
+        nws = O.linear_bwd_x_ws_floats(M, N, K)
+        ws = self.buf('bwdx.ws.' + name, (nws,), f32) if nws else None
+        O.linear_bwd_x(dy, w, dx, M, N, K, accumulate=accumulate, lddy=lddy, mul=mul, ws=ws)
 
     def refresh_weights(self, full=False):
         if not hasattr(self, 'extra_transposes'):
@@ -291,15 +302,19 @@ class resnetv1(Network):
         tanh_ws = self.buf('cap.tanh', (S, L, AH), f32); wgt = self.buf('cap.wgt', (S, L), f32)
         ares = self.buf('cap.ares', (S, R + SC), f32)
         dlogits, ad = t['cap.dlogits'], t['cap.ad']
-        O.linear_bwd_w(dlogits, t['cap.ho'], gv('logit.weight'), gv('logit.bias'), S, V1, R)
+        # Only d(att_feats) is on the step's critical path (the main queue waits for it at the caption join): the parameter
+        # gradients that nothing downstream reads are collected in `later` and issued after the branch has produced its result
+        # (caption_branch: on the language stream, behind the join point).
+        later = self._cap_deferred = []
+        later.append(lambda: O.linear_bwd_w(dlogits, t['cap.ho'], gv('logit.weight'), gv('logit.bias'), S, V1, R))
         dho = self.buf('cap.dho', (S, R), f32)
-        self.bwd_x(dlogits, 'caption_model.logit.weight', dho, S)
-        if t['cap.drop_out'] is not None:
-            O.mul(dho, t['cap.drop_out'], dho)
+        self.bwd_x(dlogits, 'caption_model.logit.weight', dho, S, mul=t['cap.drop_out'])
         dsums = self.buf('cap.dsums', (S, 5 * R), f32); da2c = self.buf('cap.da2c', (S, 2 * R), f32)
         datt_h = self.buf('cap.datt_h', (S, AH + SC), f32); dares = self.buf('cap.dares', (S, R), f32); ddot = self.buf('cap.ddot', (S, L), f32)
-        dpatt = self.buf('cap.dpatt', (L, AH), f32, zero=True); dad = self.buf('cap.dad', (L, R), f32, zero=True)
-        dh = self.buf('cap.dh', (2, R), f32, zero=True); dc = self.buf('cap.dc', (2, R), f32, zero=True)
+        # dpatt | dad | dh | dc: one buffer, one clear
+        zb = self.buf('cap.bwd_zero', (L * AH + L * R + 4 * R,), f32, zero=True)
+        dpatt = zb[:L * AH].view(L, AH); dad = zb[L * AH:L * AH + L * R].view(L, R)
+        dh = zb[L * AH + L * R:L * AH + L * R + 2 * R].view(2, R); dc = zb[L * AH + L * R + 2 * R:].view(2, R)
         wT_h2h = self.wT['caption_model.core.h2h.weight'][0]; wT_h2att = self.wT['caption_model.core.attention.h2att.weight'][0]
         k = 0
         for i in range(S - 1, -1, -1):
@@ -313,18 +328,21 @@ class resnetv1(Network):
         O.cap_attention_bwd_batched(ddot, wgt, dares, R, tanh_ws, pv('core.attention.alpha_net.weight'), S, L, AH, dpatt, dad,
                                     gv('core.attention.alpha_net.weight'), gv('core.attention.alpha_net.bias'))
         hprev = hs[0:S]
-        O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R, ldx=R + SC)
-        O.linear_bwd_w(dsums, hprev, gv('core.h2h.weight'), gv('core.h2h.bias'), S, 5 * R, R)
-        O.linear_bwd_w(datt_h, hprev, gv('core.attention.h2att.weight'), gv('core.attention.h2att.bias'), S, AH, R, lddy=AH + SC)
-        O.linear_bwd_w(dsums, t['cap.xt'], gv('core.i2h.weight'), gv('core.i2h.bias'), S, 5 * R, IE)
-        dxt = self.buf('cap.dxt', (S, IE), f32)
-        self.bwd_x(dsums, 'caption_model.core.i2h.weight', dxt, S)
-        O.embed_bwd(dxt, t['cap.xt'], d['cap_in'], t['cap.drop_xt'], gv('embed.0.weight'), S, IE, True)
+
+        def recurrence_grads():
+            O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R, ldx=R + SC)
+            O.linear_bwd_w(dsums, hprev, gv('core.h2h.weight'), gv('core.h2h.bias'), S, 5 * R, R)
+            O.linear_bwd_w(datt_h, hprev, gv('core.attention.h2att.weight'), gv('core.attention.h2att.bias'), S, AH, R, lddy=AH + SC)
+            O.linear_bwd_w(dsums, t['cap.xt'], gv('core.i2h.weight'), gv('core.i2h.bias'), S, 5 * R, IE)
+            dxt = self.buf('cap.dxt', (S, IE), f32)
+            self.bwd_x(dsums, 'caption_model.core.i2h.weight', dxt, S)
+            O.embed_bwd(dxt, t['cap.xt'], d['cap_in'], t['cap.drop_xt'], gv('embed.0.weight'), S, IE, True)
+            O.linear_bwd_w(dpatt, ad, gv('ctx2att.weight'), gv('ctx2att.bias'), L, AH, R)
+        later.append(recurrence_grads)
         # ctx2att
-        O.linear_bwd_w(dpatt, ad, gv('ctx2att.weight'), gv('ctx2att.bias'), L, AH, R)
         self.bwd_x(dpatt, 'caption_model.ctx2att.weight', dad, L, accumulate=True)
         if t['cap.drop_att'] is not None:
-            O.mul(dad, t['cap.drop_att'], dad)
+            O.mul(dad, t['cap.drop_att'], dad)                 # (the mask multiplies the accumulated sum, not only this term)
         O.act_bwd(dad, t['cap.a_pre'], 1)
         dadT = self.buf('cap.dadT', (L, R))
         O.cast(dad, dadT)
@@ -493,6 +511,7 @@ class resnetv1(Network):
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
         im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
         self._im_hw = (im_h, im_w)
+        self._mark('step start')
         O.memset_zero(P.grad)
         O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
         loss = self.buf('loss', (8,), f32, zero=True)
@@ -584,17 +603,29 @@ class resnetv1(Network):
             datt = self._caption_bwd(d, att)
             self._mark('cap: captioner bwd')
             yield
+            def deferred_grads():
+                # captioner parameter gradients off the critical path: on the language stream (idle here), ordered after this branch
+                if S is not None:
+                    self.sfork(S['cap'], S['lang'])
+                with on('lang'):
+                    for f in self._cap_deferred:
+                        f()
+                    self._mark('cap: deferred parameter gradients (lang)')
+                self._cap_deferred = []
             g = self.buf('l4m.g', (HW, 2048))
             if self.var['cap'] == 'mask':
                 O.adaptive_pool_bwd(datt, AF, 0, 2048, gm, g, feats, Hc, Wc, 2048, 14, 14)
                 r = l4_on_map_bwd(g, 'l4m')
                 self._mark('cap: pool bwd + layer4 on map dgrad')
+                deferred_grads()
                 return r, None
             gb = self.buf('l4b.g', (HW, 2048))
             O.adaptive_pool_bwd(datt, AF, 0, 0, None, gb, feats_b, Hc, Wc, 2048, 14, 14)
             O.adaptive_pool_bwd(datt, AF, 2048, 0, None, g, feats, Hc, Wc, 2048, 14, 14)
             d_base_cap = l4_on_map_bwd(gb, 'l4b', in_relu=True)
-            return l4_on_map_bwd(g, 'l4m'), d_base_cap
+            r = l4_on_map_bwd(g, 'l4m')
+            deferred_grads()
+            return r, d_base_cap
         cap_state = dict(gen=None, out=(None, None))
         if self.var['cap'] is not None:
             if S is not None:
@@ -698,6 +729,7 @@ class resnetv1(Network):
         self.rpn_conv.wgrad(drpn, net_conv, 1, Hc, Wc)
         d_nc_rpn = self.buf('rpn.dnc', (HW, C4))
         self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
+        self._mark('rpn bwd (main reaches the caption join)')
         if S is not None and self.var['cap'] is not None:
             self.sfork(S['cap'], main)                     # join the caption branch
         O.total_loss(loss, self._cap_loss_weight)
@@ -712,7 +744,7 @@ class resnetv1(Network):
             O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)
         else:
             O.add3(d_nc_rpn, None, d_nc_roi, d_nc)        # (dtype, -, fp32) operands
-        self._mark('rpn bwd + add3')
+        self._mark('caption join + add3')
         # dynamic filters (NET:504-562)
         dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (O.dynfilter_ws_floats(Hc, Wc, C4),), f32)
         O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4,

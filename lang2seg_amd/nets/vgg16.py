@@ -97,10 +97,9 @@ class vgg16(resnetv1):
             e.wb = torch.zeros(K * N, dtype=torch.float32, device=self.device)
             self.extra_transposes.append(e)
             self.wT[name] = (e.wb, N, K)
-        for sfx in ['', '_reverse']:
-            for w in ['rnn_encoder.rnn.weight_hh_l0', 'rnn_encoder.rnn.weight_ih_l0']:
-                add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
-        add('rnn_encoder.mlp.0.weight', P.view('rnn_encoder.mlp.0.weight'), *P.shapes['rnn_encoder.mlp.0.weight'])
+        for sfx in ['', '_reverse']:                         # (row-batch data gradients need no copy: resnet_v1.bwd_x)
+            w = 'rnn_encoder.rnn.weight_hh_l0'
+            add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
         NF, HD = self._NFP, P.shapes['rnn_encoder.rnn.weight_hh_l0'][1] * 2
         add('dyn_w', P.gview('dyn_w', NF * HD), NF, HD)
 

@@ -224,6 +224,11 @@ def counter_inc(counter):
     call('l2s_counter_inc', ptr(counter), stream())
 
 
+def stamp(buf, slot):
+    """diagnostics: element `slot` of the int64 tensor `buf` receives the device clock (100 MHz) when the current stream gets here"""
+    call('l2s_stamp', buf.data_ptr() + 8 * int(slot), stream())
+
+
 def dropout_mask(mask, p, seed_dev, salt):
     call('l2s_dropout_mask', ptr(mask), mask.numel(), float(p), ptr(seed_dev), int(salt), stream())
 
@@ -324,9 +329,14 @@ def linear_fwd(x, w, b, y, M, N, K, act=0, accumulate=False, ldx=None, ldy=None,
          N if ldy is None else ldy, M, N, K, act, 1 if accumulate else 0, stream())
 
 
-def linear_bwd_x(dy, w, dx, M, N, K, accumulate=False, lddy=None, lddx=None):
+def linear_bwd_x(dy, w, dx, M, N, K, accumulate=False, lddy=None, lddx=None, mul=None, ws=None):
+    """dx[M][K] (+)= (dy[M][N] . w[N][K]) (* mul); ws: float tensor of linear_bwd_x_ws_floats(M, N, K) for the split contraction"""
     call('l2s_linear_bwd_x', ptr(dy), N if lddy is None else lddy, ptr(w), ptr(dx), K if lddx is None else lddx, M, N, K,
-         1 if accumulate else 0, stream())
+         1 if accumulate else 0, ptr(mul), ptr(ws), 0 if ws is None else ws.numel(), stream())
+
+
+def linear_bwd_x_ws_floats(M, N, K):
+    return int(_lib.load().l2s_linear_bwd_x_ws_floats(M, N, K))
 
 
 def linear_bwd_w(dy, x, dw, db, M, N, K, lddy=None, ldx=None):

@@ -360,3 +360,14 @@ def test_bench_gpus_flag_spawns_ranks():
     env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launcher-check'], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_no_permute_result_consumed_behind_a_younger_lds_write():
+    """ISA check (tools/scan_lgkm_order.py): no kernel consumes a ds_bpermute result while a younger ds_write of the same wave may still be
+    outstanding -- the instruction pattern behind round 2's sporadically wrong attention-backward sums."""
+    import shutil
+    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+        pytest.skip('no hipcc')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import scan_lgkm_order
+    assert scan_lgkm_order.main() == 0

@@ -730,6 +730,44 @@ def test_losses():
     assert abs(loss[6].item() - 18.0) < 1e-6
 
 
+def test_row_batch_linears_mfma():
+    """row batches (21 tokens, 196 attention locations) of the fp32 linears: exact-fp32 MFMA kernels, forward (bias / activation /
+    accumulate, ragged M and N) and data gradient from the weight as stored (split contraction through a workspace, fused mask,
+    accumulate); tolerance 1e-5 relative to the fp64 product (fp32 products, fp32 accumulation in a different order than torch's)."""
+    O = ops()
+    g = torch.Generator().manual_seed(19)
+    for (M, N, K, act, acc) in [(21, 3350, 512, 0, False), (196, 512, 512, 0, False), (21, 2560, 512, 0, True), (2, 16, 16, 2, False),
+                                (17, 100, 2560, 1, False), (33, 50, 36, 0, True), (196, 512, 4096, 1, False)]:
+        x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / np.sqrt(K); b = torch.randn(N, generator=g)
+        y0 = torch.randn(M, N, generator=g)
+        pre = (x.double() @ w.double().t() + b.double() + (y0.double() if acc else 0.0))
+        ref = pre if act == 0 else (pre.clamp(min=0) if act == 1 else torch.tanh(pre))
+        y = y0.to(DEV).clone()
+        O.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), y, M, N, K, act, accumulate=acc)
+        torch.cuda.synchronize()
+        assert rel_err(y, ref.float()) < 1e-5, (M, N, K, act, acc)
+    for (M, N, K, use_ws, use_mul, acc) in [(21, 3350, 512, True, True, False), (21, 3350, 512, False, False, False), (196, 512, 512, True, False, True),
+                                            (5, 70, 36, True, True, True), (21, 2560, 512, True, False, False), (40, 130, 200, False, True, False)]:
+        dy = torch.randn(M, N, generator=g); w = torch.randn(N, K, generator=g) / np.sqrt(N)
+        mul = (torch.rand(M, K, generator=g) > 0.5).float() * 2 if use_mul else None
+        dx0 = torch.randn(M, K, generator=g)
+        ref = dy.double() @ w.double()
+        if mul is not None:
+            ref = ref * mul.double()
+        if acc:
+            ref = ref + dx0.double()
+        dx = dx0.to(DEV).clone()
+        nws = O.linear_bwd_x_ws_floats(M, N, K)
+        ws = torch.full((max(nws, 1),), float('nan'), device=DEV) if (use_ws and nws) else None
+        O.linear_bwd_x(dy.to(DEV), w.to(DEV), dx, M, N, K, accumulate=acc, mul=None if mul is None else mul.to(DEV), ws=ws)
+        torch.cuda.synchronize()
+        assert rel_err(dx, ref.float()) < 1e-5, (M, N, K, use_ws, use_mul, acc)
+        dx2 = dx0.to(DEV).clone()                              # bit-identical when repeated (no atomics)
+        O.linear_bwd_x(dy.to(DEV), w.to(DEV), dx2, M, N, K, accumulate=acc, mul=None if mul is None else mul.to(DEV), ws=ws)
+        torch.cuda.synchronize()
+        assert torch.equal(dx, dx2)
+
+
 def test_linear_embed_lstm():
     O = ops()
     g = torch.Generator().manual_seed(9)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""When each stream of the REPLAYED train step reaches its phase marks, on the device's own clock and without a profiler.
+
+Every Network._mark() site becomes a one-thread launch that stores the 100 MHz device clock (l2s_stamp) on whatever stream is
+current there; the stamps are recorded on the launch tape like any other launch, so the numbers are those of the normal replayed
+step (+ ~30 one-thread launches).  Shows which stream the main queue waits for at the caption join and how long the
+weight-gradient streams run past the end of the backward pass.
+
+    python tools/step_timeline.py [--steps 40] [--knockout wgrad,cap]
+"""
+import sys, os, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--knockout', default='')
+    args = ap.parse_args()
+    from lang2seg_amd.model.config import cfg
+    from lang2seg_amd.nets.resnet_v1 import resnetv1
+    from lang2seg_amd.optim import SGD
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    T, V = 20, 3349
+    cfg.COMPUTE_DTYPE = 'bf16'
+    opt = dict(vocab_size=V, word_embedding_size=512, word_vec_size=512, rnn_hidden_size=512, bidirectional=1, word_drop_out=0.5,
+               rnn_drop_out=0.2, rnn_num_layers=1, rnn_type='lstm', variable_lengths=1, C4_feat_dim=1024, cap_loss_weight=1.0,
+               caption_model='att2in2', input_encoding_size=512, rnn_size=512, num_layers=1, drop_prob_lm=0.5, seq_length=T,
+               fc_feat_size=4096, att_feat_size=4096, att_hid_size=512)
+    np.random.seed(cfg.RNG_SEED)
+    net = resnetv1(opt, batch_size=1, num_layers=101)
+    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    net.train()
+    optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY)
+    blob = SyntheticLoader(num_images=1, sents_per_image=1, H=600, W=1000, T=T, vocab_size=V).getBatch('train')
+    net.upload_blob(blob, 0)
+    net.knockout = frozenset(x for x in args.knockout.split(',') if x)
+    net.use_tape = True
+    net.stamp_buf = torch.zeros(96, dtype=torch.int64, device='cuda')
+    net.stamp_names = []
+    acc = []
+    for i in range(args.steps + 5):
+        net.train_step_async(blob, 0, optim)
+        torch.cuda.synchronize()
+        if i >= 5:
+            acc.append(net.stamp_buf[:len(net.stamp_names)].cpu().numpy().astype(np.int64))
+    a = np.stack(acc)                                    # [steps, marks] ticks of 10 ns
+    names = net.stamp_names
+    i0 = names.index('step start')
+    rel = (a - a[:, i0:i0 + 1]) * 0.01                   # us since the step's first launch
+    med = np.median(rel, 0)
+    order = np.argsort(med)
+    print('%-52s %10s %10s' % ('mark (stream order within the step)', 'median us', 'p90 us'))
+    for j in order:
+        print('%-52s %10.1f %10.1f' % (names[j], med[j], np.percentile(rel[:, j], 90)))
+
+
+if __name__ == '__main__':
+    main()
