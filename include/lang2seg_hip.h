@@ -323,6 +323,19 @@ int l2s_linear_sum2_fwd(const float* x1, const float* w1 /*[N][K1]*/, int K1, co
                         int accumulate, hipStream_t s);
 int l2s_cap_a2c_gates_fwd(const float* att_res, const float* w_a2c /*[2R][K]*/, const float* b_a2c, int K, const float* sums /*[5R]*/,
                           const float* c_prev, float* c, float* h, float* save /*[6R]*/, int R, hipStream_t s);
+/* Projected-attention form of the same step (csrc/lang.hip): P = att . W_a2c^T [L][2R] once per sentence, then per token
+ *   l2s_cap_att_dots_fwd      : dots[l] = alpha . tanh(patt[l] + att_h) + b                                  (ATT:411-418)
+ *   l2s_cap_apply_gates_fwd   : softmax(dots) -> weight[L]; a2c = sum_l weight[l] P[l] + b_a2c; gates / cell update  (ATT:419-423,449-462)
+ *   l2s_cap_gates_bwd_dw      : gate backward (as l2s_cap_gates_bwd) + dweight[l] = P[l] . da2c
+ *   l2s_cap_attention_bwd_step2 : softmax backward from dweight -> ddot[L], datt_h[D]
+ * l2s_cap_attention_bwd_batched accepts datt_res == NULL (no d(att) term: it then comes from d(P)). */
+int l2s_cap_att_dots_fwd(const float* patt, const float* att_h, const float* aw, const float* ab, int L, int D, float* tanh_ws, float* dots, hipStream_t s);
+int l2s_cap_apply_gates_fwd(const float* P, const float* dots, const float* b_a2c, const float* sums, const float* c_prev, float* c, float* h,
+                            float* save, float* weight, int L, int R, hipStream_t s);
+int l2s_cap_gates_bwd_dw(const float* dh, const float* dh2, const float* dc_in, const float* save, const float* c_prev, const float* P,
+                         float* dsums, float* da2c, float* dc_prev, float* dweight, int L, int R, hipStream_t s);
+int l2s_cap_attention_bwd_step2(const float* dweight, const float* tanh_ws, const float* weight, const float* aw, int L, int D, float* ddot,
+                                float* datt_h, hipStream_t s);
 int l2s_cap_attention_bwd_step(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,
                                float* ddot /*[L]*/, float* datt_h /*[D]*/, hipStream_t s);
 int l2s_cap_attention_bwd_batched(const float* ddot /*[S][L]*/, const float* weight /*[S][L]*/, const float* datt_res /*[S][ldr]*/, int ldr,

@@ -139,6 +139,10 @@ SIGS = {
     'l2s_linear_sum2_fwd': (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, vp]),
     'l2s_cap_a2c_gates_fwd': (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_cap_attention_bwd_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'l2s_cap_att_dots_fwd': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'l2s_cap_apply_gates_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'l2s_cap_gates_bwd_dw': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'l2s_cap_attention_bwd_step2': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'l2s_cap_attention_bwd_batched': (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_logsoftmax_nll': (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp]),

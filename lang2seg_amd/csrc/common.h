@@ -39,15 +39,31 @@ __device__ __forceinline__ void stx(void* p, long i, int dt, float v) {
   if (dt) ((bf16_t*)p)[i] = f2bf(v); else ((float*)p)[i] = v;
 }
 
+// Wave-wide reductions on the DPP path (no LDS traffic: the ds_bpermute butterflies these replace cost six LDS round trips per sum, and
+// their results must not be consumed behind a younger LDS write, see lang.hip cap_att_bwd_step_kernel): a scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3; lane 63 holds the result and is
+// broadcast.  The result is the same in every lane; the summation order is fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_take<0x111, 0xf>(0.f, v);     // row_shr:1
+  v += dpp_take<0x112, 0xf>(0.f, v);     // row_shr:2
+  v += dpp_take<0x114, 0xf>(0.f, v);     // row_shr:4
+  v += dpp_take<0x118, 0xf>(0.f, v);     // row_shr:8   -> lane 15 of each row: the row's sum
+  v += dpp_take<0x142, 0xa>(0.f, v);     // row_bcast:15 into rows 1, 3
+  v += dpp_take<0x143, 0xc>(0.f, v);     // row_bcast:31 into rows 2, 3 -> lane 63: the wave's sum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_take<0x111, 0xf>(v, v));
+  v = fmaxf(v, dpp_take<0x112, 0xf>(v, v));
+  v = fmaxf(v, dpp_take<0x114, 0xf>(v, v));
+  v = fmaxf(v, dpp_take<0x118, 0xf>(v, v));
+  v = fmaxf(v, dpp_take<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_take<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // block reductions for blockDim.x <= 1024 (result valid in every thread)
 __device__ __forceinline__ float block_sum(float v, float* sh) {

@@ -619,6 +619,128 @@ __global__ __launch_bounds__(1024) void cap_att_bwd_step_kernel(const float* __r
     datt_h[d] = v;
   }
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Projected-attention form of the att2in2 step (round 2).  a2c(att_res) = W (sum_l w_l att_l) + b = sum_l w_l (W att_l) + b because the
+// softmax weights sum to one: with P = att . W_a2c^T computed once per sentence ([L][2R], one MFMA GEMM), the per-token chain
+//     h2h/h2att GEMVs -> attention dots -> softmax + weighted sum of att -> a2c GEMV + gates          (4 launches, 2 MB of W_a2c per token)
+// becomes
+//     h2h/h2att GEMVs -> attention dots -> softmax + weighted sum of P's columns + gates               (3 launches),
+// and backward  gates -> W_a2c^T GEMV -> attention step -> W_h2h^T / W_h2att^T GEMVs  becomes
+//     gates + d(weight)_l = P_l . d(a2c)  ->  attention step  ->  GEMVs                                 (3 launches).
+// The step-summed d(P) = sum_t w_t (x) d(a2c)_t is one small GEMM after the loop; d(att) and d(W_a2c) follow from it as two more.
+// The caption branch is the train step's critical path, and each dependent launch on it costs ~10 us.
+//
+// forward: workgroup = 16 units x 16 location groups; softmax over the L dots recomputed per workgroup (L <= 256)
+__global__ __launch_bounds__(256) void cap_apply_gates_kernel(const float* __restrict__ P, const float* __restrict__ dots, const float* __restrict__ b,
+                                                             const float* __restrict__ s, const float* __restrict__ c_prev, float* c, float* h,
+                                                             float* save, float* weight, int L, int R) {
+  __shared__ float w[256];
+  __shared__ float red[4];
+  __shared__ float p0[16][17], p1[16][17];
+  const int tid = threadIdx.x, dl = tid & 15, lg = tid >> 4;
+  const float v = tid < L ? dots[tid] : -INFINITY;
+  const float mx = block_max(v, red);
+  const float e = tid < L ? expf(v - mx) : 0.f;
+  const float sum = block_sum(e, red);
+  w[tid] = tid < L ? e / sum : 0.f;
+  if (blockIdx.x == 0 && tid < L) weight[tid] = e / sum;
+  __syncthreads();
+  const int j = blockIdx.x * 16 + dl;
+  float a0 = 0.f, a1 = 0.f;
+  if (j < R) {
+    const float* q = P + j;
+    for (int l = lg; l < L; l += 16) {
+      const float wl = w[l];
+      a0 = fmaf(wl, q[(long)l * 2 * R], a0);
+      a1 = fmaf(wl, q[(long)l * 2 * R + R], a1);
+    }
+  }
+  p0[lg][dl] = a0; p1[lg][dl] = a1;
+  __syncthreads();
+  if (lg == 0 && j < R) {
+    a0 = b[j]; a1 = b[R + j];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { a0 += p0[g][dl]; a1 += p1[g][dl]; }
+    const float ig = sigm(s[j]), fg = sigm(s[R + j]), og = sigm(s[2 * R + j]);
+    const float t0 = s[3 * R + j] + a0, t1 = s[4 * R + j] + a1;
+    const float it = fmaxf(t0, t1);
+    const float cn = fg * c_prev[j] + ig * it;
+    const float tc = tanhf(cn);
+    c[j] = cn; h[j] = og * tc;
+    save[j] = ig; save[R + j] = fg; save[2 * R + j] = og; save[3 * R + j] = (t0 >= t1) ? 0.f : 1.f;
+    save[4 * R + j] = it; save[5 * R + j] = tc;
+  }
+}
+// backward (1): the gate backward of cap_gates_bwd_kernel recomputed by every workgroup into LDS (2R values; workgroup 0 also stores
+// dsums / da2c / dc_prev), then one wave per location: dweight[l] = P[l] . da2c.   R <= 1024.
+__global__ __launch_bounds__(256) void cap_gates_bwd_dw_kernel(const float* __restrict__ dh_a, const float* __restrict__ dh_b, const float* __restrict__ dc_in,
+                                                              const float* __restrict__ save, const float* __restrict__ c_prev, const float* __restrict__ P,
+                                                              float* ds, float* da2c, float* dc_prev, float* dweight, int L, int R) {
+  __shared__ __attribute__((aligned(16))) float g[2048];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool out = blockIdx.x == 0;
+  for (int j = tid; j < R; j += 256) {
+    const float ig = save[j], fg = save[R + j], og = save[2 * R + j], sel = save[3 * R + j], it = save[4 * R + j];
+    const float tc = save[5 * R + j];
+    const float dhj = dh_a[j] + (dh_b ? dh_b[j] : 0.f);
+    const float dcn = (dc_in ? dc_in[j] : 0.f) + dhj * og * (1.f - tc * tc);
+    const float dit = dcn * ig;
+    const float d0 = sel == 0.f ? dit : 0.f, d1 = sel == 0.f ? 0.f : dit;
+    g[j] = d0; g[R + j] = d1;
+    if (out) {
+      ds[j] = dcn * it * ig * (1.f - ig);
+      ds[R + j] = dcn * c_prev[j] * fg * (1.f - fg);
+      ds[2 * R + j] = dhj * tc * og * (1.f - og);
+      ds[3 * R + j] = d0; ds[4 * R + j] = d1;
+      da2c[j] = d0; da2c[R + j] = d1;
+      dc_prev[j] = dcn * fg;
+    }
+  }
+  __syncthreads();
+  const int l = blockIdx.x * 4 + wv;
+  if (l >= L) return;
+  const float* q = P + (long)l * 2 * R;
+  float a = 0.f;
+  for (int n = lane * 4; n < 2 * R; n += 256) {
+    const float4 pv = *(const float4*)(q + n), gv = *(const float4*)(g + n);
+    a = fmaf(pv.x, gv.x, fmaf(pv.y, gv.y, fmaf(pv.z, gv.z, fmaf(pv.w, gv.w, a))));
+  }
+  a = wave_sum(a);
+  if (lane == 0) dweight[l] = a;
+}
+// backward (2): softmax backward of the L location weights (recomputed by every workgroup from dweight) and
+// datt_h[d] = sum_l ddot[l] aw[d] (1 - tanh^2).  Workgroup = 16 channels x 64 location groups.
+__global__ __launch_bounds__(1024) void cap_att_bwd_step2_kernel(const float* __restrict__ dweight, const float* __restrict__ tanh_ws, const float* __restrict__ weight,
+                                                                const float* __restrict__ aw, int L, int D, float* ddot_out, float* datt_h) {
+  __shared__ float ddot[256];
+  __shared__ float red[16];
+  __shared__ float part[64][17];
+  const int tid = threadIdx.x;
+  const float wl = tid < L ? weight[tid] : 0.f;
+  const float dw = tid < L ? dweight[tid] : 0.f;
+  const float dot = block_sum(wl * dw, red);
+  const float dd = wl * (dw - dot);
+  if (tid < 256) ddot[tid] = tid < L ? dd : 0.f;
+  if (blockIdx.x == 0 && tid < L) ddot_out[tid] = dd;
+  __syncthreads();
+  const int dl = tid & 15, lg = tid >> 4;
+  const int d = blockIdx.x * 16 + dl;
+  float sah = 0.f;
+  if (d < D) {
+    const float a = aw[d];
+    for (int l = lg; l < L; l += 64) {
+      const float t = tanh_ws[(long)l * D + d];
+      sah = fmaf(ddot[l] * a, 1.f - t * t, sah);
+    }
+  }
+  part[lg][dl] = sah;
+  __syncthreads();
+  if (lg == 0 && d < D) {
+    float v = 0.f;
+    for (int gi = 0; gi < 64; ++gi) v += part[gi][dl];
+    datt_h[d] = v;
+  }
+}
 // after the loop: everything the per-step kernel left out, summed over the S steps in one launch.  A workgroup owns 16 channels d
 // (16 location lanes x 16 channels): dpatt / datt rows are written per (l, d), the alpha_net weight gradient daw[d] is summed over all
 // locations inside the workgroup in a fixed order (no atomics); workgroup 0 also takes the bias gradient.
@@ -638,11 +760,11 @@ __global__ __launch_bounds__(256) void cap_att_bwd_batched_kernel(const float* _
         const float dd = ddot[(long)t * L + l], w = weight[(long)t * L + l];
         const float th = tanh_ws[((long)t * L + l) * D + d];
         dp = fmaf(dd * a, 1.f - th * th, dp);
-        da = fmaf(w, dres[(long)t * ldr + d], da);
+        if (dres) da = fmaf(w, dres[(long)t * ldr + d], da);
         dw = fmaf(dd, th, dw);
       }
       dpatt[(long)l * D + d] += dp;
-      datt[(long)l * D + d] += da;
+      if (dres) datt[(long)l * D + d] += da;
       dwsum += dw;
     }
   }
@@ -931,6 +1053,30 @@ extern "C" int l2s_cap_attention_fwd(const float* patt, const float* att, const 
   // the softmax weights buffer doubles as the raw-dot scratch between the two launches
   L2S_LAUNCH(cap_att_dots_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, patt, att_h, aw, ab, L, D, tanh_ws, att_res + D);
   L2S_LAUNCH(cap_att_apply_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, att, att_res + D, L, D, weight, att_res);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_att_dots_fwd(const float* patt, const float* att_h, const float* aw, const float* ab, int L, int D, float* tanh_ws, float* dots,
+                                    hipStream_t s) {
+  if (L > 256) return L2S_EINVAL;
+  L2S_LAUNCH(cap_att_dots_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, patt, att_h, aw, ab, L, D, tanh_ws, dots);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_apply_gates_fwd(const float* P, const float* dots, const float* b_a2c, const float* sums, const float* c_prev, float* c, float* h,
+                                       float* save, float* weight, int L, int R, hipStream_t s) {
+  if (L > 256) return L2S_EINVAL;
+  L2S_LAUNCH(cap_apply_gates_kernel, dim3(cdiv(R, 16)), dim3(256), 0, s, P, dots, b_a2c, sums, c_prev, c, h, save, weight, L, R);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_gates_bwd_dw(const float* dh, const float* dh2, const float* dc_in, const float* save, const float* c_prev, const float* P,
+                                    float* dsums, float* da2c, float* dc_prev, float* dweight, int L, int R, hipStream_t s) {
+  if (R > 1024 || (R & 3) || ((uintptr_t)P & 15)) return L2S_EINVAL;
+  L2S_LAUNCH(cap_gates_bwd_dw_kernel, dim3(cdiv(L, 4)), dim3(256), 0, s, dh, dh2, dc_in, save, c_prev, P, dsums, da2c, dc_prev, dweight, L, R);
+  return l2s_check_launch();
+}
+extern "C" int l2s_cap_attention_bwd_step2(const float* dweight, const float* tanh_ws, const float* weight, const float* aw, int L, int D, float* ddot,
+                                           float* datt_h, hipStream_t s) {
+  if (L > 256) return L2S_EINVAL;
+  L2S_LAUNCH(cap_att_bwd_step2_kernel, dim3(cdiv(D, 16)), dim3(1024), 0, s, dweight, tanh_ws, weight, aw, L, D, ddot, datt_h);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_attention_bwd(const float* datt_res, const float* att, const float* tanh_ws, const float* weight, const float* aw, int L, int D,

@@ -251,6 +251,7 @@ class Network(object):
         self.dp = None              # data-parallel gradient reducer (lang2seg_amd/parallel.py)
         self._early_op = None       # optimiser taking early partial updates during backward (optim.SGD.partial)
         self.wgq = WgradQueue(self) # weight gradients of the current backward stage, launched together by flush_wgrads()
+        self.cap_projected = os.environ.get('L2S_CAP_PROJ', '1') == '1'   # captioner recurrence in the projected-attention form (3 launches per token)
         self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'cap'); set by bench.py --knockout
 
     # ------------------------------------------------------------------ construction

@@ -271,10 +271,20 @@ class resnetv1(Network):
         hs = self.buf('cap.hfull', (S + 1, R), f32); cs = self.buf('cap.cfull', (S + 1, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
         att_h = self.buf('cap.att_h', (S, AH), f32); tanh_ws = self.buf('cap.tanh', (S, L, AH), f32)
         wgt = self.buf('cap.wgt', (S, L), f32); ares = self.buf('cap.ares', (S, R + SC), f32); a2c = self.buf('cap.a2c', (S, 2 * R), f32)
+        proj = self.cap_projected and R <= 1024
+        if proj:
+            # projected attention (csrc/lang.hip): P = att . W_a2c^T once, then 3 launches per token
+            Pm = self.buf('cap.P', (L, 2 * R), f32); dots = self.buf('cap.dots', (S, 256), f32)
+            O.linear_fwd(ad, pv('core.a2c.weight'), None, Pm, L, 2 * R, R)
+            t['cap.P'] = Pm
         for i in range(S):
             # h2att(h) and h2h(h) (+= i2h sums) in one launch; attention; a2c Linear fused with the gates (4 launches per step)
             O.linear2_fwd(hs[i], R, pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), att_h[i], AH, False,
                           pv('core.h2h.weight'), pv('core.h2h.bias'), sums[i], 5 * R, True)
+            if proj:
+                O.cap_att_dots_fwd(patt, att_h[i], pv('core.attention.alpha_net.weight'), pv('core.attention.alpha_net.bias'), L, AH, tanh_ws[i], dots[i])
+                O.cap_apply_gates_fwd(Pm, dots[i], pv('core.a2c.bias'), sums[i], cs[i], cs[i + 1], hs[i + 1], save[i], wgt[i], L, R)
+                continue
             O.cap_attention_fwd(patt, ad, att_h[i], pv('core.attention.alpha_net.weight'), pv('core.attention.alpha_net.bias'), L, AH,
                                 tanh_ws[i], wgt[i], ares[i])
             O.cap_a2c_gates_fwd(ares[i], pv('core.a2c.weight'), pv('core.a2c.bias'), R, sums[i], cs[i], cs[i + 1], hs[i + 1], save[i], R)
@@ -311,26 +321,42 @@ class resnetv1(Network):
         self.bwd_x(dlogits, 'caption_model.logit.weight', dho, S, mul=t['cap.drop_out'])
         dsums = self.buf('cap.dsums', (S, 5 * R), f32); da2c = self.buf('cap.da2c', (S, 2 * R), f32)
         datt_h = self.buf('cap.datt_h', (S, AH + SC), f32); dares = self.buf('cap.dares', (S, R), f32); ddot = self.buf('cap.ddot', (S, L), f32)
-        # dpatt | dad | dh | dc: one buffer, one clear
-        zb = self.buf('cap.bwd_zero', (L * AH + L * R + 4 * R,), f32, zero=True)
+        proj = self.cap_projected and R <= 1024
+        # dpatt | dad | dh | dc (| dP): one buffer, one clear
+        nz = L * AH + L * R + 4 * R
+        zb = self.buf('cap.bwd_zero', (nz + (L * 2 * R if proj else 0),), f32, zero=True)
         dpatt = zb[:L * AH].view(L, AH); dad = zb[L * AH:L * AH + L * R].view(L, R)
-        dh = zb[L * AH + L * R:L * AH + L * R + 2 * R].view(2, R); dc = zb[L * AH + L * R + 2 * R:].view(2, R)
+        dh = zb[L * AH + L * R:L * AH + L * R + 2 * R].view(2, R); dc = zb[L * AH + L * R + 2 * R:nz].view(2, R)
         wT_h2h = self.wT['caption_model.core.h2h.weight'][0]; wT_h2att = self.wT['caption_model.core.attention.h2att.weight'][0]
         k = 0
+        if proj:
+            Pm = t['cap.P']; dwl = self.buf('cap.dwl', (S, 256), f32); dP = zb[nz:].view(L, 2 * R)
         for i in range(S - 1, -1, -1):
-            # 4 launches per step: gates (dh = recurrent part + this step's output gradient), a2c^T, the attention pieces the
-            # recurrence needs, and dh(i-1) = W_h2h^T dsums + W_h2att^T datt_h
-            O.cap_gates_bwd(dh[k], dc[k], save[i], cs[i], dsums[i], da2c[i], dc[1 - k], R, dh2=dho[i])
-            self.bwd_x(da2c[i], 'caption_model.core.a2c.weight', dares[i], 1)
-            O.cap_attention_bwd_step(dares[i], ad, tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, ddot[i], datt_h[i])
+            if proj:
+                # 3 launches per step: gates + d(weight) = P . d(a2c); softmax backward + datt_h; dh(i-1)
+                O.cap_gates_bwd_dw(dh[k], dc[k], save[i], cs[i], Pm, dsums[i], da2c[i], dc[1 - k], dwl[i], L, R, dh2=dho[i])
+                O.cap_attention_bwd_step2(dwl[i], tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, ddot[i], datt_h[i])
+            else:
+                # 4 launches per step: gates (dh = recurrent part + this step's output gradient), a2c^T, the attention pieces the
+                # recurrence needs, and dh(i-1) = W_h2h^T dsums + W_h2att^T datt_h
+                O.cap_gates_bwd(dh[k], dc[k], save[i], cs[i], dsums[i], da2c[i], dc[1 - k], R, dh2=dho[i])
+                self.bwd_x(da2c[i], 'caption_model.core.a2c.weight', dares[i], 1)
+                O.cap_attention_bwd_step(dares[i], ad, tanh_ws[i], wgt[i], pv('core.attention.alpha_net.weight'), L, AH, ddot[i], datt_h[i])
             O.linear_sum2_fwd(dsums[i], wT_h2h, 5 * R, datt_h[i], wT_h2att, AH, dh[1 - k], R)
             k = 1 - k
-        O.cap_attention_bwd_batched(ddot, wgt, dares, R, tanh_ws, pv('core.attention.alpha_net.weight'), S, L, AH, dpatt, dad,
+        O.cap_attention_bwd_batched(ddot, wgt, None if proj else dares, R, tanh_ws, pv('core.attention.alpha_net.weight'), S, L, AH, dpatt, dad,
                                     gv('core.attention.alpha_net.weight'), gv('core.attention.alpha_net.bias'))
+        if proj:
+            # d(P) = sum_t weight_t (x) d(a2c)_t  [L][2R];  d(att) += d(P) . W_a2c
+            O.linear_bwd_w(wgt, da2c, dP, None, S, L, 2 * R)
+            self.bwd_x(dP, 'caption_model.core.a2c.weight', dad, L, accumulate=True)
         hprev = hs[0:S]
 
         def recurrence_grads():
-            O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R, ldx=R + SC)
+            if proj:
+                O.linear_bwd_w(dP, ad, gv('core.a2c.weight'), gv('core.a2c.bias'), L, 2 * R, R)
+            else:
+                O.linear_bwd_w(da2c, ares, gv('core.a2c.weight'), gv('core.a2c.bias'), S, 2 * R, R, ldx=R + SC)
             O.linear_bwd_w(dsums, hprev, gv('core.h2h.weight'), gv('core.h2h.bias'), S, 5 * R, R)
             O.linear_bwd_w(datt_h, hprev, gv('core.attention.h2att.weight'), gv('core.attention.h2att.bias'), S, AH, R, lddy=AH + SC)
             O.linear_bwd_w(dsums, t['cap.xt'], gv('core.i2h.weight'), gv('core.i2h.bias'), S, 5 * R, IE)

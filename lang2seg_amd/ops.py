@@ -488,6 +488,23 @@ def cap_a2c_gates_fwd(att_res, w_a2c, b_a2c, K, sums, c_prev, c, h, save, R):
     call('l2s_cap_a2c_gates_fwd', ptr(att_res), ptr(w_a2c), ptr(b_a2c), K, ptr(sums), ptr(c_prev), ptr(c), ptr(h), ptr(save), R, stream())
 
 
+def cap_att_dots_fwd(patt, att_h, aw, ab, L, D, tanh_ws, dots):
+    call('l2s_cap_att_dots_fwd', ptr(patt), ptr(att_h), ptr(aw), ptr(ab), L, D, ptr(tanh_ws), ptr(dots), stream())
+
+
+def cap_apply_gates_fwd(P, dots, b_a2c, sums, c_prev, c, h, save, weight, L, R):
+    call('l2s_cap_apply_gates_fwd', ptr(P), ptr(dots), ptr(b_a2c), ptr(sums), ptr(c_prev), ptr(c), ptr(h), ptr(save), ptr(weight), L, R, stream())
+
+
+def cap_gates_bwd_dw(dh, dc_in, save, c_prev, P, dsums, da2c, dc_prev, dweight, L, R, dh2=None):
+    call('l2s_cap_gates_bwd_dw', ptr(dh), ptr(dh2), ptr(dc_in), ptr(save), ptr(c_prev), ptr(P), ptr(dsums), ptr(da2c), ptr(dc_prev), ptr(dweight),
+         L, R, stream())
+
+
+def cap_attention_bwd_step2(dweight, tanh_ws, weight, aw, L, D, ddot, datt_h):
+    call('l2s_cap_attention_bwd_step2', ptr(dweight), ptr(tanh_ws), ptr(weight), ptr(aw), L, D, ptr(ddot), ptr(datt_h), stream())
+
+
 def cap_attention_bwd_step(datt_res, att, tanh_ws, weight, aw, L, D, ddot, datt_h):
     call('l2s_cap_attention_bwd_step', ptr(datt_res), ptr(att), ptr(tanh_ws), ptr(weight), ptr(aw), L, D, ptr(ddot), ptr(datt_h), stream())
 

@@ -324,6 +324,10 @@ def test_pools(dt):
     O.adaptive_pool_bwd(dyo, 2 * Cc, 0, Cc, pm.to(DEV), dxo, None, H, W, Cc, 14, 14)
     torch.cuda.synchronize()
     assert rel_err(dxo.float().view(1, H, W, Cc), nhwc(fr.grad)) < (1e-5 if dt == 0 else 1e-2)
+    dxr = O.empty((H * W, Cc), dt)                               # with the ReLU mask of the pooled map (the caption branch's call)
+    O.adaptive_pool_bwd(dyo, 2 * Cc, 0, Cc, pm.to(DEV), dxr, fd.view(H * W, Cc), H, W, Cc, 14, 14)
+    torch.cuda.synchronize()
+    assert torch.equal(dxr.float(), dxo.float() * (fd.view(H * W, Cc).float() > 0))
     # gt mask downsample
     m = (torch.rand(600, 1000, generator=g) > 0.6).to(torch.uint8)
     out = torch.empty(38 * 63, device=DEV)
@@ -728,6 +732,47 @@ def test_losses():
     O.total_loss(loss, 0.5)
     torch.cuda.synchronize()
     assert abs(loss[6].item() - 18.0) < 1e-6
+
+
+def test_captioner_projected_attention_step():
+    """projected-attention form of one att2in2 step (P = att . W_a2c^T): forward (dots -> softmax + weighted columns of P + gates) and
+    backward (gates + dweight = P . da2c; softmax backward + datt_h) against an fp64 torch restatement of AttModel.py:406-466;
+    1e-5 relative (fp32, different summation order)."""
+    O = ops()
+    g = torch.Generator().manual_seed(23)
+    L, D, R = 196, 512, 512
+    dd = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float64)
+    att = dd(L, R).clamp(min=0); patt = dd(L, D) * 0.5; att_h = dd(D) * 0.5; aw = dd(D) * 0.1; ab = dd(1) * 0.1
+    W = dd(2 * R, R) / np.sqrt(R); b = dd(2 * R) * 0.1; sums = dd(5 * R); c_prev = dd(R)
+    f = lambda x: x.float().to(DEV).contiguous()
+    # reference forward
+    th = torch.tanh(patt + att_h); dots = th @ aw + ab; w = torch.softmax(dots, 0); ares = w @ att; a2c = W @ ares + b
+    ig, fg, og = torch.sigmoid(sums[:R]), torch.sigmoid(sums[R:2 * R]), torch.sigmoid(sums[2 * R:3 * R])
+    t0, t1 = sums[3 * R:4 * R] + a2c[:R], sums[4 * R:] + a2c[R:]
+    it = torch.maximum(t0, t1); cn = fg * c_prev + ig * it; hn = og * torch.tanh(cn)
+    P = f(att @ W.t())
+    tanh_ws = torch.empty(L, D, device=DEV); dts = torch.empty(256, device=DEV); wgt = torch.empty(L, device=DEV)
+    c = torch.empty(R, device=DEV); h = torch.empty(R, device=DEV); save = torch.empty(6 * R, device=DEV)
+    O.cap_att_dots_fwd(f(patt), f(att_h), f(aw), f(ab), L, D, tanh_ws, dts)
+    O.cap_apply_gates_fwd(P, dts, f(b), f(sums), f(c_prev), c, h, save, wgt, L, R)
+    torch.cuda.synchronize()
+    assert rel_err(wgt, w.float()) < 1e-5 and rel_err(c, cn.float()) < 1e-5 and rel_err(h, hn.float()) < 1e-5
+    assert rel_err(tanh_ws, th.float()) < 1e-6
+    # backward of the step given dh, dc
+    dh, dh2, dc = dd(R) * 0.1, dd(R) * 0.1, dd(R) * 0.1
+    tc = torch.tanh(cn); dhj = dh + dh2; dcn = dc + dhj * og * (1 - tc * tc)
+    dit = dcn * ig; sel = (t0 >= t1)
+    d0 = torch.where(sel, dit, torch.zeros_like(dit)); d1 = torch.where(sel, torch.zeros_like(dit), dit)
+    da2c_ref = torch.cat([d0, d1]); dares = W.t() @ da2c_ref; dwl = att @ dares
+    ddot_ref = w * (dwl - (w * dwl).sum()); datt_h_ref = ((ddot_ref[:, None] * aw[None, :]) * (1 - th * th)).sum(0)
+    dsums_ref = torch.cat([dcn * it * ig * (1 - ig), dcn * c_prev * fg * (1 - fg), dhj * tc * og * (1 - og), d0, d1])
+    dsums = torch.empty(5 * R, device=DEV); da2c = torch.empty(2 * R, device=DEV); dcp = torch.empty(R, device=DEV); dw = torch.empty(256, device=DEV)
+    ddot = torch.empty(L, device=DEV); datt_h = torch.empty(D + 256, device=DEV)
+    O.cap_gates_bwd_dw(f(dh), f(dc), save, f(c_prev), P, dsums, da2c, dcp, dw, L, R, dh2=f(dh2))
+    O.cap_attention_bwd_step2(dw, tanh_ws, wgt, f(aw), L, D, ddot, datt_h)
+    torch.cuda.synchronize()
+    assert rel_err(dsums, dsums_ref.float()) < 1e-5 and rel_err(da2c, da2c_ref.float()) < 1e-5 and rel_err(dcp, (dcn * fg).float()) < 1e-5
+    assert rel_err(dw[:L], dwl.float()) < 1e-5 and rel_err(ddot, ddot_ref.float()) < 2e-5 and rel_err(datt_h[:D], datt_h_ref.float()) < 2e-5
 
 
 def test_row_batch_linears_mfma():
