@@ -303,6 +303,9 @@ long l2s_dynfilter_ws_floats(int H, int W, int C);
 int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
                       void* dx, const void* relu_ref, float* dfilt, float* dr, float* ws, int H, int W, int C, int dtype,
                       int gate, const float* dresp_extra /*nullable [HW]: d(response loss)/d(response)*/, hipStream_t s);
+/* dfilt == NULL in l2s_dynfilter_bwd: only dx is produced (the main queue needs nothing else); l2s_dynfilter_bwd_finish then turns the
+ * workspace into dfilt += / dr += on whichever stream the language-side backward runs on. */
+int l2s_dynfilter_bwd_finish(const float* ws, const float* respk, float* dfilt, float* dr, int H, int W, int C, hipStream_t s);
 /* att2in2 attention (AttModel.py:406-423): patt [L][D], att [L][D] float; att_h [D]; alpha w[D], b.
  * out: weight [L] (softmax), att_res [D + 256] (the tail is scratch for the raw dots) */
 int l2s_cap_attention_fwd(const float* patt, const float* att, const float* att_h, const float* aw, const float* ab, int L, int D,

@@ -113,6 +113,7 @@ SIGS = {
     'l2s_dynfilter_fwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_dynfilter_ws_floats': (i64, [i32, i32, i32]),
     'l2s_dynfilter_bwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'l2s_dynfilter_bwd_finish': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'l2s_scale_mask': (i32, [vp, vp, vp, vp, C.c_long, i32, vp]),
     'l2s_conv3x3_c3': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'l2s_maxpool2x2_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

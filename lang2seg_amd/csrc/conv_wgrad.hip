@@ -53,7 +53,12 @@ __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int t
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int LRA = BM * ES + WGT<T>::PADB, LRB = BN * ES + WGT<T>::PADB;
   constexpr int VPA = BM / VE, VPB = BN / VE;            // 16-byte vectors per row
-  constexpr int NVA = (BKP * VPA + 255) / 256, NVB = (RB * VPB + 255) / 256;
+  // loader: TPR threads share one pixel row of the slice and own NVA / NVB CONSECUTIVE vectors of it, so a thread carries one
+  // (image, row, column) state per operand instead of one per vector (the per-vector form spent ~190 VALU + ~125 SALU instructions
+  // per slice and wave on index arithmetic against 32 MFMAs).  TX == 3: the two extra X rows belong to the first 2 TPR threads.
+  constexpr int TPR = 256 / BKP;
+  static_assert(256 % BKP == 0 && VPA % TPR == 0 && VPB % TPR == 0, "loader mapping");
+  constexpr int NVA = VPA / TPR, NVB = VPB / TPR;
   constexpr int BUF = BKP * LRA + RB * LRB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,73 +147,83 @@ __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int t
     const auto rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy[seg], 0, 0x7FFFFFFF, 0x00020000);
     const auto rxx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x[seg], 0, 0x7FFFFFFF, 0x00020000);
 
-    // ---- loader state: every thread owns NVA vectors of dY and NVB vectors of X per slice; their (image, row, column) in the
-    // virtual layout advance by BKP pixels per slice with add / compare steps ----
-    int an[NVA], ay[NVA], ax[NVA], ac[NVA]; bool aok[NVA];
-    int bn[NVB], by[NVB], bx[NVB], bc[NVB]; bool bok[NVB];
+    // ---- loader state: the thread's pixel row of the slice (dY, X) and, for the first 2 TPR threads of a filter-row tile, one of the
+    // two extra X rows; (image, row, column) in the virtual layout advance by BKP pixels per slice with add / compare steps ----
+    const int lrow = tid / TPR, lq = tid - lrow * TPR;
     const int pb0 = s_begin * BKP;
+    int an, ay, ax, bn, by, bx, tn = 0, ty = 0, tx = -1;
+    const bool tail = TX == 3 && tid < 2 * TPR;
+    bool acok[NVA], bcok[NVB];
 #pragma unroll
-    for (int j = 0; j < NVA; ++j) {
-      const int v = tid + j * 256, r = v / VPA, c = v - r * VPA;
-      aok[j] = r < BKP && (co0 + c * VE) < p.Cout;
-      ac[j] = co0 + c * VE;
-      const int pix = pb0 + min(r, BKP - 1);
-      an[j] = pix / ohwv; const int rem = pix - an[j] * ohwv; ay[j] = rem / Wv; ax[j] = rem - ay[j] * Wv;
+    for (int j = 0; j < NVA; ++j) acok[j] = (co0 + (lq * NVA + j) * VE) < p.Cout;
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) bcok[j] = (ci0 + (lq * NVB + j) * VE) < p.Cin;
+    const unsigned acol = (unsigned)((co0 + lq * NVA * VE) * ES), bcol = (unsigned)((ci0 + lq * NVB * VE) * ES);
+    {
+      const int pix = pb0 + lrow;
+      an = pix / ohwv; const int rem = pix - an * ohwv; ay = rem / Wv; ax = rem - ay * Wv;
     }
+    auto place = [&](int pix, int& n, int& y, int& x) {            // TX == 3: image row r holds virtual pixel base - 1 + r
+      if (pix < 0) { n = 0; y = 0; x = -1; }
+      else { n = pix / ohwv; const int rem = pix - n * ohwv; y = rem / Wv; x = rem - y * Wv; }
+    };
+    place(pb0 + lrow - (TX == 3 ? 1 : 0), bn, by, bx);
+    if (TX == 3) place(pb0 + BKP + lrow - 1, tn, ty, tx);           // (only used by the `tail` threads: lrow is 0 or 1 there)
+    auto advance = [&](int& n, int& y, int& x) {
+      x += sc; if (x >= Wv) { x -= Wv; ++y; }
+      y += sb; if (y >= OH) { y -= OH; ++n; }
+      n += sa;
+    };
+    auto xoff = [&](int n, int y, int x) -> unsigned {
+      const int iy = y * p.stride - p.pad + ky;
+      const int ix = TX == 3 ? x : x * p.stride - p.pad + kx;
+      const bool ok = n < n_img && x >= 0 && x < OW && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+      return ok ? (unsigned)(((n * IH + iy) * IW + ix) * ldx * ES) + bcol : OOR;
+    };
+    auto issue = [&](uint4 (&ra)[NVA], uint4 (&rb)[NVB], uint4 (&rt)[NVB]) {
+      {
+        const bool ok = ax < OW && an < n_img;
+        const unsigned o = ok ? (unsigned)((((an * OH + ay) * OW + ax) * lddy) * ES) + acol : OOR;
 #pragma unroll
-    for (int j = 0; j < NVB; ++j) {
-      const int v = tid + j * 256, r = v / VPB, c = v - r * VPB;
-      bok[j] = r < RB && (ci0 + c * VE) < p.Cin;
-      bc[j] = ci0 + c * VE;
-      const int pix = pb0 + min(r, RB - 1) - (TX == 3 ? 1 : 0);     // TX == 3: image row r holds virtual pixel base - 1 + r
-      if (pix < 0) { bn[j] = 0; by[j] = 0; bx[j] = -1; }
-      else { bn[j] = pix / ohwv; const int rem = pix - bn[j] * ohwv; by[j] = rem / Wv; bx[j] = rem - by[j] * Wv; }
-    }
-    auto issue = [&](uint4 (&ra)[NVA], uint4 (&rb)[NVB]) {
-#pragma unroll
-      for (int j = 0; j < NVA; ++j) {
-        const bool ok = aok[j] && ax[j] < OW && an[j] < n_img;
-        const unsigned o = ok ? (unsigned)((((an[j] * OH + ay[j]) * OW + ax[j]) * lddy + ac[j]) * ES) : OOR;
-        ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o, 0, 0));
-        ax[j] += sc; if (ax[j] >= Wv) { ax[j] -= Wv; ++ay[j]; }
-        ay[j] += sb; if (ay[j] >= OH) { ay[j] -= OH; ++an[j]; }
-        an[j] += sa;
+        for (int j = 0; j < NVA; ++j) ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdy, acok[j] ? o + j * 16 : OOR, 0, 0));
+        advance(an, ay, ax);
       }
+      {
+        const unsigned o = xoff(bn, by, bx);
 #pragma unroll
-      for (int j = 0; j < NVB; ++j) {
-        const int iy = by[j] * p.stride - p.pad + ky;
-        const int ix = TX == 3 ? bx[j] : bx[j] * p.stride - p.pad + kx;
-        const bool ok = bok[j] && bn[j] < n_img && bx[j] >= 0 && bx[j] < OW && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
-        const unsigned o = ok ? (unsigned)((((bn[j] * IH + iy) * IW + ix) * ldx + bc[j]) * ES) : OOR;
-        rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxx, o, 0, 0));
-        bx[j] += sc; if (bx[j] >= Wv) { bx[j] -= Wv; ++by[j]; }
-        by[j] += sb; if (by[j] >= OH) { by[j] -= OH; ++bn[j]; }
-        bn[j] += sa;
+        for (int j = 0; j < NVB; ++j) rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxx, bcok[j] ? o + j * 16 : OOR, 0, 0));
+        advance(bn, by, bx);
+      }
+      if (TX == 3) {
+        const unsigned o = tail ? xoff(tn, ty, tx) : OOR;
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) rt[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rxx, bcok[j] ? o + j * 16 : OOR, 0, 0));
+        advance(tn, ty, tx);
       }
     };
-    auto store_slice = [&](int buf, const uint4 (&ra)[NVA], const uint4 (&rb)[NVB]) {
-      char* a = smem + buf * BUF;
-      char* b = a + BKP * LRA;
+    auto store_slice = [&](int buf, const uint4 (&ra)[NVA], const uint4 (&rb)[NVB], const uint4 (&rt)[NVB]) {
+      char* a = smem + buf * BUF + lrow * LRA + lq * NVA * 16;
+      char* b = smem + buf * BUF + BKP * LRA + lrow * LRB + lq * NVB * 16;
 #pragma unroll
-      for (int j = 0; j < NVA; ++j) {
-        const int v = tid + j * 256, r = v / VPA, c = v - r * VPA;
-        if ((BKP * VPA) % 256 == 0 || r < BKP) *(uint4*)(a + r * LRA + c * 16) = ra[j];
-      }
+      for (int j = 0; j < NVA; ++j) *(uint4*)(a + j * 16) = ra[j];
 #pragma unroll
-      for (int j = 0; j < NVB; ++j) {
-        const int v = tid + j * 256, r = v / VPB, c = v - r * VPB;
-        if ((RB * VPB) % 256 == 0 || r < RB) *(uint4*)(b + r * LRB + c * 16) = rb[j];
+      for (int j = 0; j < NVB; ++j) *(uint4*)(b + j * 16) = rb[j];
+      if (TX == 3 && tail) {
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) *(uint4*)(b + BKP * LRB + j * 16) = rt[j];
       }
     };
 
     // register ring: set s holds slice k with k % D == s; iteration t: barrier -> ds_write slice t+1 -> issue slice t+1+D -> MFMAs on t
-    uint4 qa[D][NVA], qb[D][NVB];
+    uint4 qa[D][NVA], qb[D][NVB], qt[D][TX == 3 ? NVB : 1];
+    auto iss = [&](int s_) { if constexpr (TX == 3) issue(qa[s_], qb[s_], qt[s_]); else issue(qa[s_], qb[s_], qb[s_]); };
+    auto sto = [&](int buf, int s_) { if constexpr (TX == 3) store_slice(buf, qa[s_], qb[s_], qt[s_]); else store_slice(buf, qa[s_], qb[s_], qb[s_]); };
 #pragma unroll
     for (int s = 0; s < D; ++s)
-      if (s < NS) issue(qa[s], qb[s]);
+      if (s < NS) iss(s);
     __syncthreads();                                     // (the previous segment's last slice may still be read)
-    store_slice(0, qa[0], qb[0]);
-    if (D < NS) issue(qa[0], qb[0]);
+    sto(0, 0);
+    if (D < NS) iss(0);
     int t0 = 0;
     for (; t0 + 2 * D <= NS; t0 += D) {
 #pragma unroll
@@ -216,8 +231,8 @@ __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int t
         const int t = t0 + s;
         const int nxt = (s + 1) % D;
         __syncthreads();
-        store_slice((t + 1) & 1, qa[nxt], qb[nxt]);
-        issue(qa[nxt], qb[nxt]);
+        sto((t + 1) & 1, nxt);
+        iss(nxt);
         compute(t & 1);
       }
     }
@@ -228,8 +243,8 @@ __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int t
         const int nxt = (s + 1) % D;
         __syncthreads();
         if (t + 1 < NS) {
-          store_slice((t + 1) & 1, qa[nxt], qb[nxt]);
-          if (t + 1 + D < NS) issue(qa[nxt], qb[nxt]);
+          sto((t + 1) & 1, nxt);
+          if (t + 1 + D < NS) iss(nxt);
         }
         compute(t & 1);
       }

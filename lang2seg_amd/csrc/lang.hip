@@ -341,6 +341,78 @@ __global__ __launch_bounds__(256) void dynfilter_bwd2_kernel(const void* dy, con
   }
 }
 
+// bf16 fast paths of passes 1 and 2 (C % 8 == 0 / C % 4 == 0, 16- and 8-byte accesses instead of one bf16 per lane).
+__global__ __launch_bounds__(256) void dynfilter_bwd1_bf16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* dresp, int HW, int C,
+                                                                 int gate, const float* __restrict__ resp, const float* __restrict__ dresp_extra) {
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pix >= HW) return;
+  float s = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    const uint4 a = *(const uint4*)(dy + (long)pix * C + c), b = *(const uint4*)(x + (long)pix * C + c);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s = fmaf(__uint_as_float(aw[k] << 16), __uint_as_float(bw[k] << 16), s);
+      s = fmaf(__uint_as_float(aw[k] & 0xFFFF0000u), __uint_as_float(bw[k] & 0xFFFF0000u), s);
+    }
+  }
+  s = wave_sum(s);
+  if (gate) { const float sg = sigm(resp[pix]); s *= sg * (1.f - sg); }
+  if (dresp_extra) s += dresp_extra[pix];
+  if (lane == 0) dresp[pix] = s;
+}
+// block = 256 channels (64 lanes x 4) x 4 pixel lanes
+__global__ __launch_bounds__(256) void dynfilter_bwd2_bf16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ filt,
+                                                                 const float* __restrict__ r, const float* __restrict__ resp, const float* __restrict__ dresp,
+                                                                 bf16_t* dx, const bf16_t* __restrict__ ref, float* dfilt, int H, int W, int C, int pchunk, int gate) {
+  __shared__ float red[4][7][256];
+  const int lane = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int p0 = blockIdx.y * pchunk, p1 = min(H * W, p0 + pchunk);
+  float fk[7][4], acc[7][4];
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { fk[k][e] = (c < C) ? filt[k * C + c + e] * r[k] : 0.f; acc[k][e] = 0.f; }
+  if (c < C) {
+    for (int p = p0 + pl; p < p1; p += 4) {
+      float m[7]; spatial_mask7(p / W, p % W, H, W, m);
+      const float dr_ = dresp[p], mult = gate ? sigm(resp[p]) : resp[p];
+      const uint2 xr = *(const uint2*)(x + (long)p * C + c), gr = *(const uint2*)(dy + (long)p * C + c);
+      uint2 rr = make_uint2(0x3f803f80u, 0x3f803f80u);
+      if (ref) rr = *(const uint2*)(ref + (long)p * C + c);
+      const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xFFFF0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xFFFF0000u)};
+      const float gv[4] = {__uint_as_float(gr.x << 16), __uint_as_float(gr.x & 0xFFFF0000u), __uint_as_float(gr.y << 16), __uint_as_float(gr.y & 0xFFFF0000u)};
+      const float rv[4] = {__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xFFFF0000u), __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xFFFF0000u)};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = gv[e] * mult;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { t = fmaf(m[k], fk[k][e], t); acc[k][e] = fmaf(dr_ * m[k], xv[e], acc[k][e]); }
+        g = fmaf(dr_, t, g);
+        if (!(rv[e] > 0.f)) g = 0.f;
+        o[e] = g;
+      }
+      *(uint2*)(dx + (long)p * C + c) = make_uint2((uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16), (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[pl][k][lane * 4 + e] = acc[k][e];
+  __syncthreads();
+  // 256 threads: thread t finishes channel blockIdx.x * 256 + t for the seven taps
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int l = threadIdx.x;
+      dfilt[((long)blockIdx.y * 7 + k) * C + cc] = (red[0][k][l] + red[1][k][l] + red[2][k][l] + red[3][k][l]) * r[k];
+    }
+  }
+}
 // pass 3: dfilt[k][c] += sum_chunk part[chunk][k][c] (chunk order); block 0 also dr[k] += sum_p dresp[p] respk[p][k] (fixed tree)
 __global__ __launch_bounds__(256) void dynfilter_bwd3_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ dresp,
                                                             const float* __restrict__ respk, float* dfilt, float* dr, int HW, int C) {
@@ -1034,16 +1106,31 @@ extern "C" int l2s_dynfilter_fwd(const void* x, const float* filt, const float* 
   L2S_LAUNCH(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype, gate);
   return l2s_check_launch();
 }
-extern "C" long l2s_dynfilter_ws_floats(int H, int W, int C) { return (long)H * W + (long)cdiv(H * W, 64) * 7 * C; }
+constexpr int DYN_PCHUNK = 32;   // pixels per partial-sum chunk of pass 2
+extern "C" long l2s_dynfilter_ws_floats(int H, int W, int C) { return (long)H * W + (long)cdiv(H * W, DYN_PCHUNK) * 7 * C; }
+extern "C" int l2s_dynfilter_bwd_finish(const float* ws, const float* respk, float* dfilt, float* dr, int H, int W, int C, hipStream_t s) {
+  const float* dresp_ws = ws; const float* part = ws + (long)H * W;
+  L2S_LAUNCH(dynfilter_bwd3_kernel, dim3(cdiv(7 * C, 256)), dim3(256), 0, s, part, cdiv(H * W, DYN_PCHUNK), dresp_ws, respk, dfilt, dr, H * W, C);
+  return l2s_check_launch();
+}
 extern "C" int l2s_dynfilter_bwd(const void* dy, const void* x, const float* filt, const float* r, const float* resp, const float* respk,
                                  void* dx, const void* relu_ref, float* dfilt, float* dr, float* ws, int H, int W, int C, int dtype,
                                  int gate, const float* dresp_extra, hipStream_t s) {
   // ws: [H*W] d(response) followed by [chunks][7][C] partial filter gradients (l2s_dynfilter_ws_floats)
+  // dfilt == NULL: only passes 1 and 2 (dx); the caller runs l2s_dynfilter_bwd_finish on whichever stream needs dfilt / dr
   float* dresp_ws = ws; float* part = ws + (long)H * W;
-  const int pchunk = 64, nchunk = cdiv(H * W, pchunk);
-  L2S_LAUNCH(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype, gate, resp, dresp_extra);
-  L2S_LAUNCH(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, dy, x, filt, r, resp, (const float*)dresp_ws, dx, relu_ref,
-                     part, H, W, C, dtype, pchunk, gate);
+  const int pchunk = DYN_PCHUNK, nchunk = cdiv(H * W, pchunk);
+  const bool fast = dtype == L2S_BF16 && !(C & 7) && !((uintptr_t)dy & 15) && !((uintptr_t)x & 15) && !((uintptr_t)dx & 15) && !((uintptr_t)relu_ref & 15);
+  if (fast) {
+    L2S_LAUNCH(dynfilter_bwd1_bf16_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, dresp_ws, H * W, C, gate, resp, dresp_extra);
+    L2S_LAUNCH(dynfilter_bwd2_bf16_kernel, dim3(cdiv(C, 256), nchunk), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, filt, r, resp, (const float*)dresp_ws,
+               (bf16_t*)dx, (const bf16_t*)relu_ref, part, H, W, C, pchunk, gate);
+  } else {
+    L2S_LAUNCH(dynfilter_bwd1_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, dy, x, respk, dresp_ws, dr, H * W, C, dtype, gate, resp, dresp_extra);
+    L2S_LAUNCH(dynfilter_bwd2_kernel, dim3(cdiv(C, 64), nchunk), dim3(256), 0, s, dy, x, filt, r, resp, (const float*)dresp_ws, dx, relu_ref,
+                       part, H, W, C, dtype, pchunk, gate);
+  }
+  if (!dfilt) return l2s_check_launch();
   L2S_LAUNCH(dynfilter_bwd3_kernel, dim3(cdiv(7 * C, 256)), dim3(256), 0, s, (const float*)part, nchunk, (const float*)dresp_ws, respk, dfilt, dr, H * W, C);
   return l2s_check_launch();
 }

@@ -773,7 +773,8 @@ class resnetv1(Network):
         self._mark('caption join + add3')
         # dynamic filters (NET:504-562)
         dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (O.dynfilter_ws_floats(Hc, Wc, C4),), f32)
-        O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, dfilt, dfilt[7 * C4:], dresp_ws, Hc, Wc, C4,
+        # (only dbase is needed on this queue: the filter / mixing-weight gradients are finished on the language stream below)
+        O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, None, None, dresp_ws, Hc, Wc, C4,
                         gate=gate, dresp_extra=dresp_extra)
         if d_base_cap is not None:
             O.add3(dbase, d_base_cap, None, dbase)         # cycle_response: layer4 also ran on the map before the gating
@@ -782,6 +783,7 @@ class resnetv1(Network):
         if S is not None:
             self.sfork(main, S['lang'])
         with on('lang'):
+            O.dynfilter_bwd_finish(dresp_ws, respk, dfilt, dfilt[7 * C4:], Hc, Wc, C4)
             O.act_bwd(dfilt, filt, 2)
             O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NFP * HD, P.grad), P.gview('dyn_b', NFP, P.grad), 1, NFP, HD)
             dhidden = self.buf('enc.dhidden', (HD,), f32)

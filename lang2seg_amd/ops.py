@@ -395,6 +395,11 @@ def dynfilter_bwd(dy, x, filt, r, resp, respk, dx, ref, dfilt, dr, dresp_ws, H, 
          ptr(dr), ptr(dresp_ws), H, W, Cc, dt_of(x), int(gate), ptr(dresp_extra), stream())
 
 
+def dynfilter_bwd_finish(dresp_ws, respk, dfilt, dr, H, W, Cc):
+    """the part of dynfilter_bwd that only the language-side backward needs (dfilt +=, dr +=); dynfilter_bwd was called with dfilt=None"""
+    call('l2s_dynfilter_bwd_finish', ptr(dresp_ws), ptr(respk), ptr(dfilt), ptr(dr), H, W, Cc, stream())
+
+
 def roipool_fwd(feat, H, W, Cc, rois, R, P, scale, out, argmax):
     call('l2s_roipool_fwd', ptr(feat), H, W, Cc, ptr(rois), R, P, float(scale), ptr(out), ptr(argmax), dt_of(feat), stream())
 

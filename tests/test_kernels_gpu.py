@@ -893,6 +893,12 @@ def test_dynfilter(dt):
     tol = 1e-4 if dt == 0 else 2e-2
     assert rel_err(dx.float().view(1, H, W, Cc), nhwc(xr.grad * (xr > 0))) < tol
     assert rel_err(dfilt, fr.grad) < tol and rel_err(dr, rr.grad) < tol
+    # split form used by the train step: dx on the caller's stream, dfilt / dr finished later from the workspace -- bit-identical
+    dx2 = O.empty((H * W, Cc), dt); dfilt2 = torch.zeros(7, Cc, device=DEV); dr2 = torch.zeros(7, device=DEV)
+    O.dynfilter_bwd(dy, xd, filt.to(DEV), r.to(DEV), rs_, rk, dx2, xd, None, None, wsd, H, W, Cc)
+    O.dynfilter_bwd_finish(wsd, rk, dfilt2, dr2, H, W, Cc)
+    torch.cuda.synchronize()
+    assert torch.equal(dx2.float(), dx.float()) and torch.equal(dfilt2, dfilt) and torch.equal(dr2, dr)
 
 
 def test_captioner_pieces():
