@@ -133,8 +133,7 @@ class resnetv1(Network):
         capk = ['caption_model.core.a2c.weight', 'caption_model.core.h2h.weight', 'caption_model.core.attention.h2att.weight']
         for k in (capk if self.var['cap'] is not None else []):
             add(k, P.view(k), *P.shapes[k])
-        NF, HD = self._NFP, P.shapes['rnn_encoder.rnn.weight_hh_l0'][1] * 2
-        add('dyn_w', P.gview('dyn_w', NF * HD), NF, HD)
+        # (the dynamic-filter matrix, 7175 x 1024 fp32 = 29 MB, is read as stored by the split NN kernel: no copy)
         # 2x2 deconv: its forward operand [(dy,dx,co)][ci] is the transpose of the master [ci][(dy,dx,co)] (activation dtype)
         add('mask_up', P.view('mask_up_sampling.weight'), 2048, 4 * 256, dst=self.up_wT, f32=0)
 
@@ -787,7 +786,8 @@ class resnetv1(Network):
             O.act_bwd(dfilt, filt, 2)
             O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NFP * HD, P.grad), P.gview('dyn_b', NFP, P.grad), 1, NFP, HD)
             dhidden = self.buf('enc.dhidden', (HD,), f32)
-            self.bwd_x(dfilt, 'dyn_w', dhidden, 1)
+            nws = O.linear_bwd_x_ws_floats(1, NFP, HD)
+            O.linear_bwd_x(dfilt, P.gview('dyn_w', NFP * HD), dhidden, 1, NFP, HD, ws=self.buf('bwdx.ws.dyn_w', (max(nws, 1),), f32))
             self._encoder_bwd(d, dhidden)
         self._mark('dyn bwd + language bwd(lang)')
         self._backbone_bwd(dbase, saved, S, main, dp)

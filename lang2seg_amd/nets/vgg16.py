@@ -100,8 +100,6 @@ class vgg16(resnetv1):
         for sfx in ['', '_reverse']:                         # (row-batch data gradients need no copy: resnet_v1.bwd_x)
             w = 'rnn_encoder.rnn.weight_hh_l0'
             add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
-        NF, HD = self._NFP, P.shapes['rnn_encoder.rnn.weight_hh_l0'][1] * 2
-        add('dyn_w', P.gview('dyn_w', NF * HD), NF, HD)
 
     # ------------------------------------------------------------------ backbone (VGG:53-54,78-82)
     def _backbone_fwd(self, d, saved):

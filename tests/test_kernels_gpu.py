@@ -811,6 +811,27 @@ def test_row_batch_linears_mfma():
         O.linear_bwd_x(dy.to(DEV), w.to(DEV), dx2, M, N, K, accumulate=acc, mul=None if mul is None else mul.to(DEV), ws=ws)
         torch.cuda.synchronize()
         assert torch.equal(dx, dx2)
+    # a single row of a large matrix (the dynamic-filter layer: 7175 x 1024) also takes the split NN path
+    dy = torch.randn(1, 7175, generator=g); w = torch.randn(7175, 1024, generator=g) / 80.0
+    dx = torch.empty(1, 1024, device=DEV); ws = torch.full((O.linear_bwd_x_ws_floats(1, 7175, 1024),), float('nan'), device=DEV)
+    O.linear_bwd_x(dy.to(DEV), w.to(DEV), dx, 1, 7175, 1024, ws=ws)
+    torch.cuda.synchronize()
+    assert rel_err(dx, (dy.double() @ w.double()).float()) < 1e-5
+    # weight gradient of a row batch (TN): dw += dy^T x, db += column sums of dy; ragged N, dy rows that are only 8-byte aligned (3350)
+    for (M, N, K, lddy) in [(21, 3350, 512, None), (196, 512, 512, None), (196, 1024, 512, None), (21, 196, 1024, None), (7, 100, 36, None), (21, 512, 512, 768),
+                            (2, 64, 64, None)]:
+        ld = N if lddy is None else lddy
+        dyf = torch.randn(M, ld, generator=g); x = torch.randn(M, K, generator=g)
+        dw0 = torch.randn(N, K, generator=g); db0 = torch.randn(N, generator=g)
+        refw = dw0.double() + dyf[:, :N].double().t() @ x.double(); refb = db0.double() + dyf[:, :N].double().sum(0)
+        dw = dw0.to(DEV).clone(); db = db0.to(DEV).clone()
+        O.linear_bwd_w(dyf.to(DEV), x.to(DEV), dw, db, M, N, K, lddy=ld)
+        torch.cuda.synchronize()
+        assert rel_err(dw, refw.float()) < 1e-5 and rel_err(db, refb.float()) < 1e-5, (M, N, K, lddy)
+        dw2 = dw0.to(DEV).clone()
+        O.linear_bwd_w(dyf.to(DEV), x.to(DEV), dw2, None, M, N, K, lddy=ld)
+        torch.cuda.synchronize()
+        assert torch.equal(dw, dw2)
 
 
 def test_linear_embed_lstm():
