@@ -106,9 +106,10 @@ int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
 int l2s_weight_cast(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
 /* data-gradient layout: dst(dtype)[Cin][taps][Cout], tap order reversed (180-degree flip), * scale[co] */
 int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
-/* all data-gradient copies of one step in one launch: table (DEVICE memory) of n descriptors */
+/* all data-gradient copies of one step in one launch: table (DEVICE memory) of n descriptors; total_tiles = sum over the descriptors of
+ * ceil(Cin / 64) * ceil(Cout / 64) * taps (the launch walks one flat tile index) */
 typedef struct { const float* src; const float* scale; void* dst; int Cout, taps, Cin, force_f32; } l2s_transpose_desc;
-int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int dtype, hipStream_t s);
+int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int total_tiles, int dtype, hipStream_t s);
 /* column sums: out[c] += sum_r a[r][c] (bias gradients), no atomics; ws (nullable, 32*cols floats): partial sums of the row ranges a tall
  * matrix is cut into, added in order by a second launch */
 int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, float* ws, long ws_floats, int dtype, hipStream_t s);

@@ -67,7 +67,7 @@ SIGS = {
     'l2s_weight_cast': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_weight_transpose': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     'l2s_colsum': (i32, [vp, i32, i32, i32, vp, vp, i64, i32, vp]),
-    'l2s_weight_transpose_batched': (i32, [vp, i32, i32, vp]),
+    'l2s_weight_transpose_batched': (i32, [vp, i32, i32, i32, vp]),
     'l2s_stem_conv': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_maxpool3x3s2': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_fill_f32': (i32, [vp, f32, i64, vp]),

@@ -525,16 +525,17 @@ class Network(object):
                 arr[i].Cout, arr[i].taps, arr[i].Cin, arr[i].force_f32 = c.Np, c.k * c.k, c.Cin, int(getattr(c, 'force_f32', 0))
             self._tr_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             self._tr_n = len(items)
+            self._tr_tiles = sum(((c.Cin + 63) // 64) * ((c.Np + 63) // 64) * c.k * c.k for c in items)
         if self.use_streams and not full:
             # the transposed copies are first read by the NEXT step's mask head / backward: rebuild them on a side stream that
             # overlaps with the next step's backbone forward (joined by join_transposes())
             S = self.streams()
             self.sfork(torch.cuda.current_stream(), S['tr'])
             with torch.cuda.stream(S['tr']):
-                O.weight_transpose_batched(self._tr_table, self._tr_n, self.dt)
+                O.weight_transpose_batched(self._tr_table, self._tr_n, self._tr_tiles, self.dt)
             self._tr_pending = True
         else:
-            O.weight_transpose_batched(self._tr_table, self._tr_n, self.dt)
+            O.weight_transpose_batched(self._tr_table, self._tr_n, self._tr_tiles, self.dt)
 
     def join_transposes(self):
         # unconditional: whether a refresh is pending is host state, and a step recorded on a launch tape must contain the edge

@@ -130,7 +130,9 @@ class resnetv1(Network):
         for sfx in ['', '_reverse']:
             w = 'rnn_encoder.rnn.weight_hh_l0'
             add(w + sfx, P.view(w + sfx), *P.shapes[w + sfx])
-        capk = ['caption_model.core.a2c.weight', 'caption_model.core.h2h.weight', 'caption_model.core.attention.h2att.weight']
+        capk = ['caption_model.core.h2h.weight', 'caption_model.core.attention.h2att.weight']
+        if not (self.cap_projected and self.opt['rnn_size'] <= 1024):
+            capk.append('caption_model.core.a2c.weight')     # (the projected-attention recurrence never multiplies by a2c^T row by row)
         for k in (capk if self.var['cap'] is not None else []):
             add(k, P.view(k), *P.shapes[k])
         # (the dynamic-filter matrix, 7175 x 1024 fp32 = 29 MB, is read as stored by the split NN kernel: no copy)

@@ -153,8 +153,8 @@ def weight_transpose(src, scale, dst, Cout, taps, Cin):
     call('l2s_weight_transpose', ptr(src), ptr(scale), ptr(dst), Cout, taps, Cin, dt_of(dst), stream())
 
 
-def weight_transpose_batched(table_dev, n, dt):
-    call('l2s_weight_transpose_batched', ptr(table_dev), n, dt, stream())
+def weight_transpose_batched(table_dev, n, total_tiles, dt):
+    call('l2s_weight_transpose_batched', ptr(table_dev), n, total_tiles, dt, stream())
 
 
 def colsum(a, rows, cols, lda, out, ws=None):
