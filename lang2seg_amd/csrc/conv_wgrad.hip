@@ -380,7 +380,15 @@ int launch_single(const l2s_wgrad_desc& d, int split, hipStream_t st) {
 
 template <typename T, int BM, int BN, int TX, int D, int KSTEP>
 int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_split, hipStream_t st) {
-  const size_t lds = wgrad_lds<T, BM, BN, TX, KSTEP>();
+  size_t lds = wgrad_lds<T, BM, BN, TX, KSTEP>();
+  // A grouped launch is resident for hundreds of microseconds next to the main queue's small dependent launches, whose workgroups
+  // (32 KiB of LDS) can only start on a CU with that much LDS free: two 128x128 tiles (2 x 74 KiB) leave none, and every main-queue launch
+  // then waits for weight-gradient workgroups to retire.  The LDS REQUEST therefore bounds the residency: one 128x128 workgroup per CU
+  // (>= 81 KiB requested), two of the smaller tiles (>= 54 KB), which always leaves >= 50 KiB.  158.3 -> 161.9 img/s (A/B in one box).
+  static const size_t want = [] { const char* e = getenv("L2S_WGRAD_LDS"); return e ? (size_t)atol(e) : (size_t)54000; }();
+  static const size_t want_big = [] { const char* e = getenv("L2S_WGRAD_LDS_BIG"); return e ? (size_t)atol(e) : (size_t)83000; }();
+  if (BM * BN >= 128 * 128) { if (want_big > lds) lds = want_big; }
+  else if (want > lds) lds = want;
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP>), dim3(pre.tile0[pre.n]), dim3(256), lds, st, tab, pre, ws);

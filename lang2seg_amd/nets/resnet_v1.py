@@ -791,6 +791,7 @@ class resnetv1(Network):
             nws = O.linear_bwd_x_ws_floats(1, NFP, HD)
             O.linear_bwd_x(dfilt, P.gview('dyn_w', NFP * HD), dhidden, 1, NFP, HD, ws=self.buf('bwdx.ws.dyn_w', (max(nws, 1),), f32))
             self._encoder_bwd(d, dhidden)
+            self._mark('language bwd done (lang)')
         self._mark('dyn bwd + language bwd(lang)')
         self._backbone_bwd(dbase, saved, S, main, dp)
         self.flush_wgrads('backbone')                           # whatever a backbone variant left queued
