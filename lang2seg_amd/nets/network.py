@@ -497,15 +497,18 @@ class Network(object):
         return self
 
     def state_dict(self):
+        self.join_update()                          # (an update may still be running on the weight-gradient stream)
         return self.P.state_dict()
 
     def load_state_dict(self, sd, strict=False):
+        self.join_update()
         self.P.load_state_dict(sd, strict)
         self.refresh_weights(full=True)
 
     def named_parameters(self):
         """(name, fp32 tensor in the REFERENCE layout) for every trainable tensor (TV:194-220 iterates these)."""
         from .params import from_internal
+        self.join_update()
         for k in self.P.trainable:
             yield k, from_internal(k, self.P.view(k), self.P.shapes[k])
 
@@ -536,6 +539,15 @@ class Network(object):
             self._tr_pending = True
         else:
             O.weight_transpose_batched(self._tr_table, self._tr_n, self._tr_tiles, self.dt)
+
+    update_on_wg = False
+
+    def join_update(self):
+        """the current stream waits for the optimiser update of the previous step when that ran on the weight-gradient stream
+        (optim.SGD.side): called before the first launch that reads a trainable weight or writes a gradient.  Unconditional once the
+        mode is on (a step recorded on a launch tape must contain the edge)."""
+        if self.use_streams and self.update_on_wg:
+            self.sfork(self.streams()['wg'], torch.cuda.current_stream())
 
     def join_transposes(self):
         # unconditional: whether a refresh is pending is host state, and a step recorded on a launch tape must contain the edge

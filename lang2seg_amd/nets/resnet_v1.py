@@ -392,9 +392,13 @@ class resnetv1(Network):
         O.maxpool(c1, x, OH1, OW1, 64, h, w)
         self._mark('stem')
         for li in (1, 2, 3):
+            if li == cfg.RESNET.FIXED_BLOCKS + 1:
+                self.join_update()                             # first trainable layer: the previous step's update must have landed
             for b, blk in enumerate(self.layers[li]):
                 x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
                 saved[(li, b)] = sv
+        if cfg.RESNET.FIXED_BLOCKS >= 3:
+            self.join_update()
         return x, h, w
 
     def _backbone_bwd(self, dbase, saved, S, main, dp):
@@ -539,17 +543,23 @@ class resnetv1(Network):
         im_h, im_w = float(d['im_info'][0]), float(d['im_info'][1])
         self._im_hw = (im_h, im_w)
         self._mark('step start')
-        O.memset_zero(P.grad)
-        O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
-        loss = self.buf('loss', (8,), f32, zero=True)
         main = torch.cuda.current_stream()
         S = self.streams() if self.use_streams else None
+        if S is not None and self.update_on_wg:
+            with torch.cuda.stream(S['wg']):                # behind the previous step's update, which read the gradients
+                O.memset_zero(P.grad)
+        else:
+            O.memset_zero(P.grad)
+        O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
+        loss = self.buf('loss', (8,), f32, zero=True)
         import contextlib
         def on(name):
             return torch.cuda.stream(S[name]) if S is not None else contextlib.nullcontext()
         # ---- expression encoding (ENC:27-82) forked onto the language stream: 80 dependent GEMV launches that overlap with the backbone
         if S is not None:
             self.sfork(main, S['lang'])
+            if self.update_on_wg:
+                self.sfork(S['wg'], S['lang'])                  # the encoder reads updated weights
         with on('lang'):
             hidden = self._encoder_fwd(d)
             HD = hidden.numel()
@@ -807,6 +817,7 @@ class resnetv1(Network):
         P = self.P
         C4 = self._C4_feat_dim
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
+        self.join_update()
         hidden = self._encoder_fwd(d)
         HD = hidden.numel()
         NF, NFP = 7 * C4 + 7, self._NFP
