@@ -1011,6 +1011,7 @@ __global__ __launch_bounds__(256) void linear_tn_mfma_kernel(const float* __rest
   if (n0 >= N) return;
   const int nc = n0 + 4 * j, kc = min(k0 + 4 * j, K - 4);         // K % 4 == 0; clamped columns are computed and not stored
   floatx4 acc[4][4];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1035,6 +1036,8 @@ __global__ __launch_bounds__(256) void linear_tn_mfma_kernel(const float* __rest
     const float4 bv = *(const float4*)(x + (long)min(m, M - 1) * ldx_ + kc);   // rows past M meet av == 0
     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
+    for (int a = 0; a < 4; ++a) cs[a] += av[a];
+#pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bb[b], acc[a][b], 0, 0, 0);
@@ -1056,11 +1059,13 @@ __global__ __launch_bounds__(256) void linear_tn_mfma_kernel(const float* __rest
       }
   }
   if (db && blockIdx.x == 0) {
-    const int n = n0 + lane;
-    if (n < N) {
-      float sacc = 0.f;
-      for (int m = 0; m < M; ++m) sacc += dy[(long)m * lddy + n];
-      db[n] += sacc;
+    // column sums of dy from the values the lanes already hold: lane (j, kq) summed rows kq, kq + 4, ... of columns nc .. nc + 3
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = cs[q];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (kq == 0 && nc + q < N) db[nc + q] += v;
     }
   }
 }
