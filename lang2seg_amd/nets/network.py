@@ -175,7 +175,7 @@ class WgradQueue(object):
                     if ctx is not None:
                         ctx.__exit__(None, None, None)
 
-    MIN_WG = 1024        # workgroups a grouped launch should have before its problems stop splitting their pixels
+    MIN_WG = int(os.environ.get('L2S_WGRAD_MIN_WG', '384'))   # workgroups a grouped launch should have before its problems stop splitting their pixels
 
 
 class Bottleneck(object):
