@@ -546,6 +546,7 @@ class resnetv1(Network):
         main = torch.cuda.current_stream()
         S = self.streams() if self.use_streams else None
         if S is not None and self.update_on_wg:
+            self.sfork(main, S['wg'])                       # (an update that ran on this queue after all, e.g. early partial updates)
             with torch.cuda.stream(S['wg']):                # behind the previous step's update, which read the gradients
                 O.memset_zero(P.grad)
         else:

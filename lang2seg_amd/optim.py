@@ -15,6 +15,10 @@ class SGD(object):
         self.net = net
         self.lr, self.momentum, self.weight_decay, self.grad_scale = float(lr), float(momentum), float(weight_decay), float(grad_scale)
         self.param_groups = [self.__dict__]        # scale_lr()-style code can do group['lr'] *= gamma
+        # decided once, before the first step: the edges of this mode are part of every recorded launch tape
+        self.side_active = bool(self.side and not self.early and getattr(net, 'use_streams', False) and hasattr(net, 'flush_wgrads'))
+        if self.side_active:
+            net.update_on_wg = True
 
     def zero_grad(self):
         pass                                        # gradients are zeroed at the start of forward_backward
@@ -64,7 +68,7 @@ class SGD(object):
     def step(self):
         P = self.net.P
         net = self.net
-        if self.side and getattr(net, 'use_streams', False) and not self._seg_done and hasattr(net, 'flush_wgrads'):
+        if self.side_active and net.use_streams and not self.early and not self._seg_done:
             net.flush_wgrads('final')
             S = net.streams()
             for k in ('wg2', 'lang', 'cap'):
@@ -74,7 +78,6 @@ class SGD(object):
                 self._launch(0, P.nseg)
                 net.refresh_weights()
                 net._mark('update done (wg)')
-            net.update_on_wg = True
             return
         if hasattr(self.net, 'join_wgrad'):
             self.net.join_wgrad()                   # weight-gradient stream -> current stream

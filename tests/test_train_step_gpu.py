@@ -617,6 +617,35 @@ def test_tape_over_mixed_shapes_matches_eager():
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (k, order[k], a, b)
 
 
+def test_pipelined_tape_training_matches_eager_training():
+    """weights after ten PIPELINED steps with a real learning rate (no host sync between steps, so the next step's launches are queued while
+    the optimiser update of the previous one runs on the weight-gradient stream): replayed from the launch tape vs issued eagerly, f32, same
+    data.  Catches a missing cross-stream edge of the update (round 2: a tape recorded before the update moved to the weight-gradient stream
+    cleared the gradients on the main queue while the update was still reading them -- nothing learned, every test with lr 0 passed)."""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=16, RPN_PRE_NMS_TOP_N=600, RPN_POST_NMS_TOP_N=100, RPN_BATCHSIZE=64)
+    blob = OS.make_blob(160, 224, 6, 60, seed=5)
+    params = []
+    for tape in (False, True):
+        net = selftest.build_net(opt, over, 'f32', sd)            # (sampling keys and dropout masks: device RNG keyed by the step counter,
+        net.use_tape = tape                                      #  the same sequence in both runs)
+        sgd = SGD(net, 1e-3, momentum=0.9, weight_decay=1e-4)
+        p0 = net.P.param.clone()
+        for _ in range(10):
+            net.train_step_async(dict(blob), 0, sgd)
+        torch.cuda.synchronize()
+        net.join_update()
+        torch.cuda.synchronize()
+        params.append(net.P.param.clone())
+        assert bool(torch.isfinite(params[-1]).all()) and float((params[-1] - p0).abs().max()) > 1e-5       # it did learn something
+    a, b = params
+    assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
+
+
 def test_tape_stops_recording_when_shapes_keep_changing():
     """a stream of inputs whose (image size, token count) key is new almost every step: once fewer than half of the last `tape_window`
     steps were replays, a miss runs eagerly and is not recorded (no tape, no pinned activation plan per key); known keys keep replaying"""
@@ -692,3 +721,18 @@ def test_bench_json_contract():
     assert 0 < d['sync_train_step']['value'] <= d['value'] * 1.05 and 0 < d['pcie_inclusive']['value'] <= d['value'] * 1.05
     assert d['pcie_inclusive']['h2d_bytes_per_step'] == 600 * 1000 * 3 * 4
     assert all(np.isfinite(v) for v in d['final_losses'])
+
+
+def test_bench_workload_learns_when_pipelined():
+    """the timed loop of bench.py (pipelined tape replays, update on the weight-gradient stream) must actually train: after 200 steps on its four
+    synthetic images the RoI classification loss has left ln(81) = 4.394 and the RPN loss ln 2.  (Round 2: a tape recorded before the update
+    moved to the weight-gradient stream cleared the gradients while the update was still reading them; every lr-0 parity test passed and
+    the losses stayed at their initial values.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '200', '--warmup', '5', '--no-cpu-baseline', '--extras', '0'],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    rpn_cls, _, cls = d['final_losses'][:3]
+    assert cls < 4.3 and rpn_cls < 0.69, d['final_losses']
