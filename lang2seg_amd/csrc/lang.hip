@@ -614,6 +614,28 @@ __global__ __launch_bounds__(256) void linear_sum2_kernel(const float* __restric
   a1 = wave_sum(a1); a2 = wave_sum(a2);
   if (lane == 0) { float v = a1 + a2; if (accumulate) v += y[n]; y[n] = v; }
 }
+// the same with the four waves of a workgroup splitting the K range of ONE output (four times the workgroups, a quarter of the
+// dependent loads per wave): the launch sits on the caption branch's backward chain once per token
+__global__ __launch_bounds__(256) void linear_sum2_split_kernel(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
+                                                               const float* __restrict__ w2, int K2, float* y, int N, int accumulate) {
+  __shared__ float part[4];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* r1 = w1 + (long)n * K1; const float* r2 = w2 + (long)n * K2;
+  const int q1 = ((K1 / 4 + 3) / 4) * 4, q2 = ((K2 / 4 + 3) / 4) * 4;       // per-wave K ranges, multiples of 4
+  float a = 0.f;
+  for (int k = wv * q1 + lane * 4; k < min(K1, (wv + 1) * q1); k += 256) {
+    const float4 wv4 = *(const float4*)(r1 + k), xv = *(const float4*)(x1 + k);
+    a = fmaf(wv4.x, xv.x, fmaf(wv4.y, xv.y, fmaf(wv4.z, xv.z, fmaf(wv4.w, xv.w, a))));
+  }
+  for (int k = wv * q2 + lane * 4; k < min(K2, (wv + 1) * q2); k += 256) {
+    const float4 wv4 = *(const float4*)(r2 + k), xv = *(const float4*)(x2 + k);
+    a = fmaf(wv4.x, xv.x, fmaf(wv4.y, xv.y, fmaf(wv4.z, xv.z, fmaf(wv4.w, xv.w, a))));
+  }
+  a = wave_sum(a);
+  if (lane == 0) part[wv] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) { float v = ((part[0] + part[1]) + part[2]) + part[3]; if (accumulate) v += y[n]; y[n] = v; }
+}
 // a2c Linear (rows j and R + j) fused with the gate nonlinearity of unit j (ATT:449-462): one wave per unit
 __global__ __launch_bounds__(256) void cap_a2c_gates_kernel(const float* __restrict__ ares, const float* __restrict__ w, const float* __restrict__ b, int K,
                                                            const float* __restrict__ s, const float* __restrict__ c_prev, float* c, float* h,
@@ -1261,7 +1283,9 @@ extern "C" int l2s_linear2_fwd(const float* x, int K, const float* w1, const flo
 extern "C" int l2s_linear_sum2_fwd(const float* x1, const float* w1, int K1, const float* x2, const float* w2, int K2, float* y, int N,
                                    int accumulate, hipStream_t s) {
   if ((K1 & 3) || (K2 & 3) || ((uintptr_t)x1 & 15) || ((uintptr_t)x2 & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15)) return L2S_EINVAL;
-  L2S_LAUNCH(linear_sum2_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, x1, w1, K1, x2, w2, K2, y, N, accumulate);
+  static const int split = [] { const char* e = getenv("L2S_SUM2_SPLIT"); return e ? atoi(e) : 1; }();
+  if (split && N <= 4096) L2S_LAUNCH(linear_sum2_split_kernel, dim3(N), dim3(256), 0, s, x1, w1, K1, x2, w2, K2, y, N, accumulate);
+  else L2S_LAUNCH(linear_sum2_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, x1, w1, K1, x2, w2, K2, y, N, accumulate);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_a2c_gates_fwd(const float* att_res, const float* w_a2c, const float* b_a2c, int K, const float* sums, const float* c_prev,
