@@ -138,6 +138,83 @@ __device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x
     }
 }
 
+// ---- LDS-staged epilogue of the 128x128 bf16 tile (4 waves as 2 x 2, wave tile 64 x 64): the MFMA layout gives a lane 4 channels of 16
+// different pixels, i.e. 8-byte accesses in 32-byte runs to the output, the residual and the ReLU-mask operand.  Staging the fp32 tile
+// (+ bias) through LDS, 64 rows at a time, turns them into 16-byte accesses that cover whole 256-byte rows.  Same arithmetic order as
+// igemm_epilogue_fast (bias, residual, ReLU, mask in fp32, one rounding). ----
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, char* smem) {
+  constexpr int LDW = 132;                                   // floats per staged row (128 + 4: shifts consecutive rows by 4 banks)
+  constexpr unsigned NOPE = 0x80000000u;
+  float* st = (float*)smem;
+  const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFFFF, 0x00020000);
+  const auto radd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add ? p.add : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref ? p.ref : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const int tid = threadIdx.x;
+  f32x4 bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + fg * 4;
+    bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n < p.Cout) bv[j] = *(const f32x4*)(p.bias + n);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                                         // the K loop's (h = 0) / the previous half's (h = 1) LDS reads are done
+    if (wm == h) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x4 v = acc[i][j];
+          v[0] += bv[j][0]; v[1] += bv[j][1]; v[2] += bv[j][2]; v[3] += bv[j][3];
+          *(f32x4*)(st + (i * 16 + fr) * LDW + wn * 64 + j * 16 + fg * 4) = v;
+        }
+    }
+    __syncthreads();
+    // 64 rows x 16 chunks of 8 channels: 4 chunks per thread, 16 lanes per 256-byte output row
+    u32x4v av[4], rv[4];
+    unsigned off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + 256 * k, row = c >> 4, col = (c & 15) * 8;
+      const int m = m0 + h * 64 + row, n = n0 + col;
+      const bool ok = m < M && n < p.Cout;
+      off[k] = ok ? (unsigned)m : NOPE;
+      if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
+      if (p.ref) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rref, ok ? (unsigned)((m * p.ldref + n) * 2) : NOPE, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + 256 * k, row = c >> 4, col = (c & 15) * 8;
+      const f32x4 lo = *(const f32x4*)(st + row * LDW + col), hi = *(const f32x4*)(st + row * LDW + col + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (p.add) {
+        const unsigned w[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u); }
+      }
+      if (p.flags & L2S_CONV_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.ref) {
+        const unsigned w[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!(__uint_as_float(w[e] << 16) > 0.f)) v[2 * e] = 0.f;
+          if (!(__uint_as_float(w[e] & 0xFFFF0000u) > 0.f)) v[2 * e + 1] = 0.f;
+        }
+      }
+      u32x4v pk;
+      pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      const int n = n0 + col;
+      __builtin_amdgcn_raw_buffer_store_b128(pk, ry, off[k] != NOPE ? (unsigned)((off[k] * p.ldy + n) * 2) : NOPE, 0, 0);
+    }
+  }
+}
+
 // ---- shared epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 accumulator tile ----
 template <typename T, int TM, int TN, int WM, int WN, bool OUTF32, int KS = 1>
 __device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, int grp = 0) {
@@ -385,6 +462,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 // Requires Cin % BK == 0 for every tap (no K tail) and operand extents < 2 GiB; the launcher falls back otherwise.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned OOR = 0x80000000u;
+constexpr int EPI_LDS_FLAG = 1 << 29;   // internal: LDS-staged epilogue selected by the launcher (needs 34 KiB of the tile's LDS)
 
 template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS, int RB = 128>
 __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void igemm_ring_kernel(const l2s_conv_desc p) {
@@ -565,6 +643,13 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
             }
         }
       }
+  }
+  if constexpr (sizeof(T) == 2 && !OUTF32 && KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2) {
+    // whole-row 16-byte accesses through an LDS-staged fp32 tile when every row pitch allows it
+    const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
+                       !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
+                       (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
+    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
   }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp);
 }
@@ -1010,6 +1095,8 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     const double wbytes = (double)d->Cout * K * esz, abytes = (double)d->n_img * d->IH * d->IW * d->Cin * esz;
     dd.xcd_mode = (wbytes + abytes / 8.0 <= 3.0 * 1024 * 1024) ? 0 : 1;
   }
+  static const int epi_lds = [] { const char* e = getenv("L2S_IGEMM_EPI_LDS"); return e ? atoi(e) : 1; }();
+  if (epi_lds) dd.flags |= EPI_LDS_FLAG;
   d = &dd;
   // ring kernel (default): needs whole 128-byte K slices per tap and 31-bit operand extents
   static const int ring_d = [] { const char* e = getenv("L2S_IGEMM_RING"); return e ? atoi(e) : -1; }();   // 0 = off
