@@ -142,9 +142,11 @@ __device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x
 // different pixels, i.e. 8-byte accesses in 32-byte runs to the output, the residual and the ReLU-mask operand.  Staging the fp32 tile
 // (+ bias) through LDS, 64 rows at a time, turns them into 16-byte accesses that cover whole 256-byte rows.  Same arithmetic order as
 // igemm_epilogue_fast (bias, residual, ReLU, mask in fp32, one rounding). ----
-template <int TM, int TN>
+template <int TM, int TN, int WM, int WN, int WGM, int NT>
 __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, char* smem) {
+  // (tile width 128 = WGN x WN; WGM passes of WM rows: the waves of row group h stage their sub-tiles, then all NT threads store them)
   constexpr int LDW = 132;                                   // floats per staged row (128 + 4: shifts consecutive rows by 4 banks)
+  constexpr int CH = WM * 16, IT = (CH + NT - 1) / NT;        // 8-channel chunks of one pass, chunks per thread
   constexpr unsigned NOPE = 0x80000000u;
   float* st = (float*)smem;
   const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFFFF, 0x00020000);
@@ -154,13 +156,13 @@ __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f3
   f32x4 bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + fg * 4;
+    const int n = n0 + wn * WN + j * 16 + fg * 4;
     bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (p.bias && n < p.Cout) bv[j] = *(const f32x4*)(p.bias + n);
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();                                         // the K loop's (h = 0) / the previous half's (h = 1) LDS reads are done
+  for (int h = 0; h < WGM; ++h) {
+    __syncthreads();                                         // the K loop's (h = 0) / the previous pass's LDS reads are done
     if (wm == h) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -168,25 +170,25 @@ __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f3
         for (int j = 0; j < TN; ++j) {
           f32x4 v = acc[i][j];
           v[0] += bv[j][0]; v[1] += bv[j][1]; v[2] += bv[j][2]; v[3] += bv[j][3];
-          *(f32x4*)(st + (i * 16 + fr) * LDW + wn * 64 + j * 16 + fg * 4) = v;
+          *(f32x4*)(st + (i * 16 + fr) * LDW + wn * WN + j * 16 + fg * 4) = v;
         }
     }
     __syncthreads();
-    // 64 rows x 16 chunks of 8 channels: 4 chunks per thread, 16 lanes per 256-byte output row
-    u32x4v av[4], rv[4];
-    unsigned off[4];
+    // WM rows x 16 chunks of 8 channels; 16 lanes cover one 256-byte output row
+    u32x4v av[IT], rv[IT];
+    unsigned off[IT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = tid + 256 * k, row = c >> 4, col = (c & 15) * 8;
-      const int m = m0 + h * 64 + row, n = n0 + col;
-      const bool ok = m < M && n < p.Cout;
+    for (int k = 0; k < IT; ++k) {
+      const int c = tid + NT * k, row = c >> 4, col = (c & 15) * 8;
+      const int m = m0 + h * WM + row, n = n0 + col;
+      const bool ok = c < CH && m < M && n < p.Cout;
       off[k] = ok ? (unsigned)m : NOPE;
       if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
       if (p.ref) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rref, ok ? (unsigned)((m * p.ldref + n) * 2) : NOPE, 0, 0);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = tid + 256 * k, row = c >> 4, col = (c & 15) * 8;
+    for (int k = 0; k < IT; ++k) {
+      const int c = min(tid + NT * k, CH - 1), row = c >> 4, col = (c & 15) * 8;
       const f32x4 lo = *(const f32x4*)(st + row * LDW + col), hi = *(const f32x4*)(st + row * LDW + col + 4);
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       if (p.add) {
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
     const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                        !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                        (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
+    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
   }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp);
 }
@@ -850,6 +852,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
       mma(fa1, fb1);
       b0 = bt1;
     }
+  }
+  if constexpr (sizeof(T) == 2 && !OUTF32 && BN == 128) {
+    const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
+                       !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
+                       (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
+    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG>(p, acc, m0, n0, wm, wn, fr, fg, M, smem); return; }
   }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
