@@ -142,11 +142,14 @@ __device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x
 // different pixels, i.e. 8-byte accesses in 32-byte runs to the output, the residual and the ReLU-mask operand.  Staging the fp32 tile
 // (+ bias) through LDS, 64 rows at a time, turns them into 16-byte accesses that cover whole 256-byte rows.  Same arithmetic order as
 // igemm_epilogue_fast (bias, residual, ReLU, mask in fp32, one rounding). ----
-template <int TM, int TN, int WM, int WN, int WGM, int NT>
+template <int TM, int TN, int WM, int WN, int WGM, int NT, int BN, int PASSES>
 __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, char* smem) {
-  // (tile width 128 = WGN x WN; WGM passes of WM rows: the waves of row group h stage their sub-tiles, then all NT threads store them)
-  constexpr int LDW = 132;                                   // floats per staged row (128 + 4: shifts consecutive rows by 4 banks)
-  constexpr int CH = WM * 16, IT = (CH + NT - 1) / NT;        // 8-channel chunks of one pass, chunks per thread
+  // (tile width BN = WGN x WN; PASSES passes of RP rows: the waves whose rows fall into pass h stage their sub-tiles, then all NT threads
+  // store them; one pass when the whole fp32 tile fits the kernel's LDS)
+  constexpr int LDW = BN + 4;                                // floats per staged row (+ 4: shifts consecutive rows by 4 banks)
+  constexpr int RP = WM * WGM / PASSES, CPR = BN / 8;        // rows per pass, 8-channel chunks per row
+  constexpr int CH = RP * CPR, IT = (CH + NT - 1) / NT;      // chunks of one pass, chunks per thread
+  static_assert((WM * WGM) % PASSES == 0 && RP % WM == 0, "passes");
   constexpr unsigned NOPE = 0x80000000u;
   float* st = (float*)smem;
   const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFFFF, 0x00020000);
@@ -161,26 +164,27 @@ __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f3
     if (p.bias && n < p.Cout) bv[j] = *(const f32x4*)(p.bias + n);
   }
 #pragma unroll
-  for (int h = 0; h < WGM; ++h) {
+  for (int h = 0; h < PASSES; ++h) {
     __syncthreads();                                         // the K loop's (h = 0) / the previous pass's LDS reads are done
-    if (wm == h) {
+    if ((wm * WM) / RP == h) {
+      const int r0 = wm * WM - h * RP;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           f32x4 v = acc[i][j];
           v[0] += bv[j][0]; v[1] += bv[j][1]; v[2] += bv[j][2]; v[3] += bv[j][3];
-          *(f32x4*)(st + (i * 16 + fr) * LDW + wn * WN + j * 16 + fg * 4) = v;
+          *(f32x4*)(st + (r0 + i * 16 + fr) * LDW + wn * WN + j * 16 + fg * 4) = v;
         }
     }
     __syncthreads();
-    // WM rows x 16 chunks of 8 channels; 16 lanes cover one 256-byte output row
+    // RP rows x CPR chunks of 8 channels; CPR lanes cover one output row of the tile
     u32x4v av[IT], rv[IT];
     unsigned off[IT];
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
-      const int c = tid + NT * k, row = c >> 4, col = (c & 15) * 8;
-      const int m = m0 + h * WM + row, n = n0 + col;
+      const int c = tid + NT * k, row = c / CPR, col = (c % CPR) * 8;
+      const int m = m0 + h * RP + row, n = n0 + col;
       const bool ok = c < CH && m < M && n < p.Cout;
       off[k] = ok ? (unsigned)m : NOPE;
       if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
@@ -188,7 +192,7 @@ __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f3
     }
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
-      const int c = min(tid + NT * k, CH - 1), row = c >> 4, col = (c & 15) * 8;
+      const int c = min(tid + NT * k, CH - 1), row = c / CPR, col = (c % CPR) * 8;
       const f32x4 lo = *(const f32x4*)(st + row * LDW + col), hi = *(const f32x4*)(st + row * LDW + col + 4);
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       if (p.add) {
@@ -464,7 +468,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 // Requires Cin % BK == 0 for every tap (no K tail) and operand extents < 2 GiB; the launcher falls back otherwise.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned OOR = 0x80000000u;
-constexpr int EPI_LDS_FLAG = 1 << 29;   // internal: LDS-staged epilogue selected by the launcher (needs 34 KiB of the tile's LDS)
+constexpr int EPI_LDS_FLAG = 1 << 29;   // internal: LDS-staged epilogue selected by the launcher (reuses the tile's LDS)
+constexpr int EPI_LDS_FLAG64 = 1 << 28; // the same for the 64x64 tile (separate switch: its launches are latency-bound)
 
 template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS, int RB = 128>
 __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void igemm_ring_kernel(const l2s_conv_desc p) {
@@ -646,12 +651,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
         }
       }
   }
-  if constexpr (sizeof(T) == 2 && !OUTF32 && KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2) {
+  if constexpr (sizeof(T) == 2 && !OUTF32 && KS == 1 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) && WGM == 2 && WGN == 2) {
     // whole-row 16-byte accesses through an LDS-staged fp32 tile when every row pitch allows it
     const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                        !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                        (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
+    if (plain && (p.flags & (BM == 64 ? EPI_LDS_FLAG64 : EPI_LDS_FLAG))) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG, BN, (BM == 128 ? 2 : 1)>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
   }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp);
 }
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
     const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                        !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                        (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG>(p, acc, m0, n0, wm, wn, fr, fg, M, smem); return; }
+    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem); return; }
   }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
@@ -1105,6 +1110,8 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   }
   static const int epi_lds = [] { const char* e = getenv("L2S_IGEMM_EPI_LDS"); return e ? atoi(e) : 1; }();
   if (epi_lds) dd.flags |= EPI_LDS_FLAG;
+  static const int epi_lds64 = [] { const char* e = getenv("L2S_IGEMM_EPI_LDS64"); return e ? atoi(e) : 1; }();
+  if (epi_lds64) dd.flags |= EPI_LDS_FLAG64;
   d = &dd;
   // ring kernel (default): needs whole 128-byte K slices per tap and 31-bit operand extents
   static const int ring_d = [] { const char* e = getenv("L2S_IGEMM_RING"); return e ? atoi(e) : -1; }();   // 0 = off
