@@ -292,6 +292,54 @@ __global__ __launch_bounds__(256) void dynfilter_fwd_kernel(const void* x, const
   const float mult = gate ? sigm(rs) : rs;
   for (int c = lane; c < C; c += 64) stx(y, (long)pix * C + c, dt, ldx(x, (long)pix * C + c, dt) * mult);
 }
+// bf16, C % 8 == 0, C <= 2048: 8 channels (16 bytes) per lane and trip, the pixel's values stay in registers for the modulation
+__global__ __launch_bounds__(256) void dynfilter_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ filt, const float* __restrict__ r, bf16_t* y,
+                                                                float* resp, float* respk, int H, int W, int C, int gate) {
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pix >= H * W) return;
+  float d[7] = {0, 0, 0, 0, 0, 0, 0};
+  float xv[4][8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = (lane + 64 * t) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[t][e] = 0.f;
+    if (c < C) {
+      const uint4 q = *(const uint4*)(x + (long)pix * C + c);
+      const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xv[t][2 * e] = __uint_as_float(qw[e] << 16); xv[t][2 * e + 1] = __uint_as_float(qw[e] & 0xFFFF0000u); }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float4 f0 = *(const float4*)(filt + k * C + c), f1 = *(const float4*)(filt + k * C + c + 4);
+        d[k] = fmaf(xv[t][0], f0.x, d[k]); d[k] = fmaf(xv[t][1], f0.y, d[k]); d[k] = fmaf(xv[t][2], f0.z, d[k]); d[k] = fmaf(xv[t][3], f0.w, d[k]);
+        d[k] = fmaf(xv[t][4], f1.x, d[k]); d[k] = fmaf(xv[t][5], f1.y, d[k]); d[k] = fmaf(xv[t][6], f1.z, d[k]); d[k] = fmaf(xv[t][7], f1.w, d[k]);
+      }
+    }
+  }
+  float m[7]; spatial_mask7(pix / W, pix % W, H, W, m);
+  float rs = 0.f;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { d[k] = wave_sum(d[k]) * m[k]; rs = fmaf(r[k], d[k], rs); }
+  if (lane < 7) {
+    float dv = d[0];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) if (lane == k) dv = d[k];
+    respk[(long)pix * 7 + lane] = dv;
+  }
+  if (lane == 0) resp[pix] = rs;
+  const float mult = gate ? sigm(rs) : rs;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = (lane + 64 * t) * 8;
+    if (c < C) {
+      uint4 o;
+      o.x = (uint32_t)f2bf(xv[t][0] * mult) | ((uint32_t)f2bf(xv[t][1] * mult) << 16); o.y = (uint32_t)f2bf(xv[t][2] * mult) | ((uint32_t)f2bf(xv[t][3] * mult) << 16);
+      o.z = (uint32_t)f2bf(xv[t][4] * mult) | ((uint32_t)f2bf(xv[t][5] * mult) << 16); o.w = (uint32_t)f2bf(xv[t][6] * mult) | ((uint32_t)f2bf(xv[t][7] * mult) << 16);
+      *(uint4*)(y + (long)pix * C + c) = o;
+    }
+  }
+}
 // pass 1: dresp[p] = sum_c dy[p][c] x[p][c]   (dr[k] += sum_p dresp[p]*respk[p][k] is taken by pass 3, in a fixed order)
 // (sigmoid gate: times sigma'(response); dresp_extra = gradient of the response BCE loss w.r.t. the raw response)
 __global__ __launch_bounds__(256) void dynfilter_bwd1_kernel(const void* dy, const void* x, const float* respk, float* dresp, float* dr, int HW, int C, int dt,
@@ -1203,6 +1251,10 @@ extern "C" int l2s_lstm_step_bwd(const l2s_lstm_bwd_dir* dirs, int ndir, int Hh,
 }
 extern "C" int l2s_dynfilter_fwd(const void* x, const float* filt, const float* r, void* y, float* resp, float* respk, int H, int W, int C,
                                  int dtype, int gate, hipStream_t s) {
+  if (dtype == L2S_BF16 && !(C & 7) && C <= 2048 && !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && !((uintptr_t)filt & 15)) {
+    L2S_LAUNCH(dynfilter_fwd_bf16_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, (const bf16_t*)x, filt, r, (bf16_t*)y, resp, respk, H, W, C, gate);
+    return l2s_check_launch();
+  }
   L2S_LAUNCH(dynfilter_fwd_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, s, x, filt, r, y, resp, respk, H, W, C, dtype, gate);
   return l2s_check_launch();
 }

@@ -309,6 +309,50 @@ __global__ void add3_kernel(const void* a, const void* b, const float* c, void* 
   }
 }
 
+// bf16 x 8 forms (16-byte accesses) of the elementwise kernels on the main queue
+__global__ void add3_bf16x8_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ c, bf16_t* d, long n8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const uint4 qa = *(const uint4*)(a + i * 8);
+    const uint32_t aw[4] = {qa.x, qa.y, qa.z, qa.w};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(aw[e] << 16); v[2 * e + 1] = __uint_as_float(aw[e] & 0xFFFF0000u); }
+    if (b) {
+      const uint4 qb = *(const uint4*)(b + i * 8);
+      const uint32_t bw[4] = {qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(bw[e] << 16); v[2 * e + 1] += __uint_as_float(bw[e] & 0xFFFF0000u); }
+    }
+    if (c) {
+      const float4 c0 = *(const float4*)(c + i * 8), c1 = *(const float4*)(c + i * 8 + 4);
+      v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+    }
+    uint4 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *(uint4*)(d + i * 8) = o;
+  }
+}
+__global__ void avgpool_fwd_bf16x8_kernel(const bf16_t* __restrict__ x, bf16_t* y, int hw, int C) {
+  const int n = blockIdx.y;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c >= C) return;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (int p = 0; p < hw; ++p) {
+    const uint4 q = *(const uint4*)(x + ((long)n * hw + p) * C + c);
+    const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[2 * e] += __uint_as_float(qw[e] << 16); s[2 * e + 1] += __uint_as_float(qw[e] & 0xFFFF0000u); }
+  }
+  uint4 o;
+  const float inv = (float)hw;
+  o.x = (uint32_t)f2bf(s[0] / inv) | ((uint32_t)f2bf(s[1] / inv) << 16); o.y = (uint32_t)f2bf(s[2] / inv) | ((uint32_t)f2bf(s[3] / inv) << 16);
+  o.z = (uint32_t)f2bf(s[4] / inv) | ((uint32_t)f2bf(s[5] / inv) << 16); o.w = (uint32_t)f2bf(s[6] / inv) | ((uint32_t)f2bf(s[7] / inv) << 16);
+  *(uint4*)(y + (long)n * C + c) = o;
+}
+
 __global__ void avgpool_fwd_kernel(const void* x, void* y, int hw, int C, int dt) {
   const int n = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -595,10 +639,19 @@ extern "C" int l2s_scale_mask(const void* x, const float* mask, const void* relu
   return l2s_check_launch();
 }
 extern "C" int l2s_add3(const void* a, const void* b, const float* c, void* dst, long n, int dtype, hipStream_t s) {
+  if (dtype == L2S_BF16 && !(n & 7) && !((uintptr_t)a & 15) && !((uintptr_t)b & 15) && !((uintptr_t)c & 15) && !((uintptr_t)dst & 15)) {
+    L2S_LAUNCH(add3_bf16x8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, c, (bf16_t*)dst, n / 8);
+    return l2s_check_launch();
+  }
   L2S_LAUNCH(add3_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, dst, n, dtype);
   return l2s_check_launch();
 }
 extern "C" int l2s_avgpool_fwd(const void* x, void* y, int n_img, int hw, int C, int dtype, hipStream_t s) {
+  if (dtype == L2S_BF16 && !(C & 7) && !((uintptr_t)x & 15) && !((uintptr_t)y & 15)) {
+    const int th = C / 8 >= 256 ? 256 : ((C / 8 + 63) / 64) * 64;
+    L2S_LAUNCH(avgpool_fwd_bf16x8_kernel, dim3(cdiv(C / 8, th), n_img), dim3(th), 0, s, (const bf16_t*)x, (bf16_t*)y, hw, C);
+    return l2s_check_launch();
+  }
   L2S_LAUNCH(avgpool_fwd_kernel, dim3(cdiv(C, 256), n_img), dim3(256), 0, s, x, y, hw, C, dtype);
   return l2s_check_launch();
 }

@@ -742,6 +742,34 @@ __global__ void roialign_fwd_kernel(const void* feat, int H, int W, int C, const
     stx(out, (long)cell * C + c, dt, v);
   }
 }
+// bf16, C % 8 == 0: 8 channels (16 bytes) per thread; same arithmetic order as the scalar kernel
+__global__ __launch_bounds__(128) void roialign_fwd_bf16x8_kernel(const bf16_t* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois, int P,
+                                                                 float sscale, float TH, float TW, bf16_t* out) {
+  const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
+  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW);
+  const float w00 = (1.f - s.wx1) * (1.f - s.wy1), w01 = s.wx1 * (1.f - s.wy1), w10 = (1.f - s.wx1) * s.wy1, w11 = s.wx1 * s.wy1;
+  const bool vx0 = s.x0 >= 0 && s.x0 < W, vx1 = s.x0 + 1 >= 0 && s.x0 + 1 < W, vy0 = s.y0 >= 0 && s.y0 < H, vy1 = s.y0 + 1 >= 0 && s.y0 + 1 < H;
+  for (int c = threadIdx.x * 8; c < C; c += blockDim.x * 8) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    auto tap = [&](bool ok, int y, int x, float w) {
+      if (!ok) return;
+      const uint4 q = *(const uint4*)(feat + ((long)y * W + x) * C + c);
+      const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] += w * __uint_as_float(qw[e] << 16); v[2 * e + 1] += w * __uint_as_float(qw[e] & 0xFFFF0000u); }
+    };
+    tap(vy0 && vx0, s.y0, s.x0, w00);
+    tap(vy0 && vx1, s.y0, s.x0 + 1, w01);
+    tap(vy1 && vx0, s.y0 + 1, s.x0, w10);
+    tap(vy1 && vx1, s.y0 + 1, s.x0 + 1, w11);
+    uint4 o;
+    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *(uint4*)(out + (long)cell * C + c) = o;
+  }
+}
 __global__ void roialign_bwd_kernel(const void* dout, int H, int W, int C, const float* rois, int P, float sscale, float TH, float TW, float* dfeat, int dt) {
   const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
   const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW);
@@ -919,6 +947,10 @@ extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, c
 }
 static int roialign_fwd_launch(const void* feat, int H, int W, int C, const float* rois, int R, int P, float sscale, float TH, float TW,
                                void* out, int dtype, hipStream_t s) {
+  if (dtype == L2S_BF16 && !(C & 7) && !((uintptr_t)feat & 15) && !((uintptr_t)out & 15)) {
+    L2S_LAUNCH(roialign_fwd_bf16x8_kernel, dim3(R * P * P), dim3(C >= 1024 ? 128 : 64), 0, s, (const bf16_t*)feat, H, W, C, rois, P, sscale, TH, TW, (bf16_t*)out);
+    return l2s_check_launch();
+  }
   L2S_LAUNCH(roialign_fwd_kernel, dim3(R * P * P), dim3(256), 0, s, feat, H, W, C, rois, P, sscale, TH, TW, out, dtype);
   return l2s_check_launch();
 }
