@@ -20,7 +20,7 @@ res = dict(kernel='igemm_sp_kernel<bf16,224,128>, layer4@RoIs conv3x3 forward (M
            launches=len(out['FETCH_SIZE']), FETCH_SIZE_KiB=f, WRITE_SIZE_KiB=w,
            read_bytes_corrected=2 * f * 1024, write_bytes=w * 1024, traffic_bytes=2 * f * 1024 + w * 1024,
            algorithmic_bytes=12544 * 512 * 2 * 2 + 512 * 4608 * 2,
-           note='read side = 2 x FETCH_SIZE (16-byte-per-lane buffer loads are tallied at half their bytes on gfx950); write side = WRITE_SIZE as is (8-byte bf16x4 stores: uncalibrated width)')
+           note='read side = 2 x FETCH_SIZE (16-byte-per-lane buffer loads are tallied at half their bytes on gfx950); write side = WRITE_SIZE as is (16-byte bf16x8 stores from the LDS-staged epilogue)')
 print(json.dumps(res, indent=1))
 json.dump(res, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
 PY
