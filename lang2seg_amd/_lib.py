@@ -176,6 +176,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise L2SError('%s not found: run `python __graft_entry__.py` (hipcc build) first; there is no CPU fallback' % LIB_PATH)
+    # torch first: its wheel bundles its own libamdhip64, and a process must end up with ONE HIP runtime.  Loaded the other way round
+    # (this library's /opt/rocm runtime first, torch's second) every launch from here fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

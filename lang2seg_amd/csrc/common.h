@@ -1,6 +1,7 @@
 // Common device helpers for the lang2seg gfx950 kernels (wave64, CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <stdint.h>
 #include <functional>
 
@@ -108,6 +109,7 @@ void record(hipStream_t s, std::function<void(hipStream_t)> fn);
 
 static inline int l2s_check_launch() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "lang2seg_hip: launch failed: %s\n", hipGetErrorString(e));
   return e == hipSuccess ? L2S_OK : L2S_ELAUNCH;
 }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
