@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 // Requires Cin % BK == 0 for every tap (no K tail) and operand extents < 2 GiB; the launcher falls back otherwise.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned OOR = 0x80000000u;
+constexpr int RING_EARLY_READ = 1 << 27; // internal: ring kernel reads a slice's fragments before filling the next slice
 constexpr int EPI_LDS_FLAG = 1 << 29;   // internal: LDS-staged epilogue selected by the launcher (reuses the tile's LDS)
 constexpr int EPI_LDS_FLAG64 = 1 << 28; // the same for the 64x64 tile (separate switch: its launches are latency-bound)
 
@@ -595,18 +596,57 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
         for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
     }
   };
+  // fragment reads of a whole slice first (slice t's buffer is complete since the barrier), THEN the LDS fill of slice t+1 and the next
+  // global loads, then the MFMAs: the reads' latency passes under the fill / load issue instead of in front of every MFMA group
+  constexpr int KG = RB / 64;
+  uint4 fra[KG][TM], frb[KG][TN];
+  auto read_all = [&](int t) {
+    const char* base = smem + (t & 1) * BUF;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      const int ch = ((kg * 4 + fg) ^ swz) << 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fra[kg][i] = *(const uint4*)(base + offa + i * 16 * RB + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) frb[kg][j] = *(const uint4*)(base + offb + j * 16 * RB + ch);
+    }
+  };
+  auto mma_all = [&]() {
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(frb[kg][j], fra[kg][i], acc[i][j]);
+  };
+  const bool early = BM * BN <= 64 * 64 && KS == 1 && (p.flags & RING_EARLY_READ) != 0;   // (the 128x128 tile has no registers to spare)
   // steady state: every iteration stores slice t+1 and issues slice t+1+D, no conditions (so the compiler's vmcnt is the
   // exact count of the D-1 younger sets); unrolled by D so that the ring set index is a compile-time constant.
   int t0 = 0;
-  for (; t0 + 2 * D <= KT; t0 += D) {
+  if (early) {
+    for (; t0 + 2 * D <= KT; t0 += D) {
 #pragma unroll
-    for (int s = 0; s < D; ++s) {
-      const int t = t0 + s;
-      const int nxt = (s + 1) % D;
-      __syncthreads();
-      store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
-      issue(ra[nxt], rb[nxt]);
-      compute(t);
+      for (int s = 0; s < D; ++s) {
+        const int t = t0 + s;
+        const int nxt = (s + 1) % D;
+        __syncthreads();
+        read_all(t);
+        store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
+        issue(ra[nxt], rb[nxt]);
+        mma_all();
+      }
+    }
+  } else {
+    for (; t0 + 2 * D <= KT; t0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const int t = t0 + s;
+        const int nxt = (s + 1) % D;
+        __syncthreads();
+        store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
+        issue(ra[nxt], rb[nxt]);
+        compute(t);
+      }
     }
   }
   // tail: fewer than 2 D slices left
@@ -616,11 +656,12 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
     if (t < KT) {
       const int nxt = (s + 1) % D;
       __syncthreads();
+      if (early) read_all(t);
       if (t + 1 < KT) {
         store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
         if (t + 1 + D < KT) issue(ra[nxt], rb[nxt]);
       }
-      compute(t);
+      if (early) mma_all(); else compute(t);
     }
   }
   if (KS > 1) {
@@ -1110,6 +1151,8 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   }
   static const int epi_lds = [] { const char* e = getenv("L2S_IGEMM_EPI_LDS"); return e ? atoi(e) : 1; }();
   if (epi_lds) dd.flags |= EPI_LDS_FLAG;
+  static const int early_rd = [] { const char* e = getenv("L2S_IGEMM_EARLY_READ"); return e ? atoi(e) : 1; }();
+  if (early_rd) dd.flags |= RING_EARLY_READ;
   static const int epi_lds64 = [] { const char* e = getenv("L2S_IGEMM_EPI_LDS64"); return e ? atoi(e) : 1; }();
   if (epi_lds64) dd.flags |= EPI_LDS_FLAG64;
   d = &dd;
