@@ -1204,7 +1204,12 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
           return GRB(4);
 #undef GRB
         }
-        return GR(bf16_t, 64, 64, 4, 1);
+        // ring depth 2 since the fragment reads moved ahead of the LDS fill (fewer registers, more workgroups per CU): 170.5 vs 166.7 img/s
+        // for depth 4 (which was the better one before: 129 / 119 img/s for depths 8 / 12 then)
+        static const int d64 = [] { const char* e = getenv("L2S_IGEMM_D64"); return e ? atoi(e) : 2; }();
+        if (d64 == 4) return GR(bf16_t, 64, 64, 4, 1);
+        if (d64 == 3) return GR(bf16_t, 64, 64, 3, 1);
+        return GR(bf16_t, 64, 64, 2, 1);
       }
       if (dtype == L2S_F32) {
         if (tile == 224) return GSP7(float, 2);
