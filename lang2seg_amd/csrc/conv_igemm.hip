@@ -467,13 +467,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 // Iteration t:  barrier -> ds_write slice t+1 (issued D iterations ago) -> issue slice t+1+D -> MFMAs on slice t.
 // Requires Cin % BK == 0 for every tap (no K tail) and operand extents < 2 GiB; the launcher falls back otherwise.
 // ------------------------------------------------------------------------------------------------
+// minimum workgroups per CU the 64x64 / depth-2 ring tile is compiled for: 3 (168 VGPRs, three waves per SIMD) measured 174.5 vs 170.5 img/s
+// for 1 (144 VGPRs but scheduled for two); 4 spills
+#ifndef L2S_RING64_MINWG
+#define L2S_RING64_MINWG 3
+#endif
 constexpr unsigned OOR = 0x80000000u;
 constexpr int RING_EARLY_READ = 1 << 27; // internal: ring kernel reads a slice's fragments before filling the next slice
 constexpr int EPI_LDS_FLAG = 1 << 29;   // internal: LDS-staged epilogue selected by the launcher (reuses the tile's LDS)
 constexpr int EPI_LDS_FLAG64 = 1 << 28; // the same for the 64x64 tile (separate switch: its launches are latency-bound)
 
 template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS, int RB = 128>
-__global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : 1) void igemm_ring_kernel(const l2s_conv_desc p) {
+__global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : ((BM * BN <= 64 * 64 && KS == 1 && D == 2 && L2S_RING64_MINWG > 1) ? L2S_RING64_MINWG : 1)) void igemm_ring_kernel(const l2s_conv_desc p) {
   constexpr int VE = 16 / (int)sizeof(T);
   // RB = bytes of K per LDS row per slice: 128 (64 bf16) or 256.  A wave of the 64x64 tile has only 8 MFMAs per 128-byte slice, and
   // the LDS write -> barrier -> fragment read round trip (~600 cycles, measured: MFMA busy 13 % of the wave's cycles) is paid per slice:
