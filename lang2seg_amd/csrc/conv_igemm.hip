@@ -1200,7 +1200,8 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
         if (ks == 2) return GR(bf16_t, 64, 64, 3, 2);
         // (ring depth 4 = 64 KiB in flight per workgroup; depths 8 and 12 were measured slower, round 2: 129 / 119 vs 136 img/s)
         // and so was the software-pipelined (three LDS buffers) form of this tile: 132-133 img/s
-        // 256-byte K rows per slice when every tap has whole 256-byte pieces of channels
+        // 256-byte K rows per slice when every tap has whole 256-byte pieces of channels (off: with the early fragment reads the 256-byte
+        // slice needs 64 fragment + 64 ring registers and 64 KiB of LDS: 110 / 145 img/s at ring depth 2 / 3 against 170 for 128-byte rows)
         static const int rb256 = [] { const char* e = getenv("L2S_IGEMM_RB256"); return e ? atoi(e) : 0; }();
         if (rb256 && d->Cin % 128 == 0) {
 #define GRB(DD) (f32o ? launch_igemm_ring<bf16_t, 64, 64, 2, 2, DD, true, 1, 256>(*d, stream) : launch_igemm_ring<bf16_t, 64, 64, 2, 2, DD, false, 1, 256>(*d, stream))
