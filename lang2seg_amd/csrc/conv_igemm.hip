@@ -708,6 +708,173 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-specialised 64x64 bf16 tile (8 waves): waves 4-7 LOAD (global -> register ring -> LDS), waves 0-3 MULTIPLY (LDS -> fragments ->
+// MFMA).  The plain ring kernel gives one wave per SIMD the whole instruction stream of a slice, in order: address updates, buffer
+// loads, the vmcnt wait, LDS fill, barrier, fragment reads, the lgkmcnt wait, MFMAs (970 cycles per slice with 128 of MFMA, 4.1a).
+// Here a SIMD holds one wave of each kind, so the loader's waits pass under the multiplier's MFMAs and the multiplier's stream per
+// slice is a barrier, 8 ds_read_b128 and 8 MFMAs, the MFMAs of slice t-1 issued behind the reads of slice t.
+//   barrier #k: slice k complete in LDS buffer k & 1 (loaders arrive after their ds_writes, multipliers after the reads of slice
+//   k-1 returned: __syncthreads' lgkmcnt(0)), so the loaders may overwrite buffer (k+1) & 1 with slice k+1 right behind it.
+// The loaders leave after the last slice (a finished wave no longer counts at s_barrier); the epilogue is the ring kernel's.
+// ------------------------------------------------------------------------------------------------
+template <int D, int BN>
+__global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc p) {
+  typedef bf16_t T;
+  constexpr int BM = 64, RB = 128, BK = 64, CPR = 8, LR = 32, NA = BM / LR, NB = BN / LR;
+  constexpr int WM = 32, WN = BN / 2, TM = 2, TN = WN / 16, KG = 2, BUF = (BM + BN) * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  char* smem = smem_all;
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  int mt, nt;
+  {
+    const int MT = (M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;
+    if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KT = K / BK;
+
+  if (wave_all >= 4) {
+    // ---------------- loaders ----------------
+    const int tid = (int)threadIdx.x - 256;
+    const long xpix = (long)p.n_img * p.IH * p.IW;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((xpix - 1) * p.ldx + p.Cin) * 2L), 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * K * 2L), 0x00020000);
+    const int lrow = tid / CPR, cv = tid % CPR;
+    const int wchunk = ((cv ^ (lrow & (CPR - 1))) << 4);
+    int a_iy0[NA], a_ix0[NA], a_base[NA]; bool a_ok[NA];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int m = m0 + lrow + LR * j;
+      a_ok[j] = m < M;
+      const int mm = a_ok[j] ? m : 0;
+      const int n_img = mm / ohw, rem = mm - n_img * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy0[j] = oy * p.stride - p.pad;
+      a_ix0[j] = ox * p.stride - p.pad;
+      a_base[j] = n_img * p.IH * p.IW;
+    }
+    unsigned voffB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int n = n0 + lrow + LR * j;
+      voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + cv * 8) * 2L) : OOR;
+    }
+    const int taps = p.KH * p.KW;
+    int it = 0, c0 = 0, tap = 0;
+    unsigned voffA[NA];
+    auto set_tap = [&](int t) {
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+        const bool v = a_ok[j] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        voffA[j] = v ? (unsigned)(((long)(a_base[j] + iy * p.IW + ix) * p.ldx + cv * 8) * 2L) : OOR;
+      }
+    };
+    set_tap(0);
+    uint4 ra[D][NA], rb[D][NB];
+    auto issue = [&](uint4 (&a)[NA], uint4 (&b)[NB]) {
+      const int sa = c0 * 2, sb = it * RB;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) a[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, voffA[j], sa, 0));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, voffB[j], sb, 0));
+      ++it; c0 += BK;
+      if (c0 >= p.Cin && taps > 1) { c0 = 0; ++tap; if (tap < taps) set_tap(tap); }
+    };
+    auto store_slice = [&](int buf, const uint4 (&a4)[NA], const uint4 (&b4)[NB]) {
+      char* a = smem + buf * BUF + lrow * RB + wchunk;
+      char* b = a + BM * RB;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) *(uint4*)(a + LR * j * RB) = a4[j];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) *(uint4*)(b + LR * j * RB) = b4[j];
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < KT) issue(ra[s], rb[s]);
+    store_slice(0, ra[0], rb[0]);
+    if (D < KT) issue(ra[0], rb[0]);
+    __syncthreads();                                          // barrier #0
+    int t0 = 0;
+    for (; t0 + 2 * D <= KT; t0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const int t = t0 + s;
+        const int nxt = (s + 1) % D;
+        store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
+        issue(ra[nxt], rb[nxt]);
+        __syncthreads();                                      // barrier #(t+1)
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2 * D; ++s) {
+      const int t = t0 + s;
+      if (t + 1 < KT) {
+        const int nxt = (s + 1) % D;
+        store_slice((t + 1) & 1, ra[nxt], rb[nxt]);
+        if (t + 1 + D < KT) issue(ra[nxt], rb[nxt]);
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // ---------------- multipliers ----------------
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = wave_all;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = fr & (CPR - 1);
+  const int offa = (wm * WM + fr) * RB, offb = BM * RB + (wn * WN + fr) * RB;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 fa0[KG][TM], fb0[KG][TN], fa1[KG][TM], fb1[KG][TN];
+  auto read_all = [&](int t, uint4 (&fa)[KG][TM], uint4 (&fb)[KG][TN]) {
+    const char* base = smem + (t & 1) * BUF;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      const int ch = ((kg * 4 + fg) ^ swz) << 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[kg][i] = *(const uint4*)(base + offa + i * 16 * RB + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[kg][j] = *(const uint4*)(base + offb + j * 16 * RB + ch);
+    }
+  };
+  auto mma_all = [&](const uint4 (&fa)[KG][TM], const uint4 (&fb)[KG][TN]) {
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[kg][j], fa[kg][i], acc[i][j]);
+  };
+  __syncthreads();                                            // barrier #0
+  read_all(0, fa0, fb0);
+  int t = 1;
+  for (; t + 2 <= KT; t += 2) {
+    __syncthreads(); read_all(t, fa1, fb1); mma_all(fa0, fb0);
+    __syncthreads(); read_all(t + 1, fa0, fb0); mma_all(fa1, fb1);
+  }
+  if (t < KT) { __syncthreads(); read_all(t, fa1, fb1); mma_all(fa0, fb0); mma_all(fa1, fb1); }
+  else mma_all(fa0, fb0);
+  {
+    const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
+                       !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
+                       (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
+    if (plain && (p.flags & EPI_LDS_FLAG64)) { igemm_epilogue_lds128<TM, TN, WM, WN, 2, 256, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
+  }
+  igemm_epilogue<T, TM, TN, WM, WN, false, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Software-pipelined large-tile variant (256x128 tile, 8 waves = 2 per SIMD, one workgroup per CU): the ring loader of
 // igemm_ring_kernel plus THREE LDS slice buffers, so that slice t+1 is already complete in LDS while slice t is being
 // multiplied.  Iteration t (one barrier):
@@ -1092,6 +1259,15 @@ int launch_igemm_ring(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
+template <int D, int BN>
+int launch_igemm_ws64(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, 64) * cdiv(d.Cout, BN));
+  const size_t lds = 2 * 128 * 128;                                           // (also holds the staged 64 x (BN + 4) fp32 tile of the epilogue)
+  L2S_LAUNCH((igemm_ws64_kernel<D, BN>), grid, dim3(512), lds, st, d);
+  return l2s_check_launch();
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, bool TAPIN>
 int launch_igemm_sp(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
@@ -1212,6 +1388,15 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
         }
         // ring depth 2 since the fragment reads moved ahead of the LDS fill (fewer registers, more workgroups per CU): 170.5 vs 166.7 img/s
         // for depth 4 (which was the better one before: 129 / 119 img/s for depths 8 / 12 then)
+        // wave-specialised 8-wave form (loaders + multipliers), bf16 output only; 64x32 tiles when 64x64 ones leave CUs empty
+        static const int ws64 = [] { const char* e = getenv("L2S_IGEMM_WS64"); return e ? atoi(e) : 3; }();
+        static const int ws_n32 = [] { const char* e = getenv("L2S_IGEMM_WS_N32"); return e ? atoi(e) : 0; }();   // tile-count threshold
+        if (ws64 && !f32o) {
+          if (tiles64 <= ws_n32 && d->Cout % 32 == 0) return launch_igemm_ws64<3, 32>(*d, stream);
+          if (ws64 == 2) return launch_igemm_ws64<2, 64>(*d, stream);
+          if (ws64 == 4) return launch_igemm_ws64<4, 64>(*d, stream);
+          return launch_igemm_ws64<3, 64>(*d, stream);
+        }
         static const int d64 = [] { const char* e = getenv("L2S_IGEMM_D64"); return e ? atoi(e) : 2; }();
         if (d64 == 4) return GR(bf16_t, 64, 64, 4, 1);
         if (d64 == 3) return GR(bf16_t, 64, 64, 3, 1);
