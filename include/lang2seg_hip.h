@@ -384,6 +384,10 @@ int l2s_tape_run(void* tape, const hipStream_t* streams, int n);
 /* segments: l2s_tape_mark() (while recording) cuts the tape where the host must act between launches (RCCL all-reduce of a finished
  * gradient bucket); l2s_tape_run_segment replays segment `seg` in [0, l2s_tape_segments) */
 int l2s_tape_mark(void);
+/* measurement: "record a timing event here" as a tape op (id >= 0 while recording, -1 otherwise); elapsed HIP-event time between two such
+   points of the last replayed step (bench.py brackets the dominant launch inside the pipelined replay with these) */
+int l2s_tape_time_event(hipStream_t s);
+int l2s_time_event_elapsed(int a, int b, float* ms);
 int l2s_tape_segments(void* tape);
 int l2s_tape_run_segment(void* tape, const hipStream_t* streams, int n, int seg);
 int l2s_tape_destroy(void* tape);

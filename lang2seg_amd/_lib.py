@@ -158,6 +158,8 @@ SIGS = {
     'l2s_tape_run': (i32, [vp, vp, i32]),
     'l2s_tape_destroy': (i32, [vp]),
     'l2s_tape_mark': (i32, []),
+    'l2s_tape_time_event': (i32, [vp]),
+    'l2s_time_event_elapsed': (i32, [i32, i32, vp]),
     'l2s_tape_segments': (i32, [vp]),
     'l2s_tape_run_segment': (i32, [vp, vp, i32, i32]),
 }

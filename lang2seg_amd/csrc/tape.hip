@@ -14,7 +14,7 @@
 
 namespace l2s {
 
-struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };   // kind 0 launch, 1 record ev, 2 wait ev, 3 segment mark
+struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };   // kind 0 launch, 1 record ev, 2 wait ev, 3 segment mark, 4 record timing ev
 struct Tape { std::vector<Op> ops; int n_events = 0; std::vector<hipEvent_t> events; std::vector<size_t> marks; };
 
 static Tape* g_rec = nullptr;
@@ -22,6 +22,7 @@ static hipStream_t g_streams[8];
 static int g_nstreams = 0;
 static std::vector<hipEvent_t> g_pool;     // events for eager forks
 static size_t g_pool_next = 0;
+static std::vector<hipEvent_t> g_timing;  // timing events of l2s_tape_time_event (measurement only; live until the process ends)
 
 static int stream_id(hipStream_t s) {
   for (int i = 0; i < g_nstreams; ++i) if (g_streams[i] == s) return i;
@@ -65,6 +66,26 @@ extern "C" int l2s_tape_mark(void) {
   if (g_rec) g_rec->ops.push_back(Op{3, 0, -1, nullptr});
   return L2S_OK;
 }
+// Timing events on the tape (measurement): while recording, l2s_tape_time_event(s) appends "record timing event #id on s" at this point of
+// the stream's order and returns id (>= 0); every replay records the event again, so after a synchronise l2s_time_event_elapsed(a, b)
+// is the HIP-event time between two points of the LAST replayed step — launches inside the pipelined, host-unbound replay can be
+// bracketed this way (events around eager launches also measure the host's issue gaps).  Outside a recording it returns -1.
+extern "C" int l2s_tape_time_event(hipStream_t s) {
+  if (!g_rec) return -1;
+  const int sid = stream_id(s);
+  if (sid < 0) return -1;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return -1;
+  g_timing.push_back(e);
+  const int id = (int)g_timing.size() - 1;
+  g_rec->ops.push_back(Op{4, sid, id, nullptr});
+  (void)hipEventRecord(e, s);                                    // the recording step executes as well
+  return id;
+}
+extern "C" int l2s_time_event_elapsed(int a, int b, float* ms) {
+  if (!ms || a < 0 || b < 0 || a >= (int)g_timing.size() || b >= (int)g_timing.size()) return L2S_EINVAL;
+  return hipEventElapsedTime(ms, g_timing[a], g_timing[b]) == hipSuccess ? L2S_OK : L2S_ELAUNCH;
+}
 extern "C" int l2s_tape_segments(void* tape) { return tape ? (int)((Tape*)tape)->marks.size() + 1 : -1; }
 extern "C" int l2s_tape_run_segment(void* tape, const hipStream_t* streams, int n, int seg) {
   Tape* t = (Tape*)tape;
@@ -77,6 +98,7 @@ extern "C" int l2s_tape_run_segment(void* tape, const hipStream_t* streams, int 
     if (o.kind == 0) o.fn(s);
     else if (o.kind == 1) { if (hipEventRecord(t->events[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
     else if (o.kind == 2) { if (hipStreamWaitEvent(s, t->events[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 4) { if (hipEventRecord(g_timing[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
   }
   return l2s_check_launch();
 }
@@ -89,7 +111,8 @@ extern "C" int l2s_tape_run(void* tape, const hipStream_t* streams, int n) {
     hipStream_t s = streams[o.sid];
     if (o.kind == 0) o.fn(s);
     else if (o.kind == 1) { if (hipEventRecord(t->events[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
-    else { if (hipStreamWaitEvent(s, t->events[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 2) { if (hipStreamWaitEvent(s, t->events[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 4) { if (hipEventRecord(g_timing[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
   }
   return l2s_check_launch();
 }

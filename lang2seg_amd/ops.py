@@ -58,6 +58,17 @@ def tape_mark():
     call('l2s_tape_mark')
 
 
+def tape_time_event():
+    """(measurement) 'record a timing event here' on the current stream's tape order; id >= 0 while a tape is recording, else -1"""
+    return int(_lib.load().l2s_tape_time_event(stream()))
+
+
+def time_event_elapsed(a, b):
+    ms = C.c_float(0.0)
+    call('l2s_time_event_elapsed', a, b, C.byref(ms))
+    return float(ms.value)
+
+
 def tape_run_segment(h, streams, seg):
     arr = (C.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
     call('l2s_tape_run_segment', h, arr, len(streams), seg)
