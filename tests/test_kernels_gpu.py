@@ -1158,3 +1158,30 @@ def test_roipool(dt):
     torch.cuda.synchronize()
     dref = OB.roi_pool_bwd(dout.float().cpu().view(R, P, P, Cc).permute(0, 3, 1, 2).numpy(), arg, H, W)
     assert rel_err(dfeat.view(H, W, Cc).permute(2, 0, 1), torch.from_numpy(dref)) < 1e-5
+
+
+def test_tape_timing_events():
+    """timing events recorded as tape ops: outside a recording the call is refused (-1); inside, every replay records the pair again on
+    the stream and the elapsed time brackets the launches between them (here: fills of 64 MB vs of 1 MB)."""
+    O = ops()
+    s = torch.cuda.current_stream()
+    big = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    small = torch.empty(1 << 18, dtype=torch.float32, device=DEV)
+    assert O.tape_time_event() == -1
+    h = O.tape_begin([s])
+    a = O.tape_time_event(); O.memset_zero(big); b = O.tape_time_event()
+    O.memset_zero(small); c = O.tape_time_event()
+    O.tape_end(h)
+    assert a >= 0 and b == a + 1 and c == b + 1
+    torch.cuda.synchronize()
+    for _ in range(3):
+        big.fill_(1.0); small.fill_(1.0)
+        O.tape_run(h, [s])
+        torch.cuda.synchronize()
+        t_big, t_small = O.time_event_elapsed(a, b), O.time_event_elapsed(b, c)
+        assert float(big.abs().sum()) == 0.0 and float(small.abs().sum()) == 0.0
+        assert 0.0 < t_small < t_big < 5.0, (t_small, t_big)        # 64 MB at >= 1 TB/s is well under a millisecond
+        assert t_big > 0.008                                         # and cannot beat 8 TB/s
+    O.tape_destroy(h)
+    with pytest.raises(Exception):
+        O.time_event_elapsed(a, 1 << 20)
