@@ -9,6 +9,9 @@
 // (pyutils/mask-faster-rcnn/lib/nets/resnet_v1_cycle_res5_2.py:83-88,121,147,324-335 and
 // network_cycle_res5_2.py:236-251,279-301).
 //
+// Kernels: igemm_ring_kernel (128x128, and 64x64 for f32 / fp32-output launches), igemm_ws64_kernel (bf16 64x64: four loader waves +
+// four multiplier waves), igemm_sp_kernel (224x128 / 256x128, 8 waves, software pipelined); igemm_kernel / igemm_pipe_kernel are the
+// round-1 forms kept behind switches.
 // Tiling: 256 threads = 4 waves (2x2); block tile BMxBN (128x128 or 64x64); K consumed in 128-byte
 // slices per row (64 bf16 / 32 f32) staged global -> registers -> LDS (double buffered, one barrier per
 // slice); 16x16 MFMA tiles: v_mfma_f32_16x16x32_bf16 or the exact-f32 v_mfma_f32_16x16x4_f32
