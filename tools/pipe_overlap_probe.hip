@@ -1,0 +1,94 @@
+// Do the per-CU pipes of an igemm slice overlap?  Workgroups of 256 threads run N iterations of the 64x64 tile's per-slice traffic in
+// isolation and combined (bit mask MODE): 1 = 16 KiB of buffer_load_b128 from an L2-resident window, issued two iterations ahead, 2 = 16 KiB
+// of ds_write_b128 + 32 KiB of ds_read_b128 in the tile's swizzled layout, 4 = 8 MFMA 16x16x32 bf16 per wave; one barrier per iteration.
+// Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/pipe_overlap_probe tools/pipe_overlap_probe.hip   
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint4* __restrict__ out, int iters, int win_u4) {
+  __shared__ uint4 lds[2048];                                   // 32 KiB: two 16 KiB slices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)(blockIdx.x & 255) * win_u4), 0, win_u4 * 16, 0x00020000);
+  uint4 acc = make_uint4(0, 0, 0, 0), ld[3][4], fr[8];
+  f32x4 c[4];
+  for (int i = 0; i < 4; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 8; ++i) fr[i] = make_uint4(tid, i, 0x3f803f80u, 0x3f803f80u);
+  for (int s = 0; s < 3; ++s) for (int j = 0; j < 4; ++j) ld[s][j] = make_uint4(s, j, tid, 1);
+  unsigned off = tid * 16;
+  const unsigned wbytes = (unsigned)win_u4 * 16u;
+  auto issue = [&](uint4 (&d)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * 4096, 0, 0));
+    off += 16384; if (off >= wbytes) off -= wbytes;
+  };
+  // fragment-read pattern of the 64x64 tile: 128-byte rows, 16-byte chunk index xor (row & 7): conflict-free for ds_read_b128
+  const int frow = lane & 15, fg = lane >> 4, wm = wave >> 1, wn = wave & 1;
+  auto body = [&](uint4 (&cur)[4], uint4 (&nxt)[4], int buf) {
+    if (MODE & 1) issue(nxt);                                   // two iterations ahead
+    if (MODE & 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = (tid >> 3) + 32 * j, ch = (tid & 7) ^ (row & 7);
+        lds[buf * 1024 + row * 8 + ch] = (MODE & 1) ? cur[j] : fr[j];
+      }
+    } else if (MODE & 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc.x ^= cur[j].x; acc.y ^= cur[j].y; }
+    }
+    __syncthreads();
+    if (MODE & 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int half = j >> 2, t = j & 1, kg = (j >> 1) & 1;     // A rows (wm) / B rows (wn), two 16-row tiles, two k groups
+        const int row = (half ? 64 + wn * 32 : wm * 32) + t * 16 + frow, ch = (kg * 4 + fg) ^ (row & 7);
+        fr[j] = lds[buf * 1024 + row * 8 + ch];
+      }
+    }
+    if (MODE & 4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        c[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[j]), __builtin_bit_cast(bf16x8, fr[(j + 1) & 7]), c[j & 3], 0, 0, 0);
+    } else if (MODE & 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc.z ^= fr[j].x; acc.w ^= fr[j].y; }
+    }
+  };
+  if (MODE & 1) { issue(ld[0]); issue(ld[1]); }
+  for (int it = 0; it < iters; it += 6) {                       // one barrier per iteration, as the tile kernels
+    body(ld[0], ld[2], 0); body(ld[1], ld[0], 1); body(ld[2], ld[1], 0);
+    body(ld[0], ld[2], 1); body(ld[1], ld[0], 0); body(ld[2], ld[1], 1);
+  }
+  for (int i = 0; i < 4; ++i) { acc.x ^= __float_as_uint(c[i][0]); acc.y ^= __float_as_uint(c[i][1]); }
+  for (int j = 0; j < 8; ++j) acc.z ^= fr[j].z;
+  for (int s = 0; s < 3; ++s) for (int j = 0; j < 4; ++j) acc.w ^= ld[s][j].w;
+  if (acc.x == 0x12345678u && acc.w == 0x9abcdef0u) out[tid] = acc;   // keep everything alive
+}
+
+template <int MODE> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1) {
+  float ms = 0;
+  for (int w = 0; w < 3; ++w) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(probe<MODE>, dim3(g), dim3(256), 0, 0, src, out, N, win);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  return ms;
+}
+
+int main() {
+  const int G = 256, N = 12000, WIN = 4096;                     // 64 KiB window per workgroup: L2 resident (2 MiB per XCD)
+  uint4 *src, *out;
+  CK(hipMalloc(&src, (size_t)G * WIN * 16)); CK(hipMalloc(&out, 4096)); CK(hipMemset(src, 1, (size_t)G * WIN * 16));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const char* names[8] = {"barriers only", "loads", "lds", "loads+lds", "mfma", "loads+mfma", "lds+mfma", "loads+lds+mfma"};
+  for (int g : {120, 256, 512}) {
+    float ms[8] = {run<0>(g, src, out, N, WIN, e0, e1), run<1>(g, src, out, N, WIN, e0, e1), run<2>(g, src, out, N, WIN, e0, e1), run<3>(g, src, out, N, WIN, e0, e1),
+                   run<4>(g, src, out, N, WIN, e0, e1), run<5>(g, src, out, N, WIN, e0, e1), run<6>(g, src, out, N, WIN, e0, e1), run<7>(g, src, out, N, WIN, e0, e1)};
+    for (int m = 0; m < 8; ++m) { printf("grid %3d  %-16s %7.1f ns / iteration\n", g, names[m], ms[m] * 1e6 / N); fflush(stdout); }
+  }
+  return 0;
+}
