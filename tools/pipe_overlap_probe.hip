@@ -9,11 +9,11 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int MODE>
-__global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint4* __restrict__ out, int iters, int win_u4) {
+template <int MODE, bool STRIDED>
+__global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint4* __restrict__ out, int iters, int win_u4, int share, int stride) {
   __shared__ uint4 lds[2048];                                   // 32 KiB: two 16 KiB slices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)(blockIdx.x & 255) * win_u4), 0, win_u4 * 16, 0x00020000);
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)((blockIdx.x / share) & 255) * win_u4)   /* `share` workgroups read the same window in step */, 0, win_u4 * 16, 0x00020000);
   uint4 acc = make_uint4(0, 0, 0, 0), ld[3][4], fr[8];
   f32x4 c[4];
   for (int i = 0; i < 4; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -21,10 +21,20 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint
   for (int s = 0; s < 3; ++s) for (int j = 0; j < 4; ++j) ld[s][j] = make_uint4(s, j, tid, 1);
   unsigned off = tid * 16;
   const unsigned wbytes = (unsigned)win_u4 * 16u;
+  // stride == 0: a contiguous 16 KiB per iteration.  stride > 0: the tile loader's pattern — 128 rows `stride` bytes apart, the 8 lanes of
+  // a row read its next 128 bytes, the slab moves 128 bytes along the rows per iteration (rows = pixels / filters, bytes = channels)
+  unsigned kofs = 0;
   auto issue = [&](uint4 (&d)[4]) {
+    if (!STRIDED) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * 4096, 0, 0));
-    off += 16384; if (off >= wbytes) off -= wbytes;
+      for (int j = 0; j < 4; ++j) d[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * 4096, 0, 0));
+      off += 16384; if (off >= wbytes) off -= wbytes;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        d[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((tid >> 3) + 32 * j) * stride + (tid & 7) * 16), (int)kofs, 0));
+      kofs += 128; if (kofs >= (unsigned)stride) kofs = 0;
+    }
   };
   // fragment-read pattern of the 64x64 tile: 128-byte rows, 16-byte chunk index xor (row & 7): conflict-free for ds_read_b128
   const int frow = lane & 15, fg = lane >> 4, wm = wave >> 1, wn = wave & 1;
@@ -38,7 +48,7 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint
       }
     } else if (MODE & 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { acc.x ^= cur[j].x; acc.y ^= cur[j].y; }
+      for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(cur[j].x), "v"(cur[j].y), "v"(cur[j].z), "v"(cur[j].w));   // the loaded registers are needed here
     }
     __syncthreads();
     if (MODE & 2) {
@@ -50,12 +60,13 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint
       }
     }
     if (MODE & 4) {
+      if (!(MODE & 2)) asm volatile("" : "+v"(fr[0].x), "+v"(fr[1].x));   // opaque operands: the MFMAs cannot be hoisted or folded
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         c[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[j]), __builtin_bit_cast(bf16x8, fr[(j + 1) & 7]), c[j & 3], 0, 0, 0);
     } else if (MODE & 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { acc.z ^= fr[j].x; acc.w ^= fr[j].y; }
+      for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(fr[j].x), "v"(fr[j].y), "v"(fr[j].z), "v"(fr[j].w));           // every fragment read has to return
     }
   };
   if (MODE & 1) { issue(ld[0]); issue(ld[1]); }
@@ -63,17 +74,17 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint
     body(ld[0], ld[2], 0); body(ld[1], ld[0], 1); body(ld[2], ld[1], 0);
     body(ld[0], ld[2], 1); body(ld[1], ld[0], 0); body(ld[2], ld[1], 1);
   }
-  for (int i = 0; i < 4; ++i) { acc.x ^= __float_as_uint(c[i][0]); acc.y ^= __float_as_uint(c[i][1]); }
+  for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(c[i][0]), "v"(c[i][1]), "v"(c[i][2]), "v"(c[i][3])); acc.x ^= __float_as_uint(c[i][0]); acc.y ^= __float_as_uint(c[i][1]); }
   for (int j = 0; j < 8; ++j) acc.z ^= fr[j].z;
   for (int s = 0; s < 3; ++s) for (int j = 0; j < 4; ++j) acc.w ^= ld[s][j].w;
   if (acc.x == 0x12345678u && acc.w == 0x9abcdef0u) out[tid] = acc;   // keep everything alive
 }
 
-template <int MODE> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1) {
+template <int MODE, bool STRIDED = false> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1, int share = 1, int stride = 0) {
   float ms = 0;
   for (int w = 0; w < 3; ++w) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(probe<MODE>, dim3(g), dim3(256), 0, 0, src, out, N, win);
+    hipLaunchKernelGGL((probe<MODE, STRIDED>), dim3(g), dim3(256), 0, 0, src, out, N, win, share, stride);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
   }
   return ms;
@@ -89,6 +100,20 @@ int main() {
     float ms[8] = {run<0>(g, src, out, N, WIN, e0, e1), run<1>(g, src, out, N, WIN, e0, e1), run<2>(g, src, out, N, WIN, e0, e1), run<3>(g, src, out, N, WIN, e0, e1),
                    run<4>(g, src, out, N, WIN, e0, e1), run<5>(g, src, out, N, WIN, e0, e1), run<6>(g, src, out, N, WIN, e0, e1), run<7>(g, src, out, N, WIN, e0, e1)};
     for (int m = 0; m < 8; ++m) { printf("grid %3d  %-16s %7.1f ns / iteration\n", g, names[m], ms[m] * 1e6 / N); fflush(stdout); }
+  }
+  // hot lines: `share` workgroups (consecutive ids = different XCDs) stream the SAME window at the same time, as the workgroups of one
+  // tile column do with a weight slice
+  for (int share : {1, 32}) {
+    const float a = run<1>(256, src, out, N, WIN, e0, e1, share), b = run<7>(256, src, out, N, WIN, e0, e1, share);
+    printf("grid 256  share %3d   loads %7.1f   loads+lds+mfma %7.1f ns / iteration\n", share, a * 1e6 / N, b * 1e6 / N); fflush(stdout);
+  }
+  // row-strided slabs (128 rows x 128 bytes per iteration), 8 distinct windows of 128 rows shared by 32 workgroups each (L2 resident)
+  for (int stride : {2048, 4608}) {
+    const int win = 128 * stride / 16;
+    for (int g : {120, 256}) {
+      const float a = run<1, true>(g, src, out, N, win, e0, e1, 32, stride), b = run<3, true>(g, src, out, N, win, e0, e1, 32, stride), c = run<7, true>(g, src, out, N, win, e0, e1, 32, stride);
+      printf("grid %3d  row stride %4d B   loads %7.1f   loads+lds %7.1f   loads+lds+mfma %7.1f ns / iteration\n", g, stride, a * 1e6 / N, b * 1e6 / N, c * 1e6 / N); fflush(stdout);
+    }
   }
   return 0;
 }
