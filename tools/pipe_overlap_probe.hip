@@ -9,7 +9,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int MODE, bool STRIDED>
+template <int MODE, bool STRIDED, bool PIPE>
 __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint4* __restrict__ out, int iters, int win_u4, int share, int stride) {
   __shared__ uint4 lds[2048];                                   // 32 KiB: two 16 KiB slices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,6 +39,37 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint
   // fragment-read pattern of the 64x64 tile: 128-byte rows, 16-byte chunk index xor (row & 7): conflict-free for ds_read_b128
   const int frow = lane & 15, fg = lane >> 4, wm = wave >> 1, wn = wave & 1;
   auto body = [&](uint4 (&cur)[4], uint4 (&nxt)[4], int buf) {
+    if (PIPE) {
+      // the ring kernels' order: barrier; fragment reads of the slice filled during the PREVIOUS iteration and the fill of the next slice
+      // into the other buffer go to the LDS together; loads; MFMAs
+      __syncthreads();
+      if (MODE & 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int half = j >> 2, t = j & 1, kg = (j >> 1) & 1;
+          const int row = (half ? 64 + wn * 32 : wm * 32) + t * 16 + frow, ch = (kg * 4 + fg) ^ (row & 7);
+          fr[j] = lds[buf * 1024 + row * 8 + ch];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = (tid >> 3) + 32 * j, ch = (tid & 7) ^ (row & 7);
+          lds[(buf ^ 1) * 1024 + row * 8 + ch] = (MODE & 1) ? cur[j] : make_uint4(tid, j, buf, 1);
+        }
+      } else if (MODE & 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(cur[j].x), "v"(cur[j].y), "v"(cur[j].z), "v"(cur[j].w));
+      }
+      if (MODE & 1) issue(cur);                                 // refill the set just stored (three sets: two iterations of lead)
+      if (MODE & 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          c[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[j]), __builtin_bit_cast(bf16x8, fr[(j + 1) & 7]), c[j & 3], 0, 0, 0);
+      } else if (MODE & 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(fr[j].x), "v"(fr[j].y), "v"(fr[j].z), "v"(fr[j].w));
+      }
+      return;
+    }
     if (MODE & 1) issue(nxt);                                   // two iterations ahead
     if (MODE & 2) {
 #pragma unroll
@@ -69,7 +100,7 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint
       for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(fr[j].x), "v"(fr[j].y), "v"(fr[j].z), "v"(fr[j].w));           // every fragment read has to return
     }
   };
-  if (MODE & 1) { issue(ld[0]); issue(ld[1]); }
+  if (MODE & 1) { issue(ld[0]); issue(ld[1]); if (PIPE) issue(ld[2]); }
   for (int it = 0; it < iters; it += 6) {                       // one barrier per iteration, as the tile kernels
     body(ld[0], ld[2], 0); body(ld[1], ld[0], 1); body(ld[2], ld[1], 0);
     body(ld[0], ld[2], 1); body(ld[1], ld[0], 0); body(ld[2], ld[1], 1);
@@ -80,11 +111,11 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ src, uint
   if (acc.x == 0x12345678u && acc.w == 0x9abcdef0u) out[tid] = acc;   // keep everything alive
 }
 
-template <int MODE, bool STRIDED = false> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1, int share = 1, int stride = 0) {
+template <int MODE, bool STRIDED = false, bool PIPE = false> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1, int share = 1, int stride = 0) {
   float ms = 0;
   for (int w = 0; w < 3; ++w) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((probe<MODE, STRIDED>), dim3(g), dim3(256), 0, 0, src, out, N, win, share, stride);
+    hipLaunchKernelGGL((probe<MODE, STRIDED, PIPE>), dim3(g), dim3(256), 0, 0, src, out, N, win, share, stride);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
   }
   return ms;
@@ -100,6 +131,11 @@ int main() {
     float ms[8] = {run<0>(g, src, out, N, WIN, e0, e1), run<1>(g, src, out, N, WIN, e0, e1), run<2>(g, src, out, N, WIN, e0, e1), run<3>(g, src, out, N, WIN, e0, e1),
                    run<4>(g, src, out, N, WIN, e0, e1), run<5>(g, src, out, N, WIN, e0, e1), run<6>(g, src, out, N, WIN, e0, e1), run<7>(g, src, out, N, WIN, e0, e1)};
     for (int m = 0; m < 8; ++m) { printf("grid %3d  %-16s %7.1f ns / iteration\n", g, names[m], ms[m] * 1e6 / N); fflush(stdout); }
+  }
+  // the ring kernels' double-buffered order (fragment reads of slice t and the fill of slice t+1 in one LDS phase)
+  for (int g : {120, 256, 512}) {
+    const float a = run<2, false, true>(g, src, out, N, WIN, e0, e1), b = run<3, false, true>(g, src, out, N, WIN, e0, e1), c = run<6, false, true>(g, src, out, N, WIN, e0, e1), d = run<7, false, true>(g, src, out, N, WIN, e0, e1);
+    printf("grid %3d  pipelined order   lds %7.1f   loads+lds %7.1f   lds+mfma %7.1f   loads+lds+mfma %7.1f ns / iteration\n", g, a * 1e6 / N, b * 1e6 / N, c * 1e6 / N, d * 1e6 / N); fflush(stdout);
   }
   // hot lines: `share` workgroups (consecutive ids = different XCDs) stream the SAME window at the same time, as the workgroups of one
   // tile column do with a weight slice
