@@ -155,6 +155,54 @@ __global__ __launch_bounds__(256) void probe2(const uint4* __restrict__ src, uin
   if (acc.x == 0x12345678u) out[tid] = acc;
 }
 
+// The 128x128 tile's slice (4 waves, wave tile 64x64): 32 KiB of loads, 32 KiB of fill, 64 KiB of fragment reads, 32 MFMAs per wave, one barrier;
+// double-buffered order.  Half the operand bytes per MFMA of the 64x64 tile.
+__global__ __launch_bounds__(256) void probe3(const uint4* __restrict__ src, uint4* __restrict__ out, int iters, int win_u4) {
+  __shared__ uint4 lds[4096];                                   // 64 KiB: two buffers of two slices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)(blockIdx.x & 255) * win_u4), 0, win_u4 * 16, 0x00020000);
+  uint4 acc = make_uint4(0, 0, 0, 0), ld[3][8], fr[16];
+  f32x4 c[16];
+  for (int i = 0; i < 16; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 16; ++i) fr[i] = make_uint4(tid, i, 0x3f803f80u, 0x3f803f80u);
+  unsigned off = tid * 16;
+  const unsigned wbytes = (unsigned)win_u4 * 16u;
+  auto issue = [&](uint4 (&d)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + j * 4096, 0, 0));
+    off += 32768; if (off >= wbytes) off -= wbytes;
+  };
+  const int frow = lane & 15, fg = lane >> 4, wm = wave >> 1, wn = wave & 1;
+  auto body = [&](uint4 (&cur)[8], int buf) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int h = j >> 3, half = (j >> 2) & 1, t = j & 1, kg = (j >> 1) & 1;
+      const int row = (half ? 64 + wn * 32 : wm * 32) + t * 16 + frow, ch = (kg * 4 + fg) ^ (row & 7);
+      fr[j] = lds[buf * 2048 + h * 1024 + row * 8 + ch];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = (tid >> 3) + 32 * (j & 3), ch = (tid & 7) ^ (row & 7);
+      lds[(buf ^ 1) * 2048 + (j >> 2) * 1024 + row * 8 + ch] = cur[j];
+    }
+    issue(cur);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          c[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[8 + kg * 4 + j]), __builtin_bit_cast(bf16x8, fr[kg * 4 + i]), c[i * 4 + j], 0, 0, 0);
+  };
+  issue(ld[0]); issue(ld[1]); issue(ld[2]);
+  for (int it = 0; it < iters; it += 6) {
+    body(ld[0], 0); body(ld[1], 1); body(ld[2], 0); body(ld[0], 1); body(ld[1], 0); body(ld[2], 1);
+  }
+  for (int i = 0; i < 16; ++i) { asm volatile("" :: "v"(c[i][0]), "v"(c[i][1]), "v"(c[i][2]), "v"(c[i][3])); acc.x ^= __float_as_uint(c[i][0]); }
+  if (acc.x == 0x12345678u) out[tid] = acc;
+}
+
 template <int MODE, bool STRIDED = false, bool PIPE = false> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1, int share = 1, int stride = 0) {
   float ms = 0;
   for (int w = 0; w < 3; ++w) {
@@ -189,6 +237,15 @@ int main() {
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     printf("grid %3d  two slices per barrier, loads+lds+mfma %7.1f ns per 64 of K\n", g, ms * 1e6 / N); fflush(stdout);
+  }
+  for (int g : {120, 256, 512}) {
+    float ms = 0;
+    for (int w = 0; w < 3; ++w) {
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(probe3, dim3(g), dim3(256), 0, 0, (const uint4*)src, out, N / 2, WIN);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("grid %3d  128x128 tile slice (32 MFMAs per wave), loads+lds+mfma %7.1f ns per slice\n", g, ms * 1e6 / (N / 2)); fflush(stdout);
   }
   // hot lines: `share` workgroups (consecutive ids = different XCDs) stream the SAME window at the same time, as the workgroups of one
   // tile column do with a weight slice
