@@ -203,6 +203,43 @@ __global__ __launch_bounds__(256) void probe3(const uint4* __restrict__ src, uin
   if (acc.x == 0x12345678u) out[tid] = acc;
 }
 
+// LDS rates alone: W ds_write_b128 and R ds_read_b128 per thread and iteration (the tile's swizzled, conflict-free addresses), one barrier.
+template <int W, int R>
+__global__ __launch_bounds__(256) void probe4(uint4* __restrict__ out, int iters) {
+  __shared__ uint4 lds[2048];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fg = lane >> 4, wm = wave >> 1, wn = wave & 1;
+  uint4 fr[R > 0 ? R : 1], v = make_uint4(tid, 1, 2, 3);
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 1;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int half = (j >> 2) & 1, t = j & 1, kg = (j >> 1) & 1;
+      const int row = (half ? 64 + wn * 32 : wm * 32) + t * 16 + frow, ch = (kg * 4 + fg) ^ (row & 7);
+      fr[j] = lds[buf * 1024 + (((j >> 3) * 512 + row * 8 + ch) & 1023)];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int row = (tid >> 3) + 32 * (j & 3), ch = (tid & 7) ^ (row & 7);
+      lds[(buf ^ 1) * 1024 + row * 8 + ch] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) asm volatile("" :: "v"(fr[j].x), "v"(fr[j].y), "v"(fr[j].z), "v"(fr[j].w));
+  }
+  if (v.x == 0x12345678u) out[tid] = v;
+}
+template <int W, int R> void run4(int g, uint4* out, int N, hipEvent_t e0, hipEvent_t e1) {
+  float ms = 0;
+  for (int w = 0; w < 3; ++w) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((probe4<W, R>), dim3(g), dim3(256), 0, 0, out, N);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  const double ns = ms * 1e6 / N, bytes = 256.0 * 16 * (W + R);
+  printf("grid %3d  LDS only: %d writes + %2d reads (b128) per thread   %7.1f ns / iteration = %5.1f B/ns per CU\n", g, W, R, ns, bytes / ns); fflush(stdout);
+}
+
 template <int MODE, bool STRIDED = false, bool PIPE = false> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1, int share = 1, int stride = 0) {
   float ms = 0;
   for (int w = 0; w < 3; ++w) {
@@ -247,6 +284,7 @@ int main() {
     }
     printf("grid %3d  128x128 tile slice (32 MFMAs per wave), loads+lds+mfma %7.1f ns per slice\n", g, ms * 1e6 / (N / 2)); fflush(stdout);
   }
+  run4<4, 0>(256, out, N, e0, e1); run4<0, 8>(256, out, N, e0, e1); run4<0, 16>(256, out, N, e0, e1); run4<4, 8>(256, out, N, e0, e1); run4<8, 16>(256, out, N, e0, e1); run4<0, 16>(512, out, N, e0, e1);
   // hot lines: `share` workgroups (consecutive ids = different XCDs) stream the SAME window at the same time, as the workgroups of one
   // tile column do with a weight slice
   for (int share : {1, 32}) {
