@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -240,6 +241,57 @@ template <int W, int R> void run4(int g, uint4* out, int N, hipEvent_t e0, hipEv
   printf("grid %3d  LDS only: %d writes + %2d reads (b128) per thread   %7.1f ns / iteration = %5.1f B/ns per CU\n", g, W, R, ns, bytes / ns); fflush(stdout);
 }
 
+// The 64x64 tile's slice with the fill done by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): per iteration 4 DMA
+// wave-instructions per wave (16 KiB per workgroup) into an LDS ring of four slices, two iterations ahead; 8 fragment reads and 8 MFMAs per
+// wave; one barrier; vmcnt(4) before the barrier = the fill issued in the previous iteration has landed.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <bool MFMA>
+__global__ __launch_bounds__(256) void probe5(const uint4* __restrict__ src, uint4* __restrict__ out, int iters, int win_u4) {
+  __shared__ uint4 lds[4096];                                   // 64 KiB: four slices
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const uint4* base = src + (size_t)(blockIdx.x & 255) * win_u4;
+  uint4 acc = make_uint4(0, 0, 0, 0), fr[8];
+  f32x4 c[4];
+  for (int i = 0; i < 4; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fg = lane >> 4, wm = wave >> 1, wn = wave & 1;
+  unsigned off = 0;
+  auto fill = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(base + ((off + (wave * 4 + j) * 64 + lane) & (unsigned)(win_u4 - 1)), lds0 + buf * 16384 + (wave * 4 + j) * 1024);
+    off += 1024;
+  };
+  fill(0); fill(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 3;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int half = j >> 2, t = j & 1, kg = (j >> 1) & 1;
+      const int row = (half ? 64 + wn * 32 : wm * 32) + t * 16 + frow, ch = (kg * 4 + fg) ^ (row & 7);
+      fr[j] = lds[buf * 1024 + row * 8 + ch];
+    }
+    fill((it + 2) & 3);
+    if (MFMA) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        c[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[j]), __builtin_bit_cast(bf16x8, fr[(j + 1) & 7]), c[j & 3], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(fr[j].x), "v"(fr[j].y), "v"(fr[j].z), "v"(fr[j].w));
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int i = 0; i < 4; ++i) { asm volatile("" :: "v"(c[i][0]), "v"(c[i][1]), "v"(c[i][2]), "v"(c[i][3])); acc.x ^= __float_as_uint(c[i][0]); }
+  if (acc.x == 0x12345678u) out[tid] = acc;
+}
+
 template <int MODE, bool STRIDED = false, bool PIPE = false> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1, int share = 1, int stride = 0) {
   float ms = 0;
   for (int w = 0; w < 3; ++w) {
@@ -285,6 +337,14 @@ int main() {
     printf("grid %3d  128x128 tile slice (32 MFMAs per wave), loads+lds+mfma %7.1f ns per slice\n", g, ms * 1e6 / (N / 2)); fflush(stdout);
   }
   run4<4, 0>(256, out, N, e0, e1); run4<0, 8>(256, out, N, e0, e1); run4<0, 16>(256, out, N, e0, e1); run4<4, 8>(256, out, N, e0, e1); run4<8, 16>(256, out, N, e0, e1); run4<0, 16>(512, out, N, e0, e1);
+  for (int g : {120, 256, 512}) {
+    float ms[2] = {0, 0};
+    for (int w = 0; w < 3; ++w) {
+      CK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(probe5<false>, dim3(g), dim3(256), 0, 0, (const uint4*)src, out, N, WIN); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[0], e0, e1));
+      CK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(probe5<true>, dim3(g), dim3(256), 0, 0, (const uint4*)src, out, N, WIN); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[1], e0, e1));
+    }
+    printf("grid %3d  LDS-DMA fill: fill+reads %7.1f   fill+reads+mfma %7.1f ns / iteration\n", g, ms[0] * 1e6 / N, ms[1] * 1e6 / N); fflush(stdout);
+  }
   // hot lines: `share` workgroups (consecutive ids = different XCDs) stream the SAME window at the same time, as the workgroups of one
   // tile column do with a weight slice
   for (int share : {1, 32}) {
