@@ -1,7 +1,11 @@
 // Do the per-CU pipes of an igemm slice overlap?  Workgroups of 256 threads run N iterations of the 64x64 tile's per-slice traffic in
 // isolation and combined (bit mask MODE): 1 = 16 KiB of buffer_load_b128 from an L2-resident window, issued two iterations ahead, 2 = 16 KiB
 // of ds_write_b128 + 32 KiB of ds_read_b128 in the tile's swizzled layout, 4 = 8 MFMA 16x16x32 bf16 per wave; one barrier per iteration.
-// Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/pipe_overlap_probe tools/pipe_overlap_probe.hip   
+// Further variants: the ring kernels' double-buffered order (PIPE), 32 workgroups sharing one window (hot lines), the loader's row-strided
+// slabs (STRIDED), two slices per barrier (probe2), the 128x128 tile's slice (probe3), the LDS alone (probe4), the fill by LDS-DMA (probe5).
+// Check the instruction counts of a variant in the ISA before believing its number (dead-code elimination removed the fragment reads of an
+// early build).  Results and reading: DESIGN.md section 4.1c.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/_pipe_overlap_probe tools/pipe_overlap_probe.hip ; run it on the GPU box
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
