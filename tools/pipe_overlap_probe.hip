@@ -2,7 +2,7 @@
 // isolation and combined (bit mask MODE): 1 = 16 KiB of buffer_load_b128 from an L2-resident window, issued two iterations ahead, 2 = 16 KiB
 // of ds_write_b128 + 32 KiB of ds_read_b128 in the tile's swizzled layout, 4 = 8 MFMA 16x16x32 bf16 per wave; one barrier per iteration.
 // Further variants: the ring kernels' double-buffered order (PIPE), 32 workgroups sharing one window (hot lines), the loader's row-strided
-// slabs (STRIDED), two slices per barrier (probe2), the 128x128 tile's slice (probe3), the LDS alone (probe4), the fill by LDS-DMA (probe5).
+// slabs (STRIDED), two slices per barrier (probe2), the 128x128 tile's slice (probe3), the LDS alone (probe4), the fill by LDS-DMA (probe5; probe6 for the 128x128 slice).
 // Check the instruction counts of a variant in the ISA before believing its number (dead-code elimination removed the fragment reads of an
 // early build).  Results and reading: DESIGN.md section 4.1c.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/_pipe_overlap_probe tools/pipe_overlap_probe.hip ; run it on the GPU box
@@ -296,6 +296,54 @@ __global__ __launch_bounds__(256) void probe5(const uint4* __restrict__ src, uin
   if (acc.x == 0x12345678u) out[tid] = acc;
 }
 
+// the 128x128 tile's slice (probe3) with the LDS-DMA fill: 8 DMA instructions per wave and iteration into four 32 KiB slices (dynamic LDS)
+template <bool MFMA>
+__global__ __launch_bounds__(256) void probe6(const uint4* __restrict__ src, uint4* __restrict__ out, int iters, int win_u4) {
+  extern __shared__ uint4 lds[];                                // 128 KiB: four slices of 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const uint4* base = src + (size_t)(blockIdx.x & 255) * win_u4;
+  uint4 acc = make_uint4(0, 0, 0, 0), fr[16];
+  f32x4 c[16];
+  for (int i = 0; i < 16; ++i) c[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fg = lane >> 4, wm = wave >> 1, wn = wave & 1;
+  unsigned off = 0;
+  auto fill = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glds16(base + ((off + (wave * 8 + j) * 64 + lane) & (unsigned)(win_u4 - 1)), lds0 + buf * 32768 + (wave * 8 + j) * 1024);
+    off += 2048;
+  };
+  fill(0); fill(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int it = 0; it < iters; ++it) {
+    const int buf = it & 3;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int half = j >> 3, t = j & 3, kg = (j >> 2) & 1;        // A rows (wm) / B rows (wn), four 16-row tiles, two k groups
+      const int row = (half ? 128 + wn * 64 : wm * 64) + t * 16 + frow, ch = (kg * 4 + fg) ^ (row & 7);
+      fr[j] = lds[buf * 2048 + row * 8 + ch];
+    }
+    fill((it + 2) & 3);
+    if (MFMA) {
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            c[i * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[8 + kg * 4 + jj]), __builtin_bit_cast(bf16x8, fr[kg * 4 + i]), c[i * 4 + jj], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) asm volatile("" :: "v"(fr[j].x), "v"(fr[j].y), "v"(fr[j].z), "v"(fr[j].w));
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int i = 0; i < 16; ++i) { asm volatile("" :: "v"(c[i][0]), "v"(c[i][1]), "v"(c[i][2]), "v"(c[i][3])); acc.x ^= __float_as_uint(c[i][0]); }
+  if (acc.x == 0x12345678u) out[tid] = acc;
+}
+
 template <int MODE, bool STRIDED = false, bool PIPE = false> float run(int g, const uint4* src, uint4* out, int N, int win, hipEvent_t e0, hipEvent_t e1, int share = 1, int stride = 0) {
   float ms = 0;
   for (int w = 0; w < 3; ++w) {
@@ -348,6 +396,12 @@ int main() {
       CK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(probe5<true>, dim3(g), dim3(256), 0, 0, (const uint4*)src, out, N, WIN); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[1], e0, e1));
     }
     printf("grid %3d  LDS-DMA fill: fill+reads %7.1f   fill+reads+mfma %7.1f ns / iteration\n", g, ms[0] * 1e6 / N, ms[1] * 1e6 / N); fflush(stdout);
+  }
+  CK(hipFuncSetAttribute((const void*)probe6<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  for (int g : {256}) {
+    float ms = 0;
+    for (int w = 0; w < 3; ++w) { CK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(probe6<true>, dim3(g), dim3(256), 131072, 0, (const uint4*)src, out, N / 2, WIN); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); }
+    printf("grid %3d  128x128 slice, LDS-DMA fill: fill+reads+mfma %7.1f ns / iteration\n", g, ms * 1e6 / (N / 2)); fflush(stdout);
   }
   // hot lines: `share` workgroups (consecutive ids = different XCDs) stream the SAME window at the same time, as the workgroups of one
   // tile column do with a weight slice
