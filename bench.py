@@ -41,6 +41,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
     ap.add_argument('--cpu-baseline-steps', default='1,2', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3 prescribes 3,10: ~3-5 min)')
     ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
@@ -266,6 +267,9 @@ def main(argv=None):
                caption_model='att2in2', input_encoding_size=512, rnn_size=512, num_layers=1, drop_prob_lm=0.5, seq_length=T,
                fc_feat_size=4096, att_feat_size=4096, att_hid_size=512)
     np.random.seed(cfg.RNG_SEED)
+    if args.conv_algo:
+        from lang2seg_amd import ops as _O
+        _O.CONV_ALGO = args.conv_algo
     net = resnetv1(opt, batch_size=1, num_layers=101)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()

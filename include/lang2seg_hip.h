@@ -36,6 +36,9 @@ int l2s_version(void);
 #define L2S_CONV_OUT_F32 4     /* y is float regardless of dtype */
 #define L2S_CONV_DECONV2X2 8   /* Cout = 4*Cq, n = (dy*2+dx)*Cq + co; pixel-shuffled 2x upsampled output */
 #define L2S_CONV_SCATTER 16    /* output pixel (n, oy*out_stride, ox*out_stride) in an out_h x out_w grid */
+#define L2S_ALGO_AUTO 0
+#define L2S_ALGO_STAGED 1      /* register-staged tiles (ring / wave-specialised / software-pipelined kernels) */
+#define L2S_ALGO_DMA 2         /* 256x128 tile, LDS-DMA fill (buffer_load ... lds), two wave groups alternating load / multiply */
 typedef struct {
   const void* x;      /* [n_img, IH, IW, ldx] activations (dtype) */
   const void* w;      /* [Cout][KH*KW*Cin] (dtype) */
@@ -50,6 +53,7 @@ typedef struct {
   int tile;                     /* 0 = auto, 64 or 128 */
   int split_k;                  /* 0 = auto, 1 = off, n = force (needs ws) */
   int xcd_mode;                 /* tile order over the 8 XCDs: -1 = auto, 0 = M-chunks, 1 = N-chunks (speed only) */
+  int algo;                     /* kernel family: 0 = auto; L2S_ALGO_* forces one (benchmarks / tests; same arithmetic, speed only) */
   float* ws;                    /* optional ALL-ZERO float workspace >= rows*Cout for split-K partial sums; returned all-zero */
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);

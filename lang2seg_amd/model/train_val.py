@@ -114,10 +114,21 @@ class SolverWrapper(object):
             # iteration number is taken over and the rank keeps its freshly seeded streams and an in-range cursor.
             own = str(nfile)[:-len('.pkl')] + '.rank{:d}.pkl'.format(self.rank)
             if not os.path.exists(own):
+                if not getattr(cfg.TRAIN, 'ALLOW_RESHARD_RESUME', False):
+                    raise ValueError('%s: no sidecar for rank %d (snapshot written by a run with fewer ranks?).  Resuming would replay '
+                                     'different data and random streams on this rank than the run that wrote the snapshot; set '
+                                     'TRAIN.ALLOW_RESHARD_RESUME True to continue with freshly seeded cursors.' % (own, self.rank))
                 with open(nfile, 'rb') as fid:
                     for _ in range(6):
                         pickle.load(fid)
-                    return pickle.load(fid)
+                    it_ = pickle.load(fid)
+                    try:                                   # rank 0's device RNG step counter: every rank draws from the same counter stream
+                        self.net.seed_counter().fill_(int(pickle.load(fid)))
+                    except EOFError:
+                        pass
+                print('WARNING: rank {:d} resumes at iteration {:d} WITHOUT its own sidecar: loader cursor, permutation and host RNG '
+                      'streams are freshly seeded (TRAIN.ALLOW_RESHARD_RESUME)'.format(self.rank, it_))
+                return it_
             nfile = own
         with open(nfile, 'rb') as fid:
             np_state, py_state = pickle.load(fid), pickle.load(fid)

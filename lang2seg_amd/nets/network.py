@@ -164,7 +164,12 @@ class WgradQueue(object):
                     ck = (tag, rnd, v, c0, getattr(net, '_rec_key', None))
                     ent = self.tables.get(ck)
                     if ent is None or ent[0] != raw:
-                        ent = (raw, torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(net.device))
+                        # pinned staging buffer + asynchronous copy on the weight-gradient stream (a pageable .to(device) is a host stall
+                        # behind everything queued there); the pinned tensor lives as long as the table entry
+                        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+                        if net.device != 'cpu' and torch.cuda.is_available():
+                            host = host.pin_memory()
+                        ent = (raw, host.to(net.device, non_blocking=True), host)
                         self.tables[ck] = ent
                     dt = O.dt_of(chunk[0][0][2])
                     ctx = self.on_launch(tag, v, flop, chunk[0][0][10]) if self.on_launch is not None else None
@@ -356,11 +361,7 @@ class Network(object):
         self._tape_hist.append(ent is not None)
         if ent is None and len(self._tape_hist) == self._tape_hist.maxlen and sum(self._tape_hist) < self._tape_hist.maxlen // 2 \
                 and not getattr(self, 'tape_always', False):
-            loss = self.forward_backward(dev)
-            if self.dp is not None:
-                self.dp.finish()
-            train_op.step()
-            return loss
+            return self._eager_step(dev, train_op, key)
         main = torch.cuda.current_stream()
         S = self.streams()
         slist = [main, S['lang'], S['cap'], S['wg'], S['wg2'], S['tr']]
@@ -407,6 +408,44 @@ class Network(object):
         O.tape_run_segment(h, slist, len(stages))
         return loss
 
+    def _eager_step(self, dev, train_op, key):
+        """a step issued eagerly on a tape miss (low hit rate).  Its activation buffers are registered under a pseudo key per shape so
+        that they can be dropped again: the shapes used most recently keep their plans (`max_eager_plans`), older ones are freed, and
+        the byte cap of the tape plans applies to them too - otherwise one activation plan per new image size would accumulate for ever."""
+        import collections
+        if not hasattr(self, '_eager_keys'):
+            self._eager_keys = collections.OrderedDict()
+        ek = ('eager',) + key
+        self._eager_keys[ek] = True
+        self._eager_keys.move_to_end(ek)
+        self._rec_key = ek
+        try:
+            loss = self.forward_backward(dev)
+            if self.dp is not None:
+                self.dp.finish()
+            train_op.step()
+        finally:
+            self._rec_key = None
+        cap = int(getattr(self, 'max_plan_bytes', 96 << 30))
+        while len(self._eager_keys) > int(getattr(self, 'max_eager_plans', 2)) or (len(self._eager_keys) > 1 and self.plan_bytes() > cap):
+            old, _ = self._eager_keys.popitem(last=False)
+            self._drop_plan(old)
+        return loss
+
+    def _drop_plan(self, key):
+        """free every activation buffer that only the plan `key` (a tape or an eager shape) was holding.  Steps are issued asynchronously
+        and the side streams (weight gradients, optimiser) are not joined at step end, so the device is drained first: the caching
+        allocator orders reuse on the allocating stream only."""
+        torch.cuda.synchronize()
+        for bk in [bk for bk, users in self._buf_users.items() if key in users]:
+            users = self._buf_users[bk]
+            users.discard(key)
+            if not users:
+                del self._buf_users[bk]
+                self._bufs.pop(bk, None)
+        for ck in [ck for ck in self.wgq.tables if ck[-1] == key]:   # problem tables of the grouped weight-gradient launches of that plan
+            del self.wgq.tables[ck]
+
     def plan_bytes(self):
         """bytes of the persistent activation buffers (one plan per image size / token count that is on a tape)"""
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
@@ -415,16 +454,15 @@ class Network(object):
         """drop the least recently used tape and every activation buffer only it was holding (real data: one activation plan per
         image size would otherwise accumulate)"""
         key, (h, st, loss, stages) = self._tapes.popitem(last=False)
+        torch.cuda.synchronize()                                     # the tape's last replay may still be running on the side streams
         O.tape_destroy(h)
-        for bk in [bk for bk, users in self._buf_users.items() if key in users]:
-            users = self._buf_users[bk]
-            users.discard(key)
-            if not users:
-                del self._buf_users[bk]
-                self._bufs.pop(bk, None)
+        self._drop_plan(key)
 
     def dp_ready(self, stage):
         """a gradient bucket is final: hand it to the data-parallel reducer (and cut the launch tape there while recording)."""
+        # no bucket may be handed over (or updated early) with weight gradients of its stage still queued: the grouped launch would add
+        # this rank's local dW on top of the all-reduced sum afterwards (a backbone variant that forgets its own flush_wgrads, vgg16)
+        self.flush_wgrads('dp:' + stage)
         if self.dp is None:
             self._early_op.partial(stage)                        # single process: the optimiser updates the finished prefix early
             return

@@ -151,6 +151,7 @@ class vgg16(resnetv1):
             prev_is_pool = k > 0 and acts[k - 1][0] == 'pool'
             op.dgrad(g, 1, h, w, dx, ref=None if prev_is_pool else xin)
             g = dx; k -= 1
+        self.flush_wgrads('vgg backbone')                   # before the bucket goes to the reducer (dp_ready flushes too: belt and braces)
         if dp is not None:
             self.dp_ready('layer3')
 

@@ -84,6 +84,11 @@ def tape_size(h):
 
 
 # ------------------------------------------------------------------ conv / gemm
+# kernel family of every convolution that does not name one (l2s_conv_desc.algo: 0 = auto); set by the benchmark tools only
+# (bench.py --conv-algo, tools/*bench*.py): same arithmetic, speed only
+CONV_ALGO = 0
+
+
 def conv3x3_patch(x, w, y, n_img, IH, IW, Cin, Cout, bias=None, add=None, ref=None, relu=False, out_f32=False, dt=None):
     """direct 3x3 / stride 1 / pad 1 convolution through the LDS-patch kernel; False when the problem is not eligible (nothing launched)"""
     d = ConvDesc()
@@ -99,7 +104,7 @@ def conv3x3_patch(x, w, y, n_img, IH, IW, Cin, Cout, bias=None, add=None, ref=No
 
 def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
                ref=None, relu=False, out_f32=False, deconv=False, scatter=None, ldx=None, ldy=None, ldadd=None,
-               ldref=None, tile=0, dt=None, ws=None, split_k=0, xcd_mode=-1):
+               ldref=None, tile=0, dt=None, ws=None, split_k=0, xcd_mode=-1, algo=None):
     d = ConvDesc()
     d.x, d.w, d.y = ptr(x), ptr(w), ptr(y)
     d.bias, d.add, d.ref = ptr(bias), ptr(add), ptr(ref)
@@ -124,6 +129,7 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     d.tile = tile
     d.split_k = split_k
     d.xcd_mode = xcd_mode
+    d.algo = CONV_ALGO if algo is None else algo
     d.ws = ptr(ws)
     call('l2s_conv_igemm', C.byref(d), dt_of(x) if dt is None else dt, stream())
     return y

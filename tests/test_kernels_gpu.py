@@ -91,6 +91,47 @@ def test_conv_fwd(cfg, dt):
     assert rel_err(y2.view(n, OH, OW, Cout), nhwc(ref2)) < (2e-5 if dt == 0 else 1e-4)
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(n=256, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1),          # the dominant launch (M = 49 x 256, no ragged tile)
+    dict(n=23, H=7, W=7, Cin=128, Cout=200, k=3, s=1, p=1),           # ragged pixel tile (M = 1127) and ragged channel tile, borders of 7x7 maps
+    dict(n=64, H=7, W=7, Cin=512, Cout=2048, k=1, s=1, p=0),          # layer4 1x1-out: 8 slices of K
+    dict(n=40, H=7, W=7, Cin=192, Cout=128, k=1, s=1, p=0),           # exactly 3 slices of K: prologue and tail only
+    dict(n=1, H=38, W=63, Cin=1024, Cout=512, k=3, s=1, p=1),         # RPN 3x3 on the feature map: image borders, 144 slices
+    dict(n=1, H=20, W=26, Cin=256, Cout=128, k=1, s=2, p=0),          # strided 1x1
+    dict(n=2, H=19, W=23, Cin=64, Cout=64, k=3, s=1, p=1),            # two small images, 9 slices
+])
+@pytest.mark.parametrize('ALGO_DMA', [2])
+def test_conv_dma_tile(cfg, ALGO_DMA):
+    """L2S_ALGO_DMA (256x128 tile filled by buffer_load ... lds, two wave groups alternating load / multiply) against torch on the same
+    rounded bf16 operands: bias + residual + ReLU epilogue, and the data-gradient form (ReLU mask operand, no bias)."""
+    O = ops()
+    dt = 1
+    g = torch.Generator().manual_seed(11)
+    n, H, W, Cin, Cout, k, s, p = [cfg[x] for x in ['n', 'H', 'W', 'Cin', 'Cout', 'k', 's', 'p']]
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    OH = (H + 2 * p - k) // s + 1; OW = (W + 2 * p - k) // s + 1
+    res = torch.randn(n, Cout, OH, OW, generator=g)
+    xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
+    xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
+    conv = F.conv2d(xr, wr, None, stride=s, padding=p)
+    y = torch.full((n * OH * OW, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    O.conv_igemm(xd, wd, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=b.to(DEV), add=rd, relu=True, algo=ALGO_DMA)
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(n, OH, OW, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
+    y2 = torch.full((n * OH * OW, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    O.conv_igemm(xd, wd, y2, n, H, W, Cin, OH, OW, Cout, k, k, s, p, ref=rd, algo=ALGO_DMA)
+    torch.cuda.synchronize()
+    assert rel_err(y2.float().view(n, OH, OW, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
+    # the same launch twice more: no dependence on what the LDS ring held before
+    y3 = torch.empty_like(y2)
+    for _ in range(2):
+        O.conv_igemm(xd, wd, y3, n, H, W, Cin, OH, OW, Cout, k, k, s, p, ref=rd, algo=ALGO_DMA)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3)
+
+
 @pytest.mark.parametrize('dt', [0, 1])
 @pytest.mark.parametrize('cfg', [dict(H=19, W=23, Cin=64, Cout=64), dict(H=38, W=63, Cin=256, Cout=256), dict(H=75, W=125, Cin=128, Cout=128),
                                  dict(H=5, W=3, Cin=64, Cout=36), dict(H=38, W=63, Cin=1024, Cout=512)])
