@@ -39,6 +39,7 @@ int l2s_version(void);
 #define L2S_ALGO_AUTO 0
 #define L2S_ALGO_STAGED 1      /* register-staged tiles (ring / wave-specialised / software-pipelined kernels) */
 #define L2S_ALGO_DMA 2         /* 256x128 tile, LDS-DMA fill (buffer_load ... lds), two wave groups alternating load / multiply */
+#define L2S_ALGO_KSPLIT 5      /* 64x64 tile, LDS-DMA fill by four requester waves, four multiplier waves splitting each slice's K */
 typedef struct {
   const void* x;      /* [n_img, IH, IW, ldx] activations (dtype) */
   const void* w;      /* [Cout][KH*KW*Cin] (dtype) */

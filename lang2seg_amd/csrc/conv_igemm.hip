@@ -146,7 +146,10 @@ __device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x
 // (+ bias) through LDS, 64 rows at a time, turns them into 16-byte accesses that cover whole 256-byte rows.  Same arithmetic order as
 // igemm_epilogue_fast (bias, residual, ReLU, mask in fp32, one rounding). ----
 template <int TM, int TN, int WM, int WN, int WGM, int NT, int BN, int PASSES>
-__device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, char* smem) {
+__device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, char* smem,
+                                                      const u32x4v* pre_add = nullptr, const u32x4v* pre_ref = nullptr) {
+  // pre_add / pre_ref (single-pass tiles): the residual / ReLU-mask operands of this thread's chunks, requested by the caller BEFORE its K
+  // loop with igemm_epilogue_prefetch (same chunk map), so that their latency does not sit between the last MFMA and the stores
   // (tile width BN = WGN x WN; PASSES passes of RP rows: the waves whose rows fall into pass h stage their sub-tiles, then all NT threads
   // store them; one pass when the whole fp32 tile fits the kernel's LDS)
   constexpr int LDW = BN + 4;                                // floats per staged row (+ 4: shifts consecutive rows by 4 banks)
@@ -190,8 +193,10 @@ __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f3
       const int m = m0 + h * RP + row, n = n0 + col;
       const bool ok = c < CH && m < M && n < p.Cout;
       off[k] = ok ? (unsigned)m : NOPE;
-      if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
-      if (p.ref) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rref, ok ? (unsigned)((m * p.ldref + n) * 2) : NOPE, 0, 0);
+      if (PASSES == 1 && pre_add) { if (p.add) av[k] = pre_add[k]; }
+      else if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
+      if (PASSES == 1 && pre_ref) { if (p.ref) rv[k] = pre_ref[k]; }
+      else if (p.ref) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rref, ok ? (unsigned)((m * p.ldref + n) * 2) : NOPE, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < IT; ++k) {
@@ -221,6 +226,23 @@ __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f3
       const int n = n0 + col;
       __builtin_amdgcn_raw_buffer_store_b128(pk, ry, off[k] != NOPE ? (unsigned)((off[k] * p.ldy + n) * 2) : NOPE, 0, 0);
     }
+  }
+}
+
+// the chunk map of igemm_epilogue_lds128 (one pass): thread tid owns chunks tid + NT k of the ROWS x BN tile, 8 channels each
+template <int ROWS, int NT, int BN>
+__device__ __forceinline__ void igemm_epilogue_prefetch(const l2s_conv_desc& p, int m0, int n0, int M, int tid, u32x4v* av, u32x4v* rv) {
+  constexpr int CPR = BN / 8, CH = ROWS * CPR, IT = (CH + NT - 1) / NT;
+  constexpr unsigned NOPE = 0x80000000u;
+  const auto radd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add ? p.add : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref ? p.ref : p.y), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int c = tid + NT * k, row = c / CPR, col = (c % CPR) * 8;
+    const int m = m0 + row, n = n0 + col;
+    const bool ok = c < CH && m < M && n < p.Cout;
+    if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
+    if (p.ref) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rref, ok ? (unsigned)((m * p.ldref + n) * 2) : NOPE, 0, 0);
   }
 }
 
@@ -750,13 +772,14 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
     const int wchunk = ((cv ^ (lrow & (CPR - 1))) << 4);
     int a_iy0[NA], a_ix0[NA], a_base[NA]; bool a_ok[NA];
     const int ohw = p.OH * p.OW;
+    const float r_ohw = 1.0f / (float)ohw, r_ow = 1.0f / (float)p.OW;   // (M < 2^24: exact quotients with one fix-up step, no integer division)
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int m = m0 + lrow + LR * j;
       a_ok[j] = m < M;
       const int mm = a_ok[j] ? m : 0;
-      const int n_img = mm / ohw, rem = mm - n_img * ohw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int n_img = p.n_img > 1 ? fast_div(mm, ohw, r_ohw) : 0, rem = mm - n_img * ohw;
+      const int oy = fast_div(rem, p.OW, r_ow), ox = rem - oy * p.OW;
       a_iy0[j] = oy * p.stride - p.pad;
       a_ix0[j] = ox * p.stride - p.pad;
       a_base[j] = n_img * p.IH * p.IW;
@@ -832,6 +855,17 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = wave_all;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
+  const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
+                     !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
+                     (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
+  const bool staged = plain && (p.flags & EPI_LDS_FLAG64);
+  // residual / ReLU-mask operands of the LDS-staged epilogue, requested before the K loop (these waves issue no other global load)
+  constexpr int EIT = (BM * (BN / 8) + 255) / 256;
+  u32x4v eav[EIT], erv[EIT];
+  // (only behind a K loop long enough to cover them: with 4 slices they merely compete with the loaders' first, critical loads -
+  // layer3 conv3 7.5 -> 8.5 us - while the 3x3 / K = 1024 launches gain 0.3 us)
+  const bool pre = staged && KT >= 8;
+  if (pre) igemm_epilogue_prefetch<BM, 256, BN>(p, m0, n0, M, tid, eav, erv);
   const int swz = fr & (CPR - 1);
   const int offa = (wm * WM + fr) * RB, offb = BM * RB + (wn * WN + fr) * RB;
   f32x4 acc[TM][TN];
@@ -868,12 +902,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
   }
   if (t < KT) { __syncthreads(); read_all(t, fa1, fb1); mma_all(fa0, fb0); mma_all(fa1, fb1); }
   else mma_all(fa0, fb0);
-  {
-    const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
-                       !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
-                       (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-    if (plain && (p.flags & EPI_LDS_FLAG64)) { igemm_epilogue_lds128<TM, TN, WM, WN, 2, 256, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
-  }
+  if (staged) { igemm_epilogue_lds128<TM, TN, WM, WN, 2, 256, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all, pre ? eav : nullptr, pre ? erv : nullptr); return; }
   igemm_epilogue<T, TM, TN, WM, WN, false, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, 0);
 }
 
@@ -1421,6 +1450,213 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
   igemm_epilogue<T, TM, TN, WM, WN, false>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-M tile (bf16), the layer2 / layer3 launches: 64 x 64 outputs per workgroup, K in 256-byte slices (128 bf16) through a ring of D
+// LDS stages filled by LDS-DMA.  Waves 4-7 only REQUEST (eight 1-KiB pieces = 4 rows x 256 B per wave and slice, offsets as in the large
+// tile above, D-1 slices ahead, a counted vmcnt before the slice's barrier).  Waves 0-3 MULTIPLY, and they split the slice's K, not the
+// tile: wave w owns the whole 64 x 64 accumulator over k = 32 w .. 32 w + 31 of every slice, so a slice costs it 8 fragment reads for 16
+// MFMAs (the 2 x 2 spatial split of igemm_ws64_kernel: 8 reads for 8 MFMAs - a SIMD returns LDS data at 64 B/clk, ~20 cycles per
+// ds_read_b128, which is what paced that tile).  One barrier per slice: "slice t has landed" and, for the requesters, "the stage of slice
+// t-1 is free" (its reads were consumed by MFMAs issued before the barrier).  The four partial accumulators are added through LDS in a
+// fixed order (wave 0 + 1 + 2 + 3) by the epilogue, which also stages the rows for 16-byte stores; the residual / ReLU-mask operands of
+// the epilogue are requested before the K loop.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void igemm_ks64_kernel(const l2s_conv_desc p) {
+  typedef bf16_t T;
+  constexpr int BM = 64, BN = 64, RB2 = 256, BK = 128, STG = (BM + BN) * RB2, PW = 4;   // PW: pieces per requester wave and operand
+  constexpr unsigned NOPE = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  int mt, nt;
+  {
+    const int MT = (M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;
+    if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KT = K / BK;
+
+  if (wave >= 4) {
+    // ---------------- requesters ----------------
+    const int w = wave - 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const long xpix = (long)p.n_img * p.IH * p.IW;
+    i32x4s rx, rw;
+    rx.x = (int)(uintptr_t)p.x; rx.y = (int)((uintptr_t)p.x >> 32); rx.z = (int)(((xpix - 1) * p.ldx + p.Cin) * 2L); rx.w = 0x00020000;
+    rw.x = (int)(uintptr_t)p.w; rw.y = (int)((uintptr_t)p.w >> 32); rw.z = (int)((long)p.Cout * K * 2L); rw.w = 0x00020000;
+    const int prow = lane >> 4, sch = (lane & 15) ^ ((4 * w + prow) & 15);   // piece row, source chunk (16-byte chunks XOR-swizzled by row & 15)
+    const int ohw = p.OH * p.OW;
+    const float r_ohw = 1.0f / (float)ohw, r_ow = 1.0f / (float)p.OW;
+    int vbase[PW]; unsigned ntmask[PW], voffB[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int m = m0 + 4 * (w + 4 * j) + prow;
+      const bool ok = m < M;
+      const int mm = ok ? m : 0;
+      const int n_img = p.n_img > 1 ? fast_div(mm, ohw, r_ohw) : 0, rem = mm - n_img * ohw;
+      const int oy = fast_div(rem, p.OW, r_ow), ox = rem - oy * p.OW;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      vbase[j] = (((n_img * p.IH + iy0) * p.IW + ix0) * p.ldx + sch * 8) * 2;
+      unsigned mk = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = iy0 + ky, ix = ix0 + kx;
+          if (ky < p.KH && kx < p.KW && ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1u << (ky * p.KW + kx);
+        }
+      ntmask[j] = ~mk;
+      const int n = n0 + 4 * (w + 4 * j) + prow;
+      voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + sch * 8) * 2L) : OOR;
+    }
+    int c0 = 0, ky = 0, kx = 0, tapi = 0;
+    const unsigned ldsA = lds0 + (unsigned)(w * 1024), ldsB = ldsA + (unsigned)(BM * RB2);
+    auto request = [&](int stage) {                    // the slice at the cursor -> LDS stage `stage`; the cursor moves on
+      const int toff = (ky * p.IW + kx) * p.ldx * 2;
+      const unsigned soA = (unsigned)(c0 * 2), soB = (unsigned)((tapi * p.Cin + c0) * 2), sb = (unsigned)(stage * STG);
+      unsigned vo[PW];
+#pragma unroll
+      for (int j = 0; j < PW; ++j) vo[j] = (((ntmask[j] >> tapi) & 1u) << 31) | (unsigned)(vbase[j] + toff);
+#pragma unroll
+      for (int j = 0; j < PW; ++j) dma_b128(rx, vo[j], soA, ldsA + sb + (unsigned)(j * 4096));
+#pragma unroll
+      for (int j = 0; j < PW; ++j) dma_b128(rw, voffB[j], soB, ldsB + sb + (unsigned)(j * 4096));
+      const int nkx = kx + 1; const bool wx = nkx == p.KW; kx = wx ? 0 : nkx;
+      const int nky = ky + (wx ? 1 : 0); const bool wy = nky == p.KH; ky = wy ? 0 : nky;
+      tapi = wy ? 0 : tapi + 1; c0 += wy ? BK : 0;
+    };
+    auto wait_younger = [&](int younger) {             // all requests landed except those of the `younger` most recent slices
+      if (D >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PW) : "memory");
+      else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(D == 3 || D == 4, "ring depth");
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s)
+      if (s < KT) { request(s); ++issued; }
+    wait_younger(issued - 1);
+    wg_barrier();                                      // barrier #0: slice 0 landed
+    int sf = D - 1;                                    // stage of the next request: (t + D - 1) % D
+    for (int t = 0; t + 1 < KT; ++t) {
+      if (issued < KT) { request(sf); ++issued; }
+      sf = sf == D - 1 ? 0 : sf + 1;
+      wait_younger(issued - (t + 2));                  // slice t+1 landed
+      wg_barrier();                                    // barrier #(t+1)
+    }
+    return;
+  }
+
+  // ---------------- multipliers: wave w = K quarter w of every slice ----------------
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
+                     !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
+                     (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
+  // epilogue operands of this thread's two output chunks (row = chunk / 8, 8 channels each), requested now: their latency passes under the K loop
+  const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFFFF, 0x00020000);
+  const auto radd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add ? p.add : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref ? p.ref : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  u32x4v av[2], rv[2]; unsigned orow[2];
+  if (plain) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = tid + 256 * k, row = c >> 3, col = (c & 7) * 8;
+      const int m = m0 + row, n = n0 + col;
+      const bool ok = m < M && n < p.Cout;
+      orow[k] = ok ? (unsigned)m : NOPE;
+      if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
+      if (p.ref) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rref, ok ? (unsigned)((m * p.ldref + n) * 2) : NOPE, 0, 0);
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ch = ((4 * wave + fg) ^ fr) << 4;          // this lane's 16-byte chunk of a 256-byte row (row & 15 == fr)
+  const int offa = fr * RB2 + ch, offb = BM * RB2 + fr * RB2 + ch;
+  int st = 0;
+  for (int t = 0; t < KT; ++t) {
+    wg_barrier();                                      // barrier #t: slice t landed
+    const char* base = smem + st * STG;
+    uint4 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * RB2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * RB2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
+    st = st == D - 1 ? 0 : st + 1;
+  }
+  // ---- the four K quarters meet in LDS: part[w][row][col] fp32, row pitch 68 floats ----
+  constexpr int LDW = BN + 4;
+  float* part = (float*)smem;
+  __syncthreads();                                     // every wave is done reading the ring (the requesters have left)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(part + (wave * BM + i * 16 + fr) * LDW + j * 16 + fg * 4) = acc[i][j];
+  __syncthreads();
+  if (plain) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = tid + 256 * k, row = c >> 3, col = (c & 7) * 8;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 lo = *(const f32x4*)(part + (q * BM + row) * LDW + col), hi = *(const f32x4*)(part + (q * BM + row) * LDW + col + 4);
+        v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3]; v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
+      }
+      const int n = n0 + col;
+      if (p.bias && n < p.Cout) {
+        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+        v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
+      }
+      if (p.add) {
+        const unsigned wv[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(wv[e] << 16); v[2 * e + 1] += __uint_as_float(wv[e] & 0xFFFF0000u); }
+      }
+      if (p.flags & L2S_CONV_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.ref) {
+        const unsigned wv[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!(__uint_as_float(wv[e] << 16) > 0.f)) v[2 * e] = 0.f;
+          if (!(__uint_as_float(wv[e] & 0xFFFF0000u) > 0.f)) v[2 * e + 1] = 0.f;
+        }
+      }
+      u32x4v pk;
+      pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      __builtin_amdgcn_raw_buffer_store_b128(pk, ry, orow[k] != NOPE ? (unsigned)((orow[k] * p.ldy + n) * 2) : NOPE, 0, 0);
+    }
+    return;
+  }
+  // general output forms (strided scatter, pixel shuffle, odd pitches): wave w finishes rows 16 w .. 16 w + 15 through the shared epilogue
+  f32x4 fin[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const f32x4 v = *(const f32x4*)(part + (q * BM + wave * 16 + fr) * LDW + j * 16 + fg * 4); sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3]; }
+    fin[0][j] = sum;
+  }
+  igemm_epilogue<T, 1, 4, 16, 64, false>(p, fin, m0, n0, wave, 0, fr, fg, M);
+}
+
 // y = epilogue(ws) and ws = 0 (so the workspace is clean for the next split-K launch)
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const l2s_conv_desc p, long total) {
@@ -1493,6 +1729,17 @@ int launch_igemm_sp(const l2s_conv_desc& d, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32, TAPIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   L2S_LAUNCH((igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32, TAPIN>), grid, dim3(64 * WGM * WGN), lds, st, d);
+  return l2s_check_launch();
+}
+
+template <int D>
+int launch_igemm_ks64(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, 64) * cdiv(d.Cout, 64));
+  const size_t lds = (size_t)D * 128 * 256;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ks64_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_ks64_kernel<D>), grid, dim3(512), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -1601,6 +1848,12 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
       const bool dma_ok = dtype == L2S_BF16 && !f32o && KT >= 3 && d->KH <= 3 && d->KW <= 3;
       if (dma_ok && (d->algo == L2S_ALGO_DMA || d->algo == 4 || (d->algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256))))
         return d->algo == 4 ? launch_igemm_dma<256, 128, true>(*d, stream) : launch_igemm_dma<256, 128, false>(*d, stream);
+      // K-split 64x64 tile with LDS-DMA fill: the small-M launches (layer2 / layer3) with whole 128-channel pieces per tap
+      const bool ks_ok = dtype == L2S_BF16 && !f32o && d->Cin % 128 == 0 && d->KH <= 3 && d->KW <= 3 && (long)M * d->Cout * 4 < (1L << 31);
+      if (ks_ok && (d->algo == L2S_ALGO_KSPLIT || d->algo == 6)) return d->algo == 6 ? launch_igemm_ks64<3>(*d, stream) : launch_igemm_ks64<4>(*d, stream);
+      // auto: the 3x3 launches whose 64x64 tiles fit one round of workgroups (layer3, RPN, layer4 on the map): 13.8 -> 11.2 us, 61.6 -> 52.9 us
+      // (tools/dma_bench.py); the 1x1 launches gain nothing (their K loop is a few slices) and multi-round grids lose (one workgroup per CU)
+      if (ks_ok && d->algo == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && (long)cdiv(M, 64) * cdiv(d->Cout, 64) <= 256 && K >= 1024) return launch_igemm_ks64<4>(*d, stream);
       if (dtype == L2S_BF16) {
         if (tile == 224) return GSP7(bf16_t, 2);
         if (tile == 256) return sp_on ? GSP(bf16_t, 256, 128, 2) : GR8(bf16_t, 256, 128, 2);

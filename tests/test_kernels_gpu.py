@@ -132,6 +132,57 @@ def test_conv_dma_tile(cfg, ALGO_DMA):
     assert torch.equal(y2, y3)
 
 
+@pytest.mark.parametrize('algo', [5, 6])
+@pytest.mark.parametrize('cfg', [
+    dict(n=1, H=38, W=63, Cin=256, Cout=256, k=3, s=1, p=1),          # layer3 3x3: 18 slices of 128 channels, image borders, ragged pixel tile
+    dict(n=1, H=38, W=63, Cin=1024, Cout=256, k=1, s=1, p=0),         # layer3 1x1-in
+    dict(n=1, H=38, W=63, Cin=256, Cout=1024, k=1, s=1, p=0),         # layer3 1x1-out: two slices
+    dict(n=1, H=75, W=125, Cin=128, Cout=128, k=3, s=1, p=1),         # layer2 3x3: one slice per tap, 294 tiles
+    dict(n=1, H=75, W=125, Cin=128, Cout=512, k=1, s=1, p=0),         # a single slice of K
+    dict(n=1, H=75, W=125, Cin=512, Cout=256, k=1, s=2, p=0),         # layer3.0 conv1: strided 1x1
+    dict(n=5, H=7, W=7, Cin=128, Cout=200, k=3, s=1, p=1),            # several small images, ragged channel tile
+])
+def test_conv_ksplit_tile(cfg, algo):
+    """L2S_ALGO_KSPLIT (64x64 tile, LDS-DMA fill by requester waves, the four multiplier waves split each slice's K and add their partial
+    tiles in LDS in a fixed order; algo 6 = ring of three stages) against torch on the same rounded bf16 operands, in the forward form
+    (bias + residual + ReLU), the data-gradient form (ReLU mask) and the strided-scatter form of a stride-2 data gradient."""
+    O = ops()
+    dt = 1
+    g = torch.Generator().manual_seed(12)
+    n, H, W, Cin, Cout, k, s, p = [cfg[x] for x in ['n', 'H', 'W', 'Cin', 'Cout', 'k', 's', 'p']]
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    OH = (H + 2 * p - k) // s + 1; OW = (W + 2 * p - k) // s + 1
+    res = torch.randn(n, Cout, OH, OW, generator=g)
+    xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
+    xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
+    conv = F.conv2d(xr, wr, None, stride=s, padding=p)
+    y = torch.full((n * OH * OW, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    O.conv_igemm(xd, wd, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=b.to(DEV), add=rd, relu=True, algo=algo)
+    torch.cuda.synchronize()
+    assert rel_err(y.float().view(n, OH, OW, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
+    y2 = torch.full((n * OH * OW, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    O.conv_igemm(xd, wd, y2, n, H, W, Cin, OH, OW, Cout, k, k, s, p, ref=rd, algo=algo)
+    torch.cuda.synchronize()
+    assert rel_err(y2.float().view(n, OH, OW, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
+    y3 = torch.empty_like(y2)
+    for _ in range(2):
+        O.conv_igemm(xd, wd, y3, n, H, W, Cin, OH, OW, Cout, k, k, s, p, ref=rd, algo=algo)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3)                                        # fixed summation order of the four K quarters
+    if k == 1 and s == 1 and Cin % 128 == 0:
+        # the data gradient of a stride-2 1x1 convolution: a 1x1 product whose rows are scattered to every second pixel of a larger map
+        xr2 = xd.float().cpu().view(n * H * W, Cin)
+        wr2 = wd.float().cpu().view(Cout, Cin)
+        out = torch.zeros((n, 2 * H, 2 * W, Cout), dtype=torch.bfloat16, device=DEV)
+        O.conv_igemm(xd, wd, out, n, H, W, Cin, H, W, Cout, 1, 1, 1, 0, scatter=(2 * H, 2 * W, 2), algo=algo)
+        torch.cuda.synchronize()
+        ref = (xr2 @ wr2.t()).view(n, H, W, Cout)
+        assert rel_err(out.float()[:, ::2, ::2, :], ref) < TOL[dt]
+        assert float(out.float()[:, 1::2, :, :].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('dt', [0, 1])
 @pytest.mark.parametrize('cfg', [dict(H=19, W=23, Cin=64, Cout=64), dict(H=38, W=63, Cin=256, Cout=256), dict(H=75, W=125, Cin=128, Cout=128),
                                  dict(H=5, W=3, Cin=64, Cout=36), dict(H=38, W=63, Cin=1024, Cout=512)])

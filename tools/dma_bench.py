@@ -22,7 +22,24 @@ SHAPES = [
 ]
 
 
+SMALL = [
+    ('l3 3x3', 1, 38, 63, 256, 256, 3, 1),
+    ('l3 1x1 in', 1, 38, 63, 1024, 256, 1, 0),
+    ('l3 1x1 out', 1, 38, 63, 256, 1024, 1, 0),
+    ('l2 3x3', 1, 75, 125, 128, 128, 3, 1),
+    ('l2 1x1 in', 1, 75, 125, 512, 128, 1, 0),
+    ('l2 1x1 out', 1, 75, 125, 128, 512, 1, 0),
+    ('rpn 3x3', 1, 38, 63, 1024, 512, 3, 1),
+    ('l4m 3x3', 1, 38, 63, 512, 512, 3, 1),
+    ('l4m 1x1 in', 1, 38, 63, 2048, 512, 1, 0),
+    ('l4m 1x1 out', 1, 38, 63, 512, 2048, 1, 0),
+]
+
+
 def main():
+    global SHAPES
+    if os.environ.get('SHAPES', 'large') == 'small':
+        SHAPES = SMALL
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     dbg = int(os.environ.get('DBG', '0'))
     algos = [int(a) for a in os.environ.get('ALGOS', '1,2').split(',')]
