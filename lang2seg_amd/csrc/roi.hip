@@ -50,85 +50,111 @@ __device__ __forceinline__ uint64_t sort_key(float s, int idx) {
 // (freshly initialised RPNs emit 28 728 scores within 1e-3 of 0.5).  Per pass: per-block LDS histogram -> single-workgroup
 // exclusive scan over (digit, block) -> scatter with an in-LDS stable local rank.  Blocks of 256 consecutive elements.
 __device__ __forceinline__ unsigned int okey(float s) { unsigned int u = __float_as_uint(s); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+// workspace: two (key, index) buffers + one table of per-block digit counts per pass, hist[pass][block][digit]
 struct RsWs { unsigned int* kA; int* iA; unsigned int* kB; int* iB; int* hist; };
 __device__ __host__ __forceinline__ RsWs rs_ws(int* ws, int n) {
   RsWs w; w.kA = (unsigned int*)ws; w.iA = ws + n; w.kB = (unsigned int*)(ws + 2 * n); w.iB = ws + 3 * n; w.hist = ws + 4 * n;
   return w;
 }
-__global__ void rs_init_kernel(const float* scores, int n, int* ws) {
-  RsWs w = rs_ws(ws, n);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { w.kA[i] = ~okey(scores[i]); w.iA[i] = i; }
-}
-__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned int* keys, int n, int shift, int nblk, int* hist) {
+// pass 0 counts (keys come straight from the scores) and the clear of the other three tables
+__global__ __launch_bounds__(256) void rs_hist0_kernel(const float* scores, int n, int nblk, int* hist) {
   __shared__ int h[256];
-  h[threadIdx.x] = 0;
+  const int t = threadIdx.x, b = blockIdx.x;
+  h[t] = 0;
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+  const int i = b * 256 + t;
+  if (i < n) atomicAdd(&h[(~okey(scores[i])) & 255], 1);
   __syncthreads();
-  hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+  hist[b * 256 + t] = h[t];
+#pragma unroll
+  for (int p = 1; p < 4; ++p) hist[(p * nblk + b) * 256 + t] = 0;
 }
-__global__ __launch_bounds__(1024) void rs_scan_kernel(int* hist, int total, int use_lds) {
-  // exclusive scan of `total` counters by one workgroup, staged through LDS when they fit (dynamic, total ints): all loads
-  // are issued before any dependent work, the serial part runs on LDS (thread-contiguous chunks, odd stride -> no bank
-  // conflicts); larger inputs run the same code in place on global memory
-  extern __shared__ int shl[];
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  int* sh = use_lds ? shl : hist;
-  if (use_lds) for (int i = t; i < total; i += 1024) sh[i] = hist[i];
-  __syncthreads();
-  const int per = ((total + 1023) / 1024) | 1, lo = t * per, hi = min(total, lo + per);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += sh[i];
-  part[t] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) { int x = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += x; __syncthreads(); }
-  int run = part[t] - s;
-  for (int i = lo; i < hi; ++i) { const int v = sh[i]; sh[i] = run; run += v; }
-  __syncthreads();
-  if (use_lds) for (int i = t; i < total; i += 1024) hist[i] = sh[i];
-}
-__global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned int* kin, const int* iin, unsigned int* kout, int* iout, int n, int shift,
-                                                        int nblk, const int* hist) {
-  __shared__ unsigned char sd[256];
-  const int t = threadIdx.x, i = blockIdx.x * 256 + t;
-  unsigned int key = 0; int idx = 0, d = 256;
-  if (i < n) { key = kin[i]; idx = iin[i]; d = (key >> shift) & 255; }
-  sd[t] = (unsigned char)(d & 255);
-  __syncthreads();
-  if (i < n) {
-    int rank = 0;
-    for (int j = 0; j < t; ++j) rank += (sd[j] == (unsigned char)d);
-    const int pos = hist[d * nblk + blockIdx.x] + rank;
-    kout[pos] = key; iout[pos] = idx;
+// One pass = ONE launch (round 2: counts, a single-workgroup scan of 28 928 counters, scatter = three dependent launches per pass, the
+// scan alone 15 us): every block derives its own bases from the table of the pass (thread d sums digit d over all blocks - coalesced,
+// 113 KB from L2 - and over the blocks before this one; a 256-wide exclusive scan of the totals in LDS), ranks its elements stably
+// (wave ballots: lanes with the same digit, + the counts of the waves before), scatters, and counts the NEXT pass's digit of every
+// element at its destination block with a global atomic.  The last pass writes the sorted (index, score, box) rows of the top k itself.
+template <int PASS>
+__global__ __launch_bounds__(256) void rs_pass_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, const unsigned int* __restrict__ kin,
+                                                      const int* __restrict__ iin, unsigned int* __restrict__ kout, int* __restrict__ iout, int n, int nblk,
+                                                      int* __restrict__ hist, int k, float* __restrict__ sboxes, float* __restrict__ sscores, int* __restrict__ sidx) {
+  __shared__ int tot[256], base[256], wcnt[4][256];
+  const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = b * 256 + t;
+  unsigned int key = 0; int idx = 0;
+  const bool valid = i < n;
+  if (valid) {
+    if (PASS == 0) { key = ~okey(scores[i]); idx = i; } else { key = kin[i]; idx = iin[i]; }
   }
-}
-__global__ void rs_gather_kernel(const int* idx_sorted, const float* scores, const float* boxes, int k, float* sboxes, float* sscores, int* sidx) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= k) return;
-  const int i = idx_sorted[r];
-  sidx[r] = i; sscores[r] = scores[i];
-  *(float4*)(sboxes + (long)r * 4) = *(const float4*)(boxes + (long)i * 4);
+  const int d = (int)((key >> (8 * PASS)) & 255u);
+  // ---- bases: digit t over all blocks / over the blocks before this one ----
+  const int* hp = hist + (long)PASS * nblk * 256 + t;
+  int total = 0, before = 0;
+  int bb = 0;
+  for (; bb + 8 <= nblk; bb += 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = hp[(bb + u) * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { total += v[u]; before += (bb + u < b) ? v[u] : 0; }
+  }
+  for (; bb < nblk; ++bb) { const int v = hp[bb * 256]; total += v; before += (bb < b) ? v : 0; }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wcnt[w][t] = 0;
+  tot[t] = total;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) { const int x = t >= o ? tot[t - o] : 0; __syncthreads(); tot[t] += x; __syncthreads(); }
+  base[t] = tot[t] - total + before;                   // elements with a smaller digit anywhere + this digit in earlier blocks
+  // ---- stable rank inside the block ----
+  unsigned long long same = valid ? ~0ull : 0ull;      // lanes of this wave with the same digit
+#pragma unroll
+  for (int bit = 0; bit < 8; ++bit) {
+    const unsigned long long bal = __ballot(valid && ((d >> bit) & 1));
+    same &= ((d >> bit) & 1) ? bal : ~bal;
+  }
+  same &= __ballot(valid);
+  const int below = __popcll(same & ((1ull << lane) - 1ull));
+  if (valid && below == 0) wcnt[wave][d] = __popcll(same);
+  __syncthreads();
+  if (valid) {
+    int rank = below;
+    for (int w = 0; w < wave; ++w) rank += wcnt[w][d];
+    const int pos = base[d] + rank;
+    if (PASS < 3) {
+      kout[pos] = key; iout[pos] = idx;
+      atomicAdd(&hist[((long)(PASS + 1) * nblk + (pos >> 8)) * 256 + ((key >> (8 * (PASS + 1))) & 255u)], 1);
+    } else if (pos < k) {
+      sidx[pos] = idx; sscores[pos] = scores[idx];
+      *(float4*)(sboxes + (long)pos * 4) = *(const float4*)(boxes + (long)idx * 4);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ NMS
-__device__ __forceinline__ bool nms_hit(const float4& a, float aarea, const float4& b, float thr, int cmp) {
+// ovr = inter / (area_a + area_b - inter) against thr (nms.c:55-59 `>=`, nms_kernel.cu:56-66 `>`), bit for bit: the IEEE division is only
+// evaluated when inter lies within 2^-18 (relative) of thr * union - everywhere else the comparison cannot come out differently (the
+// rounding of thr * union and of the quotient are 2^-24 each), and almost every pair of a 12000-box problem is far outside the band.
+__device__ __forceinline__ bool nms_hit(const float4& a, float aarea, const float4& b, float barea, float thr, int cmp) {
   const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y), xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
   const float w = fmaxf(0.f, xx2 - xx1 + 1.f), h = fmaxf(0.f, yy2 - yy1 + 1.f);
   const float inter = w * h;
-  const float barea = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
-  const float ovr = inter / (aarea + barea - inter);     // nms.c:55-58
+  const float uni = aarea + barea - inter;
+  const float q = thr * uni;
+  if (inter < q * (1.f - 0x1p-18f)) return false;
+  if (inter > q * (1.f + 0x1p-18f)) return true;
+  const float ovr = inter / uni;                          // nms.c:55-58
   return cmp ? (ovr > thr) : (ovr >= thr);
 }
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int cb, uint64_t* mask) {
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;
   __shared__ float4 cbox[64];
+  __shared__ float carea[64];
   const int lane = threadIdx.x;
   const int cj = cbk * 64 + lane;
-  cbox[lane] = cj < n ? *(const float4*)(boxes + (long)cj * 4) : make_float4(0, 0, -1, -1);
+  const float4 cbv = cj < n ? *(const float4*)(boxes + (long)cj * 4) : make_float4(0, 0, -1, -1);
+  cbox[lane] = cbv;
+  carea[lane] = (cbv.z - cbv.x + 1.f) * (cbv.w - cbv.y + 1.f);
   __syncthreads();
   const int ri = rb * 64 + lane;
   if (ri >= n) return;
@@ -138,78 +164,104 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   uint64_t t = 0;
   const int start = (rb == cbk) ? lane + 1 : 0;
   for (int j = start; j < csize; ++j)
-    if (nms_hit(a, aarea, cbox[j], thr, cmp)) t |= 1ull << j;
+    if (nms_hit(a, aarea, cbox[j], carea[j], thr, cmp)) t |= 1ull << j;
   mask[(long)ri * cb + cbk] = t;
 }
-// Greedy scan over the bitmask, one 64-box block per phase, single workgroup of 16 waves:
-//   wave 0 (critical path): scans block j against remv[j] (only the kept boxes cost an iteration), then ORs the kept rows'
-//           words of columns j+1 and j+2 (prefetched one phase ahead) straight into remv;
-//   waves 1..15 (bulk, software pipelined): in phase j+1 they LOAD the kept rows of block j for every column >= j+3 into
-//           registers (whole rows, one wave per row: contiguous 512-byte pieces), in phase j+2 they OR them into remv with
-//           fire-and-forget LDS atomics -- so the L2 latency of the bulk rows spans a whole phase.
-// One barrier per phase; stops as soon as max_keep boxes are kept (RPN_POST_NMS_TOP_N).
+// Greedy scan over the bitmask (nms.c:35-63 / nms_cuda.c:47-58), one 64-box block per phase, a single workgroup of 16 waves, one raw
+// barrier per phase.  Round 2's form of this kernel took 0.83 us per phase (157 us for 188 blocks): every global word was requested ONE
+// phase ahead, so a phase could not be shorter than a load's round trip from one compute unit, and wave 0 walked every kept box of the
+// block.  Now:
+//   wave 0 (the chain): its words - the block's diagonal word and the NDIR following columns of every row - are requested PD phases
+//           ahead.  Only rows whose diagonal word is non-zero (rows that suppress a LATER row of the same block) are walked in order;
+//           a row without in-block suppressions never changes the block's state, so its fate is bit `row` of the final state.  The
+//           kept rows OR their words of columns b+1 .. b+NDIR straight into remv (LDS atomics).
+//   waves 1..15 (bulk), in two groups that take turns: the kept rows of block j belong to group j & 1, which requests them in phase j+1
+//           for every column >= j+NDIR+1 (one wave per row, contiguous 512-byte pieces), rests in phase j+2 and applies them in phase
+//           j+3 - two phases for the loads, still one phase before the first of those columns is read.
+// Stops as soon as max_keep boxes are kept (RPN_POST_NMS_TOP_N).
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out) {
-  extern __shared__ unsigned long long remv[];   // cb words
+  constexpr int NDIR = 3, PD = 3;                  // direct columns per row; phases between wave 0's requests and their use
+  extern __shared__ unsigned long long remv[];     // cb words
   __shared__ unsigned long long kept_sh[2];
   __shared__ int nk_sh[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < cb; c += 1024) remv[c] = 0ull;
   if (tid == 0) { nk_sh[0] = nk_sh[1] = 0; kept_sh[0] = kept_sh[1] = 0ull; }
-  int nk = 0;   // running keep count (wave 0)
   __syncthreads();
-  unsigned long long dnext = 0ull, c1next = 0ull, c2next = 0ull;
-  if (wave == 0 && lane < n) {
-    dnext = mask[(long)lane * cb];
-    if (cb > 1) c1next = mask[(long)lane * cb + 1];
-    if (cb > 2) c2next = mask[(long)lane * cb + 2];
-  }
-  // bulk waves: wave w owns rows w-1, w-1+15, ... of a block (up to RW = 5); a lane owns columns c0 + lane + 64 k (k < CK = 3).
-  // A kept row is a wave-uniform condition and its words are read as contiguous 512-byte pieces: the kernel is bound by what ONE
-  // compute unit's L1 path can move (~9 MB of mask words per 12000 boxes at 64 B/clk), so the pieces have to be whole cache lines
-  // (a 64-rows x 15-lanes map that read 120-byte pieces took 231 us, this one 198 us; 16-byte loads of column pairs took 243 us).
-  // The rows of one phase are OR-combined when they are applied, so a lane issues at most CK LDS atomics per phase.
-  constexpr int RW = 5, CK = 3;
-  unsigned long long pv[RW][CK]; int pc0 = 0;    // bulk words requested in the previous phase and their first column
+  if (wave == 0) {
+    // ---------------- the chain ----------------
+    int nk = 0;                                    // running keep count
+    unsigned long long pw[PD][NDIR + 1];           // [stage][0] = diagonal word, [c] = column blk + c of row blk * 64 + lane
+    auto w0_load = [&](int blk, unsigned long long (&dst)[NDIR + 1]) {
+      const int row = blk * 64 + lane;
+      const bool v = blk < cb && row < n;
+      const uint64_t* mr = mask + (long)row * cb + blk;
 #pragma unroll
-  for (int ri = 0; ri < RW; ++ri)
+      for (int c = 0; c <= NDIR; ++c) dst[c] = (v && blk + c < cb) ? mr[c] : 0ull;
+    };
 #pragma unroll
-    for (int k = 0; k < CK; ++k) pv[ri][k] = 0ull;
-  for (int b = 0; b < cb; ++b) {
-    if (wave == 0) {
+    for (int s = 0; s < PD; ++s) w0_load(s, pw[s]);
+    for (int b = 0; b < cb; ++b) {
       const int row = b * 64 + lane;
-      const unsigned long long d = dnext, col1 = c1next, col2 = c2next;
-      if (b + 1 < cb) {                                      // prefetch the next block's words: off this phase's latency chain
-        const int r2 = row + 64;
-        const bool v = r2 < n;
-        dnext = v ? mask[(long)r2 * cb + b + 1] : 0ull;
-        c1next = (v && b + 2 < cb) ? mask[(long)r2 * cb + b + 2] : 0ull;
-        c2next = (v && b + 3 < cb) ? mask[(long)r2 * cb + b + 3] : 0ull;
-      }
+      unsigned long long wv[NDIR + 1];
+#pragma unroll
+      for (int c = 0; c <= NDIR; ++c) wv[c] = pw[0][c];
+#pragma unroll
+      for (int s = 0; s + 1 < PD; ++s)
+#pragma unroll
+        for (int c = 0; c <= NDIR; ++c) pw[s][c] = pw[s + 1][c];
+      w0_load(b + PD, pw[PD - 1]);                         // (uses nothing of this phase: off its latency chain)
+      const unsigned long long d = wv[0];
       unsigned long long rbv = remv[b];
       unsigned long long rb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(rbv >> 32)) << 32) |
                               (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)rbv);
       const int lim = min(64, n - b * 64);
       if (lim < 64) rb |= ~0ull << lim;
-      unsigned long long K = 0ull;
       const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
-      while (~rb) {
-        const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)~rb) - 1);
-        K |= 1ull << i;
+      unsigned long long cand = __ballot(d != 0ull) & ~rb;   // rows that can change the block's state and are still alive
+      while (cand) {
+        const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
         const unsigned int lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
-        rb |= (((unsigned long long)hi << 32) | lo) | (1ull << i);
+        rb |= ((unsigned long long)hi << 32) | lo;           // (row i's word only has bits above i)
+        cand &= cand - 1ull;
+        cand &= ~rb;
       }
+      const unsigned long long K = ~rb;
       const bool mine = (K >> lane) & 1ull;
       if (mine) { const int pos = nk + __popcll(K & ((1ull << lane) - 1ull)); if (pos < max_keep) keep[pos] = row; }
-      // direct OR of columns b+1 (needed by the very next phase) and b+2
-      // (every kept lane ORs its own words: a few same-address LDS atomics cost less than a 64-lane shuffle reduction)
-      if (mine && b + 1 < cb) {
-        if (col1) atomicOr(&remv[b + 1], col1);
-        if (col2 && b + 2 < cb) atomicOr(&remv[b + 2], col2);
+      // direct OR of the next NDIR columns (every kept lane ORs its own words: a few same-address LDS atomics cost less than a
+      // 64-lane shuffle reduction)
+      if (mine) {
+#pragma unroll
+        for (int c = 1; c <= NDIR; ++c)
+          if (wv[c] && b + c < cb) atomicOr(&remv[b + c], wv[c]);
       }
       nk += __popcll(K);
       if (lane == 0) { kept_sh[b & 1] = K; nk_sh[b & 1] = nk; }
-    } else {
-      // (2) apply what was requested in the previous phase (block b-2 -> columns >= b+1)
+      // raw barrier: LDS traffic (atomics, kept_sh / nk_sh) is drained, but the global loads stay in flight across it
+      // (__syncthreads() would wait for vmcnt(0) and put their latency back in front of every phase)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (nk >= max_keep) break;
+    }
+    if (lane == 0) *num_out = min(nk, max_keep);
+    return;
+  }
+  // ---------------- bulk: wave w of group g = (w - 1) & 1 owns rows gi, gi + GN, ... of the blocks with (block & 1) == g; a lane owns
+  // columns c0 + lane + 64 k (k < CK).  A kept row is a wave-uniform condition and its words are read as contiguous 512-byte pieces
+  // (whole cache lines: the kernel moves megabytes of mask words through ONE compute unit's L1 path).  The rows of a block are
+  // OR-combined when they are applied, so a lane issues at most CK LDS atomics per block. ----------------
+  constexpr int RW = 10, CK = 3;
+  const int g = (wave - 1) & 1, gi = (wave - 1) >> 1, GN = g == 0 ? 8 : 7;
+  unsigned long long pv[RW][CK]; int pc0 = 0;
+#pragma unroll
+  for (int ri = 0; ri < RW; ++ri)
+#pragma unroll
+    for (int k = 0; k < CK; ++k) pv[ri][k] = 0ull;
+  for (int b = 0; b < cb; ++b) {
+    if (((b + 1) & 1) == g) {
+      // (2) apply what this group requested two phases ago (rows of block b - 3 -> columns >= b + 1)
 #pragma unroll
       for (int k = 0; k < CK; ++k) {
         unsigned long long a = 0ull;
@@ -217,14 +269,14 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
         for (int ri = 0; ri < RW; ++ri) { a |= pv[ri][k]; pv[ri][k] = 0ull; }
         if (a) atomicOr(&remv[pc0 + lane + 64 * k], a);
       }
-      // (1) request block b-1's kept rows for columns >= b+2
+      // (1) request block b-1's kept rows for columns >= b + NDIR
       if (b > 0) {
         const unsigned long long Kp = kept_sh[(b - 1) & 1];
-        const int c0 = b + 2;
+        const int c0 = b + NDIR;
         pc0 = c0;
 #pragma unroll
         for (int ri = 0; ri < RW; ++ri) {
-          const int r = (wave - 1) + 15 * ri;
+          const int r = gi + GN * ri;
           if (r < 64 && ((Kp >> r) & 1ull)) {                                   // wave-uniform
             const uint64_t* mr = mask + (long)((b - 1) * 64 + r) * cb;
 #pragma unroll
@@ -239,14 +291,11 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
         }
       }
     }
-    // raw barrier: LDS traffic (atomics, kept_sh / nk_sh) is drained, but the bulk waves' global loads stay in flight across
-    // it (__syncthreads() would wait for vmcnt(0) and put their latency back in front of every phase)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (nk_sh[b & 1] >= max_keep) break;
   }
-  if (tid == 0) *num_out = min(nk, max_keep);
 }
 __global__ void gather_rois_kernel(const float* sboxes, const float* sscores, const int* keep, const int* num, int max_keep, float* rois, float* rs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -872,24 +921,17 @@ extern "C" int l2s_rpn_decode(const float* heads, int ldh, const float* base_anc
   L2S_LAUNCH(rpn_decode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, heads, ldh, base_anchors, H, W, A, feat_stride, im_h, im_w, prob, boxes, scores);
   return l2s_check_launch();
 }
-extern "C" long l2s_sort_ws_ints(int n) { return 4L * n + 256L * cdiv(n, 256) + 64; }
+extern "C" long l2s_sort_ws_ints(int n) { return 4L * n + 4L * 256L * cdiv(n, 256) + 64; }
 extern "C" int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* ws, float* sorted_boxes,
                              float* sorted_scores, int* sorted_idx, hipStream_t s) {
   if (!ws || n <= 0 || k > n) return L2S_EINVAL;
   const int nblk = cdiv(n, 256);
-  const int scan_lds = (size_t)256 * nblk * 4 <= 150 * 1024;     // the counter scan is staged in LDS when it fits (n <= 38400)
-  static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)rs_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_done = true; }
   RsWs w = rs_ws(ws, n);
-  L2S_LAUNCH(rs_init_kernel, dim3(nblk), dim3(256), 0, s, scores, n, ws);
-  unsigned int* kin = w.kA; int* iin = w.iA; unsigned int* kout = w.kB; int* iout = w.iB;
-  for (int pass = 0; pass < 4; ++pass) {
-    L2S_LAUNCH(rs_hist_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, n, 8 * pass, nblk, w.hist);
-    L2S_LAUNCH(rs_scan_kernel, dim3(1), dim3(1024), scan_lds ? (size_t)256 * nblk * 4 : 0, s, w.hist, 256 * nblk, scan_lds);
-    L2S_LAUNCH(rs_scatter_kernel, dim3(nblk), dim3(256), 0, s, (const unsigned int*)kin, (const int*)iin, kout, iout, n, 8 * pass, nblk, (const int*)w.hist);
-    unsigned int* tk = kin; kin = kout; kout = tk; int* ti = iin; iin = iout; iout = ti;
-  }
-  L2S_LAUNCH(rs_gather_kernel, dim3(cdiv(k, 256)), dim3(256), 0, s, (const int*)iin, scores, boxes, k, sorted_boxes, sorted_scores, sorted_idx);
+  L2S_LAUNCH(rs_hist0_kernel, dim3(nblk), dim3(256), 0, s, scores, n, nblk, w.hist);
+  L2S_LAUNCH(rs_pass_kernel<0>, dim3(nblk), dim3(256), 0, s, scores, boxes, (const unsigned int*)nullptr, (const int*)nullptr, w.kA, w.iA, n, nblk, w.hist, k, sorted_boxes, sorted_scores, sorted_idx);
+  L2S_LAUNCH(rs_pass_kernel<1>, dim3(nblk), dim3(256), 0, s, scores, boxes, (const unsigned int*)w.kA, (const int*)w.iA, w.kB, w.iB, n, nblk, w.hist, k, sorted_boxes, sorted_scores, sorted_idx);
+  L2S_LAUNCH(rs_pass_kernel<2>, dim3(nblk), dim3(256), 0, s, scores, boxes, (const unsigned int*)w.kB, (const int*)w.iB, w.kA, w.iA, n, nblk, w.hist, k, sorted_boxes, sorted_scores, sorted_idx);
+  L2S_LAUNCH(rs_pass_kernel<3>, dim3(nblk), dim3(256), 0, s, scores, boxes, (const unsigned int*)w.kA, (const int*)w.iA, w.kB, w.iB, n, nblk, w.hist, k, sorted_boxes, sorted_scores, sorted_idx);
   return l2s_check_launch();
 }
 extern "C" size_t l2s_nms_workspace_bytes(int n) { return (size_t)n * (size_t)cdiv(n, 64) * 8; }
