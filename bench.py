@@ -42,11 +42,14 @@ def parse_args(argv=None):
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
-    ap.add_argument('--cpu-baseline-steps', default='1,2', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3 prescribes 3,10: ~3-5 min)')
+    ap.add_argument('--cpu-baseline-steps', default='3,10', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3: 3 + 10, ~2-3 min on the GPU box)')
     ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
     ap.add_argument('--main-prio', type=int, default=0, help='run the main queue on a high-priority HIP stream instead of the null stream')
     ap.add_argument('--force-dp', type=int, default=0, help='(testing) build the data-parallel reducer even for one rank')
+    ap.add_argument('--dp-wire', default='fp32', choices=['fp32', 'bf16'], help='gradient buckets on the wire: fp32 (282 MB / step) or packed to bf16 (141 MB)')
+    ap.add_argument('--dp-algo', default='allreduce', choices=['allreduce', 'rs_ag'], help='one all-reduce per bucket, or reduce-scatter + all-gather')
+    ap.add_argument('--mixed-shapes', type=int, default=1, help='extra leg: a stream of six different (image size, token count) shapes replayed from pre-recorded tapes')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
     ap.add_argument('--extras', type=int, default=1, help='0: only the headline timing (no synchronous / PCIe-inclusive / per-launch legs)')
@@ -116,15 +119,17 @@ def _baseline_metric():
         return 'train images/sec (cycle loss on), 600×1000 input, at 1/2/4/8 MI355X'
 
 
-def _pmc_traffic():
-    """PMC counters cannot be read inside the timed run; the committed measurement of the same launch is reported."""
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+def _pmc_traffic(which):
+    """PMC counters cannot be read inside the timed run; the committed same-round measurement of the same launch is reported
+    (tools/pmc_traffic.sh -> profiles/r03_pmc_traffic_<which>.json)."""
+    for name in ('r03_pmc_traffic_%s.json' % which,):
         f = os.path.join(ROOT, 'profiles', name)
         try:
-            return float(json.load(open(f))['traffic_bytes']), name
+            d = json.load(open(f))
+            return float(d['traffic_bytes']), float(d['algorithmic_bytes']), d.get('kernel'), name
         except Exception:
             continue
-    return None, None
+    return None, None, None, None
 
 
 class LaunchTimer(object):
@@ -135,6 +140,7 @@ class LaunchTimer(object):
         self.torch, self.on, self.recs = torch, False, []
         from lang2seg_amd import ops
         self.O = ops
+        self.plans = {}               # group -> kernel names the dispatcher chose (l2s_conv_plan_name)
         self.tape_pairs = []          # (id0, id1) timing events the launch tape records around the dominant launch in every replayed step
         for c in net.convs:
             self._wrap(c)
@@ -168,8 +174,10 @@ class LaunchTimer(object):
                 OH, OW = conv.out_hw(IH, IW)
                 flop = 2.0 * n * OH * OW * conv.Np * conv.k * conv.k * conv.Cin
                 e0 = T.cuda.Event(enable_timing=True); e1 = T.cuda.Event(enable_timing=True)
+                self.O.LAST_PLAN = None
                 e0.record(); r = _orig(x, n, IH, IW, *rest, **kw); e1.record()
                 self.recs.append((self._group(conv, n, IH, IW), _kind, conv.k, flop, e0, e1))
+                self.plans.setdefault('%s %s' % (self._group(conv, n, IH, IW), _kind), set()).add(self.O.LAST_PLAN or '?')
                 return r
             setattr(conv, kind, timed)
 
@@ -197,8 +205,8 @@ class LaunchTimer(object):
             g[0] += flop; g[1] += ms; g[2] += 1
             if k == 3:
                 s3[0] += flop; s3[1] += ms; s3[2] += 1
-        tab = {name: {'launches_per_step': v[2] / steps, 'ms_per_step': v[1] / steps, 'tflops': v[0] / (v[1] * 1e-3) / 1e12,
-                      'frac': v[0] / (v[1] * 1e-3) / PEAK_BF16} for name, v in groups.items() if v[1] > 0}
+        tab = {name: {'launches_per_step': v[2] / steps, 'ms_per_step': v[1] / steps, 'gflop_per_step': v[0] / steps / 1e9, 'tflops': v[0] / (v[1] * 1e-3) / 1e12,
+                      'frac': v[0] / (v[1] * 1e-3) / PEAK_BF16, 'kernels': sorted(self.plans.get(name, []))} for name, v in groups.items() if v[1] > 0}
         dom = max(tab, key=lambda n: tab[n]['ms_per_step']) if tab else None
         stack = None
         if s3[1] > 0:
@@ -280,7 +288,7 @@ def main(argv=None):
     experiment = bool(net.knockout) or bool(args.dp_skip_allreduce)
     if use_dp and args.dp_skip_allreduce != 3:
         from lang2seg_amd.parallel import GradReducer
-        net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce)
+        net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce, wire=args.dp_wire, algo=args.dp_algo, timing=True)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
     loader = SyntheticLoader(num_images=4, sents_per_image=1, H=args.height, W=args.width, T=T, vocab_size=V, rank=rank)
     blobs = [loader.getBatch('train') for _ in range(4)]
@@ -321,10 +329,14 @@ def main(argv=None):
             barrier()
             dom_ms += [lt.O.time_event_elapsed(a, b) for a, b in lt.tape_pairs]
     ranks_seen = 1
+    extras = {}
     if use_dp:
         c = torch.ones(1, device='cuda'); dist.all_reduce(c); ranks_seen = int(c.item())
         assert ranks_seen == world, (ranks_seen, world)
-    extras = {}
+        if getattr(net, 'dp', None) is not None:
+            rep = net.dp.report()                   # HIP events of the LAST timed step: per-bucket exchange time, and what the main stream waited for
+            if rep is not None:
+                extras['dp'] = rep
     if args.extras:
         # ---- the reference's unit as it stands: train_step() reads the losses back every step (NET:704-710: seven .data[0]) ----
         barrier()
@@ -347,6 +359,24 @@ def main(argv=None):
         dth = rank_max(time.time() - t0)
         extras['pcie_inclusive'] = {'ms_per_step': dth / args.steps * 1e3, 'value': world * args.steps / dth, 'unit': 'img/s',
                                     'h2d_bytes_per_step': int(hosts[0].numel() * 4), 'note': 'image blob re-uploaded from pinned host memory before every step'}
+        # ---- mixed shapes: six different (image size, token count) shapes, every tape recorded before the timed region ----
+        if args.mixed_shapes and world == 1 and args.height == 600 and args.width == 1000:
+            shapes = [(600, 800, 8), (600, 900, 12), (600, 1000, 20), (800, 600, 5), (600, 904, 9), (600, 800, 14)]
+            mb = []
+            for i, (h, w, t) in enumerate(shapes):
+                ld = SyntheticLoader(num_images=1, sents_per_image=1, H=h, W=w, T=t, vocab_size=V, seed=100 + i)
+                b = ld.getBatch('train'); net.upload_blob(b, 0); mb.append(b)
+            order = np.random.RandomState(0).randint(0, len(mb), 60)
+            for i in list(range(len(mb))) + list(order[:12]):
+                net.train_step_async(mb[i], 0, optim)
+            barrier()
+            t0 = time.time()
+            for i in order[12:]:
+                net.train_step_async(mb[i], 0, optim)
+            barrier()
+            dtm = time.time() - t0
+            extras['mixed_shapes'] = {'value': (len(order) - 12) / dtm, 'unit': 'img/s', 'ms_per_step': dtm / (len(order) - 12) * 1e3, 'shapes': shapes,
+                                      'note': 'a random stream of six (height, width, tokens) shapes replayed from their launch tapes; every shape was recorded before the timed region'}
         # ---- per-launch HIP events (eager steps: events cannot bracket launches inside a replayed tape) ----
         net.use_graph = False; net.use_tape = False
         net.train_step_async(blobs[0], 0, optim)
@@ -386,20 +416,35 @@ def main(argv=None):
             kms_eager = float(np.mean([e0.elapsed_time(e1) for _, _, _, _, e0, e1 in dk])) if dk else float('nan')
             kms = float(np.mean(dom_ms)) if dom_ms else kms_eager
             ach = kflop / (kms * 1e-3) / 1e12
-            traffic, tfile = _pmc_traffic()
-            out['roofline'] = {
-                'bound': 'mfma', 'kernel': 'igemm_sp_kernel<bf16,224,128> on layer4@RoIs conv3x3 forward (M=%d,N=512,K=4608)' % (R * 49),
-                'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': traffic,
-                'traffic_note': 'HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch (tools/pmc_traffic.sh -> '
-                                'profiles/%s; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes 30.4 MB' % tfile,
-                'avg_launch_ms': kms, 'launches_timed': len(dom_ms) if dom_ms else len(dk),
+            bt, balg, bkern, bfile = _pmc_traffic('best')
+            dt_, dalg, dkern, dfile = _pmc_traffic('dominant')
+            tnote = ('HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of one launch of this kernel '
+                     '(tools/pmc_traffic.sh -> profiles/%s; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes %s')
+            best = {
+                'kernel': 'igemm_dma_kernel<256,128> on layer4@RoIs conv3x3 forward (M=%d,N=512,K=4608)' % (R * 49),
+                'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': bt,
+                'traffic_note': tnote % (bfile, balg),
+                'avg_launch_ms': kms, 'launches_timed': len(dom_ms) if dom_ms else len(dk), 'gflop_per_launch': kflop / 1e9,
                 'timing': ('HIP events recorded by the launch tape on the main stream right before and after the launch, inside the pipelined '
                            'replayed steps (last step of the timed region + 4 later steps)') if dom_ms else 'HIP events around the launch in eager steps',
                 'eager_avg_launch_ms': kms_eager,
-                'stack3x3': stack,
-                'time_dominant': dict(tab[dom], group=dom, note='the group of convolution launches with the largest summed time per step') if dom else None,
-                'groups': tab,
             }
+            # `roofline` describes the TIME-DOMINANT group of launches (the largest summed time per step), `roofline.best` the best kernel
+            if dom:
+                g = tab[dom]
+                per_launch_ms = g['ms_per_step'] / g['launches_per_step']
+                out['roofline'] = {
+                    'bound': 'mfma', 'kernel': '%s: %d launches per step of %s' % (dom, round(g['launches_per_step']), ' / '.join(g['kernels'])),
+                    'achieved': g['tflops'], 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': g['frac'],
+                    'launches_per_step': g['launches_per_step'], 'ms_per_step': g['ms_per_step'], 'gflop_per_step': g['gflop_per_step'],
+                    'avg_launch_ms': per_launch_ms, 'traffic': dt_,
+                    'traffic_note': (tnote % (dfile, dalg)) + '; measured on the group\'s 3x3 launch (%s)' % dkern,
+                    'timing': 'summed algorithmic FLOPs / summed HIP-event time of the group\'s launches, events recorded on the stream each launch goes to, '
+                              '%d eager multi-stream steps after the timed region (events cannot bracket launches inside a replayed tape without perturbing it)' % NE,
+                    'best': best, 'stack3x3': stack, 'groups': tab,
+                }
+            else:
+                out['roofline'] = dict(best, bound='mfma', best=best, stack3x3=stack, groups=tab)
         else:
             out['roofline'] = None
         if world == 1 and not args.no_cpu_baseline:

@@ -39,7 +39,9 @@ int l2s_version(void);
 #define L2S_ALGO_AUTO 0
 #define L2S_ALGO_STAGED 1      /* register-staged tiles (ring / wave-specialised / software-pipelined kernels) */
 #define L2S_ALGO_DMA 2         /* 256x128 tile, LDS-DMA fill (buffer_load ... lds), two wave groups alternating load / multiply */
+#define L2S_ALGO_DMA_STAMPED 4 /* the same kernel with in-kernel clock stamps written to `ws` (tools/dma_stamps.py) */
 #define L2S_ALGO_KSPLIT 5      /* 64x64 tile, LDS-DMA fill by four requester waves, four multiplier waves splitting each slice's K */
+#define L2S_ALGO_KSPLIT_D3 6   /* the same with a ring of three LDS stages instead of four */
 typedef struct {
   const void* x;      /* [n_img, IH, IW, ldx] activations (dtype) */
   const void* w;      /* [Cout][KH*KW*Cin] (dtype) */
@@ -51,16 +53,15 @@ typedef struct {
   int ldx, ldy, ldadd, ldref;
   int flags;
   int out_h, out_w, out_stride; /* SCATTER */
-  int tile;                     /* 0 = auto, 64 or 128 */
+  int tile;                     /* 0 = auto, 64, 128, 224 or 256 (rows of the workgroup tile) */
   int split_k;                  /* 0 = auto, 1 = off, n = force (needs ws) */
   int xcd_mode;                 /* tile order over the 8 XCDs: -1 = auto, 0 = M-chunks, 1 = N-chunks (speed only) */
   int algo;                     /* kernel family: 0 = auto; L2S_ALGO_* forces one (benchmarks / tests; same arithmetic, speed only) */
   float* ws;                    /* optional ALL-ZERO float workspace >= rows*Cout for split-K partial sums; returned all-zero */
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);
-/* Direct 3x3 / stride 1 / pad 1 convolution with an LDS-staged input patch shared by the nine taps (csrc/conv3x3_patch.hip), for
- * single-image feature maps; l2s_conv_igemm tries it first.  Returns 1 = launched, 0 = problem not eligible (nothing done), < 0 = -error. */
-int l2s_conv3x3_patch_try(const l2s_conv_desc* d, int dtype, hipStream_t stream);
+/* name of the kernel l2s_conv_igemm launches for this problem (reporting: bench.py's roofline object); static storage */
+const char* l2s_conv_plan_name(const l2s_conv_desc* d, int dtype);
 
 /* weight gradient: dw[Cout][KH*KW*Cin] (float) += sum_pixels dy[p][co] * x(p,tap)[ci]
  * (cuDNN backward-filter behind autograd in the reference: resnet_v1_cycle_res5_2.py:83-88,324-335, network_cycle_res5_2.py:236-251,279-301).
@@ -388,6 +389,7 @@ long l2s_tape_size(void* tape);
 int l2s_tape_run(void* tape, const hipStream_t* streams, int n);
 /* segments: l2s_tape_mark() (while recording) cuts the tape where the host must act between launches (RCCL all-reduce of a finished
  * gradient bucket); l2s_tape_run_segment replays segment `seg` in [0, l2s_tape_segments) */
+int l2s_tape_pause(int on);   /* 1: launches execute but are not recorded until l2s_tape_pause(0) (host work between two segments) */
 int l2s_tape_mark(void);
 /* measurement: "record a timing event here" as a tape op (id >= 0 while recording, -1 otherwise); elapsed HIP-event time between two such
    points of the last replayed step (bench.py brackets the dominant launch inside the pipelined replay with these) */

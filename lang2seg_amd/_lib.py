@@ -57,8 +57,8 @@ LOSS_RPN_CLS, LOSS_RPN_BOX, LOSS_CLS, LOSS_BOX, LOSS_MASK, LOSS_CAP, LOSS_TOTAL,
 # name -> (restype, argtypes); the stream is always the last argument
 SIGS = {
     'l2s_version': (i32, []),
+    'l2s_conv_plan_name': (C.c_char_p, [vp, i32]),
     'l2s_conv_igemm': (i32, [C.POINTER(ConvDesc), i32, vp]),
-    'l2s_conv3x3_patch_try': (i32, [C.POINTER(ConvDesc), i32, vp]),
     'l2s_conv_wgrad': (i32, [C.POINTER(WgradDesc), i32, vp]),
     'l2s_wgrad_ws_bytes': (sz, [C.POINTER(WgradDesc), i32]),
     'l2s_wgrad_variant': (i32, [i32, i32, i32, i32, i32, i32, i32, i64, i32]),
@@ -158,6 +158,7 @@ SIGS = {
     'l2s_tape_run': (i32, [vp, vp, i32]),
     'l2s_tape_destroy': (i32, [vp]),
     'l2s_tape_mark': (i32, []),
+    'l2s_tape_pause': (i32, [i32]),
     'l2s_tape_time_event': (i32, [vp]),
     'l2s_time_event_elapsed': (i32, [i32, i32, vp]),
     'l2s_tape_segments': (i32, [vp]),

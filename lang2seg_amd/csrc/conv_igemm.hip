@@ -50,8 +50,8 @@ constexpr int LROW = ROWB + 16;  // padded LDS row
 // per sub-tile ----
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-template <typename T, int TM, int TN, int WM, int WN, bool OUTF32, int KS>
-__device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, int grp) {
+template <typename T, int TM, int TN, int WM, int WN, bool OUTF32>
+__device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M) {
   constexpr unsigned NOPE = 0x80000000u;
   constexpr int ES = (int)sizeof(T), OS = (OUTF32 || sizeof(T) == 4) ? 4 : 2;
   const int ohw = p.OH * p.OW;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x
         r2 = (n_img * 2 * p.OH + 2 * oy + (tap >> 1)) * (2 * p.OW) + 2 * ox + (tap & 1);
       }
       orow[i][j] = r2; ocol[i][j] = oc;
-      ok[i][j] = (m < M) && (n < p.Cout) && (KS == 1 || ((i * TN + j) % KS) == grp);
+      ok[i][j] = (m < M) && (n < p.Cout);
     }
   }
   f32x4 bv[TN];
@@ -247,8 +247,8 @@ __device__ __forceinline__ void igemm_epilogue_prefetch(const l2s_conv_desc& p, 
 }
 
 // ---- shared epilogue: lane owns pixel (lane&15) x 4 consecutive channels ((lane>>4)*4 + r) of each 16x16 accumulator tile ----
-template <typename T, int TM, int TN, int WM, int WN, bool OUTF32, int KS = 1>
-__device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, int grp = 0) {
+template <typename T, int TM, int TN, int WM, int WN, bool OUTF32>
+__device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M) {
   const int ohw = p.OH * p.OW;
   const int Cq = (p.flags & L2S_CONV_DECONV2X2) ? (p.Cout >> 2) : p.Cout;
   const bool vec_ok = ((p.ldy & 3) == 0) && ((p.ldadd & 3) == 0) && ((p.ldref & 3) == 0) && ((Cq & 3) == 0);
@@ -256,7 +256,7 @@ __device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&a
     const long orows = (p.flags & L2S_CONV_SCATTER) ? (long)p.n_img * p.out_h * p.out_w : ((p.flags & L2S_CONV_DECONV2X2) ? 4L * M : (long)M);
     const long lim = 1L << 31;
     const bool small = orows * p.ldy * 4 < lim && (!p.add || orows * p.ldadd * 4 < lim) && (!p.ref || orows * p.ldref * 4 < lim);
-    if (vec_ok && small) { igemm_epilogue_fast<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp); return; }
+    if (vec_ok && small) { igemm_epilogue_fast<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M); return; }
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -270,7 +270,6 @@ __device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&a
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if (KS > 1 && ((i * TN + j) % KS) != grp) continue;   // in-workgroup split-K: K-group grp finishes these sub-tiles
       const int n = n0 + wn * WN + j * 16 + fg * 4;
       if (n >= p.Cout) continue;
       int oc = n; long orow2 = orow;
@@ -498,30 +497,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
 #define L2S_RING64_MINWG 3
 #endif
 constexpr unsigned OOR = 0x80000000u;
-constexpr int RING_EARLY_READ = 1 << 27; // internal: ring kernel reads a slice's fragments before filling the next slice
-constexpr int EPI_LDS_FLAG = 1 << 29;   // internal: LDS-staged epilogue selected by the launcher (reuses the tile's LDS)
-constexpr int EPI_LDS_FLAG64 = 1 << 28; // the same for the 64x64 tile (separate switch: its launches are latency-bound)
 
-template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS, int RB = 128>
-__global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM * WGN * KS == 4) ? 2 : ((BM * BN <= 64 * 64 && KS == 1 && D == 2 && L2S_RING64_MINWG > 1) ? L2S_RING64_MINWG : 1)) void igemm_ring_kernel(const l2s_conv_desc p) {
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32>
+__global__ __launch_bounds__(64 * WGM * WGN, (BM * BN >= 128 * 128 && WGM * WGN == 4) ? 2 : ((BM * BN <= 64 * 64 && D == 2 && L2S_RING64_MINWG > 1) ? L2S_RING64_MINWG : 1)) void igemm_ring_kernel(const l2s_conv_desc p) {
   constexpr int VE = 16 / (int)sizeof(T);
-  // RB = bytes of K per LDS row per slice: 128 (64 bf16) or 256.  A wave of the 64x64 tile has only 8 MFMAs per 128-byte slice, and
-  // the LDS write -> barrier -> fragment read round trip (~600 cycles, measured: MFMA busy 13 % of the wave's cycles) is paid per slice:
-  // 256-byte rows halve the barriers per K.
+  constexpr int RB = ROWB;                      // bytes of K per LDS row per slice
   constexpr int BK = RB / (int)sizeof(T);
   constexpr int CPR = RB / 16;                  // 16-byte chunks (= loader threads) per row
-  constexpr int NTG = 64 * WGM * WGN;           // threads of one K-group: WGM x WGN waves, wave tile WM x WN
+  constexpr int NTG = 64 * WGM * WGN;           // WGM x WGN waves, wave tile WM x WN
   constexpr int LR = NTG / CPR;                 // rows covered by one loader pass
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int NA = BM / LR, NB = BN / LR;
   constexpr int BUF = (BM + BN) * RB;
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
-  // KS > 1: in-workgroup split-K.  The workgroup holds KS K-groups of 4 waves; group g runs the loop below over slices
-  // [g KT/KS, (g+1) KT/KS) (KT % KS == 0, so every group executes the same barriers) in its own LDS double buffer, then
-  // the partial accumulators are exchanged through LDS and each group finishes 1/KS of the 16x16 sub-tiles.
-  const int grp = KS > 1 ? (int)(threadIdx.x / NTG) : 0;
-  const int tid = KS > 1 ? (int)(threadIdx.x % NTG) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int M = p.n_img * p.OH * p.OW;
   const int K = p.KH * p.KW * p.Cin;
@@ -533,7 +523,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
     if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
   }
   const int m0 = mt * BM, n0 = nt * BN;
-  char* smem = smem_all + grp * (2 * BUF);
+  char* smem = smem_all;
   const long xpix = (long)p.n_img * p.IH * p.IW;
   const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(((xpix - 1) * p.ldx + p.Cin) * (long)sizeof(T)), 0x00020000);
   const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * K * (long)sizeof(T)), 0x00020000);
@@ -560,10 +550,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
     voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + cv * VE) * (long)sizeof(T)) : OOR;
   }
   // issue-side state (uniform): slice index, tap, channel offset inside the tap
-  const int KT = K / BK / KS;                   // slices of this K-group
+  const int KT = K / BK;
   const int taps = p.KH * p.KW;
-  int it = grp * KT, c0 = it * BK, tap = 0;
-  if (KS > 1 && taps > 1) { tap = c0 / p.Cin; c0 -= tap * p.Cin; }
+  int it = 0, c0 = 0, tap = 0;
   unsigned voffA[NA];
   auto set_tap = [&](int t) {
     const int ky = t / p.KW, kx = t - ky * p.KW;
@@ -649,7 +638,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(frb[kg][j], fra[kg][i], acc[i][j]);
   };
-  const bool early = BM * BN <= 64 * 64 && KS == 1 && (p.flags & RING_EARLY_READ) != 0;   // (the 128x128 tile has no registers to spare)
+  constexpr bool early = BM * BN <= 64 * 64;    // (the 128x128 tile has no registers to spare)
   // steady state: every iteration stores slice t+1 and issues slice t+1+D, no conditions (so the compiler's vmcnt is the
   // exact count of the D-1 younger sets); unrolled by D so that the ring set index is a compile-time constant.
   int t0 = 0;
@@ -694,42 +683,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS, (BM * BN >= 128 * 128 && WGM *
       if (early) mma_all(); else compute(t);
     }
   }
-  if (KS > 1) {
-    // exchange: slot [(owner group)][(source group)][sub-tile rank][thread] float4; a group keeps the sub-tiles it owns
-    __syncthreads();
-    constexpr int NSUB = TM * TN, PER = (NSUB + KS - 1) / KS;
-    float4* xch = (float4*)smem_all;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int sub = i * TN + j, owner = sub % KS;
-        if (owner != grp) xch[((owner * KS + grp) * PER + sub / KS) * NTG + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int sub = i * TN + j;
-        if (sub % KS == grp) {
-#pragma unroll
-          for (int g = 0; g < KS; ++g)
-            if (g != grp) {
-              const float4 v = xch[((grp * KS + g) * PER + sub / KS) * NTG + tid];
-              acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
-            }
-        }
-      }
-  }
-  if constexpr (sizeof(T) == 2 && !OUTF32 && KS == 1 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) && WGM == 2 && WGN == 2) {
+  if constexpr (sizeof(T) == 2 && !OUTF32 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) && WGM == 2 && WGN == 2) {
     // whole-row 16-byte accesses through an LDS-staged fp32 tile when every row pitch allows it
     const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                        !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                        (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-    if (plain && (p.flags & (BM == 64 ? EPI_LDS_FLAG64 : EPI_LDS_FLAG))) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG, BN, (BM == 128 ? 2 : 1)>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
+    if (plain) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG, BN, (BM == 128 ? 2 : 1)>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all); return; }
   }
-  igemm_epilogue<T, TM, TN, WM, WN, OUTF32, KS>(p, acc, m0, n0, wm, wn, fr, fg, M, grp);
+  igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -858,7 +819,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
   const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                      !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                      (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-  const bool staged = plain && (p.flags & EPI_LDS_FLAG64);
+  const bool staged = plain;
   // residual / ReLU-mask operands of the LDS-staged epilogue, requested before the K loop (these waves issue no other global load)
   constexpr int EIT = (BM * (BN / 8) + 255) / 256;
   u32x4v eav[EIT], erv[EIT];
@@ -903,7 +864,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
   if (t < KT) { __syncthreads(); read_all(t, fa1, fb1); mma_all(fa0, fb0); mma_all(fa1, fb1); }
   else mma_all(fa0, fb0);
   if (staged) { igemm_epilogue_lds128<TM, TN, WM, WN, 2, 256, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all, pre ? eav : nullptr, pre ? erv : nullptr); return; }
-  igemm_epilogue<T, TM, TN, WM, WN, false, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, 0);
+  igemm_epilogue<T, TM, TN, WM, WN, false>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1107,131 +1068,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_sp_kernel(const l2s_conv
     const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                        !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                        (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem); return; }
-  }
-  igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pipelined variant: operands go HBM -> LDS directly (global_load_lds_dwordx4, no register staging) into a ring of
-// STAGES slices; each iteration waits (counted vmcnt) only for the oldest slice, so STAGES-1 slices of loads stay in
-// flight across the single per-slice barrier.  LDS rows are unpadded 128-byte rows (an LDS-DMA wave instruction writes
-// 1 KiB = 8 rows linearly), made bank-conflict-free by XOR-swizzling the 16-byte chunk index with (row & 7) on the
-// per-lane SOURCE address and on the fragment reads.  Out-of-image / out-of-range rows read a zero page.
-// The LDS-DMA is issued from inline asm so that hipcc's waitcnt pass does not drain it before every ds_read.
-// ------------------------------------------------------------------------------------------------
-__device__ uint4 l2s_zero_page[8];
-
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <typename T, int BM, int BN, int STAGES, bool OUTF32>
-__global__ __launch_bounds__(256) void igemm_pipe_kernel(const l2s_conv_desc p) {
-  constexpr int VE = 16 / (int)sizeof(T);
-  constexpr int BK = ROWB / (int)sizeof(T);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int NA = BM / 32, NB = BN / 32;        // LDS-DMA instructions per wave per slice (A, B)
-  constexpr int IPS = NA + NB;
-  constexpr int BUF = (BM + BN) * ROWB;
-  static_assert((STAGES - 2) * IPS <= 63, "vmcnt range");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int M = p.n_img * p.OH * p.OW;
-  const int K = p.KH * p.KW * p.Cin;
-  const T* __restrict__ X = (const T*)p.x;
-  const T* __restrict__ Wt = (const T*)p.w;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const char* zp = (const char*)l2s_zero_page + (lane & 7) * 16;
-
-  // lane -> (row inside an 8-row DMA piece, physical 16-byte chunk); source chunk = phys ^ (row & 7)
-  const int prow = lane >> 3, pch = lane & 7, sch = pch ^ prow;
-  int a_iy0[NA], a_ix0[NA]; long a_base[NA]; bool a_ok[NA];
-  const int ohw = p.OH * p.OW;
-#pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    const int m = m0 + 8 * (wave + 4 * j) + prow;
-    a_ok[j] = m < M;
-    const int mm = a_ok[j] ? m : 0;
-    const int n_img = mm / ohw, rem = mm - n_img * ohw;
-    const int oy = rem / p.OW, ox = rem - oy * p.OW;
-    a_iy0[j] = oy * p.stride - p.pad;
-    a_ix0[j] = ox * p.stride - p.pad;
-    a_base[j] = (long)n_img * p.IH * p.IW;
-  }
-  long b_off[NB]; bool b_ok[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int n = n0 + 8 * (wave + 4 * j) + prow;
-    b_ok[j] = n < p.Cout;
-    b_off[j] = (long)(b_ok[j] ? n : 0) * K;
-  }
-  auto issue_slice = [&](int kt, int buf) {
-    const int k0 = kt * BK;
-    int tap = 0, c0 = k0;
-    if (p.KH * p.KW > 1) { tap = k0 / p.Cin; c0 = k0 - tap * p.Cin; }
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    const bool kin = (k0 + sch * VE) < K;
-    const unsigned abase = lds0 + buf * BUF, bbase = abase + BM * ROWB;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-      const bool ok = a_ok[j] && kin && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-      const void* src = ok ? (const void*)(X + ((a_base[j] + (long)iy * p.IW + ix) * p.ldx + c0 + sch * VE)) : (const void*)zp;
-      glds16(src, abase + 8 * (wave + 4 * j) * ROWB);
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const void* src = (b_ok[j] && kin) ? (const void*)(Wt + b_off[j] + k0 + sch * VE) : (const void*)zp;
-      glds16(src, bbase + 8 * (wave + 4 * j) * ROWB);
-    }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int KT = (K + BK - 1) / BK;
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < KT) issue_slice(s, s);
-  const int fr = lane & 15, fg = lane >> 4;
-  const int swz = fr & 7;
-  const int offa = (wm * WM + fr) * ROWB, offb = BM * ROWB + (wn * WN + fr) * ROWB;
-  for (int kt = 0; kt < KT; ++kt) {
-    // slices kt .. min(KT, kt+STAGES-1)-1 are in flight; wait until only the younger ones remain
-    const int younger = min(KT, kt + STAGES - 1) - kt - 1;
-    if (younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * IPS>();
-    else if (STAGES > 3 && younger == STAGES - 3) wait_vmcnt<(STAGES > 3 ? STAGES - 3 : 0) * IPS>();
-    else if (STAGES > 4 && younger == STAGES - 4) wait_vmcnt<(STAGES > 4 ? STAGES - 4 : 0) * IPS>();
-    else if (younger >= 1) wait_vmcnt<IPS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + STAGES - 1 < KT) issue_slice(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
-    const char* base = smem + (kt % STAGES) * BUF;
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      const int ch = ((kg * 4 + fg) ^ swz) << 4;
-      uint4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * ROWB + ch);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * ROWB + ch);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
-    }
+    if (plain) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, NTG, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem); return; }
   }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
@@ -1445,7 +1282,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
     const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                        !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                        (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-    if (plain && (p.flags & EPI_LDS_FLAG)) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, 512, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem); return; }
+    if (plain) { igemm_epilogue_lds128<TM, TN, WM, WN, WGM, 512, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem); return; }
   }
   igemm_epilogue<T, TM, TN, WM, WN, false>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
@@ -1701,14 +1538,14 @@ int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32, int KS = 1, int RB = 128>
+template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32>
 int launch_igemm_ring(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN));
-  size_t lds = (size_t)KS * 2 * (BM + BN) * RB;
+  size_t lds = (size_t)2 * (BM + BN) * ROWB;
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  L2S_LAUNCH((igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32, KS, RB>), grid, dim3(64 * WGM * WGN * KS), lds, st, d);
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_ring_kernel<T, BM, BN, WGM, WGN, D, OUTF32>), grid, dim3(64 * WGM * WGN), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -1754,166 +1591,105 @@ int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <typename T, int BM, int BN, int STAGES, bool OUTF32>
-int launch_igemm_pipe(const l2s_conv_desc& d, hipStream_t st) {
-  const int M = d.n_img * d.OH * d.OW;
-  dim3 grid(cdiv(M, BM), cdiv(d.Cout, BN));
-  size_t lds = (size_t)STAGES * (BM + BN) * ROWB;
-  static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  L2S_LAUNCH((igemm_pipe_kernel<T, BM, BN, STAGES, OUTF32>), grid, dim3(256), lds, st, d);
-  return l2s_check_launch();
-}
-
 }  // namespace
 
-extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream) {
-  if (!d || !d->x || !d->w || !d->y) return L2S_EINVAL;
-  const int ve = dtype == L2S_BF16 ? 8 : 4;
-  const int K = d->KH * d->KW * d->Cin;
-  if (d->ldx % ve || K % ve || (d->KH * d->KW > 1 && d->Cin % (dtype == L2S_BF16 ? 64 : 32))) return L2S_EINVAL;
-  if ((d->flags & L2S_CONV_DECONV2X2) && (d->Cout % 16)) return L2S_EINVAL;
+// ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
+enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,
+                PLAN_DMA256, PLAN_DMA256_STAMPED };
+static const char* const PLAN_NAMES[] = {"invalid", "igemm_kernel<64,64>", "igemm_kernel<128,128>", "igemm_ring_kernel<64,64>", "igemm_ring_kernel<128,128>",
+                                         "igemm_ws64_kernel", "igemm_ks64_kernel<4>", "igemm_ks64_kernel<3>", "igemm_sp_kernel<224,128>", "igemm_sp_kernel<256,128>",
+                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>"};
+static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
+  if (!d || !d->x || !d->w || !d->y || (dtype != L2S_BF16 && dtype != L2S_F32)) return PLAN_EINVAL;
+  const bool bf = dtype == L2S_BF16;
+  const int ve = bf ? 8 : 4, bk = bf ? 64 : 32;
+  const long esz = bf ? 2 : 4;
+  const int K = d->KH * d->KW * d->Cin, ntaps = d->KH * d->KW;
+  if (d->ldx % ve || K % ve || (ntaps > 1 && d->Cin % bk)) return PLAN_EINVAL;
+  if ((d->flags & L2S_CONV_DECONV2X2) && (d->Cout % 16)) return PLAN_EINVAL;
   const long M = (long)d->n_img * d->OH * d->OW;
-  if (M >= (1 << 24)) return L2S_EINVAL;
-  {
-    // 3x3 / stride 1 on a feature map: the patch kernel (one staged input patch for all nine taps) when the problem is eligible
-    static const int patch_on = [] { const char* e = getenv("L2S_CONV3X3_PATCH"); return e ? atoi(e) : 0; }();   // measured slower in the step: off
-    const int r = patch_on ? l2s_conv3x3_patch_try(d, dtype, stream) : 0;
-    if (r == 1) return L2S_OK;
-    if (r < 0) return -r;
-  }
+  if (M >= (1 << 24)) return PLAN_EINVAL;
   const bool f32o = d->flags & L2S_CONV_OUT_F32;
-  // tile choice: prefer 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64
+  // tile: 128x128 when it fills the chip (>= ~1 workgroup per CU), else 64x64; the large tiles (one workgroup per CU) when their grid is one
+  // round over most of the 256 CUs and the K loop is long enough to pay for the prologue (the layer4@RoIs shapes)
   const long t128 = (long)cdiv(M, 128) * cdiv(d->Cout, 128);
   int tile = d->tile ? d->tile : ((t128 >= 200 && d->Cout >= 96) ? 128 : 64);
-  // 256x128 (8 waves, software pipelined, one workgroup per CU) when its grid is one round over most of the 256 CUs and
-  // the K loop is long enough to pay for the prologue; measured on the layer4@RoIs shapes (profiles/r01_conv_bench.txt)
   if (!d->tile) {
     const long t256 = (long)cdiv(M, 256) * cdiv(d->Cout, 128);
-    if (t256 >= 160 && t256 <= 256 && K >= 1024) {
-      tile = 256;
-      // one round either way: the 224-row tile puts 224 instead of 196 workgroups on the 256 CUs (12 % less work per CU)
-      static const int t224 = [] { const char* e = getenv("L2S_IGEMM_T224"); return e ? atoi(e) : 1; }();
-      if (t224 && (long)cdiv(M, 224) * cdiv(d->Cout, 128) <= 256) tile = 224;
-    }
+    if (t256 >= 160 && t256 <= 256 && K >= 1024) tile = ((long)cdiv(M, 224) * cdiv(d->Cout, 128) <= 256) ? 224 : 256;   // 224 rows: 224 instead of 196 workgroups
   }
+  const long xb = (long)d->n_img * d->IH * d->IW * d->ldx * esz, wb = (long)d->Cout * K * esz;
+  const bool split_req = d->ws && d->split_k > 1;
+  // buffer-descriptor kernels: whole 128-byte K slices per tap and 31-bit operand extents
+  const bool desc_ok = (d->Cin % bk == 0) && xb < (1L << 31) && wb < (1L << 31) && !split_req;
+  if (tapin_out) *tapin_out = ntaps > 1 && ntaps <= 32 && xb < (1L << 30);     // K walked channel-chunk-major, taps innermost
+  const int algo = d->algo;
+  if (desc_ok) {
+    const int KT = K / bk;
+    const long tiles64 = (long)cdiv(M, 64) * cdiv(d->Cout, 64);
+    // LDS-DMA 256x128 tile: wherever the large register-staged tiles were chosen, measured 59 vs 74 us on the dominant 3x3 and equal or
+    // better on the 1x1 shapes (tools/dma_bench.py)
+    const bool dma_ok = bf && !f32o && KT >= 3 && d->KH <= 3 && d->KW <= 3;
+    if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
+    if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;
+    // K-split 64x64 tile with LDS-DMA fill: whole 128-channel pieces per tap.  Chosen for the 3x3 launches whose 64x64 tiles fit one round
+    // of workgroups and that carry no ReLU-mask operand, i.e. forward launches: 13.8 -> 11.2 us (layer3), 61.6 -> 52.9 us (RPN); the 1x1
+    // launches gain nothing (their K loop is a few slices), multi-round grids lose (one workgroup per CU), and in the backward pass its
+    // 128 KiB of LDS per workgroup cannot start beside the weight-gradient workgroups (step 171.9 vs 174.8 img/s)
+    const bool ks_ok = bf && !f32o && d->Cin % 128 == 0 && d->KH <= 3 && d->KW <= 3 && M * d->Cout * 4 < (1L << 31);
+    if (ks_ok && algo == L2S_ALGO_KSPLIT) return PLAN_KS64;
+    if (ks_ok && algo == L2S_ALGO_KSPLIT_D3) return PLAN_KS64_D3;
+    if (ks_ok && algo == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && tiles64 <= 256 && K >= 1024) return PLAN_KS64;
+    if (tile == 224) return PLAN_SP224;
+    if (tile == 256) return PLAN_SP256;
+    if (tile == 128) return PLAN_RING128;
+    if (bf && !f32o) return PLAN_WS64;          // wave-specialised 8-wave form (loaders + multipliers), bf16 output
+    return PLAN_RING64;
+  }
+  if (tile >= 128) return PLAN_GENERIC128;       // K tails, >= 2 GiB operands, split-K with a workspace: the register-staged generic kernel
+  return PLAN_GENERIC64;
+}
+extern "C" const char* l2s_conv_plan_name(const l2s_conv_desc* d, int dtype) { return PLAN_NAMES[conv_plan(d, dtype, nullptr)]; }
+
+extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream) {
+  bool tapin = false;
+  const ConvPlan plan = conv_plan(d, dtype, &tapin);
+  if (plan == PLAN_EINVAL) return L2S_EINVAL;
+  const bool f32o = d->flags & L2S_CONV_OUT_F32;
   // working-set heuristic for the XCD tile order: per-XCD chunk along M keeps all of W + 1/8 of A in L2; if that does not
   // fit (~3 MiB), chunk along N instead (one W column block resident, A streamed)
   l2s_conv_desc dd = *d;
   if (dd.xcd_mode < 0 || dd.xcd_mode > 1) {
     const double esz = dtype == L2S_BF16 ? 2.0 : 4.0;
+    const int K = d->KH * d->KW * d->Cin;
     const double wbytes = (double)d->Cout * K * esz, abytes = (double)d->n_img * d->IH * d->IW * d->Cin * esz;
     dd.xcd_mode = (wbytes + abytes / 8.0 <= 3.0 * 1024 * 1024) ? 0 : 1;
   }
-  static const int epi_lds = [] { const char* e = getenv("L2S_IGEMM_EPI_LDS"); return e ? atoi(e) : 1; }();
-  if (epi_lds) dd.flags |= EPI_LDS_FLAG;
-  static const int early_rd = [] { const char* e = getenv("L2S_IGEMM_EARLY_READ"); return e ? atoi(e) : 1; }();
-  if (early_rd) dd.flags |= RING_EARLY_READ;
-  static const int epi_lds64 = [] { const char* e = getenv("L2S_IGEMM_EPI_LDS64"); return e ? atoi(e) : 1; }();
-  if (epi_lds64) dd.flags |= EPI_LDS_FLAG64;
-  d = &dd;
-  // ring kernel (default): needs whole 128-byte K slices per tap and 31-bit operand extents
-  static const int ring_d = [] { const char* e = getenv("L2S_IGEMM_RING"); return e ? atoi(e) : -1; }();   // 0 = off
-  static const int sp_on = [] { const char* e = getenv("L2S_IGEMM_SP"); return e ? atoi(e) : 1; }();          // 256x128 tile: software-pipelined kernel (1) or plain ring (0)
-  static const int ring_ks = [] { const char* e = getenv("L2S_IGEMM_KS"); return e ? atoi(e) : 0; }();     // 0 = auto, 1 = off, 2/4 = forced
-  {
-    const int bk = dtype == L2S_BF16 ? 64 : 32;
-    const long esz = dtype == L2S_BF16 ? 2 : 4;
-    const long xb = (long)d->n_img * d->IH * d->IW * d->ldx * esz, wb = (long)d->Cout * K * esz;
-    const bool ok = ring_d != 0 && (d->Cin % bk == 0) && xb < (1L << 31) && wb < (1L << 31) && !(d->ws && d->split_k > 1 && d->algo < 2);
-    if (ok) {
-#define GR(T, BM, BN, DD, KS) (f32o ? launch_igemm_ring<T, BM, BN, 2, 2, DD, true, KS>(*d, stream) : launch_igemm_ring<T, BM, BN, 2, 2, DD, false, KS>(*d, stream))
-#define GR8(T, BM, BN, DD) (f32o ? launch_igemm_ring<T, BM, BN, 4, 2, DD, true, 1>(*d, stream) : launch_igemm_ring<T, BM, BN, 4, 2, DD, false, 1>(*d, stream))
-#define GSP7(T, DD) (tapin ? (f32o ? launch_igemm_sp<T, 224, 128, 2, 4, DD, true, true>(*d, stream) : launch_igemm_sp<T, 224, 128, 2, 4, DD, false, true>(*d, stream)) \
-                          : (f32o ? launch_igemm_sp<T, 224, 128, 2, 4, DD, true, false>(*d, stream) : launch_igemm_sp<T, 224, 128, 2, 4, DD, false, false>(*d, stream)))
-#define GSP(T, BM, BN, DD) (tapin ? (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true, true>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false, true>(*d, stream)) \
-                                  : (f32o ? launch_igemm_sp<T, BM, BN, 4, 2, DD, true, false>(*d, stream) : launch_igemm_sp<T, BM, BN, 4, 2, DD, false, false>(*d, stream)))
-      // in-workgroup split-K for the 64x64 tile when the tile grid cannot fill the chip with several workgroups per CU
-      static const int tapin_on = [] { const char* e = getenv("L2S_IGEMM_TAPIN"); return e ? atoi(e) : 1; }();
-      const int ntaps = d->KH * d->KW;
-      const bool tapin = tapin_on && ntaps > 1 && ntaps <= 32 && xb < (1L << 30);
-      const int KT = K / bk;
-      const long tiles64 = (long)cdiv(M, 64) * cdiv(d->Cout, 64);
-      int ks = 1;
-      if (tile == 64 && ring_ks != 1) {
-        if (ring_ks > 1) ks = ring_ks;
-        // ring_ks == 0 (default): no in-workgroup split-K.  In isolation KS = 4 is 15 % faster on the 152-tile layer3 3x3, but its
-        // workgroups are 16 waves with 128 KiB of LDS: next to the weight-gradient launches on the other queue such a workgroup only
-        // starts once a whole CU has drained, and the step as a whole is slower (115.7 vs 123.3 img/s, round 2).  -1 = the old rule.
-        else if (ring_ks < 0 && tiles64 <= 192) ks = KT >= 16 ? 4 : (KT >= 8 ? 2 : 1);
-        while (ks > 1 && (KT % ks)) ks >>= 1;
-      }
-      // LDS-DMA 256x128 tile: wherever the large register-staged tiles were chosen (one round of ~200 workgroups, K >= 1024: layer4 on the
-      // RoIs), measured 59 vs 74 us on the dominant 3x3 and equal or better on the 1x1 shapes (tools/dma_bench.py)
-      const bool dma_ok = dtype == L2S_BF16 && !f32o && KT >= 3 && d->KH <= 3 && d->KW <= 3;
-      if (dma_ok && (d->algo == L2S_ALGO_DMA || d->algo == 4 || (d->algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256))))
-        return d->algo == 4 ? launch_igemm_dma<256, 128, true>(*d, stream) : launch_igemm_dma<256, 128, false>(*d, stream);
-      // K-split 64x64 tile with LDS-DMA fill: the small-M launches (layer2 / layer3) with whole 128-channel pieces per tap
-      const bool ks_ok = dtype == L2S_BF16 && !f32o && d->Cin % 128 == 0 && d->KH <= 3 && d->KW <= 3 && (long)M * d->Cout * 4 < (1L << 31);
-      if (ks_ok && (d->algo == L2S_ALGO_KSPLIT || d->algo == 6)) return d->algo == 6 ? launch_igemm_ks64<3>(*d, stream) : launch_igemm_ks64<4>(*d, stream);
-      // auto: the 3x3 launches whose 64x64 tiles fit one round of workgroups (layer3, RPN, layer4 on the map): 13.8 -> 11.2 us, 61.6 -> 52.9 us
-      // (tools/dma_bench.py); the 1x1 launches gain nothing (their K loop is a few slices) and multi-round grids lose (one workgroup per CU)
-      if (ks_ok && d->algo == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && (long)cdiv(M, 64) * cdiv(d->Cout, 64) <= 256 && K >= 1024) return launch_igemm_ks64<4>(*d, stream);
-      if (dtype == L2S_BF16) {
-        if (tile == 224) return GSP7(bf16_t, 2);
-        if (tile == 256) return sp_on ? GSP(bf16_t, 256, 128, 2) : GR8(bf16_t, 256, 128, 2);
-        if (tile == 128) return GR(bf16_t, 128, 128, 2, 1);
-        if (ks == 4) return GR(bf16_t, 64, 64, 3, 4);
-        if (ks == 2) return GR(bf16_t, 64, 64, 3, 2);
-        // (ring depth 4 = 64 KiB in flight per workgroup; depths 8 and 12 were measured slower, round 2: 129 / 119 vs 136 img/s)
-        // and so was the software-pipelined (three LDS buffers) form of this tile: 132-133 img/s
-        // 256-byte K rows per slice when every tap has whole 256-byte pieces of channels (off: with the early fragment reads the 256-byte
-        // slice needs 64 fragment + 64 ring registers and 64 KiB of LDS: 110 / 145 img/s at ring depth 2 / 3 against 170 for 128-byte rows)
-        static const int rb256 = [] { const char* e = getenv("L2S_IGEMM_RB256"); return e ? atoi(e) : 0; }();
-        if (rb256 && d->Cin % 128 == 0) {
-#define GRB(DD) (f32o ? launch_igemm_ring<bf16_t, 64, 64, 2, 2, DD, true, 1, 256>(*d, stream) : launch_igemm_ring<bf16_t, 64, 64, 2, 2, DD, false, 1, 256>(*d, stream))
-          if (rb256 == 2) return GRB(2);
-          if (rb256 == 3) return GRB(3);
-          return GRB(4);
-#undef GRB
-        }
-        // ring depth 2 since the fragment reads moved ahead of the LDS fill (fewer registers, more workgroups per CU): 170.5 vs 166.7 img/s
-        // for depth 4 (which was the better one before: 129 / 119 img/s for depths 8 / 12 then)
-        // wave-specialised 8-wave form (loaders + multipliers), bf16 output only; 64x32 tiles when 64x64 ones leave CUs empty
-        static const int ws64 = [] { const char* e = getenv("L2S_IGEMM_WS64"); return e ? atoi(e) : 3; }();
-        static const int ws_n32 = [] { const char* e = getenv("L2S_IGEMM_WS_N32"); return e ? atoi(e) : 0; }();   // tile-count threshold
-        if (ws64 && !f32o) {
-          if (tiles64 <= ws_n32 && d->Cout % 32 == 0) return launch_igemm_ws64<3, 32>(*d, stream);
-          if (ws64 == 2) return launch_igemm_ws64<2, 64>(*d, stream);
-          if (ws64 == 4) return launch_igemm_ws64<4, 64>(*d, stream);
-          return launch_igemm_ws64<3, 64>(*d, stream);
-        }
-        static const int d64 = [] { const char* e = getenv("L2S_IGEMM_D64"); return e ? atoi(e) : 2; }();
-        if (d64 == 4) return GR(bf16_t, 64, 64, 4, 1);
-        if (d64 == 3) return GR(bf16_t, 64, 64, 3, 1);
-        return GR(bf16_t, 64, 64, 2, 1);
-      }
-      if (dtype == L2S_F32) {
-        if (tile == 224) return GSP7(float, 2);
-        if (tile == 256) return sp_on ? GSP(float, 256, 128, 2) : GR8(float, 256, 128, 2);
-        if (tile == 128) return GR(float, 128, 128, 2, 1);
-        if (ks == 4) return GR(float, 64, 64, 3, 4);
-        if (ks == 2) return GR(float, 64, 64, 3, 2);
-        return GR(float, 64, 64, 4, 1);
-      }
-#undef GR
-#undef GR8
-#undef GSP
-#undef GSP7
-    }
+#define BYT(CALL_BF, CALL_F32) (dtype == L2S_BF16 ? (CALL_BF) : (CALL_F32))
+#define OUT(NAME, T, ...) (f32o ? NAME<T, __VA_ARGS__, true>(dd, stream) : NAME<T, __VA_ARGS__, false>(dd, stream))
+  switch (plan) {
+    case PLAN_DMA256: return launch_igemm_dma<256, 128, false>(dd, stream);
+    case PLAN_DMA256_STAMPED: return launch_igemm_dma<256, 128, true>(dd, stream);
+    case PLAN_KS64: return launch_igemm_ks64<4>(dd, stream);
+    case PLAN_KS64_D3: return launch_igemm_ks64<3>(dd, stream);
+    case PLAN_WS64: return launch_igemm_ws64<3, 64>(dd, stream);
+    case PLAN_SP224:
+      if (tapin) return BYT((f32o ? launch_igemm_sp<bf16_t, 224, 128, 2, 4, 2, true, true>(dd, stream) : launch_igemm_sp<bf16_t, 224, 128, 2, 4, 2, false, true>(dd, stream)),
+                            (f32o ? launch_igemm_sp<float, 224, 128, 2, 4, 2, true, true>(dd, stream) : launch_igemm_sp<float, 224, 128, 2, 4, 2, false, true>(dd, stream)));
+      return BYT((f32o ? launch_igemm_sp<bf16_t, 224, 128, 2, 4, 2, true, false>(dd, stream) : launch_igemm_sp<bf16_t, 224, 128, 2, 4, 2, false, false>(dd, stream)),
+                 (f32o ? launch_igemm_sp<float, 224, 128, 2, 4, 2, true, false>(dd, stream) : launch_igemm_sp<float, 224, 128, 2, 4, 2, false, false>(dd, stream)));
+    case PLAN_SP256:
+      if (tapin) return BYT((f32o ? launch_igemm_sp<bf16_t, 256, 128, 4, 2, 2, true, true>(dd, stream) : launch_igemm_sp<bf16_t, 256, 128, 4, 2, 2, false, true>(dd, stream)),
+                            (f32o ? launch_igemm_sp<float, 256, 128, 4, 2, 2, true, true>(dd, stream) : launch_igemm_sp<float, 256, 128, 4, 2, 2, false, true>(dd, stream)));
+      return BYT((f32o ? launch_igemm_sp<bf16_t, 256, 128, 4, 2, 2, true, false>(dd, stream) : launch_igemm_sp<bf16_t, 256, 128, 4, 2, 2, false, false>(dd, stream)),
+                 (f32o ? launch_igemm_sp<float, 256, 128, 4, 2, 2, true, false>(dd, stream) : launch_igemm_sp<float, 256, 128, 4, 2, 2, false, false>(dd, stream)));
+    case PLAN_RING128: return BYT(OUT(launch_igemm_ring, bf16_t, 128, 128, 2, 2, 2), OUT(launch_igemm_ring, float, 128, 128, 2, 2, 2));
+    // 64x64 ring tile: depth 2 with the fragment reads ahead of the LDS fill for bf16 (fp32-output launches), depth 4 for f32
+    case PLAN_RING64: return BYT(OUT(launch_igemm_ring, bf16_t, 64, 64, 2, 2, 2), OUT(launch_igemm_ring, float, 64, 64, 2, 2, 4));
+    case PLAN_GENERIC128: return BYT(OUT(launch_igemm, bf16_t, 128, 128), OUT(launch_igemm, float, 128, 128));
+    case PLAN_GENERIC64: return BYT(OUT(launch_igemm, bf16_t, 64, 64), OUT(launch_igemm, float, 64, 64));
+    default: return L2S_EINVAL;
   }
-  if (tile == 256 || tile == 224) tile = 128;   // the large tiles exist only in the ring / software-pipelined kernels
-  static const int use_pipe = [] { const char* e = getenv("L2S_IGEMM_PIPE"); return e ? atoi(e) : 0; }();   // measured slower than the register-staged kernel at 128x128/64x64 tiles (profiles/r01_conv_bench.txt): LDS-DMA issue cost
-  const bool split_req = d->ws && d->split_k > 1;
-  if (use_pipe && !split_req) {
-#define GP(T, BM, BN, S) (f32o ? launch_igemm_pipe<T, BM, BN, S, true>(*d, stream) : launch_igemm_pipe<T, BM, BN, S, false>(*d, stream))
-    if (dtype == L2S_BF16) return tile == 128 ? GP(bf16_t, 128, 128, 4) : GP(bf16_t, 64, 64, 8);
-    if (dtype == L2S_F32) return tile == 128 ? GP(float, 128, 128, 4) : GP(float, 64, 64, 8);
-#undef GP
-  }
-#define GO(T, BM, BN) (f32o ? launch_igemm<T, BM, BN, true>(*d, stream) : launch_igemm<T, BM, BN, false>(*d, stream))
-  if (dtype == L2S_BF16) return tile == 128 ? GO(bf16_t, 128, 128) : GO(bf16_t, 64, 64);
-  if (dtype == L2S_F32) return tile == 128 ? GO(float, 128, 128) : GO(float, 64, 64);
-#undef GO
-  return L2S_EINVAL;
+#undef BYT
+#undef OUT
 }

@@ -339,8 +339,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 
 // ---- variants (tile, taps per workgroup): 0 = 64x64 per tap, 1 = 128x128 per tap, 2 = 64x64 filter row, 3 = 128(co)x64 filter row ----
 int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
-  static const int tx_on = [] { const char* e = getenv("L2S_WGRAD_TX3"); return e ? atoi(e) : 1; }();
-  const bool row3 = tx_on && KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
+  const bool row3 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
   const bool big = M >= 8192 && Cout >= 512 && Cin >= 512;
   if (row3) return (tile == 128 || (!tile && Cout >= 512)) ? 3 : 2;
   return (tile == 128 || (!tile && big && KH * KW == 1)) ? 1 : 0;
@@ -385,8 +384,7 @@ int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_spl
   // (32 KiB of LDS) can only start on a CU with that much LDS free: two 128x128 tiles (2 x 74 KiB) leave none, and every main-queue launch
   // then waits for weight-gradient workgroups to retire.  The LDS REQUEST therefore bounds the residency: one 128x128 workgroup per CU
   // (>= 81 KiB requested), two of the smaller tiles (>= 54 KB), which always leaves >= 50 KiB.  158.3 -> 161.9 img/s (A/B in one box).
-  static const size_t want = [] { const char* e = getenv("L2S_WGRAD_LDS"); return e ? (size_t)atol(e) : (size_t)54000; }();
-  static const size_t want_big = [] { const char* e = getenv("L2S_WGRAD_LDS_BIG"); return e ? (size_t)atol(e) : (size_t)83000; }();
+  constexpr size_t want = 54000, want_big = 83000;
   if (BM * BN >= 128 * 128) { if (want_big > lds) lds = want_big; }
   else if (want > lds) lds = want;
   static bool attr_done = false;
@@ -444,7 +442,6 @@ extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s
   for (int i = nprob + 1; i <= L2S_WGRAD_MAX_GROUP; ++i) pre.tile0[i] = (int)t;
   // (ring depth 2: with several workgroups per CU the other workgroups cover a load's latency; fewer registers = more of them)
   // KSTEP = MFMA k steps (32 pixels in bf16) per barrier: 2 (64-pixel slices) measured 137.4-139.7 vs 134.9-136.5 img/s for 1 (round 2)
-  static const int kstep = [] { const char* e = getenv("L2S_WGRAD_KSTEP"); return e ? atoi(e) : 2; }();
 #define GO(T, KS)                                                                                \
   switch (variant) {                                                                             \
     case 0: return launch_grouped<T, 64, 64, 1, 2, KS>(table_dev, pre, ws, any_split, stream);    \
@@ -452,7 +449,7 @@ extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s
     case 2: return launch_grouped<T, 64, 64, 3, 2, KS>(table_dev, pre, ws, any_split, stream);    \
     default: return launch_grouped<T, 128, 64, 3, 2, KS>(table_dev, pre, ws, any_split, stream);  \
   }
-  if (dtype == L2S_BF16) { if (kstep == 2) { GO(bf16_t, 2) } else { GO(bf16_t, 1) } }
+  if (dtype == L2S_BF16) { GO(bf16_t, 2) }
   if (dtype == L2S_F32) { GO(float, 1) }
 #undef GO
   return L2S_EINVAL;
@@ -466,7 +463,7 @@ static int plan_split(const l2s_wgrad_desc& d, int variant, int dtype, size_t ws
   const int slices = cdiv(Mv, bkp);
   int split = d.split_k;
   if (split <= 0) {
-    static const int min_wg = [] { const char* e = getenv("L2S_WGRAD_MINWG"); return e ? atoi(e) : 256; }();
+    constexpr int min_wg = 256;
     split = (int)((min_wg + tiles - 1) / tiles);
     const int maxs = slices / 8 > 0 ? slices / 8 : 1;
     if (split > maxs) split = maxs;

@@ -1146,8 +1146,7 @@ extern "C" int l2s_linear_fwd(const float* x, int ldx_, const float* w, int ldw,
   if (M <= 0 || N <= 0) return L2S_OK;
   const bool v4 = !((K & 3) || (ldx_ & 3) || (ldw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15));
   const bool v2 = !((K & 1) || (ldx_ & 1) || (ldw & 1) || ((uintptr_t)x & 7) || ((uintptr_t)w & 7));
-  static const int mfma_on = [] { const char* e = getenv("L2S_LINEAR_MFMA"); return e ? atoi(e) : 1; }();
-  if (mfma_on && v4 && M >= 2) {
+  if (v4 && M >= 2) {
     // row batches: exact-fp32 MFMA tiles, every weight read once
     if (M <= 16) L2S_LAUNCH((linear_nt_mfma_kernel<1>), dim3(cdiv(N, 16), 1), dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, M, N, K, act, accumulate);
     else L2S_LAUNCH((linear_nt_mfma_kernel<2>), dim3(cdiv(N, 16), cdiv(M, 32)), dim3(256), 0, s, x, ldx_, w, ldw, b, y, ldy, M, N, K, act, accumulate);
@@ -1183,9 +1182,8 @@ extern "C" long l2s_linear_bwd_x_ws_floats(int M, int N, int K) {
 extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int lddx, int M, int N, int K, int accumulate,
                                 const float* mul, float* ws, long ws_floats, hipStream_t s) {
   if (M <= 0) return L2S_OK;
-  static const int mfma_on = [] { const char* e = getenv("L2S_LINEAR_MFMA"); return e ? atoi(e) : 1; }();
   // (a single row takes this path too when the matrix is large: it streams the weight once over ~128 workgroups instead of K / 64)
-  if (mfma_on && (M >= 2 || (long)N * K >= (1L << 20)) && !(K & 3) && !((uintptr_t)w & 15) && K >= 4) {
+  if ((M >= 2 || (long)N * K >= (1L << 20)) && !(K & 3) && !((uintptr_t)w & 15) && K >= 4) {
     int sp = nn_split(M, N, K);
     const int mch = cdiv(M, 32), Mpad = mch * 32;
     if (!ws || ws_floats < (long)sp * Mpad * K) sp = 1;
@@ -1204,8 +1202,7 @@ extern "C" int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float
 }
 extern "C" int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx_, float* dw, float* db, int M, int N, int K, hipStream_t s) {
   if (M <= 0) return L2S_OK;
-  static const int mfma_on = [] { const char* e = getenv("L2S_LINEAR_MFMA"); return e ? atoi(e) : 1; }();
-  if (mfma_on && M >= 2 && K >= 4 && !(K & 3) && !(ldx_ & 3) && !((uintptr_t)x & 15) && !((uintptr_t)dw & 15)) {
+  if (M >= 2 && K >= 4 && !(K & 3) && !(ldx_ & 3) && !((uintptr_t)x & 15) && !((uintptr_t)dw & 15)) {
     const dim3 grid(cdiv(K, 64), cdiv(N, 256));
     if (!(lddy & 3) && !((uintptr_t)dy & 15)) L2S_LAUNCH((linear_tn_mfma_kernel<true>), grid, dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
     else L2S_LAUNCH((linear_tn_mfma_kernel<false>), grid, dim3(256), 0, s, dy, lddy, x, ldx_, dw, db, M, N, K);
@@ -1335,8 +1332,7 @@ extern "C" int l2s_linear2_fwd(const float* x, int K, const float* w1, const flo
 extern "C" int l2s_linear_sum2_fwd(const float* x1, const float* w1, int K1, const float* x2, const float* w2, int K2, float* y, int N,
                                    int accumulate, hipStream_t s) {
   if ((K1 & 3) || (K2 & 3) || ((uintptr_t)x1 & 15) || ((uintptr_t)x2 & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15)) return L2S_EINVAL;
-  static const int split = [] { const char* e = getenv("L2S_SUM2_SPLIT"); return e ? atoi(e) : 1; }();
-  if (split && N <= 4096) L2S_LAUNCH(linear_sum2_split_kernel, dim3(N), dim3(256), 0, s, x1, w1, K1, x2, w2, K2, y, N, accumulate);
+  if (N <= 4096) L2S_LAUNCH(linear_sum2_split_kernel, dim3(N), dim3(256), 0, s, x1, w1, K1, x2, w2, K2, y, N, accumulate);
   else L2S_LAUNCH(linear_sum2_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, x1, w1, K1, x2, w2, K2, y, N, accumulate);
   return l2s_check_launch();
 }

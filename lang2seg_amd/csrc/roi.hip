@@ -998,8 +998,7 @@ static int roialign_fwd_launch(const void* feat, int H, int W, int C, const floa
 }
 static int roialign_bwd_launch(const void* dout, int H, int W, int C, const float* rois, int R, int P, float sscale, float TH, float TW,
                                float* dfeat, int dtype, hipStream_t s) {
-  static const bool gather = !(getenv("L2S_ROIALIGN_ATOMIC") && atoi(getenv("L2S_ROIALIGN_ATOMIC")));
-  if (gather && C % 4 == 0 && P <= 32) {
+  if (C % 4 == 0 && P <= 32) {      // gather form: no atomics, fixed summation order (the scatter kernel below only serves odd channel counts)
     if (dtype) L2S_LAUNCH(roialign_bwd_gather_kernel<bf16_t>, dim3(H * W), dim3(256), 0, s, (const bf16_t*)dout, H, W, C, rois, R, P, sscale, TH, TW, dfeat);
     else L2S_LAUNCH(roialign_bwd_gather_kernel<float>, dim3(H * W), dim3(256), 0, s, (const float*)dout, H, W, C, rois, R, P, sscale, TH, TW, dfeat);
     return l2s_check_launch();

@@ -18,6 +18,7 @@ struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };  
 struct Tape { std::vector<Op> ops; int n_events = 0; std::vector<hipEvent_t> events; std::vector<size_t> marks; };
 
 static Tape* g_rec = nullptr;
+bool g_paused = false;   // l2s_tape_pause: launches issued by the host between two segments (the gradient reducer's casts) are not recorded
 static hipStream_t g_streams[8];
 static int g_nstreams = 0;
 static std::vector<hipEvent_t> g_pool;     // events for eager forks
@@ -28,9 +29,9 @@ static int stream_id(hipStream_t s) {
   for (int i = 0; i < g_nstreams; ++i) if (g_streams[i] == s) return i;
   return -1;
 }
-bool recording() { return g_rec != nullptr; }
+bool recording() { return g_rec != nullptr && !g_paused; }
 void record(hipStream_t s, std::function<void(hipStream_t)> fn) {
-  if (!g_rec) return;
+  if (!g_rec || g_paused) return;
   g_rec->ops.push_back(Op{0, stream_id(s), -1, std::move(fn)});
 }
 
@@ -49,6 +50,7 @@ extern "C" int l2s_tape_end(void* tape) {
   if (g_rec != (Tape*)tape || !tape) return L2S_EINVAL;
   Tape* t = g_rec;
   g_rec = nullptr;
+  g_paused = false;
   for (size_t i = 0; i < t->ops.size(); ++i) {
     if (t->ops[i].kind == 3) t->marks.push_back(i);
     else if (t->ops[i].sid < 0) return L2S_EINVAL;                  // a launch went to an unregistered stream
@@ -62,6 +64,9 @@ extern "C" long l2s_tape_size(void* tape) { return tape ? (long)((Tape*)tape)->o
 // Segments: l2s_tape_mark() splits a tape at the points where the host has to act between launches (the data-parallel
 // gradient all-reduce of a finished bucket goes through torch.distributed / RCCL, which cannot be recorded): segment k is
 // everything between mark k-1 and mark k.
+// While paused, launches execute but are not recorded: the data-parallel reducer runs between two segments on its own stream (its
+// collectives cannot be recorded, and its pack / unpack launches must not be replayed by the tape AND issued again by the reducer).
+extern "C" int l2s_tape_pause(int on) { g_paused = on != 0; return L2S_OK; }
 extern "C" int l2s_tape_mark(void) {
   if (g_rec) g_rec->ops.push_back(Op{3, 0, -1, nullptr});
   return L2S_OK;

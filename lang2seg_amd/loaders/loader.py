@@ -2,9 +2,9 @@
 cat_to_ix / label_length) plus the `/labels` array of `data.h5` (one zero-padded row of word indices per sentence).
 
 Same attributes and methods as the reference class (`Refs`, `Images`, `Anns`, `Sentences`, `annToRef`, `sentToRef`,
-`vocab_size`, `label_length`, `encode_labels`, `decode_labels`, `fetch_label`, `fetch_seq`).  The HDF5 file is read with h5py
-when it is importable; this image has no h5py, so a `labels` array exported once with
-`numpy.save(data_h5 + '.npy', h5py.File(data_h5)['labels'][...])` (or a `.npy` path given directly) is accepted as well."""
+`vocab_size`, `label_length`, `encode_labels`, `decode_labels`, `fetch_label`, `fetch_seq`).  `data.h5` (written by
+tools/prepro.py:287-289 with h5py) is read by the dependency-free HDF5 reader loaders/h5lite.py - this image has no h5py - which is
+pinned by files h5py itself wrote (tests/golden/h5); a `.npy` export of the labels is accepted as well."""
 import json
 import os
 import random
@@ -13,17 +13,13 @@ import numpy as np
 
 
 def load_labels(path):
-    """the /labels dataset of data.h5 as an int array [num_sentences][label_length]"""
+    """the /labels dataset of data.h5 as an int array [num_sentences][label_length] (lib/loaders/loader.py:103-104)"""
     if path.endswith('.npy'):
         return np.load(path)
-    if os.path.exists(path + '.npy'):
+    if not os.path.exists(path) and os.path.exists(path + '.npy'):
         return np.load(path + '.npy')
-    try:
-        import h5py
-    except ImportError:
-        raise ImportError('reading %s needs h5py (not installed here); export the labels once with '
-                          "numpy.save('%s.npy', h5py.File('%s', 'r')['labels'][...])" % (path, path, path))
-    return np.asarray(h5py.File(path, 'r')['labels'])
+    from .h5lite import read_dataset
+    return np.asarray(read_dataset(path, 'labels'))
 
 
 class Loader(object):

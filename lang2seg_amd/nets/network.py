@@ -180,7 +180,7 @@ class WgradQueue(object):
                     if ctx is not None:
                         ctx.__exit__(None, None, None)
 
-    MIN_WG = int(os.environ.get('L2S_WGRAD_MIN_WG', '384'))   # workgroups a grouped launch should have before its problems stop splitting their pixels
+    MIN_WG = 384   # workgroups a grouped launch should have before its problems stop splitting their pixels
 
 
 class Bottleneck(object):
@@ -256,7 +256,7 @@ class Network(object):
         self.dp = None              # data-parallel gradient reducer (lang2seg_amd/parallel.py)
         self._early_op = None       # optimiser taking early partial updates during backward (optim.SGD.partial)
         self.wgq = WgradQueue(self) # weight gradients of the current backward stage, launched together by flush_wgrads()
-        self.cap_projected = os.environ.get('L2S_CAP_PROJ', '1') == '1'   # captioner recurrence in the projected-attention form (3 launches per token)
+        self.cap_projected = True   # captioner recurrence in the projected-attention form (3 launches per token)
         self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'cap'); set by bench.py --knockout
 
     # ------------------------------------------------------------------ construction
@@ -291,8 +291,7 @@ class Network(object):
 
     def streams(self):
         if not hasattr(self, '_streams'):
-            hp = os.environ.get('L2S_HIPRIO', '').split(',')
-            mk = lambda n: torch.cuda.Stream(priority=-1) if n in hp else torch.cuda.Stream()
+            mk = lambda n: torch.cuda.Stream()          # (no priorities: any priority stream halves throughput on this stack)
             self._streams = dict(lang=mk('lang'), cap=mk('cap'), wg=mk('wg'), wg2=mk('wg2'), tr=mk('tr'))
             self._wg_flip = 0
         return self._streams
@@ -380,7 +379,12 @@ class Network(object):
             try:
                 loss = self.forward_backward(d)                       # dp_ready() cuts the tape at every bucket hand-off
                 if dp is not None:
-                    O.tape_mark(); self._tape_stages.append('finish'); dp.finish()
+                    O.tape_mark(); self._tape_stages.append('finish')
+                    O.tape_pause(True)
+                    try:
+                        dp.finish()
+                    finally:
+                        O.tape_pause(False)
                 train_op.step()
                 self._mark('optimiser')
             finally:
@@ -399,13 +403,8 @@ class Network(object):
             return loss
         # data parallel: replay segment by segment; between segments the finished gradient bucket goes to RCCL on the
         # reducer's stream (torch.distributed cannot be recorded), overlapping with the rest of the backward pass
-        for i, stage in enumerate(stages):
-            O.tape_run_segment(h, slist, i)
-            if stage == 'finish':
-                dp.finish()
-            else:
-                dp.ready(stage)
-        O.tape_run_segment(h, slist, len(stages))
+        from ..parallel import replay_segments
+        replay_segments(stages, lambda i: O.tape_run_segment(h, slist, i), dp)
         return loss
 
     def _eager_step(self, dev, train_op, key):
@@ -466,9 +465,15 @@ class Network(object):
         if self.dp is None:
             self._early_op.partial(stage)                        # single process: the optimiser updates the finished prefix early
             return
-        if getattr(self, '_tape_stages', None) is not None:
+        rec = getattr(self, '_tape_stages', None) is not None
+        if rec:
             O.tape_mark(); self._tape_stages.append(stage)
-        self.dp.ready(stage)
+            O.tape_pause(True)                                   # the reducer's own launches (bf16 pack / unpack) are issued by the host at
+        try:                                                     # every replay, between two segments: they must not be on the tape as well
+            self.dp.ready(stage)
+        finally:
+            if rec:
+                O.tape_pause(False)
 
     def _mark(self, name):
         """optional phase marker (tools/phase_times.py): a timing event on the current stream."""

@@ -58,6 +58,10 @@ def tape_mark():
     call('l2s_tape_mark')
 
 
+def tape_pause(on):
+    call('l2s_tape_pause', 1 if on else 0)
+
+
 def tape_time_event():
     """(measurement) 'record a timing event here' on the current stream's tape order; id >= 0 while a tape is recording, else -1"""
     return int(_lib.load().l2s_tape_time_event(stream()))
@@ -87,19 +91,7 @@ def tape_size(h):
 # kernel family of every convolution that does not name one (l2s_conv_desc.algo: 0 = auto); set by the benchmark tools only
 # (bench.py --conv-algo, tools/*bench*.py): same arithmetic, speed only
 CONV_ALGO = 0
-
-
-def conv3x3_patch(x, w, y, n_img, IH, IW, Cin, Cout, bias=None, add=None, ref=None, relu=False, out_f32=False, dt=None):
-    """direct 3x3 / stride 1 / pad 1 convolution through the LDS-patch kernel; False when the problem is not eligible (nothing launched)"""
-    d = ConvDesc()
-    d.x, d.w, d.y, d.bias, d.add, d.ref = ptr(x), ptr(w), ptr(y), ptr(bias), ptr(add), ptr(ref)
-    d.n_img, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout, d.KH, d.KW, d.stride, d.pad = n_img, IH, IW, Cin, IH, IW, Cout, 3, 3, 1, 1
-    d.ldx, d.ldy, d.ldadd, d.ldref = Cin, Cout, Cout, Cout
-    d.flags = (_lib.CONV_RELU if relu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0)
-    r = _lib.load().l2s_conv3x3_patch_try(C.byref(d), dt_of(x) if dt is None else dt, stream())
-    if r < 0:
-        raise _lib.L2SError('l2s_conv3x3_patch_try returned error %d' % -r)
-    return r == 1
+LAST_PLAN = None        # name of the kernel the dispatcher picked for the last conv_igemm call (bench.py's launch timer reads it)
 
 
 def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
@@ -131,7 +123,10 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     d.xcd_mode = xcd_mode
     d.algo = CONV_ALGO if algo is None else algo
     d.ws = ptr(ws)
-    call('l2s_conv_igemm', C.byref(d), dt_of(x) if dt is None else dt, stream())
+    global LAST_PLAN
+    dtv = dt_of(x) if dt is None else dt
+    LAST_PLAN = _lib.load().l2s_conv_plan_name(C.byref(d), dtv).decode()
+    call('l2s_conv_igemm', C.byref(d), dtv, stream())
     return y
 
 

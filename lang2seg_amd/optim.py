@@ -3,7 +3,6 @@ pyutils/mask-faster-rcnn/lib/model/train_val_cycle.py:194-220 (one param group p
 non-bias tensors, optional DOUBLE_BIAS), fused into one HIP launch that also rewrites the dtype
 shadow weights; the data-gradient (transposed) weight copies are refreshed right after."""
 import bisect
-import os
 
 import torch
 
@@ -28,8 +27,8 @@ class SGD(object):
     # while the earlier layers are still back-propagating (the update is HBM-bound, the convolutions are not); `step()` then
     # only has the last layers left.  Single-process only: with a gradient reducer the prefix still has to be all-reduced.
     # Measured on MI355X (bench.py, A/B in one box): 122.4 / 123.6 img/s with it vs 123.1 without — the update competes for HBM with
-    # the layer3 backward it overlaps, so it is off by default (L2S_EARLY_SGD=1 turns it on; tests cover it).
-    early = os.environ.get('L2S_EARLY_SGD', '0') == '1'
+    # the layer3 backward it overlaps, so it is off by default (SGD.early = True turns it on; tests cover it).
+    early = False                                  # set by tests / tools before the first step
     _seg_done = 0
 
     def _launch(self, s0, s1):
@@ -49,7 +48,7 @@ class SGD(object):
         if hi <= self._seg_done:
             return
         S = net.streams()
-        tr = S[os.environ.get('L2S_EARLY_SGD_STREAM', 'tr')]
+        tr = S['tr']
         net.join_transposes()                                    # (already joined at the start of the step; keeps `tr` ordered)
         net.sfork(torch.cuda.current_stream(), tr)
         for name in ('wg', 'wg2', 'lang', 'cap'):                # gradients are also produced on the side streams
@@ -62,8 +61,8 @@ class SGD(object):
     # HBM-bound update; the next step's frozen prefix (stem, layer1: small dependent launches) starts beside them and the main queue
     # joins before its first trainable layer (Network.join_update).  No extra stream: the update simply follows the weight gradients
     # it depends on in stream order.
-    # Measured (bench.py, 200 steps, A/B alternating in one box): 165.8 vs 163.0 img/s.  L2S_SGD_SIDE=0 restores the update on the caller's stream.
-    side = os.environ.get('L2S_SGD_SIDE', '1') == '1'
+    # Measured (bench.py, 200 steps, A/B alternating in one box): 165.8 vs 163.0 img/s.  SGD.side = False (before construction) restores the update on the caller's stream.
+    side = True
 
     def step(self):
         P = self.net.P
@@ -82,7 +81,7 @@ class SGD(object):
         if hasattr(self.net, 'join_wgrad'):
             self.net.join_wgrad()                   # weight-gradient stream -> current stream
         if self._seg_done:
-            self.net.sfork(self.net.streams()[os.environ.get('L2S_EARLY_SGD_STREAM', 'tr')], torch.cuda.current_stream())
+            self.net.sfork(self.net.streams()['tr'], torch.cuda.current_stream())
         self._launch(self._seg_done, P.nseg)
         self._seg_done = 0
         self.net.refresh_weights()

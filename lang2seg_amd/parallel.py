@@ -38,19 +38,89 @@ def bucket_bounds(P):
     return bounds
 
 
+def replay_segments(stages, run_segment, dp):
+    """data-parallel replay of a launch tape cut at the bucket hand-offs (Network.tape_step): segment i, then the bucket that segment
+    i completed goes to the reducer (torch.distributed cannot be recorded), ..., the last hand-off is the join before the optimiser, and
+    the final segment holds the update.  `run_segment(i)` issues the launches of segment i."""
+    for i, stage in enumerate(stages):
+        run_segment(i)
+        if stage == 'finish':
+            dp.finish()
+        else:
+            dp.ready(stage)
+    run_segment(len(stages))
+
+
 class GradReducer(object):
+    """Bucketed gradient exchange on a side stream.
+
+    wire:  'fp32' - the bucket is reduced in place (282 MB per step for the ResNet cycle network);
+           'bf16' - the bucket is packed to bf16 (one cast launch), reduced, and unpacked back into the fp32 gradient buffer: half the
+                    bytes on every xGMI link (141 MB).  Every partial sum of the collective is rounded to bf16, so the gradients agree
+                    with the fp32 exchange to ~2^-8 relative per rank added; the master weights, momentum and update stay fp32.
+    algo:  'allreduce'  - one all-reduce per bucket (RCCL picks ring / tree);
+           'rs_ag'      - reduce-scatter + all-gather per bucket: each rank reduces 1/world of the bucket, which RCCL can run as direct
+                          exchanges over all seven xGMI links of the fully connected node instead of a ring that is bound by one link
+                          (SURVEY.md section 8e).  Same sums as the all-reduce up to the order of the additions.
+    Queue / CU budget: the exchange owns ONE extra stream (`self.side`); RCCL's kernels use its default channel count (a few workgroups
+    per channel) - no CU mask, no priority (both measured harmful on this stack).
+    `timing=True` records HIP events around every bucket and around the wait in finish(); `report()` returns per-bucket durations and
+    the exposed wait (what the main stream actually stalled for) of the last step."""
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
 
-    def __init__(self, net, world, backend_stream=True, skip_allreduce=0):
+    def __init__(self, net, world, backend_stream=True, skip_allreduce=0, wire='fp32', algo='allreduce', timing=False):
+        assert wire in ('fp32', 'bf16') and algo in ('allreduce', 'rs_ag')
         self.net, self.world = net, world
         # experiment only (bench.py --dp-skip-allreduce): 1 = keep the stream structure but issue no collective, 2 = do nothing.
         # Ranks diverge with either, so model/train_val.py refuses a reducer built this way.
         self.skip_allreduce = int(skip_allreduce)
+        self.wire, self.algo, self.timing = wire, algo, bool(timing)
         P = net.P
         self.bounds = bucket_bounds(P)
         self.done = 0
         self.on_gpu = P.grad.is_cuda
         self.side = torch.cuda.Stream() if self.on_gpu else None
+        self._pack = None            # bf16 staging buffer (whole flat length: buckets are slices of it)
+        self._shard = None           # reduce-scatter output (largest bucket / world)
+        self._events = []            # (stage, start, end) of the last step
+        self._wait_events = None
+
+    # ---- one bucket, on the current stream (the side stream on the GPU) ----
+    def _cast(self, src, dst):
+        if self.on_gpu:
+            from . import ops as O
+            O.cast(src, dst)                         # the library's cast kernel (bf16 <-> f32, round to nearest even)
+        else:
+            dst.copy_(src)                           # gloo tests on the CPU box
+
+    def _collective(self, buf):
+        """sum over ranks of `buf` (a contiguous 1-D tensor), in place"""
+        W = self.world
+        n = buf.numel()
+        if self.algo == 'rs_ag' and W > 1 and n >= W:
+            m = n // W * W                           # the part that splits evenly; a tail of < world elements goes through all_reduce
+            per = m // W
+            if self._shard is None or self._shard.numel() < per or self._shard.dtype != buf.dtype:
+                big = max(per, (max(self.bounds.values()) + W - 1) // W)
+                self._shard = torch.empty(big, dtype=buf.dtype, device=buf.device)
+            sh = self._shard[:per]
+            dist.reduce_scatter_tensor(sh, buf[:m], op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(buf[:m], sh)
+            if m < n:
+                dist.all_reduce(buf[m:], op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+    def _exchange(self, seg, lo, hi):
+        if self.wire == 'bf16':
+            if self._pack is None:
+                self._pack = torch.empty(self.net.P.total, dtype=torch.bfloat16, device=seg.device)
+            pk = self._pack[lo:hi]
+            self._cast(seg, pk)
+            self._collective(pk)
+            self._cast(pk, seg)
+        else:
+            self._collective(seg)
 
     def ready(self, stage):
         if self.skip_allreduce == 2:
@@ -58,17 +128,23 @@ class GradReducer(object):
         end = min(self.bounds[stage], self.net.P.total)
         if end <= self.done:
             return
-        seg = self.net.P.grad[self.done:end]
+        lo = self.done
+        seg = self.net.P.grad[lo:end]
         if self.on_gpu:
             self.side.wait_stream(torch.cuda.current_stream())
             if getattr(self.net, 'use_streams', False) and hasattr(self.net, '_streams'):
                 for name in ('wg', 'wg2', 'lang', 'cap'):           # gradients are also produced on the side streams: the reducer
                     self.side.wait_stream(self.net._streams[name])  # waits for them, the main stream does not have to
             with torch.cuda.stream(self.side):
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 if not self.skip_allreduce:
-                    dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+                    self._exchange(seg, lo, end)
+                if self.timing:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    self._events.append((stage, end - lo, e0, e1))
         else:                                   # CPU/gloo path (tests)
-            dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+            self._exchange(seg, lo, end)
         self.done = end
 
     def finish(self):
@@ -78,6 +154,22 @@ class GradReducer(object):
         if self.done < P.total:
             self.ready('layer1')
         if self.on_gpu:
-            torch.cuda.current_stream().wait_stream(self.side)
+            main = torch.cuda.current_stream()
+            if self.timing:
+                a = torch.cuda.Event(enable_timing=True); a.record()
+            main.wait_stream(self.side)
+            if self.timing:
+                b = torch.cuda.Event(enable_timing=True); b.record()
+                self._wait_events = (a, b)
+                self._last_events, self._events = self._events, []
         self.done = 0
         # average over ranks: folded into the optimiser's grad_scale by the caller
+
+    def report(self):
+        """after a device sync: per-bucket exchange time and the exposed wait of the last finished step (timing=True)"""
+        if not self.timing or self._wait_events is None:
+            return None
+        esz = 2 if self.wire == 'bf16' else 4
+        return {'wire': self.wire, 'algo': self.algo,
+                'buckets': [{'stage': st, 'mbytes': n * esz / 1e6, 'ms': e0.elapsed_time(e1)} for st, n, e0, e1 in self._last_events],
+                'exposed_wait_ms': self._wait_events[0].elapsed_time(self._wait_events[1])}

@@ -79,3 +79,29 @@ def test_loader_index(tmp_path):
     assert enc[0, :3].tolist() == [3, 5, ld.word_to_ix['<UNK>']] and enc[1, 0] == 1 and enc[1, 1] == 0
     assert ld.decode_labels(enc)[1] == 'w1'
     assert ld.sentToRef[sid]['ref_id'] == info['refs'][1]['ref_id']
+
+
+def test_h5lite_reads_what_h5py_wrote(tmp_path):
+    """loaders/h5lite.py (no h5py in this image) against files written by h5py itself with the reference's own call
+    (tools/prepro.py:287-289: create_dataset('labels', dtype='int32', data=L)) - tests/golden/make_golden_h5.py, run with the one
+    interpreter of this container that has h5py: default (earliest) and latest file formats, several datasets and a sub-group in one file,
+    int32 / int64 / big-endian int16 / uint8, contiguous and compact layouts; chunked + gzip is refused by name."""
+    import os
+    from lang2seg_amd.loaders import h5lite
+    from lang2seg_amd.loaders.loader import load_labels
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'h5')
+    exp = np.load(os.path.join(d, 'expected.npz'))
+    for fn, name, key in (('data_prepro.h5', 'labels', 'data_prepro'), ('multi.h5', 'labels', 'multi_labels'), ('multi.h5', 'zzz_be', 'multi_zzz_be'),
+                          ('multi.h5', 'grp/inner', 'multi_inner'), ('latest.h5', 'labels', 'latest'), ('compact.h5', 'labels', 'compact')):
+        a = h5lite.File(os.path.join(d, fn))[name]
+        assert a.dtype == exp[key].dtype and a.shape == exp[key].shape and np.array_equal(a, exp[key]), (fn, name)
+    assert h5lite.File(os.path.join(d, 'multi.h5')).keys() == ['aaa', 'grp', 'labels', 'zzz_be']
+    assert np.array_equal(load_labels(os.path.join(d, 'data_prepro.h5')), exp['data_prepro'])        # the Loader's entry point
+    with pytest.raises(h5lite.H5LiteError, match='compress'):
+        h5lite.File(os.path.join(d, 'chunked_gzip.h5'))['labels']
+    with pytest.raises(KeyError):
+        h5lite.File(os.path.join(d, 'multi.h5'))['missing']
+    bad = tmp_path / 'x.h5'
+    bad.write_bytes(b'not an hdf5 file' * 40)
+    with pytest.raises(h5lite.H5LiteError):
+        h5lite.File(str(bad))

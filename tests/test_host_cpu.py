@@ -106,14 +106,26 @@ def _dp_worker(rank, world, port, ret):
     g = torch.Generator().manual_seed(100 + rank)
     P.grad.copy_(torch.randn(P.total, generator=g))
     mine = P.grad.clone()
-    red = GradReducer(net, world)
-    b = [red.bounds[s] for s in GradReducer.STAGES]
-    ok = all(x <= y for x, y in zip(b, b[1:])) and b[-1] == P.total
-    for s in ['caption', 'heads', 'language', 'layer3', 'layer2']:
-        red.ready(s)
-    red.finish()
     others = [torch.randn(P.total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
-    ok = ok and torch.allclose(P.grad, sum(others), atol=1e-6) and red.done == 0
+    ok = True
+    # every wire format x collective form: fp32 sums exact to rounding; bf16 buckets within the format's 2^-8 per addition
+    for wire, algo, tol in (('fp32', 'allreduce', 1e-6), ('fp32', 'rs_ag', 1e-6), ('bf16', 'allreduce', 3e-2), ('bf16', 'rs_ag', 3e-2)):
+        P.grad.copy_(mine)
+        red = GradReducer(net, world, wire=wire, algo=algo)
+        b = [red.bounds[s] for s in GradReducer.STAGES]
+        ok = ok and all(x <= y for x, y in zip(b, b[1:])) and b[-1] == P.total
+        for s in ['caption', 'heads', 'language', 'layer3:16', 'layer3:8', 'layer3', 'layer2']:
+            red.ready(s)
+        red.finish()
+        want = sum(others)
+        ok = ok and torch.allclose(P.grad, want, atol=tol * float(want.abs().max())) and red.done == 0
+        if wire == 'bf16':
+            ok = ok and not torch.equal(P.grad, want)          # the buckets really went through bf16
+        # every rank holds the same bits afterwards (the ranks must not drift apart)
+        chk = P.grad.double().sum().reshape(1).clone()
+        lst = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(lst, chk)
+        ok = ok and all(torch.equal(lst[0], x) for x in lst)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -124,6 +136,88 @@ def test_grad_reducer_gloo_world2():
     ret = ctx.Manager().dict()
     port = 29600 + os.getpid() % 300
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs)
+    assert ret.get(0) and ret.get(1)
+
+
+def test_dp_ready_flushes_queued_weight_gradients_first():
+    """Network.dp_ready: the queued weight gradients of the stage are launched BEFORE the bucket goes to the reducer (or to the early
+    optimiser update), whatever the backbone variant did or forgot"""
+    from lang2seg_amd.nets.network import Network
+    calls = []
+
+    class Red(object):
+        def ready(self, stage):
+            calls.append(('ready', stage))
+
+    class Early(object):
+        def partial(self, stage):
+            calls.append(('partial', stage))
+
+    class Stub(object):
+        _tape_stages = None
+        def flush_wgrads(self, tag):
+            calls.append(('flush', tag))
+    st = Stub(); st.dp = Red(); st._early_op = None
+    Network.dp_ready(st, 'layer3')
+    st2 = Stub(); st2.dp = None; st2._early_op = Early()
+    Network.dp_ready(st2, 'heads')
+    assert calls == [('flush', 'dp:layer3'), ('ready', 'layer3'), ('flush', 'dp:heads'), ('partial', 'heads')]
+
+
+def _dp_replay_worker(rank, world, port, ret):
+    """two ranks replay a (mock) launch tape cut at the bucket hand-offs: segment i produces the gradients of bucket i, everything not
+    yet produced is NaN - a bucket handed to the reducer too early, or a hand-off that is skipped, poisons or loses the sum"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lang2seg_amd._lib import F32
+    from lang2seg_amd.nets.params import ParamStore
+    from lang2seg_amd.parallel import GradReducer, replay_segments
+    from oracle import weights as OW
+    opt = OW.default_opt(vocab_size=37, seq_length=6)
+
+    class Net(object):
+        pass
+    net = Net(); net.P = ParamStore(opt, 50, 81, 12, 1, 'cpu', F32)
+    P = net.P
+    ok = True
+    for wire, algo in (('fp32', 'allreduce'), ('bf16', 'rs_ag')):
+        red = GradReducer(net, world, wire=wire, algo=algo)
+        stages = ['caption', 'heads', 'language', 'layer3:16', 'layer3:8', 'layer3', 'finish']      # what Network.tape_step records
+        ends = [red.bounds[s] for s in stages[:-1]] + [P.total]
+        src = [torch.randn(P.total, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+        P.grad.fill_(float('nan'))
+        log = []
+
+        def run_segment(i):
+            lo = 0 if i == 0 else ends[i - 1]
+            if i < len(ends):
+                P.grad[lo:ends[i]] = src[rank][lo:ends[i]]          # the backward stage of this segment wrote its bucket
+            log.append(i)
+        for _ in range(2):                                           # two replays of the same tape
+            P.grad.fill_(float('nan')); del log[:]
+            replay_segments(stages, run_segment, red)
+            want = sum(src)
+            tol = 1e-6 if wire == 'fp32' else 3e-2
+            ok = ok and log == list(range(len(stages) + 1)) and red.done == 0
+            ok = ok and bool(torch.isfinite(P.grad).all()) and torch.allclose(P.grad, want, atol=tol * float(want.abs().max()))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_dp_tape_segment_replay_gloo_world2():
+    """Network.tape_step's data-parallel replay loop (parallel.replay_segments) with two gloo ranks: every bucket reaches the reducer
+    after the segment that produces it and before the update segment, in both wire formats / collective forms."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_dp_replay_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -55,9 +55,9 @@ TOL = {0: 2e-5, 1: 5e-3}
     dict(n=256, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1),          # the dominant launch: layer4 @ 256 RoIs (M=12544, K=4608, 224x128 tile, tap-inner walk)
     dict(n=1, H=38, W=63, Cin=1024, Cout=512, k=3, s=1, p=1),         # RPN 3x3
     dict(n=256, H=7, W=7, Cin=1024, Cout=2048, k=1, s=1, p=0),        # layer4.0 downsample @ RoIs
-    dict(n=1, H=75, W=125, Cin=128, Cout=128, k=3, s=1, p=1),         # layer2 3x3 (patch kernel, wide rows)
+    dict(n=1, H=75, W=125, Cin=128, Cout=128, k=3, s=1, p=1),         # layer2 3x3 (wide rows)
     dict(n=1, H=5, W=3, Cin=64, Cout=36, k=3, s=1, p=1),              # a map smaller than one pixel tile, ragged channel tile
-    dict(n=2, H=19, W=23, Cin=64, Cout=64, k=3, s=1, p=1),            # two images: implicit GEMM (the patch kernel takes single maps)
+    dict(n=2, H=19, W=23, Cin=64, Cout=64, k=3, s=1, p=1),            # two images
 ])
 def test_conv_fwd(cfg, dt):
     O = ops()
@@ -181,35 +181,6 @@ def test_conv_ksplit_tile(cfg, algo):
         ref = (xr2 @ wr2.t()).view(n, H, W, Cout)
         assert rel_err(out.float()[:, ::2, ::2, :], ref) < TOL[dt]
         assert float(out.float()[:, 1::2, :, :].abs().max()) == 0.0
-
-
-@pytest.mark.parametrize('dt', [0, 1])
-@pytest.mark.parametrize('cfg', [dict(H=19, W=23, Cin=64, Cout=64), dict(H=38, W=63, Cin=256, Cout=256), dict(H=75, W=125, Cin=128, Cout=128),
-                                 dict(H=5, W=3, Cin=64, Cout=36), dict(H=38, W=63, Cin=1024, Cout=512)])
-def test_conv3x3_patch(cfg, dt):
-    """l2s_conv3x3_patch_try (direct 3x3 with one LDS-staged input patch for the nine taps, zero-padded virtual pixel layout) against
-    torch on the same rounded operands: bias + residual + ReLU epilogue, ReLU-mask epilogue (the data-gradient form), fp32 output."""
-    O = ops()
-    g = torch.Generator().manual_seed(8)
-    H, W, Cin, Cout = cfg['H'], cfg['W'], cfg['Cin'], cfg['Cout']
-    x = torch.randn(1, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
-    b = torch.randn(Cout, generator=g); res = torch.randn(1, Cout, H, W, generator=g)
-    xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
-    xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
-    conv = F.conv2d(xr, wr, None, padding=1)
-    y = O.empty((H * W, Cout), dt)
-    assert O.conv3x3_patch(xd, wd, y, 1, H, W, Cin, Cout, bias=b.to(DEV), add=rd, relu=True)
-    torch.cuda.synchronize()
-    assert rel_err(y.float().view(1, H, W, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
-    y2 = O.empty((H * W, Cout), dt)
-    assert O.conv3x3_patch(xd, wd, y2, 1, H, W, Cin, Cout, ref=rd)
-    torch.cuda.synchronize()
-    assert rel_err(y2.float().view(1, H, W, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
-    y3 = torch.empty((H * W, Cout), dtype=torch.float32, device=DEV)
-    assert O.conv3x3_patch(xd, wd, y3, 1, H, W, Cin, Cout, out_f32=True)
-    torch.cuda.synchronize()
-    assert rel_err(y3.view(1, H, W, Cout), nhwc(conv)) < (2e-5 if dt == 0 else 1e-4)
-    assert not O.conv3x3_patch(xd, wd, y3, 2, H, W, Cin, Cout)          # RoI batches / several images: not eligible
 
 
 @pytest.mark.parametrize('dt', [0, 1])

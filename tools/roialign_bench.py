@@ -1,5 +1,5 @@
 """Times l2s_roialign_bwd at the train-step size (256 RoIs on a 38x63x1024 map, 64 of them jittered copies of one box).
-L2S_ROIALIGN_ATOMIC=1 selects the scatter/atomic form."""
+"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,4 +22,4 @@ a.record()
 for _ in range(50):
     O.roialign_bwd(dout, H, W, C, rd, R, 7, 1.0 / 16.0, dfeat)
 b.record(); torch.cuda.synchronize()
-print('roialign_bwd %s: %.1f us' % ('atomic' if os.environ.get('L2S_ROIALIGN_ATOMIC') == '1' else 'gather', a.elapsed_time(b) * 1000 / 50))
+print('roialign_bwd %s: %.1f us' % ('gather', a.elapsed_time(b) * 1000 / 50))
