@@ -1624,13 +1624,17 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
   const bool desc_ok = (d->Cin % bk == 0) && xb < (1L << 31) && wb < (1L << 31) && !split_req;
   if (tapin_out) *tapin_out = ntaps > 1 && ntaps <= 32 && xb < (1L << 30);     // K walked channel-chunk-major, taps innermost
   const int algo = d->algo;
+  const int algo_base = algo == 7 ? L2S_ALGO_AUTO : algo;
   if (desc_ok) {
     const int KT = K / bk;
     const long tiles64 = (long)cdiv(M, 64) * cdiv(d->Cout, 64);
     // LDS-DMA 256x128 tile: wherever the large register-staged tiles were chosen, measured 59 vs 74 us on the dominant 3x3 and equal or
     // better on the 1x1 shapes (tools/dma_bench.py)
     const bool dma_ok = bf && !f32o && KT >= 3 && d->KH <= 3 && d->KW <= 3;
-    if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
+    if (dma_ok && (algo == L2S_ALGO_DMA || (algo_base == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
+    // experiment (bench.py --conv-algo 7): the N >= 1024 layer4@RoIs launches (128x128 ring tile: 230 VGPRs x 2 workgroups per CU fill
+    // every SIMD's register file, so the caption branch's small launches wait for a slot) on the DMA tile as well
+    if (dma_ok && algo == 7 && tile == 128 && M >= 8192) return PLAN_DMA256;
     if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;
     // K-split 64x64 tile with LDS-DMA fill: whole 128-channel pieces per tap.  Chosen for the 3x3 launches whose 64x64 tiles fit one round
     // of workgroups and that carry no ReLU-mask operand, i.e. forward launches: 13.8 -> 11.2 us (layer3), 61.6 -> 52.9 us (RPN); the 1x1
@@ -1639,7 +1643,7 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     const bool ks_ok = bf && !f32o && d->Cin % 128 == 0 && d->KH <= 3 && d->KW <= 3 && M * d->Cout * 4 < (1L << 31);
     if (ks_ok && algo == L2S_ALGO_KSPLIT) return PLAN_KS64;
     if (ks_ok && algo == L2S_ALGO_KSPLIT_D3) return PLAN_KS64_D3;
-    if (ks_ok && algo == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && tiles64 <= 256 && K >= 1024) return PLAN_KS64;
+    if (ks_ok && algo_base == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && tiles64 <= 256 && K >= 1024) return PLAN_KS64;
     if (tile == 224) return PLAN_SP224;
     if (tile == 256) return PLAN_SP256;
     if (tile == 128) return PLAN_RING128;
