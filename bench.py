@@ -41,6 +41,8 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fuse-roialign', type=int, default=0, help='A/B only: 1 = RoIAlign, layer4[0].conv1 and layer4[0].downsample as one launch (cfg.TRAIN.FUSE_ROIALIGN)')
+    ap.add_argument('--stream-alias', default='', help='A/B only: run one stream role on another role\'s stream, e.g. wg2=wg,tr=lang')
     ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
     ap.add_argument('--cpu-baseline-steps', default='3,10', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3: 3 + 10, ~2-3 min on the GPU box)')
     ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
@@ -279,6 +281,9 @@ def main(argv=None):
         from lang2seg_amd import ops as _O
         _O.CONV_ALGO = args.conv_algo
     net = resnetv1(opt, batch_size=1, num_layers=101)
+    net.fuse_roialign = bool(args.fuse_roialign)
+    if args.stream_alias:
+        type(net).STREAM_ALIAS = dict(kv.split('=') for kv in args.stream_alias.split(','))
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()
     net.rank_seed = rank * 1000003

@@ -204,6 +204,26 @@ int l2s_proposal_target(const float* rois, const float* roi_scores, const int* n
                         float* out_rois, int* labels, float* bbox_targets, float* bbox_inside, float* bbox_outside,
                         float* mask_targets, int* counts, int* ws, hipStream_t s);
 
+/* RoIAlign fused into the first bottleneck of the RoI head (bf16 activations): crop-and-resize (network_cycle_res5_2.py:107-149) feeding
+ * resnet.layer4[0].conv1 (+ frozen-BN shift + ReLU) and resnet.layer4[0].downsample (+ shift), resnet_v1_cycle_res5_2.py:271-273, in ONE
+ * launch, one workgroup per RoI.  `pooled` receives the P x P x C crop exactly as l2s_roialign_fwd writes it (the weight gradients and the
+ * backward pass read it; the forward pass does not).  Requirements: P*P <= 64, C % 128 == 0, P*P*C*2 + 4 KiB <= 160 KiB of LDS,
+ * N1 % 128 == 0, N2 % 128 == 0; L2S_EINVAL otherwise (callers fall back to l2s_roialign_fwd + two l2s_conv_igemm). */
+typedef struct {
+  const void* feat;        /* [H*W][C] bf16 */
+  const float* rois;       /* [R][5] (batch index, x1, y1, x2, y2) in image pixels */
+  const void* w1;          /* [N1][C] bf16 (BN scale folded) */
+  const float* b1;         /* [N1] or NULL */
+  const void* w2;          /* [N2][C] bf16 */
+  const float* b2;         /* [N2] or NULL */
+  void* pooled;            /* [R*P*P][C] bf16 */
+  void* y1;                /* [R*P*P][N1] bf16 = relu(pooled . w1^T + b1) */
+  void* y2;                /* [R*P*P][N2] bf16 = pooled . w2^T + b2 */
+  int H, W, C, R, P, N1, N2;
+  float spatial_scale;
+  int debug;               /* 0; tools/roi_block0_bench.py: 1 = no products, 2 = no weight loads behind the prologue, 4 = no stores */
+} l2s_roi_block0_desc;
+int l2s_roialign_block0_fwd(const l2s_roi_block0_desc* d, hipStream_t stream);
 /* crop-and-resize RoIAlign = affine_grid + grid_sample, align_corners=True, zero padding (NET:107-149) */
 int l2s_roialign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                      void* out, int dtype, hipStream_t s);

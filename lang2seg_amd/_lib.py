@@ -20,6 +20,11 @@ class ConvDesc(C.Structure):
                 ('out_h', i32), ('out_w', i32), ('out_stride', i32), ('tile', i32), ('split_k', i32), ('xcd_mode', i32), ('algo', i32), ('ws', vp)]
 
 
+class RoiBlock0Desc(C.Structure):
+    _fields_ = [('feat', vp), ('rois', vp), ('w1', vp), ('b1', vp), ('w2', vp), ('b2', vp), ('pooled', vp), ('y1', vp), ('y2', vp),
+                ('H', i32), ('W', i32), ('C', i32), ('R', i32), ('P', i32), ('N1', i32), ('N2', i32), ('spatial_scale', C.c_float), ('debug', i32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [('dy', vp), ('x', vp), ('dw', vp),
                 ('n_img', i32), ('IH', i32), ('IW', i32), ('Cin', i32), ('OH', i32), ('OW', i32), ('Cout', i32),
@@ -58,6 +63,7 @@ LOSS_RPN_CLS, LOSS_RPN_BOX, LOSS_CLS, LOSS_BOX, LOSS_MASK, LOSS_CAP, LOSS_TOTAL,
 SIGS = {
     'l2s_version': (i32, []),
     'l2s_conv_plan_name': (C.c_char_p, [vp, i32]),
+    'l2s_roialign_block0_fwd': (i32, [C.POINTER(RoiBlock0Desc), vp]),
     'l2s_conv_igemm': (i32, [C.POINTER(ConvDesc), i32, vp]),
     'l2s_conv_wgrad': (i32, [C.POINTER(WgradDesc), i32, vp]),
     'l2s_wgrad_ws_bytes': (sz, [C.POINTER(WgradDesc), i32]),

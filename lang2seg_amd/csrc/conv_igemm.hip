@@ -19,6 +19,7 @@
 // conflict-free.  The MFMA is issued with operands swapped (rows = n, cols = m) so that each lane ends
 // up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 #include "common.h"
+#include "roi_sample.h"
 #include "../../include/lang2seg_hip.h"
 #include <stdlib.h>
 
@@ -1494,6 +1495,142 @@ __global__ __launch_bounds__(512) void igemm_ks64_kernel(const l2s_conv_desc p) 
   igemm_epilogue<T, 1, 4, 16, 64, false>(p, fin, m0, n0, wave, 0, fr, fg, M);
 }
 
+// ------------------------------------------------------------------------------------------------
+// RoIAlign fused into the first bottleneck of the RoI head (bf16): crop-and-resize (NET:107-149) -> layer4.0.conv1 (1x1, + bias + ReLU) and
+// layer4.0.downsample (1x1, + bias), RES:271-273 - three launches of the unfused path (the crop kernel and two convolutions that each
+// re-read the 25.7 MB crop) in one.  ONE WORKGROUP PER RoI (256 RoIs = 256 compute units):
+//   * the P x P x C crop of the RoI (49 x 1024 bf16 = 98 KiB) is gathered ONCE, by all 512 threads, into LDS - bilinear blend in fp32,
+//     one rounding, the arithmetic of the stand-alone crop kernel (roi_sample.h) - and written once to `pooled`: the weight gradients
+//     of both convolutions and the backward pass read it, the forward pass never does again;
+//   * the two weight matrices are then walked as ONE matrix of N1 + N2 rows: wave w owns columns 16 w .. 16 w + 15 of every
+//     128-column tile and reads its weights STRAIGHT INTO MFMA B-FRAGMENT LAYOUT (a [Cout][K] row is K-contiguous: 16 bytes per lane),
+//     eight 128-byte K slices ahead in registers - no LDS, no barrier and no cross-wave traffic for half of the operand bytes; the crop
+//     fragments come from LDS (8 reads for 8 MFMAs per slice).  Rows 49..63 of the fourth row tile alias row 48 and are never stored.
+// What paces it: every workgroup streams all (N1 + N2) x C weights (5.2 MB) from L2 - the price of gathering the crop once.  The first
+// form of this kernel staged the weights through a three-stage LDS-DMA ring (16 KiB per slice, all the LDS the crop leaves): 173-183 us,
+// because 32 KiB in flight per CU is a third of what the L2 round trip needs; the register ring keeps 128 KiB in flight.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void roialign_block0_kernel(const l2s_roi_block0_desc p) {
+  typedef bf16_t T;
+  constexpr int BN = 128, PF = 8;                                       // columns per tile; K slices of weights in flight per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int roi = blockIdx.x, PP = p.P * p.P, C = p.C;
+  const int rowb = C * 2;                                               // bytes of one crop row in LDS
+  char* As = smem;                                                      // [PP][C] bf16, 16-byte chunks XOR-swizzled by (row & 15)
+  const T* __restrict__ feat = (const T*)p.feat;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- weight stream: slice t = (n-tile t / KS, K slice t % KS) of the N1 + N2 rows ----
+  const int KS = C / 64, NT1 = p.N1 / BN, NT = NT1 + p.N2 / BN, TOT = NT * KS;
+  const auto rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (int)((long)p.N1 * C * 2L), 0x00020000);
+  const auto rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (int)((long)p.N2 * C * 2L), 0x00020000);
+  const unsigned voffB = (unsigned)(((16 * wave + fr) * C + fg * 8) * 2);
+  int rq_nt = 0, rq_ks = 0;                                             // request cursor
+  uint4 pf[PF][2];
+  auto request = [&](uint4 (&dst)[2]) {
+    const bool first = rq_nt < NT1;
+    const int ntr = first ? rq_nt : rq_nt - NT1;
+    const unsigned so = (unsigned)((ntr * BN * C + rq_ks * 64) * 2);
+    const auto r = first ? rw1 : rw2;
+    dst[0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voffB, so, 0));
+    dst[1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voffB, so + 64u, 0));
+    if (++rq_ks == KS) { rq_ks = 0; ++rq_nt; }
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+    if (j < TOT) request(pf[j]);
+
+  // ---- the crop: sample table, then 8 channels per thread and step ----
+  {
+    RoiTaps* tab = (RoiTaps*)(smem + PP * rowb);
+    if (tid < PP) {
+      const int py = tid / p.P, px = tid - py * p.P;
+      tab[tid] = roi_taps(roi_sample(p.rois + roi * 5, p.H, p.W, p.P, py, px, p.spatial_scale, (float)p.H, (float)p.W), p.H, p.W, C);
+    }
+    __syncthreads();
+    const int cpr = C / 8;                                              // 16-byte chunks per row
+    T* pooled = (T*)p.pooled + (long)roi * PP * C;
+    // four chunks per trip: their sixteen loads are requested before the first blend (the taps are branch-free, roi_sample.h); one chunk per
+    // trip waited for its own loads thirteen times over (54 us for this phase alone)
+    constexpr int UN = 4;
+    const int total = PP * cpr;
+    for (int i0 = tid; i0 < total; i0 += 512 * UN) {
+      RoiQuad q[UN]; int row[UN], ch[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = min(i0 + 512 * u, total - 1);
+        row[u] = idx / cpr; ch[u] = idx - row[u] * cpr;
+        q[u] = roi_load8(feat, tab[row[u]], ch[u] * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (i0 + 512 * u < total) {
+          const uint4 v = roi_mix8(q[u], tab[row[u]]);
+          *(uint4*)(As + row[u] * rowb + ((ch[u] ^ (row[u] & 15)) << 4)) = v;
+          *(uint4*)(pooled + (long)row[u] * C + ch[u] * 8) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- the product ----
+  int arow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) arow[i] = min(16 * i + fr, PP - 1);
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int nt = 0, ks = 0;
+  auto step = [&](uint4 (&fb)[2], bool more) {
+    if (p.debug & 1) { acc[0][0] += __uint_as_float(fb[0].x ^ fb[1].y); }
+    else {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int ch = ks * 8 + kg * 4 + fg;
+      uint4 fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const uint4*)(As + arow[i] * rowb + ((ch ^ (arow[i] & 15)) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = Mma<T>::run(fb[kg], fa[i], acc[i]);
+    }
+    }
+    if (more && !(p.debug & 2)) request(fb);                            // the register pair just consumed takes the slice PF ahead
+    if (++ks == KS) {
+      // this wave's 16 columns of the 128-column tile are complete: + bias (+ ReLU for conv1), 4 channels = 8 bytes per lane and row tile
+      const bool first = nt < NT1;
+      const int n = (first ? nt : nt - NT1) * BN + 16 * wave + fg * 4;
+      const float* bias = first ? p.b1 : p.b2;
+      const int ldy = first ? p.N1 : p.N2;
+      T* y = (T*)(first ? p.y1 : p.y2) + (long)roi * PP * ldy + n;
+      const f32x4 bv = bias ? *(const f32x4*)(bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 16 * i + fr;
+        float v0 = acc[i][0] + bv[0], v1 = acc[i][1] + bv[1], v2 = acc[i][2] + bv[2], v3 = acc[i][3] + bv[3];
+        if (first) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        if (row < PP && !((p.debug & 4) && nt > 0)) {
+          uint2 pk;
+          pk.x = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16); pk.y = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
+          *(uint2*)(y + (long)row * ldy) = pk;
+        }
+        acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      ks = 0; ++nt;
+    }
+  };
+  int t = 0;
+  for (; t + 2 * PF <= TOT; t += PF) {                                  // steady state: every slice re-arms its register pair
+#pragma unroll
+    for (int j = 0; j < PF; ++j) step(pf[j], true);
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * PF; ++j)                                      // tail: fewer than 2 PF slices left
+    if (t + j < TOT) step(pf[j % PF], t + j + PF < TOT);
+}
+
 // y = epilogue(ws) and ws = 0 (so the workspace is clean for the next split-K launch)
 template <typename T, bool OUTF32>
 __global__ void splitk_epilogue_kernel(const l2s_conv_desc p, long total) {
@@ -1566,6 +1703,14 @@ int launch_igemm_sp(const l2s_conv_desc& d, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32, TAPIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   L2S_LAUNCH((igemm_sp_kernel<T, BM, BN, WGM, WGN, D, OUTF32, TAPIN>), grid, dim3(64 * WGM * WGN), lds, st, d);
+  return l2s_check_launch();
+}
+
+int launch_roialign_block0(const l2s_roi_block0_desc& d, hipStream_t st) {
+  const size_t lds = (size_t)d.P * d.P * d.C * 2 + 64 * sizeof(RoiTaps);   // the crop + the sample table
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)roialign_block0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+  L2S_LAUNCH(roialign_block0_kernel, dim3(d.R), dim3(512), lds, st, d);
   return l2s_check_launch();
 }
 
@@ -1696,4 +1841,14 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   }
 #undef BYT
 #undef OUT
+}
+
+extern "C" int l2s_roialign_block0_fwd(const l2s_roi_block0_desc* d, hipStream_t stream) {
+  if (!d || !d->feat || !d->rois || !d->w1 || !d->w2 || !d->pooled || !d->y1 || !d->y2) return L2S_EINVAL;
+  const int PP = d->P * d->P;
+  // one RoI per workgroup: the crop must fit LDS next to the weight ring, its rows are whole 128-byte K slices, the outputs whole 128-column tiles
+  if (d->R <= 0 || PP < 1 || PP > 64 || d->C % 128 || d->N1 % 128 || d->N2 % 128 || d->N1 <= 0 || d->N2 <= 0) return L2S_EINVAL;
+  if ((size_t)PP * d->C * 2 + 64 * sizeof(RoiTaps) > 160 * 1024) return L2S_EINVAL;
+  if ((long)d->H * d->W * d->C * 2 >= (1L << 31) || (long)d->N1 * d->C * 2 >= (1L << 31) || (long)d->N2 * d->C * 2 >= (1L << 31)) return L2S_EINVAL;
+  return launch_roialign_block0(*d, stream);
 }

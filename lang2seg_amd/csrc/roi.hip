@@ -6,6 +6,7 @@
 // nms/src/nms_cuda.c} and nets/network_cycle_res5_2.py:107-149.  Integer / byte / compare work: HBM- and
 // latency-bound, wave64-native (one u64 NMS mask word per lane).
 #include "common.h"
+#include "roi_sample.h"
 #include "../../include/lang2seg_hip.h"
 
 namespace {
@@ -759,24 +760,6 @@ __global__ __launch_bounds__(1024) void ptl_kernel(const float* rois_in, const f
 }
 
 // ------------------------------------------------------------------ RoIAlign (crop-and-resize)
-struct Samp { int x0, y0; float wx1, wy1; };
-__device__ __forceinline__ Samp roi_sample(const float* roi, int H, int W, int P, int py, int px, float sscale, float TH, float TW) {
-  // NET:122-147: theta from roi/16 over the map size, (TH, TW) = (H, W); NET:151-182 (_crop_pool_layer_align): theta from the roi in
-  // image pixels over the image size, (TH, TW) = im_info and sscale = 1; affine_grid + grid_sample, align_corners = True
-  const float x1 = roi[1] * sscale, y1 = roi[2] * sscale, x2 = roi[3] * sscale, y2 = roi[4] * sscale;
-  const float t00 = (x2 - x1) / (TW - 1.f), t02 = (x1 + x2 - TW + 1.f) / (TW - 1.f);
-  const float t11 = (y2 - y1) / (TH - 1.f), t12 = (y1 + y2 - TH + 1.f) / (TH - 1.f);
-  const float step = 2.f / (float)(P - 1);
-  // torch.linspace(-1, 1, P): start-based for i < P/2, end-based otherwise
-  const float bx = (px < P / 2) ? (-1.f + step * (float)px) : (1.f - step * (float)(P - 1 - px));
-  const float by = (py < P / 2) ? (-1.f + step * (float)py) : (1.f - step * (float)(P - 1 - py));
-  const float gx = t00 * bx + t02, gy = t11 * by + t12;
-  const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1), iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
-  Samp s;
-  const float fx = floorf(ix), fy = floorf(iy);
-  s.x0 = (int)fx; s.y0 = (int)fy; s.wx1 = ix - fx; s.wy1 = iy - fy;
-  return s;
-}
 __global__ void roialign_fwd_kernel(const void* feat, int H, int W, int C, const float* rois, int P, float sscale, float TH, float TW, void* out, int dt) {
   const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
   const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW);
@@ -791,33 +774,12 @@ __global__ void roialign_fwd_kernel(const void* feat, int H, int W, int C, const
     stx(out, (long)cell * C + c, dt, v);
   }
 }
-// bf16, C % 8 == 0: 8 channels (16 bytes) per thread; same arithmetic order as the scalar kernel
+// bf16, C % 8 == 0: 8 channels (16 bytes) per thread; same arithmetic order as the scalar kernel (roi_sample.h: roi_blend8)
 __global__ __launch_bounds__(128) void roialign_fwd_bf16x8_kernel(const bf16_t* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois, int P,
                                                                  float sscale, float TH, float TW, bf16_t* out) {
   const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;
-  const Samp s = roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW);
-  const float w00 = (1.f - s.wx1) * (1.f - s.wy1), w01 = s.wx1 * (1.f - s.wy1), w10 = (1.f - s.wx1) * s.wy1, w11 = s.wx1 * s.wy1;
-  const bool vx0 = s.x0 >= 0 && s.x0 < W, vx1 = s.x0 + 1 >= 0 && s.x0 + 1 < W, vy0 = s.y0 >= 0 && s.y0 < H, vy1 = s.y0 + 1 >= 0 && s.y0 + 1 < H;
-  for (int c = threadIdx.x * 8; c < C; c += blockDim.x * 8) {
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    auto tap = [&](bool ok, int y, int x, float w) {
-      if (!ok) return;
-      const uint4 q = *(const uint4*)(feat + ((long)y * W + x) * C + c);
-      const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[2 * e] += w * __uint_as_float(qw[e] << 16); v[2 * e + 1] += w * __uint_as_float(qw[e] & 0xFFFF0000u); }
-    };
-    tap(vy0 && vx0, s.y0, s.x0, w00);
-    tap(vy0 && vx1, s.y0, s.x0 + 1, w01);
-    tap(vy1 && vx0, s.y0 + 1, s.x0, w10);
-    tap(vy1 && vx1, s.y0 + 1, s.x0 + 1, w11);
-    uint4 o;
-    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-    *(uint4*)(out + (long)cell * C + c) = o;
-  }
+  const RoiTaps t = roi_taps(roi_sample(rois + r * 5, H, W, P, py, px, sscale, TH, TW), H, W, C);
+  for (int c = threadIdx.x * 8; c < C; c += blockDim.x * 8) *(uint4*)(out + (long)cell * C + c) = roi_blend8(feat, t, c);
 }
 __global__ void roialign_bwd_kernel(const void* dout, int H, int W, int C, const float* rois, int P, float sscale, float TH, float TW, float* dfeat, int dt) {
   const int cell = blockIdx.x, r = cell / (P * P), rem = cell - r * P * P, py = rem / P, px = rem - py * P;

@@ -61,6 +61,9 @@ __C.TRAIN.SNAPSHOT_ITERS = 5000
 __C.TRAIN.SNAPSHOT_PREFIX = 'res101_mask_rcnn'
 # replay steps from per-shape launch tapes in train_net (see model/train_val.py)
 __C.TRAIN.USE_TAPE = True
+# RoIAlign + layer4[0].conv1 + layer4[0].downsample as ONE launch, one workgroup per RoI (l2s_roialign_block0_fwd, bf16): bit-identical to
+# the three launches it replaces and measured slower (170 vs 121 us: every workgroup streams all 5.2 MB of weights), so it is opt-in
+__C.TRAIN.FUSE_ROIALIGN = False
 __C.TRAIN.BBOX_NORMALIZE_TARGETS = True
 __C.TRAIN.BBOX_INSIDE_WEIGHTS = (1.0, 1.0, 1.0, 1.0)
 __C.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = True

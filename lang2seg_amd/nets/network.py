@@ -210,6 +210,16 @@ class Bottleneck(object):
             self.c3.fwd(a2, n, OH, OW, y, add=x, relu=True)
         return y, OH, OW, (x, a1, a2, IH, IW, OH, OW, n)
 
+    def fwd_rest(self, x, a1, sc, n, IH, IW, tag):
+        """the block behind its first two 1x1 convolutions: a1 = relu(conv1(x)) and sc = downsample(x) were produced by the caller
+        (the fused RoIAlign kernel, l2s_roialign_block0_fwd); stride 1 only"""
+        net = self.net
+        a2 = net.buf(tag + '.a2', (n * IH * IW, self.planes))
+        y = net.buf(tag + '.y', (n * IH * IW, self.planes * 4))
+        self.c2.fwd(a1, n, IH, IW, a2, relu=True)
+        self.c3.fwd(a2, n, IH, IW, y, add=sc, relu=True)
+        return y, IH, IW, (x, a1, a2, IH, IW, IH, IW, n)
+
     def bwd(self, g, saved, tag, x_is_relu_out=True):
         """g = dL/d(pre-ReLU sum) (already masked by y > 0).  Returns dL/dx masked by x > 0 when x is a ReLU output."""
         net = self.net
@@ -257,6 +267,7 @@ class Network(object):
         self._early_op = None       # optimiser taking early partial updates during backward (optim.SGD.partial)
         self.wgq = WgradQueue(self) # weight gradients of the current backward stage, launched together by flush_wgrads()
         self.cap_projected = True   # captioner recurrence in the projected-attention form (3 launches per token)
+        self.fuse_roialign = bool(cfg.TRAIN.get('FUSE_ROIALIGN', False))   # RoIAlign + layer4[0].conv1 + layer4[0].downsample as one launch (bf16)
         self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'cap'); set by bench.py --knockout
 
     # ------------------------------------------------------------------ construction
@@ -288,11 +299,14 @@ class Network(object):
 
     # ------------------------------------------------------------------ HIP streams
     use_streams = True
+    STREAM_ALIAS = {}
 
     def streams(self):
         if not hasattr(self, '_streams'):
             mk = lambda n: torch.cuda.Stream()          # (no priorities: any priority stream halves throughput on this stack)
             self._streams = dict(lang=mk('lang'), cap=mk('cap'), wg=mk('wg'), wg2=mk('wg2'), tr=mk('tr'))
+            for a, b in self.STREAM_ALIAS.items():           # two roles on one stream (the runtime maps streams onto 4 hardware queues)
+                self._streams[a] = self._streams[b]
             self._wg_flip = 0
         return self._streams
 

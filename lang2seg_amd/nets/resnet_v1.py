@@ -475,9 +475,25 @@ class resnetv1(Network):
         P, dt, t = self.P, self.dt, self.t
         C4, nc = self._C4_feat_dim, self._num_classes
         PS, MS = int(cfg.POOLING_SIZE), int(cfg.MASK_SIZE)
-        pool5 = self._rois_pool_fwd(net_conv, Hc, Wc, rois, R, saved)
-        x, hh, ww = pool5, PS, PS
+        blk0 = self.layers[4][0]
+        kind, CS, mp = self._pool_mode()
+        fused = (self.fuse_roialign and dt == BF16 and kind == 'crop' and not mp and blk0.down is not None and blk0.stride == 1 and
+                 O.roialign_block0_ok(C4, PS, blk0.planes, blk0.planes * 4))
+        if fused:
+            # crop-and-resize + layer4[0].conv1 + layer4[0].downsample in one launch, one workgroup per RoI; the crop is still written
+            # (once) for the weight gradients and the backward pass
+            pool5 = self.buf('roi.pool5', (R * PS * PS, C4))
+            a1 = self.buf('l4r.0.a1', (R * PS * PS, blk0.planes)); sc = self.buf('l4r.0.sc', (R * PS * PS, blk0.planes * 4))
+            O.roialign_block0_fwd(net_conv, Hc, Wc, C4, rois, R, PS, 1.0 / 16.0, blk0.c1.wf, blk0.c1.bias, blk0.planes,
+                                  blk0.down.wf, blk0.down.bias, blk0.planes * 4, pool5, a1, sc)
+            x, hh, ww, sv = blk0.fwd_rest(pool5, a1, sc, R, PS, PS, 'l4r.0')
+            saved[('4r', 0)] = sv
+        else:
+            pool5 = self._rois_pool_fwd(net_conv, Hc, Wc, rois, R, saved)
+            x, hh, ww = pool5, PS, PS
         for b, blk in enumerate(self.layers[4]):
+            if fused and b == 0:
+                continue
             x, hh, ww, sv = blk.fwd(x, R, hh, ww, 'l4r.%d' % b)
             saved[('4r', b)] = sv
         fc7s = x

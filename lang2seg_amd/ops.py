@@ -130,6 +130,21 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     return y
 
 
+def roialign_block0_fwd(feat, H, W, C_, rois, R, P, spatial_scale, w1, b1, N1, w2, b2, N2, pooled, y1, y2, debug=0):
+    """RoIAlign fused into layer4[0].conv1 (+ shift + ReLU) and layer4[0].downsample (+ shift): one launch, one workgroup per RoI (bf16)"""
+    d = _lib.RoiBlock0Desc()
+    d.feat, d.rois, d.w1, d.b1, d.w2, d.b2 = ptr(feat), ptr(rois), ptr(w1), ptr(b1), ptr(w2), ptr(b2)
+    d.pooled, d.y1, d.y2 = ptr(pooled), ptr(y1), ptr(y2)
+    d.H, d.W, d.C, d.R, d.P, d.N1, d.N2, d.spatial_scale = H, W, C_, R, P, N1, N2, float(spatial_scale)
+    d.debug = debug
+    call('l2s_roialign_block0_fwd', C.byref(d), stream())
+
+
+def roialign_block0_ok(C_, P, N1, N2):
+    """the fused kernel's shape requirements (include/lang2seg_hip.h)"""
+    return P * P <= 64 and C_ % 128 == 0 and N1 % 128 == 0 and N2 % 128 == 0 and P * P * C_ * 2 + 4096 <= 160 * 1024
+
+
 def _wgrad_desc(dy, x, dw, n_img, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, lddy, ldx, split_k, tile, ws):
     d = WgradDesc()
     d.dy, d.x, d.dw = ptr(dy), ptr(x), ptr(dw)

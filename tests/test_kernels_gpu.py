@@ -132,6 +132,48 @@ def test_conv_dma_tile(cfg, ALGO_DMA):
     assert torch.equal(y2, y3)
 
 
+@pytest.mark.parametrize('cfg', [dict(H=38, W=63, C=1024, R=256, N1=512, N2=2048), dict(H=20, W=26, C=1024, R=37, N1=512, N2=2048),
+                                 dict(H=10, W=14, C=256, R=5, N1=128, N2=256)])
+def test_roialign_fused_into_layer4_block0(cfg):
+    """l2s_roialign_block0_fwd (crop-and-resize + layer4[0].conv1 + layer4[0].downsample in one launch, one workgroup per RoI) against
+    (a) the oracle's _crop_pool_layer restatement followed by the two 1x1 convolutions in fp32 on the same rounded operands, and
+    (b) the three launches it replaces (l2s_roialign_fwd + two l2s_conv_igemm), bit for bit: same crop arithmetic (roi_sample.h), same
+    order of the K slices.  RoIs reach over the map's borders (zero padding) and include a degenerate one."""
+    O = ops()
+    H, W, C, R, N1, N2 = [cfg[k] for k in ('H', 'W', 'C', 'R', 'N1', 'N2')]
+    P = 7
+    g = torch.Generator().manual_seed(21)
+    feat = torch.randn(H * W, C, generator=g)
+    rs = np.random.RandomState(3)
+    x1 = rs.uniform(-40, W * 16 - 60, R); y1 = rs.uniform(-40, H * 16 - 60, R)
+    rois = np.stack([np.zeros(R), x1, y1, x1 + rs.uniform(8, 400, R), y1 + rs.uniform(8, 300, R)], 1).astype(np.float32)
+    rois[0] = [0, 5.0, 7.0, 5.0, 7.0]                                  # a point
+    w1 = torch.randn(N1, C, generator=g) / np.sqrt(C); w2 = torch.randn(N2, C, generator=g) / np.sqrt(C)
+    b1 = torch.randn(N1, generator=g); b2 = torch.randn(N2, generator=g)
+    fd, w1d, w2d = to_dev(feat, 1), to_dev(w1, 1), to_dev(w2, 1)
+    rd = torch.from_numpy(rois).to(DEV)
+    pooled = torch.full((R * P * P, C), float('nan'), dtype=torch.bfloat16, device=DEV)
+    y1_ = torch.full((R * P * P, N1), float('nan'), dtype=torch.bfloat16, device=DEV)
+    y2_ = torch.full((R * P * P, N2), float('nan'), dtype=torch.bfloat16, device=DEV)
+    O.roialign_block0_fwd(fd, H, W, C, rd, R, P, 1.0 / 16.0, w1d, b1.to(DEV), N1, w2d, b2.to(DEV), N2, pooled, y1_, y2_)
+    torch.cuda.synchronize()
+    # (b) the unfused launches
+    crop = torch.empty_like(pooled); u1 = torch.empty_like(y1_); u2 = torch.empty_like(y2_)
+    O.roialign_fwd(fd, H, W, C, rd, R, P, 1.0 / 16.0, crop)
+    O.conv_igemm(crop, w1d, u1, R, P, P, C, P, P, N1, bias=b1.to(DEV), relu=True)
+    O.conv_igemm(crop, w2d, u2, R, P, P, C, P, P, N2, bias=b2.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(pooled, crop)
+    assert torch.equal(y1_, u1) and torch.equal(y2_, u2)
+    # (a) the oracle's crop on the rounded map, then fp32 products
+    net = ON.OracleNet.__new__(ON.OracleNet); net.cfg = ON.DEFAULT_CFG; net.var = {}
+    ref_crop = net.crop_pool(fd.float().cpu().view(1, H, W, C).permute(0, 3, 1, 2), torch.from_numpy(rois)).permute(0, 2, 3, 1).reshape(R * P * P, C)
+    assert rel_err(pooled.float(), ref_crop) < 1e-2
+    pc = pooled.float().cpu()
+    assert rel_err(y1_.float(), F.relu(pc @ w1d.float().cpu().t() + b1)) < TOL[1]
+    assert rel_err(y2_.float(), pc @ w2d.float().cpu().t() + b2) < TOL[1]
+
+
 @pytest.mark.parametrize('algo', [5, 6])
 @pytest.mark.parametrize('cfg', [
     dict(n=1, H=38, W=63, Cin=256, Cout=256, k=3, s=1, p=1),          # layer3 3x3: 18 slices of 128 channels, image borders, ragged pixel tile

@@ -676,6 +676,26 @@ def test_tape_stops_recording_when_shapes_keep_changing():
     assert len(net._tapes) == 3 and all(np.isfinite(v) for v in a)
 
 
+def test_fused_roialign_step_is_bit_identical():
+    """cfg.TRAIN.FUSE_ROIALIGN (crop-and-resize + layer4[0].conv1 + layer4[0].downsample in one launch): the bf16 train step with it gives the
+    same crop and the same gradient buffer, bit for bit, as the three launches it replaces (same crop arithmetic, same K order)."""
+    from lang2seg_amd import selftest
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    blob = OS.make_blob(320, 416, 6, 60, seed=5)
+    over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
+    out = []
+    for fuse in (False, True):
+        net = selftest.build_net(opt, over, 'bf16', sd)
+        net.fuse_roialign = fuse
+        lv = net.forward_backward(net.upload_blob(dict(blob), 0)).cpu().numpy()
+        torch.cuda.synchronize()
+        out.append((lv.copy(), net.P.grad.clone(), net.t['pool5'].clone()))
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-5, atol=1e-6), (out[0][0], out[1][0])     # (the reported loss scalars are summed with atomics)
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize('variant', ['cycle', 'vgg'])
 def test_no_gradient_lands_behind_its_bucket(variant):
     """Data parallel: a gradient bucket may only be handed to the reducer when every weight gradient of its stage has been launched
