@@ -42,8 +42,9 @@ def parse_args(argv=None):
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fuse-roialign', type=int, default=0, help='A/B only: 1 = RoIAlign, layer4[0].conv1 and layer4[0].downsample as one launch (cfg.TRAIN.FUSE_ROIALIGN)')
-    ap.add_argument('--stream-alias', default='', help='A/B only: run one stream role on another role\'s stream, e.g. wg2=wg,tr=lang')
     ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
+    ap.add_argument('--sgd-early', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.early on / off (update each finished prefix of the flat buffer during backward; one rank only)')
+    ap.add_argument('--lib', default='', help='A/B only: load this build of the C-ABI library instead of the in-tree one (tools/ab_build.sh <rev>); the line is marked')
     ap.add_argument('--cpu-baseline-steps', default='3,10', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3: 3 + 10, ~2-3 min on the GPU box)')
     ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
     ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
@@ -242,6 +243,9 @@ def main(argv=None):
     import numpy as np
     import torch
     import torch.distributed as dist
+    if args.lib:
+        from lang2seg_amd import _lib as _L
+        _L.LIB_PATH = os.path.abspath(args.lib)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
 
     if args.launcher_check:
@@ -282,8 +286,6 @@ def main(argv=None):
         _O.CONV_ALGO = args.conv_algo
     net = resnetv1(opt, batch_size=1, num_layers=101)
     net.fuse_roialign = bool(args.fuse_roialign)
-    if args.stream_alias:
-        type(net).STREAM_ALIAS = dict(kv.split('=') for kv in args.stream_alias.split(','))
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()
     net.rank_seed = rank * 1000003
@@ -294,6 +296,8 @@ def main(argv=None):
     if use_dp and args.dp_skip_allreduce != 3:
         from lang2seg_amd.parallel import GradReducer
         net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce, wire=args.dp_wire, algo=args.dp_algo, timing=True)
+    if args.sgd_early >= 0:
+        SGD.early = bool(args.sgd_early)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
     loader = SyntheticLoader(num_images=4, sents_per_image=1, H=args.height, W=args.width, T=T, vocab_size=V, rank=rank)
     blobs = [loader.getBatch('train') for _ in range(4)]
@@ -412,6 +416,8 @@ def main(argv=None):
             'final_losses': [float(x) for x in lv[:7]],
         }
         out.update(extras)
+        if args.lib:
+            out['lib'] = 'A/B run with ' + args.lib
         if experiment:
             out['experiment'] = 'INVALID as a measurement: knockout=%s dp_skip_allreduce=%d' % (sorted(net.knockout), args.dp_skip_allreduce)
         if args.extras:

@@ -42,6 +42,7 @@ int l2s_version(void);
 #define L2S_ALGO_DMA_STAMPED 4 /* the same kernel with in-kernel clock stamps written to `ws` (tools/dma_stamps.py) */
 #define L2S_ALGO_KSPLIT 5      /* 64x64 tile, LDS-DMA fill by four requester waves, four multiplier waves splitting each slice's K */
 #define L2S_ALGO_KSPLIT_D3 6   /* the same with a ring of three LDS stages instead of four */
+#define L2S_ALGO_WS64_STAMPED 8  /* the 64x64 wave-specialised tile with clock stamps per workgroup in ws (tools/ws64_stamps.py) */
 typedef struct {
   const void* x;      /* [n_img, IH, IW, ldx] activations (dtype) */
   const void* w;      /* [Cout][KH*KW*Cin] (dtype) */
@@ -54,10 +55,11 @@ typedef struct {
   int flags;
   int out_h, out_w, out_stride; /* SCATTER */
   int tile;                     /* 0 = auto, 64, 128, 224 or 256 (rows of the workgroup tile) */
-  int split_k;                  /* 0 = auto, 1 = off, n = force (needs ws) */
+  int split_k;                  /* K split over workgroups, partial tiles added in a fixed order by a second launch: 0 = auto, 1 = off, n = force (needs ws) */
   int xcd_mode;                 /* tile order over the 8 XCDs: -1 = auto, 0 = M-chunks, 1 = N-chunks (speed only) */
   int algo;                     /* kernel family: 0 = auto; L2S_ALGO_* forces one (benchmarks / tests; same arithmetic, speed only) */
-  float* ws;                    /* optional ALL-ZERO float workspace >= rows*Cout for split-K partial sums; returned all-zero */
+  float* ws;                    /* optional float workspace for split-K partial sums: split x rows x Cout floats (any contents; one per stream) */
+  size_t ws_floats;             /* its size; the split is reduced until the slabs fit */
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);
 /* name of the kernel l2s_conv_igemm launches for this problem (reporting: bench.py's roofline object); static storage */

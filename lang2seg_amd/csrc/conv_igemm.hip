@@ -148,7 +148,7 @@ __device__ __forceinline__ void igemm_epilogue_fast(const l2s_conv_desc& p, f32x
 // igemm_epilogue_fast (bias, residual, ReLU, mask in fp32, one rounding). ----
 template <int TM, int TN, int WM, int WN, int WGM, int NT, int BN, int PASSES>
 __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M, char* smem,
-                                                      const u32x4v* pre_add = nullptr, const u32x4v* pre_ref = nullptr) {
+                                                      const u32x4v* pre_add = nullptr, const u32x4v* pre_ref = nullptr, const f32x4* pre_bias = nullptr) {
   // pre_add / pre_ref (single-pass tiles): the residual / ReLU-mask operands of this thread's chunks, requested by the caller BEFORE its K
   // loop with igemm_epilogue_prefetch (same chunk map), so that their latency does not sit between the last MFMA and the stores
   // (tile width BN = WGN x WN; PASSES passes of RP rows: the waves whose rows fall into pass h stage their sub-tiles, then all NT threads
@@ -168,7 +168,8 @@ __device__ __forceinline__ void igemm_epilogue_lds128(const l2s_conv_desc& p, f3
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + fg * 4;
     bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n < p.Cout) bv[j] = *(const f32x4*)(p.bias + n);
+    if (pre_bias) bv[j] = pre_bias[j];                       // (requested by the caller before its K loop)
+    else if (p.bias && n < p.Cout) bv[j] = *(const f32x4*)(p.bias + n);
   }
 #pragma unroll
   for (int h = 0; h < PASSES; ++h) {
@@ -324,8 +325,12 @@ __device__ __forceinline__ void igemm_epilogue(const l2s_conv_desc& p, f32x4 (&a
   }
 }
 
-template <typename T, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void igemm_splitk_atomics(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M) {
+// split-K: the workgroup's fp32 partial tile goes to slab blockIdx.z of the workspace ([split][M][Cout] floats); splitk_reduce_kernel adds
+// the slabs in slab order and applies the epilogue, so the result does not depend on which workgroup finishes first (no atomics).
+// Cout % 4 == 0 (checked by the launcher): a lane's four channels are one 16-byte store.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void igemm_splitk_slab(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int fr, int fg, int M) {
+  float* slab = p.ws + (long)blockIdx.z * M * p.Cout;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * WM + i * 16 + fr;
@@ -333,9 +338,7 @@ __device__ __forceinline__ void igemm_splitk_atomics(const l2s_conv_desc& p, f32
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 16 + fg * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n + r < p.Cout) atomicAdd(p.ws + (long)m * p.Cout + n + r, acc[i][j][r]);
+      if (n < p.Cout) *(f32x4*)(slab + (long)m * p.Cout + n) = acc[i][j];
     }
   }
 }
@@ -396,8 +399,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
   int kt0 = 0, KT = KT_all;
   if (gridDim.z > 1) {                      // split-K: this workgroup owns slices [kt0, KT)
     const int per = (KT_all + gridDim.z - 1) / gridDim.z;
-    kt0 = blockIdx.z * per; KT = min(KT_all, kt0 + per);
-    if (kt0 >= KT) return;
+    kt0 = blockIdx.z * per; KT = min(KT_all, kt0 + per);          // (the launcher picks a split that leaves no range empty)
   }
   // loader state, advanced incrementally: (tap, c0) and one pointer per row; pointers are rebuilt only when the tap changes
   int c0 = kt0 * BK, tap = 0;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const l2s_conv_desc p) {
     __syncthreads();
   }
 
-  if (gridDim.z > 1) { igemm_splitk_atomics<T, TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, fr, fg, M); return; }
+  if (gridDim.z > 1) { igemm_splitk_slab<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, fr, fg, M); return; }
   igemm_epilogue<T, TM, TN, WM, WN, OUTF32>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
@@ -704,8 +706,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM * BN >= 128 * 128 && WGM * WGN 
 //   k-1 returned: __syncthreads' lgkmcnt(0)), so the loaders may overwrite buffer (k+1) & 1 with slice k+1 right behind it.
 // The loaders leave after the last slice (a finished wave no longer counts at s_barrier); the epilogue is the ring kernel's.
 // ------------------------------------------------------------------------------------------------
-template <int D, int BN>
+template <int D, int BN, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc p) {
+  // STAMP (tools/ws64_stamps.py, algo 8): lane 0 of the first multiplier wave stores the 100 MHz clock at four points of every workgroup
+  // into p.ws: [workgroup][entry, first slice landed, K loop done, stores drained]
+  unsigned long long t_entry = 0;
+  if constexpr (STAMP) t_entry = __builtin_amdgcn_s_memrealtime();
   typedef bf16_t T;
   constexpr int BM = 64, RB = 128, BK = 64, CPR = 8, LR = 32, NA = BM / LR, NB = BN / LR;
   constexpr int WM = 32, WN = BN / 2, TM = 2, TN = WN / 16, KG = 2, BUF = (BM + BN) * RB;
@@ -722,7 +728,12 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
     if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
   }
   const int m0 = mt * BM, n0 = nt * BN;
-  const int KT = K / BK;
+  // split-K (gridDim.z > 1): this workgroup multiplies slices [kt0, kt0 + KT) and leaves its partial tile in slab blockIdx.z
+  int kt0 = 0, KT = K / BK;
+  if (gridDim.z > 1) {
+    const int per = (KT + (int)gridDim.z - 1) / (int)gridDim.z;
+    kt0 = (int)blockIdx.z * per; KT = min(KT, kt0 + per) - kt0;
+  }
 
   if (wave_all >= 4) {
     // ---------------- loaders ----------------
@@ -753,7 +764,8 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
       voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + cv * 8) * 2L) : OOR;
     }
     const int taps = p.KH * p.KW;
-    int it = 0, c0 = 0, tap = 0;
+    int it = kt0, c0 = kt0 * BK, tap = 0;
+    if (taps > 1) { tap = c0 / p.Cin; c0 -= tap * p.Cin; }
     unsigned voffA[NA];
     auto set_tap = [&](int t) {
       const int ky = t / p.KW, kx = t - ky * p.KW;
@@ -764,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
         voffA[j] = v ? (unsigned)(((long)(a_base[j] + iy * p.IW + ix) * p.ldx + cv * 8) * 2L) : OOR;
       }
     };
-    set_tap(0);
+    set_tap(tap);
     uint4 ra[D][NA], rb[D][NB];
     auto issue = [&](uint4 (&a)[NA], uint4 (&b)[NB]) {
       const int sa = c0 * 2, sb = it * RB;
@@ -820,14 +832,21 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
   const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                      !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
                      (long)M * p.ldy * 2 < (1L << 31) && (!p.add || (long)M * p.ldadd * 2 < (1L << 31)) && (!p.ref || (long)M * p.ldref * 2 < (1L << 31));
-  const bool staged = plain;
+  const bool staged = plain && gridDim.z == 1;
   // residual / ReLU-mask operands of the LDS-staged epilogue, requested before the K loop (these waves issue no other global load)
   constexpr int EIT = (BM * (BN / 8) + 255) / 256;
   u32x4v eav[EIT], erv[EIT];
-  // (only behind a K loop long enough to cover them: with 4 slices they merely compete with the loaders' first, critical loads -
-  // layer3 conv3 7.5 -> 8.5 us - while the 3x3 / K = 1024 launches gain 0.3 us)
-  const bool pre = staged && KT >= 8;
-  if (pre) igemm_epilogue_prefetch<BM, 256, BN>(p, m0, n0, M, tid, eav, erv);
+  // (behind a K loop of >= 8 slices they go out at once; with fewer slices they would compete with the loaders' first, critical loads -
+  // layer3 conv3 7.5 -> 8.5 us - so they follow barrier #0, when the first slice has landed)
+  const bool pre = staged;
+  if (pre && KT >= 8) igemm_epilogue_prefetch<BM, 256, BN>(p, m0, n0, M, tid, eav, erv);
+  f32x4 ebv[BN / 32];                                          // the wave's bias columns (an L2 round trip that used to open the epilogue)
+#pragma unroll
+  for (int j = 0; j < BN / 32; ++j) {
+    const int n = n0 + (wave_all & 1) * (BN / 2) + j * 16 + (lane >> 4) * 4;
+    ebv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (staged && p.bias && n < p.Cout) ebv[j] = *(const f32x4*)(p.bias + n);
+  }
   const int swz = fr & (CPR - 1);
   const int offa = (wm * WM + fr) * RB, offb = BM * RB + (wn * WN + fr) * RB;
   f32x4 acc[TM][TN];
@@ -856,7 +875,10 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
         for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[kg][j], fa[kg][i], acc[i][j]);
   };
   __syncthreads();                                            // barrier #0
+  unsigned long long t_first = 0, t_loop = 0;
+  if constexpr (STAMP) t_first = __builtin_amdgcn_s_memrealtime();
   read_all(0, fa0, fb0);
+  if (pre && KT < 8) igemm_epilogue_prefetch<BM, 256, BN>(p, m0, n0, M, tid, eav, erv);
   int t = 1;
   for (; t + 2 <= KT; t += 2) {
     __syncthreads(); read_all(t, fa1, fb1); mma_all(fa0, fb0);
@@ -864,7 +886,22 @@ __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc 
   }
   if (t < KT) { __syncthreads(); read_all(t, fa1, fb1); mma_all(fa0, fb0); mma_all(fa1, fb1); }
   else mma_all(fa0, fb0);
-  if (staged) { igemm_epilogue_lds128<TM, TN, WM, WN, 2, 256, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all, pre ? eav : nullptr, pre ? erv : nullptr); return; }
+  if (gridDim.z > 1) { igemm_splitk_slab<TM, TN, WM, WN>(p, acc, m0, n0, wm, wn, fr, fg, M); return; }
+  if constexpr (STAMP) {
+    asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[TM - 1][TN - 1]));         // (the last MFMAs have retired)
+    t_loop = __builtin_amdgcn_s_memrealtime();
+  }
+  if (staged) {
+    igemm_epilogue_lds128<TM, TN, WM, WN, 2, 256, BN, 1>(p, acc, m0, n0, wm, wn, fr, fg, M, smem_all, eav, erv, ebv);
+    if constexpr (STAMP) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0 && p.ws) {
+        unsigned long long* o = (unsigned long long*)p.ws + 4L * (blockIdx.x + (long)gridDim.x * blockIdx.z);
+        o[0] = t_entry; o[1] = t_first; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memrealtime();
+      }
+    }
+    return;
+  }
   igemm_epilogue<T, TM, TN, WM, WN, false>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
@@ -1400,6 +1437,8 @@ __global__ __launch_bounds__(512) void igemm_ks64_kernel(const l2s_conv_desc p) 
   const auto radd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add ? p.add : p.y), 0, 0x7FFFFFFF, 0x00020000);
   const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref ? p.ref : p.y), 0, 0x7FFFFFFF, 0x00020000);
   u32x4v av[2], rv[2]; unsigned orow[2];
+  f32x4 bq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // bias of the thread's 8 columns (both chunks: same columns)
+  if (plain && p.bias && n0 + (tid & 7) * 8 < p.Cout) { bq[0] = *(const f32x4*)(p.bias + n0 + (tid & 7) * 8); bq[1] = *(const f32x4*)(p.bias + n0 + (tid & 7) * 8 + 4); }
   if (plain) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1455,10 +1494,7 @@ __global__ __launch_bounds__(512) void igemm_ks64_kernel(const l2s_conv_desc p) 
         v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3]; v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
       }
       const int n = n0 + col;
-      if (p.bias && n < p.Cout) {
-        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-        v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
-      }
+      if (p.bias) { v[0] += bq[0][0]; v[1] += bq[0][1]; v[2] += bq[0][2]; v[3] += bq[0][3]; v[4] += bq[1][0]; v[5] += bq[1][1]; v[6] += bq[1][2]; v[7] += bq[1][3]; }
       if (p.add) {
         const unsigned wv[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
 #pragma unroll
@@ -1631,47 +1667,70 @@ __global__ __launch_bounds__(512) void roialign_block0_kernel(const l2s_roi_bloc
     if (t + j < TOT) step(pf[j % PF], t + j + PF < TOT);
 }
 
-// y = epilogue(ws) and ws = 0 (so the workspace is clean for the next split-K launch)
+// y = epilogue(slab 0 + slab 1 + ... in this order); 4 channels per thread
 template <typename T, bool OUTF32>
-__global__ void splitk_epilogue_kernel(const l2s_conv_desc p, long total) {
-  for (long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; e < total; e += (long)gridDim.x * blockDim.x * 4) {
-    const long m = e / p.Cout; const int n = (int)(e - m * p.Cout);
-    float4 v4 = *(float4*)(p.ws + e);
-    *(float4*)(p.ws + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-    float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (p.bias) v[r] += p.bias[n + r];
-      if (p.add) v[r] += Elem<T>::ld((const T*)p.add + m * p.ldadd + n + r);
-      if (p.flags & L2S_CONV_RELU) v[r] = fmaxf(v[r], 0.f);
-      if (p.ref) { if (!(Elem<T>::ld((const T*)p.ref + m * p.ldref + n + r) > 0.f)) v[r] = 0.f; }
-    }
-    if (OUTF32) { float* o = (float*)p.y + m * p.ldy + n; for (int r = 0; r < 4; ++r) o[r] = v[r]; }
-    else { T* o = (T*)p.y + m * p.ldy + n; for (int r = 0; r < 4; ++r) Elem<T>::st(o + r, v[r]); }
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const l2s_conv_desc p, long total, int split) {
+  const long e = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+  if (e >= total) return;
+  const long m = e / p.Cout; const int n = (int)(e - m * p.Cout);
+  float4 v4 = *(const float4*)(p.ws + e);
+  for (int s = 1; s < split; ++s) {
+    const float4 u = *(const float4*)(p.ws + s * total + e);
+    v4.x += u.x; v4.y += u.y; v4.z += u.z; v4.w += u.w;
   }
+  float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (p.bias) v[r] += p.bias[n + r];
+    if (p.add) v[r] += Elem<T>::ld((const T*)p.add + m * p.ldadd + n + r);
+    if (p.flags & L2S_CONV_RELU) v[r] = fmaxf(v[r], 0.f);
+    if (p.ref) { if (!(Elem<T>::ld((const T*)p.ref + m * p.ldref + n + r) > 0.f)) v[r] = 0.f; }
+  }
+  if (OUTF32) { float* o = (float*)p.y + m * p.ldy + n; for (int r = 0; r < 4; ++r) o[r] = v[r]; }
+  else { T* o = (T*)p.y + m * p.ldy + n; for (int r = 0; r < 4; ++r) Elem<T>::st(o + r, v[r]); }
+}
+
+template <typename T, bool OUTF32>
+int launch_splitk_reduce(const l2s_conv_desc& d, int split, hipStream_t st) {
+  const long total = (long)d.n_img * d.OH * d.OW * d.Cout;
+  L2S_LAUNCH((splitk_reduce_kernel<T, OUTF32>), dim3((int)((total / 4 + 255) / 256)), dim3(256), 0, st, d, total, split);
+  return l2s_check_launch();
+}
+
+// the split the launch will use: d.split_k forced (> 1) or chosen (0), limited by the K slices (>= 2 per range, no empty range) and by
+// the workspace; 1 = no split
+static int splitk_factor(const l2s_conv_desc& d, int KT, long tiles64, bool auto_ok) {
+  if (!d.ws || d.split_k == 1 || (d.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) || (d.Cout % 4)) return 1;
+  const long out = (long)d.n_img * d.OH * d.OW * d.Cout;
+  int s = d.split_k > 1 ? d.split_k : 0;
+  if (!s) {
+    // few tiles and a long K loop (layer4 on the 19x32 map: 80 tiles x 32 / 72 slices): each workgroup streams (64 + 64) x K x 2 bytes
+    // through one CU's L2 path (~75 GB/s) while most of the chip idles - cut K so that ~320 workgroups share it
+    if (!auto_ok || tiles64 > 128 || KT < 16) return 1;
+    s = (int)((320 + tiles64 - 1) / tiles64);
+    if (s > KT / 8) s = KT / 8;
+    if (s > 8) s = 8;
+  }
+  if (s > KT / 2) s = KT / 2;
+  while (s > 1 && (long)s * out > (long)d.ws_floats) --s;
+  while (s > 1 && (s - 1) * cdiv(KT, s) >= KT) --s;                 // no empty range
+  return s < 1 ? 1 : s;
 }
 
 template <typename T, int BM, int BN, bool OUTF32>
 int launch_igemm(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   int split = 1;
-  if (d.ws && BM == 64 && !(d.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) && (d.Cout % 4 == 0)) {
+  if (BM == 64 && d.split_k > 1) {                                  // forced only: the generic kernel serves K tails and the f32 mode
     const int K = d.KH * d.KW * d.Cin, KT = cdiv(K, ROWB / (int)sizeof(T));
-    const long tiles = (long)cdiv(M, BM) * cdiv(d.Cout, BN);
-    if (d.split_k > 0) split = d.split_k;
-    (void)tiles; (void)KT;   // auto split-K is off: fp32 atomics cost more than the latency they hide on these shapes (profiles/r01 notes)
-    if (split < 1) split = 1;
+    split = splitk_factor(d, KT, (long)cdiv(M, BM) * cdiv(d.Cout, BN), false);
   }
   dim3 grid(cdiv(M, BM) * cdiv(d.Cout, BN), 1, split);
   size_t lds = 2 * (BM + BN) * ROWB;
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   L2S_LAUNCH((igemm_kernel<T, BM, BN, OUTF32>), grid, dim3(256), lds, st, d);
-  if (split > 1) {
-    const long total = (long)M * d.Cout;
-    long g = (total / 4 + 255) / 256; if (g > 2048) g = 2048;
-    L2S_LAUNCH((splitk_epilogue_kernel<T, OUTF32>), dim3((int)g), dim3(256), 0, st, d, total);
-  }
+  if (split > 1) return launch_splitk_reduce<T, OUTF32>(d, split, st);
   return l2s_check_launch();
 }
 
@@ -1686,12 +1745,13 @@ int launch_igemm_ring(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <int D, int BN>
-int launch_igemm_ws64(const l2s_conv_desc& d, hipStream_t st) {
+template <int D, int BN, bool STAMP = false>
+int launch_igemm_ws64(const l2s_conv_desc& d, hipStream_t st, int split = 1) {
   const int M = d.n_img * d.OH * d.OW;
-  dim3 grid(cdiv(M, 64) * cdiv(d.Cout, BN));
+  dim3 grid(cdiv(M, 64) * cdiv(d.Cout, BN), 1, split);
   const size_t lds = 2 * 128 * 128;                                           // (also holds the staged 64 x (BN + 4) fp32 tile of the epilogue)
-  L2S_LAUNCH((igemm_ws64_kernel<D, BN>), grid, dim3(512), lds, st, d);
+  L2S_LAUNCH((igemm_ws64_kernel<D, BN, STAMP>), grid, dim3(512), lds, st, d);
+  if (split > 1) return launch_splitk_reduce<bf16_t, false>(d, split, st);
   return l2s_check_launch();
 }
 
@@ -1740,10 +1800,10 @@ int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
 
 // ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
 enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,
-                PLAN_DMA256, PLAN_DMA256_STAMPED };
+                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK };
 static const char* const PLAN_NAMES[] = {"invalid", "igemm_kernel<64,64>", "igemm_kernel<128,128>", "igemm_ring_kernel<64,64>", "igemm_ring_kernel<128,128>",
                                          "igemm_ws64_kernel", "igemm_ks64_kernel<4>", "igemm_ks64_kernel<3>", "igemm_sp_kernel<224,128>", "igemm_sp_kernel<256,128>",
-                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>"};
+                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel"};
 static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
   if (!d || !d->x || !d->w || !d->y || (dtype != L2S_BF16 && dtype != L2S_F32)) return PLAN_EINVAL;
   const bool bf = dtype == L2S_BF16;
@@ -1764,22 +1824,21 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     if (t256 >= 160 && t256 <= 256 && K >= 1024) tile = ((long)cdiv(M, 224) * cdiv(d->Cout, 128) <= 256) ? 224 : 256;   // 224 rows: 224 instead of 196 workgroups
   }
   const long xb = (long)d->n_img * d->IH * d->IW * d->ldx * esz, wb = (long)d->Cout * K * esz;
-  const bool split_req = d->ws && d->split_k > 1;
   // buffer-descriptor kernels: whole 128-byte K slices per tap and 31-bit operand extents
-  const bool desc_ok = (d->Cin % bk == 0) && xb < (1L << 31) && wb < (1L << 31) && !split_req;
+  const bool desc_ok = (d->Cin % bk == 0) && xb < (1L << 31) && wb < (1L << 31);
   if (tapin_out) *tapin_out = ntaps > 1 && ntaps <= 32 && xb < (1L << 30);     // K walked channel-chunk-major, taps innermost
   const int algo = d->algo;
-  const int algo_base = algo == 7 ? L2S_ALGO_AUTO : algo;
   if (desc_ok) {
     const int KT = K / bk;
     const long tiles64 = (long)cdiv(M, 64) * cdiv(d->Cout, 64);
     // LDS-DMA 256x128 tile: wherever the large register-staged tiles were chosen, measured 59 vs 74 us on the dominant 3x3 and equal or
     // better on the 1x1 shapes (tools/dma_bench.py)
     const bool dma_ok = bf && !f32o && KT >= 3 && d->KH <= 3 && d->KW <= 3;
-    if (dma_ok && (algo == L2S_ALGO_DMA || (algo_base == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
-    // experiment (bench.py --conv-algo 7): the N >= 1024 layer4@RoIs launches (128x128 ring tile: 230 VGPRs x 2 workgroups per CU fill
-    // every SIMD's register file, so the caption branch's small launches wait for a slot) on the DMA tile as well
-    if (dma_ok && algo == 7 && tile == 128 && M >= 8192) return PLAN_DMA256;
+    // split-K over workgroups (slabs + ordered reduce): forced by the caller, or chosen for few-tile / long-K launches (splitk_factor)
+    if (algo == L2S_ALGO_WS64_STAMPED && bf && !f32o && tile == 64) return PLAN_WS64;   // instrumented build (tools/ws64_stamps.py)
+    if (tile == 64 && (algo == L2S_ALGO_AUTO || algo == L2S_ALGO_STAGED) && splitk_factor(*d, KT, tiles64, bf && !f32o) > 1)
+      return (bf && !f32o) ? PLAN_WS64_SPLITK : PLAN_GENERIC64;
+    if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
     if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;
     // K-split 64x64 tile with LDS-DMA fill: whole 128-channel pieces per tap.  Chosen for the 3x3 launches whose 64x64 tiles fit one round
     // of workgroups and that carry no ReLU-mask operand, i.e. forward launches: 13.8 -> 11.2 us (layer3), 61.6 -> 52.9 us (RPN); the 1x1
@@ -1788,11 +1847,19 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     const bool ks_ok = bf && !f32o && d->Cin % 128 == 0 && d->KH <= 3 && d->KW <= 3 && M * d->Cout * 4 < (1L << 31);
     if (ks_ok && algo == L2S_ALGO_KSPLIT) return PLAN_KS64;
     if (ks_ok && algo == L2S_ALGO_KSPLIT_D3) return PLAN_KS64_D3;
-    if (ks_ok && algo_base == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && tiles64 <= 256 && K >= 1024) return PLAN_KS64;
+    if (ks_ok && algo == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && tiles64 <= 256 && K >= 1024) return PLAN_KS64;
     if (tile == 224) return PLAN_SP224;
     if (tile == 256) return PLAN_SP256;
     if (tile == 128) return PLAN_RING128;
-    if (bf && !f32o) return PLAN_WS64;          // wave-specialised 8-wave form (loaders + multipliers), bf16 output
+    if (bf && !f32o) {
+      // wave-specialised 8-wave form (loaders + multipliers), bf16 output.  Two of its workgroups fit a CU (512 slots): a grid just above
+      // a multiple of that pays a whole extra round of workgroups for its last tiles (layer3 conv3 / conv1 data gradient: 608 tiles of 4
+      // slices take 9.3 us, ~3 of them for the 96 tiles of the second round: tools/ws64_stamps.py).  The 4-wave ring tile fits three per
+      // CU (768 slots); with a short K loop fewer rounds beat the faster K loop: 27.8 -> 26.2 us per layer3 block forward, 32.6 -> 30.1
+      // backward (tools/chain_bench.py), the step +1.5 % (same-box A/B)
+      if (KT <= 8 && (tiles64 + 767) / 768 < (tiles64 + 511) / 512) return PLAN_RING64;
+      return PLAN_WS64;
+    }
     return PLAN_RING64;
   }
   if (tile >= 128) return PLAN_GENERIC128;       // K tails, >= 2 GiB operands, split-K with a workspace: the register-staged generic kernel
@@ -1821,7 +1888,13 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     case PLAN_DMA256_STAMPED: return launch_igemm_dma<256, 128, true>(dd, stream);
     case PLAN_KS64: return launch_igemm_ks64<4>(dd, stream);
     case PLAN_KS64_D3: return launch_igemm_ks64<3>(dd, stream);
-    case PLAN_WS64: return launch_igemm_ws64<3, 64>(dd, stream);
+    case PLAN_WS64:
+      if (d->algo == L2S_ALGO_WS64_STAMPED) return launch_igemm_ws64<3, 64, true>(dd, stream);
+      return launch_igemm_ws64<3, 64>(dd, stream);
+    case PLAN_WS64_SPLITK: {
+      const int M = d->n_img * d->OH * d->OW, KT = d->KH * d->KW * d->Cin / 64;
+      return launch_igemm_ws64<3, 64>(dd, stream, splitk_factor(dd, KT, (long)cdiv(M, 64) * cdiv(d->Cout, 64), true));
+    }
     case PLAN_SP224:
       if (tapin) return BYT((f32o ? launch_igemm_sp<bf16_t, 224, 128, 2, 4, 2, true, true>(dd, stream) : launch_igemm_sp<bf16_t, 224, 128, 2, 4, 2, false, true>(dd, stream)),
                             (f32o ? launch_igemm_sp<float, 224, 128, 2, 4, 2, true, true>(dd, stream) : launch_igemm_sp<float, 224, 128, 2, 4, 2, false, true>(dd, stream)));

@@ -299,14 +299,11 @@ class Network(object):
 
     # ------------------------------------------------------------------ HIP streams
     use_streams = True
-    STREAM_ALIAS = {}
 
     def streams(self):
         if not hasattr(self, '_streams'):
             mk = lambda n: torch.cuda.Stream()          # (no priorities: any priority stream halves throughput on this stack)
             self._streams = dict(lang=mk('lang'), cap=mk('cap'), wg=mk('wg'), wg2=mk('wg2'), tr=mk('tr'))
-            for a, b in self.STREAM_ALIAS.items():           # two roles on one stream (the runtime maps streams onto 4 hardware queues)
-                self._streams[a] = self._streams[b]
             self._wg_flip = 0
         return self._streams
 
@@ -530,13 +527,19 @@ class Network(object):
         g.replay()
         return loss
 
+    SPLITK_WS_FLOATS = 4 * 1024 * 1024
+
     def splitk_ws(self, need):
-        """shared all-zero fp32 workspace for split-K partial sums (every launch hands it back zeroed)."""
-        if need > 4 * 1024 * 1024:          # only small-M problems are split
+        """fp32 workspace for the split-K slabs of a small convolution (csrc/conv_igemm.hip: splitk_factor decides whether and how far
+        to split; the slabs are added in slab order by a second launch).  One per stream: the caption branch and the main path run
+        split launches at the same time."""
+        if need > self.SPLITK_WS_FLOATS // 2 or self.device == 'cpu':        # only small-M problems are split
             return None
-        ws = getattr(self, '_skws', None)
+        pool = self.__dict__.setdefault('_skws', {})
+        key = torch.cuda.current_stream().cuda_stream
+        ws = pool.get(key)
         if ws is None:
-            ws = self._skws = torch.zeros(4 * 1024 * 1024, dtype=torch.float32, device=self.device)
+            ws = pool[key] = torch.empty(self.SPLITK_WS_FLOATS, dtype=torch.float32, device=self.device)
         return ws
 
     def _init_modules(self):

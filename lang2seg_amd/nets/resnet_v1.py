@@ -394,6 +394,7 @@ class resnetv1(Network):
         for li in (1, 2, 3):
             if li == cfg.RESNET.FIXED_BLOCKS + 1:
                 self.join_update()                             # first trainable layer: the previous step's update must have landed
+                self._mark('layer1 done, update joined')
             for b, blk in enumerate(self.layers[li]):
                 x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
                 saved[(li, b)] = sv

@@ -123,6 +123,7 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     d.xcd_mode = xcd_mode
     d.algo = CONV_ALGO if algo is None else algo
     d.ws = ptr(ws)
+    d.ws_floats = 0 if ws is None else ws.numel()
     global LAST_PLAN
     dtv = dt_of(x) if dt is None else dt
     LAST_PLAN = _lib.load().l2s_conv_plan_name(C.byref(d), dtv).decode()

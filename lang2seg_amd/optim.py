@@ -15,7 +15,7 @@ class SGD(object):
         self.lr, self.momentum, self.weight_decay, self.grad_scale = float(lr), float(momentum), float(weight_decay), float(grad_scale)
         self.param_groups = [self.__dict__]        # scale_lr()-style code can do group['lr'] *= gamma
         # decided once, before the first step: the edges of this mode are part of every recorded launch tape
-        self.side_active = bool(self.side and not self.early and getattr(net, 'use_streams', False) and hasattr(net, 'flush_wgrads'))
+        self.side_active = bool(self.side and getattr(net, 'use_streams', False) and hasattr(net, 'flush_wgrads'))
         if self.side_active:
             net.update_on_wg = True
 
@@ -26,8 +26,9 @@ class SGD(object):
     # it is final (parallel.bucket_bounds).  `partial(stage)` applies the update to that prefix on the idle transpose stream
     # while the earlier layers are still back-propagating (the update is HBM-bound, the convolutions are not); `step()` then
     # only has the last layers left.  Single-process only: with a gradient reducer the prefix still has to be all-reduced.
-    # Measured on MI355X (bench.py, A/B in one box): 122.4 / 123.6 img/s with it vs 123.1 without — the update competes for HBM with
-    # the layer3 backward it overlaps, so it is off by default (SGD.early = True turns it on; tests cover it).
+    # Round 1 measured it neutral (122.4 / 123.6 img/s with it vs 123.1 without) - but that form made the MAIN queue wait for the
+    # transpose stream at every hand-off, i.e. for the weight-gradient launches the partial update itself waits for.  Since round 3 the
+    # hand-off only forks, and whatever is left at the end of the step follows the last weight gradients on their stream (SGD.side).
     early = False                                  # set by tests / tools before the first step
     _seg_done = 0
 
@@ -49,12 +50,12 @@ class SGD(object):
             return
         S = net.streams()
         tr = S['tr']
-        net.join_transposes()                                    # (already joined at the start of the step; keeps `tr` ordered)
         net.sfork(torch.cuda.current_stream(), tr)
         for name in ('wg', 'wg2', 'lang', 'cap'):                # gradients are also produced on the side streams
             net.sfork(S[name], tr)
         with torch.cuda.stream(tr):
             self._launch(self._seg_done, hi)
+            net._mark('partial update %s (tr)' % stage)
         self._seg_done = hi
 
     # Update on the weight-gradient stream: the main queue does not wait for the last grouped weight-gradient launch and the ~0.28 ms
@@ -67,16 +68,19 @@ class SGD(object):
     def step(self):
         P = self.net.P
         net = self.net
-        if self.side_active and net.use_streams and not self.early and not self._seg_done:
+        if self.side_active and net.use_streams:
             net.flush_wgrads('final')
             S = net.streams()
             for k in ('wg2', 'lang', 'cap'):
                 net.sfork(S[k], S['wg'])
+            if self._seg_done:
+                net.sfork(S['tr'], S['wg'])               # early partial updates of this step (SGD.early) ran on the transpose stream
             net.sfork(torch.cuda.current_stream(), S['wg'])
             with torch.cuda.stream(S['wg']):
-                self._launch(0, P.nseg)
+                self._launch(self._seg_done, P.nseg)      # whatever the partial updates left: the last backward stages
                 net.refresh_weights()
                 net._mark('update done (wg)')
+            self._seg_done = 0
             return
         if hasattr(self.net, 'join_wgrad'):
             self.net.join_wgrad()                   # weight-gradient stream -> current stream

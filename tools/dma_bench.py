@@ -41,7 +41,6 @@ def main():
     if os.environ.get('SHAPES', 'large') == 'small':
         SHAPES = SMALL
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    dbg = int(os.environ.get('DBG', '0'))
     algos = [int(a) for a in os.environ.get('ALGOS', '1,2').split(',')]
     print('%-14s %s   (us per launch: fwd-form with bias+residual+ReLU / dgrad-form with ReLU mask; median of %d rounds)' % ('shape', ' '.join('algo%d' % a for a in algos), rounds))
     for name, n, H, W, Cin, Cout, k, p in SHAPES:
@@ -55,8 +54,8 @@ def main():
         res = {a: ([], []) for a in algos}
         for _ in range(rounds):
             for a in algos:
-                res[a][0].append(timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, H, W, Cout, k, k, 1, p, bias=bias, add=r, relu=True, algo=a, split_k=dbg if a >= 2 else 0)))
-                res[a][1].append(timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, H, W, Cout, k, k, 1, p, ref=r, algo=a, split_k=dbg if a >= 2 else 0)))
+                res[a][0].append(timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, H, W, Cout, k, k, 1, p, bias=bias, add=r, relu=True, algo=a)))
+                res[a][1].append(timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, H, W, Cout, k, k, 1, p, ref=r, algo=a)))
         med = lambda v: sorted(v)[len(v) // 2]
         print('%-14s %s' % (name, '   '.join('%6.1f/%6.1f us %5.0f/%5.0f TF' % (med(res[a][0]) * 1e6, med(res[a][1]) * 1e6, flop / med(res[a][0]) / 1e12, flop / med(res[a][1]) / 1e12) for a in algos)), flush=True)
 

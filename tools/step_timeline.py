@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=12, help='measured repetitions (eight pipelined steps each)')
     ap.add_argument('--knockout', default='')
+    ap.add_argument('--sgd-early', type=int, default=-1)
     args = ap.parse_args()
     from lang2seg_amd.model.config import cfg
     from lang2seg_amd.nets.resnet_v1 import resnetv1
@@ -33,6 +34,8 @@ def main():
     net = resnetv1(opt, batch_size=1, num_layers=101)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()
+    if args.sgd_early >= 0:
+        SGD.early = bool(args.sgd_early)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY)
     blob = SyntheticLoader(num_images=1, sents_per_image=1, H=600, W=1000, T=T, vocab_size=V).getBatch('train')
     net.upload_blob(blob, 0)
