@@ -1532,6 +1532,164 @@ __global__ __launch_bounds__(512) void igemm_ks64_kernel(const l2s_conv_desc p) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 on ONE map (bf16): the "patch" tile.  What paces the small-M launches is the rate at which one CU pulls operand
+// bytes out of L2 (~70 GB/s, tools/ws64_stamps.py: 265 ns per 16 KiB slice whatever the prefetch depth), and an im2col-style tile pulls
+// every input pixel nine times: 64 x 64 outputs of layer3's conv2 cost (64 + 64) rows x 2304 x 2 B = 590 KB per workgroup.  Here a workgroup
+// owns 128 CONSECUTIVE pixels (row-major over the map) x BN output channels and stages, per 32-channel step, the input pixels
+// m0 - (W + 1) .. m0 + 127 + (W + 1) ONCE ("patch", PR rows of 64 B) next to the nine taps' weight rows (9 BN rows of 64 B).  Tap (ky, kx)
+// of output pixel m reads input pixel m + (ky - 1) W + (kx - 1): in the patch that is row (m - m0) + ky W + kx, the same shift for all
+// 128 pixels, so the MFMA A fragment of a tap is a plain ds_read_b128 at a shifted row - no gather, no per-tap copy.  What the shift gets
+// wrong are the map's left / right edges (kx = 0 at x = 0 and kx = 2 at x = W - 1 would read the neighbouring row's pixel): those lanes'
+// fragments are zeroed in registers; above / below the map the patch rows are out-of-range buffer addresses, i.e. zeros.
+// layer3 conv2 (BN = 32: 19 x 8 = 152 workgroups): 16 KB (patch) + 18 KB (weights) per step x 8 steps = 278 KB per workgroup instead of 590.
+// Waves 4-7 request (LDS-DMA, NP one-KiB pieces per wave and step, NS - 1 steps ahead), waves 0-3 multiply: wave w owns pixels 32 w .. 32 w + 31
+// x all BN channels, and walks the nine taps of a step software-pipelined (the fragments of tap q + 1 are requested before the MFMAs of
+// tap q: one wave per SIMD, nothing else hides the LDS latency); 2 + BN / 16 fragment reads for 2 BN / 16 MFMAs per tap.  One barrier per
+// step, as in igemm_ks64_kernel.
+// Measured (isolated launch, forward form): layer3 conv2 9.5 us (wave-specialised tile 13.0, K-split tile 10.8), layer2 conv2 9.2 (11.7),
+// layer4-on-the-map conv2 21.2 (31.9), RPN 3x3 39.0 (62.0).  Knock-outs on layer3's shape: requests alone 3.2 us over 8 steps (the ~70 GB/s
+// per CU again), multipliers alone 5.6 us - the LDS read path (144 KB of fragment reads per step and CU, ~80 % of 128 B/clk) now paces
+// it; a split by filter row (three waves over the whole 128 x BN tile, 0.6 reads per MFMA instead of 1) was built and is slower (12.2 us:
+// three taps per barrier leave nothing to pipeline).  Inside the step the LDS footprint matters as much as the launch time: with a ring
+// of 4 stages (139 KB) the tile keeps the weight-gradient workgroups off its CUs and the step gains 0.8 %; with 2 stages (72 KB) 3.4 %.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int PR, int NS>
+__global__ __launch_bounds__(512) void igemm_p3_kernel(const l2s_conv_desc p) {
+  typedef bf16_t T;
+  constexpr int BM = 128, RB = 64, TN = BN / 16;
+  constexpr int PA = PR / 16, PB = 9 * BN / 16;                  // one-KiB pieces (16 rows x 64 B) of the patch / of the weights per step
+  constexpr int NP = (PA + PB + 3) / 4;                          // pieces per requester wave (the last ones may be padding)
+  constexpr int STG = 4 * NP * 1024;
+  static_assert(PR % 16 == 0 && BN % 16 == 0 && NS >= 2 && NS <= 4, "patch tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int W = p.OW, M = p.OH * p.OW;
+  const int K = 9 * p.Cin;
+  int mt, nt;
+  {
+    const int MT = (M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;                      // an XCD's chunk of tiles: a few pixel tiles x every channel tile (shared patch in L2)
+    mt = t / NT; nt = t - mt * NT;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KT = p.Cin / 32;
+
+  if (wave >= 4) {
+    // ---------------- requesters ----------------
+    const int w = wave - 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    i32x4s rx, rw;
+    rx.x = (int)(uintptr_t)p.x; rx.y = (int)((uintptr_t)p.x >> 32); rx.z = (int)((((long)M - 1) * p.ldx + p.Cin) * 2L); rx.w = 0x00020000;
+    rw.x = (int)(uintptr_t)p.w; rw.y = (int)((uintptr_t)p.w >> 32); rw.z = (int)((long)p.Cout * K * 2L); rw.w = 0x00020000;
+    const int prow = lane >> 2, pch = lane & 3;                   // row of the piece, 16-byte chunk of the row
+    unsigned voff[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int k = w + 4 * j;                                    // piece index: patch pieces first, then weight pieces, then padding
+      unsigned v = OOR;
+      if (k < PA) {
+        const int idx = m0 - (W + 1) + 16 * k + prow;
+        if (idx >= 0 && idx < M) v = (unsigned)((idx * p.ldx + pch * 8) * 2);
+      } else if (k < PA + PB) {
+        const int brow = 16 * (k - PA) + prow, tap = brow / BN, n = n0 + brow - tap * BN;
+        if (n < p.Cout) v = (unsigned)(((long)n * K + tap * p.Cin + pch * 8) * 2L);
+      }
+      voff[j] = v;
+    }
+    int c0 = 0;
+    auto request = [&](int stage) {
+      const unsigned so = (unsigned)(c0 * 2), base = lds0 + (unsigned)(stage * STG + w * 1024);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const bool patch = w + 4 * j < PA;                        // (wave-uniform choice of the descriptor: scalar selects)
+        i32x4s r;
+        r.x = patch ? rx.x : rw.x; r.y = patch ? rx.y : rw.y; r.z = patch ? rx.z : rw.z; r.w = rx.w;
+        dma_b128(r, voff[j], so, base + (unsigned)(j * 4096));
+      }
+      c0 += 32;
+    };
+    auto wait_younger = [&](int younger) {                        // everything landed except the `younger` most recent steps
+      if (NS >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+      else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    int issued = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+      if (s_ < KT) { request(s_); ++issued; }
+    wait_younger(issued - 1);
+    wg_barrier();                                                 // barrier #0: step 0 landed
+    int sf = NS - 1;
+    for (int t = 0; t + 1 < KT; ++t) {
+      if (issued < KT) { request(sf); ++issued; }
+      sf = sf == NS - 1 ? 0 : sf + 1;
+      wait_younger(issued - (t + 2));                             // step t + 1 landed
+      wg_barrier();                                               // barrier #(t + 1)
+    }
+    return;
+  }
+
+  // ---------------- multipliers: wave w owns pixels 32 w .. 32 w + 31 x all BN channels, all nine taps ----------------
+  const int fr = lane & 15, fg = lane >> 4;
+  unsigned keepL[2], keepR[2];                                  // all-ones, or zero for an edge lane (ANDed into the fragment registers)
+  {
+    const float rw_ = 1.0f / (float)W;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = min(m0 + 32 * wave + 16 * i + fr, M - 1);
+      const int y = fast_div(m, W, rw_), x = m - y * W;
+      keepL[i] = x == 0 ? 0u : 0xFFFFFFFFu; keepR[i] = x == W - 1 ? 0u : 0xFFFFFFFFu;
+    }
+  }
+  f32x4 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int arow = (32 * wave + fr) * RB + fg * 16;             // + (16 i + ky W + kx) * 64
+  const int brow = PA * 1024 + fr * RB + fg * 16;               // + (tap BN + 16 j) * 64
+  int st = 0;
+  wg_barrier();                                                 // barrier #0
+  for (int t = 0; t < KT; ++t) {
+    const char* base = smem + st * STG;
+    // the nine taps of the step, software-pipelined inside the wave (one wave per SIMD: nothing else hides the LDS latency): the
+    // fragments of tap q + 1 are requested before the MFMAs of tap q are issued
+    uint4 fa[2][2], fb[2][TN];
+    auto load = [&](int q, int b_) {
+      const int ky = q / 3, kx = q - 3 * ky;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[b_][i] = *(const uint4*)(base + arow + (ky * W + 16 * i + kx) * RB);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[b_][j] = *(const uint4*)(base + brow + (q * BN + 16 * j) * RB);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int b_ = q & 1, kx = q % 3;
+      if (q + 1 < 9) load(q + 1, b_ ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kx != 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned k_ = kx == 0 ? keepL[i] : keepR[i];
+          fa[b_][i].x &= k_; fa[b_][i].y &= k_; fa[b_][i].z &= k_; fa[b_][i].w &= k_;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[b_][j], fa[b_][i], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    st = st == NS - 1 ? 0 : st + 1;
+    if (t + 1 < KT) { wait_lgkm0(); wg_barrier(); }             // this step's reads have returned: its stage may be refilled
+  }
+  igemm_epilogue<T, 2, TN, 32, BN, false>(p, acc, m0, n0, wave, 0, fr, fg, M);
+}
+
+// ------------------------------------------------------------------------------------------------
 // RoIAlign fused into the first bottleneck of the RoI head (bf16): crop-and-resize (NET:107-149) -> layer4.0.conv1 (1x1, + bias + ReLU) and
 // layer4.0.downsample (1x1, + bias), RES:271-273 - three launches of the unfused path (the crop kernel and two convolutions that each
 // re-read the 25.7 MB crop) in one.  ONE WORKGROUP PER RoI (256 RoIs = 256 compute units):
@@ -1785,6 +1943,17 @@ int launch_igemm_ks64(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
+template <int BN, int PR, int NS>
+int launch_igemm_p3(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, 128) * cdiv(d.Cout, BN));
+  const size_t lds = (size_t)NS * 4 * ((PR / 16 + 9 * BN / 16 + 3) / 4) * 1024;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_p3_kernel<BN, PR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((igemm_p3_kernel<BN, PR, NS>), grid, dim3(512), lds, st, d);
+  return l2s_check_launch();
+}
+
 template <int BM, int BN, bool STAMP = false>
 int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
@@ -1800,10 +1969,10 @@ int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
 
 // ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
 enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,
-                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK };
+                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK, PLAN_P3_32_256, PLAN_P3_64_256, PLAN_P3_32_384, PLAN_P3_64_384 };
 static const char* const PLAN_NAMES[] = {"invalid", "igemm_kernel<64,64>", "igemm_kernel<128,128>", "igemm_ring_kernel<64,64>", "igemm_ring_kernel<128,128>",
                                          "igemm_ws64_kernel", "igemm_ks64_kernel<4>", "igemm_ks64_kernel<3>", "igemm_sp_kernel<224,128>", "igemm_sp_kernel<256,128>",
-                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel"};
+                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel", "igemm_p3_kernel<32,256>", "igemm_p3_kernel<64,256>", "igemm_p3_kernel<32,384>", "igemm_p3_kernel<64,384>"};
 static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
   if (!d || !d->x || !d->w || !d->y || (dtype != L2S_BF16 && dtype != L2S_F32)) return PLAN_EINVAL;
   const bool bf = dtype == L2S_BF16;
@@ -1840,6 +2009,16 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
       return (bf && !f32o) ? PLAN_WS64_SPLITK : PLAN_GENERIC64;
     if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
     if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;
+    // patch tile: 3x3 / stride 1 / pad 1 on one map whose row fits the patch (W + 1 <= 128 halo pixels on either side of 128 outputs)
+    const bool p3_ok = bf && !f32o && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->n_img == 1 && d->IH == d->OH && d->IW == d->OW &&
+                       d->Cin % 32 == 0 && d->OW + 1 <= 128 && !(d->flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) && xb < (1L << 30) && !d->tile;
+    if (p3_ok && (algo == L2S_ALGO_AUTO || algo == L2S_ALGO_PATCH)) {
+      const long mt128 = cdiv(M, 128);
+      const bool narrow = mt128 * cdiv(d->Cout, 32) <= 256;        // 32-channel tiles while they fit one round of workgroups (one per CU)
+      const bool small_halo = d->OW + 1 <= 64;
+      if (narrow || mt128 * cdiv(d->Cout, 64) <= 256 || algo == L2S_ALGO_PATCH)
+        return narrow ? (small_halo ? PLAN_P3_32_256 : PLAN_P3_32_384) : (small_halo ? PLAN_P3_64_256 : PLAN_P3_64_384);
+    }
     // K-split 64x64 tile with LDS-DMA fill: whole 128-channel pieces per tap.  Chosen for the 3x3 launches whose 64x64 tiles fit one round
     // of workgroups and that carry no ReLU-mask operand, i.e. forward launches: 13.8 -> 11.2 us (layer3), 61.6 -> 52.9 us (RPN); the 1x1
     // launches gain nothing (their K loop is a few slices), multi-round grids lose (one workgroup per CU), and in the backward pass its
@@ -1886,6 +2065,10 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
   switch (plan) {
     case PLAN_DMA256: return launch_igemm_dma<256, 128, false>(dd, stream);
     case PLAN_DMA256_STAMPED: return launch_igemm_dma<256, 128, true>(dd, stream);
+    case PLAN_P3_32_256: return launch_igemm_p3<32, 256, 2>(dd, stream);
+    case PLAN_P3_64_256: return launch_igemm_p3<64, 256, 3>(dd, stream);
+    case PLAN_P3_32_384: return launch_igemm_p3<32, 384, 3>(dd, stream);
+    case PLAN_P3_64_384: return launch_igemm_p3<64, 384, 2>(dd, stream);
     case PLAN_KS64: return launch_igemm_ks64<4>(dd, stream);
     case PLAN_KS64_D3: return launch_igemm_ks64<3>(dd, stream);
     case PLAN_WS64:

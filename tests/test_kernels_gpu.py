@@ -278,6 +278,47 @@ def test_conv_ksplit_tile(cfg, algo):
         assert float(out.float()[:, 1::2, :, :].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(H=38, W=63, Cin=256, Cout=256),          # layer3 conv2: 19 x 8 tiles of 128 pixels x 32 channels, ragged last pixel tile
+    dict(H=38, W=63, Cin=512, Cout=512),          # layer4 on the map: 64-channel tiles
+    dict(H=20, W=64, Cin=64, Cout=32),            # W + 1 = 65: the 384-row patch
+    dict(H=9, W=127, Cin=64, Cout=48),            # the widest row the patch holds, ragged channel tile
+    dict(H=75, W=125, Cin=128, Cout=128),         # layer2 conv2
+    dict(H=1, W=1, Cin=64, Cout=16),              # one pixel: both edges on the same lane
+    dict(H=7, W=2, Cin=192, Cout=80),             # every pixel is an edge pixel; six steps
+    dict(H=3, W=200, Cin=64, Cout=64),            # a row wider than the patch: the plan falls back (still correct)
+])
+def test_conv_patch_tile(cfg):
+    """L2S_ALGO_PATCH (3x3 / stride 1 / pad 1 on one map: 128 consecutive pixels x 32 or 64 channels per workgroup, the input patch staged
+    once per 32-channel step, taps as shifted fragment reads, edge lanes zeroed in registers) against fp64 convolution of the same rounded
+    bf16 operands: forward form (bias + residual + ReLU) and data-gradient form (add + ReLU mask); the automatic choice gives the same bits."""
+    O = ops()
+    g = torch.Generator().manual_seed(21)
+    H, W, Cin, Cout = [cfg[x] for x in ['H', 'W', 'Cin', 'Cout']]
+    M = H * W
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(1, Cout, H, W, generator=g)
+    xd, wd, rd = to_dev(nhwc(x), 1), to_dev(ohwi(w), 1), to_dev(nhwc(res), 1)
+    xr, wr, rr = [t.double().cpu().permute(0, 3, 1, 2) for t in (xd, wd, rd)]
+    conv = F.conv2d(xr, wr, None, padding=1)
+    for form in ('fwd', 'dgrad'):
+        kw = dict(bias=b.to(DEV), add=rd, relu=True) if form == 'fwd' else dict(add=rd, ref=rd)
+        ref = F.relu(conv + b.double().view(1, -1, 1, 1) + rr) if form == 'fwd' else (conv + rr) * (rr > 0)
+        y = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+        O.conv_igemm(xd, wd, y, 1, H, W, Cin, H, W, Cout, 3, 3, 1, 1, algo=3, **kw)
+        plan = O.LAST_PLAN
+        ya = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+        O.conv_igemm(xd, wd, ya, 1, H, W, Cin, H, W, Cout, 3, 3, 1, 1, **kw)
+        torch.cuda.synchronize()
+        assert ('igemm_p3' in plan) == (W + 1 <= 128), plan
+        assert rel_err(y.float().view(1, H, W, Cout), nhwc(ref.float())) < TOL[1], (form, plan)
+        assert rel_err(ya.float().view(1, H, W, Cout), nhwc(ref.float())) < TOL[1], (form, O.LAST_PLAN)
+        if 'igemm_p3' in O.LAST_PLAN:
+            assert torch.equal(y, ya)
+
+
 @pytest.mark.parametrize('dt', [0, 1])
 @pytest.mark.parametrize('cfg', [
     dict(n=1, H=19, W=23, Cin=64, Cout=128, k=3, s=1, p=1),
