@@ -686,7 +686,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM * BN >= 128 * 128 && WGM * WGN 
       if (early) mma_all(); else compute(t);
     }
   }
-  if constexpr (sizeof(T) == 2 && !OUTF32 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 64)) && WGM == 2 && WGN == 2) {
+  if constexpr (sizeof(T) == 2 && !OUTF32 && ((BM == 128 && BN == 128) || (BM == 128 && BN == 64) || (BM == 64 && BN == 64)) && WGM == 2 && WGN == 2) {
     // whole-row 16-byte accesses through an LDS-staged fp32 tile when every row pitch allows it
     const bool plain = !(p.flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(p.ldy & 7) && !(p.ldadd & 7) && !(p.ldref & 7) && !(p.Cout & 7) &&
                        !((uintptr_t)p.y & 15) && !((uintptr_t)p.add & 15) && !((uintptr_t)p.ref & 15) && !((uintptr_t)p.bias & 15) &&
@@ -1969,10 +1969,10 @@ int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
 
 // ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
 enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,
-                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK, PLAN_P3_32_256, PLAN_P3_64_256, PLAN_P3_32_384, PLAN_P3_64_384 };
+                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK, PLAN_P3_32_256, PLAN_P3_64_256, PLAN_P3_32_384, PLAN_P3_64_384, PLAN_RING128X64 };
 static const char* const PLAN_NAMES[] = {"invalid", "igemm_kernel<64,64>", "igemm_kernel<128,128>", "igemm_ring_kernel<64,64>", "igemm_ring_kernel<128,128>",
                                          "igemm_ws64_kernel", "igemm_ks64_kernel<4>", "igemm_ks64_kernel<3>", "igemm_sp_kernel<224,128>", "igemm_sp_kernel<256,128>",
-                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel", "igemm_p3_kernel<32,256>", "igemm_p3_kernel<64,256>", "igemm_p3_kernel<32,384>", "igemm_p3_kernel<64,384>"};
+                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel", "igemm_p3_kernel<32,256>", "igemm_p3_kernel<64,256>", "igemm_p3_kernel<32,384>", "igemm_p3_kernel<64,384>", "igemm_ring_kernel<128,64>"};
 static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
   if (!d || !d->x || !d->w || !d->y || (dtype != L2S_BF16 && dtype != L2S_F32)) return PLAN_EINVAL;
   const bool bf = dtype == L2S_BF16;
@@ -2029,6 +2029,9 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     if (ks_ok && algo == L2S_ALGO_AUTO && !d->ref && tile == 64 && ntaps == 9 && tiles64 <= 256 && K >= 1024) return PLAN_KS64;
     if (tile == 224) return PLAN_SP224;
     if (tile == 256) return PLAN_SP256;
+    // a 128x128 grid of less than one round of workgroups (two per CU): half-width tiles fill the chip better and halve the epilogue
+    // burst per workgroup (layer4 on the map conv3: 19 x 16 tiles, 18.5 -> 15.5 us; layer2 conv3 10.2 -> 8.8 us)
+    if (tile == 128 && bf && !f32o && !d->tile && t128 < 512 && d->Cout % 64 == 0 && algo == L2S_ALGO_AUTO) return PLAN_RING128X64;
     if (tile == 128) return PLAN_RING128;
     if (bf && !f32o) {
       // wave-specialised 8-wave form (loaders + multipliers), bf16 output.  Two of its workgroups fit a CU (512 slots): a grid just above
@@ -2088,6 +2091,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
                             (f32o ? launch_igemm_sp<float, 256, 128, 4, 2, 2, true, true>(dd, stream) : launch_igemm_sp<float, 256, 128, 4, 2, 2, false, true>(dd, stream)));
       return BYT((f32o ? launch_igemm_sp<bf16_t, 256, 128, 4, 2, 2, true, false>(dd, stream) : launch_igemm_sp<bf16_t, 256, 128, 4, 2, 2, false, false>(dd, stream)),
                  (f32o ? launch_igemm_sp<float, 256, 128, 4, 2, 2, true, false>(dd, stream) : launch_igemm_sp<float, 256, 128, 4, 2, 2, false, false>(dd, stream)));
+    case PLAN_RING128X64: return launch_igemm_ring<bf16_t, 128, 64, 2, 2, 2, false>(dd, stream);
     case PLAN_RING128: return BYT(OUT(launch_igemm_ring, bf16_t, 128, 128, 2, 2, 2), OUT(launch_igemm_ring, float, 128, 128, 2, 2, 2));
     // 64x64 ring tile: depth 2 with the fragment reads ahead of the LDS fill for bf16 (fp32-output launches), depth 4 for f32
     case PLAN_RING64: return BYT(OUT(launch_igemm_ring, bf16_t, 64, 64, 2, 2, 2), OUT(launch_igemm_ring, float, 64, 64, 2, 2, 4));

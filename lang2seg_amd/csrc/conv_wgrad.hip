@@ -43,26 +43,27 @@ typedef l2s_wgrad_prob wgp;
 
 // One output tile (co tile, ci tile, tap or filter row) of problem p over the slices [s_begin, s_end) of segment `seg`'s pixels
 // (s_end < 0: all slices of every segment).  out: where the tile goes (dW, or a split-K slab); accumulate: out += tile.
-template <typename T, int BM, int BN, int TX, int D, int KSTEP = 1>
+template <typename T, int BM, int BN, int TX, int D, int KSTEP = 1, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void wgrad_tile(const wgp& p, int co0, int ci0, int tg, int split_idx, int nsplit, float* out, bool accumulate, char* smem) {
   constexpr int ES = (int)sizeof(T);
   constexpr int VE = 16 / ES;
   constexpr int BKP0 = WGT<T>::BKP;                      // pixels of one MFMA k step
   constexpr int BKP = BKP0 * KSTEP;                      // pixels per slice (one barrier)
   constexpr int RB = BKP + TX - 1;                       // rows of the X image
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int NT = 64 * WGM * WGN;                     // WGM x WGN waves, wave tile WM x WN
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int LRA = BM * ES + WGT<T>::PADB, LRB = BN * ES + WGT<T>::PADB;
   constexpr int VPA = BM / VE, VPB = BN / VE;            // 16-byte vectors per row
   // loader: TPR threads share one pixel row of the slice and own NVA / NVB CONSECUTIVE vectors of it, so a thread carries one
   // (image, row, column) state per operand instead of one per vector (the per-vector form spent ~190 VALU + ~125 SALU instructions
   // per slice and wave on index arithmetic against 32 MFMAs).  TX == 3: the two extra X rows belong to the first 2 TPR threads.
-  constexpr int TPR = 256 / BKP;
-  static_assert(256 % BKP == 0 && VPA % TPR == 0 && VPB % TPR == 0, "loader mapping");
+  constexpr int TPR = NT / BKP;
+  static_assert(NT % BKP == 0 && VPA % TPR == 0 && VPB % TPR == 0, "loader mapping");
   constexpr int NVA = VPA / TPR, NVB = VPB / TPR;
   constexpr int BUF = BKP * LRA + RB * LRB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int ky = TX == 3 ? tg : tg / p.KW, kx = TX == 3 ? 0 : tg - ky * p.KW;
   const int fr = lane & 15, fg = lane >> 4;
 
@@ -288,10 +289,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const wgp p, int cblocks, fl
 // ---- a whole backward stage per launch: problems in a device table, workgroup -> (problem, tile) through the tile prefix ----
 struct wg_prefix { int n; int tile0[L2S_WGRAD_MAX_GROUP + 1]; };
 
-template <typename T, int BM, int BN, int TX, int D, int KSTEP>
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const wgp* __restrict__ tab, const wg_prefix pre, float* ws) {
+template <typename T, int BM, int BN, int TX, int D, int KSTEP, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void wgrad_grouped_kernel(const wgp* __restrict__ tab, const wg_prefix pre, float* ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int bid = blockIdx.x;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; XCD x takes the x-th
+  // CONTIGUOUS eighth of the tile list, whose neighbours share the X tile (same ci tile and tap, consecutive co tiles / pixel ranges),
+  // instead of every XCD fetching every operand tile
+  int bid;
+  {
+    const int G = pre.tile0[pre.n], L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    bid = x * q + min(x, r) + slot;
+  }
   int lo = 0, hi = pre.n;                                // tile0[lo] <= bid < tile0[hi]
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre.tile0[mid] <= bid) lo = mid; else hi = mid; }
   const wgp p = tab[lo];                                 // uniform: scalar loads
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const wgp* __restric
   const int sp = t % split; t /= split;
   const int cot = t % co_tiles, rest = t / co_tiles, cit = rest % ci_tiles, tg = rest / ci_tiles;
   float* out = split > 1 ? ws + p.ws_off + (long)sp * ((long)p.Cout * p.KH * p.KW * p.Cin) : p.dw;
-  wgrad_tile<T, BM, BN, TX, D, KSTEP>(p, cot * BM, cit * BN, tg, sp, split, out, split == 1, smem);
+  wgrad_tile<T, BM, BN, TX, D, KSTEP, WGM, WGN>(p, cot * BM, cit * BN, tg, sp, split, out, split == 1, smem);
 }
 
 // problems of a grouped launch whose pixels were split: dW[e] += slab_0[e] + slab_1[e] + ... (fixed order); grid (blocks, problems)
@@ -337,14 +345,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
   }
 }
 
-// ---- variants (tile, taps per workgroup): 0 = 64x64 per tap, 1 = 128x128 per tap, 2 = 64x64 filter row, 3 = 128(co)x64 filter row ----
+// ---- variants (tile, taps per workgroup): 0 = 64x64 per tap, 1 = 128x128 per tap, 2 = 64x64 filter row, 3 = 128(co)x64 filter row,
+// 4 = 256x256 per tap with 8 waves (bf16 grouped launches only; `tile` = 256 allows it) ----
 int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   const bool row3 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
   const bool big = M >= 8192 && Cout >= 512 && Cin >= 512;
-  if (row3) return (tile == 128 || (!tile && Cout >= 512)) ? 3 : 2;
-  return (tile == 128 || (!tile && big && KH * KW == 1)) ? 1 : 0;
+  if (row3) return (tile == 128 || ((!tile || tile == 256) && Cout >= 512)) ? 3 : 2;
+  if (tile == 256 && big && KH * KW == 1 && Cout % 256 == 0 && Cin % 256 == 0) return 4;
+  return (tile == 128 || ((!tile || tile == 256) && big && KH * KW == 1)) ? 1 : 0;
 }
 void variant_tile(int v, int& bm, int& bn, int& tx) {
+  if (v == 4) { bm = 256; bn = 256; tx = 1; return; }
   bm = (v == 1 || v == 3) ? 128 : 64; bn = v == 1 ? 128 : 64; tx = v >= 2 ? 3 : 1;
 }
 long variant_tiles(int v, int Cin, int Cout, int KH, int KW) {
@@ -377,7 +388,7 @@ int launch_single(const l2s_wgrad_desc& d, int split, hipStream_t st) {
   return l2s_check_launch();
 }
 
-template <typename T, int BM, int BN, int TX, int D, int KSTEP>
+template <typename T, int BM, int BN, int TX, int D, int KSTEP, int WGM = 2, int WGN = 2>
 int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_split, hipStream_t st) {
   size_t lds = wgrad_lds<T, BM, BN, TX, KSTEP>();
   // A grouped launch is resident for hundreds of microseconds next to the main queue's small dependent launches, whose workgroups
@@ -388,8 +399,8 @@ int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_spl
   if (BM * BN >= 128 * 128) { if (want_big > lds) lds = want_big; }
   else if (want > lds) lds = want;
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP>), dim3(pre.tile0[pre.n]), dim3(256), lds, st, tab, pre, ws);
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>), dim3(pre.tile0[pre.n]), dim3(64 * WGM * WGN), lds, st, tab, pre, ws);
   if (any_split) {
     const float* wsc = ws;
     L2S_LAUNCH(wgrad_reduce_grouped_kernel, dim3(64, pre.n), dim3(256), 0, st, tab, wsc);
@@ -419,7 +430,7 @@ extern "C" long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW) 
 
 extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
                                       float* ws, size_t ws_bytes, hipStream_t stream) {
-  if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 3) return L2S_EINVAL;
+  if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 4) return L2S_EINVAL;
   wg_prefix pre;
   pre.n = nprob;
   long t = 0;
@@ -427,7 +438,7 @@ extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s
   for (int i = 0; i < nprob; ++i) {
     const wgp& q = table_host[i];
     if (!prob_ok(q, dtype) || !q.dw) return L2S_EINVAL;
-    if (variant >= 2 && !(q.KH == 3 && q.KW == 3 && q.stride == 1 && q.pad == 1)) return L2S_EINVAL;
+    if ((variant == 2 || variant == 3) && !(q.KH == 3 && q.KW == 3 && q.stride == 1 && q.pad == 1)) return L2S_EINVAL;
     const int split = q.split > 1 ? q.split : 1;
     if (split > 1) {
       const long slab = (long)q.Cout * q.KH * q.KW * q.Cin;
@@ -447,9 +458,13 @@ extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s
     case 0: return launch_grouped<T, 64, 64, 1, 2, KS>(table_dev, pre, ws, any_split, stream);    \
     case 1: return launch_grouped<T, 128, 128, 1, 2, KS>(table_dev, pre, ws, any_split, stream);  \
     case 2: return launch_grouped<T, 64, 64, 3, 2, KS>(table_dev, pre, ws, any_split, stream);    \
-    default: return launch_grouped<T, 128, 64, 3, 2, KS>(table_dev, pre, ws, any_split, stream);  \
+    case 3: return launch_grouped<T, 128, 64, 3, 2, KS>(table_dev, pre, ws, any_split, stream);   \
+    default: break;                                                                              \
   }
-  if (dtype == L2S_BF16) { GO(bf16_t, 2) }
+  if (dtype == L2S_BF16) {
+    if (variant == 4) return launch_grouped<bf16_t, 256, 256, 1, 2, 1, 4, 2>(table_dev, pre, ws, any_split, stream);
+    GO(bf16_t, 2)
+  }
   if (dtype == L2S_F32) { GO(float, 1) }
 #undef GO
   return L2S_EINVAL;

@@ -128,7 +128,7 @@ class WgradQueue(object):
                 dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
                 M = max(u[3] * u[7] * u[8] for u in seg)
                 same = all(u[7] == u[4] and u[8] == u[5] for u in seg)
-                v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, stride, pad, int(same), M, 0))
+                v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, stride, pad, int(same), M, 256 if net.dt == BF16 else 0))   # (256: the 8-wave 256x256 tile may be chosen)
                 rounds.setdefault((r // 2, v), []).append(seg)
         bkp = 32 if net.dt == BF16 else 16
         with net.fork_wgrad(fixed='wg'):
@@ -142,13 +142,15 @@ class WgradQueue(object):
                     tiles = [int(lib.l2s_wgrad_tiles(v, seg[0][6], seg[0][9], seg[0][10], seg[0][10])) for seg in chunk]
                     total = sum(tiles)
                     want = max(1, -(-self.MIN_WG // max(total, 1)))
+                    if v == 4:
+                        want = max(1, 256 // max(total, 1))       # one 8-wave workgroup per CU: fill one round, not more
                     arr = (WgradProb * len(chunk))()
                     flop, off = 0.0, 0
                     for i, seg in enumerate(chunk):
                         dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
                         q = arr[i]
                         q.dw, q.nseg, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad = dw.data_ptr(), len(seg), Cin, Cout, k, k, stride, pad
-                        slices = min(u[3] * u[7] * (u[8] + (1 if v >= 2 else 0)) // bkp for u in seg)
+                        slices = min(u[3] * u[7] * (u[8] + (1 if v in (2, 3) else 0)) // bkp for u in seg)
                         split = max(1, min(want, slices // 16, 16))
                         slab = Cout * k * k * Cin
                         if split > 1 and (off + split * slab) * 4 <= ws.numel() * 4:

@@ -396,7 +396,8 @@ def test_conv_wgrad_grouped(dt):
     g = torch.Generator().manual_seed(5)
     # (uses [(n, H, W)], Cin, Cout, k, stride, pad)
     convs = [([(1, 19, 23)], 64, 128, 3, 1, 1), ([(3, 7, 7), (1, 11, 13)], 128, 64, 3, 1, 1), ([(2, 9, 9)], 256, 72, 1, 1, 0),
-             ([(40, 7, 7), (1, 10, 12)], 512, 512, 1, 1, 0), ([(1, 20, 26)], 256, 128, 1, 2, 0), ([(20, 7, 7)], 512, 512, 3, 1, 1)]
+             ([(40, 7, 7), (1, 10, 12)], 512, 512, 1, 1, 0), ([(1, 20, 26)], 256, 128, 1, 2, 0), ([(20, 7, 7)], 512, 512, 3, 1, 1),
+             ([(170, 7, 7), (1, 10, 12)], 512, 768, 1, 1, 0)]          # >= 8192 pixels, 256-multiples: the 8-wave 256x256 tile in bf16
     byv, keep = {}, []
     for uses, Cin, Cout, k, s, p in convs:
         dw = torch.ones((Cout, k * k * Cin), dtype=torch.float32, device=DEV)
@@ -415,9 +416,10 @@ def test_conv_wgrad_grouped(dt):
             q.dy[si], q.x[si] = dyd.data_ptr(), xd.data_ptr()
             q.n_img[si], q.IH[si], q.IW[si], q.OH[si], q.OW[si], q.lddy[si], q.ldx[si] = n, H, W, OH, OW, Cout, Cin
             Mmax = max(Mmax, n * OH * OW); same = same and OH == H and OW == W
-        v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, s, p, int(same), Mmax, 0))
+        v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, s, p, int(same), Mmax, 256 if dt == 1 else 0))
         byv.setdefault(v, []).append((q, dw, ohwi(ref).reshape(Cout, k * k * Cin) + 1.0))
     assert len(byv) >= 3                                        # per-tap and filter-row tiles, 64- and 128-wide
+    assert (4 in byv) == (dt == 1)
     first = {}
     for rep in range(2):
         for v, lst in byv.items():
