@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void dynfilter_bwd3_kernel(const float* __rest
 // workgroup, 196 values) and att_res[d] = sum_l w[l] att[l][d] with 4 l-groups per 64 channels.
 __global__ __launch_bounds__(256) void cap_att_dots_kernel(const float* __restrict__ patt, const float* __restrict__ att_h, const float* __restrict__ aw,
                                                           const float* __restrict__ ab, int L, int D, float* tanh_ws, float* dots) {
+  __builtin_amdgcn_s_setprio(3);   // a link of the caption branch's dependent chain (the step's critical path): issue ahead of co-resident GEMM waves
   const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (l >= L) return;
   float s = 0.f;
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(1024) void lsm_nll_kernel(const float* logits, cons
 __global__ __launch_bounds__(256) void linear2_fwd_kernel(const float* __restrict__ x, int K, const float* __restrict__ w1, const float* __restrict__ b1,
                                                          float* y1, int N1, int acc1, const float* __restrict__ w2, const float* __restrict__ b2,
                                                          float* y2, int N2, int acc2, int nb1) {
+  __builtin_amdgcn_s_setprio(3);   // a link of the caption branch's dependent chain (the step's critical path): issue ahead of co-resident GEMM waves
   const bool second = (int)blockIdx.x >= nb1;
   const int n = ((int)blockIdx.x - (second ? nb1 : 0)) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int N = second ? N2 : N1;
@@ -666,6 +668,7 @@ __global__ __launch_bounds__(256) void linear_sum2_kernel(const float* __restric
 // dependent loads per wave): the launch sits on the caption branch's backward chain once per token
 __global__ __launch_bounds__(256) void linear_sum2_split_kernel(const float* __restrict__ x1, const float* __restrict__ w1, int K1, const float* __restrict__ x2,
                                                                const float* __restrict__ w2, int K2, float* y, int N, int accumulate) {
+  __builtin_amdgcn_s_setprio(3);   // a link of the caption branch's dependent chain (the step's critical path): issue ahead of co-resident GEMM waves
   __shared__ float part[4];
   const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* r1 = w1 + (long)n * K1; const float* r2 = w2 + (long)n * K2;
@@ -776,6 +779,7 @@ __global__ __launch_bounds__(1024) void cap_att_bwd_step_kernel(const float* __r
 __global__ __launch_bounds__(256) void cap_apply_gates_kernel(const float* __restrict__ P, const float* __restrict__ dots, const float* __restrict__ b,
                                                              const float* __restrict__ s, const float* __restrict__ c_prev, float* c, float* h,
                                                              float* save, float* weight, int L, int R) {
+  __builtin_amdgcn_s_setprio(3);   // a link of the caption branch's dependent chain (the step's critical path): issue ahead of co-resident GEMM waves
   __shared__ float w[256];
   __shared__ float red[4];
   __shared__ float p0[16][17], p1[16][17];
@@ -818,6 +822,7 @@ __global__ __launch_bounds__(256) void cap_apply_gates_kernel(const float* __res
 __global__ __launch_bounds__(256) void cap_gates_bwd_dw_kernel(const float* __restrict__ dh_a, const float* __restrict__ dh_b, const float* __restrict__ dc_in,
                                                               const float* __restrict__ save, const float* __restrict__ c_prev, const float* __restrict__ P,
                                                               float* ds, float* da2c, float* dc_prev, float* dweight, int L, int R) {
+  __builtin_amdgcn_s_setprio(3);   // a link of the caption branch's dependent chain (the step's critical path): issue ahead of co-resident GEMM waves
   __shared__ __attribute__((aligned(16))) float g[2048];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool out = blockIdx.x == 0;
@@ -854,6 +859,7 @@ __global__ __launch_bounds__(256) void cap_gates_bwd_dw_kernel(const float* __re
 // datt_h[d] = sum_l ddot[l] aw[d] (1 - tanh^2).  Workgroup = 16 channels x 64 location groups.
 __global__ __launch_bounds__(1024) void cap_att_bwd_step2_kernel(const float* __restrict__ dweight, const float* __restrict__ tanh_ws, const float* __restrict__ weight,
                                                                 const float* __restrict__ aw, int L, int D, float* ddot_out, float* datt_h) {
+  __builtin_amdgcn_s_setprio(3);   // a link of the caption branch's dependent chain (the step's critical path): issue ahead of co-resident GEMM waves
   __shared__ float ddot[256];
   __shared__ float red[16];
   __shared__ float part[64][17];
