@@ -61,6 +61,8 @@ typedef struct {
   int algo;                     /* kernel family: 0 = auto; L2S_ALGO_* forces one (benchmarks / tests; same arithmetic, speed only) */
   float* ws;                    /* optional float workspace for split-K partial sums: split x rows x Cout floats (any contents; one per stream) */
   size_t ws_floats;             /* its size; the split is reduced until the slabs fit */
+  int prio;                     /* 1: the kernel's waves raise their issue priority (s_setprio 3): launches of a latency-bound dependent chain that shares
+                                   CUs with throughput-bound background work (the backbone's convolutions beside the weight-gradient stream) */
 } l2s_conv_desc;
 int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t stream);
 /* name of the kernel l2s_conv_igemm launches for this problem (reporting: bench.py's roofline object); static storage */

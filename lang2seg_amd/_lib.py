@@ -17,7 +17,7 @@ class ConvDesc(C.Structure):
                 ('n_img', i32), ('IH', i32), ('IW', i32), ('Cin', i32), ('OH', i32), ('OW', i32), ('Cout', i32),
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('ldx', i32), ('ldy', i32), ('ldadd', i32), ('ldref', i32), ('flags', i32),
-                ('out_h', i32), ('out_w', i32), ('out_stride', i32), ('tile', i32), ('split_k', i32), ('xcd_mode', i32), ('algo', i32), ('ws', vp), ('ws_floats', sz)]
+                ('out_h', i32), ('out_w', i32), ('out_stride', i32), ('tile', i32), ('split_k', i32), ('xcd_mode', i32), ('algo', i32), ('ws', vp), ('ws_floats', sz), ('prio', i32)]
 
 
 class RoiBlock0Desc(C.Structure):

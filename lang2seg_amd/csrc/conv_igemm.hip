@@ -503,6 +503,7 @@ constexpr unsigned OOR = 0x80000000u;
 
 template <typename T, int BM, int BN, int WGM, int WGN, int D, bool OUTF32>
 __global__ __launch_bounds__(64 * WGM * WGN, (BM * BN >= 128 * 128 && WGM * WGN == 4) ? 2 : ((BM * BN <= 64 * 64 && D == 2 && L2S_RING64_MINWG > 1) ? L2S_RING64_MINWG : 1)) void igemm_ring_kernel(const l2s_conv_desc p) {
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   constexpr int VE = 16 / (int)sizeof(T);
   constexpr int RB = ROWB;                      // bytes of K per LDS row per slice
   constexpr int BK = RB / (int)sizeof(T);
@@ -708,6 +709,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (BM * BN >= 128 * 128 && WGM * WGN 
 // ------------------------------------------------------------------------------------------------
 template <int D, int BN, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void igemm_ws64_kernel(const l2s_conv_desc p) {
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   // STAMP (tools/ws64_stamps.py, algo 8): lane 0 of the first multiplier wave stores the 100 MHz clock at four points of every workgroup
   // into p.ws: [workgroup][entry, first slice landed, K loop done, stores drained]
   unsigned long long t_entry = 0;
@@ -1338,6 +1340,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(512) void igemm_ks64_kernel(const l2s_conv_desc p) {
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   typedef bf16_t T;
   constexpr int BM = 64, BN = 64, RB2 = 256, BK = 128, STG = (BM + BN) * RB2, PW = 4;   // PW: pieces per requester wave and operand
   constexpr unsigned NOPE = 0x80000000u;
@@ -1555,6 +1558,7 @@ __global__ __launch_bounds__(512) void igemm_ks64_kernel(const l2s_conv_desc p) 
 // ------------------------------------------------------------------------------------------------
 template <int BN, int PR, int NS>
 __global__ __launch_bounds__(512) void igemm_p3_kernel(const l2s_conv_desc p) {
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   typedef bf16_t T;
   constexpr int BM = 128, RB = 64, TN = BN / 16;
   constexpr int PA = PR / 16, PB = 9 * BN / 16;                  // one-KiB pieces (16 rows x 64 B) of the patch / of the weights per step

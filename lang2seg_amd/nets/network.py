@@ -26,6 +26,9 @@ class ConvOp(object):
         self.net, self.wkey, self.Cin, self.Cout, self.k, self.stride, self.pad = net, wkey, Cin, Cout, k, stride, pad
         self.bias_key, self.need_dgrad, self.group = bias_key, need_dgrad, group
         self.Np = Cout if Cout_pad is None else Cout_pad      # padded output width (grouped heads)
+        # the backbone's layer1-3 launches form latency-bound dependent chains that share their CUs with the weight-gradient stream: their
+        # waves issue first (l2s_conv_desc.prio)
+        self.prio = 1 if str(wkey).startswith(('resnet.layer1.', 'resnet.layer2.', 'resnet.layer3.')) and getattr(net, 'chain_prio', True) else 0
         P = net.P
         taps = k * k
         cnt = self.Np * taps * Cin
@@ -70,7 +73,7 @@ class ConvOp(object):
     def fwd(self, x, n, IH, IW, y, add=None, relu=False, out_f32=False, tile=0):
         OH, OW = self.out_hw(IH, IW)
         O.conv_igemm(x, self.wf, y, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad,
-                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt, ws=self.net.splitk_ws(n * OH * OW * self.Np))
+                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt, ws=self.net.splitk_ws(n * OH * OW * self.Np), prio=self.prio)
         return y
 
     def dgrad(self, g, n, IH, IW, dx, add=None, ref=None):
@@ -78,11 +81,11 @@ class ConvOp(object):
         OH, OW = self.out_hw(IH, IW)
         if self.stride == 1:
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, IH, IW, self.Cin, self.k, self.k, 1, self.k - 1 - self.pad,
-                         add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin))
+                         add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin), prio=self.prio)
         else:
             assert self.k == 1
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, OH, OW, self.Cin, 1, 1, 1, 0, add=add, ref=ref,
-                         scatter=(IH, IW, self.stride), dt=self.net.dt)
+                         scatter=(IH, IW, self.stride), dt=self.net.dt, prio=self.prio)
         return dx
 
     def wgrad(self, g, x, n, IH, IW):

@@ -96,7 +96,7 @@ LAST_PLAN = None        # name of the kernel the dispatcher picked for the last 
 
 def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
                ref=None, relu=False, out_f32=False, deconv=False, scatter=None, ldx=None, ldy=None, ldadd=None,
-               ldref=None, tile=0, dt=None, ws=None, split_k=0, xcd_mode=-1, algo=None):
+               ldref=None, tile=0, dt=None, ws=None, split_k=0, xcd_mode=-1, algo=None, prio=0):
     d = ConvDesc()
     d.x, d.w, d.y = ptr(x), ptr(w), ptr(y)
     d.bias, d.add, d.ref = ptr(bias), ptr(add), ptr(ref)
@@ -124,6 +124,7 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     d.algo = CONV_ALGO if algo is None else algo
     d.ws = ptr(ws)
     d.ws_floats = 0 if ws is None else ws.numel()
+    d.prio = prio
     global LAST_PLAN
     dtv = dt_of(x) if dt is None else dt
     LAST_PLAN = _lib.load().l2s_conv_plan_name(C.byref(d), dtv).decode()
