@@ -196,7 +196,7 @@ class LaunchTimer(object):
 
             def __exit__(s, *a):
                 e1 = T.cuda.Event(enable_timing=True); e1.record()
-                recs.append(('%s [%s]' % (tag, ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3')[variant]), 'wgrad', 3 if variant >= 2 else k, flop, s.e0, e1))
+                recs.append(('%s [%s]' % (tag, ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3', '256x256/tap')[variant]), 'wgrad', 3 if variant in (2, 3) else k, flop, s.e0, e1))
         return _C()
 
     def summary(self, steps):

@@ -308,6 +308,8 @@ int l2s_linear_bwd_x(const float* dy, int lddy, const float* w, float* dx, int l
 int l2s_linear_bwd_w(const float* dy, int lddy, const float* x, int ldx, float* dw, float* db, int M, int N, int K, hipStream_t s);
 /* activation backward in place: dy *= act'(y)  (act 1 relu, 2 tanh) */
 int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream_t s);
+/* x *= mul (mul may be NULL); x = 0 where !(relu_ref > 0); out = x cast to out_dtype: dropout mask + ReLU backward + cast in one launch */
+int l2s_mask_relu_cast(float* x, const float* mul, const float* relu_ref, void* out, int out_dtype, long n, hipStream_t s);
 /* embedding gather out[t][:] = table[ids[t]][:] * (mask ? mask[t][:] : 1), optional relu; and scatter-add backward */
 int l2s_embed_fwd(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu, hipStream_t s);
 int l2s_embed_bwd(const float* dout, const float* out, const int64_t* ids, const float* mask, float* dtable, int T, int D, int relu, hipStream_t s);

@@ -112,6 +112,7 @@ SIGS = {
     'l2s_linear_bwd_x_ws_floats': (i64, [i32, i32, i32]),
     'l2s_linear_bwd_w': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, vp]),
     'l2s_act_bwd': (i32, [vp, vp, i64, i32, vp]),
+    'l2s_mask_relu_cast': (i32, [vp, vp, vp, vp, i32, i64, vp]),
     'l2s_embed_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     'l2s_embed_bwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     'l2s_lstm_cell_fwd': (i32, [vp, vp, vp, vp, vp, i32, vp]),

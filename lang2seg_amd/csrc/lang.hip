@@ -149,6 +149,19 @@ __global__ void act_bwd_kernel(float* dy, const float* y, long n, int act) {
   }
 }
 
+// x *= mul (optional); x = 0 where !(relu_ref > 0); out = x in the activation dtype: dropout mask, ReLU backward and the cast in front of a
+// convolution's data gradient in ONE launch (the tail of the captioner's backward pass, on the caption branch's critical chain)
+template <typename T>
+__global__ void mask_relu_cast_kernel(float* x, const float* __restrict__ mul, const float* __restrict__ relu_ref, T* out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (mul) v *= mul[i];
+    if (!(relu_ref[i] > 0.f)) v = 0.f;
+    x[i] = v;
+    Elem<T>::st(out + i, v);
+  }
+}
+
 __global__ void embed_fwd_kernel(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu) {
   const int t = blockIdx.x;
   const float* row = table + ids[t] * (long)D;
@@ -890,19 +903,21 @@ __global__ __launch_bounds__(1024) void cap_att_bwd_step2_kernel(const float* __
   }
 }
 // after the loop: everything the per-step kernel left out, summed over the S steps in one launch.  A workgroup owns 16 channels d
-// (16 location lanes x 16 channels): dpatt / datt rows are written per (l, d), the alpha_net weight gradient daw[d] is summed over all
-// locations inside the workgroup in a fixed order (no atomics); workgroup 0 also takes the bias gradient.
-__global__ __launch_bounds__(256) void cap_att_bwd_batched_kernel(const float* __restrict__ ddot, const float* __restrict__ weight, const float* __restrict__ dres,
-                                                                 int ldr, const float* __restrict__ tanh_ws, const float* __restrict__ aw, int S, int L, int D,
-                                                                 float* dpatt, float* datt, float* daw, float* dab) {
-  __shared__ float part[16][16];
-  __shared__ float red[4];
+// (64 location lanes x 16 channels; round 3: 1024 threads instead of 256 - the launch sits on the caption branch's critical chain and each
+// thread's (location, step) loop is a chain of dependent loads: 65-89 -> ~25 us): dpatt / datt rows are written per (l, d), the alpha_net
+// weight gradient daw[d] is summed over all locations inside the workgroup in a fixed order (no atomics); workgroup 0 also takes the bias
+// gradient.
+__global__ __launch_bounds__(1024) void cap_att_bwd_batched_kernel(const float* __restrict__ ddot, const float* __restrict__ weight, const float* __restrict__ dres,
+                                                                  int ldr, const float* __restrict__ tanh_ws, const float* __restrict__ aw, int S, int L, int D,
+                                                                  float* dpatt, float* datt, float* daw, float* dab) {
+  __shared__ float part[64][16];
+  __shared__ float red[16];
   const int tid = threadIdx.x, dl = tid & 15, ll = tid >> 4;
   const int d = blockIdx.x * 16 + dl;
   float dwsum = 0.f;
   if (d < D) {
     const float a = aw[d];
-    for (int l = ll; l < L; l += 16) {
+    for (int l = ll; l < L; l += 64) {
       float dp = 0.f, da = 0.f, dw = 0.f;
       for (int t = 0; t < S; ++t) {
         const float dd = ddot[(long)t * L + l], w = weight[(long)t * L + l];
@@ -920,12 +935,12 @@ __global__ __launch_bounds__(256) void cap_att_bwd_batched_kernel(const float* _
   __syncthreads();
   if (ll == 0 && d < D) {
     float v = 0.f;
-    for (int g = 0; g < 16; ++g) v += part[g][dl];
+    for (int g = 0; g < 64; ++g) v += part[g][dl];
     daw[d] += v;
   }
   if (blockIdx.x == 0) {
     float sb = 0.f;
-    for (int e = tid; e < S * L; e += 256) sb += ddot[e];
+    for (int e = tid; e < S * L; e += 1024) sb += ddot[e];
     sb = block_sum(sb, red);
     if (tid == 0) dab[0] += sb;
   }
@@ -1221,6 +1236,13 @@ extern "C" int l2s_act_bwd(float* dy, const float* y, long n, int act, hipStream
   L2S_LAUNCH(act_bwd_kernel, dim3(cdiv(n, 256) > 1024 ? 1024 : cdiv(n, 256)), dim3(256), 0, s, dy, y, n, act);
   return l2s_check_launch();
 }
+extern "C" int l2s_mask_relu_cast(float* x, const float* mul, const float* relu_ref, void* out, int out_dtype, long n, hipStream_t s) {
+  if (!x || !relu_ref || !out || (out_dtype != L2S_BF16 && out_dtype != L2S_F32)) return L2S_EINVAL;
+  const int g = cdiv(n, 256) > 1024 ? 1024 : (int)cdiv(n, 256);
+  if (out_dtype == L2S_BF16) { L2S_LAUNCH(mask_relu_cast_kernel<bf16_t>, dim3(g), dim3(256), 0, s, x, mul, relu_ref, (bf16_t*)out, n); }
+  else { L2S_LAUNCH(mask_relu_cast_kernel<float>, dim3(g), dim3(256), 0, s, x, mul, relu_ref, (float*)out, n); }
+  return l2s_check_launch();
+}
 extern "C" int l2s_embed_fwd(const float* table, const int64_t* ids, const float* mask, float* out, int T, int D, int relu, hipStream_t s) {
   L2S_LAUNCH(embed_fwd_kernel, dim3(T), dim3(256), 0, s, table, ids, mask, out, T, D, relu);
   return l2s_check_launch();
@@ -1356,7 +1378,7 @@ extern "C" int l2s_cap_attention_bwd_step(const float* datt_res, const float* at
 }
 extern "C" int l2s_cap_attention_bwd_batched(const float* ddot, const float* weight, const float* datt_res, int ldr, const float* tanh_ws,
                                              const float* aw, int S, int L, int D, float* dpatt, float* datt, float* daw, float* dab, hipStream_t s) {
-  L2S_LAUNCH(cap_att_bwd_batched_kernel, dim3(cdiv(D, 16)), dim3(256), 0, s, ddot, weight, datt_res, ldr, tanh_ws, aw, S, L, D, dpatt, datt, daw, dab);
+  L2S_LAUNCH(cap_att_bwd_batched_kernel, dim3(cdiv(D, 16)), dim3(1024), 0, s, ddot, weight, datt_res, ldr, tanh_ws, aw, S, L, D, dpatt, datt, daw, dab);
   return l2s_check_launch();
 }
 extern "C" int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save, int R, hipStream_t s) {

@@ -247,8 +247,26 @@ class resnetv1(Network):
 
     # ------------------------------------------------------------------ att2in2 captioner (ATT:60-101,406-466; CRIT:43-53)
     # states live in (S+1)-row arrays, row 0 = zeros: h(i) = row i+1, h(i-1) = row i.
+    def _caption_pre(self, d):
+        """token-only part of _caption_fwd / _caption_bwd, issued early on the language stream"""
+        P, S = self.P, d['S']
+        R, IE, AH, L = self.opt['rnn_size'], self.opt['input_encoding_size'], self.opt['att_hid_size'], 196
+        pv = lambda k: P.view('caption_model.' + k)
+        pre = {'drop_att': self._drop('att', (L, R), self.opt['drop_prob_lm']), 'drop_xt': self._drop('xt', (S, IE), self.opt['drop_prob_lm']),
+               'drop_out': self._drop('out', (S, R), self.opt['drop_prob_lm'])}
+        xt = self.buf('cap.xt', (S, IE), f32)
+        O.embed_fwd(pv('embed.0.weight'), d['cap_in'], pre['drop_xt'], xt, S, IE, True)
+        sums = self.buf('cap.sums', (S, 5 * R), f32)
+        O.linear_fwd(xt, pv('core.i2h.weight'), pv('core.i2h.bias'), sums, S, 5 * R, IE)
+        proj = self.cap_projected and R <= 1024
+        nz = L * AH + L * R + 4 * R
+        self.buf('cap.bwd_zero', (nz + (L * 2 * R if proj else 0),), f32, zero=True)
+        pre.update(xt=xt, sums=sums, zeroed=True)
+        return pre
+
     def _caption_fwd(self, d, att_feats, loss):
         P, t, S = self.P, self.t, d['S']
+        pre = getattr(self, '_cap_pre', None)
         R, IE, AH, L = self.opt['rnn_size'], self.opt['input_encoding_size'], self.opt['att_hid_size'], 196
         V1 = self.opt['vocab_size'] + 1
         SC = 256                                             # per-row scratch tail of the attention kernels
@@ -256,7 +274,7 @@ class resnetv1(Network):
         a = self.buf('cap.a', (L, R), f32)
         self.att_embed.fwd(att_feats, L, 1, 1, a, relu=True, out_f32=True)
         t['cap.a_pre'] = a
-        dm = self._drop('att', (L, R), self.opt['drop_prob_lm'])
+        dm = pre['drop_att'] if pre else self._drop('att', (L, R), self.opt['drop_prob_lm'])
         t['cap.drop_att'] = dm
         if dm is not None:
             ad = self.buf('cap.ad', (L, R), f32); O.mul(a, dm, ad)
@@ -264,11 +282,14 @@ class resnetv1(Network):
             ad = a
         patt = self.buf('cap.patt', (L, AH), f32)
         O.linear_fwd(ad, pv('ctx2att.weight'), pv('ctx2att.bias'), patt, L, AH, R)
-        xt = self.buf('cap.xt', (S, IE), f32)
-        t['cap.drop_xt'] = self._drop('xt', (S, IE), self.opt['drop_prob_lm'])
-        O.embed_fwd(pv('embed.0.weight'), d['cap_in'], t['cap.drop_xt'], xt, S, IE, True)
-        sums = self.buf('cap.sums', (S, 5 * R), f32)
-        O.linear_fwd(xt, pv('core.i2h.weight'), pv('core.i2h.bias'), sums, S, 5 * R, IE)
+        if pre:
+            xt, sums, t['cap.drop_xt'] = pre['xt'], pre['sums'], pre['drop_xt']
+        else:
+            xt = self.buf('cap.xt', (S, IE), f32)
+            t['cap.drop_xt'] = self._drop('xt', (S, IE), self.opt['drop_prob_lm'])
+            O.embed_fwd(pv('embed.0.weight'), d['cap_in'], t['cap.drop_xt'], xt, S, IE, True)
+            sums = self.buf('cap.sums', (S, 5 * R), f32)
+            O.linear_fwd(xt, pv('core.i2h.weight'), pv('core.i2h.bias'), sums, S, 5 * R, IE)
         hs = self.buf('cap.hfull', (S + 1, R), f32); cs = self.buf('cap.cfull', (S + 1, R), f32); save = self.buf('cap.save', (S, 6 * R), f32)
         att_h = self.buf('cap.att_h', (S, AH), f32); tanh_ws = self.buf('cap.tanh', (S, L, AH), f32)
         wgt = self.buf('cap.wgt', (S, L), f32); ares = self.buf('cap.ares', (S, R + SC), f32); a2c = self.buf('cap.a2c', (S, 2 * R), f32)
@@ -289,7 +310,7 @@ class resnetv1(Network):
             O.cap_attention_fwd(patt, ad, att_h[i], pv('core.attention.alpha_net.weight'), pv('core.attention.alpha_net.bias'), L, AH,
                                 tanh_ws[i], wgt[i], ares[i])
             O.cap_a2c_gates_fwd(ares[i], pv('core.a2c.weight'), pv('core.a2c.bias'), R, sums[i], cs[i], cs[i + 1], hs[i + 1], save[i], R)
-        t['cap.drop_out'] = self._drop('out', (S, R), self.opt['drop_prob_lm'])
+        t['cap.drop_out'] = pre['drop_out'] if pre else self._drop('out', (S, R), self.opt['drop_prob_lm'])
         if t['cap.drop_out'] is not None:
             ho = self.buf('cap.ho', (S, R), f32); O.mul(hs[1:], t['cap.drop_out'], ho)
         else:
@@ -325,7 +346,7 @@ class resnetv1(Network):
         proj = self.cap_projected and R <= 1024
         # dpatt | dad | dh | dc (| dP): one buffer, one clear
         nz = L * AH + L * R + 4 * R
-        zb = self.buf('cap.bwd_zero', (nz + (L * 2 * R if proj else 0),), f32, zero=True)
+        zb = self.buf('cap.bwd_zero', (nz + (L * 2 * R if proj else 0),), f32, zero=not (getattr(self, '_cap_pre', None) or {}).get('zeroed'))
         dpatt = zb[:L * AH].view(L, AH); dad = zb[L * AH:L * AH + L * R].view(L, R)
         dh = zb[L * AH + L * R:L * AH + L * R + 2 * R].view(2, R); dc = zb[L * AH + L * R + 2 * R:nz].view(2, R)
         wT_h2h = self.wT['caption_model.core.h2h.weight'][0]; wT_h2att = self.wT['caption_model.core.attention.h2att.weight'][0]
@@ -368,11 +389,9 @@ class resnetv1(Network):
         later.append(recurrence_grads)
         # ctx2att
         self.bwd_x(dpatt, 'caption_model.ctx2att.weight', dad, L, accumulate=True)
-        if t['cap.drop_att'] is not None:
-            O.mul(dad, t['cap.drop_att'], dad)                 # (the mask multiplies the accumulated sum, not only this term)
-        O.act_bwd(dad, t['cap.a_pre'], 1)
         dadT = self.buf('cap.dadT', (L, R))
-        O.cast(dad, dadT)
+        # dropout mask (it multiplies the accumulated sum, not only this term), ReLU backward and the cast to the activation dtype: one launch
+        O.mask_relu_cast(dad, t['cap.drop_att'], t['cap.a_pre'], dadT)
         self.att_embed.wgrad(dadT, att_feats, L, 1, 1)
         datt = self.buf('cap.datt_feats', (L, self.opt['att_feat_size']))
         self.att_embed.dgrad(dadT, L, 1, 1, datt)
@@ -590,6 +609,9 @@ class resnetv1(Network):
                 if not hasattr(self, '_r_one'):
                     self._r_one = torch.tensor([1.0, 0, 0, 0, 0, 0, 0], dtype=f32, device=self.device)
                 O.memcpy(filt[7 * C4:], self._r_one)
+            # the pieces of the captioner that depend only on the tokens and the RNG counter (dropout masks, word embedding, i2h sums, the
+            # zeroed backward buffer): off the caption branch's dependent chain, which is the step's critical path
+            self._cap_pre = self._caption_pre(d) if (self.var['cap'] is not None and 'cap' not in self.knockout) else None
         self._mark('encoder_fwd(lang)')
         saved = {}
         base, Hc, Wc = self._backbone_fwd(d, saved)

@@ -373,6 +373,11 @@ def linear_bwd_w(dy, x, dw, db, M, N, K, lddy=None, ldx=None):
          K, stream())
 
 
+def mask_relu_cast(x, mul, relu_ref, out):
+    """x *= mul (optional); x = 0 where relu_ref <= 0; out = x in out's dtype (one launch)"""
+    call('l2s_mask_relu_cast', ptr(x), ptr(mul), ptr(relu_ref), ptr(out), dt_of(out), x.numel(), stream())
+
+
 def act_bwd(dy, y, act):
     call('l2s_act_bwd', ptr(dy), ptr(y), dy.numel(), act, stream())
 
