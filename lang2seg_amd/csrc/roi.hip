@@ -146,10 +146,9 @@ __device__ __forceinline__ bool nms_hit(const float4& a, float aarea, const floa
   const float ovr = inter / uni;                          // nms.c:55-58
   return cmp ? (ovr > thr) : (ovr >= thr);
 }
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int cb, uint64_t* mask, const int* done, int done_at) {
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int cb, uint64_t* mask) {
   const int rb = blockIdx.y, cbk = blockIdx.x;
   if (cbk < rb) return;
-  if (done && *done >= done_at) return;            // (second stage of l2s_nms: the prefix already yielded max_keep boxes)
   __shared__ float4 cbox[64];
   __shared__ float carea[64];
   const int lane = threadIdx.x;
@@ -181,8 +180,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 //           for every column >= j+NDIR+1 (one wave per row, contiguous 512-byte pieces), rests in phase j+2 and applies them in phase
 //           j+3 - two phases for the loads, still one phase before the first of those columns is read.
 // Stops as soon as max_keep boxes are kept (RPN_POST_NMS_TOP_N).
-__global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out, int second) {
-  if (second && *num_out >= max_keep) return;      // (uniform: every thread reads the same word before anything is written)
+__global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out) {
   constexpr int NDIR = 3, PD = 3;                  // direct columns per row; phases between wave 0's requests and their use
   extern __shared__ unsigned long long remv[];     // cb words
   __shared__ unsigned long long kept_sh[2];
@@ -904,21 +902,8 @@ extern "C" int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_m
   if (n <= 0) return L2S_EINVAL;
   const int cb = cdiv(n, 64);
   if ((size_t)(cb + 2) * 8 > 60000) return L2S_EINVAL;
-  // Greedy NMS decides box i from boxes < i only, and the scan stops at max_keep: with 12000 -> 2000 the 2000th kept box is row 3100-4500
-  // of a fresh RPN, so the 36 M IoUs and the 188-word rows of the full mask are mostly never looked at.  Stage 1 runs the exact algorithm on
-  // the PREFIX of 2.3 max_keep boxes (mask 7x smaller, rows 72 words: the scan's bulk traffic, which paces it, shrinks 3x); if that yields
-  // max_keep boxes the answer is final and identical to the full run's.  Otherwise stage 2 - launched unconditionally, its workgroups
-  // return at once when stage 1 sufficed (no host round trip) - recomputes over all n boxes.
-  const int n1 = min(n, cdiv((int)(max_keep * 2.3f), 64) * 64);
-  const int cb1 = cdiv(n1, 64);
-  const int* nd = nullptr;
-  L2S_LAUNCH(nms_mask_kernel, dim3(cb1, cb1), dim3(64), 0, s, sorted_boxes, n1, thresh, cmp_mode, cb1, mask_ws, nd, 0);
-  L2S_LAUNCH(nms_reduce_kernel, dim3(1), dim3(1024), (size_t)(cb1 + 2) * 8, s, (const uint64_t*)mask_ws, n1, cb1, max_keep, keep_out, num_out, 0);
-  if (n1 < n) {
-    const int* done = num_out;
-    L2S_LAUNCH(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, cb, mask_ws, done, max_keep);
-    L2S_LAUNCH(nms_reduce_kernel, dim3(1), dim3(1024), (size_t)(cb + 2) * 8, s, (const uint64_t*)mask_ws, n, cb, max_keep, keep_out, num_out, 1);
-  }
+  L2S_LAUNCH(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, cb, mask_ws);
+  L2S_LAUNCH(nms_reduce_kernel, dim3(1), dim3(1024), (size_t)(cb + 2) * 8, s, (const uint64_t*)mask_ws, n, cb, max_keep, keep_out, num_out);
   return l2s_check_launch();
 }
 extern "C" int l2s_gather_rois(const float* sorted_boxes, const float* sorted_scores, const int* keep, const int* num, int max_keep,

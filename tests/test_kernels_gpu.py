@@ -384,39 +384,6 @@ def test_conv_bwd(cfg, dt):
         assert rel_err(dw3, refw) < 1e-4, kw
 
 
-@pytest.mark.parametrize('crowd', [2500, 1800, 0])
-def test_nms_prefix_stage_and_fallback(crowd):
-    """l2s_nms runs the exact algorithm on a prefix of 2.3 x max_keep boxes first and recomputes over all boxes only when the prefix did
-    not yield max_keep (decided on the device).  `crowd` leading boxes are near-copies of five boxes (so the prefix keeps only a handful
-    and the second stage has to run: 2500 > the 2304-box prefix, 1800 inside it), 0 = distinct boxes (the first stage suffices): keep lists
-    bit-exact against the numpy oracle for both comparators either way."""
-    O = ops()
-    from oracle import boxes as OB
-    rs = np.random.RandomState(3)
-    n, max_keep = 6000, 1000
-    ctr = rs.rand(n, 2) * np.array([900, 500]) + 40
-    wh = rs.rand(n, 2) * 60 + 12
-    bx = np.hstack((ctr - wh / 2, ctr + wh / 2)).astype(np.float32)
-    if crowd:
-        base = bx[:5].copy()
-        bx[:crowd] = base[np.arange(crowd) % 5] + (rs.rand(crowd, 4).astype(np.float32) - 0.5) * 0.5
-    sc = np.sort(rs.rand(n).astype(np.float32))[::-1].copy()
-    sb = torch.from_numpy(bx).to(DEV)
-    dets = np.hstack((bx, sc[:, None]))
-    for cmp_mode, name in [(0, 'ge'), (1, 'gt')]:
-        ws = torch.empty(O.nms_workspace_bytes(n) // 8 + 8, dtype=torch.int64, device=DEV)
-        keep = torch.full((max_keep,), -1, dtype=torch.int32, device=DEV); num = torch.zeros(1, dtype=torch.int32, device=DEV)
-        O.nms(sb, n, 0.7, cmp_mode, max_keep, ws, keep, num)
-        torch.cuda.synchronize()
-        ref_all = OB.nms(dets, 0.7, name)
-        prefix_kept = int((ref_all < 2304).sum())
-        assert (prefix_kept < max_keep) == bool(crowd), (crowd, prefix_kept)         # the case exercises the stage it is meant to
-        ref_keep = ref_all[:max_keep]
-        nk = int(num.item())
-        assert nk == len(ref_keep), (crowd, name, nk, len(ref_keep))
-        assert np.array_equal(keep.cpu().numpy()[:nk], ref_keep.astype(np.int32)), (crowd, name)
-
-
 @pytest.mark.parametrize('dt', [0, 1])
 def test_conv_wgrad_grouped(dt):
     """l2s_conv_wgrad_grouped: the weight gradients of several convolutions in one launch per tile variant (what a backward stage of the
