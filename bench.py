@@ -21,6 +21,7 @@ every step, the roofline of the dominant launch, of the whole 3x3 stack and of t
 convolution launches, and the CPU restatement timed on this box's host cores."""
 import argparse
 import json
+import re
 import os
 import subprocess
 import sys
@@ -135,6 +136,37 @@ def _pmc_traffic(which):
     return None, None, None, None
 
 
+def _rocprof_avgs(names):
+    """average in-step kernel durations (us) of the given kernel templates from the committed rocprofv3 summary of the same command
+    (tools/prof_step.sh -> profiles/r03_step_kernel_stats.csv): execution time only, without the wait for a free slot that the
+    HIP-event figures include"""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_step_kernel_stats.csv')
+    out = {}
+    try:
+        import csv
+        rows = list(csv.DictReader(open(f)))
+    except Exception:
+        return None
+    for n in names:
+        m = re.match(r'(\w+)<([\d, ]+)>', n) or re.match(r'(\w+)', n)
+        base, args_ = m.group(1), (m.group(2).replace(' ', '').split(',') if m.lastindex and m.lastindex > 1 else [])
+        tot = cnt = 0.0
+        for r in rows:
+            k = r['kernel'].replace(' ', '')
+            if not k.startswith(base + '<') and not k.startswith(base + '('):
+                continue
+            ka = re.findall(r'-?\d+', k.split('(')[0].split('<', 1)[1]) if '<' in k.split('(')[0] else []
+            if base == 'igemm_ring_kernel':
+                ok = ka[0:2] == args_[:2] and 'true' not in k.split('(')[0]
+            else:
+                ok = all(a in ka for a in args_)
+            if ok:
+                tot += float(r['total_us_per_step']); cnt += float(r['launches_per_step'])
+        if cnt:
+            out[n] = round(tot / cnt, 2)
+    return out or None
+
+
 class LaunchTimer(object):
     """HIP events around every convolution launch of eager steps, recorded on the stream the launch goes to (the weight-gradient
     launches run on their own streams; torch.cuda.Event.record() uses the current stream, which ConvOp switches before launching)."""
@@ -145,6 +177,9 @@ class LaunchTimer(object):
         self.O = ops
         self.plans = {}               # group -> kernel names the dispatcher chose (l2s_conv_plan_name)
         self.tape_pairs = []          # (id0, id1) timing events the launch tape records around the dominant launch in every replayed step
+        self.tape_all = False         # measurement tape: timing events around EVERY convolution / grouped weight-gradient launch
+        self.tape_recs = []           # (group, kind, k, flop, id0, id1) of that tape
+        self.tape_ms = None           # [(group, kind, k, flop, ms)]: mean over the replays read back
         for c in net.convs:
             self._wrap(c)
         net.wgq.on_launch = self.wgrad_hook
@@ -166,6 +201,15 @@ class LaunchTimer(object):
             orig = getattr(conv, kind)
 
             def timed(x, n, IH, IW, *rest, _orig=orig, _kind=kind, **kw):
+                if not self.on and self.tape_all:
+                    OH, OW = conv.out_hw(IH, IW)
+                    flop = 2.0 * n * OH * OW * conv.Np * conv.k * conv.k * conv.Cin
+                    self.O.LAST_PLAN = None
+                    a = self.O.tape_time_event(); r = _orig(x, n, IH, IW, *rest, **kw); b = self.O.tape_time_event()
+                    if a >= 0 and b >= 0:
+                        self.tape_recs.append((self._group(conv, n, IH, IW), _kind, conv.k, flop, a, b))
+                        self.plans.setdefault('%s %s' % (self._group(conv, n, IH, IW), _kind), set()).add(self.O.LAST_PLAN or '?')
+                    return r
                 if not self.on:
                     if _kind == 'fwd' and conv.k == 3 and n > 1 and self._group(conv, n, IH, IW) == 'layer4@RoIs':
                         # the step that records the tape: bracket this launch with timing events that every replay records again
@@ -186,6 +230,19 @@ class LaunchTimer(object):
 
     def wgrad_hook(self, tag, variant, flop, k):
         """context around one grouped weight-gradient launch (all weight gradients of a backward stage with one tile variant)"""
+        names = ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3', '256x256/tap')
+        if not self.on and self.tape_all:
+            lt = self
+
+            class _T(object):
+                def __enter__(s):
+                    s.a = lt.O.tape_time_event()
+
+                def __exit__(s, *a_):
+                    b = lt.O.tape_time_event()
+                    if s.a >= 0 and b >= 0:
+                        lt.tape_recs.append(('%s [%s]' % (tag, names[variant]), 'wgrad', 3 if variant in (2, 3) else k, flop, s.a, b))
+            return _T()
         if not self.on:
             return None
         T, recs = self.torch, self.recs
@@ -202,8 +259,10 @@ class LaunchTimer(object):
     def summary(self, steps):
         """(per-group table, 3x3 stack, time-dominant group); times are per step, bias column sums ride with the wgrad launches"""
         groups, s3 = {}, [0.0, 0.0, 0]
-        for grp, kind, k, flop, e0, e1 in self.recs:
-            ms = e0.elapsed_time(e1)
+        src = [(g_, kd, k, fl, ms_) for g_, kd, k, fl, ms_ in self.tape_ms] if self.tape_ms else [(g_, kd, k, fl, e0.elapsed_time(e1)) for g_, kd, k, fl, e0, e1 in self.recs]
+        if self.tape_ms:
+            steps = 1
+        for grp, kind, k, flop, ms in src:
             g = groups.setdefault('%s %s' % (grp, kind), [0.0, 0.0, 0])
             g[0] += flop; g[1] += ms; g[2] += 1
             if k == 3:
@@ -218,7 +277,7 @@ class LaunchTimer(object):
                      'launches_per_step': s3[2] / steps, 'ms_per_step': s3[1] / steps, 'gflop_per_step': s3[0] / steps / 1e9,
                      'note': 'every 3x3 convolution of the step (forward and data-gradient launches; the weight gradients as the grouped '
                              'filter-row launches of each backward stage; layer2/3/4 + RPN): summed algorithmic FLOPs / summed HIP-event time '
-                             'of the launches, eager multi-stream steps'}
+                             'of the launches (%s)' % ('events on the launch tape, pipelined replayed steps' if self.tape_ms else 'eager multi-stream steps')}
         return tab, stack, dom
 
 
@@ -337,6 +396,27 @@ def main(argv=None):
                 net.train_step_async(blobs[i % 4], 0, optim)
             barrier()
             dom_ms += [lt.O.time_event_elapsed(a, b) for a, b in lt.tape_pairs]
+    # ---- per-launch times of EVERY convolution / grouped weight-gradient launch inside pipelined replayed steps: a second tape with a timing
+    # event before and after each of those launches (outside the timed region: ~400 event records per step) ----
+    if args.extras and getattr(net, 'use_tape', False) and world == 1:
+        lt.tape_all = True
+        while getattr(net, '_tapes', None):
+            net._evict_tape()
+        net.train_step_async(blobs[0], 0, optim)                 # records the measurement tape
+        barrier()
+        acc = None
+        NREP = 4
+        for rep in range(NREP):
+            for i in range(2):
+                net.train_step_async(blobs[0], 0, optim)
+            barrier()
+            v = np.array([lt.O.time_event_elapsed(a, b) for _, _, _, _, a, b in lt.tape_recs])
+            acc = v if acc is None else acc + v
+        lt.tape_all = False
+        if acc is not None and len(acc):
+            lt.tape_ms = [(g_, kd, k, fl, float(m)) for (g_, kd, k, fl, _, _), m in zip(lt.tape_recs, acc / NREP)]
+        while getattr(net, '_tapes', None):
+            net._evict_tape()
     ranks_seen = 1
     extras = {}
     if use_dp:
@@ -448,10 +528,13 @@ def main(argv=None):
                     'bound': 'mfma', 'kernel': '%s: %d launches per step of %s' % (dom, round(g['launches_per_step']), ' / '.join(g['kernels'])),
                     'achieved': g['tflops'], 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': g['frac'],
                     'launches_per_step': g['launches_per_step'], 'ms_per_step': g['ms_per_step'], 'gflop_per_step': g['gflop_per_step'],
-                    'avg_launch_ms': per_launch_ms, 'traffic': dt_,
+                    'avg_launch_ms': per_launch_ms, 'rocprof_avg_launch_us': _rocprof_avgs(g['kernels']), 'traffic': dt_,
                     'traffic_note': (tnote % (dfile, dalg)) + '; measured on the group\'s 3x3 launch (%s)' % dkern,
-                    'timing': 'summed algorithmic FLOPs / summed HIP-event time of the group\'s launches, events recorded on the stream each launch goes to, '
-                              '%d eager multi-stream steps after the timed region (events cannot bracket launches inside a replayed tape without perturbing it)' % NE,
+                    'timing': ('summed algorithmic FLOPs / summed HIP-event time of the group\'s launches; the events are on the launch tape, right before and after '
+                               'each launch on the stream it goes to, read after pipelined replayed steps (a second tape recorded after the timed region: the '
+                               'headline tape carries no per-launch events).  An interval includes the wait for free CU slots behind the other streams\' '
+                               'workgroups; rocprof_avg_launch_us = execution time alone, from profiles/r03_step_kernel_stats.csv') if lt.tape_ms else
+                              ('summed algorithmic FLOPs / summed HIP-event time of the group\'s launches in %d eager multi-stream steps' % NE),
                     'best': best, 'stack3x3': stack, 'groups': tab,
                 }
             else:

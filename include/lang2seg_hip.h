@@ -56,7 +56,7 @@ typedef struct {
   int flags;
   int out_h, out_w, out_stride; /* SCATTER */
   int tile;                     /* 0 = auto, 64, 128, 224 or 256 (rows of the workgroup tile) */
-  int split_k;                  /* K split over workgroups, partial tiles added in a fixed order by a second launch: 0 = auto, 1 = off, n = force (needs ws) */
+  int split_k;                  /* K split over workgroups, partial tiles added in a fixed order by a second launch: 0 / 1 = off, n = force (needs ws) */
   int xcd_mode;                 /* tile order over the 8 XCDs: -1 = auto, 0 = M-chunks, 1 = N-chunks (speed only) */
   int algo;                     /* kernel family: 0 = auto; L2S_ALGO_* forces one (benchmarks / tests; same arithmetic, speed only) */
   float* ws;                    /* optional float workspace for split-K partial sums: split x rows x Cout floats (any contents; one per stream) */

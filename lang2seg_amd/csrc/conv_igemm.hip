@@ -1859,20 +1859,16 @@ int launch_splitk_reduce(const l2s_conv_desc& d, int split, hipStream_t st) {
   return l2s_check_launch();
 }
 
-// the split the launch will use: d.split_k forced (> 1) or chosen (0), limited by the K slices (>= 2 per range, no empty range) and by
-// the workspace; 1 = no split
+// the split the launch will use: only when the caller forces one (d.split_k > 1, with a workspace), limited by the K slices (>= 2 per
+// range, no empty range) and by the workspace; 1 = no split.  An automatic rule (few tiles x many slices) was built and measured: the
+// second launch costs more than the split saves on every shape tried - 80 tiles x 32 slices 10.9 -> 13.1 us, 80 x 72 (3x3) 14.8 -> 16.7,
+// 120 x 16 7.4 -> 11.0 - and inside the step it made 600x800 images 7 % slower (91 extra launches on layer3's chain) before the profile
+// showed it.  split_k = 0 therefore means "no split".
 static int splitk_factor(const l2s_conv_desc& d, int KT, long tiles64, bool auto_ok) {
-  if (!d.ws || d.split_k == 1 || (d.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) || (d.Cout % 4)) return 1;
+  (void)tiles64; (void)auto_ok;
+  if (!d.ws || d.split_k <= 1 || (d.flags & (L2S_CONV_SCATTER | L2S_CONV_DECONV2X2)) || (d.Cout % 4)) return 1;
   const long out = (long)d.n_img * d.OH * d.OW * d.Cout;
-  int s = d.split_k > 1 ? d.split_k : 0;
-  if (!s) {
-    // few tiles and a long K loop (layer4 on the 19x32 map: 80 tiles x 32 / 72 slices): each workgroup streams (64 + 64) x K x 2 bytes
-    // through one CU's L2 path (~75 GB/s) while most of the chip idles - cut K so that ~320 workgroups share it
-    if (!auto_ok || tiles64 > 128 || KT < 16) return 1;
-    s = (int)((320 + tiles64 - 1) / tiles64);
-    if (s > KT / 8) s = KT / 8;
-    if (s > 8) s = 8;
-  }
+  int s = d.split_k;
   if (s > KT / 2) s = KT / 2;
   while (s > 1 && (long)s * out > (long)d.ws_floats) --s;
   while (s > 1 && (s - 1) * cdiv(KT, s) >= KT) --s;                 // no empty range

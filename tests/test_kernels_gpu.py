@@ -179,16 +179,17 @@ def test_roialign_fused_into_layer4_block0(cfg):
 
 
 @pytest.mark.parametrize('cfg', [
-    dict(H=19, W=32, Cin=512, Cout=512, k=3, p=1, want=4),            # layer4 on the 19x32 map, conv2: 80 tiles x 72 slices -> 4 slabs
-    dict(H=19, W=32, Cin=2048, Cout=512, k=1, p=0, want=4),           # conv1 of blocks 1, 2 (and the data gradient of conv3)
-    dict(H=19, W=32, Cin=512, Cout=2048, k=1, p=0, want=1),           # conv3: 320 tiles, not split
-    dict(H=38, W=63, Cin=256, Cout=256, k=3, p=1, want=1),            # layer3 conv2: 152 tiles, not split
-    dict(H=6, W=5, Cin=1024, Cout=128, k=3, p=1, want=8),             # one pixel tile, 144 slices: the cap of 8 slabs; ragged rows
+    dict(H=19, W=32, Cin=512, Cout=512, k=3, p=1, split=4),           # 80 tiles x 72 slices in 4 slabs
+    dict(H=19, W=32, Cin=2048, Cout=512, k=1, p=0, split=3),          # ragged slice ranges (32 slices in 3 slabs)
+    dict(H=38, W=63, Cin=256, Cout=256, k=3, p=1, split=2),
+    dict(H=6, W=5, Cin=1024, Cout=128, k=3, p=1, split=8),            # one pixel tile, 144 slices; ragged rows
 ])
-def test_conv_splitk_auto(cfg):
-    """the few-tile / long-K launches (bf16) are cut along K over several workgroups when the caller lends a workspace: forward form
-    (bias + residual + ReLU) and data-gradient form (add + ReLU mask) against fp64 convolution of the same rounded operands, equal to
-    the unsplit launch within bf16 rounding, bit-identical from run to run, independent of what the workspace held"""
+def test_conv_splitk_slabs(cfg):
+    """l2s_conv_desc.split_k (bf16, 64x64 wave-specialised tile): K cut over several workgroups, partial tiles in workspace slabs, added in
+    slab order by a second launch that applies the epilogue.  Forward form (bias + residual + ReLU) and data-gradient form (add + ReLU mask)
+    against fp64 convolution of the same rounded operands, equal to the unsplit launch within bf16 rounding, bit-identical from run to run,
+    independent of what the workspace held; a workspace too small for the requested split lowers it.  (Never chosen automatically: the
+    second launch costs more than the split saves on every shape measured)"""
     O = ops()
     g = torch.Generator().manual_seed(11)
     H, W, Cin, Cout, k, p = [cfg[x] for x in ['H', 'W', 'Cin', 'Cout', 'k', 'p']]
@@ -200,31 +201,28 @@ def test_conv_splitk_auto(cfg):
     xd, wd, rd = to_dev(nhwc(x), 1), to_dev(ohwi(w), 1), to_dev(nhwc(res), 1)
     xr, wr, rr = [t.double().cpu().permute(0, 3, 1, 2) for t in (xd, wd, rd)]
     conv = F.conv2d(xr, wr, None, padding=p)
-    ws = torch.full((2 << 20,), float('nan'), dtype=torch.float32, device=DEV)
+    ws = torch.full((cfg['split'] * M * Cout + 64,), float('nan'), dtype=torch.float32, device=DEV)
     for form in ('fwd', 'dgrad'):
         kw = dict(bias=b.to(DEV), add=rd, relu=True) if form == 'fwd' else dict(add=rd, ref=rd)
         ref = F.relu(conv + b.double().view(1, -1, 1, 1) + rr) if form == 'fwd' else (conv + rr) * (rr > 0)
         ya, yb, y1 = [O.empty((M, Cout), 1) for _ in range(3)]
-        O.conv_igemm(xd, wd, ya, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=ws, **kw)
-        plan = O.LAST_PLAN
+        O.conv_igemm(xd, wd, ya, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=ws, split_k=cfg['split'], tile=64, **kw)
+        assert 'splitk' in O.LAST_PLAN, O.LAST_PLAN
         ws.fill_(-7e29)
-        O.conv_igemm(xd, wd, yb, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=ws, **kw)
-        O.conv_igemm(xd, wd, y1, 1, H, W, Cin, H, W, Cout, k, k, 1, p, **kw)
+        O.conv_igemm(xd, wd, yb, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=ws, split_k=cfg['split'], tile=64, **kw)
+        O.conv_igemm(xd, wd, y1, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=ws, **kw)
+        assert 'splitk' not in O.LAST_PLAN                         # a workspace alone never splits
         torch.cuda.synchronize()
-        assert ('splitk' in plan) == (cfg['want'] > 1), (plan, cfg)
-        assert 'splitk' not in O.LAST_PLAN
         assert torch.equal(ya, yb)
         assert rel_err(ya.float().view(1, H, W, Cout), nhwc(ref.float())) < TOL[1], form
         assert rel_err(ya.float(), y1.float()) < 1e-2
-    # a workspace too small for the chosen split lowers it; too small for two slabs: no split
     small = torch.empty(M * Cout * 2, dtype=torch.float32, device=DEV)
-    O.conv_igemm(xd, wd, ya, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=small, bias=b.to(DEV), add=rd, relu=True)
+    O.conv_igemm(xd, wd, ya, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=small, split_k=cfg['split'], tile=64, bias=b.to(DEV), add=rd, relu=True)
     torch.cuda.synchronize()
     assert rel_err(ya.float().view(1, H, W, Cout), nhwc(F.relu(conv + b.double().view(1, -1, 1, 1) + rr).float())) < TOL[1]
     tiny = torch.empty(M * Cout, dtype=torch.float32, device=DEV)
-    O.conv_igemm(xd, wd, ya, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=tiny, bias=b.to(DEV), add=rd, relu=True)
+    O.conv_igemm(xd, wd, ya, 1, H, W, Cin, H, W, Cout, k, k, 1, p, ws=tiny, split_k=cfg['split'], tile=64, bias=b.to(DEV), add=rd, relu=True)
     assert 'splitk' not in O.LAST_PLAN
-
 
 
 @pytest.mark.parametrize('algo', [5, 6])
