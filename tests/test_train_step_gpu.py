@@ -174,8 +174,13 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
     torch.cuda.synchronize()
     sd1 = net.state_dict()
     for nme in names:
-        # lr 1e-4 x a bf16-level gradient error stays far below 1e-5 of the weight scale
-        check_digest(g, 'w1.' + nme, sd1[nme].numpy(), rtol=1e-5, atol=1e-7)
+        # f32: 1e-5 of the weight scale.  bf16: the update is lr x gradient, and the gradient of a tensor may deviate from the f32 step's by
+        # what _check_grads allows (cosine >= BF16_COS, norm within BF16_NORM): that deviation times the learning rate is allowed on top - it
+        # matters for the tensors with large gradients (the dynamic-filter FC bias of the baseline network: the sum over its 1024 entries moved
+        # past 1e-5 of the weight scale when the round-3 tiles changed the rounding pattern upstream)
+        dev_ = 0.0 if f32 else 1e-4 * (BF16_NORM + (2 * (1 - BF16_COS)) ** 0.5)
+        check_digest(g, 'w1.' + nme, sd1[nme].numpy(), rtol=1e-5, atol=1e-7,
+                     extra_sample=dev_ * float(np.abs(g['g.' + nme + '.sample']).max()), extra_sum=dev_ * float(g['g.' + nme + '.abssum']))
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

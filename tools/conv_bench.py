@@ -48,7 +48,7 @@ def timeit(fn, iters=20):
 def main():
     dt = 1
     tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    xm = int(os.environ.get('L2S_XCD', '-1'))
+    xm = int(sys.argv[2]) if len(sys.argv) > 2 else -1          # xcd_mode: -1 = auto, 0 = M-chunks, 1 = N-chunks
     print('%-14s %8s %8s %8s | %8s %8s %8s (us | TFLOP/s)' % ('shape', 'fwd', 'dgrad', 'wgrad', 'fwd', 'dgrad', 'wgrad'))
     for name, n, H, W, Cin, Cout, k, s, p in SHAPES:
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of the convolution kernel families (l2s_conv_desc.algo) on the large-M shapes of the step, interleaved rounds in one process.
-GPU only.  usage: dma_bench.py [rounds]"""
+GPU only.  usage: dma_bench.py [rounds] [--shapes large|small] [--algos 0,1]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -38,10 +38,16 @@ SMALL = [
 
 def main():
     global SHAPES
-    if os.environ.get('SHAPES', 'large') == 'small':
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('rounds', nargs='?', type=int, default=3)
+    ap.add_argument('--shapes', default='large', choices=['large', 'small'])
+    ap.add_argument('--algos', default='1,2', help='l2s_conv_desc.algo values to compare (0 = the plan\'s own choice)')
+    args = ap.parse_args()
+    if args.shapes == 'small':
         SHAPES = SMALL
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    algos = [int(a) for a in os.environ.get('ALGOS', '1,2').split(',')]
+    rounds = args.rounds
+    algos = [int(a) for a in args.algos.split(',')]
     print('%-14s %s   (us per launch: fwd-form with bias+residual+ReLU / dgrad-form with ReLU mask; median of %d rounds)' % ('shape', ' '.join('algo%d' % a for a in algos), rounds))
     for name, n, H, W, Cin, Cout, k, p in SHAPES:
         M = n * H * W
