@@ -10,6 +10,7 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--lib', default='')
+    ap.add_argument('--min-wg', type=int, default=0, help='WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
     args = ap.parse_args()
     if args.lib:
         from lang2seg_amd import _lib
@@ -25,6 +26,8 @@ def main():
             if not hasattr(self, '_ws'): self._ws = torch.empty(16 << 20, dtype=torch.float32, device='cuda')
             return self._ws
     net = Net()
+    if args.min_wg:
+        WgradQueue.MIN_WG = args.min_wg
     bf = lambda *s: (torch.randn(*s, device='cuda') * 0.1).bfloat16()
     launches = []
 
