@@ -93,7 +93,9 @@ class ConvOp(object):
         QUEUED here: Network.flush_wgrads launches the queued problems of a whole backward stage as one grouped launch on the
         weight-gradient stream (csrc/conv_wgrad.hip: no split-K, no atomics, two uses of one tensor = one problem with two pixel
         segments).  The bias gradient (a column sum) is launched right away on a weight-gradient stream."""
-        if 'wgrad' in self.net.knockout:                  # experiment only (bench.py --knockout); train_net refuses it
+        ko = self.net.knockout                            # experiment only (bench.py --knockout); train_net refuses it
+        if 'wgrad' in ko or ('wgrad4' in ko and str(self.wkey).startswith('resnet.layer4.')) or \
+                ('wgrad3' in ko and str(self.wkey).startswith(('resnet.layer3.', 'resnet.layer2.'))):
             return
         OH, OW = self.out_hw(IH, IW)
         self.net.wgq.add(self.w_grad, g, x, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.stride, self.pad)
@@ -273,7 +275,7 @@ class Network(object):
         self.wgq = WgradQueue(self) # weight gradients of the current backward stage, launched together by flush_wgrads()
         self.cap_projected = True   # captioner recurrence in the projected-attention form (3 launches per token)
         self.fuse_roialign = bool(cfg.TRAIN.get('FUSE_ROIALIGN', False))   # RoIAlign + layer4[0].conv1 + layer4[0].downsample as one launch (bf16)
-        self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'cap'); set by bench.py --knockout
+        self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'wgrad3', 'wgrad4', 'cap'); set by bench.py --knockout
 
     # ------------------------------------------------------------------ construction
     def create_architecture(self, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
