@@ -167,6 +167,20 @@ def _rocprof_avgs(names):
     return out or None
 
 
+def _rocprof_group(counts, gflop):
+    """the group's execution time per step as rocprofv3 saw it: launches of each kernel template in the group (counted on the measurement
+    tape) x that template's average in-step duration in the committed profile; and the fraction of peak that gives"""
+    if not counts:
+        return None
+    avg = _rocprof_avgs(list(counts)) or {}
+    if any(k not in avg for k in counts):
+        return None
+    ms = sum(n * avg[k] for k, n in counts.items()) * 1e-3
+    ach = gflop / ms                                   # GFLOP per ms = TFLOP/s
+    return {'launches': counts, 'ms_per_step': ms, 'achieved': ach, 'frac': ach / (PEAK_BF16 / 1e12), 'unit': 'TFLOP/s',
+            'note': 'execution time only (profiles/r03_step_kernel_stats.csv); the HIP-event figure above also contains the wait for free CU slots'}
+
+
 class LaunchTimer(object):
     """HIP events around every convolution launch of eager steps, recorded on the stream the launch goes to (the weight-gradient
     launches run on their own streams; torch.cuda.Event.record() uses the current stream, which ConvOp switches before launching)."""
@@ -180,6 +194,7 @@ class LaunchTimer(object):
         self.tape_all = False         # measurement tape: timing events around EVERY convolution / grouped weight-gradient launch
         self.tape_recs = []           # (group, kind, k, flop, id0, id1) of that tape
         self.tape_ms = None           # [(group, kind, k, flop, ms)]: mean over the replays read back
+        self.tape_plan = []           # kernel (l2s_conv_plan_name) of every convolution record of that tape; '' for the grouped weight gradients
         for c in net.convs:
             self._wrap(c)
         net.wgq.on_launch = self.wgrad_hook
@@ -208,6 +223,7 @@ class LaunchTimer(object):
                     a = self.O.tape_time_event(); r = _orig(x, n, IH, IW, *rest, **kw); b = self.O.tape_time_event()
                     if a >= 0 and b >= 0:
                         self.tape_recs.append((self._group(conv, n, IH, IW), _kind, conv.k, flop, a, b))
+                        self.tape_plan.append(self.O.LAST_PLAN or '?')
                         self.plans.setdefault('%s %s' % (self._group(conv, n, IH, IW), _kind), set()).add(self.O.LAST_PLAN or '?')
                     return r
                 if not self.on:
@@ -242,6 +258,7 @@ class LaunchTimer(object):
                     b = lt.O.tape_time_event()
                     if s.a >= 0 and b >= 0:
                         lt.tape_recs.append(('%s [%s]' % (tag, names[variant]), 'wgrad', 3 if variant in (2, 3) else k, flop, s.a, b))
+                        lt.tape_plan.append('')
             return _T()
         if not self.on:
             return None
@@ -267,6 +284,12 @@ class LaunchTimer(object):
             g[0] += flop; g[1] += ms; g[2] += 1
             if k == 3:
                 s3[0] += flop; s3[1] += ms; s3[2] += 1
+        counts = {}
+        if self.tape_ms:
+            for (g_, kd, _, _, _, _), pl in zip(self.tape_recs, self.tape_plan):
+                if pl:
+                    c = counts.setdefault('%s %s' % (g_, kd), {}); c[pl] = c.get(pl, 0) + 1
+        self.group_kernel_counts = counts
         tab = {name: {'launches_per_step': v[2] / steps, 'ms_per_step': v[1] / steps, 'gflop_per_step': v[0] / steps / 1e9, 'tflops': v[0] / (v[1] * 1e-3) / 1e12,
                       'frac': v[0] / (v[1] * 1e-3) / PEAK_BF16, 'kernels': sorted(self.plans.get(name, []))} for name, v in groups.items() if v[1] > 0}
         dom = max(tab, key=lambda n: tab[n]['ms_per_step']) if tab else None
@@ -529,6 +552,7 @@ def main(argv=None):
                     'achieved': g['tflops'], 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': g['frac'],
                     'launches_per_step': g['launches_per_step'], 'ms_per_step': g['ms_per_step'], 'gflop_per_step': g['gflop_per_step'],
                     'avg_launch_ms': per_launch_ms, 'rocprof_avg_launch_us': _rocprof_avgs(g['kernels']), 'traffic': dt_,
+                    'rocprof': _rocprof_group(getattr(lt, 'group_kernel_counts', {}).get(dom), g['gflop_per_step']),
                     'traffic_note': (tnote % (dfile, dalg)) + '; measured on the group\'s 3x3 launch (%s)' % dkern,
                     'timing': ('summed algorithmic FLOPs / summed HIP-event time of the group\'s launches; the events are on the launch tape, right before and after '
                                'each launch on the stream it goes to, read after pipelined replayed steps (a second tape recorded after the timed region: the '
