@@ -18,8 +18,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=12, help='measured repetitions (eight pipelined steps each)')
     ap.add_argument('--knockout', default='')
+    ap.add_argument('--lib', default='', help='another build of the C-ABI library (tools/ab_build.sh / tools/ab_variant2.sh)')
     ap.add_argument('--sgd-early', type=int, default=-1)
     args = ap.parse_args()
+    if args.lib:
+        from lang2seg_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from lang2seg_amd.model.config import cfg
     from lang2seg_amd.nets.resnet_v1 import resnetv1
     from lang2seg_amd.optim import SGD
