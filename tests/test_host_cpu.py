@@ -64,6 +64,53 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.l2s_version() >= 100
 
 
+def test_conv_plan_table():
+    """l2s_conv_plan_name (the host-side kernel choice of l2s_conv_igemm; no launch, so it runs without a GPU): the plan of every convolution
+    shape of the BASELINE step, and of the other image sizes a training run meets - the rules were tuned on the 38x63 map, and a rule that
+    quietly caught a neighbouring shape (an automatic split-K on 38x50 maps) once cost 7 % on 600x800 images."""
+    import ctypes as C
+    from lang2seg_amd import _lib
+    L = _lib.load()
+
+    def plan(n, H, W, Cin, Cout, k=1, form='fwd', ws=False, stride=1):
+        d = _lib.ConvDesc()
+        d.x = d.w = d.y = 1 << 20
+        OH, OW = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+        d.n_img, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = n, H, W, Cin, OH, OW, Cout
+        d.KH = d.KW = k; d.stride = stride; d.pad = k // 2; d.ldx = Cin; d.ldy = d.ldadd = d.ldref = Cout; d.xcd_mode = -1
+        if form == 'dgrad':
+            d.ref = 1 << 20
+        if ws:
+            d.ws = 1 << 20; d.ws_floats = 4 << 20
+        return L.l2s_conv_plan_name(C.byref(d), _lib.BF16).decode()
+
+    # the 600x1000 step: backbone chain on the 38x63 map, layer2 on 75x125, layer4 on the RoIs and on the map, RPN
+    assert plan(1, 38, 63, 1024, 256) == 'igemm_ws64_kernel'                       # layer3 conv1: 152 tiles x 16 slices
+    assert plan(1, 38, 63, 256, 256, 3) == 'igemm_p3_kernel<32,256>'               # layer3 conv2 and its data gradient
+    assert plan(1, 38, 63, 256, 256, 3, 'dgrad') == 'igemm_p3_kernel<32,256>'
+    assert plan(1, 38, 63, 256, 1024) == 'igemm_ring_kernel<64,64>'                # layer3 conv3: 608 tiles x 4 slices -> three per CU
+    assert plan(1, 75, 125, 128, 128, 3) == 'igemm_p3_kernel<64,384>'              # layer2 conv2 (W + 1 > 64: the 384-row patch)
+    assert plan(1, 75, 125, 128, 512) == 'igemm_ring_kernel<128,64>'               # layer2 conv3: a 128x128 grid below one round
+    assert plan(256, 7, 7, 512, 512, 3) == 'igemm_dma_kernel<256,128>'             # layer4 @ RoIs conv2
+    assert plan(256, 7, 7, 2048, 512) == 'igemm_dma_kernel<256,128>'               # layer4 @ RoIs conv1
+    assert plan(256, 7, 7, 512, 2048) == 'igemm_ring_kernel<128,128>'              # layer4 @ RoIs conv3
+    assert plan(1, 38, 63, 512, 512, 3) == 'igemm_p3_kernel<64,256>'               # layer4 on the map conv2
+    assert plan(1, 38, 63, 512, 2048) == 'igemm_ring_kernel<128,64>'               # layer4 on the map conv3
+    assert plan(1, 38, 63, 1024, 512, 3) == 'igemm_p3_kernel<64,256>'              # RPN 3x3
+    # other image sizes (600x800, 800x600, 480x640) and a workspace on offer: never a split, the patch tile wherever a row fits it
+    for (H, W) in ((38, 50), (50, 38), (30, 40), (19, 32)):
+        for (Cin, Cout, k) in ((1024, 256, 1), (256, 1024, 1), (256, 256, 3), (2048, 512, 1), (512, 2048, 1), (512, 512, 3), (1024, 512, 3)):
+            for form in ('fwd', 'dgrad'):
+                p = plan(1, H, W, Cin, Cout, k, form, ws=True)
+                assert 'splitk' not in p and p != 'invalid', (H, W, Cin, Cout, k, form, p)
+                if k == 3:
+                    assert p.startswith('igemm_p3_kernel'), (H, W, Cin, Cout, p)
+    # what the patch tile does not take: several images, rows wider than its patch, strided taps
+    assert not plan(2, 19, 23, 64, 64, 3).startswith('igemm_p3')
+    assert not plan(1, 3, 200, 64, 64, 3).startswith('igemm_p3')
+    assert not plan(1, 38, 63, 256, 256, 3, stride=2).startswith('igemm_p3')
+
+
 def test_param_layout_and_state_dict_keys():
     from lang2seg_amd._lib import F32
     from lang2seg_amd.nets.params import ParamStore, to_internal, from_internal
