@@ -45,6 +45,9 @@ def parse_args(argv=None):
     ap.add_argument('--fuse-roialign', type=int, default=0, help='A/B only: 1 = RoIAlign, layer4[0].conv1 and layer4[0].downsample as one launch (cfg.TRAIN.FUSE_ROIALIGN)')
     ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
     ap.add_argument('--sgd-early', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.early on / off (update each finished prefix of the flat buffer during backward; one rank only)')
+    ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
+    ap.add_argument('--wgrad-cap', type=int, default=0, help='A/B only: at most this many workgroups per grouped weight-gradient launch')
+    ap.add_argument('--sgd-blocks', type=int, default=0, help='A/B only: persistent workgroups of the update kernel')
     ap.add_argument('--lib', default='', help='A/B only: load this build of the C-ABI library instead of the in-tree one (tools/ab_build.sh <rev>); the line is marked')
     ap.add_argument('--cpu-baseline-steps', default='3,10', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3: 3 + 10, ~2-3 min on the GPU box)')
     ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
@@ -378,9 +381,17 @@ def main(argv=None):
     if use_dp and args.dp_skip_allreduce != 3:
         from lang2seg_amd.parallel import GradReducer
         net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce, wire=args.dp_wire, algo=args.dp_algo, timing=True)
-    if args.sgd_early >= 0:
-        SGD.early = bool(args.sgd_early)
+    if args.defer >= 0:
+        SGD.defer = bool(args.defer)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
+    if args.sgd_early >= 0:
+        optim.early = bool(args.sgd_early)
+    if args.wgrad_cap > 0:
+        from lang2seg_amd import _lib as _L2
+        _L2.load().l2s_wgrad_grid_cap(args.wgrad_cap)
+    if args.sgd_blocks > 0:
+        from lang2seg_amd import ops as _O2
+        _O2.sgd_blocks(args.sgd_blocks)
     loader = SyntheticLoader(num_images=4, sents_per_image=1, H=args.height, W=args.width, T=T, vocab_size=V, rank=rank)
     blobs = [loader.getBatch('train') for _ in range(4)]
     for b in blobs:

@@ -109,6 +109,8 @@ typedef struct {
 } l2s_wgrad_prob;
 int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile);
 long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW);
+/* tools: cap the workgroups of a grouped launch (each then walks several tiles); 0 = one workgroup per tile, < 0 = query */
+int l2s_wgrad_grid_cap(int cap);
 int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
                            float* ws, size_t ws_bytes, hipStream_t stream);
 int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
@@ -406,6 +408,12 @@ int l2s_rle_to_mask(const uint32_t* cnts, const int* offs, int n, int total_coun
 /* ---------------------------------------------------------------- launch tape / streams ----- */
 /* `to` waits (device side) for everything enqueued so far on `from`; fork or join of the step's branches */
 int l2s_stream_fork(hipStream_t from, hipStream_t to);
+/* the two halves of a fork under a process-wide name (slot in [0,16)): l2s_event_record marks "everything enqueued so far on s",
+ * l2s_event_wait makes s wait for the most recent mark of that slot (no-op if never marked).  Both are tape ops.  Used where the
+ * mark and the wait belong to different steps: the first half of the optimiser update (train_val_cycle.py:194-220) is awaited
+ * before the next step's first trainable layer while the deferred weight gradients run on behind it. */
+int l2s_event_record(int slot, hipStream_t s);
+int l2s_event_wait(int slot, hipStream_t s);
 int l2s_memset_async(void* p, int value, size_t bytes, hipStream_t s);
 int l2s_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t s);
 /* record every launch / fork / memset issued through this ABI on the registered streams (they still execute), then replay
@@ -430,10 +438,14 @@ int l2s_tape_destroy(void* tape);
 /* torch.optim.SGD with momentum as configured at train_val_cycle.py:194-220, fused over a flat parameter buffer.
  * seg table (device): per segment {offset, count, rows, wd_flag}; rowscale (optional, per segment offset into a float array,
  * -1 = none) multiplies the gradient per output row (folded frozen-BN scale). */
-typedef struct { long offset; long count; int row_len; int weight_decay; long rowscale_off; float lr_mult; int pad; } l2s_sgd_seg;
-int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+typedef struct { long offset; long count; int row_len; int weight_decay; long rowscale_off; float lr_mult;
+                 int chunk0; /* running count of ceil(count / l2s_sgd_chunk()) over the table's earlier segments (any common origin) */ } l2s_sgd_seg;
+int l2s_sgd_chunk(void);          /* elements of one work chunk of the update kernel */
+int l2s_sgd_blocks(int blocks);   /* tools: persistent workgroups of the update (<= 0: query); returns the value in force */
+int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
                      float lr, float momentum, float wd, float grad_scale, void* shadow /*optional: dtype copy of rowscale*param at the same offsets*/,
-                     int shadow_dtype, hipStream_t s);
+                     int shadow_dtype, int clear_grad /*1: the gradient is zeroed as it is read (optimizer.zero_grad() of train_val_cycle.py:383 folded in)*/,
+                     hipStream_t s);
 
 #ifdef __cplusplus
 }

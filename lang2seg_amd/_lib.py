@@ -53,7 +53,7 @@ class LstmBwdDir(C.Structure):
 
 class SgdSeg(C.Structure):
     _fields_ = [('offset', i64), ('count', i64), ('row_len', i32), ('weight_decay', i32), ('rowscale_off', i64),
-                ('lr_mult', f32), ('pad', i32)]
+                ('lr_mult', f32), ('chunk0', i32)]
 
 
 CONV_RELU, CONV_OUT_F32, CONV_DECONV2X2, CONV_SCATTER = 1, 4, 8, 16
@@ -153,10 +153,15 @@ SIGS = {
     'l2s_cap_attention_bwd_step2': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'l2s_cap_attention_bwd_batched': (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_logsoftmax_nll': (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
-    'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp]),
+    'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, i32, vp]),
+    'l2s_wgrad_grid_cap': (i32, [i32]),
+    'l2s_sgd_chunk': (i32, []),
+    'l2s_sgd_blocks': (i32, [i32]),
     'l2s_mul_f32': (i32, [vp, vp, vp, i64, vp]),
     'l2s_add_f32': (i32, [vp, vp, vp, i64, vp]),
     'l2s_stream_fork': (i32, [vp, vp]),
+    'l2s_event_record': (i32, [i32, vp]),
+    'l2s_event_wait': (i32, [i32, vp]),
     'l2s_memset_async': (i32, [vp, i32, sz, vp]),
     'l2s_memcpy_d2d_async': (i32, [vp, vp, sz, vp]),
     'l2s_tape_begin': (vp, [vp, i32]),

@@ -286,6 +286,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const wgp p, int cblocks, fl
   wgrad_tile<T, BM, BN, TX, D>(p, blockIdx.x * BM, ci0, tg, blockIdx.z, gridDim.z, out, slab == 0, smem);
 }
 
+int g_wgrad_grid_cap = 0;   // > 0: at most this many workgroups per grouped launch, each walking several tiles (l2s_wgrad_grid_cap)
+
 // ---- a whole backward stage per launch: problems in a device table, workgroup -> (problem, tile) through the tile prefix ----
 struct wg_prefix { int n; int tile0[L2S_WGRAD_MAX_GROUP + 1]; };
 
@@ -294,23 +296,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_grouped_kernel(const wgp
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2; XCD x takes the x-th
   // CONTIGUOUS eighth of the tile list, whose neighbours share the X tile (same ci tile and tap, consecutive co tiles / pixel ranges),
-  // instead of every XCD fetching every operand tile
-  int bid;
-  {
-    const int G = pre.tile0[pre.n], L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
-    bid = x * q + min(x, r) + slot;
+  // instead of every XCD fetching every operand tile.  The grid may be smaller than the tile list (l2s_wgrad_grid_cap): a workgroup
+  // then walks tiles L, L + gridDim.x, ... (gridDim.x a multiple of 8 keeps a workgroup on its XCD's eighth).
+  const int G = pre.tile0[pre.n];
+  for (int L = blockIdx.x; L < G; L += gridDim.x) {
+    int bid;
+    {
+      const int x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+      bid = x * q + min(x, r) + slot;
+    }
+    int lo = 0, hi = pre.n;                                // tile0[lo] <= bid < tile0[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre.tile0[mid] <= bid) lo = mid; else hi = mid; }
+    const wgp p = tab[lo];                                 // uniform: scalar loads
+    int t = bid - pre.tile0[lo];
+    const int co_tiles = (p.Cout + BM - 1) / BM, ci_tiles = (p.Cin + BN - 1) / BN;
+    const int split = p.split > 1 ? p.split : 1;
+    // split index fastest, then co: consecutive workgroups (dealt round-robin over the XCDs) share the X tile and the tap
+    const int sp = t % split; t /= split;
+    const int cot = t % co_tiles, rest = t / co_tiles, cit = rest % ci_tiles, tg = rest / ci_tiles;
+    float* out = split > 1 ? ws + p.ws_off + (long)sp * ((long)p.Cout * p.KH * p.KW * p.Cin) : p.dw;
+    wgrad_tile<T, BM, BN, TX, D, KSTEP, WGM, WGN>(p, cot * BM, cit * BN, tg, sp, split, out, split == 1, smem);
+    __syncthreads();                                       // the next tile's first fill may not overtake this tile's last fragment reads
   }
-  int lo = 0, hi = pre.n;                                // tile0[lo] <= bid < tile0[hi]
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre.tile0[mid] <= bid) lo = mid; else hi = mid; }
-  const wgp p = tab[lo];                                 // uniform: scalar loads
-  int t = bid - pre.tile0[lo];
-  const int co_tiles = (p.Cout + BM - 1) / BM, ci_tiles = (p.Cin + BN - 1) / BN;
-  const int split = p.split > 1 ? p.split : 1;
-  // split index fastest, then co: consecutive workgroups (dealt round-robin over the XCDs) share the X tile and the tap
-  const int sp = t % split; t /= split;
-  const int cot = t % co_tiles, rest = t / co_tiles, cit = rest % ci_tiles, tg = rest / ci_tiles;
-  float* out = split > 1 ? ws + p.ws_off + (long)sp * ((long)p.Cout * p.KH * p.KW * p.Cin) : p.dw;
-  wgrad_tile<T, BM, BN, TX, D, KSTEP, WGM, WGN>(p, cot * BM, cit * BN, tg, sp, split, out, split == 1, smem);
 }
 
 // problems of a grouped launch whose pixels were split: dW[e] += slab_0[e] + slab_1[e] + ... (fixed order); grid (blocks, problems)
@@ -400,7 +407,9 @@ int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_spl
   else if (want > lds) lds = want;
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>), dim3(pre.tile0[pre.n]), dim3(64 * WGM * WGN), lds, st, tab, pre, ws);
+  int grid = pre.tile0[pre.n];
+  if (g_wgrad_grid_cap > 0 && grid > g_wgrad_grid_cap) grid = g_wgrad_grid_cap;
+  L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), lds, st, tab, pre, ws);
   if (any_split) {
     const float* wsc = ws;
     L2S_LAUNCH(wgrad_reduce_grouped_kernel, dim3(64, pre.n), dim3(256), 0, st, tab, wsc);
@@ -423,6 +432,7 @@ bool prob_ok(const wgp& p, int dtype) {
 
 }  // namespace
 
+extern "C" int l2s_wgrad_grid_cap(int cap) { if (cap >= 0) g_wgrad_grid_cap = cap; return g_wgrad_grid_cap; }
 extern "C" int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   return variant_of(Cin, Cout, KH, KW, stride, pad, same_hw, M, tile);
 }

@@ -520,47 +520,73 @@ __global__ void keys_kernel(uint32_t* k, long n, const uint64_t* seed_dev, uint6
     k[i] = (uint32_t)(mix64(seed * 0x100000001B3ull + (uint64_t)i) >> 32);
 }
 
-__global__ void sgd_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ mom,
-                           const l2s_sgd_seg* __restrict__ segs, int nseg, const float* __restrict__ rowscale,
-                           float lr, float momentum, float wd, float gscale, void* shadow, int sdt) {
-  // blockIdx.y = segment; grid-stride over the segment's elements
-  const l2s_sgd_seg sg = segs[blockIdx.y];
-  const float lwd = sg.weight_decay ? wd : 0.f;
-  const float llr = lr * sg.lr_mult;
-  // vector body: 4 consecutive elements per thread when the segment start is 16-byte aligned and a row is a multiple of 4
-  const bool vec = ((sg.offset & 3) == 0) && (sg.rowscale_off < 0 || (sg.row_len & 3) == 0);
-  const long nvec = vec ? (sg.count >> 2) : 0;
-  for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
-    const long i = v << 2, o = sg.offset + i;
-    float4 g4 = *(const float4*)(grad + o), w4 = *(const float4*)(param + o), m4 = *(const float4*)(mom + o);
-    const float rs = sg.rowscale_off >= 0 ? rowscale[sg.rowscale_off + i / sg.row_len] : 1.f;
-    float gg[4] = {g4.x, g4.y, g4.z, g4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+// SGD with momentum over a table of segments (one per tensor), fused with the dtype shadow rewrite and (clear != 0) the gradient clear.
+// Persistent grid: the work is cut into chunks of SGD_CHUNK elements of one segment (l2s_sgd_seg.chunk0 = index of the segment's first
+// chunk, filled by the host); a workgroup walks chunks blockIdx.x, blockIdx.x + gridDim.x, ...  A thread owns four 16-byte vectors of
+// each operand and requests all twelve before the first use, so one resident workgroup per CU already keeps ~48 KB in flight (the old
+// form launched 64 workgroups per tensor, 10 000 short workgroups that held every wave slot of the chip while the next step's frozen
+// prefix waited).
+constexpr int SGD_CHUNK = 4096;
+__device__ __forceinline__ void sgd_elem(float g, float& w, float& m, float rs, float gscale, float lwd, float momentum, float llr) {
+  const float gg = g * gscale * rs + lwd * w;
+  m = momentum * m + gg;
+  w = w - llr * m;
+}
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ mom,
+                                                  const l2s_sgd_seg* __restrict__ segs, int nseg, const float* __restrict__ rowscale,
+                                                  float lr, float momentum, float wd, float gscale, void* shadow, int sdt, int clear) {
+  const int c0 = segs[0].chunk0;
+  const int total = segs[nseg - 1].chunk0 - c0 + (int)((segs[nseg - 1].count + SGD_CHUNK - 1) / SGD_CHUNK);
+  for (int c = blockIdx.x; c < total; c += gridDim.x) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {                                   // the segment that holds chunk c (uniform: scalar loads)
+      const int mid = (lo + hi + 1) >> 1;
+      if (segs[mid].chunk0 - c0 <= c) lo = mid; else hi = mid - 1;
+    }
+    const l2s_sgd_seg sg = segs[lo];
+    const long base = (long)(c - (sg.chunk0 - c0)) * SGD_CHUNK;
+    const int n = (int)((sg.count - base) < SGD_CHUNK ? (sg.count - base) : SGD_CHUNK);
+    const float lwd = sg.weight_decay ? wd : 0.f;
+    const float llr = lr * sg.lr_mult;
+    const bool vec = ((sg.offset & 3) == 0) && (sg.rowscale_off < 0 || (sg.row_len & 3) == 0);
+    const int nv = vec ? (n >> 2) : 0;
+    const long o0 = sg.offset + base;
+    float4 g4[4], w4[4], m4[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float g = gg[e] * gscale * rs + lwd * ww[e];
-      mm[e] = momentum * mm[e] + g;
-      ww[e] = ww[e] - llr * mm[e];
+    for (int j = 0; j < 4; ++j) {
+      const int v = threadIdx.x + j * 256;
+      if (v < nv) {
+        g4[j] = *(const float4*)(grad + o0 + 4 * v); w4[j] = *(const float4*)(param + o0 + 4 * v); m4[j] = *(const float4*)(mom + o0 + 4 * v);
+      }
     }
-    *(float4*)(mom + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    *(float4*)(param + o) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-    if (shadow) {
-      if (sdt) {
-        uint2 pk; pk.x = (uint32_t)f2bf(ww[0] * rs) | ((uint32_t)f2bf(ww[1] * rs) << 16); pk.y = (uint32_t)f2bf(ww[2] * rs) | ((uint32_t)f2bf(ww[3] * rs) << 16);
-        *(uint2*)((bf16_t*)shadow + o) = pk;
-      } else *(float4*)((float*)shadow + o) = make_float4(ww[0] * rs, ww[1] * rs, ww[2] * rs, ww[3] * rs);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int v = threadIdx.x + j * 256;
+      if (v >= nv) continue;
+      const long o = o0 + 4 * v;
+      const float rs = sg.rowscale_off >= 0 ? rowscale[sg.rowscale_off + (unsigned)(base + 4 * v) / (unsigned)sg.row_len] : 1.f;
+      float gg[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w}, ww[4] = {w4[j].x, w4[j].y, w4[j].z, w4[j].w}, mm[4] = {m4[j].x, m4[j].y, m4[j].z, m4[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sgd_elem(gg[e], ww[e], mm[e], rs, gscale, lwd, momentum, llr);
+      *(float4*)(mom + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      *(float4*)(param + o) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+      if (clear) *(float4*)(grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (shadow) {
+        if (sdt) {
+          uint2 pk; pk.x = (uint32_t)f2bf(ww[0] * rs) | ((uint32_t)f2bf(ww[1] * rs) << 16); pk.y = (uint32_t)f2bf(ww[2] * rs) | ((uint32_t)f2bf(ww[3] * rs) << 16);
+          *(uint2*)((bf16_t*)shadow + o) = pk;
+        } else *(float4*)((float*)shadow + o) = make_float4(ww[0] * rs, ww[1] * rs, ww[2] * rs, ww[3] * rs);
+      }
     }
-  }
-  for (long i = (nvec << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < sg.count; i += (long)gridDim.x * blockDim.x) {
-    const long o = sg.offset + i;
-    float g = grad[o] * gscale;
-    if (sg.rowscale_off >= 0) g *= rowscale[sg.rowscale_off + i / sg.row_len];
-    const float w = param[o];
-    g += lwd * w;
-    const float m = momentum * mom[o] + g;
-    mom[o] = m;
-    const float wn = w - llr * m;
-    param[o] = wn;
-    if (shadow) stx(shadow, o, sdt, sg.rowscale_off >= 0 ? wn * rowscale[sg.rowscale_off + i / sg.row_len] : wn);
+    for (int i = (nv << 2) + threadIdx.x; i < n; i += 256) {
+      const long o = o0 + i;
+      const float rs = sg.rowscale_off >= 0 ? rowscale[sg.rowscale_off + (unsigned)(base + i) / (unsigned)sg.row_len] : 1.f;
+      float w = param[o], m = mom[o];
+      sgd_elem(grad[o], w, m, rs, gscale, lwd, momentum, llr);
+      mom[o] = m; param[o] = w;
+      if (clear) grad[o] = 0.f;
+      if (shadow) stx(shadow, o, sdt, w * rs);
+    }
   }
 }
 
@@ -699,9 +725,13 @@ extern "C" int l2s_random_keys(uint32_t* keys, long n, const uint64_t* seed_dev,
   L2S_LAUNCH(keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, keys, n, seed_dev, salt);
   return l2s_check_launch();
 }
-extern "C" int l2s_sgd_momentum(float* param, const float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
-                                float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, hipStream_t s) {
+static int g_sgd_blocks = 512;   // persistent workgroups of the update (two per CU)
+extern "C" int l2s_sgd_blocks(int blocks) { if (blocks > 0) g_sgd_blocks = blocks; return g_sgd_blocks; }
+extern "C" int l2s_sgd_chunk(void) { return SGD_CHUNK; }
+extern "C" int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+                                float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int clear_grad, hipStream_t s) {
   if (nseg <= 0) return L2S_OK;
-  L2S_LAUNCH(sgd_kernel, dim3(64, nseg), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype);
+  L2S_LAUNCH(sgd_kernel, dim3(g_sgd_blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype,
+             clear_grad);
   return l2s_check_launch();
 }

@@ -14,7 +14,7 @@
 
 namespace l2s {
 
-struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };   // kind 0 launch, 1 record ev, 2 wait ev, 3 segment mark, 4 record timing ev
+struct Op { int kind; int sid; int ev; std::function<void(hipStream_t)> fn; };   // kind 0 launch, 1 record ev, 2 wait ev, 3 segment mark, 4 record timing ev, 5 record slot, 6 wait slot
 struct Tape { std::vector<Op> ops; int n_events = 0; std::vector<hipEvent_t> events; std::vector<size_t> marks; };
 
 static Tape* g_rec = nullptr;
@@ -24,6 +24,20 @@ static int g_nstreams = 0;
 static std::vector<hipEvent_t> g_pool;     // events for eager forks
 static size_t g_pool_next = 0;
 static std::vector<hipEvent_t> g_timing;  // timing events of l2s_tape_time_event (measurement only; live until the process ends)
+// Event slots: process-wide named points of a stream's order.  An ordinary fork is "record now, wait now"; a slot separates the two, so that
+// a point recorded at the END of one step (by one tape) can be waited for in the MIDDLE of the next (by another tape): the first part of
+// the optimiser update is awaited before layer2 while the deferred weight gradients keep running on the same stream behind it.
+static const int kSlots = 16;
+static hipEvent_t g_slot[kSlots];
+static bool g_slot_made[kSlots];
+static hipEvent_t slot_event(int slot) {
+  if (slot < 0 || slot >= kSlots) return nullptr;
+  if (!g_slot_made[slot]) {
+    if (hipEventCreateWithFlags(&g_slot[slot], hipEventDisableTiming) != hipSuccess) return nullptr;
+    g_slot_made[slot] = true;
+  }
+  return g_slot[slot];
+}
 
 static int stream_id(hipStream_t s) {
   for (int i = 0; i < g_nstreams; ++i) if (g_streams[i] == s) return i;
@@ -104,6 +118,8 @@ extern "C" int l2s_tape_run_segment(void* tape, const hipStream_t* streams, int 
     else if (o.kind == 1) { if (hipEventRecord(t->events[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
     else if (o.kind == 2) { if (hipStreamWaitEvent(s, t->events[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
     else if (o.kind == 4) { if (hipEventRecord(g_timing[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 5) { if (hipEventRecord(g_slot[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 6) { if (hipStreamWaitEvent(s, g_slot[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
   }
   return l2s_check_launch();
 }
@@ -118,6 +134,8 @@ extern "C" int l2s_tape_run(void* tape, const hipStream_t* streams, int n) {
     else if (o.kind == 1) { if (hipEventRecord(t->events[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
     else if (o.kind == 2) { if (hipStreamWaitEvent(s, t->events[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
     else if (o.kind == 4) { if (hipEventRecord(g_timing[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 5) { if (hipEventRecord(g_slot[o.ev], s) != hipSuccess) return L2S_ELAUNCH; }
+    else if (o.kind == 6) { if (hipStreamWaitEvent(s, g_slot[o.ev], 0) != hipSuccess) return L2S_ELAUNCH; }
   }
   return l2s_check_launch();
 }
@@ -144,6 +162,22 @@ extern "C" int l2s_stream_fork(hipStream_t from, hipStream_t to) {
     g_rec->ops.push_back(Op{1, a, ev, nullptr});
     g_rec->ops.push_back(Op{2, b, ev, nullptr});
   }
+  return L2S_OK;
+}
+// slot: record "everything enqueued so far on s" under a process-wide name / make s wait for the most recent record of that name
+// (a slot that was never recorded is complete: the wait is a no-op, as for any HIP event)
+extern "C" int l2s_event_record(int slot, hipStream_t s) {
+  hipEvent_t e = slot_event(slot);
+  if (!e) return L2S_EINVAL;
+  if (hipEventRecord(e, s) != hipSuccess) return L2S_ELAUNCH;
+  if (g_rec && !g_paused) g_rec->ops.push_back(Op{5, stream_id(s), slot, nullptr});
+  return L2S_OK;
+}
+extern "C" int l2s_event_wait(int slot, hipStream_t s) {
+  hipEvent_t e = slot_event(slot);
+  if (!e) return L2S_EINVAL;
+  if (hipStreamWaitEvent(s, e, 0) != hipSuccess) return L2S_ELAUNCH;
+  if (g_rec && !g_paused) g_rec->ops.push_back(Op{6, stream_id(s), slot, nullptr});
   return L2S_OK;
 }
 // Clears are ordinary kernel launches (recorded on the tape like every other launch; word-aligned ranges only).

@@ -109,7 +109,18 @@ class WgradQueue(object):
 
     def __init__(self, net):
         self.net, self.items, self.tables = net, [], {}
+        self.deferred = []               # problems of the heads stage held back until the end of the step (Network.defer_heads)
         self.on_launch = None            # optional hook(tag, variant, flop, k) -> context manager (bench.py times the launches with it)
+
+    def defer(self):
+        """hold the queued problems back: they are launched by flush_deferred(), behind the first part of the optimiser update"""
+        self.deferred.extend(self.items)
+        self.items = []
+
+    def flush_deferred(self, tag):
+        assert not self.items, 'weight gradients queued behind the deferred ones'
+        self.items, self.deferred = self.deferred, []
+        self.flush(tag)
 
     def add(self, dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy=None, ldx=None):
         self.items.append((dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, Cout if lddy is None else lddy, Cin if ldx is None else ldx))
@@ -608,12 +619,28 @@ class Network(object):
             O.weight_transpose_batched(self._tr_table, self._tr_n, self._tr_tiles, self.dt)
 
     update_on_wg = False
+    defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
+    update_clears_grad = False   # optim.SGD(keep_grad=False): the update zeroes the gradients it consumes; forward_backward does not clear
+    SLOT_UPDATE_REST = 0     # event slot (csrc/tape.hip): the first part of the update (everything outside ParamStore.defer_range) is done
 
-    def join_update(self):
+    def join_update(self, full=True):
         """the current stream waits for the optimiser update of the previous step when that ran on the weight-gradient stream
         (optim.SGD.side): called before the first launch that reads a trainable weight or writes a gradient.  Unconditional once the
-        mode is on (a step recorded on a launch tape must contain the edge)."""
+        mode is on (a step recorded on a launch tape must contain the edge).
+        full=False (inside the step, with deferred heads): wait only for the first part of the update - the encoder, the dynamic FCs,
+        the captioner's own matrices and the backbone - which the update marks under SLOT_UPDATE_REST; the deferred weight gradients
+        of the heads stage and their part of the update keep running on the weight-gradient stream until join_deferred()."""
         if self.use_streams and self.update_on_wg:
+            if self.defer_heads and not full:
+                O.event_wait(self.SLOT_UPDATE_REST, torch.cuda.current_stream())
+            else:
+                self.sfork(self.streams()['wg'], torch.cuda.current_stream())
+
+    def join_deferred(self):
+        """the current stream waits for the deferred tail of the previous step (heads-stage weight gradients, their update): called
+        before the first launch that reads a weight of ParamStore.defer_range, overwrites an activation those weight gradients read, or
+        writes a gradient of that range"""
+        if self.use_streams and self.update_on_wg and self.defer_heads:
             self.sfork(self.streams()['wg'], torch.cuda.current_stream())
 
     def join_transposes(self):

@@ -178,6 +178,10 @@ class ParamStore(object):
         def take(pred):
             sel = [k for k in tr if pred(k) and k not in order]
             order.extend(sel)
+        # (att_embed last: its weight gradient is a convolution weight gradient of the heads stage, so that the tensors of that stage -
+        # att_embed, layer4, RoI / mask heads, RPN - form ONE contiguous range, `defer_range`, see optim.SGD.defer)
+        take(lambda k: k.startswith('caption_model.') and '.att_embed.' not in k)
+        n_cap_rest = len(order)
         take(lambda k: k.startswith('caption_model.'))
         take(lambda k: k.startswith('vgg.classifier.3.'))
         take(lambda k: k.startswith('vgg.classifier.0.'))
@@ -243,6 +247,8 @@ class ParamStore(object):
         assert not missing, missing
         self.total = (off + 63) // 64 * 64
         self.trainable = sorted(self.offsets.keys(), key=lambda k: self.offsets[k])
+        # [lo, hi) of the flat buffer whose gradients come from the heads stage's grouped weight-gradient launches (+ their biases)
+        self.defer_range = (self.offsets[order[n_cap_rest]] if n_cap_rest < len(order) else 0, self.group_off['dyn_w'])
         dev = self.device
         self.param = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -334,11 +340,27 @@ class ParamStore(object):
             sg.rowscale_off = self.rowscale_off.get(k, -1)
             sg.lr_mult = 2.0 if (is_bias and double_bias) else 1.0
             segs.append(sg)
-        arr = (SgdSeg * len(segs))(*segs)
+        CH = int(O.sgd_chunk())
+
+        def table(seq):
+            run = 0
+            for g in seq:                                             # chunk0: the update kernel finds a chunk's segment by it
+                g.chunk0 = run
+                run += -(-int(g.count) // CH)
+            arr = (SgdSeg * len(seq))(*seq)
+            return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self.nseg = len(segs)
         self.seg_ends = [int(g.offset + g.count) for g in segs]      # host copy: the optimiser's partial updates split here
         self.seg_size = C.sizeof(SgdSeg)
-        self.segs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self.segs_dev = table(segs)
+        # the same segments with the deferred range moved to the end: [0, n_rest) is updated at the end of the step, [n_rest, nseg) behind
+        # the deferred weight gradients (optim.SGD.defer).  Copies: chunk0 differs between the two tables.
+        lo, hi = self.defer_range
+        cp = lambda g: SgdSeg.from_buffer_copy(bytes(g))
+        rest = [cp(g) for g in segs if not (lo <= g.offset < hi)]
+        late = [cp(g) for g in segs if lo <= g.offset < hi]
+        self.n_rest = len(rest)
+        self.segs_split_dev = table(rest + late)
         return self.nseg
 
     def refresh_shadow_full(self):

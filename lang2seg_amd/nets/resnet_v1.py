@@ -412,13 +412,13 @@ class resnetv1(Network):
         self._mark('stem')
         for li in (1, 2, 3):
             if li == cfg.RESNET.FIXED_BLOCKS + 1:
-                self.join_update()                             # first trainable layer: the previous step's update must have landed
+                self.join_update(full=False)                   # first trainable layer: the previous step's update (of the backbone) must have landed
                 self._mark('layer1 done, update joined')
             for b, blk in enumerate(self.layers[li]):
                 x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
                 saved[(li, b)] = sv
         if cfg.RESNET.FIXED_BLOCKS >= 3:
-            self.join_update()
+            self.join_update(full=False)
         return x, h, w
 
     def _backbone_bwd(self, dbase, saved, S, main, dp):
@@ -581,7 +581,9 @@ class resnetv1(Network):
         self._mark('step start')
         main = torch.cuda.current_stream()
         S = self.streams() if self.use_streams else None
-        if S is not None and self.update_on_wg:
+        if self.update_clears_grad:
+            pass                                            # optimizer.zero_grad() (TV:383) is folded into the update kernel
+        elif S is not None and self.update_on_wg:
             self.sfork(main, S['wg'])                       # (an update that ran on this queue after all, e.g. early partial updates)
             with torch.cuda.stream(S['wg']):                # behind the previous step's update, which read the gradients
                 O.memset_zero(P.grad)
@@ -596,7 +598,8 @@ class resnetv1(Network):
         if S is not None:
             self.sfork(main, S['lang'])
             if self.update_on_wg:
-                self.sfork(S['wg'], S['lang'])                  # the encoder reads updated weights
+                with torch.cuda.stream(S['lang']):
+                    self.join_update(full=False)                # the encoder reads updated weights
         with on('lang'):
             hidden = self._encoder_fwd(d)
             HD = hidden.numel()
@@ -619,6 +622,7 @@ class resnetv1(Network):
         HW = Hc * Wc
         t['net_conv_base'] = base
         # ---- dynamic filters (NET:504-562) ----
+        self.join_deferred()         # last step's deferred weight gradients (they read the activations overwritten from here on) + their update
         self.join_transposes()       # last step's transposed weight copies (first readers: caption / RoI branches below)
         if S is not None:
             self.sfork(S['lang'], main)
@@ -813,9 +817,14 @@ class resnetv1(Network):
         t['loss'] = loss
         # weight gradients of the caption branch, the RoI head (layer4: RoI pass + caption pass = two pixel segments of one problem)
         # and the RPN, as grouped launches on the weight-gradient stream
-        self.flush_wgrads('heads')
-        if dp is not None:
-            self.dp_ready('heads')                              # caption + layer4 + RoI/mask heads are final here
+        if self.defer_heads:
+            self.wgq.defer()                                    # launched by the optimiser, behind the first part of the update (optim.SGD.defer)
+            if dp is not None:
+                self.dp_ready('caption')                        # the captioner's own matrices are final; att_embed .. RPN follow with the deferred launches
+        else:
+            self.flush_wgrads('heads')
+            if dp is not None:
+                self.dp_ready('heads')                          # caption + layer4 + RoI/mask heads are final here
         d_nc = self.buf('dyn.dy', (HW, C4))
         if d_nc_cap is not None:
             O.add3(d_nc_cap, d_nc_rpn, d_nc_roi, d_nc)

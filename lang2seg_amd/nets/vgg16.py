@@ -104,7 +104,7 @@ class vgg16(resnetv1):
     # ------------------------------------------------------------------ backbone (VGG:53-54,78-82)
     def _backbone_fwd(self, d, saved):
         P = self.P
-        self.join_update()                                 # (no frozen prefix worth overlapping here)
+        self.join_update(full=False)                       # (no frozen prefix worth overlapping here)
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
         x, h, w, c = None, H, W, 3
         acts = []                               # (kind, idx, input tensor, h, w, channels, output tensor)

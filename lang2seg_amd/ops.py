@@ -29,6 +29,16 @@ def stream_fork(from_stream, to_stream):
     call('l2s_stream_fork', from_stream.cuda_stream, to_stream.cuda_stream)
 
 
+def event_record(slot, s):
+    """mark 'everything enqueued so far on stream s' under the process-wide slot number (csrc/tape.hip)"""
+    call('l2s_event_record', int(slot), s.cuda_stream)
+
+
+def event_wait(slot, s):
+    """stream s waits for the most recent mark of the slot"""
+    call('l2s_event_wait', int(slot), s.cuda_stream)
+
+
 def memset_zero(t):
     call('l2s_memset_async', ptr(t), 0, t.numel() * t.element_size(), stream())
 
@@ -558,9 +568,18 @@ def logsoftmax_nll(logits, target, mask, S, V1, gscale, loss_slot, dlogits, logp
          ptr(logprobs), stream())
 
 
-def sgd_momentum(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale=1.0, shadow=None):
+def sgd_momentum(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale=1.0, shadow=None, clear_grad=False):
     call('l2s_sgd_momentum', ptr(param), ptr(grad), ptr(mom), ptr(segs_dev), nseg, ptr(rowscale), float(lr), float(momentum),
-         float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, stream())
+         float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, 1 if clear_grad else 0, stream())
+
+
+def sgd_chunk():
+    return int(_lib.load().l2s_sgd_chunk())
+
+
+def sgd_blocks(n=0):
+    """tools: persistent workgroups of the update kernel (0 = query)"""
+    return int(_lib.load().l2s_sgd_blocks(int(n)))
 
 
 def add_f32(a, b, out):

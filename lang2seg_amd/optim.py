@@ -10,14 +10,22 @@ from . import ops as O
 
 
 class SGD(object):
-    def __init__(self, net, lr, momentum=0.9, weight_decay=1e-4, grad_scale=1.0):
+    def __init__(self, net, lr, momentum=0.9, weight_decay=1e-4, grad_scale=1.0, keep_grad=False):
         self.net = net
         self.lr, self.momentum, self.weight_decay, self.grad_scale = float(lr), float(momentum), float(weight_decay), float(grad_scale)
         self.param_groups = [self.__dict__]        # scale_lr()-style code can do group['lr'] *= gamma
-        # decided once, before the first step: the edges of this mode are part of every recorded launch tape
+        # decided once, before the first step: the edges of these modes are part of every recorded launch tape
         self.side_active = bool(self.side and getattr(net, 'use_streams', False) and hasattr(net, 'flush_wgrads'))
         if self.side_active:
             net.update_on_wg = True
+        self.defer_active = bool(self.defer and self.side_active and not self._early and hasattr(net, 'wgq') and getattr(net, 'dp', None) is None)
+        net.defer_heads = self.defer_active
+        # keep_grad=False: the update kernel zeroes every gradient it consumes (optimizer.zero_grad(), TV:383, folded in), and
+        # forward_backward no longer clears the buffer; keep_grad=True leaves the step's gradients in P.grad (tests read them there)
+        self.clear_grad = not keep_grad
+        net.update_clears_grad = self.clear_grad
+        if self.clear_grad and hasattr(net, 'P'):
+            net.P.grad.zero_()
 
     def zero_grad(self):
         pass                                        # gradients are zeroed at the start of forward_backward
@@ -29,14 +37,25 @@ class SGD(object):
     # Round 1 measured it neutral (122.4 / 123.6 img/s with it vs 123.1 without) - but that form made the MAIN queue wait for the
     # transpose stream at every hand-off, i.e. for the weight-gradient launches the partial update itself waits for.  Since round 3 the
     # hand-off only forks, and whatever is left at the end of the step follows the last weight gradients on their stream (SGD.side).
-    early = False                                  # set by tests / tools before the first step
+    _early = False
     _seg_done = 0
 
-    def _launch(self, s0, s1):
+    @property
+    def early(self):
+        return self._early
+
+    @early.setter
+    def early(self, v):                            # set by tests / tools before the first step (the deferred heads stage excludes it)
+        self._early = bool(v)
+        if self._early and getattr(self, 'defer_active', False):
+            self.defer_active = False
+            self.net.defer_heads = False
+
+    def _launch(self, s0, s1, table=None):
         P = self.net.P
         if s1 > s0:
-            O.sgd_momentum(P.param, P.grad, P.mom, P.segs_dev[s0 * P.seg_size:], s1 - s0, P.rowscale, self.lr, self.momentum,
-                           self.weight_decay, self.grad_scale, shadow=P.shadow)
+            O.sgd_momentum(P.param, P.grad, P.mom, (P.segs_dev if table is None else table)[s0 * P.seg_size:], s1 - s0, P.rowscale, self.lr,
+                           self.momentum, self.weight_decay, self.grad_scale, shadow=P.shadow, clear_grad=self.clear_grad)
 
     def partial(self, stage):
         net = self.net
@@ -65,6 +84,18 @@ class SGD(object):
     # Measured (bench.py, 200 steps, A/B alternating in one box): 165.8 vs 163.0 img/s.  SGD.side = False (before construction) restores the update on the caller's stream.
     side = True
 
+    # Deferred heads stage (round 4).  The grouped weight-gradient launches of the heads stage (att_embed, layer4 on the RoIs and on the
+    # map, RoI / mask heads, RPN: ~0.7 ms of chip-filling kernels) used to start at the caption join and run beside the layer3 / layer2
+    # data-gradient chain - 140 short dependent launches that then waited for CU slots (0.66 ms alone, 1.67 ms beside them).  Nothing reads
+    # those gradients before the update, and nothing reads the updated weights before the NEXT step has finished its backbone forward.  So
+    # the step ends with: [weight gradients of layer3 / layer2] -> update of everything OUTSIDE ParamStore.defer_range -> mark
+    # SLOT_UPDATE_REST -> [the held-back weight gradients] -> update of defer_range -> transposes, all on the weight-gradient stream; the
+    # next step's layer2 waits for the mark only (Network.join_update(full=False)), its dynamic filters for the whole stream
+    # (Network.join_deferred()).  The launches are the same and so is their order per tensor: weights are bit-identical to the undeferred
+    # step's (tests/test_train_step_gpu.py::test_deferred_heads_bit_identical).  There is no host-side pending state: the tail is enqueued
+    # by this call, and every reader outside the step (state_dict, TEST mode, snapshots) joins the whole weight-gradient stream.
+    defer = False   # measured (round 4, same-box A/B x3): 180.7 img/s with it, 184.1 without - see DESIGN.md section 4.6
+
     def step(self):
         P = self.net.P
         net = self.net
@@ -77,7 +108,15 @@ class SGD(object):
                 net.sfork(S['tr'], S['wg'])               # early partial updates of this step (SGD.early) ran on the transpose stream
             net.sfork(torch.cuda.current_stream(), S['wg'])
             with torch.cuda.stream(S['wg']):
-                self._launch(self._seg_done, P.nseg)      # whatever the partial updates left: the last backward stages
+                if self.defer_active:
+                    self._launch(0, P.n_rest, P.segs_split_dev)
+                    O.event_record(net.SLOT_UPDATE_REST, S['wg'])
+                    net._mark('update of the rest done (wg)')
+                    net.wgq.flush_deferred('heads')
+                    net._mark('deferred weight gradients done (wg)')
+                    self._launch(P.n_rest, P.nseg, P.segs_split_dev)
+                else:
+                    self._launch(self._seg_done, P.nseg)  # whatever the partial updates left: the last backward stages
                 net.refresh_weights()
                 net._mark('update done (wg)')
             self._seg_done = 0

@@ -247,7 +247,7 @@ def test_gradients_are_bit_reproducible():
         nA = 20 * 26 * 12
         net.parity = selftest.parity_from_samp(dict(rpn_fg_keys=rs.permutation(nA).astype(np.uint32), rpn_bg_keys=rs.permutation(nA).astype(np.uint32),
                                                     roi_fg_keys=rs.permutation(300).astype(np.uint32), roi_bg_keys=rs.permutation(300).astype(np.uint32)))
-        sgd = SGD(net, 0.0)
+        sgd = SGD(net, 0.0, keep_grad=True)
         grads = []
         for _ in range(3):
             net.train_step(dict(blob), 0, sgd)
@@ -405,7 +405,7 @@ def test_dp_tape_segments_match_eager():
         net = selftest.build_net(opt, over, 'f32', sd)
         net.dp = GradReducer(net, 1)
         net.use_tape = tape
-        sgd = SGD(net, 0.0)            # lr 0: the weights stay put, so the steps are comparable one by one (the proposal list is
+        sgd = SGD(net, 0.0, keep_grad=True)   # lr 0: the weights stay put, so the steps are comparable one by one (the proposal list is
                                        # discontinuous in the weights; any update would let fp32 atomic-order noise pick different RoIs)
         # (the first tape call executes the step once and records it while it runs; the later calls replay)
         vals = [net.train_step(dict(blob), 0, sgd) for _ in range(4)]
@@ -657,6 +657,94 @@ def test_pipelined_tape_training_matches_eager_training():
     assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
 
 
+@pytest.mark.parametrize('variant', ['cycle', 'vgg'])
+def test_deferred_heads_bit_identical(variant):
+    """optim.SGD.defer (the heads stage's grouped weight-gradient launches and their part of the update run BEHIND the rest of the update,
+    beside the next step's backbone forward; layer2 waits for an event slot, the dynamic filters for the whole stream): K pipelined steps
+    with a real learning rate give the same weights and momentum, BIT FOR BIT, as K steps with the undeferred order - eager and replayed
+    from the launch tape, bf16, and with a state_dict() read in the middle of the run (a reader outside the step joins the deferred tail).
+    Semantics matched: one optimizer.step() per train_step over all parameters (train_val_cycle.py:194-220, network_cycle_res5_2.py:712-715)."""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    if variant == 'vgg':
+        opt['C4_feat_dim'] = 512
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant=variant) if variant == 'vgg' else OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
+    blobs = [OS.make_blob(320, 416, 6, 60, seed=5), OS.make_blob(320, 416, 6, 60, seed=6)]
+    out = {}
+    was = SGD.defer
+    try:
+        for defer in (False, True):
+            for tape in (False, True):
+                SGD.defer = defer
+                net = selftest.build_net(opt, over, 'bf16', sd, variant=variant)
+                net.use_tape = tape
+                sgd = SGD(net, 1e-3, momentum=0.9, weight_decay=1e-4)
+                assert sgd.defer_active == defer and net.defer_heads == defer
+                mid = None
+                for i in range(8):
+                    net.train_step_async(dict(blobs[i % 2]), 0, sgd)
+                    if i == 4:
+                        mid = {k: v.clone() for k, v in net.state_dict().items()}          # no sync before it: the tail is still in flight
+                torch.cuda.synchronize()
+                net.join_update()
+                torch.cuda.synchronize()
+                out[(defer, tape)] = (net.P.param.clone(), net.P.mom.clone(), mid, net.P.grad.clone())
+    finally:
+        SGD.defer = was
+    p0, m0, mid0, g0 = out[(False, False)]
+    assert bool(torch.isfinite(p0).all()) and float(m0.abs().max()) > 0
+    assert float(g0.abs().max()) == 0.0                       # the update consumed and cleared every gradient
+    for key, (p, m, mid, g) in out.items():
+        assert torch.equal(p, p0), (variant, key, int((p != p0).sum()))
+        assert torch.equal(m, m0), (variant, key, int((m != m0).sum()))
+        assert torch.equal(g, g0), (variant, key)
+        for k in mid0:
+            assert torch.equal(mid[k], mid0[k]), (variant, key, k)
+
+
+def test_encoder_is_deterministic_beside_other_kernels():
+    """round 4: the encoder's LSTM on the language stream, replayed from a launch tape beside the first layers of the VGG
+    backbone on the main stream, must give the same hidden state every time.  With packed fp32 VALU ops in the LSTM step kernel
+    (v_pk_fma_f32, the compiler's pairing of its four fmaf chains) 573 ... 2850 of 3000 such replays differed by up to 1e-2; the library
+    is built without them (__graft_entry__.HIPCC_FLAGS; tests/test_host_cpu.py scans the ISA)."""
+    from lang2seg_amd import selftest, ops as O
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6); opt['C4_feat_dim'] = 512
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant='vgg')
+    net = selftest.build_net(opt, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64), 'bf16', sd, variant='vgg')
+    dev = net.upload_blob(dict(OS.make_blob(320, 416, 6, 60, seed=5)), 0)
+    main = torch.cuda.current_stream()
+    S = net.streams()
+    slist = [main, S['lang'], S['cap'], S['wg'], S['wg2'], S['tr']]
+    full_plan = list(net.vgg_plan)
+    for nlayers in (3, 4):
+        net.vgg_plan = full_plan[:nlayers]
+        net.t = {}
+        torch.cuda.synchronize()
+        h = O.tape_begin(slist)
+        net._rec_key = ('fuzz', nlayers)
+        try:
+            net.sfork(main, S['lang'])
+            with torch.cuda.stream(S['lang']):
+                hidden = net._encoder_fwd(dev)
+            net._backbone_fwd(dev, {})
+            net.sfork(S['lang'], main)
+        finally:
+            O.tape_end(h); net._rec_key = None
+        torch.cuda.synchronize()
+        ref = hidden.clone()
+        bad = 0
+        for _ in range(1500):
+            O.tape_run(h, slist)
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(hidden, ref))
+        O.tape_destroy(h)
+        assert bad == 0, (nlayers, bad)
+
+
 def test_tape_stops_recording_when_shapes_keep_changing():
     """a stream of inputs whose (image size, token count) key is new almost every step: once fewer than half of the last `tape_window`
     steps were replays, a miss runs eagerly and is not recorded (no tape, no pinned activation plan per key); known keys keep replaying"""
@@ -728,7 +816,7 @@ def test_no_gradient_lands_behind_its_bucket(variant):
         net.use_tape = False
         if dp:
             net.dp = Doubler(net, 2)
-        sgd = SGD(net, 0.0, grad_scale=0.5 if dp else 1.0)
+        sgd = SGD(net, 0.0, grad_scale=0.5 if dp else 1.0, keep_grad=True)
         net.train_step(dict(blob), 0, sgd)
         torch.cuda.synchronize()
         grads.append(net.P.grad.clone())

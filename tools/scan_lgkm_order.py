@@ -7,6 +7,10 @@ wave-shuffle reductions, lane 0 storing both results to LDS) whose second sum wa
 exactly this instruction pattern, and the error went away when the pattern did.  Plain ds_read before ds_write (every software-pipelined
 GEMM) is not reported.
 
+Round 4 added a second pattern: packed fp32 VALU ops (v_pk_fma_f32, v_pk_add_f32, v_pk_mul_f32).  The LSTM step kernel's paired fmaf chains
+gave sporadically wrong low halves beside other queues' kernels (tools/vgg_corun_fuzz.py); the library is built with the target feature
+`packed-fp32-ops` off (__graft_entry__.HIPCC_FLAGS) and this scan checks that none is left in any kernel.
+
     python tools/scan_lgkm_order.py            # compiles lang2seg_amd/csrc/*.hip to assembly under /tmp and scans them
 """
 import glob, os, re, subprocess, sys
@@ -26,6 +30,8 @@ def scan(path):
         if not t or t[0] in '.;' or t.split()[0].endswith(':'):
             continue
         op = t.split()[0]
+        if re.match(r'v_pk_\w+_f32', op):
+            hits[fn + ' [packed fp32 op]'] = hits.get(fn + ' [packed fp32 op]', 0) + 1
         if op.startswith(('ds_bpermute', 'ds_permute', 'ds_swizzle')):
             out.append('P')
         elif op.startswith('ds_read'):
@@ -51,7 +57,9 @@ def main():
     bad = 0
     for src in sorted(glob.glob(os.path.join(ROOT, 'lang2seg_amd', 'csrc', '*.hip'))):
         asm = os.path.join('/tmp', 'l2s_scan_' + os.path.basename(src)[:-4] + '.s')
-        subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
+        sys.path.insert(0, ROOT)
+        from __graft_entry__ import HIPCC_FLAGS                      # the flags the library is built with
+        subprocess.run([hipcc] + [f for f in HIPCC_FLAGS if f != '-fPIC'] + ['-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
                         src, '-o', asm], check=True, capture_output=True)
         for fn, n in scan(asm).items():
             print('%s: %d site(s) in %s' % (os.path.basename(src), n, fn))

@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--knockout', default='')
     ap.add_argument('--lib', default='', help='another build of the C-ABI library (tools/ab_build.sh / tools/ab_variant2.sh)')
     ap.add_argument('--sgd-early', type=int, default=-1)
+    ap.add_argument('--defer', type=int, default=-1, help='1 / 0 = optim.SGD.defer on / off')
+    ap.add_argument('--wgrad-cap', type=int, default=0)
     args = ap.parse_args()
     if args.lib:
         from lang2seg_amd import _lib
@@ -38,9 +40,14 @@ def main():
     net = resnetv1(opt, batch_size=1, num_layers=101)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()
-    if args.sgd_early >= 0:
-        SGD.early = bool(args.sgd_early)
+    if args.wgrad_cap > 0:
+        from lang2seg_amd import _lib as _L2
+        _L2.load().l2s_wgrad_grid_cap(args.wgrad_cap)
+    if args.defer >= 0:
+        SGD.defer = bool(args.defer)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY)
+    if args.sgd_early >= 0:
+        optim.early = bool(args.sgd_early)
     blob = SyntheticLoader(num_images=1, sents_per_image=1, H=600, W=1000, T=T, vocab_size=V).getBatch('train')
     net.upload_blob(blob, 0)
     net.knockout = frozenset(x for x in args.knockout.split(',') if x)
