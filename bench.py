@@ -46,6 +46,7 @@ def parse_args(argv=None):
     ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
     ap.add_argument('--sgd-early', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.early on / off (update each finished prefix of the flat buffer during backward; one rank only)')
     ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
+    ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
     ap.add_argument('--wgrad-cap', type=int, default=0, help='A/B only: at most this many workgroups per grouped weight-gradient launch')
     ap.add_argument('--sgd-blocks', type=int, default=0, help='A/B only: persistent workgroups of the update kernel')
     ap.add_argument('--lib', default='', help='A/B only: load this build of the C-ABI library instead of the in-tree one (tools/ab_build.sh <rev>); the line is marked')
@@ -249,7 +250,7 @@ class LaunchTimer(object):
 
     def wgrad_hook(self, tag, variant, flop, k):
         """context around one grouped weight-gradient launch (all weight gradients of a backward stage with one tile variant)"""
-        names = ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3', '256x256/tap')
+        names = ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3', '256x256/tap', '128x128/row3-dma')
         if not self.on and self.tape_all:
             lt = self
 
@@ -260,7 +261,7 @@ class LaunchTimer(object):
                 def __exit__(s, *a_):
                     b = lt.O.tape_time_event()
                     if s.a >= 0 and b >= 0:
-                        lt.tape_recs.append(('%s [%s]' % (tag, names[variant]), 'wgrad', 3 if variant in (2, 3) else k, flop, s.a, b))
+                        lt.tape_recs.append(('%s [%s]' % (tag, names[variant]), 'wgrad', 3 if variant in (2, 3, 5) else k, flop, s.a, b))
                         lt.tape_plan.append('')
             return _T()
         if not self.on:
@@ -273,7 +274,7 @@ class LaunchTimer(object):
 
             def __exit__(s, *a):
                 e1 = T.cuda.Event(enable_timing=True); e1.record()
-                recs.append(('%s [%s]' % (tag, ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3', '256x256/tap')[variant]), 'wgrad', 3 if variant in (2, 3) else k, flop, s.e0, e1))
+                recs.append(('%s [%s]' % (tag, names[variant]), 'wgrad', 3 if variant in (2, 3, 5) else k, flop, s.e0, e1))
         return _C()
 
     def summary(self, steps):
@@ -386,6 +387,9 @@ def main(argv=None):
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
     if args.sgd_early >= 0:
         optim.early = bool(args.sgd_early)
+    if args.wgrad_row3_dma >= 0:
+        from lang2seg_amd import _lib as _L3
+        _L3.load().l2s_wgrad_row3_dma(args.wgrad_row3_dma, 0)
     if args.wgrad_cap > 0:
         from lang2seg_amd import _lib as _L2
         _L2.load().l2s_wgrad_grid_cap(args.wgrad_cap)

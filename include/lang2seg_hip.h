@@ -109,6 +109,10 @@ typedef struct {
 } l2s_wgrad_prob;
 int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile);
 long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW);
+/* variant 5 (bf16, 3x3 / stride 1 / pad 1, >= 8192 pixels, channels multiples of 128): the LDS-DMA filter-row tile, balanced stream-K style
+ * over `wgs` workgroups; its slabs need l2s_wgrad_grouped_ws_bytes(5) of workspace.  l2s_wgrad_row3_dma(on, wgs): tools (A/B); < 0 / <= 0 keep */
+int l2s_wgrad_row3_dma(int on, int wgs);
+size_t l2s_wgrad_grouped_ws_bytes(int variant);
 /* tools: cap the workgroups of a grouped launch (each then walks several tiles); 0 = one workgroup per tile, < 0 = query */
 int l2s_wgrad_grid_cap(int cap);
 int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,

@@ -29,6 +29,7 @@
 //     order (still no floating-point atomics).
 #include "common.h"
 #include "../../include/lang2seg_hip.h"
+#include "wgrad_internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -353,19 +354,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 }
 
 // ---- variants (tile, taps per workgroup): 0 = 64x64 per tap, 1 = 128x128 per tap, 2 = 64x64 filter row, 3 = 128(co)x64 filter row,
-// 4 = 256x256 per tap with 8 waves (bf16 grouped launches only; `tile` = 256 allows it) ----
+// 4 = 256x256 per tap with 8 waves, 5 = the LDS-DMA 128x128 filter-row tile with stream-K balancing (conv_wgrad_dma.hip)
+// (4 and 5: bf16 grouped launches only; `tile` = 256 allows them) ----
+int g_wgrad_row3_dma_wgs = 256;   // workgroups of the stream-K launch (one per CU)
+int g_wgrad_row3_dma = 1;   // tools: 0 sends the large 3x3 problems back to the register-staged filter-row tile (A/B)
 int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   const bool row3 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
   const bool big = M >= 8192 && Cout >= 512 && Cin >= 512;
+  if (row3 && tile == 256 && g_wgrad_row3_dma && M >= 8192 && Cout % 128 == 0 && Cin % 128 == 0) return 5;
   if (row3) return (tile == 128 || ((!tile || tile == 256) && Cout >= 512)) ? 3 : 2;
   if (tile == 256 && big && KH * KW == 1 && Cout % 256 == 0 && Cin % 256 == 0) return 4;
   return (tile == 128 || ((!tile || tile == 256) && big && KH * KW == 1)) ? 1 : 0;
 }
 void variant_tile(int v, int& bm, int& bn, int& tx) {
   if (v == 4) { bm = 256; bn = 256; tx = 1; return; }
+  if (v == 5) { bm = 128; bn = 128; tx = 3; return; }
   bm = (v == 1 || v == 3) ? 128 : 64; bn = v == 1 ? 128 : 64; tx = v >= 2 ? 3 : 1;
 }
 long variant_tiles(int v, int Cin, int Cout, int KH, int KW) {
+  if (v == 5) return l2s::wgrad_row3_dma_tiles(Cin, Cout);
   int bm, bn, tx; variant_tile(v, bm, bn, tx);
   return (long)cdiv(Cout, bm) * cdiv(Cin, bn) * (tx == 3 ? KH : KH * KW);
 }
@@ -432,6 +439,13 @@ bool prob_ok(const wgp& p, int dtype) {
 
 }  // namespace
 
+extern "C" int l2s_wgrad_row3_dma(int on, int wgs) {
+  if (on >= 16) { l2s::g_row3_form = on - 16; return g_wgrad_row3_dma; }      // tools: 16 + form selects the pipeline form of the kernel
+  if (on >= 0) g_wgrad_row3_dma = on;
+  if (wgs > 0) g_wgrad_row3_dma_wgs = wgs;
+  return g_wgrad_row3_dma;
+}
+extern "C" size_t l2s_wgrad_grouped_ws_bytes(int variant) { return variant == 5 ? l2s::wgrad_row3_dma_ws_bytes(g_wgrad_row3_dma_wgs) : 0; }
 extern "C" int l2s_wgrad_grid_cap(int cap) { if (cap >= 0) g_wgrad_grid_cap = cap; return g_wgrad_grid_cap; }
 extern "C" int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   return variant_of(Cin, Cout, KH, KW, stride, pad, same_hw, M, tile);
@@ -440,7 +454,12 @@ extern "C" long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW) 
 
 extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
                                       float* ws, size_t ws_bytes, hipStream_t stream) {
-  if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 4) return L2S_EINVAL;
+  if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 5) return L2S_EINVAL;
+  if (variant == 5) {
+    if (dtype != L2S_BF16) return L2S_EINVAL;
+    for (int i = 0; i < nprob; ++i) if (!prob_ok(table_host[i], dtype) || !table_host[i].dw) return L2S_EINVAL;
+    return l2s::wgrad_row3_dma_launch(table_dev, table_host, nprob, ws, ws_bytes, g_wgrad_row3_dma_wgs, stream);
+  }
   wg_prefix pre;
   pre.n = nprob;
   long t = 0;

@@ -1,0 +1,15 @@
+// shared between conv_wgrad.hip (dispatch of the grouped launches) and conv_wgrad_dma.hip (the LDS-DMA filter-row tile)
+#pragma once
+#include "../../include/lang2seg_hip.h"
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace l2s {
+// stream-K plan of one launch: problem i owns the (tile, slice) units [unit0[i], unit0[i + 1]), S[i] slices per tile; U units in all
+struct wgrad_sk_plan { int n; long U; long unit0[L2S_WGRAD_MAX_GROUP + 1]; int S[L2S_WGRAD_MAX_GROUP]; };
+extern int g_row3_form;
+bool wgrad_row3_dma_ok(const l2s_wgrad_prob& q);
+long wgrad_row3_dma_tiles(int Cin, int Cout);
+size_t wgrad_row3_dma_ws_bytes(int G);
+int wgrad_row3_dma_launch(const l2s_wgrad_prob* tab_dev, const l2s_wgrad_prob* tab_host, int nprob, float* ws, size_t ws_bytes, int G, hipStream_t st);
+}

@@ -166,8 +166,10 @@ class WgradQueue(object):
                         dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
                         q = arr[i]
                         q.dw, q.nseg, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad = dw.data_ptr(), len(seg), Cin, Cout, k, k, stride, pad
-                        slices = min(u[3] * u[7] * (u[8] + (1 if v in (2, 3) else 0)) // bkp for u in seg)
+                        slices = min(u[3] * u[7] * (u[8] + (1 if v in (2, 3, 5) else 0)) // bkp for u in seg)
                         split = max(1, min(want, slices // 16, 16))
+                        if v == 5:
+                            split = 1                                   # the LDS-DMA filter-row launch balances itself (stream-K, slabs per workgroup)
                         slab = Cout * k * k * Cin
                         if split > 1 and (off + split * slab) * 4 <= ws.numel() * 4:
                             q.split, q.ws_off = split, off
@@ -345,7 +347,7 @@ class Network(object):
         self.sfork(torch.cuda.current_stream(), S[name])
         return torch.cuda.stream(S[name])
 
-    WGRAD_WS_BYTES = 64 << 20
+    WGRAD_WS_BYTES = 128 << 20       # (the stream-K launch of the large 3x3 problems needs 2 slabs of 192 KiB per workgroup: 101 MB)
 
     def wgrad_ws(self):
         """split-K slabs of the grouped weight-gradient launches (one buffer: they all run on the 'wg' stream, in order)"""

@@ -582,7 +582,12 @@ class resnetv1(Network):
         main = torch.cuda.current_stream()
         S = self.streams() if self.use_streams else None
         if self.update_clears_grad:
-            pass                                            # optimizer.zero_grad() (TV:383) is folded into the update kernel
+            # optimizer.zero_grad() (TV:383) is folded into the update kernel: the buffer is zero here unless a backward pass went by without an update
+            if backward:
+                if getattr(self, '_bwd_pending', 0):
+                    raise RuntimeError('two backward passes without an optimiser update in between: the gradients would add up '
+                                       '(the update clears them; construct SGD(keep_grad=True) to have every step clear them itself)')
+                self._bwd_pending = 1
         elif S is not None and self.update_on_wg:
             self.sfork(main, S['wg'])                       # (an update that ran on this queue after all, e.g. early partial updates)
             with torch.cuda.stream(S['wg']):                # behind the previous step's update, which read the gradients

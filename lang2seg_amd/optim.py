@@ -21,11 +21,10 @@ class SGD(object):
         self.defer_active = bool(self.defer and self.side_active and not self._early and hasattr(net, 'wgq') and getattr(net, 'dp', None) is None)
         net.defer_heads = self.defer_active
         # keep_grad=False: the update kernel zeroes every gradient it consumes (optimizer.zero_grad(), TV:383, folded in), and
-        # forward_backward no longer clears the buffer; keep_grad=True leaves the step's gradients in P.grad (tests read them there)
+        # forward_backward no longer clears the buffer (it is zero when the network is built, and every update leaves it zero; a second
+        # backward pass without an update in between is refused); keep_grad=True leaves the step's gradients in P.grad (tests read them there)
         self.clear_grad = not keep_grad
         net.update_clears_grad = self.clear_grad
-        if self.clear_grad and hasattr(net, 'P'):
-            net.P.grad.zero_()
 
     def zero_grad(self):
         pass                                        # gradients are zeroed at the start of forward_backward
@@ -99,6 +98,7 @@ class SGD(object):
     def step(self):
         P = self.net.P
         net = self.net
+        net._bwd_pending = 0
         if self.side_active and net.use_streams:
             net.flush_wgrads('final')
             S = net.streams()

@@ -395,7 +395,8 @@ def test_conv_wgrad_grouped(dt):
     # (uses [(n, H, W)], Cin, Cout, k, stride, pad)
     convs = [([(1, 19, 23)], 64, 128, 3, 1, 1), ([(3, 7, 7), (1, 11, 13)], 128, 64, 3, 1, 1), ([(2, 9, 9)], 256, 72, 1, 1, 0),
              ([(40, 7, 7), (1, 10, 12)], 512, 512, 1, 1, 0), ([(1, 20, 26)], 256, 128, 1, 2, 0), ([(20, 7, 7)], 512, 512, 3, 1, 1),
-             ([(170, 7, 7), (1, 10, 12)], 512, 768, 1, 1, 0)]          # >= 8192 pixels, 256-multiples: the 8-wave 256x256 tile in bf16
+             ([(170, 7, 7), (1, 10, 12)], 512, 768, 1, 1, 0),          # >= 8192 pixels, 256-multiples: the 8-wave 256x256 tile in bf16
+             ([(170, 7, 7), (1, 10, 12)], 256, 384, 3, 1, 1), ([(180, 7, 7)], 128, 128, 3, 1, 1)]   # 3x3, >= 8192 pixels: the LDS-DMA filter-row tile in bf16
     byv, keep = {}, []
     for uses, Cin, Cout, k, s, p in convs:
         dw = torch.ones((Cout, k * k * Cin), dtype=torch.float32, device=DEV)
@@ -417,7 +418,7 @@ def test_conv_wgrad_grouped(dt):
         v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, s, p, int(same), Mmax, 256 if dt == 1 else 0))
         byv.setdefault(v, []).append((q, dw, ohwi(ref).reshape(Cout, k * k * Cin) + 1.0))
     assert len(byv) >= 3                                        # per-tap and filter-row tiles, 64- and 128-wide
-    assert (4 in byv) == (dt == 1)
+    assert (4 in byv) == (dt == 1) and (5 in byv) == (dt == 1)
     first = {}
     for rep in range(2):
         for v, lst in byv.items():
@@ -426,17 +427,17 @@ def test_conv_wgrad_grouped(dt):
                 for _, dw, _ in lst:
                     dw.fill_(1.0)
             tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
-            if rep:                                              # second pass: pixels of the first problem cut into 3 ranges (slabs, fixed-order sum)
+            if rep and v != 5:                                   # second pass: pixels of the first problem cut into 3 ranges (slabs, fixed-order sum)
                 arr[0].split, arr[0].ws_off = 3, 0
                 tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
-            ws = torch.empty(8 << 20, dtype=torch.float32, device=DEV)
+            ws = torch.empty(max(8 << 20, int(lib.l2s_wgrad_grouped_ws_bytes(v)) // 4), dtype=torch.float32, device=DEV)
             O.call('l2s_conv_wgrad_grouped', tab.data_ptr(), C.cast(arr, C.c_void_p), len(lst), v, dt, ws.data_ptr(), ws.numel() * 4, O.stream())
             torch.cuda.synchronize()
             for i, (_, dw, ref) in enumerate(lst):
                 assert rel_err(dw, ref) < 1e-4, (v, i)
                 if rep == 0:
                     first[(v, i)] = dw.clone()
-                elif i > 0:
+                elif i > 0 or v == 5:
                     assert torch.equal(dw, first[(v, i)])       # unsplit problems: bit-identical from run to run
 
 
@@ -1225,10 +1226,21 @@ def test_sgd_and_misc():
     segs[0].offset, segs[0].count, segs[0].row_len, segs[0].weight_decay, segs[0].rowscale_off, segs[0].lr_mult = 0, n1, 1, 1, -1, 1.0
     segs[1].offset, segs[1].count, segs[1].row_len, segs[1].weight_decay, segs[1].rowscale_off, segs[1].lr_mult = n1, rows * rl, rl, 1, 0, 1.0
     segs[2].offset, segs[2].count, segs[2].row_len, segs[2].weight_decay, segs[2].rowscale_off, segs[2].lr_mult = n1 + rows * rl, n3, 1, 0, -1, 2.0
+    run = 0
+    for sg in segs:                                  # l2s_sgd_seg.chunk0: running count of the segments' work chunks (include/lang2seg_hip.h)
+        sg.chunk0 = run; run += -(-int(sg.count) // O.sgd_chunk())
     sb = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(DEV)
     pd, gd, md = p.to(DEV), gr.to(DEV), m.to(DEV)
     shadow = torch.empty(tot, dtype=torch.bfloat16, device=DEV)
     O.sgd_momentum(pd, gd, md, sb, 3, rowscale.to(DEV), 0.01, 0.9, 1e-2, shadow=shadow)
+    torch.cuda.synchronize()
+    assert torch.equal(gd.cpu(), gr)                 # clear_grad = 0: the gradients are left alone
+    # the same update on the last two segments only, with the gradient clear folded in (the table may start at any segment)
+    p2, g2, m2 = p.to(DEV), gr.to(DEV), m.to(DEV)
+    O.sgd_momentum(p2, g2, m2, sb[C.sizeof(SgdSeg):], 2, rowscale.to(DEV), 0.01, 0.9, 1e-2, shadow=None, clear_grad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(p2[n1:], pd[n1:]) and torch.equal(m2[n1:], md[n1:]) and torch.equal(p2[:n1].cpu(), p[:n1])
+    assert float(g2[n1:].abs().max()) == 0.0 and torch.equal(g2[:n1].cpu(), gr[:n1])
     ge = gr.clone(); ge[n1:n1 + rows * rl] = (ge[n1:n1 + rows * rl].view(rows, rl) * rowscale.view(-1, 1)).view(-1)
     wd = torch.ones(tot) * 1e-2; wd[n1 + rows * rl:] = 0
     lr = torch.ones(tot) * 0.01; lr[n1 + rows * rl:] = 0.02

@@ -10,12 +10,21 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--lib', default='')
+    ap.add_argument('--row3-dma', type=int, default=-1, help='1 / 0: the LDS-DMA filter-row tile for the large 3x3 problems on / off')
+    ap.add_argument('--form', type=int, default=-1, help='pipeline form of the LDS-DMA filter-row kernel (0..3)')
+    ap.add_argument('--only', default='', help='substring of the stage names to run')
+    ap.add_argument('--wgs', type=int, default=0, help='workgroups of its stream-K launch')
+    ap.add_argument('--check', type=int, default=0, help='1: compare the layer4 3x3 weight gradients of the two filter-row kernels')
     ap.add_argument('--min-wg', type=int, default=0, help='WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
     args = ap.parse_args()
     if args.lib:
         from lang2seg_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args.lib)
-    from lang2seg_amd import ops as O
+    from lang2seg_amd import ops as O, _lib as L_
+    if args.form >= 0:
+        L_.load().l2s_wgrad_row3_dma(16 + args.form, 0)
+    if args.row3_dma >= 0 or args.wgs:
+        L_.load().l2s_wgrad_row3_dma(args.row3_dma, args.wgs)
     from lang2seg_amd.nets.network import WgradQueue
     from lang2seg_amd._lib import BF16
 
@@ -23,7 +32,7 @@ def main():
         dt = BF16; device = 'cuda'; _rec_key = None
         def fork_wgrad(self, alt=False, fixed=None): return contextlib.nullcontext()
         def wgrad_ws(self):
-            if not hasattr(self, '_ws'): self._ws = torch.empty(16 << 20, dtype=torch.float32, device='cuda')
+            if not hasattr(self, '_ws'): self._ws = torch.empty(32 << 20, dtype=torch.float32, device='cuda')
             return self._ws
     net = Net()
     if args.min_wg:
@@ -37,6 +46,8 @@ def main():
         def __exit__(self, *a): pass
 
     def stage(name, probs):
+        if args.only and args.only not in name:
+            return
         q = WgradQueue(net)
         q.on_launch = lambda tag, v, flop, k: Hook(tag, v, flop, k)
         keep = []
@@ -64,6 +75,24 @@ def main():
 
     R, MAP = (256, 7, 7), (1, 38, 63)
     l4_3x3 = [(512, 512, 3, [R, MAP])] * 3
+    if args.check:
+        torch.manual_seed(0)
+        res = []
+        data = [(bf(n * H * W, 512), bf(n * H * W, 512), n, H, W) for (n, H, W) in (R, MAP)]
+        for on in (0, 1):
+            L_.load().l2s_wgrad_row3_dma(on, 0)
+            q = WgradQueue(net)
+            dws = [torch.ones(512, 9 * 512, device='cuda') for _ in range(3)]
+            for dw in dws:
+                for g, x, n, H, W in data:
+                    q.add(dw, g, x, n, H, W, 512, H, W, 512, 3, 1, 1)
+            q.flush('check%d' % on); torch.cuda.synchronize()
+            res.append(dws)
+        for i in range(3):
+            a, b = res[0][i], res[1][i]
+            print('problem %d: max |old - new| %.3e, max |old| %.3e, equal to each other across problems: %s' % (
+                i, float((a - b).abs().max()), float(a.abs().max()), torch.equal(res[1][i], res[1][0])))
+        L_.load().l2s_wgrad_row3_dma(args.row3_dma if args.row3_dma >= 0 else 1, 0)
     l4_1x1 = [(1024, 512, 1, [R, MAP]), (2048, 512, 1, [R, MAP]), (2048, 512, 1, [R, MAP]), (512, 2048, 1, [R, MAP]), (512, 2048, 1, [R, MAP]),
               (512, 2048, 1, [R, MAP]), (1024, 2048, 1, [R, MAP])]
     stage('layer4 3x3 (filter rows)', l4_3x3)
