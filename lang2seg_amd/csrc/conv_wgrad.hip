@@ -440,7 +440,8 @@ bool prob_ok(const wgp& p, int dtype) {
 }  // namespace
 
 extern "C" int l2s_wgrad_row3_dma(int on, int wgs) {
-  if (on >= 16) { l2s::g_row3_form = on - 16; return g_wgrad_row3_dma; }      // tools: 16 + form selects the pipeline form of the kernel
+  if (on >= 32) { l2s::g_row3_plan_mode = on - 32; return g_wgrad_row3_dma; } // tools: 32 / 33 = contiguous stream-K ranges always / XCD-lockstep plan where it applies
+  if (on >= 16) { l2s::g_row3_form = on - 16; return g_wgrad_row3_dma; }      // tools: 16 + mask = knock-outs of the kernel
   if (on >= 0) g_wgrad_row3_dma = on;
   if (wgs > 0) g_wgrad_row3_dma_wgs = wgs;
   return g_wgrad_row3_dma;

@@ -12,6 +12,7 @@ def main():
     ap.add_argument('--lib', default='')
     ap.add_argument('--row3-dma', type=int, default=-1, help='1 / 0: the LDS-DMA filter-row tile for the large 3x3 problems on / off')
     ap.add_argument('--form', type=int, default=-1, help='pipeline form of the LDS-DMA filter-row kernel (0..3)')
+    ap.add_argument('--plan', type=int, default=-1, help='0: contiguous stream-K ranges, 1: XCD-lockstep plan')
     ap.add_argument('--only', default='', help='substring of the stage names to run')
     ap.add_argument('--wgs', type=int, default=0, help='workgroups of its stream-K launch')
     ap.add_argument('--check', type=int, default=0, help='1: compare the layer4 3x3 weight gradients of the two filter-row kernels')
@@ -21,6 +22,8 @@ def main():
         from lang2seg_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args.lib)
     from lang2seg_amd import ops as O, _lib as L_
+    if args.plan >= 0:
+        L_.load().l2s_wgrad_row3_dma(32 + args.plan, 0)
     if args.form >= 0:
         L_.load().l2s_wgrad_row3_dma(16 + args.form, 0)
     if args.row3_dma >= 0 or args.wgs:
