@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument('--sgd-early', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.early on / off (update each finished prefix of the flat buffer during backward; one rank only)')
     ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
     ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
+    ap.add_argument('--wgrad-wgs', type=int, default=0, help='A/B only: workgroups of the stream-K launch of the LDS-DMA filter-row tile (default 256 = one per CU)')
     ap.add_argument('--wgrad-cap', type=int, default=0, help='A/B only: at most this many workgroups per grouped weight-gradient launch')
     ap.add_argument('--sgd-blocks', type=int, default=0, help='A/B only: persistent workgroups of the update kernel')
     ap.add_argument('--lib', default='', help='A/B only: load this build of the C-ABI library instead of the in-tree one (tools/ab_build.sh <rev>); the line is marked')
@@ -389,7 +390,10 @@ def main(argv=None):
         optim.early = bool(args.sgd_early)
     if args.wgrad_row3_dma >= 0:
         from lang2seg_amd import _lib as _L3
-        _L3.load().l2s_wgrad_row3_dma(args.wgrad_row3_dma, 0)
+        _L3.load().l2s_wgrad_row3_dma(args.wgrad_row3_dma, args.wgrad_wgs)
+    elif args.wgrad_wgs > 0:
+        from lang2seg_amd import _lib as _L3
+        _L3.load().l2s_wgrad_row3_dma(-1, args.wgrad_wgs)
     if args.wgrad_cap > 0:
         from lang2seg_amd import _lib as _L2
         _L2.load().l2s_wgrad_grid_cap(args.wgrad_cap)

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 // ---- variants (tile, taps per workgroup): 0 = 64x64 per tap, 1 = 128x128 per tap, 2 = 64x64 filter row, 3 = 128(co)x64 filter row,
 // 4 = 256x256 per tap with 8 waves, 5 = the LDS-DMA 128x128 filter-row tile with stream-K balancing (conv_wgrad_dma.hip)
 // (4 and 5: bf16 grouped launches only; `tile` = 256 allows them) ----
-int g_wgrad_row3_dma_wgs = 256;   // workgroups of the stream-K launch (one per CU)
+int g_wgrad_row3_dma_wgs = 128;   // workgroups of the stream-K launch: half the CUs (a workgroup owns its CU - 132 KB of LDS, 240 VGPRs x 8 waves -
+                                  // and the other queues' launches need somewhere to run: 96 / 128 / 160 / 256 -> 190.1 / 189.1 / 189.0 / 185.5 img/s, same box x 3)
 int g_wgrad_row3_dma = 1;   // tools: 0 sends the large 3x3 problems back to the register-staged filter-row tile (A/B)
 int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   const bool row3 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
@@ -415,7 +416,11 @@ int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_spl
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   int grid = pre.tile0[pre.n];
-  if (g_wgrad_grid_cap > 0 && grid > g_wgrad_grid_cap) grid = g_wgrad_grid_cap;
+  {
+    const int cap = g_wgrad_grid_cap & 0xffff, vmask = g_wgrad_grid_cap >> 16;      // (tools: cap | variant mask << 16; mask 0 = every variant)
+    const int var = BM == 256 ? 4 : (TX == 3 ? (BM == 128 ? 3 : 2) : (BM == 128 ? 1 : 0));
+    if (cap > 0 && grid > cap && (vmask == 0 || ((vmask >> var) & 1))) grid = cap;
+  }
   L2S_LAUNCH((wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>), dim3(grid), dim3(64 * WGM * WGN), lds, st, tab, pre, ws);
   if (any_split) {
     const float* wsc = ws;

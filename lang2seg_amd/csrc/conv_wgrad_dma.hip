@@ -417,6 +417,9 @@ int wgrad_row3_dma_launch(const l2s_wgrad_prob* tab_dev, const l2s_wgrad_prob* t
   plan.U = U;
   if (U < 1) return L2S_OK;
   if ((long)G > U) G = (int)U;
+  // few tiles (layer2's 128-channel 3x3 problems: 12 tiles of 147 slices): every workgroup leaves up to two 192-KiB slabs for the second
+  // launch to add, so at least 24 slices of work per workgroup (a multiple of 8 workgroups: the XCD-aware order)
+  if (U / 24 < G) { G = (int)(U / 24) & ~7; if (G < 8) G = U < 8 ? (int)U : 8; }
   // XCD-lockstep plan: with the contiguous ranges above, the workgroups of an XCD work on DIFFERENT slices of their tiles at any moment, so
   // every operand slab comes through the fabric once per workgroup (1.25 GB per launch at ~10 TB/s: 118 us, as long as the MFMAs).  If
   // the tiles form groups (problem, filter row) of T tiles that share their dY / X slabs 4 ways, an XCD's G / 8 workgroups take ONE
