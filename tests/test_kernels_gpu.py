@@ -136,6 +136,48 @@ def test_conv_dma_tile(cfg, ALGO_DMA):
     assert torch.equal(y2, y3)
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(n=256, H=7, W=7, Cin=512, Cout=2048),     # layer4 1x1-out on the RoIs: 784 tiles of 8 slices on 256 persistent workgroups (3 - 4 tiles each)
+    dict(n=256, H=7, W=7, Cin=1024, Cout=2048),    # layer4[0].downsample: 16 slices
+    dict(n=37, H=7, W=7, Cin=192, Cout=392),       # ragged pixel tile (M = 1813), ragged channel tile, 3 slices: 32 tiles on 32 workgroups (one each)
+    dict(n=75, H=7, W=7, Cin=256, Cout=1048),      # 15 x 9 = 135 tiles on 136 workgroups: one workgroup without a tile
+    dict(n=5, H=3, W=3, Cin=192, Cout=64),         # a single tile
+])
+def test_conv_persistent_dma_tile(cfg):
+    """L2S_ALGO_PDMA (the LDS-DMA 256x128 tile as one persistent workgroup per CU that walks its tiles, the requests running ahead
+    across tile boundaries, per-wave epilogues) against torch on the same rounded bf16 operands and BIT FOR BIT against the one-shot
+    LDS-DMA tile (same slices in the same order): bias + residual + ReLU epilogue, and the data-gradient form (ReLU mask, no bias)."""
+    O = ops()
+    dt = 1
+    g = torch.Generator().manual_seed(12)
+    n, H, W, Cin, Cout = [cfg[x] for x in ['n', 'H', 'W', 'Cin', 'Cout']]
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(n, Cout, H, W, generator=g)
+    xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
+    xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
+    conv = F.conv2d(xr, wr, None)
+    M = n * H * W
+    ys = {}
+    for algo in (7, 2):
+        y = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+        O.conv_igemm(xd, wd, y, n, H, W, Cin, H, W, Cout, 1, 1, 1, 0, bias=b.to(DEV), add=rd, relu=True, algo=algo)
+        y2 = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+        O.conv_igemm(xd, wd, y2, n, H, W, Cin, H, W, Cout, 1, 1, 1, 0, ref=rd, algo=algo)
+        torch.cuda.synchronize()
+        ys[algo] = (y, y2)
+    y, y2 = ys[7]
+    assert rel_err(y.float().view(n, H, W, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
+    assert rel_err(y2.float().view(n, H, W, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
+    assert torch.equal(y, ys[2][0]) and torch.equal(y2, ys[2][1])
+    y3 = torch.empty_like(y2)
+    for _ in range(3):
+        O.conv_igemm(xd, wd, y3, n, H, W, Cin, H, W, Cout, 1, 1, 1, 0, ref=rd, algo=7)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3)
+
+
 @pytest.mark.parametrize('cfg', [dict(H=38, W=63, C=1024, R=256, N1=512, N2=2048), dict(H=20, W=26, C=1024, R=37, N1=512, N2=2048),
                                  dict(H=10, W=14, C=256, R=5, N1=128, N2=256)])
 def test_roialign_fused_into_layer4_block0(cfg):

@@ -62,8 +62,9 @@ def main():
         dw = torch.zeros(Cout, k * k * Cin, device='cuda')
         bias = torch.randn(Cout, device='cuda')
         flop = 2.0 * M * Cout * k * k * Cin
-        tf = timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=bias, add=y, relu=True, tile=tile, xcd_mode=xm))
-        td = timeit(lambda: O.conv_igemm(dy, wt, dx, n, OH, OW, Cout, H, W, Cin, k, k, 1, k - 1 - p, ref=x, tile=tile, xcd_mode=xm))
+        algo = int(sys.argv[3]) if len(sys.argv) > 3 else None
+        tf = timeit(lambda: O.conv_igemm(x, w, y, n, H, W, Cin, OH, OW, Cout, k, k, s, p, bias=bias, add=y, relu=True, tile=tile, xcd_mode=xm, algo=algo))
+        td = timeit(lambda: O.conv_igemm(dy, wt, dx, n, OH, OW, Cout, H, W, Cin, k, k, 1, k - 1 - p, ref=x, tile=tile, xcd_mode=xm, algo=algo))
         ws = torch.empty(64 << 18, device='cuda')
         tw = timeit(lambda: O.conv_wgrad(dy, x, dw, n, H, W, Cin, OH, OW, Cout, k, k, s, p, ws=ws))
         print('%-14s %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f' % (name, tf * 1e6, td * 1e6, tw * 1e6, flop / tf / 1e12, flop / td / 1e12, flop / tw / 1e12))
