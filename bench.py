@@ -56,8 +56,9 @@ def parse_args(argv=None):
     ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
     ap.add_argument('--main-prio', type=int, default=0, help='run the main queue on a high-priority HIP stream instead of the null stream')
     ap.add_argument('--force-dp', type=int, default=0, help='(testing) build the data-parallel reducer even for one rank')
-    ap.add_argument('--dp-wire', default='fp32', choices=['fp32', 'bf16'], help='gradient buckets on the wire: fp32 (282 MB / step) or packed to bf16 (141 MB)')
-    ap.add_argument('--dp-algo', default='allreduce', choices=['allreduce', 'rs_ag'], help='one all-reduce per bucket, or reduce-scatter + all-gather')
+    ap.add_argument('--dp-wire', default='', choices=['', 'fp32', 'bf16'], help='gradient buckets on the wire: fp32 (282 MB / step) or packed to bf16 (141 MB); default: bf16 for N > 1')
+    ap.add_argument('--dp-algo', default='', choices=['', 'allreduce', 'rs_ag'], help='one all-reduce per bucket, or reduce-scatter + all-gather; default: rs_ag for N > 1')
+    ap.add_argument('--dp-shard-update', type=int, default=-1, help='with rs_ag: every rank updates only its slice of a bucket and the WEIGHTS are all-gathered; default: on for N > 1')
     ap.add_argument('--mixed-shapes', type=int, default=1, help='extra leg: a stream of six different (image size, token count) shapes replayed from pre-recorded tapes')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
@@ -128,10 +129,43 @@ def _baseline_metric():
         return 'train images/sec (cycle loss on), 600×1000 input, at 1/2/4/8 MI355X'
 
 
+PROFILE_ROUND = 'r04'
+
+
+def src_hash():
+    """sha256[:16] over the kernel sources + the build flags: figures taken from a committed profile are only reported while the library they
+    were measured on is the one being benchmarked (tools/prof_step.sh writes the same hash next to the profile)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'lang2seg_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    try:
+        sys.path.insert(0, ROOT)
+        from __graft_entry__ import HIPCC_FLAGS
+        h.update(' '.join(HIPCC_FLAGS).encode())
+    except Exception:
+        pass
+    return h.hexdigest()[:16]
+
+
+def _profile_meta():
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', '%s_step_kernel_stats.meta.json' % PROFILE_ROUND)))
+    except Exception:
+        return None
+
+
+def _profile_is_current():
+    m = _profile_meta()
+    return bool(m) and m.get('src_hash') == src_hash()
+
+
 def _pmc_traffic(which):
     """PMC counters cannot be read inside the timed run; the committed same-round measurement of the same launch is reported
-    (tools/pmc_traffic.sh -> profiles/r03_pmc_traffic_<which>.json)."""
-    for name in ('r03_pmc_traffic_%s.json' % which,):
+    (tools/pmc_traffic.sh -> profiles/<round>_pmc_traffic_<which>.json; round 3's where this round has none: the kernels it names did not change)."""
+    for name in ('%s_pmc_traffic_%s.json' % (PROFILE_ROUND, which), 'r03_pmc_traffic_%s.json' % which):
         f = os.path.join(ROOT, 'profiles', name)
         try:
             d = json.load(open(f))
@@ -145,7 +179,9 @@ def _rocprof_avgs(names):
     """average in-step kernel durations (us) of the given kernel templates from the committed rocprofv3 summary of the same command
     (tools/prof_step.sh -> profiles/r03_step_kernel_stats.csv): execution time only, without the wait for a free slot that the
     HIP-event figures include"""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_step_kernel_stats.csv')
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '%s_step_kernel_stats.csv' % PROFILE_ROUND)
+    if not _profile_is_current():
+        return None                                    # the committed profile was taken on another build of the kernels: not this run's numbers
     out = {}
     try:
         import csv
@@ -183,7 +219,8 @@ def _rocprof_group(counts, gflop):
     ms = sum(n * avg[k] for k, n in counts.items()) * 1e-3
     ach = gflop / ms                                   # GFLOP per ms = TFLOP/s
     return {'launches': counts, 'ms_per_step': ms, 'achieved': ach, 'frac': ach / (PEAK_BF16 / 1e12), 'unit': 'TFLOP/s',
-            'note': 'execution time only (profiles/r03_step_kernel_stats.csv); the HIP-event figure above also contains the wait for free CU slots'}
+            'profile': 'profiles/%s_step_kernel_stats.csv' % PROFILE_ROUND, 'profile_src_hash': (_profile_meta() or {}).get('src_hash'),
+            'note': 'execution time only (rocprofv3 --kernel-trace of the same command on the same kernel sources); the HIP-event figure also contains the wait for free CU slots'}
 
 
 class LaunchTimer(object):
@@ -194,6 +231,7 @@ class LaunchTimer(object):
         self.torch, self.on, self.recs = torch, False, []
         from lang2seg_amd import ops
         self.O = ops
+        ops.TRACK_PLAN = True
         self.plans = {}               # group -> kernel names the dispatcher chose (l2s_conv_plan_name)
         self.tape_pairs = []          # (id0, id1) timing events the launch tape records around the dominant launch in every replayed step
         self.tape_all = False         # measurement tape: timing events around EVERY convolution / grouped weight-gradient launch
@@ -380,9 +418,16 @@ def main(argv=None):
     net.use_tape = bool(args.tape)          # N > 1: the tape is cut at the gradient-bucket hand-offs (Network.tape_step)
     net.knockout = frozenset(x for x in args.knockout.split(',') if x)
     experiment = bool(net.knockout) or bool(args.dp_skip_allreduce)
+    dp_desc = 'dp%d' % world
     if use_dp and args.dp_skip_allreduce != 3:
         from lang2seg_amd.parallel import GradReducer
-        net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce, wire=args.dp_wire, algo=args.dp_algo, timing=True)
+        # N > 1 defaults (round 4): bf16 buckets, reduce-scatter + all-gather (direct exchanges over all seven xGMI links), sharded update
+        dp_wire = args.dp_wire or ('bf16' if world > 1 else 'fp32')
+        dp_algo = args.dp_algo or ('rs_ag' if world > 1 else 'allreduce')
+        dp_shard = (args.dp_shard_update if args.dp_shard_update >= 0 else int(world > 1)) and dp_algo == 'rs_ag'
+        net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce, wire=dp_wire, algo=dp_algo, timing=True, rank=rank,
+                             shard_update=True if dp_shard else None)
+        dp_desc = 'dp%d (%s buckets, %s%s)' % (world, dp_wire, dp_algo, ', sharded update' if dp_shard else '')
     if args.defer >= 0:
         SGD.defer = bool(args.defer)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
@@ -531,13 +576,15 @@ def main(argv=None):
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'train_cycle.sh step: ResNet-101 C4 + 7 spatial dynamic filters + att2in2 cycle loss, %dx%d image, '
                                    '20-token expression (V=3349), 12000->2000 proposals, 256 RoIs, per-GPU batch 1' % (args.height, args.width),
-                       'parallelism': 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12,
+                       'parallelism': dp_desc if use_dp else 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12,
                        'weights': 'random (reference initialisers; trunk BN gains scaled so activations stay O(1)), fixed seed',
                        'timed': 'K pipelined train steps (launch tape), losses read back once after the region'},
             'step_tflops_per_gpu': STEP_FLOP / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': STEP_FLOP / (ms * 1e-3) / PEAK_BF16,
             'final_losses': [float(x) for x in lv[:7]],
         }
         out.update(extras)
+        if 'sync_train_step' in extras:
+            out['sync_train_step_value'] = extras['sync_train_step']['value']      # Network.train_step as the reference calls it (seven floats read back per step)
         if args.lib:
             out['lib'] = 'A/B run with ' + args.lib
         if experiment:
@@ -566,17 +613,22 @@ def main(argv=None):
             if dom:
                 g = tab[dom]
                 per_launch_ms = g['ms_per_step'] / g['launches_per_step']
+                rp = _rocprof_group(getattr(lt, 'group_kernel_counts', {}).get(dom), g['gflop_per_step'])
+                # `achieved` / `frac`: the group's FLOPs over its EXECUTION time (launches x the committed rocprofv3 average of each kernel
+                # template, reproducible from profiles/); `achieved_in_step` / `frac_in_step`: over the HIP-event time inside the pipelined
+                # step, which also holds the wait for free CU slots.  Without a profile of this build of the kernels both are the event figure.
                 out['roofline'] = {
                     'bound': 'mfma', 'kernel': '%s: %d launches per step of %s' % (dom, round(g['launches_per_step']), ' / '.join(g['kernels'])),
-                    'achieved': g['tflops'], 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': g['frac'],
+                    'achieved': rp['achieved'] if rp else g['tflops'], 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': rp['frac'] if rp else g['frac'],
+                    'achieved_in_step': g['tflops'], 'frac_in_step': g['frac'], 'frac_source': 'rocprofv3 execution time (profiles/)' if rp else 'HIP events inside the step',
                     'launches_per_step': g['launches_per_step'], 'ms_per_step': g['ms_per_step'], 'gflop_per_step': g['gflop_per_step'],
                     'avg_launch_ms': per_launch_ms, 'rocprof_avg_launch_us': _rocprof_avgs(g['kernels']), 'traffic': dt_,
-                    'rocprof': _rocprof_group(getattr(lt, 'group_kernel_counts', {}).get(dom), g['gflop_per_step']),
+                    'rocprof': rp,
                     'traffic_note': (tnote % (dfile, dalg)) + '; measured on the group\'s 3x3 launch (%s)' % dkern,
                     'timing': ('summed algorithmic FLOPs / summed HIP-event time of the group\'s launches; the events are on the launch tape, right before and after '
                                'each launch on the stream it goes to, read after pipelined replayed steps (a second tape recorded after the timed region: the '
                                'headline tape carries no per-launch events).  An interval includes the wait for free CU slots behind the other streams\' '
-                               'workgroups; rocprof_avg_launch_us = execution time alone, from profiles/r03_step_kernel_stats.csv') if lt.tape_ms else
+                               'workgroups; rocprof_avg_launch_us = execution time alone, from profiles/%s_step_kernel_stats.csv' % PROFILE_ROUND) if lt.tape_ms else
                               ('summed algorithmic FLOPs / summed HIP-event time of the group\'s launches in %d eager multi-stream steps' % NE),
                     'best': best, 'stack3x3': stack, 'groups': tab,
                 }

@@ -445,6 +445,12 @@ int l2s_tape_destroy(void* tape);
  * -1 = none) multiplies the gradient per output row (folded frozen-BN scale). */
 typedef struct { long offset; long count; int row_len; int weight_decay; long rowscale_off; float lr_mult;
                  int chunk0; /* running count of ceil(count / l2s_sgd_chunk()) over the table's earlier segments (any common origin) */ } l2s_sgd_seg;
+/* the same update restricted to the elements [lo, hi) of the flat buffer: a rank's shard of a gradient bucket (data parallel, reduce-scatter
+ * -> sharded update -> all-gather of the weights).  [chunk_lo, chunk_hi): the work chunks of the table that can hold such elements, numbered from the
+ * table's first chunk (chunk_hi < 0: to the end).  flags: 1 = zero the gradients consumed, 2 = only rewrite the shadow from the parameters. */
+int l2s_sgd_momentum_range(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+                           float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int flags,
+                           long lo, long hi, int chunk_lo, int chunk_hi, hipStream_t s);
 int l2s_sgd_chunk(void);          /* elements of one work chunk of the update kernel */
 int l2s_sgd_blocks(int blocks);   /* tools: persistent workgroups of the update (<= 0: query); returns the value in force */
 int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,

@@ -532,31 +532,39 @@ __device__ __forceinline__ void sgd_elem(float g, float& w, float& m, float rs, 
   m = momentum * m + gg;
   w = w - llr * m;
 }
+// flags: 1 = zero the gradient as it is read; 2 = only rewrite the dtype shadow from the parameters (no update: after an all-gather of
+// weights other ranks updated).  [lo, hi): only elements at these offsets of the flat buffer are touched (a rank's shard of a gradient
+// bucket); [chunk_lo, chunk_hi): the chunks of the table that can hold them (numbered from the table's first chunk).
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ mom,
                                                   const l2s_sgd_seg* __restrict__ segs, int nseg, const float* __restrict__ rowscale,
-                                                  float lr, float momentum, float wd, float gscale, void* shadow, int sdt, int clear) {
+                                                  float lr, float momentum, float wd, float gscale, void* shadow, int sdt, int flags,
+                                                  long lo, long hi, int chunk_lo, int chunk_hi) {
+  const bool clear = flags & 1, shadow_only = flags & 2;
   const int c0 = segs[0].chunk0;
-  const int total = segs[nseg - 1].chunk0 - c0 + (int)((segs[nseg - 1].count + SGD_CHUNK - 1) / SGD_CHUNK);
-  for (int c = blockIdx.x; c < total; c += gridDim.x) {
-    int lo = 0, hi = nseg - 1;
-    while (lo < hi) {                                   // the segment that holds chunk c (uniform: scalar loads)
-      const int mid = (lo + hi + 1) >> 1;
-      if (segs[mid].chunk0 - c0 <= c) lo = mid; else hi = mid - 1;
+  int total = segs[nseg - 1].chunk0 - c0 + (int)((segs[nseg - 1].count + SGD_CHUNK - 1) / SGD_CHUNK);
+  if (chunk_hi >= 0 && chunk_hi < total) total = chunk_hi;
+  for (int c = (chunk_lo > 0 ? chunk_lo : 0) + blockIdx.x; c < total; c += gridDim.x) {
+    int slo = 0, shi = nseg - 1;
+    while (slo < shi) {                                 // the segment that holds chunk c (uniform: scalar loads)
+      const int mid = (slo + shi + 1) >> 1;
+      if (segs[mid].chunk0 - c0 <= c) slo = mid; else shi = mid - 1;
     }
-    const l2s_sgd_seg sg = segs[lo];
+    const l2s_sgd_seg sg = segs[slo];
     const long base = (long)(c - (sg.chunk0 - c0)) * SGD_CHUNK;
     const int n = (int)((sg.count - base) < SGD_CHUNK ? (sg.count - base) : SGD_CHUNK);
     const float lwd = sg.weight_decay ? wd : 0.f;
     const float llr = lr * sg.lr_mult;
-    const bool vec = ((sg.offset & 3) == 0) && (sg.rowscale_off < 0 || (sg.row_len & 3) == 0);
-    const int nv = vec ? (n >> 2) : 0;
     const long o0 = sg.offset + base;
+    const bool inside = o0 >= lo && o0 + n <= hi;       // (a chunk that the range cuts goes element by element)
+    const bool vec = inside && ((sg.offset & 3) == 0) && (sg.rowscale_off < 0 || (sg.row_len & 3) == 0);
+    const int nv = vec ? (n >> 2) : 0;
     float4 g4[4], w4[4], m4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int v = threadIdx.x + j * 256;
       if (v < nv) {
-        g4[j] = *(const float4*)(grad + o0 + 4 * v); w4[j] = *(const float4*)(param + o0 + 4 * v); m4[j] = *(const float4*)(mom + o0 + 4 * v);
+        w4[j] = *(const float4*)(param + o0 + 4 * v);
+        if (!shadow_only) { g4[j] = *(const float4*)(grad + o0 + 4 * v); m4[j] = *(const float4*)(mom + o0 + 4 * v); }
       }
     }
 #pragma unroll
@@ -565,12 +573,15 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
       if (v >= nv) continue;
       const long o = o0 + 4 * v;
       const float rs = sg.rowscale_off >= 0 ? rowscale[sg.rowscale_off + (unsigned)(base + 4 * v) / (unsigned)sg.row_len] : 1.f;
-      float gg[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w}, ww[4] = {w4[j].x, w4[j].y, w4[j].z, w4[j].w}, mm[4] = {m4[j].x, m4[j].y, m4[j].z, m4[j].w};
+      float ww[4] = {w4[j].x, w4[j].y, w4[j].z, w4[j].w};
+      if (!shadow_only) {
+        float gg[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w}, mm[4] = {m4[j].x, m4[j].y, m4[j].z, m4[j].w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) sgd_elem(gg[e], ww[e], mm[e], rs, gscale, lwd, momentum, llr);
-      *(float4*)(mom + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-      *(float4*)(param + o) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-      if (clear) *(float4*)(grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = 0; e < 4; ++e) sgd_elem(gg[e], ww[e], mm[e], rs, gscale, lwd, momentum, llr);
+        *(float4*)(mom + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *(float4*)(param + o) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+        if (clear) *(float4*)(grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (shadow) {
         if (sdt) {
           uint2 pk; pk.x = (uint32_t)f2bf(ww[0] * rs) | ((uint32_t)f2bf(ww[1] * rs) << 16); pk.y = (uint32_t)f2bf(ww[2] * rs) | ((uint32_t)f2bf(ww[3] * rs) << 16);
@@ -580,11 +591,15 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
     }
     for (int i = (nv << 2) + threadIdx.x; i < n; i += 256) {
       const long o = o0 + i;
+      if (o < lo || o >= hi) continue;
       const float rs = sg.rowscale_off >= 0 ? rowscale[sg.rowscale_off + (unsigned)(base + i) / (unsigned)sg.row_len] : 1.f;
-      float w = param[o], m = mom[o];
-      sgd_elem(grad[o], w, m, rs, gscale, lwd, momentum, llr);
-      mom[o] = m; param[o] = w;
-      if (clear) grad[o] = 0.f;
+      float w = param[o];
+      if (!shadow_only) {
+        float m = mom[o];
+        sgd_elem(grad[o], w, m, rs, gscale, lwd, momentum, llr);
+        mom[o] = m; param[o] = w;
+        if (clear) grad[o] = 0.f;
+      }
       if (shadow) stx(shadow, o, sdt, w * rs);
     }
   }
@@ -732,6 +747,17 @@ extern "C" int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s
                                 float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int clear_grad, hipStream_t s) {
   if (nseg <= 0) return L2S_OK;
   L2S_LAUNCH(sgd_kernel, dim3(g_sgd_blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype,
-             clear_grad);
+             clear_grad, 0L, (long)1 << 62, 0, -1);
+  return l2s_check_launch();
+}
+extern "C" int l2s_sgd_momentum_range(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+                                      float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int flags,
+                                      long lo, long hi, int chunk_lo, int chunk_hi, hipStream_t s) {
+  if (nseg <= 0 || hi <= lo) return L2S_OK;
+  if (chunk_hi >= 0 && chunk_hi <= chunk_lo) return L2S_OK;
+  int blocks = g_sgd_blocks;
+  if (chunk_hi >= 0 && chunk_hi - chunk_lo < blocks) blocks = chunk_hi - chunk_lo;
+  L2S_LAUNCH(sgd_kernel, dim3(blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype, flags,
+             lo, hi, chunk_lo, chunk_hi);
   return l2s_check_launch();
 }

@@ -61,6 +61,14 @@ __C.TRAIN.SNAPSHOT_ITERS = 5000
 __C.TRAIN.SNAPSHOT_PREFIX = 'res101_mask_rcnn'
 # replay steps from per-shape launch tapes in train_net (see model/train_val.py)
 __C.TRAIN.USE_TAPE = True
+# data parallel: resume from a snapshot that lacks a rank's own sidecar (written by a run with fewer ranks) with freshly seeded loader
+# cursors / RNG streams on that rank instead of refusing (model/train_val.py from_snapshot)
+__C.TRAIN.ALLOW_RESHARD_RESUME = False
+# data parallel (one process per GPU, RCCL over xGMI; parallel.GradReducer): gradient buckets on the wire in bf16 or fp32, one all-reduce per
+# bucket or reduce-scatter + all-gather, and (with rs_ag) each rank updating only its slice of a bucket before the weights are gathered
+__C.TRAIN.DP_WIRE = 'bf16'
+__C.TRAIN.DP_ALGO = 'rs_ag'
+__C.TRAIN.DP_SHARD_UPDATE = True
 # RoIAlign + layer4[0].conv1 + layer4[0].downsample as ONE launch, one workgroup per RoI (l2s_roialign_block0_fwd, bf16): bit-identical to
 # the three launches it replaces and measured slower (170 vs 121 us: every workgroup streams all 5.2 MB of weights), so it is opt-in
 __C.TRAIN.FUSE_ROIALIGN = False

@@ -105,19 +105,31 @@ class SolverWrapper(object):
         print('size partially match:', n_part); print('size not match:', n_miss)
         self.net.load_state_dict(cur)
 
+    def _any_rank(self, flag):
+        """logical OR of `flag` over the ranks of the run (one small all-reduce; the local value in a single-process run)"""
+        import torch.distributed as dist
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return bool(int(t.item()))
+        return bool(flag)
+
     def from_snapshot(self, sfile, nfile):
         print('Restoring model snapshots from {:s}'.format(sfile))
         self.load_matched(torch.load(str(sfile), map_location='cpu'))
+        # data parallel: every rank but 0 has its own sidecar (its shard has its own length, permutation and RNG streams); rank 0's file is the
+        # reference-format one.  A snapshot written by a single-process or a smaller run lacks some of them.  Whether to go on is decided
+        # TOGETHER, before anything else is exchanged: a rank that raised alone would leave the others waiting in their first collective
+        # until the RCCL timeout.
+        own = str(nfile)[:-len('.pkl')] + '.rank{:d}.pkl'.format(self.rank)
+        missing = self.rank != 0 and not os.path.exists(own)
+        if self._any_rank(missing) and not cfg.TRAIN.ALLOW_RESHARD_RESUME:
+            raise ValueError('%s: a rank of this %d-rank run has no sidecar in the snapshot (%s; written by a run with fewer ranks?).  Resuming '
+                             'would replay different data and random streams on that rank than the run that wrote the snapshot; set '
+                             'TRAIN.ALLOW_RESHARD_RESUME True to continue with freshly seeded cursors there.'
+                             % (nfile, self.world, ('missing here: ' + own) if missing else 'present on this rank'))
         if self.rank != 0:
-            # data parallel: this rank's own sidecar (its shard has its own length, permutation and RNG streams); rank 0's
-            # file is the reference-format one.  Without it (a snapshot written by a single-process or a smaller run) only the
-            # iteration number is taken over and the rank keeps its freshly seeded streams and an in-range cursor.
-            own = str(nfile)[:-len('.pkl')] + '.rank{:d}.pkl'.format(self.rank)
-            if not os.path.exists(own):
-                if not getattr(cfg.TRAIN, 'ALLOW_RESHARD_RESUME', False):
-                    raise ValueError('%s: no sidecar for rank %d (snapshot written by a run with fewer ranks?).  Resuming would replay '
-                                     'different data and random streams on this rank than the run that wrote the snapshot; set '
-                                     'TRAIN.ALLOW_RESHARD_RESUME True to continue with freshly seeded cursors.' % (own, self.rank))
+            if missing:
                 with open(nfile, 'rb') as fid:
                     for _ in range(6):
                         pickle.load(fid)

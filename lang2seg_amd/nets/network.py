@@ -457,7 +457,7 @@ class Network(object):
         finally:
             self._rec_key = None
         cap = int(getattr(self, 'max_plan_bytes', 96 << 30))
-        while len(self._eager_keys) > int(getattr(self, 'max_eager_plans', 2)) or (len(self._eager_keys) > 1 and self.plan_bytes() > cap):
+        while len(self._eager_keys) > int(getattr(self, 'max_eager_plans', 8)) or (len(self._eager_keys) > 1 and self.plan_bytes() > cap):
             old, _ = self._eager_keys.popitem(last=False)
             self._drop_plan(old)
         return loss
@@ -484,8 +484,7 @@ class Network(object):
         """drop the least recently used tape and every activation buffer only it was holding (real data: one activation plan per
         image size would otherwise accumulate)"""
         key, (h, st, loss, stages) = self._tapes.popitem(last=False)
-        torch.cuda.synchronize()                                     # the tape's last replay may still be running on the side streams
-        O.tape_destroy(h)
+        O.tape_destroy(h)                                            # (synchronises: the tape's last replay may still be running on the side streams)
         self._drop_plan(key)
 
     def dp_ready(self, stage):
@@ -553,8 +552,8 @@ class Network(object):
         """fp32 workspace for the split-K slabs of a small convolution (csrc/conv_igemm.hip: splitk_factor decides whether and how far
         to split; the slabs are added in slab order by a second launch).  One per stream: the caption branch and the main path run
         split launches at the same time."""
-        if need > self.SPLITK_WS_FLOATS // 2 or self.device == 'cpu':        # only small-M problems are split
-            return None
+        if not getattr(self, 'conv_split_k', False) or need > self.SPLITK_WS_FLOATS // 2 or self.device == 'cpu':
+            return None                                  # (no launch of the step asks for a split: no workspace is allocated; tools set conv_split_k)
         pool = self.__dict__.setdefault('_skws', {})
         key = torch.cuda.current_stream().cuda_stream
         ws = pool.get(key)

@@ -351,6 +351,10 @@ class ParamStore(object):
             return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self.nseg = len(segs)
         self.seg_ends = [int(g.offset + g.count) for g in segs]      # host copy: the optimiser's partial updates split here
+        self.seg_offs = [int(g.offset) for g in segs]
+        self.seg_chunks = [-(-int(g.count) // CH) for g in segs]
+        self.seg_chunk0 = [sum(self.seg_chunks[:i]) for i in range(len(segs))]
+        self.sgd_chunk = CH
         self.seg_size = C.sizeof(SgdSeg)
         self.segs_dev = table(segs)
         # the same segments with the deferred range moved to the end: [0, n_rest) is updated at the end of the step, [n_rest, nseg) behind
@@ -362,6 +366,18 @@ class ParamStore(object):
         self.n_rest = len(rest)
         self.segs_split_dev = table(rest + late)
         return self.nseg
+
+    def chunk_range(self, lo, hi):
+        """[chunk_lo, chunk_hi) of the update kernel's work chunks (segs_dev order) that hold elements of [lo, hi) of the flat buffer"""
+        import bisect
+        s0 = bisect.bisect_right(self.seg_ends, lo)                  # first segment that ends behind lo
+        s1 = bisect.bisect_left(self.seg_offs, hi)                   # first segment that starts at or behind hi
+        if s0 >= s1:
+            return 0, 0
+        c_lo = self.seg_chunk0[s0] + max(0, lo - self.seg_offs[s0]) // self.sgd_chunk
+        last = s1 - 1
+        c_hi = self.seg_chunk0[last] + min(self.seg_chunks[last], -(-(min(hi, self.seg_ends[last]) - self.seg_offs[last]) // self.sgd_chunk))
+        return c_lo, c_hi
 
     def refresh_shadow_full(self):
         """shadow = dtype(rowscale * param) for every trainable tensor (the SGD kernel keeps it current afterwards)."""

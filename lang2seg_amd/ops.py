@@ -102,6 +102,7 @@ def tape_size(h):
 # (bench.py --conv-algo, tools/*bench*.py): same arithmetic, speed only
 CONV_ALGO = 0
 LAST_PLAN = None        # name of the kernel the dispatcher picked for the last conv_igemm call (bench.py's launch timer reads it)
+TRACK_PLAN = False      # set by bench.py's LaunchTimer: the extra ctypes call per launch is measurement only
 
 
 def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, pad=0, bias=None, add=None,
@@ -137,7 +138,8 @@ def conv_igemm(x, w, y, n_img, IH, IW, Cin, OH, OW, Cout, KH=1, KW=1, stride=1, 
     d.prio = prio
     global LAST_PLAN
     dtv = dt_of(x) if dt is None else dt
-    LAST_PLAN = _lib.load().l2s_conv_plan_name(C.byref(d), dtv).decode()
+    if TRACK_PLAN:
+        LAST_PLAN = _lib.load().l2s_conv_plan_name(C.byref(d), dtv).decode()
     call('l2s_conv_igemm', C.byref(d), dtv, stream())
     return y
 
@@ -571,6 +573,12 @@ def logsoftmax_nll(logits, target, mask, S, V1, gscale, loss_slot, dlogits, logp
 def sgd_momentum(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale=1.0, shadow=None, clear_grad=False):
     call('l2s_sgd_momentum', ptr(param), ptr(grad), ptr(mom), ptr(segs_dev), nseg, ptr(rowscale), float(lr), float(momentum),
          float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, 1 if clear_grad else 0, stream())
+
+
+def sgd_momentum_range(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale, shadow, flags, lo, hi, chunk_lo, chunk_hi):
+    """the update on the elements [lo, hi) only (flags: 1 = clear the gradients consumed, 2 = shadow rewrite only)"""
+    call('l2s_sgd_momentum_range', ptr(param), ptr(grad), ptr(mom), ptr(segs_dev), nseg, ptr(rowscale), float(lr), float(momentum),
+         float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, int(flags), int(lo), int(hi), int(chunk_lo), int(chunk_hi), stream())
 
 
 def sgd_chunk():

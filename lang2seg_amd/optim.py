@@ -23,7 +23,10 @@ class SGD(object):
         # keep_grad=False: the update kernel zeroes every gradient it consumes (optimizer.zero_grad(), TV:383, folded in), and
         # forward_backward no longer clears the buffer (it is zero when the network is built, and every update leaves it zero; a second
         # backward pass without an update in between is refused); keep_grad=True leaves the step's gradients in P.grad (tests read them there)
-        self.clear_grad = not keep_grad
+        dp = getattr(net, 'dp', None)
+        if dp is not None and getattr(dp, 'shard_update', None) is True:
+            dp.shard_update = self                   # the reducer calls update_range() on this rank's slice of every bucket
+        self.clear_grad = not keep_grad and getattr(dp, 'shard_update', None) is None   # (a sharded update touches a slice only)
         net.update_clears_grad = self.clear_grad
 
     def zero_grad(self):
@@ -99,6 +102,14 @@ class SGD(object):
         P = self.net.P
         net = self.net
         net._bwd_pending = 0
+        if getattr(getattr(net, 'dp', None), 'shard_update', None) is not None:
+            # the reducer updated this rank's slice of every bucket and gathered the others' (parallel.GradReducer): what is left is the dtype
+            # shadow of the gathered weights and the data-gradient copies
+            if hasattr(net, 'join_wgrad'):
+                net.join_wgrad()
+            self.refresh_shadow()
+            net.refresh_weights()
+            return
         if self.side_active and net.use_streams:
             net.flush_wgrads('final')
             S = net.streams()
@@ -128,6 +139,20 @@ class SGD(object):
         self._launch(self._seg_done, P.nseg)
         self._seg_done = 0
         self.net.refresh_weights()
+
+    # ---- data parallel, sharded update (parallel.GradReducer(shard_update=...)): a rank updates only ITS slice of a reduce-scattered bucket ----
+    def update_range(self, lo, hi):
+        """the update on the elements [lo, hi) of the flat buffer, on the current stream (gradients there are final and summed over ranks)"""
+        P = self.net.P
+        c_lo, c_hi = P.chunk_range(lo, hi)
+        if c_hi > c_lo:
+            O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay, self.grad_scale,
+                                 None, 0, lo, hi, c_lo, c_hi)
+
+    def refresh_shadow(self):
+        """dtype shadow of every tensor from the (gathered) parameters: shadow = dtype(rowscale * param), no update"""
+        P = self.net.P
+        O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, 0.0, 1.0, 0.0, 0.0, P.shadow, 2, 0, P.total, 0, -1)
 
     def state_dict(self):
         return {'lr': self.lr, 'momentum': self.momentum, 'weight_decay': self.weight_decay}

@@ -68,9 +68,17 @@ class GradReducer(object):
     the exposed wait (what the main stream actually stalled for) of the last step."""
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
 
-    def __init__(self, net, world, backend_stream=True, skip_allreduce=0, wire='fp32', algo='allreduce', timing=False):
+    def __init__(self, net, world, backend_stream=True, skip_allreduce=0, wire='fp32', algo='allreduce', timing=False, shard_update=None, rank=None):
         assert wire in ('fp32', 'bf16') and algo in ('allreduce', 'rs_ag')
+        assert shard_update is None or algo == 'rs_ag', 'the sharded update rides on reduce-scatter + all-gather'
         self.net, self.world = net, world
+        # Sharded update (round 4): with algo = 'rs_ag' the all-gather does not have to carry GRADIENTS.  Each rank keeps the slice of the bucket
+        # the reduce-scatter left it with, runs the optimiser on that slice only (`shard_update.update_range(lo, hi)`: fp32 master weights and
+        # momentum of the slice; the 1 / world averaging is the optimiser's grad_scale) and the ranks all-gather the updated WEIGHTS - the
+        # same bytes as gathering fp32 gradients, the update's HBM traffic divided by `world`, and the update of a bucket overlaps with
+        # the rest of the backward pass instead of trailing the step.  Momentum of the other slices is never read on this rank.
+        self.shard_update = shard_update
+        self.rank = rank if rank is not None else (dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0)
         # experiment only (bench.py --dp-skip-allreduce): 1 = keep the stream structure but issue no collective, 2 = do nothing.
         # Ranks diverge with either, so model/train_val.py refuses a reducer built this way.
         self.skip_allreduce = int(skip_allreduce)
@@ -82,6 +90,7 @@ class GradReducer(object):
         self.side = torch.cuda.Stream() if self.on_gpu else None
         self._pack = None            # bf16 staging buffer (whole flat length: buckets are slices of it)
         self._shard = None           # reduce-scatter output (largest bucket / world)
+        self._wshard = None          # this rank's updated weights of a bucket, the all-gather's input
         self._events = []            # (stage, start, end) of the last step
         self._wait_events = None
 
@@ -111,7 +120,47 @@ class GradReducer(object):
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 
+    def _exchange_sharded(self, seg, lo, hi):
+        """bucket [lo, hi): reduce-scatter the gradients, update this rank's slice, all-gather the weights (the < 4 world elements that do not
+        split evenly are all-reduced and updated by every rank)"""
+        W, r, P = self.world, self.rank, self.net.P
+        n = hi - lo
+        if self.wire == 'bf16' and self._pack is None:
+            self._pack = torch.empty(P.total, dtype=torch.bfloat16, device=seg.device)
+        m = n // (4 * W) * (4 * W)                          # slices start at multiples of four elements (the update kernel's vector width)
+        per = m // W
+        if m:
+            if self.wire == 'bf16':
+                src = self._pack[lo:lo + m]
+                self._cast(seg[:m], src)
+            else:
+                src = seg[:m]
+            if self._shard is None or self._shard.numel() < per or self._shard.dtype != src.dtype:
+                big = max(per, (max(self.bounds.values()) + W - 1) // W)
+                self._shard = torch.empty(big, dtype=src.dtype, device=src.device)
+            sh = self._shard[:per]
+            dist.reduce_scatter_tensor(sh, src, op=dist.ReduceOp.SUM)
+            own = seg[r * per:(r + 1) * per]
+            self._cast(sh, own) if self.wire == 'bf16' else own.copy_(sh)
+            self.shard_update.update_range(lo + r * per, lo + (r + 1) * per)
+            wsl = P.param[lo:lo + m]
+            if self._wshard is None or self._wshard.numel() < per:
+                self._wshard = torch.empty(max(per, (max(self.bounds.values()) + W - 1) // W), dtype=P.param.dtype, device=P.param.device)
+            mine = self._wshard[:per]
+            mine.copy_(wsl[r * per:(r + 1) * per])
+            dist.all_gather_into_tensor(wsl, mine)
+        if m < n:
+            tail = seg[m:]
+            if self.wire == 'bf16':
+                tb = self._pack[lo + m:hi]
+                self._cast(tail, tb); dist.all_reduce(tb, op=dist.ReduceOp.SUM); self._cast(tb, tail)
+            else:
+                dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+            self.shard_update.update_range(lo + m, hi)
+
     def _exchange(self, seg, lo, hi):
+        if self.shard_update is not None:
+            return self._exchange_sharded(seg, lo, hi)
         if self.wire == 'bf16':
             if self._pack is None:
                 self._pack = torch.empty(self.net.P.total, dtype=torch.bfloat16, device=seg.device)

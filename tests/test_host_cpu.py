@@ -173,6 +173,40 @@ def _dp_worker(rank, world, port, ret):
         lst = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(lst, chk)
         ok = ok and all(torch.equal(lst[0], x) for x in lst)
+    # sharded update (round 4): reduce-scatter -> every rank runs the optimiser on ITS slice of the bucket -> all-gather of the WEIGHTS.
+    # The optimiser here is SGD with momentum in torch (the HIP kernel's arithmetic, element by element); afterwards every rank must hold the
+    # same weights, equal to the unsharded update of the summed gradients (fp32 wire: to fp32 rounding of the sum; bf16 wire: 2^-8 of it),
+    # and its own slices' momentum must be the full update's.
+    class TorchSGD(object):
+        def __init__(self, P, lr, mu, scale):
+            self.P, self.lr, self.mu, self.scale, self.ranges = P, lr, mu, scale, []
+        def update_range(self, lo, hi):
+            P = self.P
+            g = P.grad[lo:hi] * self.scale
+            P.mom[lo:hi] = self.mu * P.mom[lo:hi] + g
+            P.param[lo:hi] -= self.lr * P.mom[lo:hi]
+            self.ranges.append((lo, hi))
+    w0 = torch.randn(P.total, generator=torch.Generator().manual_seed(7))
+    m0 = torch.randn(P.total, generator=torch.Generator().manual_seed(8))
+    want_g = sum(others) * (1.0 / world)
+    want_m = 0.9 * m0 + want_g
+    want_w = w0 - 0.1 * want_m
+    for wire, tol in (('fp32', 1e-6), ('bf16', 3e-2)):
+        P.grad.copy_(mine); P.param.copy_(w0); P.mom.copy_(m0)
+        upd = TorchSGD(P, 0.1, 0.9, 1.0 / world)
+        red = GradReducer(net, world, wire=wire, algo='rs_ag', shard_update=upd, rank=rank)
+        for st in ['caption', 'heads', 'language', 'layer3:16', 'layer3:8', 'layer3', 'layer2']:
+            red.ready(st)
+        red.finish()
+        scale = float(want_g.abs().max())
+        ok = ok and torch.allclose(P.param, want_w, atol=0.1 * tol * scale + 1e-6)
+        covered = sum(h - l for l, h in upd.ranges)
+        ok = ok and covered < P.total * 0.51 + 64 * world                 # this rank updated about 1 / world of the elements (+ the bucket tails)
+        for l, h in upd.ranges:
+            ok = ok and torch.allclose(P.mom[l:h], want_m[l:h], atol=tol * scale + 1e-6)
+        lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(lst, P.param.double().sum().reshape(1).clone())
+        ok = ok and all(torch.equal(lst[0], x) for x in lst)              # every rank holds the same weights, bit for bit
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -454,17 +488,41 @@ def _resume_worker(rank, world, port, outdir, ret):
     ok = ok and np.random.rand() == expect_next
     for _ in range(7):                                      # keeps walking its own shard without running past its end
         ld2.getBatch('train', 1)
+    from lang2seg_amd.model.config import cfg_from_list
+    pre = os.path.join(outdir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_8')
+    # (a) rank 1's sidecar is missing (a snapshot written by a one-rank run): the refusal is decided TOGETHER - every rank raises, nobody is
+    # left waiting in a collective - unless TRAIN.ALLOW_RESHARD_RESUME (a declared key: settable from a config file / the command line)
+    dist.barrier()
     if rank == 1:
-        # a snapshot written by another world size must be refused, not silently mis-indexed
-        os.replace(os.path.join(outdir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_8.pkl'), os.path.join(outdir, 'tmp.pkl'))
+        os.replace(pre + '.rank1.pkl', pre + '.rank1.hidden')
+    dist.barrier()
+    try:
+        sw2.from_snapshot(sfiles[-1], nfiles[-1]); ok = False
+    except ValueError as e:
+        ok = ok and 'ALLOW_RESHARD_RESUME' in str(e)
+    cfg_from_list(['TRAIN.ALLOW_RESHARD_RESUME', 'True'])
+    try:
+        ok = ok and sw2.from_snapshot(sfiles[-1], nfiles[-1]) == 8
+    finally:
+        cfg_from_list(['TRAIN.ALLOW_RESHARD_RESUME', 'False'])
+    dist.barrier()
+    if rank == 1:
+        os.replace(pre + '.rank1.hidden', pre + '.rank1.pkl')
+    # (b) a sidecar whose permutation does not fit this rank's shard (written with another world size) must be refused on that rank,
+    # not silently mis-indexed (rank 0's own file is fine: it resumes)
+    if rank == 1:
         import shutil
-        shutil.copy(os.path.join(outdir, 'tmp.pkl'), os.path.join(outdir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_8.rank1.pkl'))
-        os.replace(os.path.join(outdir, 'tmp.pkl'), os.path.join(outdir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_8.pkl'))
-        try:
-            sw2.from_snapshot(sfiles[-1], nfiles[-1])
-            ok = False
-        except ValueError:
-            pass
+        shutil.copy(pre + '.rank1.pkl', pre + '.rank1.keep')
+        shutil.copy(pre + '.pkl', pre + '.rank1.pkl')
+    dist.barrier()
+    try:
+        sw2.from_snapshot(sfiles[-1], nfiles[-1])
+        ok = ok and rank == 0
+    except ValueError:
+        ok = ok and rank == 1
+    dist.barrier()
+    if rank == 1:
+        os.replace(pre + '.rank1.keep', pre + '.rank1.pkl')
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

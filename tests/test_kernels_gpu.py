@@ -1291,6 +1291,27 @@ def test_sgd_and_misc():
     assert rel_err(md, mref) < 1e-6 and rel_err(pd, pref) < 1e-6
     sref = pref.clone(); sref[n1:n1 + rows * rl] = (sref[n1:n1 + rows * rl].view(rows, rl) * rowscale.view(-1, 1)).view(-1)
     assert rel_err(shadow.float(), sref) < 1e-2
+    # l2s_sgd_momentum_range: the update cut into two "rank" slices at an arbitrary multiple of four elements (+ a tail every rank updates) gives
+    # the single launch's result bit for bit (data parallel, sharded update); flags = 2 rewrites the shadow only
+    from lang2seg_amd._lib import load as _load
+    CH = O.sgd_chunk()
+    offs = [0, n1, n1 + rows * rl]; cnts = [n1, rows * rl, n3]; ch0 = [0, -(-n1 // CH), -(-n1 // CH) + -(-(rows * rl) // CH)]
+    def chunk_range(lo, hi):
+        import bisect
+        ends = [o + c for o, c in zip(offs, cnts)]
+        s0 = bisect.bisect_right(ends, lo); s1 = bisect.bisect_left(offs, hi)
+        if s0 >= s1:
+            return 0, 0
+        return ch0[s0] + max(0, lo - offs[s0]) // CH, ch0[s1 - 1] + -(-(min(hi, ends[s1 - 1]) - offs[s1 - 1]) // CH)
+    p3, g3, m3 = p.to(DEV), gr.to(DEV), m.to(DEV)
+    sh3 = torch.zeros(tot, dtype=torch.bfloat16, device=DEV)
+    cut, tail0 = 1284, tot - 5
+    for lo, hi in ((cut, tail0), (0, cut), (tail0, tot)):
+        c_lo, c_hi = chunk_range(lo, hi)
+        O.sgd_momentum_range(p3, g3, m3, sb, 3, rowscale.to(DEV), 0.01, 0.9, 1e-2, 1.0, None, 0, lo, hi, c_lo, c_hi)
+    O.sgd_momentum_range(p3, g3, m3, sb, 3, rowscale.to(DEV), 0.0, 1.0, 0.0, 0.0, sh3, 2, 0, tot, 0, -1)
+    torch.cuda.synchronize()
+    assert torch.equal(p3, pd) and torch.equal(m3, md) and torch.equal(sh3, shadow) and torch.equal(g3.cpu(), gr)
     # dropout mask statistics + determinism, random keys
     ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
     mk = torch.empty(100000, device=DEV); O.dropout_mask(mk, 0.5, ctr, 42)

@@ -36,6 +36,7 @@ def _setup(dtype, tag='tiny'):
 # d(response)[p] = <dy[p], x[p]>, a 1024-term dot product of bf16 values that nearly cancels); integer outputs still bit-exact (they depend on the boxes, not on the activations, once the
 # proposals are teacher-forced).
 BF16_LOSS_RTOL, BF16_COS, BF16_NORM = 1e-2, 0.99, 0.25
+BF16_NORM_DYN_FULL = 0.10      # dynamic-filter FCs at the BASELINE size (measured <= 0.03)
 VARIANT_TAGS = ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align']
 
 
@@ -75,12 +76,13 @@ def _check_grads(g, net, dtype, rtol_f32, ref_net=None, norm_tol=None):
                 continue
             cos = float((a * b).sum() / (na * nb + 1e-300))
             table[k] = [round(cos, 6), round(nb / na, 6)]
-            # The dynamic-filter FCs keep the loose norm bound at every size: their gradient is sum_p dresp[p] x[:, p] with
-            # dresp[p] = <dy[p], x[p]>, a 1024-term dot product of bf16 values that nearly cancels, and a handful of pixels dominates
-            # the sum - the DIRECTION is theirs (cosine 0.9999), the LENGTH re-rolls with every change of rounding pattern upstream
-            # (round 3: the LDS-DMA / K-split tiles, whose outputs have the same half-ulp error statistics against an fp64 reference as
-            # the tiles they replace, moved dynamic_fc_2 / _3 from 0.97 to 0.88 / 0.92 at full size).
-            ntol = BF16_NORM if (norm_tol is None or k.startswith(('dynamic_fc_', 'response_fc'))) else norm_tol
+            # The dynamic-filter FCs: their gradient is sum_p dresp[p] x[:, p] with dresp[p] = <dy[p], x[p]>, a 1024-term dot product of bf16
+            # values that nearly cancels, and a handful of pixels dominates the sum - the DIRECTION is theirs (cosine 0.9999), the LENGTH
+            # re-rolls with the rounding pattern upstream.  On the tiny fixtures (520 pixels) that is worth up to 20 % (BF16_NORM); at the
+            # BASELINE size (2394 pixels) the committed runs measure <= 2 % (profiles/r03_bf16_grad_agreement.jsonl, r04: <= 3 %), and the
+            # gate there is 10 % for these tensors, `norm_tol` (5 %) for every other one.
+            dyn = k.startswith(('dynamic_fc_', 'response_fc'))
+            ntol = BF16_NORM if norm_tol is None else (max(norm_tol, BF16_NORM_DYN_FULL) if dyn else norm_tol)
             if not (cos >= BF16_COS and abs(nb / na - 1.0) <= ntol):
                 bad.append((k, cos, nb / na))
     _log_grad_table(g, dtype, table)
@@ -415,6 +417,41 @@ def test_dp_tape_segments_match_eager():
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)
     # all-reduced gradients of the last step (fp32 atomics: order noise only)
     assert rel(res[0][1], res[1][1]) < 1e-3 and rel(res[0][2], res[1][2]) < 1e-3
+
+
+def test_dp_sharded_update_matches_plain_update():
+    """parallel.GradReducer(algo='rs_ag', shard_update=...) on ONE rank of a real RCCL process group: reduce-scatter, the update of this rank's
+    slice of every bucket on the reducer's stream (l2s_sgd_momentum_range), all-gather of the weights, shadow rewrite - the weights and the
+    momentum after four steps are those of the plain single-launch update, bit for bit (world 1: the slice is the bucket), eager and from
+    the segmented tape.  (Two ranks: tests/test_host_cpu.py::test_grad_reducer_gloo_world2.)"""
+    import tempfile
+    import torch.distributed as dist
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from lang2seg_amd.parallel import GradReducer
+    from oracle import weights as OW, synth as OS
+    if not dist.is_initialized():
+        f = tempfile.NamedTemporaryFile(delete=False); f.close()
+        dist.init_process_group('nccl', init_method='file://' + f.name, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    blob = OS.make_blob(320, 416, 6, 60, seed=5)
+    over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
+    out = {}
+    for mode in ('plain', 'sharded', 'sharded+tape'):
+        net = selftest.build_net(opt, over, 'bf16', sd)
+        net.use_tape = mode.endswith('tape')
+        if mode != 'plain':
+            net.dp = GradReducer(net, 1, wire='fp32', algo='rs_ag', shard_update=True, rank=0)
+        sgd = SGD(net, 1e-3, momentum=0.9, weight_decay=1e-4)
+        assert (net.dp is None) or net.dp.shard_update is sgd
+        for _ in range(4):
+            net.train_step_async(dict(blob), 0, sgd)
+        torch.cuda.synchronize(); net.join_update(); torch.cuda.synchronize()
+        out[mode] = (net.P.param.clone(), net.P.mom.clone(), net.P.shadow.clone())
+    for mode in ('sharded', 'sharded+tape'):
+        for a, b, nm in zip(out[mode], out['plain'], ('param', 'momentum', 'shadow')):
+            assert torch.equal(a, b), (mode, nm, int((a != b).sum()))
 
 
 def test_early_partial_sgd_matches_single_update():
