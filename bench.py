@@ -45,8 +45,10 @@ def parse_args(argv=None):
     ap.add_argument('--fuse-roialign', type=int, default=0, help='A/B only: 1 = RoIAlign, layer4[0].conv1 and layer4[0].downsample as one launch (cfg.TRAIN.FUSE_ROIALIGN)')
     ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
     ap.add_argument('--sgd-early', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.early on / off (update each finished prefix of the flat buffer during backward; one rank only)')
+    ap.add_argument('--wgrad-overwrite', type=int, default=-1, help='A/B only: 1 / 0 = Network.wgrad_overwrite (first weight-gradient problem of a tensor writes dW; the update skips its clear)')
     ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
     ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
+    ap.add_argument('--wgrad-minm', type=int, default=0, help='A/B only: pixels from which a 3x3 weight gradient takes the LDS-DMA filter-row tile')
     ap.add_argument('--wgrad-wgs', type=int, default=0, help='A/B only: workgroups of the stream-K launch of the LDS-DMA filter-row tile (default 256 = one per CU)')
     ap.add_argument('--wgrad-cap', type=int, default=0, help='A/B only: at most this many workgroups per grouped weight-gradient launch')
     ap.add_argument('--sgd-blocks', type=int, default=0, help='A/B only: persistent workgroups of the update kernel')
@@ -430,9 +432,15 @@ def main(argv=None):
         dp_desc = 'dp%d (%s buckets, %s%s)' % (world, dp_wire, dp_algo, ', sharded update' if dp_shard else '')
     if args.defer >= 0:
         SGD.defer = bool(args.defer)
+    if args.wgrad_overwrite >= 0:
+        from lang2seg_amd.nets.network import Network as _Net
+        _Net.wgrad_overwrite = bool(args.wgrad_overwrite)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
     if args.sgd_early >= 0:
         optim.early = bool(args.sgd_early)
+    if args.wgrad_minm > 0:
+        from lang2seg_amd import _lib as _L4
+        _L4.load().l2s_wgrad_row3_dma(64, args.wgrad_minm)
     if args.wgrad_row3_dma >= 0:
         from lang2seg_amd import _lib as _L3
         _L3.load().l2s_wgrad_row3_dma(args.wgrad_row3_dma, args.wgrad_wgs)

@@ -107,6 +107,8 @@ typedef struct {
   int nseg, Cin, Cout, KH, KW, stride, pad;
   int split;                           /* <= 1: whole tiles; n: the pixels of every segment are cut into n ranges whose partial tiles go to */
   long ws_off;                         /*       n slabs at float offset ws_off of the launch's workspace, summed in order by a second launch */
+  int flags;                           /* 1: dw = gradient (the tensor's first contribution of the step: nothing is read, nothing had to be cleared); */
+  int reserved;                        /*    0: dw += gradient */
 } l2s_wgrad_prob;
 int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile);
 long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW);
@@ -444,7 +446,9 @@ int l2s_tape_destroy(void* tape);
  * seg table (device): per segment {offset, count, rows, wd_flag}; rowscale (optional, per segment offset into a float array,
  * -1 = none) multiplies the gradient per output row (folded frozen-BN scale). */
 typedef struct { long offset; long count; int row_len; int weight_decay; long rowscale_off; float lr_mult;
-                 int chunk0; /* running count of ceil(count / l2s_sgd_chunk()) over the table's earlier segments (any common origin) */ } l2s_sgd_seg;
+                 int chunk0; /* running count of ceil(count / l2s_sgd_chunk()) over the table's earlier segments (any common origin) */
+                 int flags;  /* 1: the gradient is overwritten whole by its producer every step (l2s_wgrad_prob.flags): the update leaves it alone */
+                 int reserved; } l2s_sgd_seg;
 /* the same update restricted to the elements [lo, hi) of the flat buffer: a rank's shard of a gradient bucket (data parallel, reduce-scatter
  * -> sharded update -> all-gather of the weights).  [chunk_lo, chunk_hi): the work chunks of the table that can hold such elements, numbered from the
  * table's first chunk (chunk_hi < 0: to the end).  flags: 1 = zero the gradients consumed, 2 = only rewrite the shadow from the parameters. */

@@ -36,7 +36,7 @@ class WgradProb(C.Structure):
     _fields_ = [('dy', vp * 2), ('x', vp * 2), ('n_img', i32 * 2), ('IH', i32 * 2), ('IW', i32 * 2), ('OH', i32 * 2), ('OW', i32 * 2),
                 ('lddy', i32 * 2), ('ldx', i32 * 2), ('dw', vp),
                 ('nseg', i32), ('Cin', i32), ('Cout', i32), ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
-                ('split', i32), ('ws_off', i64)]
+                ('split', i32), ('ws_off', i64), ('flags', i32), ('reserved', i32)]
 
 
 class TransposeDesc(C.Structure):
@@ -53,7 +53,7 @@ class LstmBwdDir(C.Structure):
 
 class SgdSeg(C.Structure):
     _fields_ = [('offset', i64), ('count', i64), ('row_len', i32), ('weight_decay', i32), ('rowscale_off', i64),
-                ('lr_mult', f32), ('chunk0', i32)]
+                ('lr_mult', f32), ('chunk0', i32), ('flags', i32), ('reserved', i32)]
 
 
 CONV_RELU, CONV_OUT_F32, CONV_DECONV2X2, CONV_SCATTER = 1, 4, 8, 16

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512) void wgrad_row3_dma_kernel(const wgp* __restri
           float4 v = make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
           if (full) {
             float4* q = (float4*)(p.dw + (long)(co0 + col) * Kw + (long)(ky * 3 + t) * p.Cin + ci0 + cil);
-            const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            if (!(p.flags & 1)) { const float4 o = *q; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             *q = v;
           } else {
             *(float4*)(slab + ((long)(t * BM + col) * BN + cil)) = v;
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(256) void wgrad_row3_reduce_kernel(const wgp* __res
     }
     const int f = e * 4, t = f / (BM * BN), col = (f - t * BM * BN) / BN, cil = f % BN;
     float4* q = (float4*)(p.dw + (long)(cot * BM + col) * Kw + (long)(ky * 3 + t) * p.Cin + cit * BN + cil);
-    float4 o = *q; o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-    *q = o;
+    if (!(p.flags & 1)) { const float4 o = *q; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *q = s;
   }
 }
 

@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
     const int n = (int)((sg.count - base) < SGD_CHUNK ? (sg.count - base) : SGD_CHUNK);
     const float lwd = sg.weight_decay ? wd : 0.f;
     const float llr = lr * sg.lr_mult;
+    const bool clr = clear && !(sg.flags & 1);          // (a gradient its producer overwrites whole needs no clear)
     const long o0 = sg.offset + base;
     const bool inside = o0 >= lo && o0 + n <= hi;       // (a chunk that the range cuts goes element by element)
     const bool vec = inside && ((sg.offset & 3) == 0) && (sg.rowscale_off < 0 || (sg.row_len & 3) == 0);
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
         for (int e = 0; e < 4; ++e) sgd_elem(gg[e], ww[e], mm[e], rs, gscale, lwd, momentum, llr);
         *(float4*)(mom + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
         *(float4*)(param + o) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-        if (clear) *(float4*)(grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (clr) *(float4*)(grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (shadow) {
         if (sdt) {
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
         float m = mom[o];
         sgd_elem(grad[o], w, m, rs, gscale, lwd, momentum, llr);
         mom[o] = m; param[o] = w;
-        if (clear) grad[o] = 0.f;
+        if (clr) grad[o] = 0.f;
       }
       if (shadow) stx(shadow, o, sdt, w * rs);
     }

@@ -147,6 +147,9 @@ class WgradQueue(object):
                 v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, stride, pad, int(same), M, 256 if net.dt == BF16 else 0))   # (256: the 8-wave 256x256 tile may be chosen)
                 rounds.setdefault((r // 2, v), []).append(seg)
         bkp = 32 if net.dt == BF16 else 16
+        # a tensor's first problem of the step WRITES its gradient (l2s_wgrad_prob.flags = 1: no read of dW, and the update need not clear it,
+        # ParamStore.mark_overwritten); later contributions (a third use) add.  Network._fresh: the tensors written so far in this backward pass.
+        fresh = getattr(net, '_fresh', None) if getattr(net, 'wgrad_overwrite', False) else None
         with net.fork_wgrad(fixed='wg'):
             ws = net.wgrad_ws()
             for (rnd, v) in sorted(rounds):
@@ -166,6 +169,10 @@ class WgradQueue(object):
                         dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
                         q = arr[i]
                         q.dw, q.nseg, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad = dw.data_ptr(), len(seg), Cin, Cout, k, k, stride, pad
+                        q.flags = 0
+                        if fresh is not None and rnd == 0 and dw.data_ptr() not in fresh and dw.numel() == Cout * k * k * Cin:
+                            q.flags = 1
+                            fresh.add(dw.data_ptr())
                         slices = min(u[3] * u[7] * (u[8] + (1 if v in (2, 3, 5) else 0)) // bkp for u in seg)
                         split = max(1, min(want, slices // 16, 16))
                         if v == 5:
@@ -621,6 +628,7 @@ class Network(object):
 
     update_on_wg = False
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
+    wgrad_overwrite = True       # grouped weight gradients write (instead of add to) a tensor's gradient at its first problem of the step
     update_clears_grad = False   # optim.SGD(keep_grad=False): the update zeroes the gradients it consumes; forward_backward does not clear
     SLOT_UPDATE_REST = 0     # event slot (csrc/tape.hip): the first part of the update (everything outside ParamStore.defer_range) is done
 

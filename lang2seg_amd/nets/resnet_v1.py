@@ -581,6 +581,7 @@ class resnetv1(Network):
         self._mark('step start')
         main = torch.cuda.current_stream()
         S = self.streams() if self.use_streams else None
+        self._fresh = set()                                 # gradients written (not added to) by this pass's grouped weight gradients
         if self.update_clears_grad:
             # optimizer.zero_grad() (TV:383) is folded into the update kernel: the buffer is zero here unless a backward pass went by without an update
             if backward:

@@ -98,6 +98,13 @@ class SGD(object):
     # by this call, and every reader outside the step (state_dict, TEST mode, snapshots) joins the whole weight-gradient stream.
     defer = False   # measured (round 4, same-box A/B x3): 180.7 img/s with it, 184.1 without - see DESIGN.md section 4.6
 
+    def _mark_overwritten(self):
+        # gradients the grouped weight gradients of this step wrote whole are not cleared by the update (ParamStore.mark_overwritten).
+        # Only where the update runs once, behind every weight gradient: not with early partial updates or the deferred heads stage.
+        net = self.net
+        if self.clear_grad and not self._early and not self.defer_active and getattr(net, 'wgrad_overwrite', False):
+            net.P.mark_overwritten(getattr(net, '_fresh', ()))
+
     def step(self):
         P = self.net.P
         net = self.net
@@ -112,6 +119,7 @@ class SGD(object):
             return
         if self.side_active and net.use_streams:
             net.flush_wgrads('final')
+            self._mark_overwritten()
             S = net.streams()
             for k in ('wg2', 'lang', 'cap'):
                 net.sfork(S[k], S['wg'])
@@ -136,6 +144,7 @@ class SGD(object):
             self.net.join_wgrad()                   # weight-gradient stream -> current stream
         if self._seg_done:
             self.net.sfork(self.net.streams()['tr'], torch.cuda.current_stream())
+        self._mark_overwritten()
         self._launch(self._seg_done, P.nseg)
         self._seg_done = 0
         self.net.refresh_weights()

@@ -694,6 +694,56 @@ def test_pipelined_tape_training_matches_eager_training():
     assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
 
 
+def _grad_outside_overwritten(P):
+    """P.grad with the segments zeroed whose gradients the grouped weight gradients overwrite every step (l2s_sgd_seg.flags = 1: the update
+    does not clear those, ParamStore.mark_overwritten)"""
+    g = P.grad.clone()
+    for sg in P._seg_tables[0]:
+        if sg.flags & 1:
+            g[int(sg.offset):int(sg.offset + sg.count)] = 0
+    return g
+
+
+def test_wgrad_overwrite_bit_identical():
+    """Network.wgrad_overwrite (a tensor's first grouped weight-gradient problem of the step writes dW instead of adding to it, and the update
+    leaves those gradients uncleared): K pipelined steps give the same weights and momentum, bit for bit, as K steps that add into cleared
+    gradients; the convolution weights are the overwritten ones, everything else is still cleared by the update.
+    Semantics matched: optimizer.zero_grad() + backward() + step() (train_val_cycle.py:383-386)."""
+    from lang2seg_amd import selftest
+    from lang2seg_amd.optim import SGD
+    from lang2seg_amd.nets.network import Network
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0)
+    over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
+    blobs = [OS.make_blob(320, 416, 6, 60, seed=5), OS.make_blob(320, 416, 6, 60, seed=6)]
+    out = {}
+    for ow in (False, True):
+        for tape in (False, True):
+            net = selftest.build_net(opt, over, 'bf16', sd)
+            net.wgrad_overwrite = ow
+            net.use_tape = tape
+            sgd = SGD(net, 1e-3, momentum=0.9, weight_decay=1e-4)
+            for i in range(6):
+                net.train_step_async(dict(blobs[i % 2]), 0, sgd)
+            torch.cuda.synchronize()
+            net.join_update()
+            torch.cuda.synchronize()
+            flagged = [sg for sg in net.P._seg_tables[0] if sg.flags & 1]
+            assert bool(flagged) == ow
+            if ow:
+                names = {k for k in net.P.trainable if any(net.P.offsets[k] == int(sg.offset) for sg in flagged)}
+                assert names and all(k.endswith('.weight') for k in names) and any('layer4' in k for k in names) and any('layer2' in k for k in names)
+                assert any(float(net.P.grad[int(sg.offset):int(sg.offset + sg.count)].abs().max()) > 0 for sg in flagged)
+            assert float(_grad_outside_overwritten(net.P).abs().max()) == 0.0
+            out[(ow, tape)] = (net.P.param.clone(), net.P.mom.clone())
+    p0, m0 = out[(False, False)]
+    assert bool(torch.isfinite(p0).all()) and float(m0.abs().max()) > 0
+    for key, (p, m) in out.items():
+        assert torch.equal(p, p0), (key, int((p != p0).sum()))
+        assert torch.equal(m, m0), (key, int((m != m0).sum()))
+
+
 @pytest.mark.parametrize('variant', ['cycle', 'vgg'])
 def test_deferred_heads_bit_identical(variant):
     """optim.SGD.defer (the heads stage's grouped weight-gradient launches and their part of the update run BEHIND the rest of the update,
@@ -728,7 +778,7 @@ def test_deferred_heads_bit_identical(variant):
                 torch.cuda.synchronize()
                 net.join_update()
                 torch.cuda.synchronize()
-                out[(defer, tape)] = (net.P.param.clone(), net.P.mom.clone(), mid, net.P.grad.clone())
+                out[(defer, tape)] = (net.P.param.clone(), net.P.mom.clone(), mid, _grad_outside_overwritten(net.P))
     finally:
         SGD.defer = was
     p0, m0, mid0, g0 = out[(False, False)]

@@ -16,12 +16,15 @@ def main():
     ap.add_argument('--only', default='', help='substring of the stage names to run')
     ap.add_argument('--wgs', type=int, default=0, help='workgroups of its stream-K launch')
     ap.add_argument('--check', type=int, default=0, help='1: compare the layer4 3x3 weight gradients of the two filter-row kernels')
+    ap.add_argument('--minm', type=int, default=0, help='pixels from which a 3x3 problem takes the LDS-DMA filter-row tile')
     ap.add_argument('--min-wg', type=int, default=0, help='WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
     args = ap.parse_args()
     if args.lib:
         from lang2seg_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args.lib)
     from lang2seg_amd import ops as O, _lib as L_
+    if args.minm:
+        L_.load().l2s_wgrad_row3_dma(64, args.minm)
     if args.plan >= 0:
         L_.load().l2s_wgrad_row3_dma(32 + args.plan, 0)
     if args.form >= 0:
