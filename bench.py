@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
     ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
     ap.add_argument('--wgrad-minm', type=int, default=0, help='A/B only: pixels from which a 3x3 weight gradient takes the LDS-DMA filter-row tile')
+    ap.add_argument('--wgrad-wide', type=int, default=-1, help='A/B only: 1 / 0 = 3x3 problems with 512+ channels take the LDS-DMA filter-row tile at any pixel count')
     ap.add_argument('--wgrad-wgs', type=int, default=0, help='A/B only: workgroups of the stream-K launch of the LDS-DMA filter-row tile (default 256 = one per CU)')
     ap.add_argument('--wgrad-cap', type=int, default=0, help='A/B only: at most this many workgroups per grouped weight-gradient launch')
     ap.add_argument('--sgd-blocks', type=int, default=0, help='A/B only: persistent workgroups of the update kernel')
@@ -438,6 +439,9 @@ def main(argv=None):
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
     if args.sgd_early >= 0:
         optim.early = bool(args.sgd_early)
+    if args.wgrad_wide >= 0:
+        from lang2seg_amd import _lib as _L5
+        _L5.load().l2s_wgrad_row3_dma(65, args.wgrad_wide)
     if args.wgrad_minm > 0:
         from lang2seg_amd import _lib as _L4
         _L4.load().l2s_wgrad_row3_dma(64, args.wgrad_minm)

@@ -358,11 +358,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 int g_wgrad_row3_dma_wgs = 128;   // workgroups of the stream-K launch: half the CUs (a workgroup owns its CU - 132 KB of LDS, 240 VGPRs x 8 waves -
                                   // and the other queues' launches need somewhere to run: 96 / 128 / 160 / 256 -> 190.1 / 189.1 / 189.0 / 185.5 img/s, same box x 3)
 int g_wgrad_row3_dma = 1;   // tools: 0 sends the large 3x3 problems back to the register-staged filter-row tile (A/B)
+int g_wgrad_row3_wide = 1;         // 512+ channels on both sides (RPN's 3x3 on the map): the tile from any pixel count (its stream-K launch needs no pixel split)
 int g_wgrad_row3_min_m = 8192;     // pixels from which a 3x3 problem takes the LDS-DMA filter-row tile
 int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   const bool row3 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
   const bool big = M >= 8192 && Cout >= 512 && Cin >= 512;
-  if (row3 && tile == 256 && g_wgrad_row3_dma && M >= g_wgrad_row3_min_m && Cout % 128 == 0 && Cin % 128 == 0) return 5;
+  if (row3 && tile == 256 && g_wgrad_row3_dma && (M >= g_wgrad_row3_min_m || (g_wgrad_row3_wide && Cin >= 512 && Cout >= 512)) && Cout % 128 == 0 && Cin % 128 == 0) return 5;
   if (row3) return (tile == 128 || ((!tile || tile == 256) && Cout >= 512)) ? 3 : 2;
   if (tile == 256 && big && KH * KW == 1 && Cout % 256 == 0 && Cin % 256 == 0) return 4;
   return (tile == 128 || ((!tile || tile == 256) && big && KH * KW == 1)) ? 1 : 0;
@@ -445,6 +446,7 @@ bool prob_ok(const wgp& p, int dtype) {
 }  // namespace
 
 extern "C" int l2s_wgrad_row3_dma(int on, int wgs) {
+  if (on == 65) { g_wgrad_row3_wide = wgs; return wgs; }
   if (on == 64) { if (wgs > 0) g_wgrad_row3_min_m = wgs; return g_wgrad_row3_min_m; }   // tools: 64, m = pixel threshold of the tile
   if (on >= 32) { l2s::g_row3_plan_mode = on - 32; return g_wgrad_row3_dma; } // tools: 32 / 33 = contiguous stream-K ranges always / XCD-lockstep plan where it applies
   if (on >= 16) { l2s::g_row3_form = on - 16; return g_wgrad_row3_dma; }      // tools: 16 + mask = knock-outs of the kernel

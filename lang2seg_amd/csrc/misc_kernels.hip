@@ -741,7 +741,11 @@ extern "C" int l2s_random_keys(uint32_t* keys, long n, const uint64_t* seed_dev,
   L2S_LAUNCH(keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, keys, n, seed_dev, salt);
   return l2s_check_launch();
 }
-static int g_sgd_blocks = 512;   // persistent workgroups of the update (two per CU)
+// persistent workgroups of the update: one per CU.  The update is HBM-bound either way (1.2 GB in ~0.3 ms); what the count decides is how
+// deep the memory queues stand for everybody else: with 512 workgroups (25 MB of requests in flight) the next step's stem ended 475 us into the
+// step and layer1 at 697 us; with 256 at 287 / 567 us while the update itself got no slower (409 against 430 us).  64 / 96 / 128 / 192 / 256 / 320 /
+// 384 / 512 -> -- / 185.2 / 189.4 / 193.6 / 194.5 / 194.4 / 193.4 / 191.6 img/s, same box (profiles/r04_sgd_blocks.txt)
+static int g_sgd_blocks = 256;
 extern "C" int l2s_sgd_blocks(int blocks) { if (blocks > 0) g_sgd_blocks = blocks; return g_sgd_blocks; }
 extern "C" int l2s_sgd_chunk(void) { return SGD_CHUNK; }
 extern "C" int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,

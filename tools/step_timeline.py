@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--sgd-early', type=int, default=-1)
     ap.add_argument('--defer', type=int, default=-1, help='1 / 0 = optim.SGD.defer on / off')
     ap.add_argument('--wgrad-cap', type=int, default=0)
+    ap.add_argument('--sgd-blocks', type=int, default=0, help='persistent workgroups of the update kernel')
     args = ap.parse_args()
     if args.lib:
         from lang2seg_amd import _lib
@@ -43,6 +44,9 @@ def main():
     if args.wgrad_cap > 0:
         from lang2seg_amd import _lib as _L2
         _L2.load().l2s_wgrad_grid_cap(args.wgrad_cap)
+    if args.sgd_blocks > 0:
+        from lang2seg_amd import ops as _O
+        _O.sgd_blocks(args.sgd_blocks)
     if args.defer >= 0:
         SGD.defer = bool(args.defer)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY)
