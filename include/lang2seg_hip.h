@@ -137,6 +137,13 @@ int l2s_colsum(const void* a, int rows, int cols, int lda, float* out, float* ws
 /* stem: conv 7x7 s2 p3 (3->64) + frozen-BN affine + ReLU (RES:121-124), input float NHWC; then maxpool k3 s2 p1 (RES:126) */
 int l2s_stem_conv(const float* img, const float* w /*[64][7][7][3]*/, const float* scale, const float* bias,
                   void* y, int H, int W, int OH, int OW, int dtype, hipStream_t s);
+/* bf16 mode: the same stem AND the pooling behind it in one launch on the matrix cores (stem_mfma.hip): image as two bf16 terms (16
+ * significant bits), weights rounded to bf16 in the fragment order l2s_stem_pack() writes (l2s_stem_pack_bytes() bytes; repack whenever
+ * conv1's weights change), f32 accumulation / affine / ReLU, one rounding to bf16, pooled output y [PH*PW][64] bf16. */
+size_t l2s_stem_pack_bytes(void);
+int l2s_stem_pack(const float* w /*[64][7][7][3]*/, void* pack, hipStream_t s);
+int l2s_stem_pool_bf16(const float* img, const void* pack, const float* scale, const float* bias, void* y, int H, int W,
+                       int OH, int OW, int PH, int PW, hipStream_t s);
 /* VGG16 variant (nets/vgg16.py:43-54, network_vgg.py:139-143): conv1_1 (3 -> 64, 3x3, pad 1, bias, ReLU) on the fp32 NHWC image with
  * weights [64][3][3][3]; 2x2 / stride-2 max pooling (floor mode) forward / backward over n_img NHWC maps [IH][IW][C] (also the
  * 14x14 -> 7x7 pool behind the crop-pool).  relu_out != 0: x is a ReLU output, dx is the gradient of its pre-activation. */

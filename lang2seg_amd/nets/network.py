@@ -628,6 +628,7 @@ class Network(object):
 
     update_on_wg = False
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
+    stem_mfma = True             # bf16 mode: stem + pooling as one launch on the matrix cores (stem_mfma.hip); False: the f32 stem + pooling launches
     wgrad_overwrite = True       # grouped weight gradients write (instead of add to) a tensor's gradient at its first problem of the step
     update_clears_grad = False   # optim.SGD(keep_grad=False): the update zeroes the gradients it consumes; forward_backward does not clear
     SLOT_UPDATE_REST = 0     # event slot (csrc/tape.hip): the first part of the update (everything outside ParamStore.defer_range) is done

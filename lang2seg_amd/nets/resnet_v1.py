@@ -403,12 +403,18 @@ class resnetv1(Network):
         P = self.P
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
         OH1, OW1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        c1 = self.buf('stem.c1', (OH1 * OW1, 64))
-        O.stem_conv(d['data'], P.frozen['resnet.conv1.weight'], P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'],
-                    c1, H, W, OH1, OW1)
         h, w = (OH1 + 2 - 3) // 2 + 1, (OW1 + 2 - 3) // 2 + 1
         x = self.buf('stem.pool', (h * w, 64))
-        O.maxpool(c1, x, OH1, OW1, 64, h, w)
+        w1 = P.frozen['resnet.conv1.weight']
+        if self.dt == BF16 and self.stem_mfma:
+            # conv + affine + ReLU + pooling in one launch on the matrix cores (stem_mfma.hip); the weights in fragment order, repacked when they change
+            if getattr(self, '_stem_pack_ver', None) != (w1.data_ptr(), w1._version):
+                self._stem_pack, self._stem_pack_ver = O.stem_pack(w1, getattr(self, '_stem_pack', None)), (w1.data_ptr(), w1._version)
+            O.stem_pool_bf16(d['data'], self._stem_pack, P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'], x, H, W, OH1, OW1, h, w)
+        else:
+            c1 = self.buf('stem.c1', (OH1 * OW1, 64))
+            O.stem_conv(d['data'], w1, P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'], c1, H, W, OH1, OW1)
+            O.maxpool(c1, x, OH1, OW1, 64, h, w)
         self._mark('stem')
         for li in (1, 2, 3):
             if li == cfg.RESNET.FIXED_BLOCKS + 1:

@@ -203,6 +203,18 @@ def colsum(a, rows, cols, lda, out, ws=None):
     call('l2s_colsum', ptr(a), rows, cols, lda, ptr(out), ptr(ws), 0 if ws is None else ws.numel(), dt_of(a), stream())
 
 
+def stem_pack(w, pack=None):
+    """conv1's weights [64][7][7][3] f32 -> the bf16 fragment order of l2s_stem_pool_bf16 (into `pack` when given: recorded tapes hold its address)"""
+    if pack is None:
+        pack = torch.empty(int(_lib.load().l2s_stem_pack_bytes()), dtype=torch.uint8, device=w.device)
+    call('l2s_stem_pack', ptr(w), ptr(pack), stream())
+    return pack
+
+
+def stem_pool_bf16(img, pack, scale, bias, y, H, W, OH, OW, PH, PW):
+    call('l2s_stem_pool_bf16', ptr(img), ptr(pack), ptr(scale), ptr(bias), ptr(y), H, W, OH, OW, PH, PW, stream())
+
+
 def stem_conv(img, w, scale, bias, y, H, W, OH, OW):
     call('l2s_stem_conv', ptr(img), ptr(w), ptr(scale), ptr(bias), ptr(y), H, W, OH, OW, dt_of(y), stream())
 

@@ -17,6 +17,7 @@ DEV = 'cuda'
 
 def ops():
     from lang2seg_amd import ops as O
+    O.TRACK_PLAN = True            # ops.LAST_PLAN: the plan name of the last convolution launch (off outside tests / bench timers)
     return O
 
 
@@ -529,6 +530,42 @@ def test_stem_maxpool(dt):
     refp = F.max_pool2d(y.float().cpu().view(1, OH, OW, 64).permute(0, 3, 1, 2), 3, 2, 1)
     torch.cuda.synchronize()
     assert rel_err(yp.float().view(1, PH, PW, 64), nhwc(refp)) < 1e-6
+
+
+@pytest.mark.parametrize('hw', [(600, 1000), (37, 53), (64, 64), (7, 250), (131, 9)])
+def test_stem_pool_mfma(hw):
+    """l2s_stem_pool_bf16 (stem + frozen-BN affine + ReLU + 3x3/2 pooling on the matrix cores, one launch; resnet_v1.py:121-126) against
+    torch in f32 with the SAME bf16-rounded weights (what differs then is the image's 16-bit split and the summation order: far below the
+    output's bf16 rounding), against f32 weights (the bf16 mode's weight rounding on top), and against the two-launch path it replaces."""
+    O = ops()
+    H, W = hw
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(1, H, W, 3, generator=g) * 60 + 10
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.02
+    sc = torch.rand(64, generator=g) + 0.5; bi = torch.randn(64, generator=g) * 0.3
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (OH + 2 - 3) // 2 + 1, (OW + 2 - 3) // 2 + 1
+    wd = ohwi(w).to(DEV)
+    pack = O.stem_pack(wd)
+    yp = torch.full((PH * PW, 64), float('nan'), device=DEV).bfloat16()
+    O.stem_pool_bf16(img.to(DEV), pack, sc.to(DEV), bi.to(DEV), yp, H, W, OH, OW, PH, PW)
+    torch.cuda.synchronize()
+    def ref(wt):
+        c = F.relu(F.conv2d(img.double().permute(0, 3, 1, 2), wt.double(), None, stride=2, padding=3) * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1))
+        return nhwc(F.max_pool2d(c, 3, 2, 1)).float()
+    got = yp.float().view(1, PH, PW, 64)
+    assert bool(torch.isfinite(got).all())
+    r_same = ref(w.bfloat16().float())
+    assert rel_err(got, r_same.bfloat16().float()) < 4e-3          # one bf16 ulp where the f32 sums straddle a rounding boundary
+    assert float(((got.cpu() - r_same).abs() / (r_same.abs() + 1.0)).mean()) < 2e-3
+    assert rel_err(got, ref(w)) < 1e-2                              # the bf16 mode's weight rounding
+    # the two-launch path (f32 weights, bf16 output)
+    y = O.empty((OH * OW, 64), 1)
+    O.stem_conv(img.to(DEV), wd, sc.to(DEV), bi.to(DEV), y, H, W, OH, OW)
+    y2 = O.empty((PH * PW, 64), 1)
+    O.maxpool(y, y2, OH, OW, 64, PH, PW)
+    torch.cuda.synchronize()
+    assert rel_err(got, y2.float().view(1, PH, PW, 64)) < 1e-2
 
 
 @pytest.mark.parametrize('dt', [0, 1])
