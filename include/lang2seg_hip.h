@@ -128,7 +128,8 @@ int l2s_weight_cast(const float* src, const float* scale, void* dst, int Cout, i
 int l2s_weight_transpose(const float* src, const float* scale, void* dst, int Cout, int taps, int Cin, int dtype, hipStream_t s);
 /* all data-gradient copies of one step in one launch: table (DEVICE memory) of n descriptors; total_tiles = sum over the descriptors of
  * ceil(Cin / 64) * ceil(Cout / 64) * taps (the launch walks one flat tile index) */
-typedef struct { const float* src; const float* scale; void* dst; int Cout, taps, Cin, force_f32; } l2s_transpose_desc;
+typedef struct { const float* src; const float* scale; void* dst; int Cout, taps, Cin;
+                 int force_f32; /* bit 0: dst is f32 whatever the launch's dtype; bit 1: src points at bf16 values (the shadow: scale = NULL) */ } l2s_transpose_desc;
 int l2s_weight_transpose_batched(const l2s_transpose_desc* table_dev, int n, int total_tiles, int dtype, hipStream_t s);
 /* column sums: out[c] += sum_r a[r][c] (bias gradients), no atomics; ws (nullable, 32*cols floats): partial sums of the row ranges a tall
  * matrix is cut into, added in order by a second launch */

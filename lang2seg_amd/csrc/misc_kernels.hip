@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const l2s
       tci = (d.Cin + 63) / 64; tco = (d.Cout + 63) / 64; ntiles = tci * tco * d.taps;
     }
     const int t = tt - base;
-    const int dt = d.force_f32 ? L2S_F32 : dt_in;
+    const int dt = (d.force_f32 & 1) ? L2S_F32 : dt_in;
+    const bool src16 = d.force_f32 & 2;                  // src is the bf16 shadow (already scaled): half the bytes of the f32 master
     const bool vec_in = (d.Cin & 3) == 0, vec_out = (d.Cout & 7) == 0;
     const int tap = t / (tci * tco), rem = t - tap * (tci * tco);
     const int co0 = (rem / tci) * 64, ci0 = (rem % tci) * 64;
@@ -80,6 +81,11 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const l2s
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (co < d.Cout) {
           const float* sp = d.src + ((long)co * d.taps + tap) * d.Cin + ci;
+          if (src16) {
+            const bf16_t* hp = (const bf16_t*)d.src + ((long)co * d.taps + tap) * d.Cin + ci;
+            if (vec_in && ci + 3 < d.Cin) { const uint2 u = *(const uint2*)hp; v = make_float4(bf2f(u.x & 0xffffu), bf2f(u.x >> 16), bf2f(u.y & 0xffffu), bf2f(u.y >> 16)); }
+            else { if (ci < d.Cin) v.x = bf2f(hp[0]); if (ci + 1 < d.Cin) v.y = bf2f(hp[1]); if (ci + 2 < d.Cin) v.z = bf2f(hp[2]); if (ci + 3 < d.Cin) v.w = bf2f(hp[3]); }
+          } else
           if (vec_in && ci + 3 < d.Cin) v = *(const float4*)sp;
           else { if (ci < d.Cin) v.x = sp[0]; if (ci + 1 < d.Cin) v.y = sp[1]; if (ci + 2 < d.Cin) v.z = sp[2]; if (ci + 3 < d.Cin) v.w = sp[3]; }
           if (d.scale) { const float sc = d.scale[co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }

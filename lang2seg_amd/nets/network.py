@@ -612,6 +612,9 @@ class Network(object):
             for i, c in enumerate(items):
                 arr[i].src, arr[i].scale, arr[i].dst = c.w_master.data_ptr(), (c.scale.data_ptr() if c.scale is not None else None), c.wb.data_ptr()
                 arr[i].Cout, arr[i].taps, arr[i].Cin, arr[i].force_f32 = c.Np, c.k * c.k, c.Cin, int(getattr(c, 'force_f32', 0))
+                if self.dt == BF16 and isinstance(c, ConvOp) and c.trainable and not arr[i].force_f32:
+                    # the bf16 shadow the update kernel keeps current holds the same values (bf16(scale * w)): half the bytes to read
+                    arr[i].src, arr[i].scale, arr[i].force_f32 = c.wf.data_ptr(), None, 2
             self._tr_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             self._tr_n = len(items)
             self._tr_tiles = sum(((c.Cin + 63) // 64) * ((c.Np + 63) // 64) * c.k * c.k for c in items)
@@ -628,6 +631,7 @@ class Network(object):
 
     update_on_wg = False
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
+    join_before_layer1 = False   # A/B: the frozen layer1 also waits for the previous step's update (it then runs alone instead of beside it)
     stem_mfma = True             # bf16 mode: stem + pooling as one launch on the matrix cores (stem_mfma.hip); False: the f32 stem + pooling launches
     wgrad_overwrite = True       # grouped weight gradients write (instead of add to) a tensor's gradient at its first problem of the step
     update_clears_grad = False   # optim.SGD(keep_grad=False): the update zeroes the gradients it consumes; forward_backward does not clear

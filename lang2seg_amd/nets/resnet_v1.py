@@ -417,7 +417,7 @@ class resnetv1(Network):
             O.maxpool(c1, x, OH1, OW1, 64, h, w)
         self._mark('stem')
         for li in (1, 2, 3):
-            if li == cfg.RESNET.FIXED_BLOCKS + 1:
+            if li == (1 if self.join_before_layer1 else cfg.RESNET.FIXED_BLOCKS + 1):
                 self.join_update(full=False)                   # first trainable layer: the previous step's update (of the backbone) must have landed
                 self._mark('layer1 done, update joined')
             for b, blk in enumerate(self.layers[li]):

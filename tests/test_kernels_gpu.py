@@ -532,6 +532,42 @@ def test_stem_maxpool(dt):
     assert rel_err(yp.float().view(1, PH, PW, 64), nhwc(refp)) < 1e-6
 
 
+def test_weight_transpose_batched_from_shadow():
+    """l2s_weight_transpose_batched: the data-gradient copies [Cin][taps flipped][Cout] of several layers in one launch, read from the f32
+    master (* scale) and - bf16 mode, trainable layers - from the bf16 shadow the update keeps current (l2s_transpose_desc.force_f32 bit 1):
+    bit-identical outputs, equal to a torch permute of the rounded weights."""
+    import ctypes as C
+    from lang2seg_amd._lib import TransposeDesc
+    O = ops()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(512, 9, 512), (72, 1, 256), (2048, 1, 512), (256, 9, 64), (24, 1, 516)]
+    keep, tabs = [], {}
+    for mode in ('master', 'shadow'):
+        arr = (TransposeDesc * len(shapes))()
+        outs = []
+        gg = torch.Generator().manual_seed(9)
+        for i, (Cout, taps, Cin) in enumerate(shapes):
+            w = (torch.randn(Cout, taps, Cin, generator=gg) * 0.1).to(DEV)
+            sc = (torch.rand(Cout, generator=gg) + 0.5).to(DEV)
+            sh = (w * sc.view(-1, 1, 1)).bfloat16().contiguous()
+            dst = torch.full((Cin, taps, Cout), float('nan'), device=DEV).bfloat16()
+            keep += [w, sc, sh, dst]
+            if mode == 'master':
+                arr[i].src, arr[i].scale, arr[i].force_f32 = w.data_ptr(), sc.data_ptr(), 0
+            else:
+                arr[i].src, arr[i].scale, arr[i].force_f32 = sh.data_ptr(), None, 2
+            arr[i].dst, arr[i].Cout, arr[i].taps, arr[i].Cin = dst.data_ptr(), Cout, taps, Cin
+            outs.append((dst, sh))
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+        tiles = sum(((Cin + 63) // 64) * ((Cout + 63) // 64) * taps for (Cout, taps, Cin) in shapes)
+        O.weight_transpose_batched(tab, len(shapes), tiles, 1)
+        torch.cuda.synchronize()
+        tabs[mode] = outs
+    for (a, sh), (b, _) in zip(tabs['master'], tabs['shadow']):
+        ref = sh.flip(1).permute(2, 1, 0).contiguous()
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+
+
 @pytest.mark.parametrize('hw', [(600, 1000), (37, 53), (64, 64), (7, 250), (131, 9)])
 def test_stem_pool_mfma(hw):
     """l2s_stem_pool_bf16 (stem + frozen-BN affine + ReLU + 3x3/2 pooling on the matrix cores, one launch; resnet_v1.py:121-126) against

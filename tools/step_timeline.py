@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--sgd-early', type=int, default=-1)
     ap.add_argument('--defer', type=int, default=-1, help='1 / 0 = optim.SGD.defer on / off')
     ap.add_argument('--wgrad-cap', type=int, default=0)
+    ap.add_argument('--stem-mfma', type=int, default=-1)
     ap.add_argument('--sgd-blocks', type=int, default=0, help='persistent workgroups of the update kernel')
     args = ap.parse_args()
     if args.lib:
@@ -39,6 +40,8 @@ def main():
                fc_feat_size=4096, att_feat_size=4096, att_hid_size=512)
     np.random.seed(cfg.RNG_SEED)
     net = resnetv1(opt, batch_size=1, num_layers=101)
+    if args.stem_mfma >= 0:
+        net.stem_mfma = bool(args.stem_mfma)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()
     if args.wgrad_cap > 0:
