@@ -631,6 +631,7 @@ class Network(object):
 
     update_on_wg = False
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
+    rpn_bwd_early = True         # RPN losses + the RPN's own backward on the language stream beside the proposal chain (False: on the main stream behind the RoI head's backward)
     join_before_layer1 = False   # A/B: the frozen layer1 also waits for the previous step's update (it then runs alone instead of beside it)
     stem_mfma = True             # bf16 mode: stem + pooling as one launch on the matrix cores (stem_mfma.hip); False: the f32 stem + pooling launches
     wgrad_overwrite = True       # grouped weight gradients write (instead of add to) a tensor's gradient at its first problem of the step

@@ -779,6 +779,22 @@ class resnetv1(Network):
             O.anchor_target(d['gt_boxes'], n_gt, self.base_anchors, Hc, Wc, A, 16, im_h, im_w, self._keys('rpn_fg_keys', nA),
                             self._keys('rpn_bg_keys', nA), TR.RPN_NEGATIVE_OVERLAP, TR.RPN_POSITIVE_OVERLAP, int(TR.RPN_BATCHSIZE),
                             TR.RPN_FG_FRACTION, rl, rt, ri, ro, aws)
+            # ... and so do the RPN losses and the RPN's own backward pass (NET:375-390): nothing of them depends on the proposals, the proposal
+            # chain keeps ONE compute unit busy for 0.3 ms, and at the end of the window these four launches were 0.11 ms of the main path
+            d_rheads = self.buf('rpn.dheads', (HW, NPR))
+            d_nc_rpn = self.buf('rpn.dnc', (HW, C4))
+
+            def rpn_bwd():
+                O.rpn_loss(rheads, NPR, rl, rt, ri, ro, Hc, Wc, A, 3.0, 1.0, loss, d_rheads, NPR, atl_ws=aws)
+                if backward:
+                    self.rpn_heads.wgrad(d_rheads, rpn, 1, Hc, Wc)
+                    drpn = self.buf('rpn.da', (HW, 512))
+                    self.rpn_heads.dgrad(d_rheads, 1, Hc, Wc, drpn, ref=rpn)
+                    self.rpn_conv.wgrad(drpn, net_conv, 1, Hc, Wc)
+                    self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
+                    self._mark('rpn loss + bwd')
+            if self.rpn_bwd_early:
+                rpn_bwd()
         t.update({'rpn_labels': rl, 'rpn_bbox_targets': rt, 'rpn_bbox_inside': ri, 'rpn_bbox_outside': ro})
         rois = self.buf('ptl.rois', (R, 5), f32); labels = self.buf('ptl.labels', (R,), torch.int32)
         bt = self.buf('ptl.bt', (R, 4 * nc), f32); bi = self.buf('ptl.bi', (R, 4 * nc), f32); bo = self.buf('ptl.bo', (R, 4 * nc), f32)
@@ -794,10 +810,11 @@ class resnetv1(Network):
         self._mark('roi head fwd')
         cap_advance()                                         # captioner backward
         # ---- detection losses + head gradients (NET:375-413) ----
-        d_rheads = self.buf('rpn.dheads', (HW, NPR)); d_cheads = self.buf('roi.dheads', (R, NPC)); dscore = self.buf('mask.dscore', (FGM * MS * MS,), f32)
+        d_cheads = self.buf('roi.dheads', (R, NPC)); dscore = self.buf('mask.dscore', (FGM * MS * MS,), f32)
         if S is not None:
-            self.sfork(S['lang'], main)                    # anchor targets
-        O.rpn_loss(rheads, NPR, rl, rt, ri, ro, Hc, Wc, A, 3.0, 1.0, loss, d_rheads, NPR, atl_ws=aws)
+            self.sfork(S['lang'], main)                    # anchor targets, RPN losses, RPN backward
+        if not self.rpn_bwd_early:
+            rpn_bwd()
         O.rcnn_loss(cheads, NPC, labels, bt, bi, bo, R, nc, 1.0, loss, d_cheads, NPC)
         if mscore is not None:
             O.mask_loss(mscore, nc, labels, mt, counts, FGM, MS * MS, 1.0, loss, dscore)
@@ -815,14 +832,7 @@ class resnetv1(Network):
         self._mark('roialign bwd')
         cap_advance(finish=True)                              # layer4 on the map backward
         d_nc_cap, d_base_cap = cap_state['out']
-        # rpn
-        self.rpn_heads.wgrad(d_rheads, rpn, 1, Hc, Wc)
-        drpn = self.buf('rpn.da', (HW, 512))
-        self.rpn_heads.dgrad(d_rheads, 1, Hc, Wc, drpn, ref=rpn)
-        self.rpn_conv.wgrad(drpn, net_conv, 1, Hc, Wc)
-        d_nc_rpn = self.buf('rpn.dnc', (HW, C4))
-        self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
-        self._mark('rpn bwd (main reaches the caption join)')
+        self._mark('main reaches the caption join')
         if S is not None and self.var['cap'] is not None:
             self.sfork(S['cap'], main)                     # join the caption branch
         O.total_loss(loss, self._cap_loss_weight)
