@@ -73,7 +73,7 @@ class ConvOp(object):
     def fwd(self, x, n, IH, IW, y, add=None, relu=False, out_f32=False, tile=0):
         OH, OW = self.out_hw(IH, IW)
         O.conv_igemm(x, self.wf, y, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad,
-                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt, ws=self.net.splitk_ws(n * OH * OW * self.Np), prio=self.prio)
+                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt, ws=self.net.splitk_ws(n * OH * OW * self.Np), prio=max(self.prio, self.net.prio_floor))
         return y
 
     def dgrad(self, g, n, IH, IW, dx, add=None, ref=None):
@@ -81,11 +81,11 @@ class ConvOp(object):
         OH, OW = self.out_hw(IH, IW)
         if self.stride == 1:
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, IH, IW, self.Cin, self.k, self.k, 1, self.k - 1 - self.pad,
-                         add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin), prio=self.prio)
+                         add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin), prio=max(self.prio, self.net.prio_floor))
         else:
             assert self.k == 1
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, OH, OW, self.Cin, 1, 1, 1, 0, add=add, ref=ref,
-                         scatter=(IH, IW, self.stride), dt=self.net.dt, prio=self.prio)
+                         scatter=(IH, IW, self.stride), dt=self.net.dt, prio=max(self.prio, self.net.prio_floor))
         return dx
 
     def wgrad(self, g, x, n, IH, IW):
@@ -631,6 +631,8 @@ class Network(object):
 
     update_on_wg = False
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
+    prio_floor = 0               # wave priority the convolution launches get at least (raised around a latency-bound chain: cap_map_prio)
+    cap_map_prio = 0             # priority of layer4's data-gradient launches on the map (caption stream), beside the RoI head's backward
     rpn_bwd_early = True         # RPN losses + the RPN's own backward on the language stream beside the proposal chain (False: on the main stream behind the RoI head's backward)
     join_before_layer1 = False   # A/B: the frozen layer1 also waits for the previous step's update (it then runs alone instead of beside it)
     stem_mfma = True             # bf16 mode: stem + pooling as one launch on the matrix cores (stem_mfma.hip); False: the f32 stem + pooling launches

@@ -389,6 +389,14 @@ class ParamStore(object):
         torch.cuda.synchronize() if self.grad.is_cuda else None
         self._ow_key = key
 
+    def stale_marked(self, s0, s1, fresh):
+        """gradient pointers of the segments [s0, s1) (segs_dev order) that are marked as overwritten but are NOT in `fresh` (the tensors this
+        backward pass has written so far): a partial update about to consume them would read last step's values (optim.SGD.partial)"""
+        if not self._ow_key:
+            return []
+        base = self.grad.data_ptr()
+        return [base + 4 * o for o in self.seg_offs[s0:s1] if (base + 4 * o) in self._ow_key and (base + 4 * o) not in fresh]
+
     def chunk_range(self, lo, hi):
         """[chunk_lo, chunk_hi) of the update kernel's work chunks (segs_dev order) that hold elements of [lo, hi) of the flat buffer"""
         import bisect

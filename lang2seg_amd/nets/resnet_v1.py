@@ -660,8 +660,10 @@ class resnetv1(Network):
 
         def l4_on_map_bwd(g, tag, in_relu=False):
             # in_relu: the map that was fed in is itself a ReLU output (layer3's), so its gradient is masked here
+            self.prio_floor = self.cap_map_prio
             for b in reversed(range(len(self.layers[4]))):
                 g = self.layers[4][b].bwd(g, saved[(tag, b)], '%s.%d' % (tag, b), x_is_relu_out=(b > 0 or in_relu))
+            self.prio_floor = 0
             return g
 
         def caption_branch():

@@ -18,6 +18,7 @@ class SGD(object):
         self.side_active = bool(self.side and getattr(net, 'use_streams', False) and hasattr(net, 'flush_wgrads'))
         if self.side_active:
             net.update_on_wg = True
+        self._early = bool(type(self)._early and not self.defer)      # (the deferred heads stage, when asked for, excludes the early partial updates)
         self.defer_active = bool(self.defer and self.side_active and not self._early and hasattr(net, 'wgq') and getattr(net, 'dp', None) is None)
         net.defer_heads = self.defer_active
         # keep_grad=False: the update kernel zeroes every gradient it consumes (optimizer.zero_grad(), TV:383, folded in), and
@@ -39,7 +40,10 @@ class SGD(object):
     # Round 1 measured it neutral (122.4 / 123.6 img/s with it vs 123.1 without) - but that form made the MAIN queue wait for the
     # transpose stream at every hand-off, i.e. for the weight-gradient launches the partial update itself waits for.  Since round 3 the
     # hand-off only forks, and whatever is left at the end of the step follows the last weight gradients on their stream (SGD.side).
-    _early = False
+    # Round 4: ON by default (one rank).  With the update kernel as one persistent workgroup per CU (shallow memory queues) and gradients
+    # that are overwritten instead of cleared, the partial updates beside the layer3 / layer2 backward leave 0.13 ms of update at the
+    # end of the step instead of 0.29 ms: 199.3 -> 202.7 img/s, same box x 3 (profiles/r04_sgd_early_ab.txt).
+    _early = True
     _seg_done = 0
 
     @property
@@ -69,6 +73,10 @@ class SGD(object):
         hi = bisect.bisect_right(P.seg_ends, self._bounds[stage])
         if hi <= self._seg_done:
             return
+        # the marks of the previous complete step hold for this prefix only if its marked tensors were written again (same schedule: always)
+        stale = P.stale_marked(self._seg_done, hi, getattr(net, '_fresh', ()))
+        if stale:
+            P.mark_overwritten(P._ow_key - frozenset(stale))
         S = net.streams()
         tr = S['tr']
         net.sfork(torch.cuda.current_stream(), tr)
@@ -99,10 +107,11 @@ class SGD(object):
     defer = False   # measured (round 4, same-box A/B x3): 180.7 img/s with it, 184.1 without - see DESIGN.md section 4.6
 
     def _mark_overwritten(self):
-        # gradients the grouped weight gradients of this step wrote whole are not cleared by the update (ParamStore.mark_overwritten).
-        # Only where the update runs once, behind every weight gradient: not with early partial updates or the deferred heads stage.
+        # gradients the grouped weight gradients of this step wrote whole are not cleared by the update (ParamStore.mark_overwritten): marked
+        # at the end of a step, behind every weight gradient, for this step's last launch and the steps that follow (early partial updates
+        # check their prefix against the marks, partial()); not with the deferred heads stage, whose gradients arrive after this point.
         net = self.net
-        if self.clear_grad and not self._early and not self.defer_active and getattr(net, 'wgrad_overwrite', False):
+        if self.clear_grad and not self.defer_active and getattr(net, 'wgrad_overwrite', False):
             net.P.mark_overwritten(getattr(net, '_fresh', ()))
 
     def step(self):

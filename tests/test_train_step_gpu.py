@@ -718,12 +718,13 @@ def test_wgrad_overwrite_bit_identical():
     over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
     blobs = [OS.make_blob(320, 416, 6, 60, seed=5), OS.make_blob(320, 416, 6, 60, seed=6)]
     out = {}
-    for ow in (False, True):
-        for tape in (False, True):
+    for ow, tape, early in ((False, False, False), (False, True, False), (True, False, False), (True, True, False), (True, False, True), (True, True, True)):
+        if True:
             net = selftest.build_net(opt, over, 'bf16', sd)
             net.wgrad_overwrite = ow
             net.use_tape = tape
             sgd = SGD(net, 1e-3, momentum=0.9, weight_decay=1e-4)
+            sgd.early = early                   # partial updates during backward consume the marks of the previous complete step
             for i in range(6):
                 net.train_step_async(dict(blobs[i % 2]), 0, sgd)
             torch.cuda.synchronize()
@@ -736,8 +737,8 @@ def test_wgrad_overwrite_bit_identical():
                 assert names and all(k.endswith('.weight') for k in names) and any('layer4' in k for k in names) and any('layer2' in k for k in names)
                 assert any(float(net.P.grad[int(sg.offset):int(sg.offset + sg.count)].abs().max()) > 0 for sg in flagged)
             assert float(_grad_outside_overwritten(net.P).abs().max()) == 0.0
-            out[(ow, tape)] = (net.P.param.clone(), net.P.mom.clone())
-    p0, m0 = out[(False, False)]
+            out[(ow, tape, early)] = (net.P.param.clone(), net.P.mom.clone())
+    p0, m0 = out[(False, False, False)]
     assert bool(torch.isfinite(p0).all()) and float(m0.abs().max()) > 0
     for key, (p, m) in out.items():
         assert torch.equal(p, p0), (key, int((p != p0).sum()))
