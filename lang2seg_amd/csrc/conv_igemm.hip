@@ -2204,11 +2204,13 @@ int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
+int g_pdma_wgs = 0;
 template <int BM, int BN>
 int launch_igemm_pdma(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   const int G = cdiv(M, BM) * cdiv(d.Cout, BN);
-  const int grid = G < 256 ? ((G + 7) & ~7) : 256;     // one resident workgroup per CU, a multiple of 8 (the XCD-aware tile order)
+  const int cap = g_pdma_wgs > 0 ? (g_pdma_wgs & ~7) : 256;  // (tools: fewer resident workgroups than CUs leaves whole CUs to the other queues)
+  const int grid = G < cap ? ((G + 7) & ~7) : cap;     // one resident workgroup per CU, a multiple of 8 (the XCD-aware tile order)
   const size_t lds = (size_t)3 * (BM + BN) * ROWB + 8 * 2048;      // the ring + 2 KiB of epilogue staging per wave = 160 KiB
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_pdma_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
@@ -2217,6 +2219,8 @@ int launch_igemm_pdma(const l2s_conv_desc& d, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int l2s_conv_pdma_wgs(int n) { if (n >= 0) g_pdma_wgs = n; return g_pdma_wgs; }   // tools: resident workgroups of the persistent LDS-DMA tile (0 = one per CU)
 
 // ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
 enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,

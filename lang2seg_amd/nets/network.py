@@ -73,7 +73,8 @@ class ConvOp(object):
     def fwd(self, x, n, IH, IW, y, add=None, relu=False, out_f32=False, tile=0):
         OH, OW = self.out_hw(IH, IW)
         O.conv_igemm(x, self.wf, y, n, IH, IW, self.Cin, OH, OW, self.Np, self.k, self.k, self.stride, self.pad,
-                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt, ws=self.net.splitk_ws(n * OH * OW * self.Np), prio=max(self.prio, self.net.prio_floor))
+                     bias=self.bias, add=add, relu=relu, out_f32=out_f32, tile=tile, dt=self.net.dt, ws=self.net.splitk_ws(n * OH * OW * self.Np), prio=max(self.prio, self.net.prio_floor),
+                     algo=(self.net.conv_algo if self.k == 1 and self.stride == 1 and self.Np >= 1024 else None))
         return y
 
     def dgrad(self, g, n, IH, IW, dx, add=None, ref=None):
@@ -81,7 +82,8 @@ class ConvOp(object):
         OH, OW = self.out_hw(IH, IW)
         if self.stride == 1:
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, IH, IW, self.Cin, self.k, self.k, 1, self.k - 1 - self.pad,
-                         add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin), prio=max(self.prio, self.net.prio_floor))
+                         add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin), prio=max(self.prio, self.net.prio_floor),
+                         algo=(self.net.conv_algo if self.k == 1 and self.Cin >= 1024 else None))
         else:
             assert self.k == 1
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, OH, OW, self.Cin, 1, 1, 1, 0, add=add, ref=ref,
@@ -631,6 +633,8 @@ class Network(object):
 
     update_on_wg = False
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
+    conv_algo = None             # A/B: l2s_conv_desc.algo for the wide 1x1 launches issued while it is set (roi_pdma: the RoI head's N >= 1024 GEMMs on the persistent tile)
+    roi_pdma = False
     prio_floor = 0               # wave priority the convolution launches get at least (raised around a latency-bound chain: cap_map_prio)
     cap_map_prio = 0             # priority of layer4's data-gradient launches on the map (caption stream), beside the RoI head's backward
     rpn_bwd_early = True         # RPN losses + the RPN's own backward on the language stream beside the proposal chain (False: on the main stream behind the RoI head's backward)

@@ -808,7 +808,9 @@ class resnetv1(Network):
                           TR.BG_THRESH_LO, cst['means'], cst['stds'], cst['inw'], nc, MS, rois, labels, bt, bi, bo, mt, counts, pws)
         t.update({'rois': rois, 'labels': labels, 'bbox_targets': bt, 'bbox_inside': bi, 'bbox_outside': bo, 'mask_targets': mt, 'counts': counts})
         self._mark('targets')
+        self.conv_algo = 7 if self.roi_pdma else None       # (L2S_ALGO_PDMA)
         cheads, NPC, mscore = self._roi_head_fwd(net_conv, Hc, Wc, rois, R, FGM, saved)
+        self.conv_algo = None
         self._mark('roi head fwd')
         cap_advance()                                         # captioner backward
         # ---- detection losses + head gradients (NET:375-413) ----
@@ -830,7 +832,9 @@ class resnetv1(Network):
             t['loss'] = loss
             return loss
         self._mark('losses')
+        self.conv_algo = 7 if self.roi_pdma else None
         d_nc_roi = self._roi_head_bwd(d_cheads, dscore, labels, counts, rois, Hc, Wc, R, FGM, saved)
+        self.conv_algo = None
         self._mark('roialign bwd')
         cap_advance(finish=True)                              # layer4 on the map backward
         d_nc_cap, d_base_cap = cap_state['out']
