@@ -48,7 +48,7 @@ def parse_args(argv=None):
     ap.add_argument('--wgrad-overwrite', type=int, default=-1, help='A/B only: 1 / 0 = Network.wgrad_overwrite (first weight-gradient problem of a tensor writes dW; the update skips its clear)')
     ap.add_argument('--roi-pdma', type=int, default=-1, help='A/B only: N > 0 = the RoI head\'s wide 1x1 GEMMs on the persistent LDS-DMA tile with N resident workgroups (256 = one per CU)')
     ap.add_argument('--cap-map-prio', type=int, default=-1, help='A/B only: Network.cap_map_prio')
-    ap.add_argument('--rpn-early', type=int, default=-1, help='A/B only: 1 / 0 = Network.rpn_bwd_early')
+    ap.add_argument('--rpn-early', type=int, default=-1, help='A/B only: bit 0 = Network.rpn_bwd_early, bit 1 = rpn_wgrad_early')
     ap.add_argument('--join-l1', type=int, default=-1, help='A/B only: 1 = layer1 waits for the previous update too')
     ap.add_argument('--stem-mfma', type=int, default=-1, help='A/B only: 1 / 0 = Network.stem_mfma (bf16: stem + pooling as one matrix-core launch)')
     ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
@@ -448,7 +448,8 @@ def main(argv=None):
         _Net5.cap_map_prio = args.cap_map_prio
     if args.rpn_early >= 0:
         from lang2seg_amd.nets.network import Network as _Net4
-        _Net4.rpn_bwd_early = bool(args.rpn_early)
+        _Net4.rpn_bwd_early = bool(args.rpn_early & 1)
+        _Net4.rpn_wgrad_early = bool(args.rpn_early & 2)
     if args.join_l1 >= 0:
         from lang2seg_amd.nets.network import Network as _Net3
         _Net3.join_before_layer1 = bool(args.join_l1)

@@ -637,6 +637,7 @@ class Network(object):
     roi_pdma = False
     prio_floor = 0               # wave priority the convolution launches get at least (raised around a latency-bound chain: cap_map_prio)
     cap_map_prio = 0             # priority of layer4's data-gradient launches on the map (caption stream), beside the RoI head's backward
+    rpn_wgrad_early = False      # A/B: with rpn_bwd_early, launch the RPN's weight gradients right away instead of with the heads stage
     rpn_bwd_early = True         # RPN losses + the RPN's own backward on the language stream beside the proposal chain (False: on the main stream behind the RoI head's backward)
     join_before_layer1 = False   # A/B: the frozen layer1 also waits for the previous step's update (it then runs alone instead of beside it)
     stem_mfma = True             # bf16 mode: stem + pooling as one launch on the matrix cores (stem_mfma.hip); False: the f32 stem + pooling launches

@@ -794,6 +794,8 @@ class resnetv1(Network):
                     self.rpn_heads.dgrad(d_rheads, 1, Hc, Wc, drpn, ref=rpn)
                     self.rpn_conv.wgrad(drpn, net_conv, 1, Hc, Wc)
                     self.rpn_conv.dgrad(drpn, 1, Hc, Wc, d_nc_rpn)
+                    if self.rpn_bwd_early and self.rpn_wgrad_early:
+                        self.flush_wgrads('rpn')                # the weight-gradient stream is idle until the caption join
                     self._mark('rpn loss + bwd')
             if self.rpn_bwd_early:
                 rpn_bwd()
