@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument('--dp-wire', default='', choices=['', 'fp32', 'bf16'], help='gradient buckets on the wire: fp32 (282 MB / step) or packed to bf16 (141 MB); default: bf16 for N > 1')
     ap.add_argument('--dp-algo', default='', choices=['', 'allreduce', 'rs_ag'], help='one all-reduce per bucket, or reduce-scatter + all-gather; default: rs_ag for N > 1')
     ap.add_argument('--dp-shard-update', type=int, default=-1, help='with rs_ag: every rank updates only its slice of a bucket and the WEIGHTS are all-gathered; default: on for N > 1')
+    ap.add_argument('--dp-bucket-update', type=int, default=-1, help='unsharded: 1 = every bucket is updated right behind its all-reduce, on the reducer\'s stream (one rank: 187.9 against 191.3 img/s without: off)')
     ap.add_argument('--mixed-shapes', type=int, default=1, help='extra leg: a stream of six different (image size, token count) shapes replayed from pre-recorded tapes')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
@@ -433,9 +434,10 @@ def main(argv=None):
         dp_wire = args.dp_wire or ('bf16' if world > 1 else 'fp32')
         dp_algo = args.dp_algo or ('rs_ag' if world > 1 else 'allreduce')
         dp_shard = (args.dp_shard_update if args.dp_shard_update >= 0 else int(world > 1)) and dp_algo == 'rs_ag'
+        dp_bucket = (not dp_shard) and (args.dp_bucket_update > 0) and not args.dp_skip_allreduce
         net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce, wire=dp_wire, algo=dp_algo, timing=True, rank=rank,
-                             shard_update=True if dp_shard else None)
-        dp_desc = 'dp%d (%s buckets, %s%s)' % (world, dp_wire, dp_algo, ', sharded update' if dp_shard else '')
+                             shard_update=True if dp_shard else None, bucket_update=True if dp_bucket else None)
+        dp_desc = 'dp%d (%s buckets, %s%s)' % (world, dp_wire, dp_algo, ', sharded update' if dp_shard else (', update per bucket' if dp_bucket else ''))
     if args.defer >= 0:
         SGD.defer = bool(args.defer)
     if args.roi_pdma > 0:

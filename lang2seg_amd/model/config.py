@@ -69,6 +69,7 @@ __C.TRAIN.ALLOW_RESHARD_RESUME = False
 __C.TRAIN.DP_WIRE = 'bf16'
 __C.TRAIN.DP_ALGO = 'rs_ag'
 __C.TRAIN.DP_SHARD_UPDATE = True
+__C.TRAIN.DP_BUCKET_UPDATE = False    # unsharded data parallel: each gradient bucket is updated right behind its all-reduce (parallel.GradReducer.bucket_update); one rank: slower
 # RoIAlign + layer4[0].conv1 + layer4[0].downsample as ONE launch, one workgroup per RoI (l2s_roialign_block0_fwd, bf16): bit-identical to
 # the three launches it replaces and measured slower (170 vs 121 us: every workgroup streams all 5.2 MB of weights), so it is opt-in
 __C.TRAIN.FUSE_ROIALIGN = False

@@ -27,6 +27,9 @@ class SGD(object):
         dp = getattr(net, 'dp', None)
         if dp is not None and getattr(dp, 'shard_update', None) is True:
             dp.shard_update = self                   # the reducer calls update_range() on this rank's slice of every bucket
+        if dp is not None and getattr(dp, 'bucket_update', None) is True:
+            dp.bucket_update = self                  # ... or on every whole bucket, right behind its all-reduce
+        self.in_reducer = dp is not None and (getattr(dp, 'shard_update', None) is self or getattr(dp, 'bucket_update', None) is self)
         self.clear_grad = not keep_grad and getattr(dp, 'shard_update', None) is None   # (a sharded update touches a slice only)
         net.update_clears_grad = self.clear_grad
 
@@ -126,6 +129,21 @@ class SGD(object):
             self.refresh_shadow()
             net.refresh_weights()
             return
+        if getattr(getattr(net, 'dp', None), 'bucket_update', None) is self:
+            # every bucket was updated behind its all-reduce (weights, momentum, shadow, gradient clear): the data-gradient copies are left.
+            # With the tail on the weight-gradient stream the reducer made THAT stream wait for the last bucket (GradReducer.finish)
+            if self.side_active and net.use_streams:
+                net.flush_wgrads('final')
+                self._mark_overwritten()
+                with torch.cuda.stream(net.streams()['wg']):
+                    net.refresh_weights()
+                    net._mark('update done (wg)')
+                return
+            if hasattr(net, 'join_wgrad'):
+                net.join_wgrad()
+            self._mark_overwritten()
+            net.refresh_weights()
+            return
         if self.side_active and net.use_streams:
             net.flush_wgrads('final')
             self._mark_overwritten()
@@ -159,13 +177,22 @@ class SGD(object):
         self.net.refresh_weights()
 
     # ---- data parallel, sharded update (parallel.GradReducer(shard_update=...)): a rank updates only ITS slice of a reduce-scattered bucket ----
-    def update_range(self, lo, hi):
-        """the update on the elements [lo, hi) of the flat buffer, on the current stream (gradients there are final and summed over ranks)"""
+    def update_range(self, lo, hi, full=False):
+        """the update on the elements [lo, hi) of the flat buffer, on the current stream (gradients there are final and summed over ranks).
+        full: also rewrite the dtype shadow and clear the gradients consumed (a whole bucket updated on this rank: GradReducer.bucket_update);
+        otherwise weights and momentum only (a rank's slice: the shadow follows the all-gather, the clear the next step's memset)."""
         P = self.net.P
         c_lo, c_hi = P.chunk_range(lo, hi)
-        if c_hi > c_lo:
-            O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay, self.grad_scale,
-                                 None, 0, lo, hi, c_lo, c_hi)
+        if c_hi <= c_lo:
+            return
+        if full and self.clear_grad:
+            # (the overwrite marks are those of the previous complete step: a marked tensor that was not written again is cleared here)
+            s0, s1 = bisect.bisect_right(P.seg_ends, lo), bisect.bisect_left(P.seg_offs, hi)
+            stale = P.stale_marked(s0, s1, getattr(self.net, '_fresh', ()))
+            if stale:
+                P.mark_overwritten(P._ow_key - frozenset(stale))
+        O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay, self.grad_scale,
+                             P.shadow if full else None, int(bool(full and self.clear_grad)), lo, hi, c_lo, c_hi)
 
     def refresh_shadow(self):
         """dtype shadow of every tensor from the (gathered) parameters: shadow = dtype(rowscale * param), no update"""

@@ -68,10 +68,17 @@ class GradReducer(object):
     the exposed wait (what the main stream actually stalled for) of the last step."""
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
 
-    def __init__(self, net, world, backend_stream=True, skip_allreduce=0, wire='fp32', algo='allreduce', timing=False, shard_update=None, rank=None):
+    def __init__(self, net, world, backend_stream=True, skip_allreduce=0, wire='fp32', algo='allreduce', timing=False, shard_update=None, rank=None,
+                 bucket_update=None):
         assert wire in ('fp32', 'bf16') and algo in ('allreduce', 'rs_ag')
         assert shard_update is None or algo == 'rs_ag', 'the sharded update rides on reduce-scatter + all-gather'
+        assert shard_update is None or bucket_update is None
         self.net, self.world = net, world
+        # Update per bucket (round 4, unsharded): as soon as a bucket's gradients are summed, the optimiser updates that bucket on the reducer's
+        # stream (`bucket_update.update_range(lo, hi, full=True)`: weights, momentum, dtype shadow, gradient clear) - data parallel's form of the
+        # single-process early partial updates (optim.SGD.early): only the last, smallest bucket's update trails the step.  True = "the optimiser
+        # built for this network binds itself" (optim.SGD.__init__).
+        self.bucket_update = bucket_update
         # Sharded update (round 4): with algo = 'rs_ag' the all-gather does not have to carry GRADIENTS.  Each rank keeps the slice of the bucket
         # the reduce-scatter left it with, runs the optimiser on that slice only (`shard_update.update_range(lo, hi)`: fp32 master weights and
         # momentum of the slice; the 1 / world averaging is the optimiser's grad_scale) and the ranks all-gather the updated WEIGHTS - the
@@ -170,6 +177,8 @@ class GradReducer(object):
             self._cast(pk, seg)
         else:
             self._collective(seg)
+        if self.bucket_update is not None and self.bucket_update is not True:
+            self.bucket_update.update_range(lo, hi, full=True)
 
     def ready(self, stage):
         if self.skip_allreduce == 2:
@@ -204,11 +213,16 @@ class GradReducer(object):
             self.ready('layer1')
         if self.on_gpu:
             main = torch.cuda.current_stream()
+            # who waits for the last bucket: the main stream - or, when the buckets were updated here and the optimiser's tail runs on the
+            # weight-gradient stream (optim.SGD.side), that stream: the next step's frozen prefix then starts beside the last update and the main
+            # stream joins before its first trainable layer (Network.join_update), as in the single-process step
+            if self.bucket_update not in (None, True) and getattr(self.bucket_update, 'side_active', False) and getattr(self.net, 'use_streams', False):
+                main = self.net.streams()['wg']
             if self.timing:
-                a = torch.cuda.Event(enable_timing=True); a.record()
+                a = torch.cuda.Event(enable_timing=True); a.record(main)
             main.wait_stream(self.side)
             if self.timing:
-                b = torch.cuda.Event(enable_timing=True); b.record()
+                b = torch.cuda.Event(enable_timing=True); b.record(main)
                 self._wait_events = (a, b)
                 self._last_events, self._events = self._events, []
         self.done = 0

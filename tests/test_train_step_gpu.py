@@ -438,18 +438,25 @@ def test_dp_sharded_update_matches_plain_update():
     blob = OS.make_blob(320, 416, 6, 60, seed=5)
     over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
     out = {}
-    for mode in ('plain', 'sharded', 'sharded+tape'):
+    # 'bucket': the unsharded form - every bucket is updated whole right behind its all-reduce (GradReducer.bucket_update), gradients
+    # cleared / overwrite-marked as in the single-process step
+    for mode in ('plain', 'sharded', 'sharded+tape', 'bucket', 'bucket+tape'):
         net = selftest.build_net(opt, over, 'bf16', sd)
         net.use_tape = mode.endswith('tape')
-        if mode != 'plain':
+        if mode.startswith('sharded'):
             net.dp = GradReducer(net, 1, wire='fp32', algo='rs_ag', shard_update=True, rank=0)
+        elif mode.startswith('bucket'):
+            net.dp = GradReducer(net, 1, wire='fp32', algo='allreduce', bucket_update=True, rank=0)
         sgd = SGD(net, 1e-3, momentum=0.9, weight_decay=1e-4)
-        assert (net.dp is None) or net.dp.shard_update is sgd
+        assert (net.dp is None) or (net.dp.shard_update is sgd) != (net.dp.bucket_update is sgd)
         for _ in range(4):
             net.train_step_async(dict(blob), 0, sgd)
         torch.cuda.synchronize(); net.join_update(); torch.cuda.synchronize()
+        if mode.startswith('bucket'):
+            assert any(sg.flags & 1 for sg in net.P._seg_tables[0])                     # the overwrite marks are in force under the reducer too
+            assert float(_grad_outside_overwritten(net.P).abs().max()) == 0.0
         out[mode] = (net.P.param.clone(), net.P.mom.clone(), net.P.shadow.clone())
-    for mode in ('sharded', 'sharded+tape'):
+    for mode in ('sharded', 'sharded+tape', 'bucket', 'bucket+tape'):
         for a, b, nm in zip(out[mode], out['plain'], ('param', 'momentum', 'shadow')):
             assert torch.equal(a, b), (mode, nm, int((a != b).sum()))
 

@@ -73,7 +73,8 @@ def main(args, variant='cycle'):
     if world > 1:
         from lang2seg_amd.parallel import GradReducer
         net.dp = GradReducer(net, world, wire=cfg.TRAIN.DP_WIRE, algo=cfg.TRAIN.DP_ALGO, rank=rank,
-                             shard_update=True if (cfg.TRAIN.DP_SHARD_UPDATE and cfg.TRAIN.DP_ALGO == 'rs_ag') else None)   # (the optimiser binds itself to the reducer)
+                             shard_update=True if (cfg.TRAIN.DP_SHARD_UPDATE and cfg.TRAIN.DP_ALGO == 'rs_ag') else None,   # (the optimiser binds itself to the reducer)
+                             bucket_update=True if (cfg.TRAIN.DP_BUCKET_UPDATE and not (cfg.TRAIN.DP_SHARD_UPDATE and cfg.TRAIN.DP_ALGO == 'rs_ag')) else None)
     output_dir = osp.join(ROOT, opt['dataset_splitBy'], 'output_{}'.format(args['output_postfix']))
     tb_dir = osp.join(ROOT, opt['dataset_splitBy'], 'tb_{}'.format(args['output_postfix']))
     pretrained = osp.join(ROOT, 'pyutils/mask-faster-rcnn/output/%s/%s_2014_train_minus_refer_valtest+%s_2014_valminusminival/%s/%s_mask_rcnn_iter_%s.pth' % (
