@@ -123,7 +123,15 @@ class SGD(object):
         net._bwd_pending = 0
         if getattr(getattr(net, 'dp', None), 'shard_update', None) is not None:
             # the reducer updated this rank's slice of every bucket and gathered the others' (parallel.GradReducer): what is left is the dtype
-            # shadow of the gathered weights and the data-gradient copies
+            # shadow of the gathered weights and the data-gradient copies - on the weight-gradient stream where the tail lives there (the reducer
+            # made that stream wait for the last all-gather, GradReducer.finish; the next step joins it before its first trainable layer)
+            if self.side_active and net.use_streams:
+                net.flush_wgrads('final')
+                with torch.cuda.stream(net.streams()['wg']):
+                    self.refresh_shadow()
+                    net.refresh_weights()
+                    net._mark('update done (wg)')
+                return
             if hasattr(net, 'join_wgrad'):
                 net.join_wgrad()
             self.refresh_shadow()

@@ -213,10 +213,11 @@ class GradReducer(object):
             self.ready('layer1')
         if self.on_gpu:
             main = torch.cuda.current_stream()
-            # who waits for the last bucket: the main stream - or, when the buckets were updated here and the optimiser's tail runs on the
-            # weight-gradient stream (optim.SGD.side), that stream: the next step's frozen prefix then starts beside the last update and the main
+            # who waits for the last bucket: the main stream - or, when the buckets were updated here (whole, or this rank's slices) and the
+            # optimiser's tail runs on the weight-gradient stream (optim.SGD.side), that stream: the next step's frozen prefix then starts beside the last update and the main
             # stream joins before its first trainable layer (Network.join_update), as in the single-process step
-            if self.bucket_update not in (None, True) and getattr(self.bucket_update, 'side_active', False) and getattr(self.net, 'use_streams', False):
+            upd = self.bucket_update if self.bucket_update not in (None, True) else self.shard_update
+            if upd not in (None, True) and getattr(upd, 'side_active', False) and getattr(self.net, 'use_streams', False):
                 main = self.net.streams()['wg']
             if self.timing:
                 a = torch.cuda.Event(enable_timing=True); a.record(main)
