@@ -46,6 +46,7 @@ def parse_args(argv=None):
     ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
     ap.add_argument('--sgd-early', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.early on / off (update each finished prefix of the flat buffer during backward; one rank only)')
     ap.add_argument('--wgrad-overwrite', type=int, default=-1, help='A/B only: 1 / 0 = Network.wgrad_overwrite (first weight-gradient problem of a tensor writes dW; the update skips its clear)')
+    ap.add_argument('--dma256', type=int, default=-1, help='A/B only: 1 / 0 = the 256x256 LDS-DMA tile for wide plain GEMMs on / off (l2s_conv_dma256)')
     ap.add_argument('--roi-pdma', type=int, default=-1, help='A/B only: N > 0 = the RoI head\'s wide 1x1 GEMMs on the persistent LDS-DMA tile with N resident workgroups (256 = one per CU)')
     ap.add_argument('--cap-map-prio', type=int, default=-1, help='A/B only: Network.cap_map_prio')
     ap.add_argument('--rpn-early', type=int, default=-1, help='A/B only: bit 0 = Network.rpn_bwd_early, bit 1 = rpn_wgrad_early')
@@ -440,6 +441,9 @@ def main(argv=None):
         dp_desc = 'dp%d (%s buckets, %s%s)' % (world, dp_wire, dp_algo, ', sharded update' if dp_shard else (', update per bucket' if dp_bucket else ''))
     if args.defer >= 0:
         SGD.defer = bool(args.defer)
+    if args.dma256 >= 0:
+        from lang2seg_amd import _lib as _L8
+        _L8.load().l2s_conv_dma256(args.dma256)
     if args.roi_pdma > 0:
         from lang2seg_amd.nets.network import Network as _Net6
         from lang2seg_amd import _lib as _L6

@@ -44,6 +44,8 @@ int l2s_version(void);
 #define L2S_ALGO_KSPLIT_D3 6   /* the same with a ring of three LDS stages instead of four */
 #define L2S_ALGO_PATCH 3       /* 3x3 / stride 1 / pad 1 on one map: 128 pixels x 32 or 64 channels per workgroup, input patch staged once for the nine taps */
 #define L2S_ALGO_PDMA 7
+#define L2S_ALGO_DMA256 9          /* igemm_dma256_kernel: 256x256 LDS-DMA tile for wide plain GEMMs (chosen automatically for them) */
+int l2s_conv_dma256(int on);      /* tools: 1 / 0 = that automatic choice on / off (< 0: query) */
 int l2s_conv_pdma_wgs(int n);   /* tools: resident workgroups of the persistent LDS-DMA tile (0 = one per CU; < 0 = query) */        /* the LDS-DMA tile as ONE persistent workgroup per CU walking its tiles, requests running ahead across tile boundaries (plain GEMMs) */
 #define L2S_ALGO_WS64_STAMPED 8  /* the 64x64 wave-specialised tile with clock stamps per workgroup in ws (tools/ws64_stamps.py) */
 typedef struct {

@@ -76,6 +76,7 @@ SIGS = {
     'l2s_weight_transpose_batched': (i32, [vp, i32, i32, i32, vp]),
     'l2s_stem_conv': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'l2s_conv_pdma_wgs': (i32, [i32]),
+    'l2s_conv_dma256': (i32, [i32]),
     'l2s_stem_pack_bytes': (C.c_size_t, []),
     'l2s_stem_pack': (i32, [vp, vp, vp]),
     'l2s_stem_pool_bf16': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -1398,6 +1398,172 @@ __device__ __forceinline__ void igemm_epilogue_wave(const l2s_conv_desc& p, f32x
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 LDS-DMA tile for the wide plain GEMMs (round 4: layer4 on the RoIs, conv3 / downsample forward and the conv1 / downsample
+// data gradients - M = 12544, N = 1024 / 2048, K = 512 ... 2048).  Same pipeline as igemm_dma_kernel (two wave groups one slot apart,
+// three LDS stages, counted vmcnt), different arithmetic per slot: the 256 x 128 tile multiplies 32 MFMAs per wave and slot against
+// 16 fragment reads + 6 DMA requests, and its LOAD slot (1100-1300 cycles by the stamps of tools/dma_stamps.py) is twice its MULTIPLY
+// slot - 37 % of a CU's matrix pipe.  Here a wave owns 64 x 128 of the tile and a slice is 32 channels (64-byte rows, so that three
+// stages of 512 rows still fit): the same 32 MFMAs per slot against 12 fragment reads + 4 requests, and no offset arithmetic at all
+// (1x1 / stride 1: the slice's byte offset is a scalar).  1 KiB requests = 16 rows x 64 B; a row's four 16-byte chunks are
+// XOR-swizzled with (row >> 2) & 3: the 16 rows a quarter-wave reads then cover all 64 banks.
+// Epilogue per wave through 4 KiB of LDS of its own (16 rows x 128 channels at a time, 16-byte chunks XOR row): bias, residual, ReLU /
+// mask in fp32, one rounding, 16-byte stores of whole 256-byte runs.
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue_wave128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int M, char* wlds) {
+  static_assert(TN == 8, "128-channel sub-tiles");
+  constexpr unsigned NOPE = 0x80000000u;
+  constexpr int WM = TM * 16, WN = TN * 16;
+  const int fr = lane & 15, fg = lane >> 4;
+  const void* op = p.add ? p.add : p.ref;
+  const int ldo = p.add ? p.ldadd : p.ldref;
+  const auto rop = __builtin_amdgcn_make_buffer_rsrc((void*)(op ? op : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const auto rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : (const void*)p.y), 0, 0x7FFFFFFF, 0x00020000);
+  const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFFFF, 0x00020000);
+  f32x4 bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + fg * 4;
+    bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (p.bias && n < p.Cout) ? (unsigned)(n * 4) : NOPE, 0, 0));
+  }
+  u32x2 ov[2][TN];                                         // operands of row block i, requested one block ahead
+  auto fetch = [&](int i, u32x2 (&o)[TN]) {
+    const int m = m0 + wm * WM + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fg * 4;
+      o[j] = __builtin_amdgcn_raw_buffer_load_b64(rop, (op && m < M && n < p.Cout) ? (unsigned)(((long)m * ldo + n) * 2) : NOPE, 0, 0);
+    }
+  };
+  fetch(0, ov[0]);
+  const int rrow = lane >> 4, rch = lane & 15;             // read side: 4 rows x 16 chunks per instruction
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i + 1 < TM) fetch(i + 1, ov[(i + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const u32x2 oo = ov[i & 1][j];
+      float v[4] = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};   // (no bias: zeros were loaded)
+      const float o[4] = {__uint_as_float(oo.x << 16), __uint_as_float(oo.x & 0xFFFF0000u), __uint_as_float(oo.y << 16), __uint_as_float(oo.y & 0xFFFF0000u)};
+      if (p.add) { v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+      if (p.flags & L2S_CONV_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (p.ref) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) v[e] = 0.f;
+      }
+      u32x2 pk;
+      pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      *(u32x2*)(wlds + fr * 256 + (((2 * j + (fg >> 1)) ^ fr) << 4) + ((fg & 1) << 3)) = pk;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int row = rrow + 4 * h;
+      const u32x4v q = *(const u32x4v*)(wlds + row * 256 + ((rch ^ row) << 4));
+      const int m = m0 + wm * WM + i * 16 + row, n = n0 + wn * WN + rch * 8;
+      const unsigned o = (m < M && n < p.Cout) ? (unsigned)(((long)m * p.ldy + n) * 2) : NOPE;
+      __builtin_amdgcn_raw_buffer_store_b128(q, ry, o, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void igemm_dma256_kernel(const l2s_conv_desc p) {
+  typedef bf16_t T;
+  constexpr int BM = 256, BN = 256, WM = 64, WN = 128, TM = 4, TN = 8;
+  constexpr int RB = 64;                                   // bytes of K per LDS row and slice (32 channels)
+  constexpr int STG = (BM + BN) * RB;                      // 32 KiB per stage
+  constexpr int NP = 4;                                    // 1-KiB requests per wave and slice: two of A, two of B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.Cin;                                     // 1x1
+  int mt, nt;
+  {
+    const int MT = (M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;
+    if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  i32x4s rx, rw;
+  rx.x = (int)(uintptr_t)p.x; rx.y = (int)((uintptr_t)p.x >> 32); rx.z = (int)(((long)(M - 1) * p.ldx + p.Cin) * 2L); rx.w = 0x00020000;
+  rw.x = (int)(uintptr_t)p.w; rw.y = (int)((uintptr_t)p.w >> 32); rw.z = (int)((long)p.Cout * K * 2L); rw.w = 0x00020000;
+  // DMA coordinates: lane -> (row of a 16-row piece, physical chunk); source chunk = physical ^ ((row >> 2) & 3)
+  const int prow = lane >> 2, sch = (lane & 3) ^ ((prow >> 2) & 3);
+  unsigned voA[2], voB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + 16 * (wave + 8 * j) + prow, n = n0 + 16 * (wave + 8 * j) + prow;
+    voA[j] = m < M ? (unsigned)(((long)m * p.ldx + sch * 8) * 2L) : OOR;
+    voB[j] = n < p.Cout ? (unsigned)(((long)n * K + sch * 8) * 2L) : OOR;
+  }
+  const int KT = K / 32;
+  const unsigned ldsA = lds0 + (unsigned)(wave * 1024), ldsB = ldsA + (unsigned)(BM * RB);
+  auto request = [&](int stage, int t) {                   // slice t -> LDS stage `stage`
+    const unsigned sb = (unsigned)(stage * STG), so = (unsigned)(t * RB);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma_b128(rx, voA[j], so, ldsA + sb + (unsigned)(j * 8192));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma_b128(rw, voB[j], so, ldsB + sb + (unsigned)(j * 8192));
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ch = (fg ^ ((fr >> 2) & 3)) << 4;
+  const int offa = (wm * WM + fr) * RB + ch, offb = BM * RB + (wn * WN + fr) * RB + ch;
+  uint4 fa[TM], fb[TN];
+  auto read_all = [&](int stage) {
+    const char* base = smem + stage * STG;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(base + offa + i * 16 * RB);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(base + offb + j * 16 * RB);
+  };
+  auto mma_all = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(fb[j], fa[i], acc[i][j]);
+  };
+  // prologue: slices 0 and 1 requested; everybody waits for its share of slice 0
+  request(0, 0);
+  if (1 < KT) { request(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wg_barrier();
+  if (grp == 1) wg_barrier();                              // one slot behind group 0
+  int st = 0;
+  for (int t = 0; t < KT; ++t) {
+    const int st2 = st == 0 ? 2 : st - 1;                  // (t + 2) % 3: the stage of slice t - 1
+    read_all(st);
+    if (t + 2 < KT) request(st2, t + 2);
+    wait_lgkm0();
+    if (grp == 1) {
+      if (t + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");   // slice t + 1 landed (slice t + 2 may be in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    wg_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) {
+      if (t + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    wg_barrier();
+    st = st == 2 ? 0 : st + 1;
+  }
+  if (grp == 0) wg_barrier();                              // group 1's last MULTIPLY slot
+  igemm_epilogue_wave128<TM, TN>(p, acc, m0, n0, wm, wn, lane, M, smem + 3 * STG + wave * 4096);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent form of the LDS-DMA tile for the multi-round 1x1 launches (bf16, plain GEMM: layer4 on the RoIs, conv3 / downsample forward
 // and the conv1 / downsample data gradients: M = 12544, N = 1024..2048, K = 512..1024 - 784 tiles of 8 or 16 slices).  As separate
 // workgroups every tile pays its own prologue (~2 us until the first slice has crossed L2 -> LDS) and its own epilogue with nothing
@@ -2204,6 +2370,16 @@ int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
+int launch_igemm_dma256(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, 256) * cdiv(d.Cout, 256));
+  const size_t lds = (size_t)3 * 512 * 64 + 8 * 4096;     // the ring + 4 KiB of epilogue staging per wave = 128 KiB
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_dma256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH(igemm_dma256_kernel, grid, dim3(512), lds, st, d);
+  return l2s_check_launch();
+}
+
 int g_pdma_wgs = 0;
 template <int BM, int BN>
 int launch_igemm_pdma(const l2s_conv_desc& d, hipStream_t st) {
@@ -2220,14 +2396,16 @@ int launch_igemm_pdma(const l2s_conv_desc& d, hipStream_t st) {
 
 }  // namespace
 
+int g_dma256_auto = 1;   // tools: 0 sends the wide plain GEMMs back to the 128x128 ring tile
+extern "C" int l2s_conv_dma256(int on) { if (on >= 0) g_dma256_auto = on; return g_dma256_auto; }
 extern "C" int l2s_conv_pdma_wgs(int n) { if (n >= 0) g_pdma_wgs = n; return g_pdma_wgs; }   // tools: resident workgroups of the persistent LDS-DMA tile (0 = one per CU)
 
 // ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
 enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,
-                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK, PLAN_P3_32_256, PLAN_P3_64_256, PLAN_P3_32_384, PLAN_P3_64_384, PLAN_RING128X64, PLAN_PDMA256 };
+                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK, PLAN_P3_32_256, PLAN_P3_64_256, PLAN_P3_32_384, PLAN_P3_64_384, PLAN_RING128X64, PLAN_PDMA256, PLAN_DMA256X256 };
 static const char* const PLAN_NAMES[] = {"invalid", "igemm_kernel<64,64>", "igemm_kernel<128,128>", "igemm_ring_kernel<64,64>", "igemm_ring_kernel<128,128>",
                                          "igemm_ws64_kernel", "igemm_ks64_kernel<4>", "igemm_ks64_kernel<3>", "igemm_sp_kernel<224,128>", "igemm_sp_kernel<256,128>",
-                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel", "igemm_p3_kernel<32,256>", "igemm_p3_kernel<64,256>", "igemm_p3_kernel<32,384>", "igemm_p3_kernel<64,384>", "igemm_ring_kernel<128,64>", "igemm_pdma_kernel<256,128>"};
+                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel", "igemm_p3_kernel<32,256>", "igemm_p3_kernel<64,256>", "igemm_p3_kernel<32,384>", "igemm_p3_kernel<64,384>", "igemm_ring_kernel<128,64>", "igemm_pdma_kernel<256,128>", "igemm_dma256_kernel"};
 static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
   if (!d || !d->x || !d->w || !d->y || (dtype != L2S_BF16 && dtype != L2S_F32)) return PLAN_EINVAL;
   const bool bf = dtype == L2S_BF16;
@@ -2269,6 +2447,11 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     // (on request only: measured 69 / 99 / 78 us against 65 / 92 / 84 us of the one-shot tiles on layer4's 1x1-out / downsample / downsample
     // data-gradient launches - the two wave groups write their sub-tiles out in different slots, and each waits for the other's stores)
     if (pdma_ok && algo == L2S_ALGO_PDMA) return PLAN_PDMA256;
+    // 256x256 LDS-DMA tile: the same plain GEMMs when they are wide (N a multiple of 256, >= 1024) and tall enough for more than one round of
+    // 256x128 tiles (layer4 on the RoIs: conv3, downsample and the data gradients of conv1 / downsample)
+    const bool d256_ok = pdma_ok && d->Cout % 256 == 0 && d->Cout >= 1024 && M >= 4096 && !(d->ldy & 7) && !(d->Cout & 7) &&
+                         (!d->add || !d->ref) && !((uintptr_t)d->y & 15) && !(d->ldadd & 3) && !(d->ldref & 3);
+    if (d256_ok && (algo == L2S_ALGO_DMA256 || (algo == L2S_ALGO_AUTO && g_dma256_auto))) return PLAN_DMA256X256;
     if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
     if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;
     // patch tile: 3x3 / stride 1 / pad 1 on one map whose row fits the patch (W + 1 <= 128 halo pixels on either side of 128 outputs)
@@ -2329,6 +2512,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
 #define OUT(NAME, T, ...) (f32o ? NAME<T, __VA_ARGS__, true>(dd, stream) : NAME<T, __VA_ARGS__, false>(dd, stream))
   switch (plan) {
     case PLAN_PDMA256: return launch_igemm_pdma<256, 128>(dd, stream);
+    case PLAN_DMA256X256: return launch_igemm_dma256(dd, stream);
     case PLAN_DMA256: return launch_igemm_dma<256, 128, false>(dd, stream);
     case PLAN_DMA256_STAMPED: return launch_igemm_dma<256, 128, true>(dd, stream);
     case PLAN_P3_32_256: return launch_igemm_p3<32, 256, 2>(dd, stream);

@@ -179,6 +179,55 @@ def test_conv_persistent_dma_tile(cfg):
     assert torch.equal(y2, y3)
 
 
+@pytest.mark.parametrize('cfg', [
+    dict(n=256, H=7, W=7, Cin=512, Cout=2048),     # layer4 conv3 on the RoIs: 392 tiles of 16 slices
+    dict(n=256, H=7, W=7, Cin=1024, Cout=2048),    # layer4[0].downsample
+    dict(n=256, H=7, W=7, Cin=2048, Cout=1024),    # the downsample's data gradient
+    dict(n=91, H=7, W=7, Cin=192, Cout=1024),      # ragged pixel tile (M = 4459 = 17 x 256 + 107), six slices
+    dict(n=100, H=7, W=7, Cin=320, Cout=1280),     # five channel tiles, ten slices
+])
+def test_conv_dma256_tile(cfg):
+    """igemm_dma256_kernel (256x256 LDS-DMA tile, 32-channel slices, per-wave epilogue through LDS; the automatic choice for wide plain
+    GEMMs) against torch on the same rounded bf16 operands and BIT FOR BIT against the 256x128 LDS-DMA tile (same k order inside every
+    accumulator): bias + residual + ReLU epilogue, the data-gradient form (ReLU mask), plain; the automatic plan picks it."""
+    O = ops()
+    dt = 1
+    g = torch.Generator().manual_seed(13)
+    n, H, W, Cin, Cout = [cfg[x] for x in ['n', 'H', 'W', 'Cin', 'Cout']]
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(n, Cout, H, W, generator=g)
+    xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
+    xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
+    conv = F.conv2d(xr, wr, None)
+    M = n * H * W
+    ys = {}
+    for algo in (9, 2, 0):
+        outs = []
+        for kw in (dict(bias=b.to(DEV), add=rd, relu=True), dict(ref=rd), dict(bias=b.to(DEV))):
+            y = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+            O.conv_igemm(xd, wd, y, n, H, W, Cin, H, W, Cout, 1, 1, 1, 0, algo=algo, **kw)
+            if algo == 9 or (algo == 0 and M >= 4096):
+                assert 'dma256' in O.LAST_PLAN, O.LAST_PLAN
+            outs.append(y)
+        torch.cuda.synchronize()
+        ys[algo] = outs
+    y, y2, y3 = ys[9]
+    assert rel_err(y.float().view(n, H, W, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
+    assert rel_err(y2.float().view(n, H, W, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
+    assert rel_err(y3.float().view(n, H, W, Cout), nhwc(conv + b.view(1, -1, 1, 1))) < TOL[dt]
+    for a, c in zip(ys[9], ys[2]):
+        assert torch.equal(a, c)
+    for a, c in zip(ys[9], ys[0]):
+        assert torch.equal(a, c)
+    y4 = torch.empty_like(y2)
+    for _ in range(3):
+        O.conv_igemm(xd, wd, y4, n, H, W, Cin, H, W, Cout, 1, 1, 1, 0, ref=rd, algo=9)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y4)
+
+
 @pytest.mark.parametrize('cfg', [dict(H=38, W=63, C=1024, R=256, N1=512, N2=2048), dict(H=20, W=26, C=1024, R=37, N1=512, N2=2048),
                                  dict(H=10, W=14, C=256, R=5, N1=128, N2=256)])
 def test_roialign_fused_into_layer4_block0(cfg):
