@@ -1409,7 +1409,7 @@ __device__ __forceinline__ void igemm_epilogue_wave(const l2s_conv_desc& p, f32x
 // Epilogue per wave through 4 KiB of LDS of its own (16 rows x 128 channels at a time, 16-byte chunks XOR row): bias, residual, ReLU /
 // mask in fp32, one rounding, 16-byte stores of whole 256-byte runs.
 // ------------------------------------------------------------------------------------------------
-template <int TM, int TN>
+template <int TM, int TN, bool BOTH>
 __device__ __forceinline__ void igemm_epilogue_wave128(const l2s_conv_desc& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int M, char* wlds) {
   static_assert(TN == 8, "128-channel sub-tiles");
   constexpr unsigned NOPE = 0x80000000u;
@@ -1426,13 +1426,16 @@ __device__ __forceinline__ void igemm_epilogue_wave128(const l2s_conv_desc& p, f
     const int n = n0 + wn * WN + j * 16 + fg * 4;
     bv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (p.bias && n < p.Cout) ? (unsigned)(n * 4) : NOPE, 0, 0));
   }
-  u32x2 ov[2][TN];                                         // operands of row block i, requested one block ahead
+  // BOTH: residual AND mask (the data gradient of a block's first 1x1: dx = mask(conv^T(dz) + g)): `op` is the residual, `rv` the mask operand
+  const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref ? p.ref : p.y), 0, 0x7FFFFFFF, 0x00020000);
+  u32x2 ov[2][TN], rv[BOTH ? 2 : 1][BOTH ? TN : 1];       // operands of row block i, requested one block ahead
   auto fetch = [&](int i, u32x2 (&o)[TN]) {
     const int m = m0 + wm * WM + i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 16 + fg * 4;
       o[j] = __builtin_amdgcn_raw_buffer_load_b64(rop, (op && m < M && n < p.Cout) ? (unsigned)(((long)m * ldo + n) * 2) : NOPE, 0, 0);
+      if constexpr (BOTH) rv[i & 1][j] = __builtin_amdgcn_raw_buffer_load_b64(rref, (m < M && n < p.Cout) ? (unsigned)(((long)m * p.ldref + n) * 2) : NOPE, 0, 0);
     }
   };
   fetch(0, ov[0]);
@@ -1448,8 +1451,13 @@ __device__ __forceinline__ void igemm_epilogue_wave128(const l2s_conv_desc& p, f
       if (p.add) { v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
       if (p.flags & L2S_CONV_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       if (p.ref) {
+        float q[4] = {o[0], o[1], o[2], o[3]};
+        if constexpr (BOTH) {
+          const u32x2 rr = rv[i & 1][j];
+          q[0] = __uint_as_float(rr.x << 16); q[1] = __uint_as_float(rr.x & 0xFFFF0000u); q[2] = __uint_as_float(rr.y << 16); q[3] = __uint_as_float(rr.y & 0xFFFF0000u);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) v[e] = 0.f;
+        for (int e = 0; e < 4; ++e) if (!(q[e] > 0.f)) v[e] = 0.f;
       }
       u32x2 pk;
       pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
@@ -1560,7 +1568,8 @@ __global__ __launch_bounds__(512) void igemm_dma256_kernel(const l2s_conv_desc p
     st = st == 2 ? 0 : st + 1;
   }
   if (grp == 0) wg_barrier();                              // group 1's last MULTIPLY slot
-  igemm_epilogue_wave128<TM, TN>(p, acc, m0, n0, wm, wn, lane, M, smem + 3 * STG + wave * 4096);
+  if (p.add && p.ref) igemm_epilogue_wave128<TM, TN, true>(p, acc, m0, n0, wm, wn, lane, M, smem + 3 * STG + wave * 4096);
+  else igemm_epilogue_wave128<TM, TN, false>(p, acc, m0, n0, wm, wn, lane, M, smem + 3 * STG + wave * 4096);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2450,7 +2459,7 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     // 256x256 LDS-DMA tile: the same plain GEMMs when they are wide (N a multiple of 256, >= 1024) and tall enough for more than one round of
     // 256x128 tiles (layer4 on the RoIs: conv3, downsample and the data gradients of conv1 / downsample)
     const bool d256_ok = pdma_ok && d->Cout % 256 == 0 && d->Cout >= 1024 && M >= 4096 && !(d->ldy & 7) && !(d->Cout & 7) &&
-                         (!d->add || !d->ref) && !((uintptr_t)d->y & 15) && !(d->ldadd & 3) && !(d->ldref & 3);
+                         !((uintptr_t)d->y & 15) && !(d->ldadd & 3) && !(d->ldref & 3);
     if (d256_ok && (algo == L2S_ALGO_DMA256 || (algo == L2S_ALGO_AUTO && g_dma256_auto))) return PLAN_DMA256X256;
     if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
     if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;

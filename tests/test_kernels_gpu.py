@@ -189,7 +189,7 @@ def test_conv_persistent_dma_tile(cfg):
 def test_conv_dma256_tile(cfg):
     """igemm_dma256_kernel (256x256 LDS-DMA tile, 32-channel slices, per-wave epilogue through LDS; the automatic choice for wide plain
     GEMMs) against torch on the same rounded bf16 operands and BIT FOR BIT against the 256x128 LDS-DMA tile (same k order inside every
-    accumulator): bias + residual + ReLU epilogue, the data-gradient form (ReLU mask), plain; the automatic plan picks it."""
+    accumulator): bias + residual + ReLU epilogue, the data-gradient forms (ReLU mask; residual + mask), plain; the automatic plan picks it."""
     O = ops()
     dt = 1
     g = torch.Generator().manual_seed(13)
@@ -199,13 +199,15 @@ def test_conv_dma256_tile(cfg):
     b = torch.randn(Cout, generator=g)
     res = torch.randn(n, Cout, H, W, generator=g)
     xd, wd, rd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt), to_dev(nhwc(res), dt)
+    r2d = to_dev(nhwc(torch.randn(n, Cout, H, W, generator=g)), dt)
     xr, wr, rr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2), rd.float().cpu().permute(0, 3, 1, 2)
+    r2 = r2d.float().cpu().permute(0, 3, 1, 2)
     conv = F.conv2d(xr, wr, None)
     M = n * H * W
     ys = {}
     for algo in (9, 2, 0):
         outs = []
-        for kw in (dict(bias=b.to(DEV), add=rd, relu=True), dict(ref=rd), dict(bias=b.to(DEV))):
+        for kw in (dict(bias=b.to(DEV), add=rd, relu=True), dict(ref=rd), dict(bias=b.to(DEV)), dict(add=rd, ref=r2d)):
             y = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
             O.conv_igemm(xd, wd, y, n, H, W, Cin, H, W, Cout, 1, 1, 1, 0, algo=algo, **kw)
             if algo == 9 or (algo == 0 and M >= 4096):
@@ -213,7 +215,8 @@ def test_conv_dma256_tile(cfg):
             outs.append(y)
         torch.cuda.synchronize()
         ys[algo] = outs
-    y, y2, y3 = ys[9]
+    y, y2, y3, y5 = ys[9]
+    assert rel_err(y5.float().view(n, H, W, Cout), nhwc((conv + rr) * (r2 > 0))) < TOL[dt]      # residual AND mask: a block's first 1x1, data gradient
     assert rel_err(y.float().view(n, H, W, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
     assert rel_err(y2.float().view(n, H, W, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
     assert rel_err(y3.float().view(n, H, W, Cout), nhwc(conv + b.view(1, -1, 1, 1))) < TOL[dt]
