@@ -93,7 +93,10 @@ def test_conv_plan_table():
     assert plan(1, 75, 125, 128, 512) == 'igemm_ring_kernel<128,64>'               # layer2 conv3: a 128x128 grid below one round
     assert plan(256, 7, 7, 512, 512, 3) == 'igemm_dma_kernel<256,128>'             # layer4 @ RoIs conv2
     assert plan(256, 7, 7, 2048, 512) == 'igemm_dma_kernel<256,128>'               # layer4 @ RoIs conv1
-    assert plan(256, 7, 7, 512, 2048) == 'igemm_ring_kernel<128,128>'              # layer4 @ RoIs conv3
+    assert plan(256, 7, 7, 512, 2048) == 'igemm_dma256_kernel'                     # layer4 @ RoIs conv3: a wide plain GEMM -> the 256x256 LDS-DMA tile
+    assert plan(256, 7, 7, 1024, 2048) == 'igemm_dma256_kernel'                    # layer4[0].downsample
+    assert plan(256, 7, 7, 2048, 1024, form='dgrad') == 'igemm_dma256_kernel'      # ... and its data gradient (N = 1024)
+    assert plan(64, 7, 7, 512, 2048) == 'igemm_ring_kernel<128,64>'                # fewer than 4096 pixels: not worth 256-row tiles
     assert plan(1, 38, 63, 512, 512, 3) == 'igemm_p3_kernel<64,256>'               # layer4 on the map conv2
     assert plan(1, 38, 63, 512, 2048) == 'igemm_ring_kernel<128,64>'               # layer4 on the map conv3
     assert plan(1, 38, 63, 1024, 512, 3) == 'igemm_p3_kernel<64,256>'              # RPN 3x3
