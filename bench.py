@@ -55,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
     ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
     ap.add_argument('--wgrad-minm', type=int, default=0, help='A/B only: pixels from which a 3x3 weight gradient takes the LDS-DMA filter-row tile')
+    ap.add_argument('--wgrad-min-wg', type=int, default=0, help='A/B only: WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
+    ap.add_argument('--wgrad-v4-fill', type=int, default=0, help='A/B only: WgradQueue.V4_FILL (workgroups the 256x256 weight-gradient launch splits its pixels up to)')
     ap.add_argument('--wgrad-wide', type=int, default=-1, help='A/B only: 1 / 0 = 3x3 problems with 512+ channels take the LDS-DMA filter-row tile at any pixel count')
     ap.add_argument('--wgrad-wgs', type=int, default=0, help='A/B only: workgroups of the stream-K launch of the LDS-DMA filter-row tile (default 256 = one per CU)')
     ap.add_argument('--wgrad-cap', type=int, default=0, help='A/B only: at most this many workgroups per grouped weight-gradient launch')
@@ -468,6 +470,12 @@ def main(argv=None):
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
     if args.sgd_early >= 0:
         optim.early = bool(args.sgd_early)
+    if args.wgrad_min_wg > 0:
+        from lang2seg_amd.nets.network import WgradQueue as _WQ2
+        _WQ2.MIN_WG = args.wgrad_min_wg
+    if args.wgrad_v4_fill > 0:
+        from lang2seg_amd.nets.network import WgradQueue as _WQ
+        _WQ.V4_FILL = args.wgrad_v4_fill
     if args.wgrad_wide >= 0:
         from lang2seg_amd import _lib as _L5
         _L5.load().l2s_wgrad_row3_dma(65, args.wgrad_wide)

@@ -164,7 +164,7 @@ class WgradQueue(object):
                     total = sum(tiles)
                     want = max(1, -(-self.MIN_WG // max(total, 1)))
                     if v == 4:
-                        want = max(1, 256 // max(total, 1))       # one 8-wave workgroup per CU: fill one round, not more
+                        want = max(1, self.V4_FILL // max(total, 1))   # one 8-wave workgroup per CU: fill one round, not more
                     arr = (WgradProb * len(chunk))()
                     flop, off = 0.0, 0
                     for i, seg in enumerate(chunk):
@@ -209,7 +209,11 @@ class WgradQueue(object):
                     if ctx is not None:
                         ctx.__exit__(None, None, None)
 
-    MIN_WG = 384   # workgroups a grouped launch should have before its problems stop splitting their pixels
+    MIN_WG = 256   # workgroups a grouped launch should have before its problems stop splitting their pixels (384 until round 4: 208.5 -> 209.1 img/s, x4)
+    # workgroups the 256x256 launch splits its pixels up to.  Round 4: 128, i.e. layer4's 120 tiles are NOT split any more - 120 workgroups on 120 CUs
+    # leave the other CUs to the data-gradient chain (as the LDS-DMA filter-row launch does), and the slabs + reduce of the split are gone:
+    # 202.0 -> 205.6 img/s, same box x 3
+    V4_FILL = 128
 
 
 class Bottleneck(object):
