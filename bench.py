@@ -56,6 +56,8 @@ def parse_args(argv=None):
     ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
     ap.add_argument('--wgrad-minm', type=int, default=0, help='A/B only: pixels from which a 3x3 weight gradient takes the LDS-DMA filter-row tile')
     ap.add_argument('--wgrad-min-wg', type=int, default=0, help='A/B only: WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
+    ap.add_argument('--wgrad-v5-stream', default='', help='A/B only: WgradQueue.V5_STREAM (tr: the filter-row launch beside the 256x256 one)')
+    ap.add_argument('--wgrad-small-tile', type=int, default=-1, help='A/B only: WgradQueue.SMALL_M_TILE')
     ap.add_argument('--wgrad-v4-fill', type=int, default=0, help='A/B only: WgradQueue.V4_FILL (workgroups the 256x256 weight-gradient launch splits its pixels up to)')
     ap.add_argument('--wgrad-wide', type=int, default=-1, help='A/B only: 1 / 0 = 3x3 problems with 512+ channels take the LDS-DMA filter-row tile at any pixel count')
     ap.add_argument('--wgrad-wgs', type=int, default=0, help='A/B only: workgroups of the stream-K launch of the LDS-DMA filter-row tile (default 256 = one per CU)')
@@ -473,6 +475,12 @@ def main(argv=None):
     if args.wgrad_min_wg > 0:
         from lang2seg_amd.nets.network import WgradQueue as _WQ2
         _WQ2.MIN_WG = args.wgrad_min_wg
+    if args.wgrad_v5_stream:
+        from lang2seg_amd.nets.network import WgradQueue as _WQ4
+        _WQ4.V5_STREAM = args.wgrad_v5_stream
+    if args.wgrad_small_tile >= 0:
+        from lang2seg_amd.nets.network import WgradQueue as _WQ3
+        _WQ3.SMALL_M_TILE = args.wgrad_small_tile
     if args.wgrad_v4_fill > 0:
         from lang2seg_amd.nets.network import WgradQueue as _WQ
         _WQ.V4_FILL = args.wgrad_v4_fill

@@ -146,15 +146,24 @@ class WgradQueue(object):
                 dw, g, x, n, IH, IW, Cin, OH, OW, Cout, k, stride, pad, lddy, ldx = seg[0]
                 M = max(u[3] * u[7] * u[8] for u in seg)
                 same = all(u[7] == u[4] and u[8] == u[5] for u in seg)
-                v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, stride, pad, int(same), M, 256 if net.dt == BF16 else 0))   # (256: the 8-wave 256x256 tile may be chosen)
+                tl = 256 if net.dt == BF16 else 0                   # (256: the 8-wave 256x256 tile / the LDS-DMA filter-row tile may be chosen)
+                if self.SMALL_M_TILE and net.dt == BF16 and M < 8192 and Cin >= 256 and Cout >= 256 and Cin % 128 == 0 and Cout % 128 == 0:
+                    tl = self.SMALL_M_TILE                          # A/B: 128-wide tiles for the backbone's problems (layer3)
+                v = int(lib.l2s_wgrad_variant(Cin, Cout, k, k, stride, pad, int(same), M, tl))
                 rounds.setdefault((r // 2, v), []).append(seg)
         bkp = 32 if net.dt == BF16 else 16
         # a tensor's first problem of the step WRITES its gradient (l2s_wgrad_prob.flags = 1: no read of dW, and the update need not clear it,
         # ParamStore.mark_overwritten); later contributions (a third use) add.  Network._fresh: the tensors written so far in this backward pass.
         fresh = getattr(net, '_fresh', None) if getattr(net, 'wgrad_overwrite', False) else None
-        with net.fork_wgrad(fixed='wg'):
-            ws = net.wgrad_ws()
-            for (rnd, v) in sorted(rounds):
+        order = sorted(rounds)
+        # A/B (V5_STREAM): the LDS-DMA filter-row launch (128 workgroups) on another stream, beside the 120-workgroup 256x256 launch
+        plan = [('wg', order)]
+        if self.V5_STREAM != 'wg' and net.use_streams and getattr(net, 'dp', None) is None and (0, 5) in rounds and (0, 4) in rounds:
+            plan = [(self.V5_STREAM, [(0, 5)]), ('wg', [o for o in order if o != (0, 5)])]
+        for sname, keys in plan:
+          with net.fork_wgrad(fixed=sname):
+            ws = net.wgrad_ws() if sname == 'wg' else net.wgrad_ws(alt=True)
+            for (rnd, v) in keys:
                 probs = rounds[(rnd, v)]
                 for c0 in range(0, len(probs), 64):
                     chunk = probs[c0:c0 + 64]
@@ -209,6 +218,8 @@ class WgradQueue(object):
                     if ctx is not None:
                         ctx.__exit__(None, None, None)
 
+    V5_STREAM = 'wg'   # A/B: 'tr' = the filter-row launch of a stage beside the stage's other launches instead of behind them
+    SMALL_M_TILE = 0   # A/B: tile argument for problems with fewer than 8192 pixels (128: 128x128 / 128x64-row tiles instead of 64x64)
     MIN_WG = 256   # workgroups a grouped launch should have before its problems stop splitting their pixels (384 until round 4: 208.5 -> 209.1 img/s, x4)
     # workgroups the 256x256 launch splits its pixels up to.  Round 4: 128, i.e. layer4's 120 tiles are NOT split any more - 120 workgroups on 120 CUs
     # leave the other CUs to the data-gradient chain (as the LDS-DMA filter-row launch does), and the slabs + reduce of the split are gone:
@@ -362,8 +373,12 @@ class Network(object):
 
     WGRAD_WS_BYTES = 128 << 20       # (the stream-K launch of the large 3x3 problems needs 2 slabs of 192 KiB per workgroup: 101 MB)
 
-    def wgrad_ws(self):
+    def wgrad_ws(self, alt=False):
         """split-K slabs of the grouped weight-gradient launches (one buffer: they all run on the 'wg' stream, in order)"""
+        if alt:                                              # (A/B: a second buffer for a launch that runs on another stream)
+            if getattr(self, '_wg_ws2', None) is None:
+                self._wg_ws2 = torch.empty((64 << 20) // 4, dtype=torch.float32, device=self.device)
+            return self._wg_ws2
         ws = getattr(self, '_wg_ws', None)
         if ws is None:
             ws = self._wg_ws = torch.empty(self.WGRAD_WS_BYTES // 4, dtype=torch.float32, device=self.device)

@@ -158,7 +158,7 @@ class SGD(object):
             S = net.streams()
             for k in ('wg2', 'lang', 'cap'):
                 net.sfork(S[k], S['wg'])
-            if self._seg_done:
+            if self._seg_done or getattr(net.wgq, 'V5_STREAM', 'wg') == 'tr':
                 net.sfork(S['tr'], S['wg'])               # early partial updates of this step (SGD.early) ran on the transpose stream
             net.sfork(torch.cuda.current_stream(), S['wg'])
             with torch.cuda.stream(S['wg']):
