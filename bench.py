@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
     ap.add_argument('--wgrad-minm', type=int, default=0, help='A/B only: pixels from which a 3x3 weight gradient takes the LDS-DMA filter-row tile')
     ap.add_argument('--wgrad-min-wg', type=int, default=0, help='A/B only: WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
+    ap.add_argument('--wgrad-1x1-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA 256x256 tile for the large 1x1 weight gradients on / off')
     ap.add_argument('--wgrad-v5-stream', default='', help='A/B only: WgradQueue.V5_STREAM (tr: the filter-row launch beside the 256x256 one)')
     ap.add_argument('--wgrad-small-tile', type=int, default=-1, help='A/B only: WgradQueue.SMALL_M_TILE')
     ap.add_argument('--wgrad-v4-fill', type=int, default=0, help='A/B only: WgradQueue.V4_FILL (workgroups the 256x256 weight-gradient launch splits its pixels up to)')
@@ -303,7 +304,7 @@ class LaunchTimer(object):
 
     def wgrad_hook(self, tag, variant, flop, k):
         """context around one grouped weight-gradient launch (all weight gradients of a backward stage with one tile variant)"""
-        names = ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3', '256x256/tap', '128x128/row3-dma')
+        names = ('64x64/tap', '128x128/tap', '64x64/row3', '128x64/row3', '256x256/tap', '128x128/row3-dma', '256x256/tap-dma')
         if not self.on and self.tape_all:
             lt = self
 
@@ -475,6 +476,9 @@ def main(argv=None):
     if args.wgrad_min_wg > 0:
         from lang2seg_amd.nets.network import WgradQueue as _WQ2
         _WQ2.MIN_WG = args.wgrad_min_wg
+    if args.wgrad_1x1_dma >= 0:
+        from lang2seg_amd import _lib as _L9
+        _L9.load().l2s_wgrad_row3_dma(67, args.wgrad_1x1_dma)
     if args.wgrad_v5_stream:
         from lang2seg_amd.nets.network import WgradQueue as _WQ4
         _WQ4.V5_STREAM = args.wgrad_v5_stream

@@ -357,6 +357,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 // (4 and 5: bf16 grouped launches only; `tile` = 256 allows them) ----
 int g_wgrad_row3_dma_wgs = 128;   // workgroups of the stream-K launch: half the CUs (a workgroup owns its CU - 132 KB of LDS, 240 VGPRs x 8 waves -
                                   // and the other queues' launches need somewhere to run: 96 / 128 / 160 / 256 -> 190.1 / 189.1 / 189.0 / 185.5 img/s, same box x 3)
+int g_wgrad_1x1_dma = 0;    // 1: the large 1x1 problems take the LDS-DMA 256x256 tile of conv_wgrad_dma1.hip (variant 6) - built, tested, and no faster:
+                            // 447-455 against 425-431 us alone on 120 CUs, 206.9 against 208.4 img/s in the step; both tiles move 32 KB per slice and CU in ~0.95 us
 int g_wgrad_row3_dma = 1;   // tools: 0 sends the large 3x3 problems back to the register-staged filter-row tile (A/B)
 int g_wgrad_row3_wide = 1;         // 512+ channels on both sides (RPN's 3x3 on the map): the tile from any pixel count (its stream-K launch needs no pixel split)
 int g_wgrad_row3_min_m = 8192;     // pixels from which a 3x3 problem takes the LDS-DMA filter-row tile
@@ -365,11 +367,12 @@ int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_
   const bool big = M >= 8192 && Cout >= 512 && Cin >= 512;
   if (row3 && tile == 256 && g_wgrad_row3_dma && (M >= g_wgrad_row3_min_m || (g_wgrad_row3_wide && Cin >= 512 && Cout >= 512)) && Cout % 128 == 0 && Cin % 128 == 0) return 5;
   if (row3) return (tile == 128 || ((!tile || tile == 256) && Cout >= 512)) ? 3 : 2;
+  if (g_wgrad_1x1_dma && tile == 256 && big && KH * KW == 1 && stride == 1 && pad == 0 && same_hw && Cout % 256 == 0 && Cin % 256 == 0) return 6;
   if (tile == 256 && big && KH * KW == 1 && Cout % 256 == 0 && Cin % 256 == 0) return 4;
   return (tile == 128 || ((!tile || tile == 256) && big && KH * KW == 1)) ? 1 : 0;
 }
 void variant_tile(int v, int& bm, int& bn, int& tx) {
-  if (v == 4) { bm = 256; bn = 256; tx = 1; return; }
+  if (v == 4 || v == 6) { bm = 256; bn = 256; tx = 1; return; }
   if (v == 5) { bm = 128; bn = 128; tx = 3; return; }
   bm = (v == 1 || v == 3) ? 128 : 64; bn = v == 1 ? 128 : 64; tx = v >= 2 ? 3 : 1;
 }
@@ -446,6 +449,7 @@ bool prob_ok(const wgp& p, int dtype) {
 }  // namespace
 
 extern "C" int l2s_wgrad_row3_dma(int on, int wgs) {
+  if (on == 67) { g_wgrad_1x1_dma = wgs; return wgs; }                                  // tools: 67, 1 / 0 = the LDS-DMA 1x1 tile on / off
   if (on == 65) { g_wgrad_row3_wide = wgs; return wgs; }
   if (on == 64) { if (wgs > 0) g_wgrad_row3_min_m = wgs; return g_wgrad_row3_min_m; }   // tools: 64, m = pixel threshold of the tile
   if (on >= 32) { l2s::g_row3_plan_mode = on - 32; return g_wgrad_row3_dma; } // tools: 32 / 33 = contiguous stream-K ranges always / XCD-lockstep plan where it applies
@@ -463,7 +467,12 @@ extern "C" long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW) 
 
 extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
                                       float* ws, size_t ws_bytes, hipStream_t stream) {
-  if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 5) return L2S_EINVAL;
+  if (!table_dev || !table_host || nprob < 1 || nprob > L2S_WGRAD_MAX_GROUP || variant < 0 || variant > 6) return L2S_EINVAL;
+  if (variant == 6) {
+    if (dtype != L2S_BF16) return L2S_EINVAL;
+    for (int i = 0; i < nprob; ++i) if (!prob_ok(table_host[i], dtype) || !table_host[i].dw) return L2S_EINVAL;
+    return l2s::wgrad_1x1_dma_launch(table_dev, table_host, nprob, stream);
+  }
   if (variant == 5) {
     if (dtype != L2S_BF16) return L2S_EINVAL;
     for (int i = 0; i < nprob; ++i) if (!prob_ok(table_host[i], dtype) || !table_host[i].dw) return L2S_EINVAL;

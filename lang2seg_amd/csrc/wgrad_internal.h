@@ -12,5 +12,10 @@ extern int g_row3_form, g_row3_plan_mode;
 bool wgrad_row3_dma_ok(const l2s_wgrad_prob& q);
 long wgrad_row3_dma_tiles(int Cin, int Cout);
 size_t wgrad_row3_dma_ws_bytes(int G);
+// the LDS-DMA 256x256 tile of the large 1x1 problems (conv_wgrad_dma1.hip): one workgroup per tile, problem i owns tiles [tile0[i], tile0[i + 1])
+struct wgrad_tile_prefix { int n; int tile0[L2S_WGRAD_MAX_GROUP + 1]; };
+bool wgrad_1x1_dma_ok(const l2s_wgrad_prob& q);
+long wgrad_1x1_dma_tiles(int Cin, int Cout);
+int wgrad_1x1_dma_launch(const l2s_wgrad_prob* tab_dev, const l2s_wgrad_prob* tab_host, int nprob, hipStream_t st);
 int wgrad_row3_dma_launch(const l2s_wgrad_prob* tab_dev, const l2s_wgrad_prob* tab_host, int nprob, float* ws, size_t ws_bytes, int G, hipStream_t st);
 }

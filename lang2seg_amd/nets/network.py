@@ -186,8 +186,8 @@ class WgradQueue(object):
                             fresh.add(dw.data_ptr())
                         slices = min(u[3] * u[7] * (u[8] + (1 if v in (2, 3, 5) else 0)) // bkp for u in seg)
                         split = max(1, min(want, slices // 16, 16))
-                        if v == 5:
-                            split = 1                                   # the LDS-DMA filter-row launch balances itself (stream-K, slabs per workgroup)
+                        if v in (5, 6):
+                            split = 1                                   # the LDS-DMA launches: stream-K balanced (5) / one workgroup per 256x256 tile on purpose (6)
                         slab = Cout * k * k * Cin
                         if split > 1 and (off + split * slab) * 4 <= ws.numel() * 4:
                             q.split, q.ws_off = split, off

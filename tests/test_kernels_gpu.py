@@ -514,6 +514,11 @@ def test_conv_wgrad_grouped(dt):
         byv.setdefault(v, []).append((q, dw, ohwi(ref).reshape(Cout, k * k * Cin) + 1.0))
     assert len(byv) >= 3                                        # per-tap and filter-row tiles, 64- and 128-wide
     assert (4 in byv) == (dt == 1) and (5 in byv) == (dt == 1)
+    if 4 in byv:                                                # the LDS-DMA 256x256 tile (variant 6, on request only) on copies of the register-staged tile's problems
+        byv[6] = []
+        for q, dw, ref in byv[4]:
+            q6 = WgradProb.from_buffer_copy(bytes(q)); dw6 = torch.ones_like(dw); q6.dw = dw6.data_ptr()
+            byv[6].append((q6, dw6, ref))
     first = {}
     for rep in range(4):                                        # 2, 3: flags = 1 - the gradient is written, whatever dW held (unsplit / split)
         for v, lst in byv.items():
@@ -524,7 +529,7 @@ def test_conv_wgrad_grouped(dt):
             for q_ in arr:
                 q_.flags = int(rep >= 2)
             tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
-            if rep in (1, 3) and v != 5:                         # pixels of the first problem cut into 3 ranges (slabs, fixed-order sum)
+            if rep in (1, 3) and v not in (5, 6):                # pixels of the first problem cut into 3 ranges (slabs, fixed-order sum)
                 arr[0].split, arr[0].ws_off = 3, 0
                 tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
             ws = torch.empty(max(8 << 20, int(lib.l2s_wgrad_grouped_ws_bytes(v)) // 4), dtype=torch.float32, device=DEV)
@@ -534,7 +539,7 @@ def test_conv_wgrad_grouped(dt):
                 assert rel_err(dw, ref - (1.0 if rep >= 2 else 0.0)) < 1e-4, (v, rep, i)
                 if rep == 0:
                     first[(v, i)] = dw.clone()
-                elif rep == 1 and (i > 0 or v == 5):
+                elif rep == 1 and (i > 0 or v in (5, 6)):
                     assert torch.equal(dw, first[(v, i)])       # unsplit problems: bit-identical from run to run
 
 

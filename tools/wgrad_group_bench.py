@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--only', default='', help='substring of the stage names to run')
     ap.add_argument('--wgs', type=int, default=0, help='workgroups of its stream-K launch')
     ap.add_argument('--check', type=int, default=0, help='1: compare the layer4 3x3 weight gradients of the two filter-row kernels')
+    ap.add_argument('--dma1', type=int, default=-1, help='1 / 0: the LDS-DMA 256x256 tile for the large 1x1 problems on / off')
     ap.add_argument('--minm', type=int, default=0, help='pixels from which a 3x3 problem takes the LDS-DMA filter-row tile')
     ap.add_argument('--min-wg', type=int, default=0, help='WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
     args = ap.parse_args()
@@ -23,6 +24,8 @@ def main():
         from lang2seg_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args.lib)
     from lang2seg_amd import ops as O, _lib as L_
+    if args.dma1 >= 0:
+        L_.load().l2s_wgrad_row3_dma(67, args.dma1)
     if args.minm:
         L_.load().l2s_wgrad_row3_dma(64, args.minm)
     if args.plan >= 0:
