@@ -2516,6 +2516,10 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     const int K = d->KH * d->KW * d->Cin;
     const double wbytes = (double)d->Cout * K * esz, abytes = (double)d->n_img * d->IH * d->IW * d->Cin * esz;
     dd.xcd_mode = (wbytes + abytes / 8.0 <= 3.0 * 1024 * 1024) ? 0 : 1;
+    // 1x1: chunks along M even where that sum is larger (round 4, tools/conv_bench.py 0 <mode>: layer4 on the RoIs conv1 39.0 -> 34.2 us, conv3's data
+    // gradient 39.4 -> 36.1, downsample 74.5 -> 70.7 / 63.0 -> 56.3, layer4 on the map conv3's data gradient 19.9 -> 16.7; the 3x3 launches, whose
+    // W is nine times larger per channel pair, keep the rule: 62.7 against 64.2 us with N-chunks)
+    if (d->KH * d->KW == 1) dd.xcd_mode = 0;
   }
 #define BYT(CALL_BF, CALL_F32) (dtype == L2S_BF16 ? (CALL_BF) : (CALL_F32))
 #define OUT(NAME, T, ...) (f32o ? NAME<T, __VA_ARGS__, true>(dd, stream) : NAME<T, __VA_ARGS__, false>(dd, stream))
