@@ -35,51 +35,57 @@ STEP_FLOP = 2.0 * (321.29e9 + 2.0 * (321.29e9 - 9.40e9))
 PEAK_BF16 = 2.5e15      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
+VARIANT_CHOICES = ('cycle', 'baseline', 'spatial', 'cycle_response', 'vgg')
+# algorithmic work per image-step (BASELINE.md section 2 / SURVEY.md section 8d), TFLOP: forward + 2 x (forward - frozen prefix)
+VARIANT_TFLOP = {'cycle': 1.89, 'baseline': 1.68, 'spatial': 1.68, 'cycle_response': 2.10, 'vgg': 1.09}
+# expression length / vocabulary: refcocog (umd) for the headline and config 4, refcoco(+) (unc) for configs 1, 2 and 5
+VARIANT_TV = {'cycle': (20, 3349), 'cycle_response': (20, 3349), 'baseline': (10, 1999), 'spatial': (10, 1999), 'vgg': (10, 1999)}
+VARIANT_DESC = {'cycle': 'ResNet-101 C4 + 7 spatial dynamic filters + att2in2 cycle loss',
+                'baseline': 'ResNet-101 C4 + 1 dynamic filter', 'spatial': 'ResNet-101 C4 + 7 spatial dynamic filters',
+                'cycle_response': 'ResNet-101 C4 + 7 spatial dynamic filters (sigmoid gating, response loss) + att2in2 cycle loss on the map before and after the gating',
+                'vgg': 'VGG16 conv5_3 Faster R-CNN (no mask branch) + 7 spatial dynamic filters (sigmoid gating, response loss)'}
+VARIANT_SCRIPT = {'cycle': 'train_cycle.sh', 'baseline': 'train_baseline.sh', 'spatial': 'train_spatial.sh', 'cycle_response': 'train_cycle_response.sh',
+                  'vgg': 'train_vgg.sh'}
+
+
+class Hooks(object):
+    """What tools/ab.py (A/B experiments, knock-outs, forced one-rank data parallel) can change around the measured run.  bench.py itself
+    runs with the defaults below: the product configuration, nothing patched."""
+    lib = ''                  # another build of the C-ABI library (tools/build_tools_lib.py); the line is marked
+    force_dp = False          # build the data-parallel reducer even for one rank
+    dp_skip_allreduce = 0     # EXPERIMENT: 1 = no collective, 2 = no reducer calls, 3 = no reducer; the line is marked invalid
+    dp_bucket_update = False
+    knockout = ''             # EXPERIMENT: leave parts of the step out (wgrad,cap); the line is marked invalid
+    tape, graph, main_prio = True, False, False
+    note = ''                 # what was changed, for the JSON line
+
+    def before_net(self):     # class attributes / library tunables, before the network exists
+        pass
+
+    def after_net(self, net):
+        pass
+
+    def after_optim(self, optim):
+        pass
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--variant', default='cycle', choices=VARIANT_CHOICES,
+                    help='network variant = BASELINE.json config: cycle (the headline, config 3), baseline (1), spatial (2), cycle_response (4), vgg (5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--fuse-roialign', type=int, default=0, help='A/B only: 1 = RoIAlign, layer4[0].conv1 and layer4[0].downsample as one launch (cfg.TRAIN.FUSE_ROIALIGN)')
-    ap.add_argument('--conv-algo', type=int, default=0, help='A/B only: l2s_conv_desc.algo for every convolution (0 = auto, 1 = register-staged tiles, 2 = LDS-DMA tile)')
-    ap.add_argument('--sgd-early', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.early on / off (update each finished prefix of the flat buffer during backward; one rank only)')
-    ap.add_argument('--wgrad-overwrite', type=int, default=-1, help='A/B only: 1 / 0 = Network.wgrad_overwrite (first weight-gradient problem of a tensor writes dW; the update skips its clear)')
-    ap.add_argument('--dma256', type=int, default=-1, help='A/B only: 1 / 0 = the 256x256 LDS-DMA tile for wide plain GEMMs on / off (l2s_conv_dma256)')
-    ap.add_argument('--roi-pdma', type=int, default=-1, help='A/B only: N > 0 = the RoI head\'s wide 1x1 GEMMs on the persistent LDS-DMA tile with N resident workgroups (256 = one per CU)')
-    ap.add_argument('--cap-map-prio', type=int, default=-1, help='A/B only: Network.cap_map_prio')
-    ap.add_argument('--rpn-early', type=int, default=-1, help='A/B only: bit 0 = Network.rpn_bwd_early, bit 1 = rpn_wgrad_early')
-    ap.add_argument('--join-l1', type=int, default=-1, help='A/B only: 1 = layer1 waits for the previous update too')
-    ap.add_argument('--stem-mfma', type=int, default=-1, help='A/B only: 1 / 0 = Network.stem_mfma (bf16: stem + pooling as one matrix-core launch)')
-    ap.add_argument('--defer', type=int, default=-1, help='A/B only: 1 / 0 = optim.SGD.defer on / off (heads-stage weight gradients + their update behind the rest of the update)')
-    ap.add_argument('--wgrad-row3-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA filter-row weight-gradient tile for the large 3x3 problems on / off')
-    ap.add_argument('--wgrad-minm', type=int, default=0, help='A/B only: pixels from which a 3x3 weight gradient takes the LDS-DMA filter-row tile')
-    ap.add_argument('--wgrad-min-wg', type=int, default=0, help='A/B only: WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
-    ap.add_argument('--wgrad-1x1-dma', type=int, default=-1, help='A/B only: 1 / 0 = the LDS-DMA 256x256 tile for the large 1x1 weight gradients on / off')
-    ap.add_argument('--wgrad-v5-stream', default='', help='A/B only: WgradQueue.V5_STREAM (tr: the filter-row launch beside the 256x256 one)')
-    ap.add_argument('--wgrad-small-tile', type=int, default=-1, help='A/B only: WgradQueue.SMALL_M_TILE')
-    ap.add_argument('--wgrad-v4-fill', type=int, default=0, help='A/B only: WgradQueue.V4_FILL (workgroups the 256x256 weight-gradient launch splits its pixels up to)')
-    ap.add_argument('--wgrad-wide', type=int, default=-1, help='A/B only: 1 / 0 = 3x3 problems with 512+ channels take the LDS-DMA filter-row tile at any pixel count')
-    ap.add_argument('--wgrad-wgs', type=int, default=0, help='A/B only: workgroups of the stream-K launch of the LDS-DMA filter-row tile (default 256 = one per CU)')
-    ap.add_argument('--wgrad-cap', type=int, default=0, help='A/B only: at most this many workgroups per grouped weight-gradient launch')
-    ap.add_argument('--sgd-blocks', type=int, default=0, help='A/B only: persistent workgroups of the update kernel')
-    ap.add_argument('--lib', default='', help='A/B only: load this build of the C-ABI library instead of the in-tree one (tools/ab_build.sh <rev>); the line is marked')
     ap.add_argument('--cpu-baseline-steps', default='3,10', help='W,K: warm-up and timed steps of the CPU restatement (BASELINE.md section 3: 3 + 10, ~2-3 min on the GPU box)')
-    ap.add_argument('--tape', type=int, default=1, help='replay the step from the recorded multi-stream launch tape')
-    ap.add_argument('--graph', type=int, default=0, help='replay the step as one captured hipGraph (single GPU)')
-    ap.add_argument('--main-prio', type=int, default=0, help='run the main queue on a high-priority HIP stream instead of the null stream')
-    ap.add_argument('--force-dp', type=int, default=0, help='(testing) build the data-parallel reducer even for one rank')
     ap.add_argument('--dp-wire', default='', choices=['', 'fp32', 'bf16'], help='gradient buckets on the wire: fp32 (282 MB / step) or packed to bf16 (141 MB); default: bf16 for N > 1')
     ap.add_argument('--dp-algo', default='', choices=['', 'allreduce', 'rs_ag'], help='one all-reduce per bucket, or reduce-scatter + all-gather; default: rs_ag for N > 1')
     ap.add_argument('--dp-shard-update', type=int, default=-1, help='with rs_ag: every rank updates only its slice of a bucket and the WEIGHTS are all-gathered; default: on for N > 1')
-    ap.add_argument('--dp-bucket-update', type=int, default=-1, help='unsharded: 1 = every bucket is updated right behind its all-reduce, on the reducer\'s stream (one rank: 187.9 against 191.3 img/s without: off)')
     ap.add_argument('--mixed-shapes', type=int, default=1, help='extra leg: a stream of six different (image size, token count) shapes replayed from pre-recorded tapes')
     ap.add_argument('--height', type=int, default=600)
     ap.add_argument('--width', type=int, default=1000)
     ap.add_argument('--extras', type=int, default=1, help='0: only the headline timing (no synchronous / PCIe-inclusive / per-launch legs)')
-    ap.add_argument('--knockout', default='', help='EXPERIMENT: leave parts of the step out (wgrad,cap); the line is marked invalid')
-    ap.add_argument('--dp-skip-allreduce', type=int, default=0, help='EXPERIMENT: 1 = no collective, 2 = no reducer calls, 3 = no reducer; the line is marked invalid')
     ap.add_argument('--launcher-check', action='store_true', help='only bring the ranks up (gloo without GPUs), count them with an all-reduce, print the line')
     return ap.parse_args(argv)
 
@@ -266,6 +272,12 @@ class LaunchTimer(object):
             return li
         if k.startswith('rpn') or k == 'rpn_head_w':
             return 'rpn'
+        if k.startswith('vgg.features.'):              # VGG16: one group per convolution (conv1_2 ... conv5_3; conv1_1 is its own 3-channel kernel)
+            names = {2: 'conv1_2', 5: 'conv2_1', 7: 'conv2_2', 10: 'conv3_1', 12: 'conv3_2', 14: 'conv3_3', 17: 'conv4_1', 19: 'conv4_2', 21: 'conv4_3',
+                     24: 'conv5_1', 26: 'conv5_2', 28: 'conv5_3'}
+            return 'vgg.' + names.get(int(k.split('.')[2]), k)
+        if k.startswith('vgg.classifier.'):
+            return {'0': 'vgg.fc6', '3': 'vgg.fc7'}.get(k.split('.')[2], k)
         return 'heads'
 
     def _wrap(self, conv):
@@ -362,9 +374,10 @@ class LaunchTimer(object):
         return tab, stack, dom
 
 
-def main(argv=None):
+def main(argv=None, hooks=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    hooks = hooks or Hooks()
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
         return spawn_ranks(args, argv)
@@ -383,9 +396,9 @@ def main(argv=None):
     import numpy as np
     import torch
     import torch.distributed as dist
-    if args.lib:
+    if hooks.lib:
         from lang2seg_amd import _lib as _L
-        _L.LIB_PATH = os.path.abspath(args.lib)
+        _L.LIB_PATH = os.path.abspath(hooks.lib)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
 
     if args.launcher_check:
@@ -402,7 +415,7 @@ def main(argv=None):
         return 0
 
     torch.cuda.set_device(local)
-    use_dp = world > 1 or args.force_dp
+    use_dp = world > 1 or hooks.force_dp
     if use_dp:
         # no device_id: binding the process group to the device eagerly costs 7 % of the step on this stack even when no collective
         # is ever issued (112 vs 121 img/s at one rank); the communicator is created by the first all-reduce
@@ -412,100 +425,45 @@ def main(argv=None):
     from lang2seg_amd.optim import SGD
     from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
 
-    if args.main_prio:
+    if hooks.main_prio:
         torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
-    T, V = 20, 3349
+    variant = args.variant
+    T, V = VARIANT_TV[variant]
+    step_flop = STEP_FLOP if variant == 'cycle' else VARIANT_TFLOP[variant] * 1e12
     cfg.COMPUTE_DTYPE = args.dtype
     opt = dict(vocab_size=V, word_embedding_size=512, word_vec_size=512, rnn_hidden_size=512, bidirectional=1, word_drop_out=0.5,
                rnn_drop_out=0.2, rnn_num_layers=1, rnn_type='lstm', variable_lengths=1, C4_feat_dim=1024, cap_loss_weight=1.0,
                caption_model='att2in2', input_encoding_size=512, rnn_size=512, num_layers=1, drop_prob_lm=0.5, seq_length=T,
                fc_feat_size=4096, att_feat_size=4096, att_hid_size=512)
     np.random.seed(cfg.RNG_SEED)
-    if args.conv_algo:
-        from lang2seg_amd import ops as _O
-        _O.CONV_ALGO = args.conv_algo
-    net = resnetv1(opt, batch_size=1, num_layers=101)
-    net.fuse_roialign = bool(args.fuse_roialign)
+    hooks.before_net()
+    if variant == 'vgg':
+        from lang2seg_amd.nets.vgg16 import vgg16
+        opt['C4_feat_dim'] = 512
+        net = vgg16(opt, batch_size=1)
+    else:
+        net = resnetv1(opt, batch_size=1, num_layers=101, variant=variant)
     net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     net.train()
     net.rank_seed = rank * 1000003
-    net.use_graph = bool(args.graph) and world == 1
-    net.use_tape = bool(args.tape)          # N > 1: the tape is cut at the gradient-bucket hand-offs (Network.tape_step)
-    net.knockout = frozenset(x for x in args.knockout.split(',') if x)
-    experiment = bool(net.knockout) or bool(args.dp_skip_allreduce)
+    net.use_graph = bool(hooks.graph) and world == 1
+    net.use_tape = bool(hooks.tape)          # N > 1: the tape is cut at the gradient-bucket hand-offs (Network.tape_step)
+    net.knockout = frozenset(x for x in hooks.knockout.split(',') if x)
+    hooks.after_net(net)
+    experiment = bool(net.knockout) or bool(hooks.dp_skip_allreduce)
     dp_desc = 'dp%d' % world
-    if use_dp and args.dp_skip_allreduce != 3:
+    if use_dp and hooks.dp_skip_allreduce != 3:
         from lang2seg_amd.parallel import GradReducer
         # N > 1 defaults (round 4): bf16 buckets, reduce-scatter + all-gather (direct exchanges over all seven xGMI links), sharded update
         dp_wire = args.dp_wire or ('bf16' if world > 1 else 'fp32')
         dp_algo = args.dp_algo or ('rs_ag' if world > 1 else 'allreduce')
         dp_shard = (args.dp_shard_update if args.dp_shard_update >= 0 else int(world > 1)) and dp_algo == 'rs_ag'
-        dp_bucket = (not dp_shard) and (args.dp_bucket_update > 0) and not args.dp_skip_allreduce
-        net.dp = GradReducer(net, world, skip_allreduce=args.dp_skip_allreduce, wire=dp_wire, algo=dp_algo, timing=True, rank=rank,
+        dp_bucket = (not dp_shard) and hooks.dp_bucket_update and not hooks.dp_skip_allreduce
+        net.dp = GradReducer(net, world, skip_allreduce=hooks.dp_skip_allreduce, wire=dp_wire, algo=dp_algo, timing=True, rank=rank,
                              shard_update=True if dp_shard else None, bucket_update=True if dp_bucket else None)
         dp_desc = 'dp%d (%s buckets, %s%s)' % (world, dp_wire, dp_algo, ', sharded update' if dp_shard else (', update per bucket' if dp_bucket else ''))
-    if args.defer >= 0:
-        SGD.defer = bool(args.defer)
-    if args.dma256 >= 0:
-        from lang2seg_amd import _lib as _L8
-        _L8.load().l2s_conv_dma256(args.dma256)
-    if args.roi_pdma > 0:
-        from lang2seg_amd.nets.network import Network as _Net6
-        from lang2seg_amd import _lib as _L6
-        _Net6.roi_pdma = True
-        _L6.load().l2s_conv_pdma_wgs(args.roi_pdma)
-    if args.cap_map_prio >= 0:
-        from lang2seg_amd.nets.network import Network as _Net5
-        _Net5.cap_map_prio = args.cap_map_prio
-    if args.rpn_early >= 0:
-        from lang2seg_amd.nets.network import Network as _Net4
-        _Net4.rpn_bwd_early = bool(args.rpn_early & 1)
-        _Net4.rpn_wgrad_early = bool(args.rpn_early & 2)
-    if args.join_l1 >= 0:
-        from lang2seg_amd.nets.network import Network as _Net3
-        _Net3.join_before_layer1 = bool(args.join_l1)
-    if args.stem_mfma >= 0:
-        from lang2seg_amd.nets.network import Network as _Net2
-        _Net2.stem_mfma = bool(args.stem_mfma)
-    if args.wgrad_overwrite >= 0:
-        from lang2seg_amd.nets.network import Network as _Net
-        _Net.wgrad_overwrite = bool(args.wgrad_overwrite)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
-    if args.sgd_early >= 0:
-        optim.early = bool(args.sgd_early)
-    if args.wgrad_min_wg > 0:
-        from lang2seg_amd.nets.network import WgradQueue as _WQ2
-        _WQ2.MIN_WG = args.wgrad_min_wg
-    if args.wgrad_1x1_dma >= 0:
-        from lang2seg_amd import _lib as _L9
-        _L9.load().l2s_wgrad_row3_dma(67, args.wgrad_1x1_dma)
-    if args.wgrad_v5_stream:
-        from lang2seg_amd.nets.network import WgradQueue as _WQ4
-        _WQ4.V5_STREAM = args.wgrad_v5_stream
-    if args.wgrad_small_tile >= 0:
-        from lang2seg_amd.nets.network import WgradQueue as _WQ3
-        _WQ3.SMALL_M_TILE = args.wgrad_small_tile
-    if args.wgrad_v4_fill > 0:
-        from lang2seg_amd.nets.network import WgradQueue as _WQ
-        _WQ.V4_FILL = args.wgrad_v4_fill
-    if args.wgrad_wide >= 0:
-        from lang2seg_amd import _lib as _L5
-        _L5.load().l2s_wgrad_row3_dma(65, args.wgrad_wide)
-    if args.wgrad_minm > 0:
-        from lang2seg_amd import _lib as _L4
-        _L4.load().l2s_wgrad_row3_dma(64, args.wgrad_minm)
-    if args.wgrad_row3_dma >= 0:
-        from lang2seg_amd import _lib as _L3
-        _L3.load().l2s_wgrad_row3_dma(args.wgrad_row3_dma, args.wgrad_wgs)
-    elif args.wgrad_wgs > 0:
-        from lang2seg_amd import _lib as _L3
-        _L3.load().l2s_wgrad_row3_dma(-1, args.wgrad_wgs)
-    if args.wgrad_cap > 0:
-        from lang2seg_amd import _lib as _L2
-        _L2.load().l2s_wgrad_grid_cap(args.wgrad_cap)
-    if args.sgd_blocks > 0:
-        from lang2seg_amd import ops as _O2
-        _O2.sgd_blocks(args.sgd_blocks)
+    hooks.after_optim(optim)
     loader = SyntheticLoader(num_images=4, sents_per_image=1, H=args.height, W=args.width, T=T, vocab_size=V, rank=rank)
     blobs = [loader.getBatch('train') for _ in range(4)]
     for b in blobs:
@@ -635,21 +593,21 @@ def main(argv=None):
             'metric': _baseline_metric(), 'value': val, 'unit': 'img/s', 'n_gpus': world, 'ranks_seen': ranks_seen,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'train_cycle.sh step: ResNet-101 C4 + 7 spatial dynamic filters + att2in2 cycle loss, %dx%d image, '
-                                   '20-token expression (V=3349), 12000->2000 proposals, 256 RoIs, per-GPU batch 1' % (args.height, args.width),
-                       'parallelism': dp_desc if use_dp else 'dp%d' % world, 'step_tflop': STEP_FLOP / 1e12,
+            'config': {'workload': '%s step: %s, %dx%d image, %d-token expression (V=%d), 12000->2000 proposals, 256 RoIs, per-GPU batch 1'
+                                   % (VARIANT_SCRIPT[variant], VARIANT_DESC[variant], args.height, args.width, T, V),
+                       'variant': variant, 'parallelism': dp_desc if use_dp else 'dp%d' % world, 'step_tflop': step_flop / 1e12,
                        'weights': 'random (reference initialisers; trunk BN gains scaled so activations stay O(1)), fixed seed',
                        'timed': 'K pipelined train steps (launch tape), losses read back once after the region'},
-            'step_tflops_per_gpu': STEP_FLOP / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': STEP_FLOP / (ms * 1e-3) / PEAK_BF16,
+            'step_tflops_per_gpu': step_flop / (ms * 1e-3) / 1e12, 'step_frac_of_bf16_peak': step_flop / (ms * 1e-3) / PEAK_BF16,
             'final_losses': [float(x) for x in lv[:7]],
         }
         out.update(extras)
         if 'sync_train_step' in extras:
             out['sync_train_step_value'] = extras['sync_train_step']['value']      # Network.train_step as the reference calls it (seven floats read back per step)
-        if args.lib:
-            out['lib'] = 'A/B run with ' + args.lib
+        if hooks.lib or hooks.note:
+            out['ab'] = 'A/B run (tools/ab.py): %s %s' % (hooks.note, hooks.lib)
         if experiment:
-            out['experiment'] = 'INVALID as a measurement: knockout=%s dp_skip_allreduce=%d' % (sorted(net.knockout), args.dp_skip_allreduce)
+            out['experiment'] = 'INVALID as a measurement: knockout=%s dp_skip_allreduce=%d' % (sorted(net.knockout), hooks.dp_skip_allreduce)
         if args.extras:
             tab, stack, dom = lt.summary(NE)
             dk = [r for r in lt.recs if r[0] == 'layer4@RoIs' and r[1] == 'fwd' and r[2] == 3]
@@ -657,12 +615,18 @@ def main(argv=None):
             kms_eager = float(np.mean([e0.elapsed_time(e1) for _, _, _, _, e0, e1 in dk])) if dk else float('nan')
             kms = float(np.mean(dom_ms)) if dom_ms else kms_eager
             ach = kflop / (kms * 1e-3) / 1e12
+            if not (dk or dom_ms):                       # a variant without layer4 on the RoIs (VGG): the best group of the table stands in
+                bn = max(tab, key=lambda n_: tab[n_]['frac']) if tab else None
+                if bn:
+                    kflop = tab[bn]['gflop_per_step'] * 1e9 / tab[bn]['launches_per_step']; kms = tab[bn]['ms_per_step'] / tab[bn]['launches_per_step']
+                    ach = tab[bn]['tflops']
             bt, balg, bkern, bfile = _pmc_traffic('best')
             dt_, dalg, dkern, dfile = _pmc_traffic('dominant')
             tnote = ('HBM/fabric-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of one launch of this kernel '
                      '(tools/pmc_traffic.sh -> profiles/%s; read side doubled per the gfx950 FETCH_SIZE correction); algorithmic bytes %s')
             best = {
-                'kernel': 'igemm_dma_kernel<256,128> on layer4@RoIs conv3x3 forward (M=%d,N=512,K=4608)' % (R * 49),
+                'kernel': ('igemm_dma_kernel<256,128> on layer4@RoIs conv3x3 forward (M=%d,N=512,K=4608)' % (R * 49)) if (dk or dom_ms) else
+                          ('%s: %s' % (bn, ' / '.join(tab[bn]['kernels'])) if bn else None),
                 'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': ach / (PEAK_BF16 / 1e12), 'traffic': bt,
                 'traffic_note': tnote % (bfile, balg),
                 'avg_launch_ms': kms, 'launches_timed': len(dom_ms) if dom_ms else len(dk), 'gflop_per_launch': kflop / 1e9,

@@ -43,10 +43,8 @@ int l2s_version(void);
 #define L2S_ALGO_KSPLIT 5      /* 64x64 tile, LDS-DMA fill by four requester waves, four multiplier waves splitting each slice's K */
 #define L2S_ALGO_KSPLIT_D3 6   /* the same with a ring of three LDS stages instead of four */
 #define L2S_ALGO_PATCH 3       /* 3x3 / stride 1 / pad 1 on one map: 128 pixels x 32 or 64 channels per workgroup, input patch staged once for the nine taps */
-#define L2S_ALGO_PDMA 7
+#define L2S_ALGO_PDMA 7           /* the LDS-DMA tile as ONE persistent workgroup per CU walking its tiles, requests running ahead across tile boundaries (plain GEMMs) */
 #define L2S_ALGO_DMA256 9          /* igemm_dma256_kernel: 256x256 LDS-DMA tile for wide plain GEMMs (chosen automatically for them) */
-int l2s_conv_dma256(int on);      /* tools: 1 / 0 = that automatic choice on / off (< 0: query) */
-int l2s_conv_pdma_wgs(int n);   /* tools: resident workgroups of the persistent LDS-DMA tile (0 = one per CU; < 0 = query) */        /* the LDS-DMA tile as ONE persistent workgroup per CU walking its tiles, requests running ahead across tile boundaries (plain GEMMs) */
 #define L2S_ALGO_WS64_STAMPED 8  /* the 64x64 wave-specialised tile with clock stamps per workgroup in ws (tools/ws64_stamps.py) */
 typedef struct {
   const void* x;      /* [n_img, IH, IW, ldx] activations (dtype) */
@@ -116,11 +114,8 @@ typedef struct {
 int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile);
 long l2s_wgrad_tiles(int variant, int Cin, int Cout, int KH, int KW);
 /* variant 5 (bf16, 3x3 / stride 1 / pad 1, >= 8192 pixels, channels multiples of 128): the LDS-DMA filter-row tile, balanced stream-K style
- * over `wgs` workgroups; its slabs need l2s_wgrad_grouped_ws_bytes(5) of workspace.  l2s_wgrad_row3_dma(on, wgs): tools (A/B); < 0 / <= 0 keep */
-int l2s_wgrad_row3_dma(int on, int wgs);
+ * over 128 workgroups; its slabs need l2s_wgrad_grouped_ws_bytes(5) of workspace. */
 size_t l2s_wgrad_grouped_ws_bytes(int variant);
-/* tools: cap the workgroups of a grouped launch (each then walks several tiles); 0 = one workgroup per tile, < 0 = query */
-int l2s_wgrad_grid_cap(int cap);
 int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s_wgrad_prob* table_host, int nprob, int variant, int dtype,
                            float* ws, size_t ws_bytes, hipStream_t stream);
 int l2s_conv_wgrad(const l2s_wgrad_desc* d, int dtype, hipStream_t stream);
@@ -467,7 +462,6 @@ int l2s_sgd_momentum_range(float* param, float* grad, float* mom, const l2s_sgd_
                            float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int flags,
                            long lo, long hi, int chunk_lo, int chunk_hi, hipStream_t s);
 int l2s_sgd_chunk(void);          /* elements of one work chunk of the update kernel */
-int l2s_sgd_blocks(int blocks);   /* tools: persistent workgroups of the update (<= 0: query); returns the value in force */
 int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
                      float lr, float momentum, float wd, float grad_scale, void* shadow /*optional: dtype copy of rowscale*param at the same offsets*/,
                      int shadow_dtype, int clear_grad /*1: the gradient is zeroed as it is read (optimizer.zero_grad() of train_val_cycle.py:383 folded in)*/,

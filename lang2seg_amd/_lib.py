@@ -75,8 +75,6 @@ SIGS = {
     'l2s_colsum': (i32, [vp, i32, i32, i32, vp, vp, i64, i32, vp]),
     'l2s_weight_transpose_batched': (i32, [vp, i32, i32, i32, vp]),
     'l2s_stem_conv': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    'l2s_conv_pdma_wgs': (i32, [i32]),
-    'l2s_conv_dma256': (i32, [i32]),
     'l2s_stem_pack_bytes': (C.c_size_t, []),
     'l2s_stem_pack': (i32, [vp, vp, vp]),
     'l2s_stem_pool_bf16': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -159,12 +157,9 @@ SIGS = {
     'l2s_cap_attention_bwd_batched': (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'l2s_logsoftmax_nll': (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]),
     'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, i32, vp]),
-    'l2s_wgrad_grid_cap': (i32, [i32]),
-    'l2s_wgrad_row3_dma': (i32, [i32, i32]),
     'l2s_wgrad_grouped_ws_bytes': (sz, [i32]),
     'l2s_sgd_momentum_range': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, i32, i64, i64, i32, i32, vp]),
     'l2s_sgd_chunk': (i32, []),
-    'l2s_sgd_blocks': (i32, [i32]),
     'l2s_mul_f32': (i32, [vp, vp, vp, i64, vp]),
     'l2s_add_f32': (i32, [vp, vp, vp, i64, vp]),
     'l2s_stream_fork': (i32, [vp, vp]),
@@ -209,6 +204,18 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def tools_set(name, value):
+    """A/B tools only: set a tunable of the TOOLS build of the library (csrc/knobs.h; tools/build_tools_lib.py builds it, a tool points
+    LIB_PATH at it before the first load()).  The product library has no such symbol - its tunables are compile-time constants - and this raises."""
+    lib = load()
+    fn = getattr(lib, 'l2s_tools_set', None)
+    if fn is None:
+        raise L2SError('%s is the product library: it has no tunables; build and load the tools library (tools/build_tools_lib.py)' % LIB_PATH)
+    fn.restype, fn.argtypes = i32, [C.c_char_p, i32]
+    if fn(name.encode(), int(value)) != 0:
+        raise L2SError('l2s_tools_set: unknown tunable %r' % name)
 
 
 def ptr(t):

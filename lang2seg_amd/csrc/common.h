@@ -1,5 +1,6 @@
 // Common device helpers for the lang2seg gfx950 kernels (wave64, CDNA4 only).
 #pragma once
+#include "knobs.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <stdint.h>

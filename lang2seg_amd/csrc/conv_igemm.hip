@@ -2389,12 +2389,11 @@ int launch_igemm_dma256(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
-int g_pdma_wgs = 0;
 template <int BM, int BN>
 int launch_igemm_pdma(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   const int G = cdiv(M, BM) * cdiv(d.Cout, BN);
-  const int cap = g_pdma_wgs > 0 ? (g_pdma_wgs & ~7) : 256;  // (tools: fewer resident workgroups than CUs leaves whole CUs to the other queues)
+  const int cap = l2s_knobs::pdma_wgs > 0 ? (l2s_knobs::pdma_wgs & ~7) : 256;  // (tools: fewer resident workgroups than CUs leaves whole CUs to the other queues)
   const int grid = G < cap ? ((G + 7) & ~7) : cap;     // one resident workgroup per CU, a multiple of 8 (the XCD-aware tile order)
   const size_t lds = (size_t)3 * (BM + BN) * ROWB + 8 * 2048;      // the ring + 2 KiB of epilogue staging per wave = 160 KiB
   static bool attr_done = false;
@@ -2405,9 +2404,6 @@ int launch_igemm_pdma(const l2s_conv_desc& d, hipStream_t st) {
 
 }  // namespace
 
-int g_dma256_auto = 1;   // tools: 0 sends the wide plain GEMMs back to the 128x128 ring tile
-extern "C" int l2s_conv_dma256(int on) { if (on >= 0) g_dma256_auto = on; return g_dma256_auto; }
-extern "C" int l2s_conv_pdma_wgs(int n) { if (n >= 0) g_pdma_wgs = n; return g_pdma_wgs; }   // tools: resident workgroups of the persistent LDS-DMA tile (0 = one per CU)
 
 // ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
 enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,
@@ -2460,7 +2456,7 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     // 256x128 tiles (layer4 on the RoIs: conv3, downsample and the data gradients of conv1 / downsample)
     const bool d256_ok = pdma_ok && d->Cout % 256 == 0 && d->Cout >= 1024 && M >= 4096 && !(d->ldy & 7) && !(d->Cout & 7) &&
                          !((uintptr_t)d->y & 15) && !(d->ldadd & 3) && !(d->ldref & 3);
-    if (d256_ok && (algo == L2S_ALGO_DMA256 || (algo == L2S_ALGO_AUTO && g_dma256_auto))) return PLAN_DMA256X256;
+    if (d256_ok && (algo == L2S_ALGO_DMA256 || (algo == L2S_ALGO_AUTO && l2s_knobs::dma256_auto))) return PLAN_DMA256X256;
     if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
     if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;
     // patch tile: 3x3 / stride 1 / pad 1 on one map whose row fits the patch (W + 1 <= 128 halo pixels on either side of 128 outputs)

@@ -287,7 +287,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const wgp p, int cblocks, fl
   wgrad_tile<T, BM, BN, TX, D>(p, blockIdx.x * BM, ci0, tg, blockIdx.z, gridDim.z, out, slab == 0, smem);
 }
 
-int g_wgrad_grid_cap = 0;   // > 0: at most this many workgroups per grouped launch, each walking several tiles (l2s_wgrad_grid_cap)
 
 // ---- a whole backward stage per launch: problems in a device table, workgroup -> (problem, tile) through the tile prefix ----
 struct wg_prefix { int n; int tile0[L2S_WGRAD_MAX_GROUP + 1]; };
@@ -355,19 +354,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 // ---- variants (tile, taps per workgroup): 0 = 64x64 per tap, 1 = 128x128 per tap, 2 = 64x64 filter row, 3 = 128(co)x64 filter row,
 // 4 = 256x256 per tap with 8 waves, 5 = the LDS-DMA 128x128 filter-row tile with stream-K balancing (conv_wgrad_dma.hip)
 // (4 and 5: bf16 grouped launches only; `tile` = 256 allows them) ----
-int g_wgrad_row3_dma_wgs = 128;   // workgroups of the stream-K launch: half the CUs (a workgroup owns its CU - 132 KB of LDS, 240 VGPRs x 8 waves -
-                                  // and the other queues' launches need somewhere to run: 96 / 128 / 160 / 256 -> 190.1 / 189.1 / 189.0 / 185.5 img/s, same box x 3)
-int g_wgrad_1x1_dma = 0;    // 1: the large 1x1 problems take the LDS-DMA 256x256 tile of conv_wgrad_dma1.hip (variant 6) - built, tested, and no faster:
-                            // 447-455 against 425-431 us alone on 120 CUs, 206.9 against 208.4 img/s in the step; both tiles move 32 KB per slice and CU in ~0.95 us
-int g_wgrad_row3_dma = 1;   // tools: 0 sends the large 3x3 problems back to the register-staged filter-row tile (A/B)
-int g_wgrad_row3_wide = 1;         // 512+ channels on both sides (RPN's 3x3 on the map): the tile from any pixel count (its stream-K launch needs no pixel split)
-int g_wgrad_row3_min_m = 8192;     // pixels from which a 3x3 problem takes the LDS-DMA filter-row tile
+// The choices below are constants of the product build (csrc/knobs.h):
+//  * wgrad_row3_dma_wgs = 128: the stream-K launch of the LDS-DMA filter-row tile takes half the CUs (a workgroup owns its CU - 132 KB of LDS, 240 VGPRs
+//    x 8 waves - and the other queues' launches need somewhere to run: 96 / 128 / 160 / 256 -> 190.1 / 189.1 / 189.0 / 185.5 img/s, same box x 3)
+//  * wgrad_1x1_dma = 0: the LDS-DMA 256x256 tile of conv_wgrad_dma1.hip (variant 6) for the large 1x1 problems is built, tested, and no faster:
+//    447-455 against 425-431 us alone on 120 CUs, 206.9 against 208.4 img/s in the step; both tiles move 32 KB per slice and CU in ~0.95 us
+//  * wgrad_row3_wide = 1: 512+ channels on both sides (RPN's 3x3 on the map) take the filter-row tile from any pixel count (its stream-K launch needs no pixel split)
+using namespace l2s_knobs;
 int variant_of(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   const bool row3 = KH == 3 && KW == 3 && stride == 1 && pad == 1 && same_hw;
   const bool big = M >= 8192 && Cout >= 512 && Cin >= 512;
-  if (row3 && tile == 256 && g_wgrad_row3_dma && (M >= g_wgrad_row3_min_m || (g_wgrad_row3_wide && Cin >= 512 && Cout >= 512)) && Cout % 128 == 0 && Cin % 128 == 0) return 5;
+  if (row3 && tile == 256 && wgrad_row3_dma && (M >= wgrad_row3_min_m || (wgrad_row3_wide && Cin >= 512 && Cout >= 512)) && Cout % 128 == 0 && Cin % 128 == 0) return 5;
   if (row3) return (tile == 128 || ((!tile || tile == 256) && Cout >= 512)) ? 3 : 2;
-  if (g_wgrad_1x1_dma && tile == 256 && big && KH * KW == 1 && stride == 1 && pad == 0 && same_hw && Cout % 256 == 0 && Cin % 256 == 0) return 6;
+  if (wgrad_1x1_dma && tile == 256 && big && KH * KW == 1 && stride == 1 && pad == 0 && same_hw && Cout % 256 == 0 && Cin % 256 == 0) return 6;
   if (tile == 256 && big && KH * KW == 1 && Cout % 256 == 0 && Cin % 256 == 0) return 4;
   return (tile == 128 || ((!tile || tile == 256) && big && KH * KW == 1)) ? 1 : 0;
 }
@@ -421,7 +420,7 @@ int launch_grouped(const wgp* tab, const wg_prefix& pre, float* ws, bool any_spl
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_grouped_kernel<T, BM, BN, TX, D, KSTEP, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
   int grid = pre.tile0[pre.n];
   {
-    const int cap = g_wgrad_grid_cap & 0xffff, vmask = g_wgrad_grid_cap >> 16;      // (tools: cap | variant mask << 16; mask 0 = every variant)
+    const int cap = l2s_knobs::wgrad_grid_cap & 0xffff, vmask = l2s_knobs::wgrad_grid_cap >> 16;      // (tools build: cap | variant mask << 16; mask 0 = every variant)
     const int var = BM == 256 ? 4 : (TX == 3 ? (BM == 128 ? 3 : 2) : (BM == 128 ? 1 : 0));
     if (cap > 0 && grid > cap && (vmask == 0 || ((vmask >> var) & 1))) grid = cap;
   }
@@ -448,18 +447,7 @@ bool prob_ok(const wgp& p, int dtype) {
 
 }  // namespace
 
-extern "C" int l2s_wgrad_row3_dma(int on, int wgs) {
-  if (on == 67) { g_wgrad_1x1_dma = wgs; return wgs; }                                  // tools: 67, 1 / 0 = the LDS-DMA 1x1 tile on / off
-  if (on == 65) { g_wgrad_row3_wide = wgs; return wgs; }
-  if (on == 64) { if (wgs > 0) g_wgrad_row3_min_m = wgs; return g_wgrad_row3_min_m; }   // tools: 64, m = pixel threshold of the tile
-  if (on >= 32) { l2s::g_row3_plan_mode = on - 32; return g_wgrad_row3_dma; } // tools: 32 / 33 = contiguous stream-K ranges always / XCD-lockstep plan where it applies
-  if (on >= 16) { l2s::g_row3_form = on - 16; return g_wgrad_row3_dma; }      // tools: 16 + mask = knock-outs of the kernel
-  if (on >= 0) g_wgrad_row3_dma = on;
-  if (wgs > 0) g_wgrad_row3_dma_wgs = wgs;
-  return g_wgrad_row3_dma;
-}
-extern "C" size_t l2s_wgrad_grouped_ws_bytes(int variant) { return variant == 5 ? l2s::wgrad_row3_dma_ws_bytes(g_wgrad_row3_dma_wgs) : 0; }
-extern "C" int l2s_wgrad_grid_cap(int cap) { if (cap >= 0) g_wgrad_grid_cap = cap; return g_wgrad_grid_cap; }
+extern "C" size_t l2s_wgrad_grouped_ws_bytes(int variant) { return variant == 5 ? l2s::wgrad_row3_dma_ws_bytes(l2s_knobs::wgrad_row3_dma_wgs) : 0; }
 extern "C" int l2s_wgrad_variant(int Cin, int Cout, int KH, int KW, int stride, int pad, int same_hw, long M, int tile) {
   return variant_of(Cin, Cout, KH, KW, stride, pad, same_hw, M, tile);
 }
@@ -476,7 +464,7 @@ extern "C" int l2s_conv_wgrad_grouped(const l2s_wgrad_prob* table_dev, const l2s
   if (variant == 5) {
     if (dtype != L2S_BF16) return L2S_EINVAL;
     for (int i = 0; i < nprob; ++i) if (!prob_ok(table_host[i], dtype) || !table_host[i].dw) return L2S_EINVAL;
-    return l2s::wgrad_row3_dma_launch(table_dev, table_host, nprob, ws, ws_bytes, g_wgrad_row3_dma_wgs, stream);
+    return l2s::wgrad_row3_dma_launch(table_dev, table_host, nprob, ws, ws_bytes, l2s_knobs::wgrad_row3_dma_wgs, stream);
   }
   wg_prefix pre;
   pre.n = nprob;

@@ -384,8 +384,6 @@ __global__ __launch_bounds__(256) void wgrad_row3_reduce_kernel(const wgp* __res
 
 namespace l2s {
 
-int g_row3_form = 0;   // tools: knock-out mask of the kernel (results are then garbage)
-int g_row3_plan_mode = 0;   // 1: the XCD-lockstep plan where it applies (tools; measured 272-281 us against 265-268 for the contiguous ranges)
 
 bool wgrad_row3_dma_ok(const l2s_wgrad_prob& q) {
   if (!(q.KH == 3 && q.KW == 3 && q.stride == 1 && q.pad == 1) || q.Cin % BN || q.Cout % BM || q.split > 1) return false;
@@ -426,7 +424,7 @@ int wgrad_row3_dma_launch(const l2s_wgrad_prob* tab_dev, const l2s_wgrad_prob* t
   // group and walk its slices together - each slab then crosses the fabric once per XCD - and the groups left over after 8 q are
   // spread over all XCDs, slices cut finer.  Needs equal S, T | G / 8 and r | 8.
   plan.mode = 0; plan.T = plan.Ng = plan.k1 = plan.Q = plan.r = plan.m = 0;
-  if (g_row3_plan_mode != 0 && (G & 7) == 0) {
+  if (l2s_knobs::row3_plan_mode != 0 && (G & 7) == 0) {   // (tools build only: measured 272-281 us against 265-268 for the contiguous ranges)
     const int T = (int)wgrad_row3_dma_tiles(tab_host[0].Cin, tab_host[0].Cout) / 3, P = G / 8;
     bool same = true;
     for (int i = 1; i < nprob; ++i) same = same && plan.S[i] == plan.S[0] && tab_host[i].Cin == tab_host[0].Cin && tab_host[i].Cout == tab_host[0].Cout;
@@ -445,11 +443,15 @@ int wgrad_row3_dma_launch(const l2s_wgrad_prob* tab_dev, const l2s_wgrad_prob* t
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)wgrad_row3_dma_kernel<KO_, NST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; } \
     L2S_LAUNCH((wgrad_row3_dma_kernel<KO_, NST_>), dim3(G), dim3(512), lds, st, tab_dev, plan, ws);                                            \
   }
-  switch (g_row3_form) {
+#ifdef L2S_TOOLS
+  switch (l2s_knobs::row3_form) {   // knock-out builds of the kernel for tools/wgrad_stamps.py (their results are garbage); not in the product library
     case 1: GO(1, 4) break; case 2: GO(2, 4) break; case 5: GO(5, 4) break; case 6: GO(6, 4) break; case 7: GO(7, 4) break;
     case 8: GO(8, 4) break; case 12: GO(12, 4) break; case 24: GO(24, 4) break; case 10: GO(10, 4) break;
     default: GO(0, 4) break;
   }
+#else
+  GO(0, 4)
+#endif
 #undef GO
   const float* wsc = ws;
   L2S_LAUNCH(wgrad_row3_reduce_kernel, dim3(12, total_tiles), dim3(256), 0, st, tab_dev, plan, wsc, G);

@@ -751,13 +751,11 @@ extern "C" int l2s_random_keys(uint32_t* keys, long n, const uint64_t* seed_dev,
 // deep the memory queues stand for everybody else: with 512 workgroups (25 MB of requests in flight) the next step's stem ended 475 us into the
 // step and layer1 at 697 us; with 256 at 287 / 567 us while the update itself got no slower (409 against 430 us).  64 / 96 / 128 / 192 / 256 / 320 /
 // 384 / 512 -> -- / 185.2 / 189.4 / 193.6 / 194.5 / 194.4 / 193.4 / 191.6 img/s, same box (profiles/r04_sgd_blocks.txt)
-static int g_sgd_blocks = 256;
-extern "C" int l2s_sgd_blocks(int blocks) { if (blocks > 0) g_sgd_blocks = blocks; return g_sgd_blocks; }
 extern "C" int l2s_sgd_chunk(void) { return SGD_CHUNK; }
 extern "C" int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
                                 float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int clear_grad, hipStream_t s) {
   if (nseg <= 0) return L2S_OK;
-  L2S_LAUNCH(sgd_kernel, dim3(g_sgd_blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype,
+  L2S_LAUNCH(sgd_kernel, dim3(l2s_knobs::sgd_blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype,
              clear_grad, 0L, (long)1 << 62, 0, -1);
   return l2s_check_launch();
 }
@@ -766,9 +764,27 @@ extern "C" int l2s_sgd_momentum_range(float* param, float* grad, float* mom, con
                                       long lo, long hi, int chunk_lo, int chunk_hi, hipStream_t s) {
   if (nseg <= 0 || hi <= lo) return L2S_OK;
   if (chunk_hi >= 0 && chunk_hi <= chunk_lo) return L2S_OK;
-  int blocks = g_sgd_blocks;
+  int blocks = l2s_knobs::sgd_blocks;
   if (chunk_hi >= 0 && chunk_hi - chunk_lo < blocks) blocks = chunk_hi - chunk_lo;
   L2S_LAUNCH(sgd_kernel, dim3(blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype, flags,
              lo, hi, chunk_lo, chunk_hi);
   return l2s_check_launch();
 }
+
+#ifdef L2S_TOOLS
+// ---- the tools build only (csrc/knobs.h): the tunables as variables, one setter.  Not compiled into liblang2seg_hip.so. ----
+#include <string.h>
+namespace l2s_knobs {
+int pdma_wgs = 0, dma256_auto = 1, wgrad_grid_cap = 0, wgrad_row3_dma = 1, wgrad_row3_dma_wgs = 128, wgrad_row3_wide = 1, wgrad_row3_min_m = 8192,
+    wgrad_1x1_dma = 0, row3_form = 0, row3_plan_mode = 0, sgd_blocks = 256;
+}
+extern "C" int l2s_tools_set(const char* name, int value) {
+  using namespace l2s_knobs;
+  struct { const char* n; int* p; } tab[] = {{"pdma_wgs", &pdma_wgs}, {"dma256_auto", &dma256_auto}, {"wgrad_grid_cap", &wgrad_grid_cap},
+    {"wgrad_row3_dma", &wgrad_row3_dma}, {"wgrad_row3_dma_wgs", &wgrad_row3_dma_wgs}, {"wgrad_row3_wide", &wgrad_row3_wide},
+    {"wgrad_row3_min_m", &wgrad_row3_min_m}, {"wgrad_1x1_dma", &wgrad_1x1_dma}, {"row3_form", &row3_form}, {"row3_plan_mode", &row3_plan_mode},
+    {"sgd_blocks", &sgd_blocks}};
+  for (auto& e : tab) if (!strcmp(e.n, name)) { *e.p = value; return L2S_OK; }
+  return L2S_EINVAL;
+}
+#endif

@@ -8,7 +8,6 @@ namespace l2s {
 // stream-K plan of one launch: problem i owns the (tile, slice) units [unit0[i], unit0[i + 1]), S[i] slices per tile; U units in all
 // mode 1 (XCD-lockstep, see conv_wgrad_dma.hip): T tiles per (problem, filter row) group, Ng groups, k1 workgroups per tile and XCD
 struct wgrad_sk_plan { int n; long U; long unit0[L2S_WGRAD_MAX_GROUP + 1]; int S[L2S_WGRAD_MAX_GROUP]; int mode, T, Ng, k1, Q, r, m; };
-extern int g_row3_form, g_row3_plan_mode;
 bool wgrad_row3_dma_ok(const l2s_wgrad_prob& q);
 long wgrad_row3_dma_tiles(int Cin, int Cout);
 size_t wgrad_row3_dma_ws_bytes(int G);

@@ -597,11 +597,6 @@ def sgd_chunk():
     return int(_lib.load().l2s_sgd_chunk())
 
 
-def sgd_blocks(n=0):
-    """tools: persistent workgroups of the update kernel (0 = query)"""
-    return int(_lib.load().l2s_sgd_blocks(int(n)))
-
-
 def add_f32(a, b, out):
     call('l2s_add_f32', ptr(a), ptr(b), ptr(out), a.numel(), stream())
 

@@ -64,6 +64,27 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.l2s_version() >= 100
 
 
+def test_product_library_has_no_tunables():
+    """verdict r4 item 8: the C ABI is re-entrant per stream - no process-global A/B switch.  The product library exports no setter (every
+    tunable of csrc/knobs.h is a compile-time constant there; the tools build with l2s_tools_set is a different file that only tools/ loads),
+    the header has no 'tools:' entry, bench.py has at most 15 flags and none of them patches the package."""
+    import subprocess
+    from lang2seg_amd import _lib
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert 'l2s_tools_set' not in syms
+    for bad in ('l2s_conv_dma256', 'l2s_conv_pdma_wgs', 'l2s_wgrad_row3_dma', 'l2s_wgrad_grid_cap', 'l2s_sgd_blocks'):
+        assert bad not in syms, bad
+    assert not [s_ for s_ in syms if 'knobs' in s_ or s_.startswith('g_')], [s_ for s_ in syms if 'knobs' in s_ or s_.startswith('g_')]
+    hdr = open(os.path.join(ROOT, 'include/lang2seg_hip.h')).read()
+    assert 'tools:' not in hdr and 'A/B' not in hdr
+    with pytest.raises(_lib.L2SError):
+        _lib.tools_set('sgd_blocks', 128)
+    bench_src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert bench_src.count('ap.add_argument(') <= 15
+    assert 'tools_set' not in bench_src
+
+
 def test_conv_plan_table():
     """l2s_conv_plan_name (the host-side kernel choice of l2s_conv_igemm; no launch, so it runs without a GPU): the plan of every convolution
     shape of the BASELINE step, and of the other image sizes a training run meets - the rules were tuned on the 38x63 map, and a rule that

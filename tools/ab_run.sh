@@ -1,11 +1,10 @@
 #!/bin/bash
-# Same-box A/B of two builds of the library: tools/ab_run.sh <lib A or ''> <lib B or ''> [rounds] [extra bench args]; '' = the in-tree build
+# Same-box A/B: tools/ab_run.sh "<tools/ab.py flags of arm A, '' = product>" "<flags of arm B>" [rounds] [extra bench.py args]
 A=$1; B=$2; N=${3:-3}; shift 3
 for i in $(seq $N); do
   for L in "$A" "$B"; do
-    if [ -n "$L" ]; then X="--lib $L"; else X=""; fi
-    timeout 300 python bench.py --no-cpu-baseline --extras 0 --mixed-shapes 0 --steps 100 --warmup 10 $X "$@" 2>/dev/null | tail -1 | python -c "
+    timeout 300 python tools/ab.py $L -- --no-cpu-baseline --extras 0 --mixed-shapes 0 --steps 100 --warmup 10 "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('%-40s %.2f img/s  %.3f ms' % ('${L:-in-tree}', d['value'], d['ms_per_step']))"
+d=json.loads(sys.stdin.readline()); print('%-40s %.2f img/s  %.3f ms' % ('${L:-product}', d['value'], d['ms_per_step']))"
   done
 done

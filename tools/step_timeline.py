@@ -46,10 +46,10 @@ def main():
     net.train()
     if args.wgrad_cap > 0:
         from lang2seg_amd import _lib as _L2
-        _L2.load().l2s_wgrad_grid_cap(args.wgrad_cap)
+        _L2.tools_set('wgrad_grid_cap', args.wgrad_cap)          # needs --lib <tools build> (tools/build_tools_lib.py)
     if args.sgd_blocks > 0:
-        from lang2seg_amd import ops as _O
-        _O.sgd_blocks(args.sgd_blocks)
+        from lang2seg_amd import _lib as _L3
+        _L3.tools_set('sgd_blocks', args.sgd_blocks)
     if args.defer >= 0:
         SGD.defer = bool(args.defer)
     optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY)

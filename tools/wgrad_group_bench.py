@@ -20,20 +20,19 @@ def main():
     ap.add_argument('--minm', type=int, default=0, help='pixels from which a 3x3 problem takes the LDS-DMA filter-row tile')
     ap.add_argument('--min-wg', type=int, default=0, help='WgradQueue.MIN_WG (workgroups a grouped launch should have before its problems stop splitting their pixels)')
     args = ap.parse_args()
+    from lang2seg_amd import _lib
+    knobs = [(n, v) for n, v, on in (('wgrad_1x1_dma', args.dma1, args.dma1 >= 0), ('wgrad_row3_min_m', args.minm, args.minm > 0),
+                                      ('row3_plan_mode', args.plan, args.plan >= 0), ('row3_form', args.form, args.form >= 0),
+                                      ('wgrad_row3_dma', args.row3_dma, args.row3_dma >= 0), ('wgrad_row3_dma_wgs', args.wgs, args.wgs > 0)) if on]
     if args.lib:
-        from lang2seg_amd import _lib
         _lib.LIB_PATH = os.path.abspath(args.lib)
+    elif knobs or args.check:                  # tunables exist only in the tools build of the library (csrc/knobs.h)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from build_tools_lib import build
+        _lib.LIB_PATH = build()
     from lang2seg_amd import ops as O, _lib as L_
-    if args.dma1 >= 0:
-        L_.load().l2s_wgrad_row3_dma(67, args.dma1)
-    if args.minm:
-        L_.load().l2s_wgrad_row3_dma(64, args.minm)
-    if args.plan >= 0:
-        L_.load().l2s_wgrad_row3_dma(32 + args.plan, 0)
-    if args.form >= 0:
-        L_.load().l2s_wgrad_row3_dma(16 + args.form, 0)
-    if args.row3_dma >= 0 or args.wgs:
-        L_.load().l2s_wgrad_row3_dma(args.row3_dma, args.wgs)
+    for n, v in knobs:
+        L_.tools_set(n, v)
     from lang2seg_amd.nets.network import WgradQueue
     from lang2seg_amd._lib import BF16
 
@@ -89,7 +88,7 @@ def main():
         res = []
         data = [(bf(n * H * W, 512), bf(n * H * W, 512), n, H, W) for (n, H, W) in (R, MAP)]
         for on in (0, 1):
-            L_.load().l2s_wgrad_row3_dma(on, 0)
+            L_.tools_set('wgrad_row3_dma', on)
             q = WgradQueue(net)
             dws = [torch.ones(512, 9 * 512, device='cuda') for _ in range(3)]
             for dw in dws:
@@ -101,7 +100,7 @@ def main():
             a, b = res[0][i], res[1][i]
             print('problem %d: max |old - new| %.3e, max |old| %.3e, equal to each other across problems: %s' % (
                 i, float((a - b).abs().max()), float(a.abs().max()), torch.equal(res[1][i], res[1][0])))
-        L_.load().l2s_wgrad_row3_dma(args.row3_dma if args.row3_dma >= 0 else 1, 0)
+        L_.tools_set('wgrad_row3_dma', args.row3_dma if args.row3_dma >= 0 else 1)
     l4_1x1 = [(1024, 512, 1, [R, MAP]), (2048, 512, 1, [R, MAP]), (2048, 512, 1, [R, MAP]), (512, 2048, 1, [R, MAP]), (512, 2048, 1, [R, MAP]),
               (512, 2048, 1, [R, MAP]), (1024, 2048, 1, [R, MAP])]
     stage('layer4 3x3 (filter rows)', l4_3x3)

@@ -4,7 +4,11 @@ of a slice spend their cycles.  Waves 0 (group 0) and 4 (group 1) of workgroup 0
 import sys, os, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lang2seg_amd import ops as O, _lib as L_
+from lang2seg_amd import _lib as L_
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_tools_lib import build
+L_.LIB_PATH = build()          # the stamped / knock-out builds of the kernel exist only in the tools build of the library
+from lang2seg_amd import ops as O
 from lang2seg_amd.nets.network import WgradQueue
 from lang2seg_amd._lib import BF16
 
@@ -34,7 +38,7 @@ def run():
 lib = L_.load()
 for _ in range(30):
     run()
-lib.l2s_wgrad_row3_dma(16 + (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 0)
+L_.tools_set('row3_form', int(sys.argv[1]) if len(sys.argv) > 1 else 8)
 run()
 torch.cuda.synchronize()
 G = 256
