@@ -393,6 +393,39 @@ int l2s_cap_attention_bwd_step(const float* datt_res, const float* att, const fl
 int l2s_cap_attention_bwd_batched(const float* ddot /*[S][L]*/, const float* weight /*[S][L]*/, const float* datt_res /*[S][ldr]*/, int ldr,
                                   const float* tanh_ws /*[S][L][D]*/, const float* aw, int S, int L, int D, float* dpatt /*+=*/, float* datt /*+=*/,
                                   float* daw /*+=*/, float* dab /*+=*/, hipStream_t s);
+/* The whole recurrence as ONE resident launch per direction (csrc/cap_recur.hip; ATT:406-423,446-466): L2S_CAP_RECUR_WGS workgroups own 16 hidden units each
+ * (weights in registers, fp32), three granule exchanges per token.  Supported for rnn_size = att_hid_size = 512 and L <= 224 locations
+ * (l2s_cap_recur_supported); callers fall back to the three launches per token above otherwise.  `state`: a caller-owned buffer of
+ * l2s_cap_recur_state_bytes(backward) bytes, 16-byte aligned, ZEROED ONCE when it is allocated and then left to the kernels (word 0: launch
+ * count = the exchange epoch; word 1: set to 1 when a bounded spin gave up - results are then invalid); one per direction. */
+#define L2S_CAP_RECUR_WGS 32
+typedef struct {
+  const float *w_h2h, *b_h2h;      /* [5R][R], [5R] */
+  const float *w_h2att, *b_h2att;  /* [AH][R], [AH] */
+  const float *patt;               /* [L][AH]  ctx2att(att) */
+  const float *aw, *ab;            /* alpha_net weight [AH], bias [1] */
+  const float *P, *b_a2c;          /* [L][2R] = att . W_a2c^T, [2R] */
+  const float *sums;               /* [S][5R]  i2h(x_t) + b_i2h (read only) */
+  float *hs, *cs;                  /* [(S+1)][R], row 0 = the initial state */
+  float *save;                     /* [S][6R] as l2s_cap_gates_fwd */
+  float *tanh_ws;                  /* [S][L][AH] */
+  float *wgt;                      /* [S][L] attention weights */
+  unsigned* state;
+  int S, R, AH, L;
+} l2s_cap_recur_fwd_args;
+typedef struct {
+  const float *w_h2h, *w_h2att, *P, *aw;
+  const float *save, *cs, *wgt, *tanh_ws;   /* as written by the forward launch */
+  const float *dho;                /* [S][R] gradient of the loss w.r.t. h_t through the logit layer */
+  float *dsums, *da2c;             /* [S][5R], [S][2R] */
+  float *ddot, *datt_h;            /* [S][ld_ddot] (L used), [S][ld_datt_h] (AH used) */
+  unsigned* state;
+  int S, R, AH, L, ld_ddot, ld_datt_h;
+} l2s_cap_recur_bwd_args;
+int l2s_cap_recur_supported(int S, int R, int AH, int L);
+size_t l2s_cap_recur_state_bytes(int backward);
+int l2s_cap_recur_fwd(const l2s_cap_recur_fwd_args* a, hipStream_t s);
+int l2s_cap_recur_bwd(const l2s_cap_recur_bwd_args* a, hipStream_t s);
 int l2s_cap_gates_fwd(const float* sums, const float* a2c, const float* c_prev, float* c, float* h, float* save /*[6R]: sig(3R), sel(R), cand(R), tanh(c)(R)*/, int R, hipStream_t s);
 int l2s_cap_gates_bwd(const float* dh, const float* dh2 /*nullable: dh = dh + dh2*/, const float* dc_in, const float* save, const float* c_prev, float* dsums /*[5R]*/, float* da2c /*[2R]*/, float* dc_prev, int R, hipStream_t s);
 /* log_softmax + masked NLL (AttModel.py:98, misc/utils.py:43-53): logits [S][V1]; dlogits = gscale*(softmax - onehot)*mask/sum(mask) */

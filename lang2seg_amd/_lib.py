@@ -51,6 +51,16 @@ class LstmBwdDir(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w_hh_T', 'dgates_next', 'dh_ext', 'dc_in', 'act', 'c_prev', 'c', 'dgates', 'dc_prev')]
 
 
+class CapRecurFwdArgs(C.Structure):
+    _fields_ = [(n, vp) for n in ('w_h2h', 'b_h2h', 'w_h2att', 'b_h2att', 'patt', 'aw', 'ab', 'P', 'b_a2c', 'sums', 'hs', 'cs', 'save', 'tanh_ws', 'wgt', 'state')] + \
+               [(n, i32) for n in ('S', 'R', 'AH', 'L')]
+
+
+class CapRecurBwdArgs(C.Structure):
+    _fields_ = [(n, vp) for n in ('w_h2h', 'w_h2att', 'P', 'aw', 'save', 'cs', 'wgt', 'tanh_ws', 'dho', 'dsums', 'da2c', 'ddot', 'datt_h', 'state')] + \
+               [(n, i32) for n in ('S', 'R', 'AH', 'L', 'ld_ddot', 'ld_datt_h')]
+
+
 class SgdSeg(C.Structure):
     _fields_ = [('offset', i64), ('count', i64), ('row_len', i32), ('weight_decay', i32), ('rowscale_off', i64),
                 ('lr_mult', f32), ('chunk0', i32), ('flags', i32), ('reserved', i32)]
@@ -151,6 +161,10 @@ SIGS = {
     'l2s_cap_a2c_gates_fwd': (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_cap_attention_bwd_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'l2s_cap_att_dots_fwd': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'l2s_cap_recur_supported': (i32, [i32, i32, i32, i32]),
+    'l2s_cap_recur_state_bytes': (sz, [i32]),
+    'l2s_cap_recur_fwd': (i32, [C.POINTER(CapRecurFwdArgs), vp]),
+    'l2s_cap_recur_bwd': (i32, [C.POINTER(CapRecurBwdArgs), vp]),
     'l2s_cap_apply_gates_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     'l2s_cap_gates_bwd_dw': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     'l2s_cap_attention_bwd_step2': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),

@@ -311,6 +311,7 @@ class Network(object):
         self._early_op = None       # optimiser taking early partial updates during backward (optim.SGD.partial)
         self.wgq = WgradQueue(self) # weight gradients of the current backward stage, launched together by flush_wgrads()
         self.cap_projected = True   # captioner recurrence in the projected-attention form (3 launches per token)
+        self._cap_state = None      # exchange state of the resident recurrence launches (csrc/cap_recur.hip), allocated on first use
         self.fuse_roialign = bool(cfg.TRAIN.get('FUSE_ROIALIGN', False))   # RoIAlign + layer4[0].conv1 + layer4[0].downsample as one launch (bf16)
         self.knockout = frozenset() # experiment only: parts of the step to leave out ('wgrad', 'wgrad3', 'wgrad4', 'cap'); set by bench.py --knockout
 
@@ -654,6 +655,7 @@ class Network(object):
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
     conv_algo = None             # A/B: l2s_conv_desc.algo for the wide 1x1 launches issued while it is set (roi_pdma: the RoI head's N >= 1024 GEMMs on the persistent tile)
     roi_pdma = False
+    cap_persistent = True        # the captioner recurrence as one resident launch per direction where the shapes allow (rnn_size = att_hid_size = 512, <= 224 locations)
     prio_floor = 0               # wave priority the convolution launches get at least (raised around a latency-bound chain: cap_map_prio)
     cap_map_prio = 0             # priority of layer4's data-gradient launches on the map (caption stream), beside the RoI head's backward
     rpn_wgrad_early = False      # A/B: with rpn_bwd_early, launch the RPN's weight gradients right away instead of with the heads stage

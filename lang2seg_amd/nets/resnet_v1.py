@@ -299,7 +299,15 @@ class resnetv1(Network):
             Pm = self.buf('cap.P', (L, 2 * R), f32); dots = self.buf('cap.dots', (S, 256), f32)
             O.linear_fwd(ad, pv('core.a2c.weight'), None, Pm, L, 2 * R, R)
             t['cap.P'] = Pm
-        for i in range(S):
+        t['cap.resident'] = resident = proj and self.cap_persistent and O.cap_recur_supported(S, R, AH, L)
+        if resident:
+            # the whole recurrence as one resident launch (csrc/cap_recur.hip): 32 workgroups own 16 units each, three granule exchanges per token
+            if getattr(self, '_cap_state', None) is None:
+                self._cap_state = (O.cap_recur_state(False), O.cap_recur_state(True))
+            O.cap_recur_fwd(pv('core.h2h.weight'), pv('core.h2h.bias'), pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), patt,
+                            pv('core.attention.alpha_net.weight'), pv('core.attention.alpha_net.bias'), Pm, pv('core.a2c.bias'), sums, hs, cs, save,
+                            tanh_ws, wgt, self._cap_state[0], S, R, AH, L)
+        for i in range(0 if resident else S):
             # h2att(h) and h2h(h) (+= i2h sums) in one launch; attention; a2c Linear fused with the gates (4 launches per step)
             O.linear2_fwd(hs[i], R, pv('core.attention.h2att.weight'), pv('core.attention.h2att.bias'), att_h[i], AH, False,
                           pv('core.h2h.weight'), pv('core.h2h.bias'), sums[i], 5 * R, True)
@@ -353,7 +361,10 @@ class resnetv1(Network):
         k = 0
         if proj:
             Pm = t['cap.P']; dwl = self.buf('cap.dwl', (S, 256), f32); dP = zb[nz:].view(L, 2 * R)
-        for i in range(S - 1, -1, -1):
+        if t.get('cap.resident'):
+            O.cap_recur_bwd(pv('core.h2h.weight'), pv('core.attention.h2att.weight'), Pm, pv('core.attention.alpha_net.weight'), save, cs, wgt, tanh_ws, dho,
+                            dsums, da2c, ddot, datt_h, self._cap_state[1], S, R, AH, L)
+        for i in range(-1 if t.get('cap.resident') else S - 1, -1, -1):
             if proj:
                 # 3 launches per step: gates + d(weight) = P . d(a2c); softmax backward + datt_h; dh(i-1)
                 O.cap_gates_bwd_dw(dh[k], dc[k], save[i], cs[i], Pm, dsums[i], da2c[i], dc[1 - k], dwl[i], L, R, dh2=dho[i])

@@ -559,6 +559,28 @@ def cap_apply_gates_fwd(P, dots, b_a2c, sums, c_prev, c, h, save, weight, L, R):
     call('l2s_cap_apply_gates_fwd', ptr(P), ptr(dots), ptr(b_a2c), ptr(sums), ptr(c_prev), ptr(c), ptr(h), ptr(save), ptr(weight), L, R, stream())
 
 
+def cap_recur_supported(S, R, AH, L):
+    return bool(_lib.load().l2s_cap_recur_supported(int(S), int(R), int(AH), int(L)))
+
+
+def cap_recur_state(backward, device='cuda'):
+    """the exchange state of one direction of the resident recurrence: zeroed ONCE here, then owned by the kernels (launch count, give-up flag, granules)"""
+    n = int(_lib.load().l2s_cap_recur_state_bytes(int(backward)))
+    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+
+
+def cap_recur_fwd(w_h2h, b_h2h, w_h2att, b_h2att, patt, aw, ab, P, b_a2c, sums, hs, cs, save, tanh_ws, wgt, state, S, R, AH, L):
+    a = _lib.CapRecurFwdArgs(ptr(w_h2h), ptr(b_h2h), ptr(w_h2att), ptr(b_h2att), ptr(patt), ptr(aw), ptr(ab), ptr(P), ptr(b_a2c), ptr(sums), ptr(hs), ptr(cs),
+                             ptr(save), ptr(tanh_ws), ptr(wgt), ptr(state), S, R, AH, L)
+    call('l2s_cap_recur_fwd', C.byref(a), stream())
+
+
+def cap_recur_bwd(w_h2h, w_h2att, P, aw, save, cs, wgt, tanh_ws, dho, dsums, da2c, ddot, datt_h, state, S, R, AH, L):
+    a = _lib.CapRecurBwdArgs(ptr(w_h2h), ptr(w_h2att), ptr(P), ptr(aw), ptr(save), ptr(cs), ptr(wgt), ptr(tanh_ws), ptr(dho), ptr(dsums), ptr(da2c), ptr(ddot),
+                             ptr(datt_h), ptr(state), S, R, AH, L, ddot.stride(0), datt_h.stride(0))
+    call('l2s_cap_recur_bwd', C.byref(a), stream())
+
+
 def cap_gates_bwd_dw(dh, dc_in, save, c_prev, P, dsums, da2c, dc_prev, dweight, L, R, dh2=None):
     call('l2s_cap_gates_bwd_dw', ptr(dh), ptr(dh2), ptr(dc_in), ptr(save), ptr(c_prev), ptr(P), ptr(dsums), ptr(da2c), ptr(dc_prev), ptr(dweight),
          L, R, stream())

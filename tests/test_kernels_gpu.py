@@ -1149,6 +1149,76 @@ def test_captioner_projected_attention_step():
     assert rel_err(dw[:L], dwl.float()) < 1e-5 and rel_err(ddot, ddot_ref.float()) < 2e-5 and rel_err(datt_h[:D], datt_h_ref.float()) < 2e-5
 
 
+def _cap_recurrence_ref(S, L, R, AH, W_h2h, b_h2h, W_att, b_att, patt, aw, ab, P, b_a2c, sums, dho):
+    """fp64 autograd restatement of the att2in2 recurrence in projected form (ATT:406-423,446-466) with per-token probes whose gradients are
+    the tensors the kernels hand on: d(sums), d(a2c), ddot, d(att_h)."""
+    sums = sums.clone().requires_grad_(True)
+    B = b_a2c[None].repeat(S, 1).requires_grad_(True)
+    Zd = torch.zeros(S, L, dtype=torch.float64, requires_grad=True); Za = torch.zeros(S, AH, dtype=torch.float64, requires_grad=True)
+    h = torch.zeros(R, dtype=torch.float64); c = torch.zeros(R, dtype=torch.float64)
+    hs, cs, ws, ths = [], [], [], []
+    for t in range(S):
+        att_h = W_att @ h + b_att + Za[t]
+        th = torch.tanh(patt + att_h[None]); dots = th @ aw + ab + Zd[t]; w = torch.softmax(dots, 0)
+        a2c = w @ P + B[t]
+        s = sums[t] + W_h2h @ h + b_h2h
+        ig, fg, og = torch.sigmoid(s[:R]), torch.sigmoid(s[R:2 * R]), torch.sigmoid(s[2 * R:3 * R])
+        it = torch.maximum(s[3 * R:4 * R] + a2c[:R], s[4 * R:] + a2c[R:])
+        c = fg * c + ig * it; h = og * torch.tanh(c)
+        hs.append(h); cs.append(c); ws.append(w); ths.append(th)
+    (torch.stack(hs) * dho).sum().backward()
+    return (torch.stack(hs).detach(), torch.stack(cs).detach(), torch.stack(ws).detach(), torch.stack(ths).detach(), sums.grad, B.grad, Zd.grad, Za.grad)
+
+
+@pytest.mark.parametrize('S,L', [(21, 196), (1, 196), (4, 50), (11, 224)])
+def test_captioner_resident_recurrence(S, L):
+    """csrc/cap_recur.hip: the whole captioner recurrence as one resident launch per direction (32 workgroups, weights in registers, three granule
+    exchanges per token) against an fp64 autograd restatement of AttModel.py:406-466 - states, attention weights, tanh values forward; d(sums),
+    d(a2c), ddot, d(att_h) backward; 2e-5 relative (fp32, a summation order of its own).  Run three times on the same state buffers (the exchange
+    epochs of consecutive launches) with other kernels on a second stream the third time: bit-identical each time, no give-up flag."""
+    O = ops()
+    R = AH = 512
+    g = torch.Generator().manual_seed(31 + S)
+    dd = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float64)
+    W_h2h = dd(5 * R, R) / np.sqrt(R); b_h2h = dd(5 * R) * 0.1; W_att = dd(AH, R) / np.sqrt(R); b_att = dd(AH) * 0.1
+    patt = dd(L, AH) * 0.5; aw = dd(AH) * 0.1; ab = dd(1) * 0.1; P = dd(L, 2 * R) * 0.5; b_a2c = dd(2 * R) * 0.1
+    sums = dd(S, 5 * R) * 0.7; dho = dd(S, R) * 0.1
+    assert O.cap_recur_supported(S, R, AH, L) and not O.cap_recur_supported(S, 256, AH, L) and not O.cap_recur_supported(S, R, AH, 225)
+    hs_r, cs_r, w_r, th_r, dsums_r, da2c_r, ddot_r, datt_h_r = _cap_recurrence_ref(S, L, R, AH, W_h2h, b_h2h, W_att, b_att, patt, aw, ab, P, b_a2c, sums, dho)
+    f = lambda x: x.float().to(DEV).contiguous()
+    dv = dict(W_h2h=f(W_h2h), b_h2h=f(b_h2h), W_att=f(W_att), b_att=f(b_att), patt=f(patt), aw=f(aw), ab=f(ab), P=f(P), b_a2c=f(b_a2c), sums=f(sums), dho=f(dho))
+    st = (O.cap_recur_state(False), O.cap_recur_state(True))
+    side = torch.cuda.Stream()
+    big = torch.randn(64 << 20, device=DEV)
+    outs = []
+    for rep in range(3):
+        hs = torch.zeros(S + 1, R, device=DEV); cs = torch.zeros(S + 1, R, device=DEV); save = torch.full((S, 6 * R), float('nan'), device=DEV)
+        tanh_ws = torch.full((S, L, AH), float('nan'), device=DEV); wgt = torch.full((S, L), float('nan'), device=DEV)
+        dsums = torch.full((S, 5 * R), float('nan'), device=DEV); da2c = torch.full((S, 2 * R), float('nan'), device=DEV)
+        ddot = torch.full((S, L), float('nan'), device=DEV); datt_h = torch.full((S, AH + 256), float('nan'), device=DEV)
+        torch.cuda.synchronize()
+        if rep == 2:                                  # uneven load: HBM-streaming kernels on another queue while the resident launches run
+            with torch.cuda.stream(side):
+                for _ in range(40):
+                    big.mul_(1.0001)
+        O.cap_recur_fwd(dv['W_h2h'], dv['b_h2h'], dv['W_att'], dv['b_att'], dv['patt'], dv['aw'], dv['ab'], dv['P'], dv['b_a2c'], dv['sums'], hs, cs, save,
+                        tanh_ws, wgt, st[0], S, R, AH, L)
+        O.cap_recur_bwd(dv['W_h2h'], dv['W_att'], dv['P'], dv['aw'], save, cs, wgt, tanh_ws, dv['dho'], dsums, da2c, ddot, datt_h, st[1], S, R, AH, L)
+        torch.cuda.synchronize()
+        assert int(st[0][1].item()) == 0 and int(st[1][1].item()) == 0, 'a bounded spin of the resident recurrence gave up'
+        assert int(st[0][0].item()) == rep + 1 and int(st[1][0].item()) == rep + 1
+        outs.append([x.clone() for x in (hs, cs, save, tanh_ws, wgt, dsums, da2c, ddot, datt_h[:, :AH])])
+    hs, cs, save, tanh_ws, wgt, dsums, da2c, ddot, datt_h = outs[0]
+    assert float(hs[0].abs().max()) == 0.0
+    assert rel_err(hs[1:], hs_r.float()) < 2e-5 and rel_err(cs[1:], cs_r.float()) < 2e-5 and rel_err(wgt, w_r.float()) < 2e-5
+    assert rel_err(tanh_ws, th_r.float()) < 2e-6
+    assert rel_err(dsums, dsums_r.float()) < 2e-5 and rel_err(da2c, da2c_r.float()) < 2e-5, (rel_err(dsums, dsums_r.float()), rel_err(da2c, da2c_r.float()))
+    assert rel_err(ddot, ddot_r.float()) < 5e-5 and rel_err(datt_h, datt_h_r.float()) < 5e-5, (rel_err(ddot, ddot_r.float()), rel_err(datt_h, datt_h_r.float()))
+    for o in outs[1:]:
+        for a_, b_ in zip(outs[0], o):
+            assert torch.equal(a_, b_), 'the resident recurrence is not bit-reproducible across launches'
+
+
 def test_row_batch_linears_mfma():
     """row batches (21 tokens, 196 attention locations) of the fp32 linears: exact-fp32 MFMA kernels, forward (bias / activation /
     accumulate, ragged M and N) and data gradient from the weight as stored (split contraction through a workspace, fused mask,
