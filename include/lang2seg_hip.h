@@ -393,6 +393,21 @@ int l2s_cap_attention_bwd_step(const float* datt_res, const float* att, const fl
 int l2s_cap_attention_bwd_batched(const float* ddot /*[S][L]*/, const float* weight /*[S][L]*/, const float* datt_res /*[S][ldr]*/, int ldr,
                                   const float* tanh_ws /*[S][L][D]*/, const float* aw, int S, int L, int D, float* dpatt /*+=*/, float* datt /*+=*/,
                                   float* daw /*+=*/, float* dab /*+=*/, hipStream_t s);
+/* A frozen 64-plane bottleneck behind its first 1x1 convolution as ONE launch (csrc/bottleneck_fused.hip; RES:78-114, the frozen layer1 of
+ * RES:291-299), bf16, forward only: b = relu(conv3x3(a) + b2); y = relu(conv1x1(b) + b3 + shortcut), shortcut = x (Cx = 256) or conv1x1(x; wd) + bd
+ * (Cx = 64); optionally a_next = relu(conv1x1(y; w1n) + b1n) = the next block's first convolution.  Weights BN-folded bf16 [Cout][KH][KW][Cin],
+ * biases f32; every pointer 16-byte aligned; any H, W. */
+typedef struct {
+  const void* a;                    /* [H*W][64]  */
+  const void* x;                    /* [H*W][Cx]  */
+  const void *w2, *w3, *wd, *w1n;   /* [64][3][3][64], [256][64], [256][64] (Cx = 64) or NULL, [64][256] or NULL */
+  const float *b2, *b3, *bd, *b1n;
+  void* y;                          /* [H*W][256] */
+  void* a_next;                     /* [H*W][64] or NULL */
+  int H, W, Cx;
+} l2s_bottleneck64_desc;
+int l2s_bottleneck64_fwd(const l2s_bottleneck64_desc* d, hipStream_t s);
+
 /* The whole recurrence as ONE resident launch per direction (csrc/cap_recur.hip; ATT:406-423,446-466): L2S_CAP_RECUR_WGS workgroups own 16 hidden units each
  * (weights in registers, fp32), three granule exchanges per token.  Supported for rnn_size = att_hid_size = 512 and L <= 224 locations
  * (l2s_cap_recur_supported); callers fall back to the three launches per token above otherwise.  `state`: a caller-owned buffer of

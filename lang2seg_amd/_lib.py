@@ -51,6 +51,10 @@ class LstmBwdDir(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w_hh_T', 'dgates_next', 'dh_ext', 'dc_in', 'act', 'c_prev', 'c', 'dgates', 'dc_prev')]
 
 
+class Bottleneck64Desc(C.Structure):
+    _fields_ = [(n, vp) for n in ('a', 'x', 'w2', 'w3', 'wd', 'w1n', 'b2', 'b3', 'bd', 'b1n', 'y', 'a_next')] + [(n, i32) for n in ('H', 'W', 'Cx')]
+
+
 class CapRecurFwdArgs(C.Structure):
     _fields_ = [(n, vp) for n in ('w_h2h', 'b_h2h', 'w_h2att', 'b_h2att', 'patt', 'aw', 'ab', 'P', 'b_a2c', 'sums', 'hs', 'cs', 'save', 'tanh_ws', 'wgt', 'state')] + \
                [(n, i32) for n in ('S', 'R', 'AH', 'L')]
@@ -161,6 +165,7 @@ SIGS = {
     'l2s_cap_a2c_gates_fwd': (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp]),
     'l2s_cap_attention_bwd_step': (i32, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     'l2s_cap_att_dots_fwd': (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    'l2s_bottleneck64_fwd': (i32, [C.POINTER(Bottleneck64Desc), vp]),
     'l2s_cap_recur_supported': (i32, [i32, i32, i32, i32]),
     'l2s_cap_recur_state_bytes': (sz, [i32]),
     'l2s_cap_recur_fwd': (i32, [C.POINTER(CapRecurFwdArgs), vp]),

@@ -131,7 +131,7 @@ class WgradQueue(object):
         from .._lib import WgradProb, ptr, load
         import ctypes as C
         if not self.items:
-            return
+            return False
         lib = load()
         net = self.net
         items, self.items = self.items, []
@@ -217,6 +217,7 @@ class WgradQueue(object):
                            ws.numel() * 4, O.stream())
                     if ctx is not None:
                         ctx.__exit__(None, None, None)
+        return True
 
     V5_STREAM = 'wg'   # A/B: 'tr' = the filter-row launch of a stage beside the stage's other launches instead of behind them
     SMALL_M_TILE = 0   # A/B: tile argument for problems with fewer than 8192 pixels (128: 128x128 / 128x64-row tiles instead of 64x64)
@@ -389,7 +390,7 @@ class Network(object):
         """launch the weight gradients queued since the last flush as grouped launches (one per tile variant) on the weight-gradient
         stream, after everything enqueued so far on the current stream.  Called at the end of every backward stage; join_wgrad()
         flushes whatever is left, so no gradient can be missed."""
-        self.wgq.flush(tag)
+        return self.wgq.flush(tag)
 
     def join_wgrad(self):
         self.flush_wgrads('final')
@@ -655,6 +656,7 @@ class Network(object):
     defer_heads = False      # optim.SGD.defer: the heads stage's weight gradients + their part of the update run behind the rest of the update
     conv_algo = None             # A/B: l2s_conv_desc.algo for the wide 1x1 launches issued while it is set (roi_pdma: the RoI head's N >= 1024 GEMMs on the persistent tile)
     roi_pdma = False
+    layer1_fused = True          # bf16: the frozen layer1 as 4 launches (conv1 of block 0 + one fused launch per bottleneck, csrc/bottleneck_fused.hip)
     cap_persistent = True        # the captioner recurrence as one resident launch per direction where the shapes allow (rnn_size = att_hid_size = 512, <= 224 locations)
     prio_floor = 0               # wave priority the convolution launches get at least (raised around a latency-bound chain: cap_map_prio)
     cap_map_prio = 0             # priority of layer4's data-gradient launches on the map (caption stream), beside the RoI head's backward
@@ -665,8 +667,11 @@ class Network(object):
     wgrad_overwrite = True       # grouped weight gradients write (instead of add to) a tensor's gradient at its first problem of the step
     update_clears_grad = False   # optim.SGD(keep_grad=False): the update zeroes the gradients it consumes; forward_backward does not clear
     SLOT_UPDATE_REST = 0     # event slot (csrc/tape.hip): the first part of the update (everything outside ParamStore.defer_range) is done
+    SLOT_UPDATE_L2 = 1       # ... the update of the LAST segments of the flat buffer (layer2) is done: all the next step's layer2 has to wait for
+    SLOT_WGRADS = 2          # ... every launch of the two weight-gradient streams (they read the previous pass's activation buffers) is done
+    update_split = False     # set by optim.SGD (side-stream update, one process): layer2 joins the slot, layer3 the whole weight-gradient stream
 
-    def join_update(self, full=True):
+    def join_update(self, full=True, layer2_only=False):
         """the current stream waits for the optimiser update of the previous step when that ran on the weight-gradient stream
         (optim.SGD.side): called before the first launch that reads a trainable weight or writes a gradient.  Unconditional once the
         mode is on (a step recorded on a launch tape must contain the edge).
@@ -674,7 +679,13 @@ class Network(object):
         the captioner's own matrices and the backbone - which the update marks under SLOT_UPDATE_REST; the deferred weight gradients
         of the heads stage and their part of the update keep running on the weight-gradient stream until join_deferred()."""
         if self.use_streams and self.update_on_wg:
-            if self.defer_heads and not full:
+            if layer2_only and self.update_split and not self.defer_heads:
+                # Round 5: the tail of a step is [last weight gradients -> update of layer2 -> (join of the early partial updates) -> transposes];
+                # the next step's layer2 needs the second item only.  The transposes (data-gradient copies: read in backward) and the partial
+                # update of layer3 (its weights are first read ~0.4 ms later) are joined before layer3 (resnet_v1._backbone_fwd).
+                O.event_wait(self.SLOT_UPDATE_L2, torch.cuda.current_stream())
+                O.event_wait(self.SLOT_WGRADS, torch.cuda.current_stream())
+            elif self.defer_heads and not full:
                 O.event_wait(self.SLOT_UPDATE_REST, torch.cuda.current_stream())
             else:
                 self.sfork(self.streams()['wg'], torch.cuda.current_stream())

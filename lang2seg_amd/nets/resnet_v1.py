@@ -157,6 +157,11 @@ class resnetv1(Network):
     def refresh_weights(self, full=False):
         if not hasattr(self, 'extra_transposes'):
             self._make_transposes()
+        if full and getattr(self, '_stem_pack', None) is not None:
+            # the matrix-core stem's fragment-ordered conv1 weights: repacked IN PLACE with the other frozen weights, so that a state dict
+            # loaded after launch tapes were recorded reaches the replayed steps too (the tapes hold this buffer's address)
+            w1 = self.P.frozen['resnet.conv1.weight']
+            self._stem_pack, self._stem_pack_ver = O.stem_pack(w1, self._stem_pack), (w1.data_ptr(), w1._version)
         Network.refresh_weights(self, full)
 
     # ------------------------------------------------------------------ helpers
@@ -427,16 +432,56 @@ class resnetv1(Network):
             O.stem_conv(d['data'], w1, P.bn_scale['resnet.conv1.weight'], P.bn_bias['resnet.conv1.weight'], c1, H, W, OH1, OW1)
             O.maxpool(c1, x, OH1, OW1, 64, h, w)
         self._mark('stem')
+        first = 1 if self.join_before_layer1 else cfg.RESNET.FIXED_BLOCKS + 1        # first trainable layer
+        # The previous step's tail (its last weight gradients, the update, the transposes) runs beside this step's frozen prefix, and the last
+        # weight gradients READ the activation buffers this pass is about to overwrite: layer2[0]'s read the output of layer1, layer3[0]'s the
+        # output of layer2.  So the join sits in front of the launch that writes layer1's output (a latent race until round 5, when the fused
+        # layer1 became fast enough to lose it): with the split update it waits for [layer2's weight gradients + update] and for the
+        # weight-gradient streams' launches only (join_update(layer2_only=True)); layer3 then joins the rest (partial updates, transposes).
+        def join_tail():
+            self.join_update(full=False, layer2_only=(first == 2))
+            self._mark('layer1 done, update joined')
         for li in (1, 2, 3):
-            if li == (1 if self.join_before_layer1 else cfg.RESNET.FIXED_BLOCKS + 1):
-                self.join_update(full=False)                   # first trainable layer: the previous step's update (of the backbone) must have landed
-                self._mark('layer1 done, update joined')
+            if li == first and not (first == 2 and cfg.RESNET.FIXED_BLOCKS == 1):
+                join_tail()
+            if li == 3 and self.update_split and first == 2:
+                self.join_update(full=False)                   # everything else of the previous step's tail (layer3's partial update, the transposes)
+            before_last = join_tail if (li == 1 and first == 2) else None
+            if li == 1 and self._layer1_is_fusable():
+                x = self._layer1_fused_fwd(x, h, w, before_last)
+                continue
             for b, blk in enumerate(self.layers[li]):
+                if before_last is not None and b == len(self.layers[li]) - 1:
+                    before_last()
                 x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
                 saved[(li, b)] = sv
         if cfg.RESNET.FIXED_BLOCKS >= 3:
             self.join_update(full=False)
         return x, h, w
+
+    def _layer1_is_fusable(self):
+        """the frozen layer1 (RES:291-299) in bf16: every block behind its conv1 as one launch (csrc/bottleneck_fused.hip)"""
+        blks = self.layers[1]
+        return (self.layer1_fused and self.dt == BF16 and cfg.RESNET.FIXED_BLOCKS >= 1 and blks[0].planes == 64 and blks[0].stride == 1
+                and blks[0].down is not None and all(not c.trainable for b in blks for c in (b.c1, b.c2, b.c3)))
+
+    def _layer1_fused_fwd(self, x, h, w, before_last=None):
+        """4 launches instead of 10: conv1 of the first block, then per block [3x3 -> 1x1 + shortcut (+ the next block's conv1)]; nothing of a
+        frozen block is kept for backward"""
+        blks = self.layers[1]
+        a = self.buf('l1f.a0', (h * w, 64))
+        blks[0].c1.fwd(x, 1, h, w, a, relu=True)
+        for b, blk in enumerate(blks):
+            nxt = blks[b + 1] if b + 1 < len(blks) else None
+            if nxt is None and before_last is not None:
+                before_last()                                  # the previous step's last weight gradients still read this block's output buffer
+            y = self.buf('l1f.y%d' % b, (h * w, 256))
+            an = self.buf('l1f.a%d' % (b + 1), (h * w, 64)) if nxt is not None else None
+            O.bottleneck64_fwd(a, x, blk.c2.wf, blk.c2.bias, blk.c3.wf, blk.c3.bias, y, h, w,
+                               wd=blk.down.wf if b == 0 else None, bd=blk.down.bias if b == 0 else None,
+                               w1n=nxt.c1.wf if nxt is not None else None, b1n=nxt.c1.bias if nxt is not None else None, a_next=an)
+            x, a = y, an
+        return x
 
     def _backbone_bwd(self, dbase, saved, S, main, dp):
         """layer3, layer2 (layer1 and the stem are frozen: RES:290-299)"""
@@ -598,7 +643,8 @@ class resnetv1(Network):
         self._mark('step start')
         main = torch.cuda.current_stream()
         S = self.streams() if self.use_streams else None
-        self._fresh = set()                                 # gradients written (not added to) by this pass's grouped weight gradients
+        if backward:                                        # (a forward-only pass - get_summary() between two replayed steps - leaves the last backward pass's set in place:
+            self._fresh = set()                             # optim.update_range judges staleness from it)  gradients written (not added to) by this pass's grouped weight gradients
         if self.update_clears_grad:
             # optimizer.zero_grad() (TV:383) is folded into the update kernel: the buffer is zero here unless a backward pass went by without an update
             if backward:

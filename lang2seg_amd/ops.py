@@ -559,6 +559,12 @@ def cap_apply_gates_fwd(P, dots, b_a2c, sums, c_prev, c, h, save, weight, L, R):
     call('l2s_cap_apply_gates_fwd', ptr(P), ptr(dots), ptr(b_a2c), ptr(sums), ptr(c_prev), ptr(c), ptr(h), ptr(save), ptr(weight), L, R, stream())
 
 
+def bottleneck64_fwd(a, x, w2, b2, w3, b3, y, H, W, wd=None, bd=None, w1n=None, b1n=None, a_next=None):
+    """csrc/bottleneck_fused.hip: a frozen 64-plane bottleneck behind its conv1 (+ the next block's conv1) in one launch, bf16"""
+    d = _lib.Bottleneck64Desc(ptr(a), ptr(x), ptr(w2), ptr(w3), ptr(wd), ptr(w1n), ptr(b2), ptr(b3), ptr(bd), ptr(b1n), ptr(y), ptr(a_next), H, W, x.shape[-1])
+    call('l2s_bottleneck64_fwd', C.byref(d), stream())
+
+
 def cap_recur_supported(S, R, AH, L):
     return bool(_lib.load().l2s_cap_recur_supported(int(S), int(R), int(AH), int(L)))
 

@@ -21,6 +21,8 @@ class SGD(object):
         self._early = bool(type(self)._early and not self.defer)      # (the deferred heads stage, when asked for, excludes the early partial updates)
         self.defer_active = bool(self.defer and self.side_active and not self._early and hasattr(net, 'wgq') and getattr(net, 'dp', None) is None)
         net.defer_heads = self.defer_active
+        # the plain side-stream update records when the LAST segments (layer2) are done: the next step's layer2 waits for that only
+        net.update_split = bool(self.side_active and getattr(net, 'dp', None) is None and not self.defer_active)
         # keep_grad=False: the update kernel zeroes every gradient it consumes (optimizer.zero_grad(), TV:383, folded in), and
         # forward_backward no longer clears the buffer (it is zero when the network is built, and every update leaves it zero; a second
         # backward pass without an update in between is refused); keep_grad=True leaves the step's gradients in P.grad (tests read them there)
@@ -156,6 +158,29 @@ class SGD(object):
             net.flush_wgrads('final')
             self._mark_overwritten()
             S = net.streams()
+            # what the early partial updates left is layer2 alone (the last segments of the buffer): its gradients come from the main queue and
+            # the two weight-gradient streams, so that launch does not wait for the language / caption / transpose streams - they are joined
+            # behind it, before the transposes.  The next step's layer2 waits for SLOT_UPDATE_L2 only (Network.join_update(layer2_only=True)).
+            early_tail = bool(self._seg_done and net.update_split and not self.defer_active and getattr(net.wgq, 'V5_STREAM', 'wg') != 'tr')
+            net.sfork(S['wg2'], S['wg'])
+            if getattr(net.wgq, 'V5_STREAM', 'wg') == 'tr':
+                net.sfork(S['tr'], S['wg'])               # (A/B: a weight-gradient launch on the transpose stream)
+            O.event_record(net.SLOT_WGRADS, S['wg'])          # behind every weight-gradient launch of this step on 'wg' / 'wg2'
+            if early_tail:
+                T = S['wg']
+                net.sfork(torch.cuda.current_stream(), T)
+                with torch.cuda.stream(T):
+                    self._launch(self._seg_done, P.nseg)
+                    O.event_record(net.SLOT_UPDATE_L2, T)
+                    net._mark('update of layer2 done')
+                for k in ('wg2', 'lang', 'cap', 'tr'):
+                    net.sfork(S[k], S['wg'])
+                net.sfork(torch.cuda.current_stream(), S['wg'])
+                with torch.cuda.stream(S['wg']):
+                    net.refresh_weights()
+                    net._mark('update done (wg)')
+                self._seg_done = 0
+                return
             for k in ('wg2', 'lang', 'cap'):
                 net.sfork(S[k], S['wg'])
             if self._seg_done or getattr(net.wgq, 'V5_STREAM', 'wg') == 'tr':
@@ -171,6 +196,7 @@ class SGD(object):
                     self._launch(P.n_rest, P.nseg, P.segs_split_dev)
                 else:
                     self._launch(self._seg_done, P.nseg)  # whatever the partial updates left: the last backward stages
+                    O.event_record(net.SLOT_UPDATE_L2, S['wg'])
                 net.refresh_weights()
                 net._mark('update done (wg)')
             self._seg_done = 0

@@ -18,7 +18,7 @@ this harness only restores the environment it expects, in-process (SURVEY.md §8
 sets the same attributes forward() sets (NET:632-648) and calls `_predict()` /
 `_add_losses()` / backward / torch.optim.SGD exactly as NET:650-662,712-715, TV:194-220.
 
-Usage: python tests/golden/make_golden.py [tiny|full|leaf|variants|test|all]
+Usage: python tests/golden/make_golden.py [tiny|full|full_variants [names]|leaf|variants|test|all]
 """
 import os
 import sys
@@ -675,3 +675,11 @@ if __name__ == '__main__':
         hook_proposals()
         run_reference('full', 600, 1000, 20, 3349, dict(BATCH_SIZE=256, RPN_PRE_NMS_TOP_N=12000,
                                                          RPN_POST_NMS_TOP_N=2000, RPN_BATCHSIZE=256))
+    if what == 'full_variants':
+        # BASELINE.json configs 2, 4, 5 (and 1) at their stated size: 600x1000, 12000 -> 2000 proposals, 256 RoIs; expression length / vocabulary
+        # of the config's dataset (refcoco(+) unc: 10 tokens, V = 1999; refcocog umd: 20 tokens, V = 3349).  Not part of 'all': minutes each.
+        TV = dict(baseline=(10, 1999), spatial=(10, 1999), response=(10, 1999), cycle_response=(20, 3349), vgg=(10, 1999))
+        for v in (sys.argv[2:] or ['spatial', 'cycle_response', 'vgg']):
+            hook_proposals(v)
+            run_reference('full_' + v, 600, 1000, TV[v][0], TV[v][1], dict(BATCH_SIZE=256, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000,
+                                                                          RPN_BATCHSIZE=256), variant=v)

@@ -96,6 +96,41 @@ def test_conv_fwd(cfg, dt):
     assert rel_err(y2.view(n, OH, OW, Cout), nhwc(ref2)) < (2e-5 if dt == 0 else 1e-4)
 
 
+@pytest.mark.parametrize('H,W', [(150, 250), (13, 31), (6, 25), (41, 57)])
+@pytest.mark.parametrize('down', [True, False])
+def test_bottleneck64_fused(H, W, down):
+    """csrc/bottleneck_fused.hip: a frozen 64-plane bottleneck behind its conv1 as one launch (3x3 -> 1x1 + shortcut -> ReLU, + the next block's
+    conv1), bf16, against torch-CPU on the same rounded operands with the same rounding points (b and y rounded to bf16 where the kernel stores
+    them): the 150x250 map of the 600x1000 step (no ragged tile), a map smaller than one tile row, exactly one tile, and a ragged 41x57 map; first
+    block (Cx = 64, shortcut convolution) and later blocks (Cx = 256, identity).  5e-3 of the tensor's maximum = one bf16 ulp at that scale."""
+    O = ops()
+    g = torch.Generator().manual_seed(7 + H + int(down))
+    Cx = 64 if down else 256
+    rb = lambda t: t.bfloat16().float()
+    a = rb(torch.randn(1, 64, H, W, generator=g).clamp(min=0)); x = rb(torch.randn(1, Cx, H, W, generator=g).clamp(min=0))
+    w2 = rb(torch.randn(64, 64, 3, 3, generator=g) / np.sqrt(576)); w3 = rb(torch.randn(256, 64, 1, 1, generator=g) / 8)
+    wd_ = rb(torch.randn(256, 64, 1, 1, generator=g) / 8); w1n = rb(torch.randn(64, 256, 1, 1, generator=g) / 16)
+    b2, b3, bd, b1n = [torch.randn(n, generator=g) * 0.2 for n in (64, 256, 256, 64)]
+    b = rb(F.relu(F.conv2d(a, w2, b2, padding=1)))
+    sc = F.conv2d(x, wd_, bd) if down else x
+    yr = rb(F.relu(F.conv2d(b, w3, b3) + sc))
+    anr = rb(F.relu(F.conv2d(yr, w1n, b1n)))
+    dev = lambda t: to_dev(nhwc(t), 1).view(-1, t.shape[1]).contiguous()
+    dw = lambda t: to_dev(ohwi(t), 1).contiguous()
+    f = lambda t: t.float().to(DEV).contiguous()
+    ad, xd = dev(a), dev(x)
+    for with_next in (True, False):
+        y = torch.full((H * W, 256), float('nan'), device=DEV).bfloat16(); an = torch.full((H * W, 64), float('nan'), device=DEV).bfloat16()
+        O.bottleneck64_fwd(ad, xd, dw(w2), f(b2), dw(w3), f(b3), y, H, W, wd=dw(wd_) if down else None, bd=f(bd) if down else None,
+                           w1n=dw(w1n) if with_next else None, b1n=f(b1n) if with_next else None, a_next=an if with_next else None)
+        torch.cuda.synchronize()
+        assert rel_err(y.float().view(1, H, W, 256), nhwc(yr)) < 5e-3, (H, W, down, rel_err(y.float().view(1, H, W, 256), nhwc(yr)))
+        if with_next:
+            assert rel_err(an.float().view(1, H, W, 64), nhwc(anr)) < 5e-3, (H, W, down, rel_err(an.float().view(1, H, W, 64), nhwc(anr)))
+        else:
+            assert bool(torch.isnan(an.float()).all())
+
+
 @pytest.mark.parametrize('cfg', [
     dict(n=256, H=7, W=7, Cin=512, Cout=512, k=3, s=1, p=1),          # the dominant launch (M = 49 x 256, no ragged tile)
     dict(n=23, H=7, W=7, Cin=128, Cout=200, k=3, s=1, p=1),           # ragged pixel tile (M = 1127) and ragged channel tile, borders of 7x7 maps

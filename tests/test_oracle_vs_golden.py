@@ -90,6 +90,27 @@ def test_train_step_tiny_variants(variant):
     _run_e2e('tiny_' + variant)
 
 
+@pytest.mark.parametrize('tag', ['full_spatial', 'full_cycle_response', 'full_vgg'])
+def test_forward_full_size_variants(tag):
+    """BASELINE.json configs 2, 4 and 5 at their stated size (600x1000, 12000 -> 2000 proposals, 256 RoIs; tests/golden/make_golden.py full_variants):
+    the oracle's forward pass against the reference's own run - every loss 1e-4, integer targets exact (forward only: the CPU suite stays in minutes;
+    the backward pass of every variant is pinned at the tiny size above and, on the device, against these fixtures' gradients)."""
+    g = load(tag)
+    opt, sd, blob, cfg, samp = setup_from_fixture(g)
+    net = ON.OracleNet(sd, opt, cfg, variant=variant_of(g))
+    samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
+    with torch.no_grad():
+        T, L = net.forward_train(blob, samp)
+    assert np.array_equal(T['rpn_labels'].astype(np.int8), g['int.rpn_labels'])
+    assert np.array_equal(T['labels'].reshape(-1).astype(np.int64), g['int.labels'])
+    if 'int.mask_targets' in g:
+        assert np.array_equal(T['mask_targets'].astype(np.uint8), g['int.mask_targets'])
+    for k in ['net_conv', 'cls_score', 'bbox_pred'] + [k for k in ('mask_score', 'response') if 't.%s.sum' % k in g]:
+        check_digest(g, 't.' + k, T[k].detach().numpy())
+    for k, v in L.items():
+        assert abs(float(v) - float(g['loss.' + k])) < 1e-4 * max(1, abs(float(g['loss.' + k]))), (k, float(v), g['loss.' + k])
+
+
 @pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top', 'test_tiny_vgg'])
 def test_test_mode(tag):
     """TEST mode of the reference (test_image NET:684-699 + _predict_masks_from_boxes_and_labels NET:595-626):
