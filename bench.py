@@ -117,16 +117,18 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(H, W, T, V, warm, timed):
+def cpu_baseline(H, W, T, V, warm, timed, variant='cycle'):
     """The oracle's fp32 CPU restatement of the same step on this box's host cores (baseline only, the checker is not shipped)."""
     import copy
     import numpy as np
     import torch
     from oracle import weights as OW, synth as OS, net as ON
     opt = OW.default_opt(vocab_size=V, seq_length=T)
-    sd = OW.make_state_dict(opt, seed=3)
+    if variant == 'vgg':
+        opt['C4_feat_dim'] = 512
+    sd = OW.make_state_dict(opt, seed=3, variant=variant) if variant != 'cycle' else OW.make_state_dict(opt, seed=3)
     blob = OS.make_blob(H, W, T, V, seed=1234)
-    net = ON.OracleNet(sd, opt, copy.deepcopy(ON.DEFAULT_CFG))
+    net = ON.OracleNet(sd, opt, copy.deepcopy(ON.DEFAULT_CFG), variant=variant)
     rng = np.random.RandomState(3)
     for _ in range(warm):
         net.train_step(blob, dict(rng=rng))
@@ -138,8 +140,8 @@ def cpu_baseline(H, W, T, V, warm, timed):
     dt = float(np.mean(ts))
     return {'value': 1.0 / dt, 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model(),
             's_per_step': dt, 's_per_step_all': [round(t, 3) for t in ts],
-            'sample': '%d warm-up + %d timed train steps (%dx%d image, %d tokens, 256 RoIs, fp32, torch-CPU restatement in oracle/), mean %.1f s / step'
-                      % (warm, timed, H, W, T, dt)}
+            'sample': '%d warm-up + %d timed train steps of the %s variant (%dx%d image, %d tokens, 256 RoIs, fp32, torch-CPU restatement in oracle/), mean %.1f s / step'
+                      % (warm, timed, variant, H, W, T, dt)}
 
 
 def _baseline_metric():
@@ -150,7 +152,7 @@ def _baseline_metric():
         return 'train images/sec (cycle loss on), 600×1000 input, at 1/2/4/8 MI355X'
 
 
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 
 
 def src_hash():
@@ -181,6 +183,19 @@ def _profile_meta():
 def _profile_is_current():
     m = _profile_meta()
     return bool(m) and m.get('src_hash') == src_hash()
+
+
+def _profile_kernel_time_ms():
+    """sum of the committed rocprofv3 per-step kernel table (profiles/<round>_step_kernel_stats.csv), ms per step; None while the table
+    was taken on other kernel sources"""
+    if not _profile_is_current():
+        return None
+    try:
+        import csv
+        rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', '%s_step_kernel_stats.csv' % PROFILE_ROUND))))
+        return sum(float(r['total_us_per_step']) for r in rows) * 1e-3
+    except Exception:
+        return None
 
 
 def _pmc_traffic(which):
@@ -554,6 +569,17 @@ def main(argv=None, hooks=None):
         dth = rank_max(time.time() - t0)
         extras['pcie_inclusive'] = {'ms_per_step': dth / args.steps * 1e3, 'value': world * args.steps / dth, 'unit': 'img/s',
                                     'h2d_bytes_per_step': int(hosts[0].numel() * 4), 'note': 'image blob re-uploaded from pinned host memory before every step'}
+        # ---- the reference's train_step as it stands, both at once: the image goes host -> device (NET:633-636) AND the losses come back as
+        # Python floats after every step (NET:704-710) ----
+        barrier()
+        t0 = time.time()
+        for i in range(args.steps):
+            devd[i % 4].copy_(hosts[i % 4], non_blocking=True)
+            net.train_step(blobs[i % 4], 0, optim)
+        barrier()
+        dtd = rank_max(time.time() - t0)
+        extras['dropin_train_step'] = {'ms_per_step': dtd / args.steps * 1e3, 'value': world * args.steps / dtd, 'unit': 'img/s',
+                                       'note': 'Network.train_step with the 7.2 MB image uploaded from pinned host memory before the step and the loss floats read back after it'}
         # ---- mixed shapes: six different (image size, token count) shapes, every tape recorded before the timed region ----
         if args.mixed_shapes and world == 1 and args.height == 600 and args.width == 1000:
             shapes = [(600, 800, 8), (600, 900, 12), (600, 1000, 20), (800, 600, 5), (600, 904, 9), (600, 800, 14)]
@@ -604,6 +630,8 @@ def main(argv=None, hooks=None):
         out.update(extras)
         if 'sync_train_step' in extras:
             out['sync_train_step_value'] = extras['sync_train_step']['value']      # Network.train_step as the reference calls it (seven floats read back per step)
+        if 'dropin_train_step' in extras:
+            out['dropin_train_step_value'] = extras['dropin_train_step']['value']  # ... with the image uploaded before every step as well: the reference's unit as it stands
         if hooks.lib or hooks.note:
             out['ab'] = 'A/B run (tools/ab.py): %s %s' % (hooks.note, hooks.lib)
         if experiment:
@@ -639,13 +667,15 @@ def main(argv=None, hooks=None):
                 g = tab[dom]
                 per_launch_ms = g['ms_per_step'] / g['launches_per_step']
                 rp = _rocprof_group(getattr(lt, 'group_kernel_counts', {}).get(dom), g['gflop_per_step'])
-                # `achieved` / `frac`: the group's FLOPs over its EXECUTION time (launches x the committed rocprofv3 average of each kernel
-                # template, reproducible from profiles/); `achieved_in_step` / `frac_in_step`: over the HIP-event time inside the pipelined
-                # step, which also holds the wait for free CU slots.  Without a profile of this build of the kernels both are the event figure.
+                # `achieved` / `frac`: the group's FLOPs over the HIP-event time of its launches in THIS run (inside the pipelined step: the
+                # intervals also hold the wait for free CU slots); `rocprof`: the same launches x the committed rocprofv3 execution time of each
+                # kernel template (profiles/, only while its source hash is this build's); `kernel_time_ms_per_step`: the sum of that table.
                 out['roofline'] = {
                     'bound': 'mfma', 'kernel': '%s: %d launches per step of %s' % (dom, round(g['launches_per_step']), ' / '.join(g['kernels'])),
-                    'achieved': rp['achieved'] if rp else g['tflops'], 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': rp['frac'] if rp else g['frac'],
-                    'achieved_in_step': g['tflops'], 'frac_in_step': g['frac'], 'frac_source': 'rocprofv3 execution time (profiles/)' if rp else 'HIP events inside the step',
+                    'achieved': g['tflops'], 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s', 'frac': g['frac'],
+                    'frac_source': 'HIP events of this run, on the launch tape inside pipelined replayed steps (they include the wait for free CU slots); '
+                                   'rocprof.frac = the same launches by the committed rocprofv3 execution times',
+                    'kernel_time_ms_per_step': _profile_kernel_time_ms(),
                     'launches_per_step': g['launches_per_step'], 'ms_per_step': g['ms_per_step'], 'gflop_per_step': g['gflop_per_step'],
                     'avg_launch_ms': per_launch_ms, 'rocprof_avg_launch_us': _rocprof_avgs(g['kernels']), 'traffic': dt_,
                     'rocprof': rp,
@@ -663,7 +693,7 @@ def main(argv=None, hooks=None):
             out['roofline'] = None
         if world == 1 and not args.no_cpu_baseline:
             w, k = [int(x) for x in args.cpu_baseline_steps.split(',')]
-            out['cpu_baseline'] = cpu_baseline(args.height, args.width, T, V, w, k)
+            out['cpu_baseline'] = cpu_baseline(args.height, args.width, T, V, w, k, variant)
         emit(out)
     if use_dp:
         dist.destroy_process_group()

@@ -22,8 +22,15 @@ from . import anchors as ANC
 class ConvOp(object):
     """One convolution / linear layer on the MFMA implicit-GEMM kernels (forward, data-grad, weight-grad)."""
 
-    def __init__(self, net, wkey, Cin, Cout, k=1, stride=1, pad=0, bias_key=None, need_dgrad=True, group=None, Cout_pad=None):
+    def __init__(self, net, wkey, Cin, Cout, k=1, stride=1, pad=0, bias_key=None, need_dgrad=True, group=None, Cout_pad=None, full_map=False):
         self.net, self.wkey, self.Cin, self.Cout, self.k, self.stride, self.pad = net, wkey, Cin, Cout, k, stride, pad
+        # full_map: a 'valid' k x k convolution that is only ever applied to k x k maps (VGG's fc6 on the 7x7 pooled RoIs: one output pixel).  Its
+        # data gradient is then a plain GEMM dx[n][(y, x, ci)] = sum_co g[n][co] W[co][y][x][ci]: the data-gradient weight copy is the transpose of
+        # the [Cout][k k Cin] matrix ("one tap, k k Cin channels"), not the flipped-tap layout of a general convolution, which would run it as a
+        # k x k convolution with pad k - 1 over 1x1 maps - 48 of every 49 taps on padding (fc6 at 600x1000: 2.42 ms = 0.009 of peak, a third of the
+        # VGG step, found when bench.py --variant vgg first ran at the BASELINE size in round 5).
+        self.full_map = bool(full_map and k > 1 and pad == 0 and stride == 1)
+        self.t_taps, self.t_cin = (1, k * k * Cin) if self.full_map else (k * k, Cin)     # shape of the transposed (data-gradient) copy
         self.bias_key, self.need_dgrad, self.group = bias_key, need_dgrad, group
         self.Np = Cout if Cout_pad is None else Cout_pad      # padded output width (grouped heads)
         # the backbone's layer1-3 launches form latency-bound dependent chains that share their CUs with the weight-gradient stream: their
@@ -65,7 +72,7 @@ class ConvOp(object):
         if not self.trainable and full:
             O.weight_cast(self.w_master, self.scale, self.wf, self.Np, taps, self.Cin)
         if self.wb is not None:
-            O.weight_transpose(self.w_master, self.scale, self.wb, self.Np, taps, self.Cin)
+            O.weight_transpose(self.w_master, self.scale, self.wb, self.Np, self.t_taps, self.t_cin)
 
     def out_hw(self, IH, IW):
         return (IH + 2 * self.pad - self.k) // self.stride + 1, (IW + 2 * self.pad - self.k) // self.stride + 1
@@ -80,6 +87,11 @@ class ConvOp(object):
     def dgrad(self, g, n, IH, IW, dx, add=None, ref=None):
         """dx[n,IH,IW,Cin] = conv^T(g); epilogue: (+ add) then ReLU mask by ref > 0."""
         OH, OW = self.out_hw(IH, IW)
+        if self.full_map:
+            assert IH == self.k and IW == self.k and OH == 1 and OW == 1
+            O.conv_igemm(g, self.wb, dx, n, 1, 1, self.Np, 1, 1, self.t_cin, 1, 1, 1, 0, add=add, ref=ref, dt=self.net.dt,
+                         prio=max(self.prio, self.net.prio_floor))
+            return dx
         if self.stride == 1:
             O.conv_igemm(g, self.wb, dx, n, OH, OW, self.Np, IH, IW, self.Cin, self.k, self.k, 1, self.k - 1 - self.pad,
                          add=add, ref=ref, dt=self.net.dt, ws=self.net.splitk_ws(n * IH * IW * self.Cin), prio=max(self.prio, self.net.prio_floor),
@@ -634,7 +646,7 @@ class Network(object):
             arr = (TransposeDesc * len(items))()
             for i, c in enumerate(items):
                 arr[i].src, arr[i].scale, arr[i].dst = c.w_master.data_ptr(), (c.scale.data_ptr() if c.scale is not None else None), c.wb.data_ptr()
-                arr[i].Cout, arr[i].taps, arr[i].Cin, arr[i].force_f32 = c.Np, c.k * c.k, c.Cin, int(getattr(c, 'force_f32', 0))
+                arr[i].Cout, arr[i].taps, arr[i].Cin, arr[i].force_f32 = c.Np, getattr(c, 't_taps', c.k * c.k), getattr(c, 't_cin', c.Cin), int(getattr(c, 'force_f32', 0))
                 if self.dt == BF16 and isinstance(c, ConvOp) and c.trainable and not arr[i].force_f32:
                     # the bf16 shadow the update kernel keeps current holds the same values (bf16(scale * w)): half the bytes to read
                     arr[i].src, arr[i].scale, arr[i].force_f32 = c.wf.data_ptr(), None, 2

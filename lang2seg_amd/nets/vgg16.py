@@ -46,7 +46,7 @@ class vgg16(resnetv1):
             need_dx = trainable and first_trainable_seen      # nothing trainable below the first trainable conv (conv3_1)
             first_trainable_seen = first_trainable_seen or trainable
             self.vgg_plan.append(('conv', i, ConvOp(self, wk, cin, cout, 3, 1, 1, bias_key=bk, need_dgrad=need_dx), cin, cout))
-        self.fc6 = ConvOp(self, 'vgg.classifier.0.weight', 512, 4096, 7, 1, 0, bias_key='vgg.classifier.0.bias')
+        self.fc6 = ConvOp(self, 'vgg.classifier.0.weight', 512, 4096, 7, 1, 0, bias_key='vgg.classifier.0.bias', full_map=True)
         self.fc7 = ConvOp(self, 'vgg.classifier.3.weight', 4096, 4096, 1, 1, 0, bias_key='vgg.classifier.3.bias')
         self.rpn_conv = ConvOp(self, 'rpn_net.weight', C4, 512, 3, 1, 1, bias_key='rpn_net.bias')
         self.rpn_heads = ConvOp(self, None, 512, 6 * A, group=('rpn_head_w', 'rpn_head_b'), Cout_pad=P.rpn_npad)
