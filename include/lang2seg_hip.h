@@ -44,6 +44,7 @@ int l2s_version(void);
 #define L2S_ALGO_KSPLIT_D3 6   /* the same with a ring of three LDS stages instead of four */
 #define L2S_ALGO_PATCH 3       /* 3x3 / stride 1 / pad 1 on one map: 128 pixels x 32 or 64 channels per workgroup, input patch staged once for the nine taps */
 #define L2S_ALGO_PDMA 7           /* the LDS-DMA tile as ONE persistent workgroup per CU walking its tiles, requests running ahead across tile boundaries (plain GEMMs) */
+#define L2S_ALGO_DMA196 10         /* igemm_dma196_kernel: the 256 x 128 LDS-DMA pipeline on tiles of 196 rows (on request: 2-4 % faster alone, 1 % slower inside the step) */
 #define L2S_ALGO_DMA256 9          /* igemm_dma256_kernel: 256x256 LDS-DMA tile for wide plain GEMMs (chosen automatically for them) */
 #define L2S_ALGO_WS64_STAMPED 8  /* the 64x64 wave-specialised tile with clock stamps per workgroup in ws (tools/ws64_stamps.py) */
 typedef struct {

@@ -1328,6 +1328,238 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
   igemm_epilogue<T, TM, TN, WM, WN, false>(p, acc, m0, n0, wm, wn, fr, fg, M);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same LDS-DMA pipeline on tiles of 196 ROWS (round 5).  The dominant launch - layer4's 3x3 on the 256 RoIs, M = 12544 = 49 x 256,
+// N = 512 - is 196 tiles of 256 x 128 on 256 CUs: inside its busy CUs the 256-row kernel runs within ~15 % of the matrix pipe's rate at
+// the clock the chip holds, and a quarter of the chip idles.  M = 64 x 196, so a 196-row tile gives 64 x 4 = EXACTLY 256
+// workgroups whose tiles are 13 row fragments (208 rows, 6 % padding) instead of 16.  13 does not divide by the four wave rows: wave row 0
+// keeps four fragments (rows 0-63) and wave rows 1-3 take three (rows 64-111, 112-159, 160-207), i.e. the two groups' MULTIPLY slots are
+// 32 and 24 MFMAs long - 56 per slice instead of 64 - while the LDS geometry, the requests (the pieces of rows >= 208 carry the
+// out-of-range offset), the K walk and every wait stay those of igemm_dma_kernel<256,128>.  The two fragment counts are two
+// instantiations of the body, chosen per wave (the barriers of a workgroup count arrivals, not program locations).
+// Rows 196-207 of a tile belong to the next tile: they are computed (their operands are valid rows) and not stored.
+// ------------------------------------------------------------------------------------------------
+constexpr int T196 = 196, R208 = 208;
+template <int TMW>
+__device__ __forceinline__ void igemm_dma196_body(const l2s_conv_desc& p, char* smem, int wave, int lane) {
+  typedef bf16_t T;
+  constexpr int BM = 256, BN = 128, TN = 4;
+  constexpr int PA = BM / 64, PB = BN / 64, NP = PA + PB;
+  constexpr int STG = (BM + BN) * ROWB;
+  const int tid = threadIdx.x;
+  const int grp = wave >> 2;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int rbase = wm == 0 ? 0 : 16 + 48 * wm;             // 0, 64, 112, 160
+  const int M = p.n_img * p.OH * p.OW;
+  const int K = p.KH * p.KW * p.Cin;
+  int mt, nt;
+  {
+    const int MT = (M + T196 - 1) / T196, NT = (p.Cout + BN - 1) / BN, G = MT * NT;
+    const int L = blockIdx.x, x = L & 7, slot = L >> 3, q = G >> 3, r = G & 7;
+    const int t = x * q + min(x, r) + slot;
+    if (p.xcd_mode == 0) { mt = t / NT; nt = t - mt * NT; } else { nt = t / MT; mt = t - nt * MT; }
+  }
+  const int m0 = mt * T196, n0 = nt * BN;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const long xpix = (long)p.n_img * p.IH * p.IW;
+  i32x4s rx, rw;
+  rx.x = (int)(uintptr_t)p.x; rx.y = (int)((uintptr_t)p.x >> 32); rx.z = (int)(((xpix - 1) * p.ldx + p.Cin) * 2L); rx.w = 0x00020000;
+  rw.x = (int)(uintptr_t)p.w; rw.y = (int)((uintptr_t)p.w >> 32); rw.z = (int)((long)p.Cout * K * 2L); rw.w = 0x00020000;
+  const int prow = lane >> 3, sch = (lane & 7) ^ prow;
+  const int ohw = p.OH * p.OW;
+  int vbase[PA]; unsigned ntmask[PA];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) {
+    const int lr = 8 * (wave + 8 * j) + prow;                // row of the tile
+    const int m = m0 + lr;
+    const bool ok = m < M && lr < R208;
+    const int mm = ok ? m : 0;
+    const int n_img = mm / ohw, rem = mm - n_img * ohw;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    vbase[j] = (((n_img * p.IH + iy0) * p.IW + ix0) * p.ldx + sch * 8) * 2;
+    unsigned mk = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        if (ky < p.KH && kx < p.KW && ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1u << (ky * p.KW + kx);
+      }
+    ntmask[j] = ~mk;
+  }
+  unsigned voffB[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int n = n0 + 8 * (wave + 8 * j) + prow;
+    voffB[j] = n < p.Cout ? (unsigned)(((long)n * K + sch * 8) * 2L) : OOR;
+  }
+  const int KT = K / 64;
+  int c0 = 0, ky = 0, kx = 0, tapi = 0;
+  unsigned vo[PA], soA = 0, soB = 0;
+  int toff = 0;
+  auto prep_s = [&]() {
+    toff = (ky * p.IW + kx) * p.ldx * 2;
+    soA = (unsigned)(c0 * 2); soB = (unsigned)((tapi * p.Cin + c0) * 2);
+  };
+  auto prep_v = [&](int j) { vo[j] = (((ntmask[j] >> tapi) & 1u) << 31) | (unsigned)(vbase[j] + toff); asm volatile("" : "+v"(vo[j])); };
+  auto prep_adv = [&]() {
+    const int nkx = kx + 1; const bool wx = nkx == p.KW; kx = wx ? 0 : nkx;
+    const int nky = ky + (wx ? 1 : 0); const bool wy = nky == p.KH; ky = wy ? 0 : nky;
+    tapi = wy ? 0 : tapi + 1; c0 += wy ? 64 : 0;
+  };
+  auto prep = [&]() {
+    prep_s();
+#pragma unroll
+    for (int j = 0; j < PA; ++j) prep_v(j);
+    prep_adv();
+  };
+  const unsigned ldsA = lds0 + (unsigned)(wave * 1024), ldsB = ldsA + (unsigned)(BM * ROWB);
+  auto request = [&](int stage) {
+    const unsigned sb = (unsigned)(stage * STG);
+#pragma unroll
+    for (int j = 0; j < PA; ++j) dma_b128(rx, vo[j], soA, ldsA + sb + (unsigned)(j * 8192));
+#pragma unroll
+    for (int j = 0; j < PB; ++j) dma_b128(rw, voffB[j], soB, ldsB + sb + (unsigned)(j * 8192));
+  };
+  f32x4 acc[TMW][TN];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = fr & 7;
+  const int offa = (rbase + fr) * ROWB, offb = BM * ROWB + (wn * 64 + fr) * ROWB;
+  uint4 fa[2][TMW], fb[2][TN];
+  auto read_all = [&](int stage) {
+    const char* base = smem + stage * STG;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int ch = ((kg * 4 + fg) ^ swz) << 4;
+#pragma unroll
+      for (int i = 0; i < TMW; ++i) fa[kg][i] = *(const uint4*)(base + offa + i * 16 * ROWB + ch);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[kg][j] = *(const uint4*)(base + offb + j * 16 * ROWB + ch);
+    }
+  };
+  auto mma_all = [&]() {
+    int q = 0;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = Mma<T>::run(fb[kg][j], fa[kg][i], acc[i][j]);
+          if (q == 2) { __builtin_amdgcn_sched_barrier(0); prep_s(); __builtin_amdgcn_sched_barrier(0); }
+          if (q >= 5 && (q - 5) % 4 == 0 && (q - 5) / 4 < PA) { __builtin_amdgcn_sched_barrier(0); prep_v((q - 5) / 4); __builtin_amdgcn_sched_barrier(0); }
+          if (q == 5 + 4 * PA) { __builtin_amdgcn_sched_barrier(0); prep_adv(); __builtin_amdgcn_sched_barrier(0); }
+          ++q;
+        }
+  };
+  prep(); request(0);
+  if (1 < KT) { prep(); request(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (2 < KT) prep();
+  wg_barrier();
+  if (grp == 1) wg_barrier();
+  int st = 0;
+  for (int t = 0; t < KT; ++t) {
+    const int st2 = st == 0 ? 2 : st - 1;
+    read_all(st);
+    if (t + 2 < KT) request(st2);
+    wait_lgkm0();
+    if (grp == 1) {
+      if (t + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    wg_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) {
+      if (t + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    wg_barrier();
+    st = st == 2 ? 0 : st + 1;
+  }
+  if (grp == 0) wg_barrier();
+  // ---- epilogue: the fp32 tile (+ bias) through LDS (row pitch BN + 4 floats), then bias / residual / ReLU / mask in fp32, one rounding,
+  // 16-byte stores of whole rows (the arithmetic of igemm_epilogue_lds128); rows >= 196 of the tile are the next tile's ----
+  {
+    constexpr int LDW = BN + 4, CPR = BN / 8, CH = R208 * CPR, NTH = 512, IT = (CH + NTH - 1) / NTH;
+    constexpr unsigned NOPE = 0x80000000u;
+    float* stg = (float*)smem;
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, 0x7FFFFFFF, 0x00020000);
+    const auto radd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.add ? p.add : p.y), 0, 0x7FFFFFFF, 0x00020000);
+    const auto rref = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref ? p.ref : p.y), 0, 0x7FFFFFFF, 0x00020000);
+    f32x4 bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.Cout) bv[j] = *(const f32x4*)(p.bias + n);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x4 v = acc[i][j];
+        v[0] += bv[j][0]; v[1] += bv[j][1]; v[2] += bv[j][2]; v[3] += bv[j][3];
+        *(f32x4*)(stg + (rbase + i * 16 + fr) * LDW + wn * 64 + j * 16 + fg * 4) = v;
+      }
+    __syncthreads();
+    u32x4v av[IT], rv[IT];
+    unsigned off[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const int c = tid + NTH * k, row = c / CPR, col = (c % CPR) * 8;
+      const int m = m0 + row, n = n0 + col;
+      const bool ok = c < CH && row < T196 && m < M && n < p.Cout;
+      off[k] = ok ? (unsigned)m : NOPE;
+      if (p.add) av[k] = __builtin_amdgcn_raw_buffer_load_b128(radd, ok ? (unsigned)((m * p.ldadd + n) * 2) : NOPE, 0, 0);
+      if (p.ref) rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rref, ok ? (unsigned)((m * p.ldref + n) * 2) : NOPE, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const int c = min(tid + NTH * k, CH - 1), row = c / CPR, col = (c % CPR) * 8;
+      const f32x4 lo = *(const f32x4*)(stg + row * LDW + col), hi = *(const f32x4*)(stg + row * LDW + col + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (p.add) {
+        const unsigned w[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u); }
+      }
+      if (p.flags & L2S_CONV_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.ref) {
+        const unsigned w[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!(__uint_as_float(w[e] << 16) > 0.f)) v[2 * e] = 0.f;
+          if (!(__uint_as_float(w[e] & 0xFFFF0000u) > 0.f)) v[2 * e + 1] = 0.f;
+        }
+      }
+      u32x4v pk;
+      pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      pk.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); pk.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      const int n = n0 + col;
+      __builtin_amdgcn_raw_buffer_store_b128(pk, ry, off[k] != NOPE ? (unsigned)((off[k] * p.ldy + n) * 2) : NOPE, 0, 0);
+    }
+  }
+}
+__global__ __launch_bounds__(512) void igemm_dma196_kernel(const l2s_conv_desc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if ((wave >> 1) == 0) igemm_dma196_body<4>(p, smem, wave, lane);
+  else igemm_dma196_body<3>(p, smem, wave, lane);
+}
+
 // ---- per-WAVE epilogue of a 64 x 64 sub-tile (bf16 out, plain row-major output): the arithmetic of igemm_epilogue_fast (bias, residual,
 // ReLU, mask in fp32, one rounding; operands requested up front in the MFMA layout), but the results leave through 2 KiB of LDS that
 // belong to this wave alone: 16 rows x 64 channels at a time are written in the MFMA layout (8 bytes per lane) and read back row-major
@@ -2379,6 +2611,16 @@ int launch_igemm_dma(const l2s_conv_desc& d, hipStream_t st) {
   return l2s_check_launch();
 }
 
+int launch_igemm_dma196(const l2s_conv_desc& d, hipStream_t st) {
+  const int M = d.n_img * d.OH * d.OW;
+  dim3 grid(cdiv(M, T196) * cdiv(d.Cout, 128));
+  const size_t lds = (size_t)3 * (256 + 128) * ROWB;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)igemm_dma196_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  L2S_LAUNCH(igemm_dma196_kernel, grid, dim3(512), lds, st, d);
+  return l2s_check_launch();
+}
+
 int launch_igemm_dma256(const l2s_conv_desc& d, hipStream_t st) {
   const int M = d.n_img * d.OH * d.OW;
   dim3 grid(cdiv(M, 256) * cdiv(d.Cout, 256));
@@ -2407,10 +2649,10 @@ int launch_igemm_pdma(const l2s_conv_desc& d, hipStream_t st) {
 
 // ---- kernel choice (one place; l2s_conv_plan_name reports it) ----
 enum ConvPlan { PLAN_EINVAL = 0, PLAN_GENERIC64, PLAN_GENERIC128, PLAN_RING64, PLAN_RING128, PLAN_WS64, PLAN_KS64, PLAN_KS64_D3, PLAN_SP224, PLAN_SP256,
-                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK, PLAN_P3_32_256, PLAN_P3_64_256, PLAN_P3_32_384, PLAN_P3_64_384, PLAN_RING128X64, PLAN_PDMA256, PLAN_DMA256X256 };
+                PLAN_DMA256, PLAN_DMA256_STAMPED, PLAN_WS64_SPLITK, PLAN_P3_32_256, PLAN_P3_64_256, PLAN_P3_32_384, PLAN_P3_64_384, PLAN_RING128X64, PLAN_PDMA256, PLAN_DMA256X256, PLAN_DMA196 };
 static const char* const PLAN_NAMES[] = {"invalid", "igemm_kernel<64,64>", "igemm_kernel<128,128>", "igemm_ring_kernel<64,64>", "igemm_ring_kernel<128,128>",
                                          "igemm_ws64_kernel", "igemm_ks64_kernel<4>", "igemm_ks64_kernel<3>", "igemm_sp_kernel<224,128>", "igemm_sp_kernel<256,128>",
-                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel", "igemm_p3_kernel<32,256>", "igemm_p3_kernel<64,256>", "igemm_p3_kernel<32,384>", "igemm_p3_kernel<64,384>", "igemm_ring_kernel<128,64>", "igemm_pdma_kernel<256,128>", "igemm_dma256_kernel"};
+                                         "igemm_dma_kernel<256,128>", "igemm_dma_kernel<256,128,stamped>", "igemm_ws64_kernel + splitk_reduce_kernel", "igemm_p3_kernel<32,256>", "igemm_p3_kernel<64,256>", "igemm_p3_kernel<32,384>", "igemm_p3_kernel<64,384>", "igemm_ring_kernel<128,64>", "igemm_pdma_kernel<256,128>", "igemm_dma256_kernel", "igemm_dma196_kernel"};
 static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
   if (!d || !d->x || !d->w || !d->y || (dtype != L2S_BF16 && dtype != L2S_F32)) return PLAN_EINVAL;
   const bool bf = dtype == L2S_BF16;
@@ -2457,6 +2699,15 @@ static ConvPlan conv_plan(const l2s_conv_desc* d, int dtype, bool* tapin_out) {
     const bool d256_ok = pdma_ok && d->Cout % 256 == 0 && d->Cout >= 1024 && M >= 4096 && !(d->ldy & 7) && !(d->Cout & 7) &&
                          !((uintptr_t)d->y & 15) && !(d->ldadd & 3) && !(d->ldref & 3);
     if (d256_ok && (algo == L2S_ALGO_DMA256 || (algo == L2S_ALGO_AUTO && l2s_knobs::dma256_auto))) return PLAN_DMA256X256;
+    // 196-row tiles of the same pipeline (layer4 on 256 RoIs with N = 512: 256 workgroups of 13 row fragments instead of 196 of 16); plain row-major
+    // bf16 outputs only (its epilogue is the LDS-staged one).  ON REQUEST ONLY: measured (round 5, tools/conv_bench.py, same box) 62.8 / 60.5 us
+    // against 64.1 / 61.6 us for the 3x3 and 32.5 against 33.8 us for the 1x1 - 2-4 % for 19 % less work per CU, because with all 256 CUs multiplying
+    // the chip holds a lower clock (the loop is power-bound) - and the step is 1 % SLOWER with it (213.8 against 216.1 img/s, x2):
+    // the 60 CUs the 256-row grid leaves idle are where the caption branch and the other queues run.
+    const bool d196_ok = dma_ok && !(d->flags & (L2S_CONV_DECONV2X2 | L2S_CONV_SCATTER)) && !(d->ldy & 7) && !(d->ldadd & 7) && !(d->ldref & 7) && !(d->Cout & 7) &&
+                         !((uintptr_t)d->y & 15) && !((uintptr_t)d->add & 15) && !((uintptr_t)d->ref & 15) && !((uintptr_t)d->bias & 15) &&
+                         M * d->ldy * 2 < (1L << 31) && (!d->add || M * d->ldadd * 2 < (1L << 31)) && (!d->ref || M * d->ldref * 2 < (1L << 31));
+    if (d196_ok && algo == L2S_ALGO_DMA196) return PLAN_DMA196;
     if (dma_ok && (algo == L2S_ALGO_DMA || (algo == L2S_ALGO_AUTO && (tile == 224 || tile == 256)))) return PLAN_DMA256;
     if (dma_ok && algo == L2S_ALGO_DMA_STAMPED) return PLAN_DMA256_STAMPED;
     // patch tile: 3x3 / stride 1 / pad 1 on one map whose row fits the patch (W + 1 <= 128 halo pixels on either side of 128 outputs)
@@ -2523,6 +2774,7 @@ extern "C" int l2s_conv_igemm(const l2s_conv_desc* d, int dtype, hipStream_t str
     case PLAN_PDMA256: return launch_igemm_pdma<256, 128>(dd, stream);
     case PLAN_DMA256X256: return launch_igemm_dma256(dd, stream);
     case PLAN_DMA256: return launch_igemm_dma<256, 128, false>(dd, stream);
+    case PLAN_DMA196: return launch_igemm_dma196(dd, stream);
     case PLAN_DMA256_STAMPED: return launch_igemm_dma<256, 128, true>(dd, stream);
     case PLAN_P3_32_256: return launch_igemm_p3<32, 256, 2>(dd, stream);
     case PLAN_P3_64_256: return launch_igemm_p3<64, 256, 3>(dd, stream);

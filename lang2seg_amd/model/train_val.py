@@ -81,6 +81,10 @@ class SolverWrapper(object):
     # ---- TV:57-104 -----------------------------------------------------
     def snapshot(self, it):
         nfilename = self._sidecar(it)
+        dp = getattr(self.net, 'dp', None)
+        if dp is not None and hasattr(dp, 'gather_master'):
+            self.net.join_update()
+            dp.gather_master()                           # (a collective: every rank is here) the fp32 masters of the sharded update, together again
         if self.rank != 0:
             self._write_sidecar(nfilename, it)           # this rank's own loader cursor / permutation / RNG streams
             return None, nfilename

@@ -619,6 +619,12 @@ class Network(object):
 
     def state_dict(self):
         self.join_update()                          # (an update may still be running on the weight-gradient stream)
+        dp = getattr(self, 'dp', None)
+        if dp is not None and getattr(dp, 'master_stale', False):
+            # sharded data-parallel update with the shadow on the wire: the fp32 masters of the other ranks' slices are behind until they are
+            # gathered - a collective, so a state_dict() taken on one rank only must be preceded by dp.gather_master() on EVERY rank
+            # (model/train_val.py does that before a snapshot)
+            raise RuntimeError('state_dict() of a sharded data-parallel run: call net.dp.gather_master() on every rank first')
         return self.P.state_dict()
 
     def load_state_dict(self, sd, strict=False):

@@ -127,16 +127,19 @@ class SGD(object):
             # the reducer updated this rank's slice of every bucket and gathered the others' (parallel.GradReducer): what is left is the dtype
             # shadow of the gathered weights and the data-gradient copies - on the weight-gradient stream where the tail lives there (the reducer
             # made that stream wait for the last all-gather, GradReducer.finish; the next step joins it before its first trainable layer)
+            gathered = bool(getattr(net.dp, 'gather_shadow', False))      # the all-gathers carried the shadow itself: nothing to rewrite
             if self.side_active and net.use_streams:
                 net.flush_wgrads('final')
                 with torch.cuda.stream(net.streams()['wg']):
-                    self.refresh_shadow()
+                    if not gathered:
+                        self.refresh_shadow()
                     net.refresh_weights()
                     net._mark('update done (wg)')
                 return
             if hasattr(net, 'join_wgrad'):
                 net.join_wgrad()
-            self.refresh_shadow()
+            if not gathered:
+                self.refresh_shadow()
             net.refresh_weights()
             return
         if getattr(getattr(net, 'dp', None), 'bucket_update', None) is self:
@@ -211,7 +214,7 @@ class SGD(object):
         self.net.refresh_weights()
 
     # ---- data parallel, sharded update (parallel.GradReducer(shard_update=...)): a rank updates only ITS slice of a reduce-scattered bucket ----
-    def update_range(self, lo, hi, full=False):
+    def update_range(self, lo, hi, full=False, shadow=False):
         """the update on the elements [lo, hi) of the flat buffer, on the current stream (gradients there are final and summed over ranks).
         full: also rewrite the dtype shadow and clear the gradients consumed (a whole bucket updated on this rank: GradReducer.bucket_update);
         otherwise weights and momentum only (a rank's slice: the shadow follows the all-gather, the clear the next step's memset)."""
@@ -225,8 +228,9 @@ class SGD(object):
             stale = P.stale_marked(s0, s1, getattr(self.net, '_fresh', ()))
             if stale:
                 P.mark_overwritten(P._ow_key - frozenset(stale))
+        # shadow (a rank's slice whose dtype shadow goes on the wire instead of its weights, GradReducer.gather_shadow): written with the update
         O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay, self.grad_scale,
-                             P.shadow if full else None, int(bool(full and self.clear_grad)), lo, hi, c_lo, c_hi)
+                             P.shadow if (full or shadow) else None, int(bool(full and self.clear_grad)), lo, hi, c_lo, c_hi)
 
     def refresh_shadow(self):
         """dtype shadow of every tensor from the (gathered) parameters: shadow = dtype(rowscale * param), no update"""

@@ -85,6 +85,14 @@ class GradReducer(object):
         # same bytes as gathering fp32 gradients, the update's HBM traffic divided by `world`, and the update of a bucket overlaps with
         # the rest of the backward pass instead of trailing the step.  Momentum of the other slices is never read on this rank.
         self.shard_update = shard_update
+        # Round 5: what the all-gather of a sharded bucket carries is the dtype SHADOW the kernels read (bf16(scale * w) in the benchmarked mode), not
+        # the fp32 master weights: half the bytes on the wire (203 -> 102 MB per step at 70 M parameters), and the shadow-only pass over the whole
+        # buffer at the end of the step (0.23 GB of HBM) is gone - every rank writes the shadow of its slice in the update and receives the others'.
+        # The fp32 master weights and the momentum of a slice then live on its owner ONLY; gather_master() (a collective: every rank calls it,
+        # model/train_val.py before a snapshot, Network.state_dict through it) brings the masters together again.
+        self.gather_shadow = shard_update is not None and getattr(net.P, 'shadow', None) is not None
+        self._parts = {}             # bucket lo -> (m, per): the partition of every sharded bucket, for gather_master()
+        self.master_stale = False    # other ranks' slices of P.param are behind (until gather_master())
         self.rank = rank if rank is not None else (dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0)
         # experiment only (bench.py --dp-skip-allreduce): 1 = keep the stream structure but issue no collective, 2 = do nothing.
         # Ranks diverge with either, so model/train_val.py refuses a reducer built this way.
@@ -149,10 +157,16 @@ class GradReducer(object):
             dist.reduce_scatter_tensor(sh, src, op=dist.ReduceOp.SUM)
             own = seg[r * per:(r + 1) * per]
             self._cast(sh, own) if self.wire == 'bf16' else own.copy_(sh)
-            self.shard_update.update_range(lo + r * per, lo + (r + 1) * per)
-            wsl = P.param[lo:lo + m]
-            if self._wshard is None or self._wshard.numel() < per:
-                self._wshard = torch.empty(max(per, (max(self.bounds.values()) + W - 1) // W), dtype=P.param.dtype, device=P.param.device)
+            self._parts[lo] = (m, per)
+            if self.gather_shadow:
+                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per, shadow=True)
+                wsl = P.shadow[lo:lo + m]
+                self.master_stale = W > 1
+            else:
+                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per)
+                wsl = P.param[lo:lo + m]
+            if self._wshard is None or self._wshard.numel() < per or self._wshard.dtype != wsl.dtype:
+                self._wshard = torch.empty(max(per, (max(self.bounds.values()) + W - 1) // W), dtype=wsl.dtype, device=wsl.device)
             mine = self._wshard[:per]
             mine.copy_(wsl[r * per:(r + 1) * per])
             dist.all_gather_into_tensor(wsl, mine)
@@ -163,7 +177,28 @@ class GradReducer(object):
                 self._cast(tail, tb); dist.all_reduce(tb, op=dist.ReduceOp.SUM); self._cast(tb, tail)
             else:
                 dist.all_reduce(tail, op=dist.ReduceOp.SUM)
-            self.shard_update.update_range(lo + m, hi)
+            if self.gather_shadow:
+                self.shard_update.update_range(lo + m, hi, shadow=True)
+            else:
+                self.shard_update.update_range(lo + m, hi)
+
+    def gather_master(self):
+        """sharded update with the shadow on the wire: all-gather the fp32 master weights of every bucket (each rank contributes the slices it owns).
+        A COLLECTIVE - every rank calls it at the same point (before a snapshot, an evaluation on the master weights, a state_dict()); cheap to call
+        when nothing is stale."""
+        if not (self.gather_shadow and self.master_stale) or self.world <= 1:
+            self.master_stale = False
+            return
+        P, W, r = self.net.P, self.world, self.rank
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        for lo, (m, per) in sorted(self._parts.items()):
+            wsl = P.param[lo:lo + m]
+            mine = wsl[r * per:(r + 1) * per].clone()
+            dist.all_gather_into_tensor(wsl, mine)
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        self.master_stale = False
 
     def _exchange(self, seg, lo, hi):
         if self.shard_update is not None:

@@ -204,11 +204,13 @@ def _dp_worker(rank, world, port, ret):
     class TorchSGD(object):
         def __init__(self, P, lr, mu, scale):
             self.P, self.lr, self.mu, self.scale, self.ranges = P, lr, mu, scale, []
-        def update_range(self, lo, hi):
+        def update_range(self, lo, hi, shadow=False):
             P = self.P
             g = P.grad[lo:hi] * self.scale
             P.mom[lo:hi] = self.mu * P.mom[lo:hi] + g
             P.param[lo:hi] -= self.lr * P.mom[lo:hi]
+            if shadow:                                                   # (the HIP kernel writes dtype(rowscale * w); no BN fold in this stand-in)
+                P.shadow[lo:hi] = P.param[lo:hi].to(P.shadow.dtype)
             self.ranges.append((lo, hi))
     w0 = torch.randn(P.total, generator=torch.Generator().manual_seed(7))
     m0 = torch.randn(P.total, generator=torch.Generator().manual_seed(8))
@@ -223,6 +225,19 @@ def _dp_worker(rank, world, port, ret):
             red.ready(st)
         red.finish()
         scale = float(want_g.abs().max())
+        # round 5: the all-gathers carried the dtype SHADOW (what the kernels read); the fp32 masters of the other rank's slices are behind until
+        # gather_master() - a collective - brings them together (train_val.snapshot calls it on every rank)
+        ok = ok and red.gather_shadow and red.master_stale
+        ok = ok and torch.allclose(P.shadow.float(), want_w, atol=0.1 * tol * scale + 1e-6)
+        own = torch.zeros(P.total, dtype=torch.bool)
+        for l, h in upd.ranges:
+            own[l:h] = True
+        ok = ok and torch.allclose(P.param[own], want_w[own], atol=0.1 * tol * scale + 1e-6) and torch.equal(P.param[~own], w0[~own])
+        lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(lst, P.shadow.double().sum().reshape(1).clone())
+        ok = ok and all(torch.equal(lst[0], x) for x in lst)              # every rank holds the same shadow, bit for bit
+        red.gather_master()
+        ok = ok and not red.master_stale
         ok = ok and torch.allclose(P.param, want_w, atol=0.1 * tol * scale + 1e-6)
         covered = sum(h - l for l, h in upd.ranges)
         ok = ok and covered < P.total * 0.51 + 64 * world                 # this rank updated about 1 / world of the elements (+ the bucket tails)

@@ -215,6 +215,52 @@ def test_conv_persistent_dma_tile(cfg):
 
 
 @pytest.mark.parametrize('cfg', [
+    dict(n=256, H=7, W=7, Cin=512, Cout=512, k=3),      # the dominant launch: 64 x 4 = 256 tiles of 196 rows, no ragged tile
+    dict(n=91, H=7, W=7, Cin=128, Cout=256, k=3),       # M = 4459 = 22 x 196 + 147: ragged last tile
+    dict(n=37, H=7, W=7, Cin=192, Cout=200, k=3),       # ragged rows AND a ragged channel tile, three slices per tap
+    dict(n=5, H=7, W=7, Cin=64, Cout=128, k=3),         # M = 245: two tiles, the second nearly empty
+    dict(n=256, H=7, W=7, Cin=1024, Cout=512, k=1),     # layer4[0].conv1 on the RoIs (1x1)
+    dict(n=3, H=9, W=11, Cin=128, Cout=136, k=3),       # maps that are not 7x7: rows of a tile cross images at arbitrary places
+])
+def test_conv_dma196_tile(cfg):
+    """igemm_dma196_kernel (the 256x128 LDS-DMA pipeline on tiles of 196 rows: wave row 0 keeps four row fragments, wave rows 1-3 three; rows
+    196-207 of a tile are computed and not stored) against torch on the same rounded bf16 operands and BIT FOR BIT against the 256-row tile
+    (same k order inside every accumulator): bias + residual + ReLU, the data-gradient forms (ReLU mask; residual + mask), plain.  The tile is
+    on request only (l2s_conv_desc.algo = L2S_ALGO_DMA196): 2-4 % faster alone, 1 % slower inside the step."""
+    O = ops()
+    dt = 1
+    g = torch.Generator().manual_seed(17)
+    n, H, W, Cin, Cout, k = [cfg[x] for x in ['n', 'H', 'W', 'Cin', 'Cout', 'k']]
+    pd = k // 2
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    xd, wd = to_dev(nhwc(x), dt), to_dev(ohwi(w), dt)
+    rd = to_dev(nhwc(torch.randn(n, Cout, H, W, generator=g)), dt); r2d = to_dev(nhwc(torch.randn(n, Cout, H, W, generator=g)), dt)
+    xr, wr = xd.float().cpu().permute(0, 3, 1, 2), wd.float().cpu().permute(0, 3, 1, 2)
+    rr, r2 = rd.float().cpu().permute(0, 3, 1, 2), r2d.float().cpu().permute(0, 3, 1, 2)
+    conv = F.conv2d(xr, wr, None, padding=pd)
+    M = n * H * W
+    ys = {}
+    for algo in (10, 2):
+        outs = []
+        for kw in (dict(bias=b.to(DEV), add=rd, relu=True), dict(ref=rd), dict(bias=b.to(DEV)), dict(add=rd, ref=r2d)):
+            y = torch.full((M, Cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+            O.conv_igemm(xd, wd, y, n, H, W, Cin, H, W, Cout, k, k, 1, pd, algo=algo, **kw)
+            assert ('dma196' in O.LAST_PLAN) == (algo == 10), O.LAST_PLAN
+            outs.append(y)
+        torch.cuda.synchronize()
+        ys[algo] = outs
+    y, y2, y3, y5 = ys[10]
+    assert rel_err(y.float().view(n, H, W, Cout), nhwc(F.relu(conv + b.view(1, -1, 1, 1) + rr))) < TOL[dt]
+    assert rel_err(y2.float().view(n, H, W, Cout), nhwc(conv * (rr > 0))) < TOL[dt]
+    assert rel_err(y3.float().view(n, H, W, Cout), nhwc(conv + b.view(1, -1, 1, 1))) < TOL[dt]
+    assert rel_err(y5.float().view(n, H, W, Cout), nhwc((conv + rr) * (r2 > 0))) < TOL[dt]
+    for a, c in zip(ys[10], ys[2]):
+        assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize('cfg', [
     dict(n=256, H=7, W=7, Cin=512, Cout=2048),     # layer4 conv3 on the RoIs: 392 tiles of 16 slices
     dict(n=256, H=7, W=7, Cin=1024, Cout=2048),    # layer4[0].downsample
     dict(n=256, H=7, W=7, Cin=2048, Cout=1024),    # the downsample's data gradient
