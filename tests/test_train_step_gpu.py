@@ -462,8 +462,13 @@ def test_dp_sharded_update_matches_plain_update():
             net.dp = GradReducer(net, 1, wire='fp32', algo='allreduce', bucket_update=True, rank=0)
         sgd = SGD(net, 1e-3, momentum=0.9, weight_decay=1e-4)
         assert (net.dp is None) or (net.dp.shard_update is sgd) != (net.dp.bucket_update is sgd)
-        for _ in range(4):
+        for i in range(4):
             net.train_step_async(dict(blob), 0, sgd)
+            if i == 1:
+                # a validation summary between two replayed steps (forward only, TV:389-396): it must not disturb the overwrite marks the next
+                # update judges staleness by (Network._fresh used to be reset by forward-only passes, and the bucket update of the
+                # next replayed step then cleared gradients that had already been reduced)
+                net.get_summary(dict(blob), 0)
         torch.cuda.synchronize(); net.join_update(); torch.cuda.synchronize()
         if mode.startswith('bucket'):
             assert any(sg.flags & 1 for sg in net.P._seg_tables[0])                     # the overwrite marks are in force under the reducer too
