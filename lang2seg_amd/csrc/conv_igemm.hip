@@ -1209,7 +1209,14 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
     toff = (ky * p.IW + kx) * p.ldx * 2;
     soA = (unsigned)(c0 * 2); soB = (unsigned)((tapi * p.Cin + c0) * 2);
   };
+#ifdef L2S_TOOLS
+  // tools build: l2s_conv_desc.prio bit 8 = the A operand is requested for tap 0 only (the other taps' requests carry the out-of-range offset: zeros
+  // land in LDS, nothing crosses L2) - the operand traffic of a patch tile that stages the input once for the nine taps; results are garbage
+  const bool ko_a = (p.prio >> 8) & 1;
+  auto prep_v = [&](int j) { vo[j] = ((((ntmask[j] >> tapi) & 1u) | (unsigned)(ko_a && tapi != 0)) << 31) | (unsigned)(vbase[j] + toff); asm volatile("" : "+v"(vo[j])); };
+#else
   auto prep_v = [&](int j) { vo[j] = (((ntmask[j] >> tapi) & 1u) << 31) | (unsigned)(vbase[j] + toff); asm volatile("" : "+v"(vo[j])); };   // (the empty asm pins the arithmetic where it is written: hipcc otherwise sinks it behind the MFMAs)
+#endif
   auto prep_adv = [&]() {
     const int nkx = kx + 1; const bool wx = nkx == p.KW; kx = wx ? 0 : nkx;
     const int nky = ky + (wx ? 1 : 0); const bool wy = nky == p.KH; ky = wy ? 0 : nky;
