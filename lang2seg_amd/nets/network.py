@@ -697,10 +697,12 @@ class Network(object):
         the captioner's own matrices and the backbone - which the update marks under SLOT_UPDATE_REST; the deferred weight gradients
         of the heads stage and their part of the update keep running on the weight-gradient stream until join_deferred()."""
         if self.use_streams and self.update_on_wg:
-            if layer2_only and self.update_split and not self.defer_heads:
+            if layer2_only and self.update_split and not self.defer_heads and not getattr(self, '_pass_without_step', False):
                 # Round 5: the tail of a step is [last weight gradients -> update of layer2 -> (join of the early partial updates) -> transposes];
                 # the next step's layer2 needs the second item only.  The transposes (data-gradient copies: read in backward) and the partial
                 # update of layer3 (its weights are first read ~0.4 ms later) are joined before layer3 (resnet_v1._backbone_fwd).
+                # (The slots are recorded by optim.SGD.step: a backward pass that was NOT followed by a step - tests, gradient checks - left weight
+                # gradients on the side streams that no slot covers; the next pass then takes the whole-stream join below.)
                 O.event_wait(self.SLOT_UPDATE_L2, torch.cuda.current_stream())
                 O.event_wait(self.SLOT_WGRADS, torch.cuda.current_stream())
             elif self.defer_heads and not full:

@@ -944,6 +944,7 @@ class resnetv1(Network):
         self._mark('layer3-2 bwd')
         if S is not None:
             self.sfork(S['lang'], main)
+        self._pass_without_step = True                          # until optim.SGD.step records the tail's event slots (Network.join_update)
         return loss
 
 

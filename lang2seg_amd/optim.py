@@ -123,6 +123,7 @@ class SGD(object):
         P = self.net.P
         net = self.net
         net._bwd_pending = 0
+        net._pass_without_step = False
         if getattr(getattr(net, 'dp', None), 'shard_update', None) is not None:
             # the reducer updated this rank's slice of every bucket and gathered the others' (parallel.GradReducer): what is left is the dtype
             # shadow of the gathered weights and the data-gradient copies - on the weight-gradient stream where the tail lives there (the reducer
