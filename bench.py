@@ -277,6 +277,18 @@ class LaunchTimer(object):
         for c in net.convs:
             self._wrap(c)
         net.wgq.on_launch = self.wgrad_hook
+        # VGG's conv1_1 (3 -> 64 channels, its own kernel, not a ConvOp): timed like the convolutions, group 'vgg.conv1_1 fwd'
+        orig_c3 = ops.conv3x3_c3
+
+        def c3_timed(img, w, bias, y, H, W, _o=orig_c3):
+            if not self.on and self.tape_all:
+                a = self.O.tape_time_event(); _o(img, w, bias, y, H, W); b_ = self.O.tape_time_event()
+                if a >= 0 and b_ >= 0:
+                    self.tape_recs.append(('vgg.conv1_1', 'fwd', 3, 2.0 * H * W * 64 * 27, a, b_)); self.tape_plan.append('conv3x3_c3_kernel')
+                    self.plans.setdefault('vgg.conv1_1 fwd', set()).add('conv3x3_c3_kernel')
+                return
+            _o(img, w, bias, y, H, W)
+        ops.conv3x3_c3 = c3_timed
 
     def _group(self, conv, n, IH, IW):
         k = conv.wkey or (conv.group[0] if conv.group else '?')

@@ -104,11 +104,18 @@ class vgg16(resnetv1):
     # ------------------------------------------------------------------ backbone (VGG:53-54,78-82)
     def _backbone_fwd(self, d, saved):
         P = self.P
-        self.join_update(full=False)                       # (no frozen prefix worth overlapping here)
+        # The frozen prefix (conv1_1 .. conv2_2: 56 GMAC at 600x1000, ~0.35 ms) runs beside the previous step's tail - VGG's update moves 3.3 GB - and
+        # the main queue joins that tail in front of the launch that WRITES the first trainable convolution's input (the pooling behind conv2_2): the
+        # previous step's weight gradient of conv3_1 reads that buffer (the race of resnet_v1._backbone_fwd, round 5).
+        first_tr = next((k for k, l in enumerate(self.vgg_plan) if l[0] == 'conv' and l[2] is not None and l[2].trainable), 0)
+        join_at = first_tr - 1 if (first_tr > 0 and self.vgg_plan[first_tr - 1][0] == 'pool') else first_tr
         H, W = int(d['data'].shape[1]), int(d['data'].shape[2])
         x, h, w, c = None, H, W, 3
         acts = []                               # (kind, idx, input tensor, h, w, channels, output tensor)
-        for l in self.vgg_plan:
+        for k, l in enumerate(self.vgg_plan):
+            if k == join_at:
+                self.join_update(full=False)
+                self._mark('frozen prefix done, update joined')
             if l[0] == 'pool':
                 oh, ow = h // 2, w // 2
                 y = self.buf('vgg.p%d' % l[1], (oh * ow, c))
