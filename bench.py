@@ -130,13 +130,21 @@ def cpu_baseline(H, W, T, V, warm, timed, variant='cycle'):
     blob = OS.make_blob(H, W, T, V, seed=1234)
     net = ON.OracleNet(sd, opt, copy.deepcopy(ON.DEFAULT_CFG), variant=variant)
     rng = np.random.RandomState(3)
+    # a BOUNDED sample: up to `warm` warm-up and `timed` timed steps (3 + 10, ~2 min on an idle 128-thread host), cut short
+    # when the box's host is busy - warm-up stops after 30 s, the timed leg after 100 s (at least two steps) - so that the run stays within minutes
+    t_w, n_w = time.time(), 0
     for _ in range(warm):
-        net.train_step(blob, dict(rng=rng))
-    ts = []
+        net.train_step(blob, dict(rng=rng)); n_w += 1
+        if time.time() - t_w > 30.0:
+            break
+    ts, t_t = [], time.time()
     for _ in range(timed):
         t0 = time.time()
         net.train_step(blob, dict(rng=rng))
         ts.append(time.time() - t0)
+        if len(ts) >= 2 and time.time() - t_t > 100.0:
+            break
+    warm, timed = n_w, len(ts)
     dt = float(np.mean(ts))
     return {'value': 1.0 / dt, 'unit': 'img/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu': cpu_model(),
             's_per_step': dt, 's_per_step_all': [round(t, 3) for t in ts],
