@@ -189,6 +189,31 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
                      extra_sample=dev_ * float(np.abs(g['g.' + nme + '.sample']).max()), extra_sum=dev_ * float(g['g.' + nme + '.abssum']))
 
 
+def test_train_step_per_token_captioner_fallback():
+    """The three-launches-per-token form of the captioner recurrence (lang.hip) is what a network whose shapes the resident launches do not take
+    (rnn_size / att_hid_size != 512, > 224 attention locations) falls back to; every fixture has the resident shapes, so the fallback is run
+    here explicitly (Network.cap_persistent = False) on the tiny cycle fixture: same losses and caption-side gradients as the reference run, and
+    within fp32 rounding of the resident form."""
+    from lang2seg_amd.nets.network import Network
+    was = Network.cap_persistent
+    try:
+        out = {}
+        for resident in (False, True):
+            Network.cap_persistent = resident
+            g, opt, sd, blob, ocfg, samp, net = _setup('f32', 'tiny')
+            lv = net.forward_backward(net.upload_blob(blob, 0)).cpu().numpy()
+            torch.cuda.synchronize()
+            assert bool(net.t.get('cap.resident')) == resident
+            for i, k in enumerate(NAMES):
+                assert abs(lv[i] - float(g['loss.' + k])) < 1e-4 * max(1.0, abs(float(g['loss.' + k]))), (resident, k, lv[i], g['loss.' + k])
+            out[resident] = {k: _grad_of(net, k) for k in ('caption_model.core.h2h.weight', 'caption_model.core.attention.h2att.weight', 'caption_model.att_embed.0.weight')}
+        for k in out[True]:
+            a_, b_ = out[True][k], out[False][k]
+            assert np.abs(a_ - b_).max() <= 1e-4 * max(1e-12, np.abs(b_).max()), k
+    finally:
+        Network.cap_persistent = was
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('tag', ['full', 'full_spatial', 'full_cycle_response', 'full_vgg'])
 def test_train_step_full_size(tag, dtype):
