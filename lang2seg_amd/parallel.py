@@ -165,11 +165,15 @@ class GradReducer(object):
             else:
                 self.shard_update.update_range(lo + r * per, lo + (r + 1) * per)
                 wsl = P.param[lo:lo + m]
-            if self._wshard is None or self._wshard.numel() < per or self._wshard.dtype != wsl.dtype:
-                self._wshard = torch.empty(max(per, (max(self.bounds.values()) + W - 1) // W), dtype=wsl.dtype, device=wsl.device)
-            mine = self._wshard[:per]
-            mine.copy_(wsl[r * per:(r + 1) * per])
-            dist.all_gather_into_tensor(wsl, mine)
+            if self.on_gpu:
+                # in place: this rank's slice already sits where the gathered buffer wants it (RCCL's in-place all-gather: send = recv + rank * count)
+                dist.all_gather_into_tensor(wsl, wsl[r * per:(r + 1) * per])
+            else:
+                if self._wshard is None or self._wshard.numel() < per or self._wshard.dtype != wsl.dtype:
+                    self._wshard = torch.empty(max(per, (max(self.bounds.values()) + W - 1) // W), dtype=wsl.dtype, device=wsl.device)
+                mine = self._wshard[:per]
+                mine.copy_(wsl[r * per:(r + 1) * per])
+                dist.all_gather_into_tensor(wsl, mine)
         if m < n:
             tail = seg[m:]
             if self.wire == 'bf16':
