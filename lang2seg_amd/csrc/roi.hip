@@ -146,76 +146,140 @@ __device__ __forceinline__ bool nms_hit(const float4& a, float aarea, const floa
   const float ovr = inter / uni;                          // nms.c:55-58
   return cmp ? (ovr > thr) : (ovr >= thr);
 }
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int cb, uint64_t* mask) {
-  const int rb = blockIdx.y, cbk = blockIdx.x;
-  if (cbk < rb) return;
+// Round 5: greedy NMS in STAGES of NMS_SB blocks of 64 boxes (4096 boxes), column form.
+//   In the training step the scan runs to the LAST of the 12000 sorted boxes (721 - 2000 of them survive with untrained and early-trained
+//   RPN heads: tools/proposal_depth.py), so the cost is the 188 dependent block resolutions, not the bytes.  Round 4's scan kept the mask in
+//   ROW form (row i = the boxes i suppresses) and fetched the rows of kept boxes - loads that DEPEND on the previous resolutions, two
+//   phases of slack for a memory round trip: 0.9 - 1.2 us per block, 225 - 255 us per call.
+//   Now a stage needs (1) what the boxes kept by EARLIER stages suppress among its columns - one OR-reduction per column block (the
+//   "carry-in", never stored as a mask; all compute units) - and (2) its own diagonal part in COLUMN form: word T[rb][c][lane] = the boxes of
+//   block c that suppress box rb * 64 + lane.  Which words the scan loads no longer depends on what it decides: fifteen waves stream them
+//   ahead of the chain wave and AND them with the keep words as those appear; the chain wave finds, per block, one finished OR word, the
+//   words of the LAG newest blocks and the block's own row-form word in LDS.
+#ifdef L2S_TOOLS
+__device__ long long nms_dbg[16];     // tools build: cycles of the last scan launch - [0] chain total, [1] chain waiting for ready, [2] blocks, [3] wave 1 waiting for loads, [4] wave 1 waiting for keep words, [5] wave 1 total
+#define NMS_T() ((long long)__builtin_readcyclecounter())
+#else
+#define NMS_T() 0ll
+#endif
+constexpr int NMS_SB = 64;     // blocks of 64 boxes per stage
+constexpr int NMS_LAG = 6;     // the newest LAG keep words of a block's predecessors are applied by the chain wave itself
+constexpr int NMS_RING = 16;   // blocks whose LDS slots exist at a time (> LAG)
+constexpr int NMS_SLOT = NMS_LAG + 2;    // LDS words per box: [0] OR of (T & keep) over the older blocks, [1 .. LAG] raw T words, [LAG + 1] the row-form word
+// blockIdx.y < sbw: stage-local row block rb = blockIdx.y against column block blockIdx.x <= rb -> mask[(rb * sbw + c) * 64 + lane]; for
+// c == rb the word is the ROW form (bits above the lane: the later boxes of the block this box suppresses).  blockIdx.y >= sbw (stages after
+// the first): 64 entries of the keep list against column block blockIdx.x -> OR into carry[blockIdx.x] (bit = that box is suppressed).
+// nms_hit always gets the earlier (higher-scored) box first, as the row-form kernel of rounds 1-4 did.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int row0, int sbw, uint64_t* mask,
+                                                      unsigned long long* carry, const int* __restrict__ keep, const int* nk_p, int max_keep,
+                                                      unsigned long long* carry_all, int carry_words) {
+  const int cbk = blockIdx.x, lane = threadIdx.x;
+  int nk = 0;
+  if (row0 > 0) { nk = *nk_p; if (nk >= max_keep) return; }
+  else if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = lane; i < carry_words; i += 64) carry_all[i] = 0ull;
+  const bool diag = (int)blockIdx.y < sbw;
+  const int rb = blockIdx.y;
+  if (diag && cbk > rb) return;
+  if (!diag && ((int)blockIdx.y - sbw) * 64 >= nk) return;
   __shared__ float4 cbox[64];
   __shared__ float carea[64];
-  const int lane = threadIdx.x;
-  const int cj = cbk * 64 + lane;
+  const int cj = row0 + cbk * 64 + lane;
   const float4 cbv = cj < n ? *(const float4*)(boxes + (long)cj * 4) : make_float4(0, 0, -1, -1);
   cbox[lane] = cbv;
   carea[lane] = (cbv.z - cbv.x + 1.f) * (cbv.w - cbv.y + 1.f);
   __syncthreads();
-  const int ri = rb * 64 + lane;
-  if (ri >= n) return;
-  const float4 a = *(const float4*)(boxes + (long)ri * 4);
-  const float aarea = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
-  const int csize = min(64, n - cbk * 64);
+  const int csize = min(64, n - row0 - cbk * 64);
+  if (diag) {
+    const int ri = row0 + rb * 64 + lane;
+    if (ri >= n) return;
+    const float4 a = *(const float4*)(boxes + (long)ri * 4);
+    const float aarea = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+    uint64_t t = 0;
+    if (rb == cbk) {
+      for (int j = lane + 1; j < csize; ++j)
+        if (nms_hit(a, aarea, cbox[j], carea[j], thr, cmp)) t |= 1ull << j;
+    } else {
+      for (int j = 0; j < 64; ++j)
+        if (nms_hit(cbox[j], carea[j], a, aarea, thr, cmp)) t |= 1ull << j;
+    }
+    mask[(long)(rb * sbw + cbk) * 64 + lane] = t;
+    return;
+  }
+  const int ki = ((int)blockIdx.y - sbw) * 64 + lane;
   uint64_t t = 0;
-  const int start = (rb == cbk) ? lane + 1 : 0;
-  for (int j = start; j < csize; ++j)
-    if (nms_hit(a, aarea, cbox[j], carea[j], thr, cmp)) t |= 1ull << j;
-  mask[(long)ri * cb + cbk] = t;
+  if (ki < nk) {
+    const int ri = keep[ki];
+    const float4 a = *(const float4*)(boxes + (long)ri * 4);
+    const float aarea = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
+    for (int j = 0; j < csize; ++j)
+      if (nms_hit(a, aarea, cbox[j], carea[j], thr, cmp)) t |= 1ull << j;
+  }
+  unsigned int lo = (unsigned int)t, hi = (unsigned int)(t >> 32);
+#pragma unroll
+  for (int off = 32; off; off >>= 1) { lo |= __shfl_xor(lo, off); hi |= __shfl_xor(hi, off); }
+  if (lane == 0 && (lo | hi)) atomicOr(&carry[cbk], ((unsigned long long)hi << 32) | lo);
 }
-// Greedy scan over the bitmask (nms.c:35-63 / nms_cuda.c:47-58), one 64-box block per phase, a single workgroup of 16 waves, one raw
-// barrier per phase.  Round 2's form of this kernel took 0.83 us per phase (157 us for 188 blocks): every global word was requested ONE
-// phase ahead, so a phase could not be shorter than a load's round trip from one compute unit, and wave 0 walked every kept box of the
-// block.  Now:
-//   wave 0 (the chain): its words - the block's diagonal word and the NDIR following columns of every row - are requested PD phases
-//           ahead.  Only rows whose diagonal word is non-zero (rows that suppress a LATER row of the same block) are walked in order;
-//           a row without in-block suppressions never changes the block's state, so its fate is bit `row` of the final state.  The
-//           kept rows OR their words of columns b+1 .. b+NDIR straight into remv (LDS atomics).
-//   waves 1..15 (bulk), in two groups that take turns: the kept rows of block j belong to group j & 1, which requests them in phase j+1
-//           for every column >= j+NDIR+1 (one wave per row, contiguous 512-byte pieces), rests in phase j+2 and applies them in phase
-//           j+3 - two phases for the loads, still one phase before the first of those columns is read.
-// Stops as soon as max_keep boxes are kept (RPN_POST_NMS_TOP_N).
-__global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out) {
-  constexpr int NDIR = 3, PD = 3;                  // direct columns per row; phases between wave 0's requests and their use
-  extern __shared__ unsigned long long remv[];     // cb words
-  __shared__ unsigned long long kept_sh[2];
-  __shared__ int nk_sh[2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < cb; c += 1024) remv[c] = 0ull;
-  if (tid == 0) { nk_sh[0] = nk_sh[1] = 0; kept_sh[0] = kept_sh[1] = 0ull; }
+// The scan of one stage (nms.c:35-63 / nms_cuda.c:47-58): n boxes / cb blocks, numbered from row0 in the keep list; the keep count starts
+// from *num_out in the stages after the first, which return at once when the list is already full (RPN_POST_NMS_TOP_N).  One workgroup of
+// sixteen waves, no barrier inside the scan: the waves meet through LDS words.
+//   wave 0 (the chain), block b: waits for ready[b]; removed = carry | slot[0] | (slot[1 .. LAG] & the keep words of the LAG previous blocks,
+//           which it holds itself); then the rows that suppress a later row of their own block are walked in order (the row-form word);
+//           publishes the block's keep word and kdone = b + 1.
+//   waves 1 .. 15, wave w owns blocks w - 1, w + 14, ...: loads the block's column-form words (whatever the chain decides), ANDs word c with
+//           keep word c as soon as kdone > c, stores the OR, the raw words of the newest LAG blocks and the row-form word into the block's LDS
+//           slot, and sets ready[b].
+// A wave that has waited 2^22 polls aborts the launch (it cannot happen while the other waves of the workgroup run).
+__global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out,
+                                                          int row0, const unsigned long long* __restrict__ carry) {
+  constexpr int LAG = NMS_LAG, SLOT = NMS_SLOT, NBULK = 15;
+  extern __shared__ unsigned long long slots[];     // [RING][SLOT][64], then keep words [cb], then carry words [cb]
+  __shared__ int kdone_sh, stop_sh;
+  __shared__ int ready_sh[NMS_SB];
+  unsigned long long* ksh = slots + (size_t)NMS_RING * SLOT * 64;
+  unsigned long long* csh = ksh + cb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: everything a wave branches on is uniform)
+  int nk0 = 0;
+  if (row0 > 0) { nk0 = *num_out; if (nk0 >= max_keep) return; }
+  for (int c = tid; c < cb; c += 1024) { ksh[c] = 0ull; csh[c] = carry ? carry[c] : 0ull; ready_sh[c] = 0; }
+  if (tid == 0) { kdone_sh = 0; stop_sh = 0; }
   __syncthreads();
+  // The LDS words the waves meet through are plain volatile accesses between compiler barriers: one wave's LDS instructions execute in
+  // order, so "data, then flag" needs no wait - and a RELEASE store would wait for vmcnt(0), i.e. for the chain wave's own store into the
+  // keep list (2 - 3 us per block; measured: 535 us per call).
+  // (through address-space-3 pointers: a volatile access through a generic pointer stays a FLAT load - the vector memory path, sc0 sc1, and
+  // an s_waitcnt vmcnt(0) that also waits for every global load in flight; measured: 4300 cycles from the last keep word to a block's ready)
+  typedef __attribute__((address_space(3))) volatile int lds_vint;
+  typedef __attribute__((address_space(3))) volatile unsigned long long lds_vu64;
+  auto lds_ld = [](const int* p) { const int v = *(const lds_vint*)p; asm volatile("" ::: "memory"); return v; };
+  auto lds_st = [](int* p, int v) { asm volatile("" ::: "memory"); *(lds_vint*)p = v; };
+  auto lds_ld64 = [](const unsigned long long* p) { return *(const lds_vu64*)p; };
+  auto lds_st64 = [](unsigned long long* p, unsigned long long v) { *(lds_vu64*)p = v; };
+  auto poll = [&](int* p, int want) {                     // until *p >= want
+    int spins = 0;
+    while (lds_ld(p) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) __builtin_trap();
+    }
+  };
   if (wave == 0) {
     // ---------------- the chain ----------------
-    int nk = 0;                                    // running keep count
-    unsigned long long pw[PD][NDIR + 1];           // [stage][0] = diagonal word, [c] = column blk + c of row blk * 64 + lane
-    auto w0_load = [&](int blk, unsigned long long (&dst)[NDIR + 1]) {
-      const int row = blk * 64 + lane;
-      const bool v = blk < cb && row < n;
-      const uint64_t* mr = mask + (long)row * cb + blk;
+    __builtin_amdgcn_s_setprio(3);
+    int nk = nk0;
+    unsigned long long kprev[LAG];                          // keep words of blocks b-1, b-2, ...
 #pragma unroll
-      for (int c = 0; c <= NDIR; ++c) dst[c] = (v && blk + c < cb) ? mr[c] : 0ull;
-    };
-#pragma unroll
-    for (int s = 0; s < PD; ++s) w0_load(s, pw[s]);
+    for (int k = 0; k < LAG; ++k) kprev[k] = 0ull;
+    long long t_wait = 0, t_res = 0; const long long t_begin = NMS_T(); int nb_done = 0;
     for (int b = 0; b < cb; ++b) {
-      const int row = b * 64 + lane;
-      unsigned long long wv[NDIR + 1];
+      const long long tp = NMS_T();
+      poll(&ready_sh[b], 1);
+      const long long tr = NMS_T();
+      t_wait += tr - tp; ++nb_done;
+      const unsigned long long* sl = slots + (size_t)(b % NMS_RING) * SLOT * 64 + lane;
+      unsigned long long hit = sl[0];
 #pragma unroll
-      for (int c = 0; c <= NDIR; ++c) wv[c] = pw[0][c];
-#pragma unroll
-      for (int s = 0; s + 1 < PD; ++s)
-#pragma unroll
-        for (int c = 0; c <= NDIR; ++c) pw[s][c] = pw[s + 1][c];
-      w0_load(b + PD, pw[PD - 1]);                         // (uses nothing of this phase: off its latency chain)
-      const unsigned long long d = wv[0];
-      unsigned long long rbv = remv[b];
-      unsigned long long rb = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(rbv >> 32)) << 32) |
-                              (unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)rbv);
+      for (int k = 1; k <= LAG; ++k) hit |= sl[k * 64] & kprev[LAG - k];        // slot k holds column block b - LAG + k - 1
+      const unsigned long long d = sl[(LAG + 1) * 64];
+      unsigned long long rb = __ballot(hit != 0ull) | csh[b];
       const int lim = min(64, n - b * 64);
       if (lim < 64) rb |= ~0ull << lim;
       const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
@@ -228,75 +292,93 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
         cand &= ~rb;
       }
       const unsigned long long K = ~rb;
-      const bool mine = (K >> lane) & 1ull;
-      if (mine) { const int pos = nk + __popcll(K & ((1ull << lane) - 1ull)); if (pos < max_keep) keep[pos] = row; }
-      // direct OR of the next NDIR columns (every kept lane ORs its own words: a few same-address LDS atomics cost less than a
-      // 64-lane shuffle reduction)
-      if (mine) {
-#pragma unroll
-        for (int c = 1; c <= NDIR; ++c)
-          if (wv[c] && b + c < cb) atomicOr(&remv[b + c], wv[c]);
+      if (lane == 0) {
+        lds_st64(&ksh[b], K);
+        lds_st(&kdone_sh, b + 1);
       }
+      t_res += NMS_T() - tr;
+      const int row = b * 64 + lane;
+      if ((K >> lane) & 1ull) { const int pos = nk + __popcll(K & ((1ull << lane) - 1ull)); if (pos < max_keep) keep[pos] = row0 + row; }
       nk += __popcll(K);
-      if (lane == 0) { kept_sh[b & 1] = K; nk_sh[b & 1] = nk; }
-      // raw barrier: LDS traffic (atomics, kept_sh / nk_sh) is drained, but the global loads stay in flight across it
-      // (__syncthreads() would wait for vmcnt(0) and put their latency back in front of every phase)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = LAG - 1; k > 0; --k) kprev[k] = kprev[k - 1];
+      kprev[0] = K;
       if (nk >= max_keep) break;
     }
-    if (lane == 0) *num_out = min(nk, max_keep);
+    if (lane == 0) {
+#ifdef L2S_TOOLS
+      nms_dbg[0] = NMS_T() - t_begin; nms_dbg[1] = t_wait; nms_dbg[2] = nb_done; nms_dbg[7] = t_res;
+#endif
+      lds_st(&stop_sh, 1);
+      lds_st(&kdone_sh, 1 << 20);
+      *num_out = min(nk, max_keep);
+    }
     return;
   }
-  // ---------------- bulk: wave w of group g = (w - 1) & 1 owns rows gi, gi + GN, ... of the blocks with (block & 1) == g; a lane owns
-  // columns c0 + lane + 64 k (k < CK).  A kept row is a wave-uniform condition and its words are read as contiguous 512-byte pieces
-  // (whole cache lines: the kernel moves megabytes of mask words through ONE compute unit's L1 path).  The rows of a block are
-  // OR-combined when they are applied, so a lane issues at most CK LDS atomics per block. ----------------
-  constexpr int RW = 10, CK = 3;
-  const int g = (wave - 1) & 1, gi = (wave - 1) >> 1, GN = g == 0 ? 8 : 7;
-  unsigned long long pv[RW][CK]; int pc0 = 0;
+  // ---------------- the column words, ahead of the chain ----------------
+  // A block's words are loaded in batches of 32 (all in flight at once; which words is known without the chain), ANDed with the keep words that
+  // are already published when the batch arrives, and once more after ONE wait for keep word b - LAG - 1 for the rest: the path from that keep
+  // word to ready[b] is one LDS read and a few readlane / AND / OR per late word, and the chain has LAG blocks of its own to cover it.
+  long long t_ld = 0, t_k = 0, t_tail = 0; const long long t_begin = NMS_T();
+  for (int b = wave - 1; b < cb; b += NBULK) {
+    if (lds_ld(&stop_sh)) break;
+    const uint64_t* tb = mask + (long)b * cb * 64 + lane;
+    unsigned long long* sl = slots + (size_t)(b % NMS_RING) * SLOT * 64 + lane;
+    const int nold = b - LAG;                                // column blocks [0, nold) are ANDed here
+    unsigned long long acc = 0ull;
+    // the words that go to the slot as they are: column blocks nold .. b - 1 and the row-form word (index b).  Straight-line code throughout:
+    // a taken scalar branch costs ~20 cycles, and 64 of them per block (a guard per word) were 4600 cycles between the last keep word and ready.
+    unsigned long long raw[LAG + 1];
 #pragma unroll
-  for (int ri = 0; ri < RW; ++ri)
+    for (int k = 0; k <= LAG; ++k) raw[k] = tb[(long)max(nold + k, 0) * 64];
+    for (int base = 0; base < nold; base += 32) {
+      unsigned long long tw[32];
+      const long long tl = NMS_T();
 #pragma unroll
-    for (int k = 0; k < CK; ++k) pv[ri][k] = 0ull;
-  for (int b = 0; b < cb; ++b) {
-    if (((b + 1) & 1) == g) {
-      // (2) apply what this group requested two phases ago (rows of block b - 3 -> columns >= b + 1)
+      for (int i = 0; i < 32; ++i) tw[i] = tb[(long)min(base + i, b) * 64];      // (past nold the word meets a zero keep word)
+      // (left to itself the compiler sinks every load next to its use, below the polls - one memory round trip per word)
 #pragma unroll
-      for (int k = 0; k < CK; ++k) {
-        unsigned long long a = 0ull;
-#pragma unroll
-        for (int ri = 0; ri < RW; ++ri) { a |= pv[ri][k]; pv[ri][k] = 0ull; }
-        if (a) atomicOr(&remv[pc0 + lane + 64 * k], a);
-      }
-      // (1) request block b-1's kept rows for columns >= b + NDIR
-      if (b > 0) {
-        const unsigned long long Kp = kept_sh[(b - 1) & 1];
-        const int c0 = b + NDIR;
-        pc0 = c0;
-#pragma unroll
-        for (int ri = 0; ri < RW; ++ri) {
-          const int r = gi + GN * ri;
-          if (r < 64 && ((Kp >> r) & 1ull)) {                                   // wave-uniform
-            const uint64_t* mr = mask + (long)((b - 1) * 64 + r) * cb;
-#pragma unroll
-            for (int k = 0; k < CK; ++k) {
-              const int c = c0 + lane + 64 * k;
-              if (c < cb) pv[ri][k] = mr[c];
-            }
-            for (int c = c0 + lane + 64 * CK; c < cb; c += 64) {                // larger problems: the rest synchronously
-              const unsigned long long v = mr[c]; if (v) atomicOr(&remv[c], v);
-            }
+      for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(tw[i]));
+      t_ld += NMS_T() - tl;
+      const int hi = min(nold, base + 32);                   // this batch ANDs column blocks [base, hi)
+      int from = base;
+      for (int pass = 0; pass < 2 && from < hi; ++pass) {
+        int have = __builtin_amdgcn_readfirstlane(lds_ld(&kdone_sh));
+        if (pass == 1) {                                     // (the chain sets kdone past every block when it stops early: no wave waits forever)
+          const long long tk = NMS_T();
+          int spins = 0;
+          while (have < hi) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) __builtin_trap();
+            have = __builtin_amdgcn_readfirstlane(lds_ld(&kdone_sh));
           }
+          t_k += NMS_T() - tk;
         }
+        const int to = min(have, hi);
+        // one LDS read for the batch's keep words (lane i reads word base + i), handed out by readlane
+        const unsigned long long kw = (lane < 32 && base + lane >= from && base + lane < to) ? lds_ld64(&ksh[base + lane]) : 0ull;
+        const unsigned int klo = (unsigned int)kw, khi = (unsigned int)(kw >> 32);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const unsigned int k0 = __builtin_amdgcn_readlane(klo, i), k1 = __builtin_amdgcn_readlane(khi, i);
+          acc |= tw[i] & (((unsigned long long)k1 << 32) | k0);          // (words outside [from, to) meet a zero keep word)
+        }
+        from = to;
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (nk_sh[b & 1] >= max_keep) break;
+    // slot b % RING was block b - RING's, which the chain has left (kdone >= nold > b - RING) once the last wait above is over; the first
+    // RING blocks of a stage find theirs unused
+    const long long tt = NMS_T();
+#pragma unroll
+    for (int k = 0; k < LAG; ++k) sl[(k + 1) * 64] = nold + k >= 0 ? raw[k] : 0ull;      // (a stage's first blocks have fewer than LAG predecessors)
+    sl[(LAG + 1) * 64] = raw[LAG];
+    t_tail += NMS_T() - tt;
+    lds_st64(&sl[0], acc);
+    lds_st(&ready_sh[b], 1);                                // (every lane, behind its own slot words)
   }
+#ifdef L2S_TOOLS
+  if (wave == 1 && lane == 0) { nms_dbg[3] = t_ld; nms_dbg[4] = t_k; nms_dbg[5] = NMS_T() - t_begin; nms_dbg[6] = t_tail; }
+#endif
 }
 __global__ void gather_rois_kernel(const float* sboxes, const float* sscores, const int* keep, const int* num, int max_keep, float* rois, float* rs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -896,16 +978,29 @@ extern "C" int l2s_sort_topk(const float* scores, const float* boxes, int n, int
   L2S_LAUNCH(rs_pass_kernel<3>, dim3(nblk), dim3(256), 0, s, scores, boxes, (const unsigned int*)w.kA, (const int*)w.iA, w.kB, w.iB, n, nblk, w.hist, k, sorted_boxes, sorted_scores, sorted_idx);
   return l2s_check_launch();
 }
-extern "C" size_t l2s_nms_workspace_bytes(int n) { return (size_t)n * (size_t)cdiv(n, 64) * 8; }
+static inline size_t nms_mask_words(int n) { const int sbw = min(cdiv(n, 64), NMS_SB); return (size_t)sbw * sbw * 64; }
+static inline size_t nms_scan_lds(int sbw) { return ((size_t)NMS_RING * NMS_SLOT * 64 + 2 * (size_t)sbw) * 8; }
+extern "C" size_t l2s_nms_workspace_bytes(int n) { return (nms_mask_words(n) + (size_t)cdiv(cdiv(n, 64), NMS_SB) * NMS_SB) * 8; }
 extern "C" int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_mode, int max_keep, uint64_t* mask_ws,
                        int* keep_out, int* num_out, hipStream_t s) {
-  if (n <= 0) return L2S_EINVAL;
-  const int cb = cdiv(n, 64);
-  if ((size_t)(cb + 2) * 8 > 60000) return L2S_EINVAL;
-  L2S_LAUNCH(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, cb, mask_ws);
-  L2S_LAUNCH(nms_reduce_kernel, dim3(1), dim3(1024), (size_t)(cb + 2) * 8, s, (const uint64_t*)mask_ws, n, cb, max_keep, keep_out, num_out);
+  if (n <= 0 || max_keep < 1) return L2S_EINVAL;
+  const int cb = cdiv(n, 64), nst = cdiv(cb, NMS_SB);
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)nms_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_scan_lds(NMS_SB)); attr_done = true; }
+  unsigned long long* carry_all = (unsigned long long*)mask_ws + nms_mask_words(n);
+  for (int st = 0; st < nst; ++st) {
+    const int row0 = st * NMS_SB * 64, rows = min(n - row0, NMS_SB * 64), sbw = cdiv(rows, 64);
+    unsigned long long* carry = carry_all + (size_t)st * NMS_SB;
+    L2S_LAUNCH(nms_mask_kernel, dim3(sbw, sbw + (st ? cdiv(max_keep, 64) : 0)), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, row0, sbw, mask_ws,
+               carry, (const int*)keep_out, (const int*)num_out, max_keep, carry_all, nst * NMS_SB);
+    L2S_LAUNCH(nms_reduce_kernel, dim3(1), dim3(1024), nms_scan_lds(sbw), s, (const uint64_t*)mask_ws, rows, sbw, max_keep, keep_out, num_out, row0,
+               st ? (const unsigned long long*)carry : (const unsigned long long*)nullptr);
+  }
   return l2s_check_launch();
 }
+#ifdef L2S_TOOLS
+extern "C" int l2s_tools_nms_dbg(long long* host16) { return hipMemcpyFromSymbol(host16, HIP_SYMBOL(nms_dbg), sizeof(long long) * 16) == hipSuccess ? 0 : L2S_ELAUNCH; }
+#endif
 extern "C" int l2s_gather_rois(const float* sorted_boxes, const float* sorted_scores, const int* keep, const int* num, int max_keep,
                                float* rois, float* roi_scores, hipStream_t s) {
   L2S_LAUNCH(gather_rois_kernel, dim3(cdiv(max_keep, 256)), dim3(256), 0, s, sorted_boxes, sorted_scores, keep, num, max_keep, rois, roi_scores);
