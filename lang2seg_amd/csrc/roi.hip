@@ -89,23 +89,38 @@ __global__ __launch_bounds__(256) void rs_pass_kernel(const float* __restrict__ 
   }
   const int d = (int)((key >> (8 * PASS)) & 255u);
   // ---- bases: digit t over all blocks / over the blocks before this one ----
-  const int* hp = hist + (long)PASS * nblk * 256 + t;
-  int total = 0, before = 0;
-  int bb = 0;
-  for (; bb + 8 <= nblk; bb += 8) {
-    int v[8];
+  // (round 5: as 16-byte loads, sixteen in flight per thread - thread (q, g) sums digits 4q .. 4q + 3 over blocks g, g + 4, ... - and one LDS
+  // exchange; one 4-byte column per thread, eight loads at a time, was fourteen dependent L2 round trips, ~8 of the pass's 11 us)
+  __shared__ int ptot[4][256], pbef[4][256];
+  {
+    const int q = t & 63, g = t >> 6;
+    const int4* hp4 = (const int4*)(hist + (long)PASS * nblk * 256) + q;
+    int4 tv = make_int4(0, 0, 0, 0), bv = make_int4(0, 0, 0, 0);
+    for (int b0 = g; b0 < nblk; b0 += 64) {
+      int4 v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = hp[(bb + u) * 256];
+      for (int u = 0; u < 16; ++u) v[u] = (b0 + 4 * u < nblk) ? hp4[(long)(b0 + 4 * u) * 64] : make_int4(0, 0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { total += v[u]; before += (bb + u < b) ? v[u] : 0; }
+      for (int u = 0; u < 16; ++u) {
+        tv.x += v[u].x; tv.y += v[u].y; tv.z += v[u].z; tv.w += v[u].w;
+        if (b0 + 4 * u < b) { bv.x += v[u].x; bv.y += v[u].y; bv.z += v[u].z; bv.w += v[u].w; }
+      }
+    }
+    *(int4*)&ptot[g][4 * q] = tv; *(int4*)&pbef[g][4 * q] = bv;
   }
-  for (; bb < nblk; ++bb) { const int v = hp[bb * 256]; total += v; before += (bb < b) ? v : 0; }
+  __syncthreads();
+  const int total = ptot[0][t] + ptot[1][t] + ptot[2][t] + ptot[3][t];
+  const int before = pbef[0][t] + pbef[1][t] + pbef[2][t] + pbef[3][t];
 #pragma unroll
   for (int w = 0; w < 4; ++w) wcnt[w][t] = 0;
-  tot[t] = total;
+  // inclusive scan of the 256 totals: shuffles inside a wave + the three wave sums through LDS (sixteen barriers before)
+  int incl = total;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+  if (lane == 63) tot[wave] = incl;
   __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) { const int x = t >= o ? tot[t - o] : 0; __syncthreads(); tot[t] += x; __syncthreads(); }
-  base[t] = tot[t] - total + before;                   // elements with a smaller digit anywhere + this digit in earlier blocks
+  for (int w = 0; w < wave; ++w) incl += tot[w];
+  base[t] = incl - total + before;                     // elements with a smaller digit anywhere + this digit in earlier blocks
   // ---- stable rank inside the block ----
   unsigned long long same = valid ? ~0ull : 0ull;      // lanes of this wave with the same digit
 #pragma unroll

@@ -952,6 +952,38 @@ def test_sort_nms_full_size(dist):
         assert counts['gt'] == counts['ge'] + 100   # the planted threshold-exact pairs tell the two comparators apart
 
 
+@pytest.mark.parametrize('n', [12000, 8192, 4097, 4096, 4033, 1500, 65, 64, 1])
+def test_nms_deep_scan(n):
+    """The proposal chain's NMS in the regime of the training step itself: tests/golden/nms_deep_boxes.npy holds the 12000 sorted boxes of the
+    bench step after 40 updates (tools/proposal_depth.py) - 721 survive, the scan visits every box, all three 4096-box stages of
+    l2s_nms run with their carry-in.  Prefixes of the list put the stage boundary in every position (full, one box over, ragged
+    last block, a single block, a single box); keep lists bit-exact against the C oracle, both comparators, capped and uncapped."""
+    import ctypes as C, os
+    O = ops()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sbx = np.ascontiguousarray(np.load(os.path.join(root, 'tests', 'golden', 'nms_deep_boxes.npy'))[:n])
+    clib = C.CDLL(os.path.join(root, 'oracle', '_build', 'liboracle_ref.so'))
+    sb = torch.from_numpy(sbx).to(DEV)
+    for cmp_mode in (0, 1):
+        ko = np.zeros(n, np.int64)
+        if cmp_mode == 0:
+            od = np.arange(n, dtype=np.int64)
+            cn = clib.oracle_cpu_nms(sbx.ctypes.data_as(C.c_void_p), od.ctypes.data_as(C.c_void_p), C.c_long(n), C.c_float(0.7), ko.ctypes.data_as(C.c_void_p))
+        else:
+            cn = clib.oracle_gpu_nms(sbx.ctypes.data_as(C.c_void_p), C.c_long(n), C.c_float(0.7), ko.ctypes.data_as(C.c_void_p))
+        if n == 12000:
+            assert cn < 2000 and ko[cn - 1] > 11900          # the regime: fewer than RPN_POST_NMS_TOP_N survive, the scan reaches the end
+        for max_keep in (2000, 300, n):
+            ws = torch.empty(O.nms_workspace_bytes(n) // 8 + 8, dtype=torch.int64, device=DEV)
+            keep = torch.full((max_keep,), -1, dtype=torch.int32, device=DEV); num = torch.full((1,), -7, dtype=torch.int32, device=DEV)
+            for rep in range(2):                                 # (the second call finds the workspace and the counters as the first left them)
+                O.nms(sb, n, 0.7, cmp_mode, max_keep, ws, keep, num)
+            torch.cuda.synchronize()
+            ref = ko[:cn][:max_keep]
+            assert int(num.item()) == len(ref), (n, cmp_mode, max_keep, int(num.item()), len(ref))
+            assert np.array_equal(keep.cpu().numpy()[:len(ref)], ref.astype(np.int32)), (n, cmp_mode, max_keep)
+
+
 @pytest.mark.parametrize('seed', [0, 1, 2])
 def test_anchor_target(seed):
     O = ops()
