@@ -170,6 +170,11 @@ class WgradQueue(object):
         order = sorted(rounds)
         # A/B (V5_STREAM): the LDS-DMA filter-row launch (128 workgroups) on another stream, beside the 120-workgroup 256x256 launch
         plan = [('wg', order)]
+        if tag == 'layer2' and net.use_streams and getattr(net, 'layer2_side', False):
+            # the LAST stage of the backward pass on the other weight-gradient stream: 'wg' is still ~0.25 ms behind (a serial queue of grouped
+            # launches since the caption join), and the next step's layer2 waits for exactly these gradients and their update, not for that backlog
+            plan = [('wg2', order)]
+            net._layer2_on_side = True
         if self.V5_STREAM != 'wg' and net.use_streams and getattr(net, 'dp', None) is None and (0, 5) in rounds and (0, 4) in rounds:
             plan = [(self.V5_STREAM, [(0, 5)]), ('wg', [o for o in order if o != (0, 5)])]
         for sname, keys in plan:
@@ -391,7 +396,7 @@ class Network(object):
         """split-K slabs of the grouped weight-gradient launches (one buffer: they all run on the 'wg' stream, in order)"""
         if alt:                                              # (A/B: a second buffer for a launch that runs on another stream)
             if getattr(self, '_wg_ws2', None) is None:
-                self._wg_ws2 = torch.empty((64 << 20) // 4, dtype=torch.float32, device=self.device)
+                self._wg_ws2 = torch.empty(self.WGRAD_WS_BYTES // 4, dtype=torch.float32, device=self.device)
             return self._wg_ws2
         ws = getattr(self, '_wg_ws', None)
         if ws is None:
@@ -688,6 +693,8 @@ class Network(object):
     SLOT_UPDATE_L2 = 1       # ... the update of the LAST segments of the flat buffer (layer2) is done: all the next step's layer2 has to wait for
     SLOT_WGRADS = 2          # ... every launch of the two weight-gradient streams (they read the previous pass's activation buffers) is done
     update_split = False     # set by optim.SGD (side-stream update, one process): layer2 joins the slot, layer3 the whole weight-gradient stream
+    layer2_side = False      # set with update_split: layer2's weight gradients and their update run on 'wg2', beside the backlog of 'wg'; then
+                             # SLOT_UPDATE_L2 = [layer2's weight gradients + update] and SLOT_WGRADS = [every other weight gradient of the step]
 
     def join_update(self, full=True, layer2_only=False):
         """the current stream waits for the optimiser update of the previous step when that ran on the weight-gradient stream
@@ -704,11 +711,21 @@ class Network(object):
                 # (The slots are recorded by optim.SGD.step: a backward pass that was NOT followed by a step - tests, gradient checks - left weight
                 # gradients on the side streams that no slot covers; the next pass then takes the whole-stream join below.)
                 O.event_wait(self.SLOT_UPDATE_L2, torch.cuda.current_stream())
-                O.event_wait(self.SLOT_WGRADS, torch.cuda.current_stream())
+                if not self.layer2_side:                         # (else: join_backlog(), before the launch that overwrites layer2's output)
+                    O.event_wait(self.SLOT_WGRADS, torch.cuda.current_stream())
             elif self.defer_heads and not full:
                 O.event_wait(self.SLOT_UPDATE_REST, torch.cuda.current_stream())
             else:
                 self.sfork(self.streams()['wg'], torch.cuda.current_stream())
+                if self.layer2_side:
+                    self.sfork(self.streams()['wg2'], torch.cuda.current_stream())
+
+    def join_backlog(self):
+        """layer2_side: the current stream waits for the previous step's weight gradients on 'wg' (everything but layer2's).  The first of them
+        to lose a race would be layer3[0]'s, which read layer2's output: called before the launch that writes it."""
+        if self.use_streams and self.update_on_wg and self.layer2_side and self.update_split and not self.defer_heads \
+                and not getattr(self, '_pass_without_step', False):
+            O.event_wait(self.SLOT_WGRADS, torch.cuda.current_stream())
 
     def join_deferred(self):
         """the current stream waits for the deferred tail of the previous step (heads-stage weight gradients, their update): called

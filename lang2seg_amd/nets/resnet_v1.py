@@ -453,6 +453,8 @@ class resnetv1(Network):
             for b, blk in enumerate(self.layers[li]):
                 if before_last is not None and b == len(self.layers[li]) - 1:
                     before_last()
+                if li == 2 and first == 2 and b == len(self.layers[li]) - 1:
+                    self.join_backlog()                            # layer3[0]'s weight gradients of the previous step read this block's output buffer
                 x, h, w, sv = blk.fwd(x, 1, h, w, 'l%d.%d' % (li, b))
                 saved[(li, b)] = sv
         if cfg.RESNET.FIXED_BLOCKS >= 3:

@@ -23,6 +23,7 @@ class SGD(object):
         net.defer_heads = self.defer_active
         # the plain side-stream update records when the LAST segments (layer2) are done: the next step's layer2 waits for that only
         net.update_split = bool(self.side_active and getattr(net, 'dp', None) is None and not self.defer_active)
+        net.layer2_side = bool(net.update_split and self.layer2_side)
         # keep_grad=False: the update kernel zeroes every gradient it consumes (optimizer.zero_grad(), TV:383, folded in), and
         # forward_backward no longer clears the buffer (it is zero when the network is built, and every update leaves it zero; a second
         # backward pass without an update in between is refused); keep_grad=True leaves the step's gradients in P.grad (tests read them there)
@@ -109,6 +110,7 @@ class SGD(object):
     # (Network.join_deferred()).  The launches are the same and so is their order per tensor: weights are bit-identical to the undeferred
     # step's (tests/test_train_step_gpu.py::test_deferred_heads_bit_identical).  There is no host-side pending state: the tail is enqueued
     # by this call, and every reader outside the step (state_dict, TEST mode, snapshots) joins the whole weight-gradient stream.
+    layer2_side = True   # with the split update: layer2's weight gradients + update on 'wg2' instead of behind the backlog of 'wg' (Network.layer2_side)
     defer = False   # measured (round 4, same-box A/B x3): 180.7 img/s with it, 184.1 without - see DESIGN.md section 4.6
 
     def _mark_overwritten(self):
@@ -166,12 +168,15 @@ class SGD(object):
             # the two weight-gradient streams, so that launch does not wait for the language / caption / transpose streams - they are joined
             # behind it, before the transposes.  The next step's layer2 waits for SLOT_UPDATE_L2 only (Network.join_update(layer2_only=True)).
             early_tail = bool(self._seg_done and net.update_split and not self.defer_active and getattr(net.wgq, 'V5_STREAM', 'wg') != 'tr')
-            net.sfork(S['wg2'], S['wg'])
+            side2 = bool(early_tail and getattr(net, '_layer2_on_side', False))     # layer2's weight gradients went to 'wg2' (WgradQueue.flush)
+            net._layer2_on_side = False
+            if not side2:
+                net.sfork(S['wg2'], S['wg'])
             if getattr(net.wgq, 'V5_STREAM', 'wg') == 'tr':
                 net.sfork(S['tr'], S['wg'])               # (A/B: a weight-gradient launch on the transpose stream)
-            O.event_record(net.SLOT_WGRADS, S['wg'])          # behind every weight-gradient launch of this step on 'wg' / 'wg2'
+            O.event_record(net.SLOT_WGRADS, S['wg'])          # behind every weight-gradient launch of this step on 'wg' (/ 'wg2' unless side2)
             if early_tail:
-                T = S['wg']
+                T = S['wg2'] if side2 else S['wg']            # side2: behind layer2's weight gradients, beside the backlog of 'wg'
                 net.sfork(torch.cuda.current_stream(), T)
                 with torch.cuda.stream(T):
                     self._launch(self._seg_done, P.nseg)
