@@ -192,8 +192,11 @@ int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* ws
                   float* sorted_scores, int* sorted_idx, hipStream_t s);
 /* greedy NMS over score-sorted boxes (replaces gpu_nms / cpu_nms, nms_cuda.c:17, nms.c:4).
  * cmp_mode 0: suppress when IoU >= thresh (cpu_nms, nms.c:59); 1: IoU > thresh (nms_kernel.cu:63).
- * mask_ws: n * ceil(n/64) uint64 workspace. keep_out[max_keep] int32 (indices into the sorted list),
- * num_out[1] int32 — both DEVICE memory (the 18 MB D2H + host loop of nms_cuda.c:47-58 is gone). */
+ * mask_ws: l2s_nms_workspace_bytes(n) bytes (8-byte aligned; the bit mask of ONE 4096-box stage - the boxes are scanned in stages, a
+ * stage's mask is that of its own boxes and what earlier stages kept enters as one OR word per 64 boxes - plus those words: 2 MB at
+ * n = 12000, where the reference's mask is 18 MB).  max_keep >= 1.  keep_out[max_keep] int32 (indices into the sorted list),
+ * num_out[1] int32 — both DEVICE memory (the 18 MB D2H + host loop of nms_cuda.c:47-58 is gone); the stages after the first return
+ * at once when keep_out is already full. */
 size_t l2s_nms_workspace_bytes(int n);
 int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_mode, int max_keep, uint64_t* mask_ws,
             int* keep_out, int* num_out, hipStream_t s);

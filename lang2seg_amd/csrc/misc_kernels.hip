@@ -792,6 +792,21 @@ namespace l2s_knobs {
 int pdma_wgs = 0, dma256_auto = 1, wgrad_grid_cap = 0, wgrad_row3_dma = 1, wgrad_row3_dma_wgs = 128, wgrad_row3_wide = 1, wgrad_row3_min_m = 8192,
     wgrad_1x1_dma = 0, row3_form = 0, row3_plan_mode = 0, sgd_blocks = 256;
 }
+// clock probe (tools/clock_probe.py): one wave runs a fixed dependent chain of 2048 integer multiply-adds; out[0] = its duration in ticks of the
+// constant 100 MHz clock, out[1] = in s_memtime counts.  The chain's length in core cycles is fixed, so out[0] is inversely proportional
+// to the core clock at that point of the step.
+__global__ void clock_probe_kernel(uint64_t* out) {
+  const uint64_t w0 = wall_clock64(), c0 = __builtin_amdgcn_s_memtime();
+  unsigned int x = threadIdx.x + 1;
+#pragma unroll 16
+  for (int i = 0; i < 2048; ++i) { x = x * 1664525u + 1013904223u; asm volatile("" : "+v"(x)); }
+  const uint64_t w1 = wall_clock64(), c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { out[0] = w1 - w0; out[1] = c1 - c0; out[2] = x; }
+}
+extern "C" int l2s_tools_clock_probe(uint64_t* out3, hipStream_t s) {
+  L2S_LAUNCH(clock_probe_kernel, dim3(1), dim3(64), 0, s, out3);
+  return l2s_check_launch();
+}
 extern "C" int l2s_tools_set(const char* name, int value) {
   using namespace l2s_knobs;
   struct { const char* n; int* p; } tab[] = {{"pdma_wgs", &pdma_wgs}, {"dma256_auto", &dma256_auto}, {"wgrad_grid_cap", &wgrad_grid_cap},

@@ -1053,7 +1053,9 @@ extern "C" int l2s_proposal_target(const float* rois, const float* roi_scores, c
   // the three [R][4 ncls] target arrays are sparse (4 floats per foreground row): cleared by the copy engine / fill kernel
   // instead of 730 stores per thread of the single-workgroup kernel
   const size_t tb = (size_t)R * 4 * ncls * sizeof(float);
-  if (l2s_memset_async(bbox_targets, 0, tb, s) || l2s_memset_async(bbox_inside, 0, tb, s) || l2s_memset_async(bbox_outside, 0, tb, s)) return L2S_ELAUNCH;
+  if ((char*)bbox_inside == (char*)bbox_targets + tb && (char*)bbox_outside == (char*)bbox_inside + tb) {      // one allocation: one clear
+    if (l2s_memset_async(bbox_targets, 0, 3 * tb, s)) return L2S_ELAUNCH;
+  } else if (l2s_memset_async(bbox_targets, 0, tb, s) || l2s_memset_async(bbox_inside, 0, tb, s) || l2s_memset_async(bbox_outside, 0, tb, s)) return L2S_ELAUNCH;
   L2S_LAUNCH(ptl_kernel, dim3(1), dim3(1024), 0, s, rois, roi_scores, n_rois, n_max, gt, n_gt, gt_masks, im_h, im_w,
                      fg_keys, bg_keys, bg_rand, R, fg_max, mask_slots, fg_thresh, bg_hi, bg_lo, means4, stds4, inw4, ncls, ms,
                      out_rois, labels, bbox_targets, bbox_inside, bbox_outside, mask_targets, counts, ws);

@@ -860,7 +860,7 @@ class resnetv1(Network):
                 rpn_bwd()
         t.update({'rpn_labels': rl, 'rpn_bbox_targets': rt, 'rpn_bbox_inside': ri, 'rpn_bbox_outside': ro})
         rois = self.buf('ptl.rois', (R, 5), f32); labels = self.buf('ptl.labels', (R,), torch.int32)
-        bt = self.buf('ptl.bt', (R, 4 * nc), f32); bi = self.buf('ptl.bi', (R, 4 * nc), f32); bo = self.buf('ptl.bo', (R, 4 * nc), f32)
+        btio = self.buf('ptl.btio', (3, R, 4 * nc), f32); bt, bi, bo = btio[0], btio[1], btio[2]     # (one allocation: l2s_proposal_target clears it in one launch)
         mt = self.buf('ptl.mt', (FGM, MS * MS), f32); counts = self.buf('ptl.counts', (4,), torch.int32)
         pws = self.buf('ptl.ws', (4 * (post + n_gt) + R + 16,), torch.int32)
         cst = self._consts()
