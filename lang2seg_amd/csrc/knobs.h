@@ -15,7 +15,8 @@ L2S_KNOB(pdma_wgs, 0)              // resident workgroups of the persistent LDS-
 L2S_KNOB(dma256_auto, 1)           // wide plain GEMMs (N >= 1024, N % 256 == 0, M >= 4096) take the 256x256 LDS-DMA tile
 L2S_KNOB(wgrad_grid_cap, 0)        // > 0: at most this many workgroups per grouped weight-gradient launch (cap | variant mask << 16)
 L2S_KNOB(wgrad_row3_dma, 1)        // large 3x3 weight gradients on the LDS-DMA filter-row tile
-L2S_KNOB(wgrad_row3_dma_wgs, 128)  // workgroups of its stream-K launch: half the CUs (96 / 128 / 160 / 256 -> 190.1 / 189.1 / 189.0 / 185.5 img/s, same box x 3)
+L2S_KNOB(wgrad_row3_dma_wgs, 160)  // workgroups of its stream-K launch (round 4, 96 / 128 / 160 / 256 -> 190.1 / 189.1 / 189.0 / 185.5 img/s; round 5, with the shorter
+                                   // proposal chain and the split tail, 96 / 128 / 160 / 176 / 192 -> 213.2 / 218.3 / 220.8 / 218.3 / 218.6 img/s, same box x 2)
 L2S_KNOB(wgrad_row3_wide, 1)       // 512+ channels on both sides: that tile from any pixel count
 L2S_KNOB(wgrad_row3_min_m, 8192)   // pixels from which a 3x3 problem takes it
 L2S_KNOB(wgrad_1x1_dma, 0)         // the LDS-DMA 256x256 tile for the large 1x1 problems (built, tested, no faster: conv_wgrad_dma1.hip)

@@ -789,7 +789,7 @@ extern "C" int l2s_sgd_momentum_range(float* param, float* grad, float* mom, con
 // ---- the tools build only (csrc/knobs.h): the tunables as variables, one setter.  Not compiled into liblang2seg_hip.so. ----
 #include <string.h>
 namespace l2s_knobs {
-int pdma_wgs = 0, dma256_auto = 1, wgrad_grid_cap = 0, wgrad_row3_dma = 1, wgrad_row3_dma_wgs = 128, wgrad_row3_wide = 1, wgrad_row3_min_m = 8192,
+int pdma_wgs = 0, dma256_auto = 1, wgrad_grid_cap = 0, wgrad_row3_dma = 1, wgrad_row3_dma_wgs = 160, wgrad_row3_wide = 1, wgrad_row3_min_m = 8192,
     wgrad_1x1_dma = 0, row3_form = 0, row3_plan_mode = 0, sgd_blocks = 256;
 }
 // clock probe (tools/clock_probe.py): one wave runs a fixed dependent chain of 2048 integer multiply-adds; out[0] = its duration in ticks of the
