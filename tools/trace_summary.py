@@ -2,8 +2,9 @@
 """Summarise a rocprofv3 --kernel-trace CSV of bench.py: per-kernel totals per step and per-queue busy time.
 
 usage: trace_summary.py <kernel_trace.csv> <steps_in_trace_tail> [out.csv]
-The last `steps` train steps of the trace are isolated by looking for a kernel with exactly one launch per step: the NMS scan in the
-middle of the step (the SGD kernel, used until round 3, has several launches per step since the early partial updates are on)."""
+The last `steps` train steps of the trace are isolated by looking for a kernel with exactly one launch per step: the gather of the kept
+proposals in the middle of the step (the SGD kernel, used until round 3, has several launches per step since the early partial updates
+are on; the NMS scan, used until round 5, has one per 4096-box stage now)."""
 import csv, sys, collections, re
 
 def short(n):
@@ -14,7 +15,7 @@ def short(n):
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2])
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-sgd = [i for i, r in enumerate(rows) if 'nms_reduce_kernel' in r['Kernel_Name']]
+sgd = [i for i, r in enumerate(rows) if 'gather_rois_kernel' in r['Kernel_Name']]
 if len(sgd) <= steps:
     sgd = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
 assert len(sgd) > steps, 'not enough steps in trace'
