@@ -251,7 +251,8 @@ int l2s_roialign_block0_fwd(const l2s_roi_block0_desc* d, hipStream_t stream);
 /* crop-and-resize RoIAlign = affine_grid + grid_sample, align_corners=True, zero padding (NET:107-149) */
 int l2s_roialign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                      void* out, int dtype, hipStream_t s);
-/* scatter dout [R*P*P][C] back into dfeat float [H*W][C] (atomic) */
+/* d(feat) float [H*W][C] of dout [R*P*P][C].  dfeat is WRITTEN (round 5: it need not arrive cleared): a gather per map pixel in a fixed
+ * summation order, no atomics, when C % 4 == 0 and P <= 32; otherwise cleared here and scattered into with atomics */
 int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float spatial_scale,
                      float* dfeat, int dtype, hipStream_t s);
 

@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const T* dout,
   __shared__ float e_w[CAP];
   __shared__ int sc[256];
   const int pix = blockIdx.x, y = pix / W, x = pix - y * W, t = threadIdx.x, nv = C >> 2;
+  bool wrote = false;                                // (uniform) the first chunk WRITES the pixel's channels: dfeat need not arrive zeroed
   for (int r0 = 0; r0 < R; r0 += 256) {
     const int r = r0 + t;
     unsigned my = 0, mx = 0;
@@ -965,11 +966,14 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const T* dout,
           a0 += w * g[0]; a1 += w * g[1]; a2 += w * g[2]; a3 += w * g[3];
         }
         float4* d = (float4*)(dfeat + (long)pix * C + v * 4);
-        float4 q = *d; q.x += a0; q.y += a1; q.z += a2; q.w += a3; *d = q;
+        float4 q = wrote ? *d : make_float4(0.f, 0.f, 0.f, 0.f); q.x += a0; q.y += a1; q.z += a2; q.w += a3; *d = q;
       }
+      wrote = true;
       __syncthreads();
     }
   }
+  if (!wrote)                                        // no sample of any RoI touches this pixel
+    for (int v = t; v < nv; v += 256) *(float4*)(dfeat + (long)pix * C + v * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 }  // namespace
@@ -1077,6 +1081,7 @@ static int roialign_bwd_launch(const void* dout, int H, int W, int C, const floa
     else L2S_LAUNCH(roialign_bwd_gather_kernel<float>, dim3(H * W), dim3(256), 0, s, (const float*)dout, H, W, C, rois, R, P, sscale, TH, TW, dfeat);
     return l2s_check_launch();
   }
+  if (l2s_memset_async(dfeat, 0, (size_t)H * W * C * sizeof(float), s)) return L2S_ELAUNCH;     // the scatter form adds
   L2S_LAUNCH(roialign_bwd_kernel, dim3(R * P * P), dim3(256), 0, s, dout, H, W, C, rois, P, sscale, TH, TW, dfeat, dtype);
   return l2s_check_launch();
 }

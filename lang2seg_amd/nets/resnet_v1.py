@@ -539,7 +539,7 @@ class resnetv1(Network):
         """g = d(pool5) [R*PS*PS][C4] -> d(net_conv) float [H*W][C4]"""
         C4, PS = self._C4_feat_dim, int(cfg.POOLING_SIZE)
         kind, CS, mp = self._pool_mode()
-        d_nc_roi = self.buf('roi.dfeat', (Hc * Wc, C4), f32, zero=True)
+        d_nc_roi = self.buf('roi.dfeat', (Hc * Wc, C4), f32, zero=(kind == 'pool'))    # (the RoIAlign backward writes every element itself, or clears first)
         if kind == 'pool':
             O.roipool_bwd(g, saved['roi_argmax'], R, PS, C4, d_nc_roi)
             return d_nc_roi
@@ -660,17 +660,27 @@ class resnetv1(Network):
                 O.memset_zero(P.grad)
         else:
             O.memset_zero(P.grad)
-        O.counter_inc(self.seed_counter())                 # device-side step counter: fresh RNG on every (graph) replay
-        loss = self.buf('loss', (8,), f32, zero=True)
         import contextlib
         def on(name):
             return torch.cuda.stream(S[name]) if S is not None else contextlib.nullcontext()
         # ---- expression encoding (ENC:27-82) forked onto the language stream: 80 dependent GEMV launches that overlap with the backbone
         if S is not None:
             self.sfork(main, S['lang'])
-            if self.update_on_wg:
-                with torch.cuda.stream(S['lang']):
-                    self.join_update(full=False)                # the encoder reads updated weights
+        # Round 5: every launch that does not depend on the image leaves the main queue, where a launch boundary is 2.4 - 3.2 us of the step
+        # (DESIGN.md 4.7l).  The step counter (fresh RNG on every replay: every reader - dropout masks, sampling keys - runs on the language
+        # stream, behind this launch), the clear of the loss accumulators and of the dynamic-filter gradient, the RoI sampling keys: all at
+        # the head of the language stream, which the main queue joins before the dynamic filters.
+        post_ = int(cfg['TRAIN' if self._mode == 'TRAIN' else 'TEST'].RPN_POST_NMS_TOP_N)
+        with on('lang'):
+            O.counter_inc(self.seed_counter())
+            loss = self.buf('loss', (8,), f32, zero=True)
+            NF_ = 7 * C4 + 7
+            dfilt_ = self.buf('dyn.dfilt', (NF_,), f32, zero=True) if backward else None
+            n_gt_ = int(d['gt_boxes'].shape[0])
+            roi_keys = (self._keys('roi_fg_keys', post_ + n_gt_), self._keys('roi_bg_keys', post_ + n_gt_), self._keys('roi_bg_rand', R))
+        if S is not None and self.update_on_wg:
+            with torch.cuda.stream(S['lang']):
+                self.join_update(full=False)                # the encoder reads updated weights
         with on('lang'):
             hidden = self._encoder_fwd(d)
             HD = hidden.numel()
@@ -864,8 +874,9 @@ class resnetv1(Network):
         mt = self.buf('ptl.mt', (FGM, MS * MS), f32); counts = self.buf('ptl.counts', (4,), torch.int32)
         pws = self.buf('ptl.ws', (4 * (post + n_gt) + R + 16,), torch.int32)
         cst = self._consts()
-        O.proposal_target(rois_all, rsc_all, nkeep, post, d['gt_boxes'], n_gt, d['gt_masks'], H, W, self._keys('roi_fg_keys', post + n_gt),
-                          self._keys('roi_bg_keys', post + n_gt), self._keys('roi_bg_rand', R), R, FGS, FGM, TR.FG_THRESH, TR.BG_THRESH_HI,
+        assert post == post_ and n_gt == n_gt_
+        O.proposal_target(rois_all, rsc_all, nkeep, post, d['gt_boxes'], n_gt, d['gt_masks'], H, W, roi_keys[0],
+                          roi_keys[1], roi_keys[2], R, FGS, FGM, TR.FG_THRESH, TR.BG_THRESH_HI,
                           TR.BG_THRESH_LO, cst['means'], cst['stds'], cst['inw'], nc, MS, rois, labels, bt, bi, bo, mt, counts, pws)
         t.update({'rois': rois, 'labels': labels, 'bbox_targets': bt, 'bbox_inside': bi, 'bbox_outside': bo, 'mask_targets': mt, 'counts': counts})
         self._mark('targets')
@@ -902,8 +913,7 @@ class resnetv1(Network):
         self._mark('main reaches the caption join')
         if S is not None and self.var['cap'] is not None:
             self.sfork(S['cap'], main)                     # join the caption branch
-        O.total_loss(loss, self._cap_loss_weight)
-        t['loss'] = loss
+        t['loss'] = loss                                    # (summed on the language stream below, behind every loss launch)
         # weight gradients of the caption branch, the RoI head (layer4: RoI pass + caption pass = two pixel segments of one problem)
         # and the RPN, as grouped launches on the weight-gradient stream
         if self.defer_heads:
@@ -921,7 +931,7 @@ class resnetv1(Network):
             O.add3(d_nc_rpn, None, d_nc_roi, d_nc)        # (dtype, -, fp32) operands
         self._mark('caption join + add3')
         # dynamic filters (NET:504-562)
-        dbase = self.buf('dyn.dx', (HW, C4)); dfilt = self.buf('dyn.dfilt', (NF,), f32, zero=True); dresp_ws = self.buf('dyn.dresp', (O.dynfilter_ws_floats(Hc, Wc, C4),), f32)
+        dbase = self.buf('dyn.dx', (HW, C4)); dfilt = dfilt_; dresp_ws = self.buf('dyn.dresp', (O.dynfilter_ws_floats(Hc, Wc, C4),), f32)
         # (only dbase is needed on this queue: the filter / mixing-weight gradients are finished on the language stream below)
         O.dynfilter_bwd(d_nc, base, filt, filt[7 * C4:], resp, respk, dbase, base, None, None, dresp_ws, Hc, Wc, C4,
                         gate=gate, dresp_extra=dresp_extra)
@@ -932,6 +942,7 @@ class resnetv1(Network):
         if S is not None:
             self.sfork(main, S['lang'])
         with on('lang'):
+            O.total_loss(loss, self._cap_loss_weight)
             O.dynfilter_bwd_finish(dresp_ws, respk, dfilt, dfilt[7 * C4:], Hc, Wc, C4)
             O.act_bwd(dfilt, filt, 2)
             O.linear_bwd_w(dfilt, hidden, P.gview('dyn_w', NFP * HD, P.grad), P.gview('dyn_b', NFP, P.grad), 1, NFP, HD)

@@ -1084,7 +1084,7 @@ def test_roialign(dt):
     assert rel_err(out.float().view(R, 7, 7, Cc), ref.permute(0, 2, 3, 1)) < (2e-5 if dt == 0 else 1e-2)
     dout = to_dev(torch.randn(R, 7, 7, Cc, generator=g), dt)
     ref.backward(dout.float().cpu().permute(0, 3, 1, 2))
-    dfeat = torch.zeros(H * W, Cc, device=DEV)
+    dfeat = torch.full((H * W, Cc), 3.0, device=DEV)   # (garbage: the launch writes every element)
     O.roialign_bwd(dout, H, W, Cc, torch.from_numpy(rois).to(DEV), R, 7, 1.0 / 16.0, dfeat)
     torch.cuda.synchronize()
     assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
@@ -1119,7 +1119,7 @@ def test_cropalign_with_max_pool():
     ref.backward(dout.permute(0, 3, 1, 2))
     dcrop = torch.empty(R * 14 * 14, Cc, device=DEV)
     O.maxpool2x2_bwd(dout.to(DEV).view(R * 49, Cc).contiguous(), crop, dcrop, R, 14, 14, Cc, False)
-    dfeat = torch.zeros(H * W, Cc, device=DEV)
+    dfeat = torch.full((H * W, Cc), 3.0, device=DEV)   # (garbage: the launch writes every element)
     O.cropalign_bwd(dcrop, H, W, Cc, rd, R, 14, im_h, im_w, dfeat)
     torch.cuda.synchronize()
     assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
@@ -1145,7 +1145,7 @@ def test_roialign_bwd_clustered_rois():
     ref = net.crop_pool(fr, torch.from_numpy(rois))
     dout = torch.randn(R, 7, 7, Cc, generator=g)
     ref.backward(dout.permute(0, 3, 1, 2))
-    dfeat = torch.zeros(H * W, Cc, device=DEV)
+    dfeat = torch.full((H * W, Cc), 3.0, device=DEV)   # (garbage: the launch writes every element)
     O.roialign_bwd(dout.to(DEV), H, W, Cc, torch.from_numpy(rois).to(DEV), R, 7, 1.0 / 16.0, dfeat)
     torch.cuda.synchronize()
     assert rel_err(dfeat.view(1, H, W, Cc), nhwc(fr.grad)) < 1e-4
