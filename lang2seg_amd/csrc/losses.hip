@@ -68,8 +68,12 @@ __global__ void count_labels_kernel(const int* labels, int n, int* out) {   // f
 // one wave per roi
 __global__ __launch_bounds__(256) void rcnn_loss_kernel(const float* heads, int ldh, const int* labels, const float* bt, const float* bi,
                                                        const float* bo, int R, int ncls, float gscale, float* loss, void* dheads, int ldd, int dt) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (r >= R) return;
+  // (round 5: the two loss terms of a workgroup's four RoIs are summed in LDS and added with ONE atomic each - 512 float atomics on two
+  // addresses serialised in the L2 for ~10 of the launch's 15 us)
+  __shared__ float part[4][2];
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { part[wv][0] = 0.f; part[wv][1] = 0.f; }
+  if (r < R) {
   const float* hr = heads + (long)r * ldh;
   const int lab = labels[r];
   float mx = -INFINITY;
@@ -92,10 +96,10 @@ __global__ __launch_bounds__(256) void rcnn_loss_kernel(const float* heads, int 
   }
   for (int c = 5 * ncls + lane; c < ldd; c += 64) stx(dheads, (long)r * ldd + c, dt, 0.f);
   lb = wave_sum(lb);
-  if (lane == 0) {
-    atomicAdd(loss + L2S_LOSS_CLS, (lse - hr[lab]) * invR);
-    atomicAdd(loss + L2S_LOSS_BOX, lb * invR);
+  if (lane == 0) { part[wv][0] = (lse - hr[lab]) * invR; part[wv][1] = lb * invR; }
   }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(loss + (threadIdx.x ? L2S_LOSS_BOX : L2S_LOSS_CLS), (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
 __global__ __launch_bounds__(256) void mask_loss_kernel(const float* score, int ldsc, const int* labels, const float* mt, const int* num_fg,
