@@ -181,28 +181,33 @@ constexpr int NMS_SB = 64;     // blocks of 64 boxes per stage
 constexpr int NMS_LAG = 6;     // the newest LAG keep words of a block's predecessors are applied by the chain wave itself
 constexpr int NMS_RING = 16;   // blocks whose LDS slots exist at a time (> LAG)
 constexpr int NMS_SLOT = NMS_LAG + 2;    // LDS words per box: [0] OR of (T & keep) over the older blocks, [1 .. LAG] raw T words, [LAG + 1] the row-form word
-// blockIdx.y < sbw: stage-local row block rb = blockIdx.y against column block blockIdx.x <= rb -> mask[(rb * sbw + c) * 64 + lane]; for
+// blockIdx.y < sbw: stage-local row block rb = blockIdx.y against column block c = 4 blockIdx.x + wave <= rb -> mask[(rb * sbw + c) * 64 + lane]; for
 // c == rb the word is the ROW form (bits above the lane: the later boxes of the block this box suppresses).  blockIdx.y >= sbw (stages after
 // the first): 64 entries of the keep list against column block blockIdx.x -> OR into carry[blockIdx.x] (bit = that box is suppressed).
 // nms_hit always gets the earlier (higher-scored) box first, as the row-form kernel of rounds 1-4 did.
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int row0, int sbw, uint64_t* mask,
-                                                      unsigned long long* carry, const int* __restrict__ keep, const int* nk_p, int max_keep,
-                                                      unsigned long long* carry_all, int carry_words) {
-  const int cbk = blockIdx.x, lane = threadIdx.x;
+// (Four column blocks per workgroup, one per wave: 64-thread workgroups - 2080 to 6000 per launch - took 16 - 18 us beside the caption stream's
+// convolutions where they take 7 - 10 alone.)
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr, int cmp, int row0, int sbw, uint64_t* mask,
+                                                       unsigned long long* carry_base, const int* __restrict__ keep, const int* nk_p, int max_keep,
+                                                       unsigned long long* carry_all, int carry_words) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cbk = blockIdx.x * 4 + wv;
   int nk = 0;
   if (row0 > 0) { nk = *nk_p; if (nk >= max_keep) return; }
-  else if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = lane; i < carry_words; i += 64) carry_all[i] = 0ull;
+  else if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < carry_words; i += 256) carry_all[i] = 0ull;
   const bool diag = (int)blockIdx.y < sbw;
   const int rb = blockIdx.y;
-  if (diag && cbk > rb) return;
-  if (!diag && ((int)blockIdx.y - sbw) * 64 >= nk) return;
-  __shared__ float4 cbox[64];
-  __shared__ float carea[64];
+  const bool active = cbk < sbw && (diag ? cbk <= rb : ((int)blockIdx.y - sbw) * 64 < nk);
+  __shared__ float4 cbox_s[4][64];
+  __shared__ float carea_s[4][64];
+  float4* cbox = cbox_s[wv]; float* carea = carea_s[wv];
   const int cj = row0 + cbk * 64 + lane;
-  const float4 cbv = cj < n ? *(const float4*)(boxes + (long)cj * 4) : make_float4(0, 0, -1, -1);
+  const float4 cbv = (active && cj < n) ? *(const float4*)(boxes + (long)cj * 4) : make_float4(0, 0, -1, -1);
   cbox[lane] = cbv;
   carea[lane] = (cbv.z - cbv.x + 1.f) * (cbv.w - cbv.y + 1.f);
   __syncthreads();
+  if (!active) return;
+  unsigned long long* carry = carry_base;
   const int csize = min(64, n - row0 - cbk * 64);
   if (diag) {
     const int ri = row0 + rb * 64 + lane;
@@ -1010,7 +1015,7 @@ extern "C" int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_m
   for (int st = 0; st < nst; ++st) {
     const int row0 = st * NMS_SB * 64, rows = min(n - row0, NMS_SB * 64), sbw = cdiv(rows, 64);
     unsigned long long* carry = carry_all + (size_t)st * NMS_SB;
-    L2S_LAUNCH(nms_mask_kernel, dim3(sbw, sbw + (st ? cdiv(max_keep, 64) : 0)), dim3(64), 0, s, sorted_boxes, n, thresh, cmp_mode, row0, sbw, mask_ws,
+    L2S_LAUNCH(nms_mask_kernel, dim3(cdiv(sbw, 4), sbw + (st ? cdiv(max_keep, 64) : 0)), dim3(256), 0, s, sorted_boxes, n, thresh, cmp_mode, row0, sbw, mask_ws,
                carry, (const int*)keep_out, (const int*)num_out, max_keep, carry_all, nst * NMS_SB);
     L2S_LAUNCH(nms_reduce_kernel, dim3(1), dim3(1024), nms_scan_lds(sbw), s, (const uint64_t*)mask_ws, rows, sbw, max_keep, keep_out, num_out, row0,
                st ? (const unsigned long long*)carry : (const unsigned long long*)nullptr);
