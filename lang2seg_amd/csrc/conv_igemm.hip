@@ -1289,7 +1289,11 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
   const bool stamping = STAMP && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
   auto stamp = [&](int t, int i) {
     if constexpr (STAMP) {
-      if (t < 24) { const unsigned long long c = __builtin_amdgcn_s_memtime(); if (stamping) stamps[t * 8 + i] = c; }
+      if (t < 24) {
+        const unsigned long long c = __builtin_amdgcn_s_memtime(); if (stamping) stamps[t * 8 + i] = c;
+        // (the constant 100 MHz clock next to the first stamp of a slice: delta s_memtime / delta s_memrealtime = the core clock the loop runs at)
+        if (i == 0) { const unsigned long long r = __builtin_amdgcn_s_memrealtime(); if (stamping) ((unsigned long long*)(smem + 3 * STG))[2 * 24 * 8 + grp * 24 + t] = r; }
+      }
     }
   };
   for (int t = 0; t < KT; ++t) {
@@ -1323,7 +1327,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
   if (grp == 0) wg_barrier();                          // group 1's last MULTIPLY slot
   if constexpr (STAMP) {
     __syncthreads();
-    if (blockIdx.x == 0 && tid < 2 * 24 * 8 && p.ws) ((unsigned long long*)p.ws)[tid] = ((unsigned long long*)(smem + 3 * STG))[tid];
+    if (blockIdx.x == 0 && tid < 2 * 24 * 8 + 2 * 24 && p.ws) ((unsigned long long*)p.ws)[tid] = ((unsigned long long*)(smem + 3 * STG))[tid];
     __syncthreads();
   }
   {

@@ -170,7 +170,7 @@ __device__ __forceinline__ bool nms_hit(const float4& a, float aarea, const floa
 //   "carry-in", never stored as a mask; all compute units) - and (2) its own diagonal part in COLUMN form: word T[rb][c][lane] = the boxes of
 //   block c that suppress box rb * 64 + lane.  Which words the scan loads no longer depends on what it decides: fifteen waves stream them
 //   ahead of the chain wave and AND them with the keep words as those appear; the chain wave finds, per block, one finished OR word, the
-//   words of the LAG newest blocks and the block's own row-form word in LDS.
+//   words of the LAG newest blocks and the block's own diagonal word in LDS.
 #ifdef L2S_TOOLS
 __device__ long long nms_dbg[16];     // tools build: cycles of the last scan launch - [0] chain total, [1] chain waiting for ready, [2] blocks, [3] wave 1 waiting for loads, [4] wave 1 waiting for keep words, [5] wave 1 total
 #define NMS_T() ((long long)__builtin_readcyclecounter())
@@ -180,9 +180,9 @@ __device__ long long nms_dbg[16];     // tools build: cycles of the last scan la
 constexpr int NMS_SB = 64;     // blocks of 64 boxes per stage
 constexpr int NMS_LAG = 6;     // the newest LAG keep words of a block's predecessors are applied by the chain wave itself
 constexpr int NMS_RING = 16;   // blocks whose LDS slots exist at a time (> LAG)
-constexpr int NMS_SLOT = NMS_LAG + 2;    // LDS words per box: [0] OR of (T & keep) over the older blocks, [1 .. LAG] raw T words, [LAG + 1] the row-form word
+constexpr int NMS_SLOT = NMS_LAG + 2;    // LDS words per box: [0] OR of (T & keep) over the older blocks, [1 .. LAG] raw T words, [LAG + 1] the diagonal word (the earlier boxes of the own block that suppress the box)
 // blockIdx.y < sbw: stage-local row block rb = blockIdx.y against column block c = 4 blockIdx.x + wave <= rb -> mask[(rb * sbw + c) * 64 + lane]; for
-// c == rb the word is the ROW form (bits above the lane: the later boxes of the block this box suppresses).  blockIdx.y >= sbw (stages after
+// c == rb the word holds the earlier boxes of the same block that suppress this one (bits below the lane).  blockIdx.y >= sbw (stages after
 // the first): 64 entries of the keep list against column block blockIdx.x -> OR into carry[blockIdx.x] (bit = that box is suppressed).
 // nms_hit always gets the earlier (higher-scored) box first, as the row-form kernel of rounds 1-4 did.
 // (Four column blocks per workgroup, one per wave: 64-thread workgroups - 2080 to 6000 per launch - took 16 - 18 us beside the caption stream's
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
     const float aarea = (a.z - a.x + 1.f) * (a.w - a.y + 1.f);
     uint64_t t = 0;
     if (rb == cbk) {
-      for (int j = lane + 1; j < csize; ++j)
-        if (nms_hit(a, aarea, cbox[j], carea[j], thr, cmp)) t |= 1ull << j;
+      for (int j = 0; j < lane; ++j)                     // (the diagonal block too: the earlier boxes of the block that suppress this one)
+        if (nms_hit(cbox[j], carea[j], a, aarea, thr, cmp)) t |= 1ull << j;
     } else {
       for (int j = 0; j < 64; ++j)
         if (nms_hit(cbox[j], carea[j], a, aarea, thr, cmp)) t |= 1ull << j;
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
 // from *num_out in the stages after the first, which return at once when the list is already full (RPN_POST_NMS_TOP_N).  One workgroup of
 // sixteen waves, no barrier inside the scan: the waves meet through LDS words.
 //   wave 0 (the chain), block b: waits for ready[b]; removed = carry | slot[0] | (slot[1 .. LAG] & the keep words of the LAG previous blocks,
-//           which it holds itself); then the rows that suppress a later row of their own block are walked in order (the row-form word);
+//           which it holds itself); then the block itself: kept = alive & ~(suppressed by a kept earlier box of the block), swept to its fixed point;
 //           publishes the block's keep word and kdone = b + 1.
 //   waves 1 .. 15, wave w owns blocks w - 1, w + 14, ...: loads the block's column-form words (whatever the chain decides), ANDs word c with
-//           keep word c as soon as kdone > c, stores the OR, the raw words of the newest LAG blocks and the row-form word into the block's LDS
+//           keep word c as soon as kdone > c, stores the OR, the raw words of the newest LAG blocks and the diagonal word into the block's LDS
 //           slot, and sets ready[b].
 // A wave that has waited 2^22 polls aborts the launch (it cannot happen while the other waves of the workgroup run).
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out,
@@ -302,15 +302,17 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
       unsigned long long rb = __ballot(hit != 0ull) | csh[b];
       const int lim = min(64, n - b * 64);
       if (lim < 64) rb |= ~0ull << lim;
-      const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
-      unsigned long long cand = __ballot(d != 0ull) & ~rb;   // rows that can change the block's state and are still alive
-      while (cand) {
-        const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
-        const unsigned int lo = __builtin_amdgcn_readlane(dlo, i), hi = __builtin_amdgcn_readlane(dhi, i);
-        rb |= ((unsigned long long)hi << 32) | lo;           // (row i's word only has bits above i)
-        cand &= cand - 1ull;
-        cand &= ~rb;
+      // in-block resolution: kept = alive & ~{ i : a KEPT earlier box of the block suppresses i } - the greedy recursion has exactly one solution, and
+      // sweeping from "every alive box is kept" reaches it in (longest suppression chain among the alive boxes) + 1 sweeps, 2 - 4 in practice; a sweep is
+      // two ANDs, a compare and a ballot (the walk over the row-form word of rounds 3 - 5 cost a readlane round trip per kept box, ~100 cycles each)
+      const unsigned long long alive = ~rb;
+      unsigned long long kept = alive;
+      for (int sweep = 0; sweep < 65; ++sweep) {
+        const unsigned long long nk2 = alive & ~__ballot((d & kept) != 0ull);
+        if (nk2 == kept) break;
+        kept = nk2;
       }
+      rb = ~kept;
       const unsigned long long K = ~rb;
       if (lane == 0) {
         lds_st64(&ksh[b], K);
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
     unsigned long long* sl = slots + (size_t)(b % NMS_RING) * SLOT * 64 + lane;
     const int nold = b - LAG;                                // column blocks [0, nold) are ANDed here
     unsigned long long acc = 0ull;
-    // the words that go to the slot as they are: column blocks nold .. b - 1 and the row-form word (index b).  Straight-line code throughout:
+    // the words that go to the slot as they are: column blocks nold .. b - 1 and the diagonal word (index b).  Straight-line code throughout:
     // a taken scalar branch costs ~20 cycles, and 64 of them per block (a guard per word) were 4600 cycles between the last keep word and ready.
     unsigned long long raw[LAG + 1];
 #pragma unroll

@@ -14,11 +14,25 @@ x = torch.randn(M, Cin, device='cuda').bfloat16()
 w = (torch.randn(Cout, k * k * Cin, device='cuda') * 0.05).bfloat16()
 y = torch.empty(M, Cout, device='cuda', dtype=torch.bfloat16)
 ws = torch.zeros(1 << 16, device='cuda')
-for _ in range(200):                      # warm clocks
+# two seconds of back-to-back launches on random data first (MI355X_MICROARCH.md, DVFS item 6), replayed from a launch tape
+stq = torch.cuda.current_stream()
+O.conv_igemm(x, w, y, n, H, W, Cin, H, W, Cout, k, k, 1, p, algo=2); torch.cuda.synchronize()
+h = O.tape_begin([stq])
+for _ in range(500):
     O.conv_igemm(x, w, y, n, H, W, Cin, H, W, Cout, k, k, 1, p, algo=2)
+O.tape_end(h)
+import time
+t0 = time.time()
+while time.time() - t0 < 2.0:
+    O.tape_run(h, [stq]); torch.cuda.synchronize()
+O.tape_run(h, [stq])
 O.conv_igemm(x, w, y, n, H, W, Cin, H, W, Cout, k, k, 1, p, algo=4, ws=ws)
 torch.cuda.synchronize()
 st = ws.view(torch.int64)[:2 * 24 * 8].cpu().view(2, 24, 8)
+rt = ws.view(torch.int64)[2 * 24 * 8:2 * 24 * 8 + 48].cpu().view(2, 24)
+for g in range(2):
+    dc = int(st[g, 22, 0] - st[g, 2, 0]); dr = int(rt[g, 22] - rt[g, 2])
+    print('group %d: slices 2 .. 22 took %d s_memtime counts in %d ticks of the 100 MHz clock: the loop runs at %.2f GHz' % (g, dc, dr, dc / max(dr, 1) * 0.1))
 names = ['top', 'reads issued', 'dma issued', 'lgkm0', 'barrier->M', 'mfma issued', 'vm wait', 'barrier->L']
 for g in range(2):
     print('group %d: cycles since previous stamp (columns: %s); last column = whole iteration' % (g, ', '.join(names[1:])))
