@@ -19,7 +19,7 @@ KNOBS = {'dma256': 'dma256_auto', 'pdma_wgs': 'pdma_wgs', 'wgrad_row3_dma': 'wgr
 # flag -> (class, attribute, type)
 ATTRS = {'fuse_roialign': ('Network', 'fuse_roialign', bool), 'wgrad_overwrite': ('Network', 'wgrad_overwrite', bool), 'cap_map_prio': ('Network', 'cap_map_prio', int),
          'join_l1': ('Network', 'join_before_layer1', bool), 'stem_mfma': ('Network', 'stem_mfma', bool), 'cap_persist': ('Network', 'cap_persistent', bool),
-         'roi_patch': ('Network', 'roi_patch', bool), 'layer1_fused': ('Network', 'layer1_fused', bool),
+         'layer1_fused': ('Network', 'layer1_fused', bool),
          'wgrad_min_wg': ('WgradQueue', 'MIN_WG', int), 'wgrad_v5_stream': ('WgradQueue', 'V5_STREAM', str), 'wgrad_small_tile': ('WgradQueue', 'SMALL_M_TILE', int),
          'wgrad_v4_fill': ('WgradQueue', 'V4_FILL', int), 'defer': ('SGD', 'defer', bool), 'layer2_side': ('SGD', 'layer2_side', bool)}
 
