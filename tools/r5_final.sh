@@ -6,6 +6,8 @@ cd $R
 timeout 900 bash tools/prof_step.sh > $O/prof_step.log 2>&1
 cp gpurun_out/prof_step/summary.csv $O/step_kernel_stats.csv; cp gpurun_out/prof_step/summary.meta.json $O/step_kernel_stats.meta.json
 cp gpurun_out/prof_step/s_kernel_stats.csv $O/rocprofv3_kernel_stats.csv
+# (bench.py reports roofline.kernel_time_ms_per_step / roofline.rocprof from the committed table while its source hash matches: put this run's table there first)
+cp $O/step_kernel_stats.csv profiles/r05_step_kernel_stats.csv; cp $O/step_kernel_stats.meta.json profiles/r05_step_kernel_stats.meta.json
 timeout 400 bash tools/pmc_traffic.sh dominant igemm_p3_kernel 1 38 63 256 256 3 1 1 dgrad > $O/pmc_traffic_dominant.log 2>&1; cp gpurun_out/pmc_traffic_dominant.json $O/ 2>/dev/null
 timeout 400 bash tools/pmc_traffic.sh best igemm_dma_kernel 256 7 7 512 512 3 1 1 fwd > $O/pmc_traffic_best.log 2>&1; cp gpurun_out/pmc_traffic_best.json $O/ 2>/dev/null
 timeout 300 python tools/wgrad_group_bench.py > $O/wgrad_group_bench.txt 2>&1
