@@ -300,8 +300,8 @@ class Bottleneck(object):
         dx = net.buf(tag + '.dx', (n * IH * IW, self.inpl))
         ref = x if x_is_relu_out else None
         if self.down is not None:
-            if self.stride != 1:
-                O.memset_zero(dx)                             # scatter writes only the strided positions
+            if self.stride != 1 and tag not in net._precleared:
+                O.memset_zero(dx)                             # scatter writes only the strided positions (resnet_v1 clears the backbone's ahead of time)
             self.c1.dgrad(dz1, n, IH, IW, dx)
             self.down.dgrad(g, n, IH, IW, dx, add=dx, ref=ref)
         else:
@@ -681,6 +681,7 @@ class Network(object):
     roi_pdma = False
     layer1_fused = True          # bf16: the frozen layer1 as 4 launches (conv1 of block 0 + one fused launch per bottleneck, csrc/bottleneck_fused.hip)
     cap_persistent = True        # the captioner recurrence as one resident launch per direction where the shapes allow (rnn_size = att_hid_size = 512, <= 224 locations)
+    _precleared = frozenset()    # tags of the bottleneck blocks whose scatter target (dx of a stride-2 block) this pass has cleared already, off the main queue
     prio_floor = 0               # wave priority the convolution launches get at least (raised around a latency-bound chain: cap_map_prio)
     cap_map_prio = 0             # priority of layer4's data-gradient launches on the map (caption stream), beside the RoI head's backward
     rpn_wgrad_early = False      # A/B: with rpn_bwd_early, launch the RPN's weight gradients right away instead of with the heads stage

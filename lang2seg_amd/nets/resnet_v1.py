@@ -707,6 +707,19 @@ class resnetv1(Network):
         self.join_transposes()       # last step's transposed weight copies (first readers: caption / RoI branches below)
         if S is not None:
             self.sfork(S['lang'], main)
+        # the scatter targets of the backbone's stride-2 blocks (layer3[0]'s dx) are cleared here on the language stream, idle until the RPN
+        # losses, instead of by a launch inside the backward chain on the main queue (which joins this stream again before the losses)
+        self._precleared = set()
+        if backward and S is not None:
+            with on('lang'):
+                for li in (3, 2):
+                    if (li, 0) not in saved:                    # (another backbone: vgg16)
+                        continue
+                    blk = self.layers[li][0]
+                    if li > cfg.RESNET.FIXED_BLOCKS and blk.down is not None and blk.stride != 1 and blk.need_dx:
+                        x_, a1_, a2_, IH_, IW_, OH_, OW_, n_ = saved[(li, 0)]
+                        O.memset_zero(self.buf('l%d.0.dx' % li, (n_ * IH_ * IW_, blk.inpl)))
+                        self._precleared.add('l%d.0' % li)
         net_conv = self.buf('dyn.y', (HW, C4)); resp = self.buf('dyn.resp', (HW,), f32); respk = self.buf('dyn.respk', (HW, 7), f32)
         gate = 1 if self.var['gate'] == 'sigmoid' else 0
         O.dynfilter_fwd(base, filt, filt[7 * C4:], net_conv, resp, respk, Hc, Wc, C4, gate=gate)
