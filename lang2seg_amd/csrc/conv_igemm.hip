@@ -1287,9 +1287,14 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
   // into 8 KiB of LDS behind the ring (requested by the launcher for this build only); copied to p.ws at the end
   unsigned long long* stamps = (unsigned long long*)(smem + 3 * STG) + (grp * 24 * 8);
   const bool stamping = STAMP && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
+  // (l2s_conv_desc.prio bit 9 in this build: NO stamps inside the loop, only the two clocks before and behind it - the loop as the product
+  // runs it, for the clock it holds: MI355X_MICROARCH.md DVFS item 6)
+  const bool fine = STAMP && !(p.prio & 0x200);
+  unsigned long long loop_c0 = 0, loop_r0 = 0;
+  if constexpr (STAMP) { loop_c0 = __builtin_amdgcn_s_memtime(); loop_r0 = __builtin_amdgcn_s_memrealtime(); }
   auto stamp = [&](int t, int i) {
     if constexpr (STAMP) {
-      if (t < 24) {
+      if (fine && t < 24) {
         const unsigned long long c = __builtin_amdgcn_s_memtime(); if (stamping) stamps[t * 8 + i] = c;
         // (the constant 100 MHz clock next to the first stamp of a slice: delta s_memtime / delta s_memrealtime = the core clock the loop runs at)
         if (i == 0) { const unsigned long long r = __builtin_amdgcn_s_memrealtime(); if (stamping) ((unsigned long long*)(smem + 3 * STG))[2 * 24 * 8 + grp * 24 + t] = r; }
@@ -1326,8 +1331,13 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel(const l2s_conv_desc p) {
   }
   if (grp == 0) wg_barrier();                          // group 1's last MULTIPLY slot
   if constexpr (STAMP) {
+    const unsigned long long loop_c1 = __builtin_amdgcn_s_memtime(), loop_r1 = __builtin_amdgcn_s_memrealtime();
+    if (stamping) {
+      unsigned long long* o = (unsigned long long*)(smem + 3 * STG) + 2 * 24 * 8 + 48 + grp * 2;
+      o[0] = loop_c1 - loop_c0; o[1] = loop_r1 - loop_r0;
+    }
     __syncthreads();
-    if (blockIdx.x == 0 && tid < 2 * 24 * 8 + 2 * 24 && p.ws) ((unsigned long long*)p.ws)[tid] = ((unsigned long long*)(smem + 3 * STG))[tid];
+    if (blockIdx.x == 0 && tid < 2 * 24 * 8 + 2 * 24 + 4 && p.ws) ((unsigned long long*)p.ws)[tid] = ((unsigned long long*)(smem + 3 * STG))[tid];
     __syncthreads();
   }
   {
