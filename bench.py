@@ -457,7 +457,8 @@ def main(argv=None, hooks=None):
         dist.init_process_group('nccl', rank=rank, world_size=world)
     from lang2seg_amd.model.config import cfg
     from lang2seg_amd.nets.resnet_v1 import resnetv1
-    from lang2seg_amd.optim import SGD
+    from lang2seg_amd.optim import SGD  # noqa: F401
+    from lang2seg_amd.model.train_val import make_optimizer
     from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
 
     if hooks.main_prio:
@@ -497,7 +498,8 @@ def main(argv=None, hooks=None):
         net.dp = GradReducer(net, world, skip_allreduce=hooks.dp_skip_allreduce, wire=dp_wire, algo=dp_algo, timing=True, rank=rank,
                              shard_update=True if dp_shard else None, bucket_update=True if dp_bucket else None)
         dp_desc = 'dp%d (%s buckets, %s%s)' % (world, dp_wire, dp_algo, ', sharded update' if dp_shard else (', update per bucket' if dp_bucket else ''))
-    optim = SGD(net, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world)
+    # the optimiser of this variant's own solver (train_val*.py construct_graph: param groups, lr x 10 rule, config_vgg for VGG)
+    optim = make_optimizer(net, None, world)
     hooks.after_optim(optim)
     loader = SyntheticLoader(num_images=4, sents_per_image=1, H=args.height, W=args.width, T=T, vocab_size=V, rank=rank)
     blobs = [loader.getBatch('train') for _ in range(4)]

@@ -154,21 +154,22 @@ def _merge_a_into_b(a, b):
             b[k] = v
 
 
-def cfg_from_file(filename):
-    """Load a yaml config file and merge it into the default options (config.py:358-364)."""
+def cfg_from_file(filename, target=None):
+    """Load a yaml config file and merge it into the default options (config.py:358-364).  `target`: another cfg object
+    (model/config_vgg.py binds its own)."""
     import yaml
     with open(filename, 'r') as f:
         yaml_cfg = yaml.safe_load(f)
-    _merge_a_into_b(yaml_cfg, __C)
+    _merge_a_into_b(yaml_cfg, __C if target is None else target)
 
 
-def cfg_from_list(cfg_list):
+def cfg_from_list(cfg_list, target=None):
     """Set config keys via list, e.g. from the command line (config.py:367-387)."""
     from ast import literal_eval
     assert len(cfg_list) % 2 == 0
     for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
         key_list = k.split('.')
-        d = __C
+        d = __C if target is None else target
         for subkey in key_list[:-1]:
             assert subkey in d
             d = d[subkey]

@@ -49,8 +49,25 @@ def scale_lr(optimizer, scale):
         g['lr'] *= scale
 
 
+def make_optimizer(net, solver_cfg=None, world=1, **kw):
+    """The optimiser the reference's solver of this network's variant builds in construct_graph() (train_val.py:186-207 and its five
+    siblings, see nets/variants.SOLVERS): torch.optim.SGD with momentum and one param group per tensor - weight decay on non-bias tensors
+    (BIAS_DECAY False), lr x (DOUBLE_BIAS + 1) on biases, lr x 10 on rnn_encoder / dynamic_fc / response keys outside the two cycle solvers;
+    hyper-parameters from the config module THAT solver imports (config_vgg.py for VGG: WEIGHT_DECAY 5e-4, DOUBLE_BIAS True).  Here the
+    groups are the rows of ParamStore's segment table and the update is one fused launch (optim.SGD)."""
+    from ..nets.variants import solver_cfg as _scfg
+    c = _scfg(net.variant) if solver_cfg is None else solver_cfg
+    if c.TRAIN.FROM_FRCN:
+        raise NotImplementedError('TRAIN.FROM_FRCN (train_val.py:175-185: a detector fine-tuning rule none of the lang2seg entry points sets)')
+    net.P.build_segments(double_bias=c.TRAIN.DOUBLE_BIAS, bias_decay=c.TRAIN.BIAS_DECAY)
+    return SGD(net, c.TRAIN.LEARNING_RATE, c.TRAIN.MOMENTUM, c.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world, **kw)
+
+
 class SolverWrapper(object):
-    def __init__(self, network, loader, output_dir, tbdir, pretrained_model=None, rank=0, world=1):
+    def __init__(self, network, loader, output_dir, tbdir, pretrained_model=None, rank=0, world=1, solver_cfg=None):
+        from ..nets.variants import solver_cfg as _scfg
+        # the config object this variant's solver reads (model/config_vgg.py for VGG, train_val_vgg.py:12); shadows the module's `cfg` below
+        self.cfg = _scfg(getattr(network, 'variant', 'cycle')) if solver_cfg is None else solver_cfg
         self.net, self.loader = network, loader
         self.output_dir, self.tbdir, self.pretrained_model = output_dir, tbdir, pretrained_model
         self.rank, self.world = rank, world
@@ -63,7 +80,7 @@ class SolverWrapper(object):
 
     def _sidecar(self, it, rank=None):
         rank = self.rank if rank is None else rank
-        base = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it))
+        base = os.path.join(self.output_dir, self.cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it))
         return base + ('.pkl' if rank == 0 else '.rank{:d}.pkl'.format(rank))
 
     def _write_sidecar(self, nfilename, it):
@@ -88,7 +105,7 @@ class SolverWrapper(object):
         if self.rank != 0:
             self._write_sidecar(nfilename, it)           # this rank's own loader cursor / permutation / RNG streams
             return None, nfilename
-        filename = os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it) + '.pth')
+        filename = os.path.join(self.output_dir, self.cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it) + '.pth')
         torch.save(self.net.state_dict(), filename)
         print('Wrote snapshot to: {:s}'.format(filename))
         self._write_sidecar(nfilename, it)
@@ -127,7 +144,7 @@ class SolverWrapper(object):
         # until the RCCL timeout.
         own = str(nfile)[:-len('.pkl')] + '.rank{:d}.pkl'.format(self.rank)
         missing = self.rank != 0 and not os.path.exists(own)
-        if self._any_rank(missing) and not cfg.TRAIN.ALLOW_RESHARD_RESUME:
+        if self._any_rank(missing) and not self.cfg.TRAIN.ALLOW_RESHARD_RESUME:
             raise ValueError('%s: a rank of this %d-rank run has no sidecar in the snapshot (%s; written by a run with fewer ranks?).  Resuming '
                              'would replay different data and random streams on that rank than the run that wrote the snapshot; set '
                              'TRAIN.ALLOW_RESHARD_RESUME True to continue with freshly seeded cursors there.'
@@ -170,22 +187,21 @@ class SolverWrapper(object):
 
     # ---- TV:167-225 ----------------------------------------------------
     def construct_graph(self):
-        torch.manual_seed(cfg.RNG_SEED)
-        random.seed(cfg.RNG_SEED)
-        np.random.seed(cfg.RNG_SEED + self.rank)
+        torch.manual_seed(self.cfg.RNG_SEED)
+        random.seed(self.cfg.RNG_SEED)
+        np.random.seed(self.cfg.RNG_SEED + self.rank)
         if not hasattr(self.net, 'P'):
-            self.net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
-        lr = cfg.TRAIN.LEARNING_RATE
-        self.net.P.build_segments(double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
-        self.optimizer = SGD(self.net, lr, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / self.world)
+            self.net.create_architecture(81, tag='default', anchor_scales=self.cfg.ANCHOR_SCALES, anchor_ratios=self.cfg.ANCHOR_RATIOS)
+        lr = self.cfg.TRAIN.LEARNING_RATE
+        self.optimizer = make_optimizer(self.net, self.cfg, self.world)
         return lr, self.optimizer
 
     def find_previous(self):
-        sfiles = glob.glob(os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pth'))
+        sfiles = glob.glob(os.path.join(self.output_dir, self.cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pth'))
         sfiles.sort(key=os.path.getmtime)
-        red = [os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}.pth'.format(s + 1)) for s in cfg.TRAIN.STEPSIZE]
+        red = [os.path.join(self.output_dir, self.cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}.pth'.format(s + 1)) for s in self.cfg.TRAIN.STEPSIZE]
         sfiles = [s for s in sfiles if s not in red]
-        nfiles = [f for f in glob.glob(os.path.join(self.output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pkl')) if '.rank' not in os.path.basename(f)]
+        nfiles = [f for f in glob.glob(os.path.join(self.output_dir, self.cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pkl')) if '.rank' not in os.path.basename(f)]
         nfiles.sort(key=os.path.getmtime)
         red = [r.replace('.pth', '.pkl') for r in red]
         nfiles = [n for n in nfiles if n not in red]
@@ -205,25 +221,25 @@ class SolverWrapper(object):
             print('Loading initial model weights from {:s}'.format(self.pretrained_model))
             self.load_matched(torch.load(self.pretrained_model, map_location='cpu'))
             print('Loaded.')
-        return cfg.TRAIN.LEARNING_RATE, 0, list(cfg.TRAIN.STEPSIZE), [], []
+        return self.cfg.TRAIN.LEARNING_RATE, 0, list(self.cfg.TRAIN.STEPSIZE), [], []
 
     def restore(self, sfile, nfile):
         last = self.from_snapshot(sfile, nfile)
         lr_scale, stepsizes = 1, []
-        for s in cfg.TRAIN.STEPSIZE:
+        for s in self.cfg.TRAIN.STEPSIZE:
             if last > s:
-                lr_scale *= cfg.TRAIN.GAMMA
+                lr_scale *= self.cfg.TRAIN.GAMMA
             else:
                 stepsizes.append(s)
         scale_lr(self.optimizer, lr_scale)
         if self.rank != 0:                       # the files this rank owns (rank 0 owns the weights and the reference-format sidecar)
             own = str(nfile)[:-len('.pkl')] + '.rank{:d}.pkl'.format(self.rank)
-            return cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [own if os.path.exists(own) else None], [None]
-        return cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [nfile], [sfile]
+            return self.cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [own if os.path.exists(own) else None], [None]
+        return self.cfg.TRAIN.LEARNING_RATE * lr_scale, last, stepsizes, [nfile], [sfile]
 
     def remove_snapshot(self, np_paths, ss_paths):
         for paths in (np_paths, ss_paths):
-            while len(paths) > cfg.TRAIN.SNAPSHOT_KEPT:
+            while len(paths) > self.cfg.TRAIN.SNAPSHOT_KEPT:
                 f = paths.pop(0)
                 if f is not None and os.path.exists(str(f)):        # every rank removes the files it wrote
                     os.remove(str(f))
@@ -244,7 +260,7 @@ class SolverWrapper(object):
         # (Network.tape_step; least recently used tapes and their activation plans are evicted).  Measured: a stream of six mixed
         # shapes 120-121 img/s against 116 img/s issued eagerly (tools/mixed_shape_bench.py); one fixed shape 122 vs 102-110 (600x1000),
         # 127.5 vs 112-116 (600x800), 135 vs 101 (480x640) (bench.py --tape 1/0).
-        self.net.use_tape = bool(getattr(cfg.TRAIN, 'USE_TAPE', True))
+        self.net.use_tape = bool(getattr(self.cfg.TRAIN, 'USE_TAPE', True))
         timer = Timer()
         pending = 0                     # steps issued since the timer was started
         while it < max_iters + 1:
@@ -256,15 +272,15 @@ class SolverWrapper(object):
                     timer.tic()
                 if it == next_stepsize + 1:
                     self.snapshot(it)
-                    lr *= cfg.TRAIN.GAMMA
-                    scale_lr(self.optimizer, cfg.TRAIN.GAMMA)
+                    lr *= self.cfg.TRAIN.GAMMA
+                    scale_lr(self.optimizer, self.cfg.TRAIN.GAMMA)
                     next_stepsize = stepsizes.pop()
                 # The reference reads its 7 losses back after every step (NET:704-710) and brackets every step with a device-synchronising
                 # timer (TV:371,404; utils/timer.py:20-35), but only shows both every DISPLAY iterations (TV:404-411).  Here the steps of a
                 # display window are issued back to back without a host sync; the losses are fetched and the window is timed when they are shown
                 # (`speed` stays the running average of seconds per iteration).
-                show = it % cfg.TRAIN.DISPLAY == 0
-                snap = it % cfg.TRAIN.SNAPSHOT_ITERS == 0
+                show = it % self.cfg.TRAIN.DISPLAY == 0
+                snap = it % self.cfg.TRAIN.SNAPSHOT_ITERS == 0
                 if show or not hasattr(self.net, 'train_step_async'):
                     vals = self.net.train_step(blobs, int(arr[idx]), self.optimizer)  # 6, 7 or 8 floats depending on the network variant
                 else:
@@ -281,7 +297,7 @@ class SolverWrapper(object):
                         print(' >>> %s: %.6f' % (short.get(n, n), v))
                     print(' >>> lr: %f' % lr)
                     print('speed: {:.3f}s / iter'.format(timer.average_time()))
-                if it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                if it % self.cfg.TRAIN.SNAPSHOT_ITERS == 0:
                     last_snapshot_iter = it
                     ss, nn = self.snapshot(it)
                     np_paths.append(nn); ss_paths.append(ss)
@@ -293,9 +309,9 @@ class SolverWrapper(object):
             self.snapshot(it - 1)
 
 
-def train_net(network, loader, output_dir, tb_dir, pretrained_model=None, max_iters=40000, rank=0, world=1):
-    """TV:477-490."""
-    sw = SolverWrapper(network, loader, output_dir, tb_dir, pretrained_model=pretrained_model, rank=rank, world=world)
+def train_net(network, loader, output_dir, tb_dir, pretrained_model=None, max_iters=40000, rank=0, world=1, solver_cfg=None):
+    """TV:477-490.  `solver_cfg`: the config object of the variant's solver (default: nets/variants.solver_cfg(network.variant))."""
+    sw = SolverWrapper(network, loader, output_dir, tb_dir, pretrained_model=pretrained_model, rank=rank, world=world, solver_cfg=solver_cfg)
     print('Solving...')
     sw.train_model(max_iters)
     print('done solving')

@@ -14,6 +14,7 @@ from .._lib import F32, BF16
 from ..model.config import cfg
 from .network import Network, ConvOp, Bottleneck
 from .params import ParamStore
+from .variants import solver_cfg
 from . import anchors as ANC
 
 f32 = torch.float32
@@ -67,7 +68,8 @@ class resnetv1(Network):
         self.up_wT = O.empty((4 * 256 * 2048,), self.dt)     # ConvTranspose forward operand [(dy,dx,co)][ci]
         self.base_anchors = torch.from_numpy(ANC.base_anchors(self._anchor_scales, self._anchor_ratios)).to(self.device)
         self.init_weights()
-        P.build_segments(double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
+        sc = solver_cfg(self.variant)           # the param groups of this variant's solver (model/train_val.make_optimizer rebuilds them)
+        P.build_segments(double_bias=sc.TRAIN.DOUBLE_BIAS, bias_decay=sc.TRAIN.BIAS_DECAY)
         self.load_state_dict(self._initial_state, strict=False)
         del self._initial_state
         # RES:256 -> caption_models.setup(opt): `--start_from` warm-starts the captioner from <dataset_splitBy>/<start_from>/model-best.pth

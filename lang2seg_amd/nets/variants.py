@@ -19,6 +19,30 @@ VARIANTS = {
     # fc6 / fc7, no mask branch, sigmoid gating + response loss
     'vgg': dict(nfilt=7, gate='sigmoid', cap=None, backbone='vgg', mask=False),
 }
+# The solver of each variant (the reference has one model/train_val*.py per entry point, tools/train*.py:22-24).  Their construct_graph()
+# differ in two things:
+#   lang_lr_mult : learning-rate factor of every parameter whose key contains 'rnn_encoder', 'dynamic_fc' or 'response' - x10 in
+#                  train_val.py:193-198 (baseline AND spatial), train_val_response.py:193-198, train_val_vgg.py:193-198; the same lines are
+#                  commented out in train_val_cycle.py:199-204 and train_val_cycle_response.py:193-198 (factor 1)
+#   config       : the config module the solver imports - model/config_vgg.py for VGG (train_val_vgg.py:12: WEIGHT_DECAY 5e-4, DOUBLE_BIAS True,
+#                  config_vgg.py:28,40), model/config.py for the rest
+SOLVERS = {
+    'baseline': dict(module='train_val', lang_lr_mult=10.0, config='config'),
+    'spatial': dict(module='train_val', lang_lr_mult=10.0, config='config'),
+    'response': dict(module='train_val_response', lang_lr_mult=10.0, config='config'),
+    'cycle': dict(module='train_val_cycle', lang_lr_mult=1.0, config='config'),
+    'cycle_response': dict(module='train_val_cycle_response', lang_lr_mult=1.0, config='config'),
+    'vgg': dict(module='train_val_vgg', lang_lr_mult=10.0, config='config_vgg'),
+}
+LANG_LR_KEYS = ('rnn_encoder', 'dynamic_fc', 'response')
+
+
+def solver_cfg(variant):
+    """the `cfg` object the variant's solver reads its TRAIN.* hyper-parameters from"""
+    import importlib
+    return importlib.import_module('lang2seg_amd.model.' + SOLVERS[variant]['config']).cfg
+
+
 _ALL = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_response', 'loss_caption', 'total_loss']
 # slot of each loss in the device loss[8] buffer (include/lang2seg_hip.h L2S_LOSS_*)
 SLOT = dict(rpn_cross_entropy=0, rpn_loss_box=1, cross_entropy=2, loss_box=3, loss_mask=4, loss_caption=5, total_loss=6, loss_response=7)

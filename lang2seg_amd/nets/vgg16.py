@@ -15,6 +15,7 @@ from .. import ops as O
 from ..model.config import cfg
 from .network import ConvOp
 from .params import ParamStore
+from .variants import solver_cfg
 from .resnet_v1 import resnetv1, f32
 from . import anchors as ANC
 
@@ -54,7 +55,8 @@ class vgg16(resnetv1):
         self._NFP = 7 * C4 + 7
         self.base_anchors = torch.from_numpy(ANC.base_anchors(self._anchor_scales, self._anchor_ratios)).to(self.device)
         self.init_weights()
-        P.build_segments(double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
+        sc = solver_cfg(self.variant)           # the param groups of this variant's solver (model/train_val.make_optimizer rebuilds them)
+        P.build_segments(double_bias=sc.TRAIN.DOUBLE_BIAS, bias_decay=sc.TRAIN.BIAS_DECAY)
         self.load_state_dict(self._initial_state, strict=False)
         del self._initial_state
 

@@ -417,19 +417,21 @@ class OracleNet(object):
         return {k: (self.p[k].grad if self.p[k].grad is not None else torch.zeros_like(self.p[k])) for k in self.trainable}
 
     def sgd_step(self, lr=None):
-        """torch.optim.SGD as configured at TV:194-220: momentum .9, weight decay on non-bias only."""
+        """torch.optim.SGD as the variant's solver configures it (weights.SOLVERS / param_group: train_val.py:186-205 and its five
+        siblings): momentum .9, one group per tensor - weight decay on non-bias tensors only, DOUBLE_BIAS, and lr x 10 on the
+        rnn_encoder / dynamic_fc / response keys outside the two cycle solvers; config_vgg's WEIGHT_DECAY / DOUBLE_BIAS for VGG."""
+        from .weights import param_group
         ct = self.cfg['TRAIN']
         lr = ct['LEARNING_RATE'] if lr is None else lr
         with torch.no_grad():
             for k in self.trainable:
                 p = self.p[k]
-                g = p.grad if p.grad is not None else torch.zeros_like(p)
-                is_bias = 'bias' in k
-                wd = (ct['WEIGHT_DECAY'] if ct['BIAS_DECAY'] else 0.0) if is_bias else ct['WEIGHT_DECAY']
-                plr = lr * ((2.0 if ct['DOUBLE_BIAS'] else 1.0) if is_bias else 1.0)
-                d = g + wd * p
+                if p.grad is None:                       # torch.optim.SGD skips a parameter without a gradient (resnet.fc)
+                    continue
+                mult, wd = param_group(self.variant, k, ct)
+                d = p.grad + wd * p
                 self.momentum[k].mul_(ct['MOMENTUM']).add_(d)
-                p.add_(self.momentum[k], alpha=-plr)
+                p.add_(self.momentum[k], alpha=-lr * mult)
 
     def train_step(self, blob, samp, drops=None, lr=None):
         """NET:702-719: forward, losses, backward, SGD.  Returns the 7 floats."""

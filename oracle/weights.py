@@ -25,6 +25,34 @@ VARIANTS = {
     # 2x2 max pool, fc6/fc7, no mask branch, sigmoid gating + response loss
     'vgg': dict(nfilt=7, gate='sigmoid', cap=None, module='vgg16', net='network_vgg', backbone='vgg', mask=False),
 }
+# The solver each variant is trained with (tools/train*.py:22-24 import one model/train_val*.py each; construct_graph there):
+#   lang_lr_mult: learning-rate factor of the parameters whose key contains 'rnn_encoder', 'dynamic_fc' or 'response'
+#                 (train_val.py:193-198, train_val_response.py:193-198, train_val_vgg.py:193-198: x10; the two cycle solvers have the
+#                 rule commented out, train_val_cycle.py:199-204, train_val_cycle_response.py:193-198)
+#   cfg         : overrides of model/config.py's TRAIN defaults in the config module the solver imports (train_val_vgg.py:12 ->
+#                 model/config_vgg.py:28,40: WEIGHT_DECAY 5e-4, DOUBLE_BIAS True)
+SOLVERS = {
+    'baseline': dict(module='train_val', lang_lr_mult=10.0, cfg={}),
+    'spatial': dict(module='train_val', lang_lr_mult=10.0, cfg={}),
+    'response': dict(module='train_val_response', lang_lr_mult=10.0, cfg={}),
+    'cycle': dict(module='train_val_cycle', lang_lr_mult=1.0, cfg={}),
+    'cycle_response': dict(module='train_val_cycle_response', lang_lr_mult=1.0, cfg={}),
+    'vgg': dict(module='train_val_vgg', lang_lr_mult=10.0, cfg=dict(WEIGHT_DECAY=5e-4, DOUBLE_BIAS=True)),
+}
+LANG_KEYS = ('rnn_encoder', 'dynamic_fc', 'response')
+
+
+def param_group(variant, key, train_cfg):
+    """(lr factor, weight decay) of one parameter as the variant's construct_graph() sets them (FROM_FRCN False)."""
+    sv = SOLVERS[variant]
+    ct = dict(train_cfg, **sv['cfg'])
+    is_bias = 'bias' in key
+    mult = sv['lang_lr_mult'] if any(t in key for t in LANG_KEYS) else 1.0
+    if is_bias:
+        return mult * ((2.0 if ct['DOUBLE_BIAS'] else 1.0)), (ct['WEIGHT_DECAY'] if ct['BIAS_DECAY'] else 0.0)
+    return mult, ct['WEIGHT_DECAY']
+
+
 VGG_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]   # torchvision cfg 'D' minus the last pool
 LOSS_KEYS = ['rpn_cross_entropy', 'rpn_loss_box', 'cross_entropy', 'loss_box', 'loss_mask', 'loss_response', 'loss_caption', 'total_loss']
 

@@ -159,6 +159,42 @@ def install_harness():
     PTL.bbox_overlaps = bbox_overlaps_byte
 
 
+SOLVER_MODULE = dict(baseline='train_val', spatial='train_val', response='train_val_response', cycle='train_val_cycle',
+                     cycle_response='train_val_cycle_response', vgg='train_val_vgg')     # tools/train*.py:22-23
+
+
+class StubLoader(object):
+    """what SolverWrapper.snapshot / from_snapshot touch of the loader (TV:74-77,152-158)"""
+
+    def __init__(self, n_train=11, n_val=5, seed=5):
+        rs = np.random.RandomState(seed)
+        self.split_ix = {'train': list(range(n_train)), 'val': list(range(100, 100 + n_val))}
+        self.iterators = {'train': 4, 'val': 2}
+        self.perm = {'train': rs.permutation(n_train), 'val': rs.permutation(n_val)}
+
+
+def reference_solver(variant, net, output_dir=None, loader=None):
+    """the reference's SolverWrapper of this variant around `net` (not yet constructed: construct_graph() calls create_architecture)"""
+    import importlib
+    import tempfile
+    tbx = sys.modules['tensorboardX']
+
+    class FileWriter(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def add_summary(self, *a, **k):
+            pass
+
+        def close(self):
+            pass
+    tbx.writer.FileWriter = FileWriter
+    TV = importlib.import_module('model.' + SOLVER_MODULE[variant])
+    d = output_dir or tempfile.mkdtemp(prefix='l2s_ref_solver_')
+    sw = TV.SolverWrapper(net, loader or StubLoader(), os.path.join(d, 'output'), os.path.join(d, 'tb'), pretrained_model=None)
+    return sw, TV.cfg
+
+
 def digest(t, nsamp=2048):
     a = t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
     a = a.astype(np.float64).ravel()
@@ -207,22 +243,19 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
 
     torch.manual_seed(0)
     net = RESM.vgg16(opt, batch_size=1) if is_vgg else RESM.resnetv1(opt, batch_size=1, num_layers=101)
-    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    # The optimiser is the one the reference's OWN solver of this variant builds: SolverWrapper.construct_graph() (train_val.py:167-214 for
+    # baseline / spatial, train_val_response.py, train_val_cycle.py, train_val_cycle_response.py, train_val_vgg.py) creates the architecture,
+    # then one param group per tensor - with lr x 10 on rnn_encoder / dynamic_fc / response keys in four of the six solvers, and
+    # config_vgg's WEIGHT_DECAY / DOUBLE_BIAS for the VGG one (train_val_vgg.py:12).  Only tensorboardX's FileWriter is a stub.
+    sw, scfg = reference_solver(variant, net)
+    scfg.ANCHOR_SCALES = list(cfg.ANCHOR_SCALES); scfg.ANCHOR_RATIOS = list(cfg.ANCHOR_RATIOS)     # (tools/train*.py --set, the solver's own cfg)
+    lr0, optimizer = sw.construct_graph()
     ref_sd = net.state_dict()
     for k, v in sd.items():
         assert k in ref_sd and tuple(ref_sd[k].shape) == v.shape, k
         ref_sd[k].copy_(torch.from_numpy(v))
-    # optimizer exactly as TV:194-220 (FROM_FRCN False)
-    lr = cfg.TRAIN.LEARNING_RATE
-    params = []
-    for key, value in dict(net.named_parameters()).items():
-        if value.requires_grad:
-            if 'bias' in key:
-                params += [{'params': [value], 'lr': lr * (cfg.TRAIN.DOUBLE_BIAS + 1),
-                            'weight_decay': cfg.TRAIN.BIAS_DECAY and cfg.TRAIN.WEIGHT_DECAY or 0}]
-            else:
-                params += [{'params': [value], 'lr': lr, 'weight_decay': cfg.TRAIN.WEIGHT_DECAY}]
-    optimizer = torch.optim.SGD(params, momentum=cfg.TRAIN.MOMENTUM)
+    group_of = {id(g['params'][0]): g for g in optimizer.param_groups}
+    assert all(len(g['params']) == 1 for g in optimizer.param_groups)
     net.train()
     for mod in net.modules():                       # dropout off (parity runs inject masks = identity)
         if isinstance(mod, nn.Dropout):
@@ -252,6 +285,15 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
                meta_head_gain=head_gain, meta_variant=variant)
     for k, v in cfg_over.items():
         out['cfg.' + k] = v
+    # the solver's configuration and its param-group table, as the reference built them
+    for k in ('LEARNING_RATE', 'MOMENTUM', 'WEIGHT_DECAY', 'DOUBLE_BIAS', 'BIAS_DECAY', 'GAMMA'):
+        out['solver.' + k] = getattr(scfg.TRAIN, k)
+    out['solver.module'] = SOLVER_MODULE[variant]
+    names_tr = [k for k, p in net.named_parameters() if p.requires_grad]
+    out['solver.keys'] = np.array(names_tr)
+    out['solver.lr'] = np.array([group_of[id(p)]['lr'] for k, p in net.named_parameters() if p.requires_grad], np.float64)
+    out['solver.wd'] = np.array([group_of[id(p)]['weight_decay'] for k, p in net.named_parameters() if p.requires_grad], np.float64)
+    assert float(lr0) == float(scfg.TRAIN.LEARNING_RATE) and optimizer.defaults['momentum'] == scfg.TRAIN.MOMENTUM
     for k, v in L.items():
         out['loss.' + k] = v
     # sampling draws -> keys

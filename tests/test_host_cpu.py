@@ -459,6 +459,7 @@ def test_caption_warm_start_rules(tmp_path):
 # solver: missing pretrained file, data-parallel resume with per-rank sidecars
 class _FakeSolverNet(object):
     _batch_size = 1
+    variant = 'cycle'
     knockout = frozenset()
     dp = None
 
@@ -474,6 +475,42 @@ class _FakeSolverNet(object):
 
     def seed_counter(self):
         return self.ctr
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg'])
+def test_segment_table_is_the_reference_solvers_param_groups(tag):
+    """ParamStore.param_group / nets.variants.SOLVERS / model.config_vgg against the param groups the reference's own
+    SolverWrapper.construct_graph() of each variant built (fixture keys solver.*): lr x 10 on rnn_encoder / dynamic_fc / response keys for
+    baseline, spatial, response and vgg (train_val.py:193-198, train_val_response.py, train_val_vgg.py), not for the two cycle solvers;
+    WEIGHT_DECAY 5e-4 and DOUBLE_BIAS for VGG (config_vgg.py:28,40)."""
+    from golden_util import load, variant_of
+    from lang2seg_amd._lib import F32
+    from lang2seg_amd.nets.params import ParamStore
+    from lang2seg_amd.nets.variants import solver_cfg, SOLVERS
+    from oracle import weights as OW
+    g = load(tag)
+    v = variant_of(g)
+    sc = solver_cfg(v)
+    assert SOLVERS[v]['module'] == str(g['solver.module'])
+    for k in ('LEARNING_RATE', 'MOMENTUM', 'WEIGHT_DECAY', 'GAMMA'):
+        assert float(sc.TRAIN[k]) == float(g['solver.' + k]), k
+    assert bool(sc.TRAIN.DOUBLE_BIAS) == bool(g['solver.DOUBLE_BIAS']) and bool(sc.TRAIN.BIAS_DECAY) == bool(g['solver.BIAS_DECAY'])
+    opt = OW.default_opt(vocab_size=int(g['meta_V']), seq_length=int(g['meta_T']))
+    if v == 'vgg':
+        opt['C4_feat_dim'] = 512
+    P = ParamStore(opt, 101, 81, 12, 0 if v == 'vgg' else 1, 'cpu', F32, v)
+    ref = {str(k): (float(lr), float(wd)) for k, lr, wd in zip(g['solver.keys'], g['solver.lr'], g['solver.wd'])}
+    # resnet.fc is a parameter of the reference's module that never receives a gradient (torch.optim.SGD skips it): not in the flat buffer
+    assert set(P.trainable) == set(ref) - {'resnet.fc.weight', 'resnet.fc.bias'}
+    for k in P.trainable:
+        f, wd_on = P.param_group(k, sc.TRAIN.DOUBLE_BIAS, sc.TRAIN.BIAS_DECAY)
+        assert abs(sc.TRAIN.LEARNING_RATE * f - ref[k][0]) <= 1e-12 and abs(wd_on * sc.TRAIN.WEIGHT_DECAY - ref[k][1]) <= 1e-15, (k, f, wd_on, ref[k])
+    if v in ('baseline', 'spatial', 'response', 'vgg'):
+        k = 'dynamic_fc.weight' if v == 'baseline' else 'dynamic_fc_0.weight'
+        assert P.param_group(k, sc.TRAIN.DOUBLE_BIAS, sc.TRAIN.BIAS_DECAY)[0] == 10.0
+        assert P.param_group('rnn_encoder.mlp.0.bias', sc.TRAIN.DOUBLE_BIAS, sc.TRAIN.BIAS_DECAY)[0] == (20.0 if v == 'vgg' else 10.0)
+    else:
+        assert P.param_group('dynamic_fc_0.weight', sc.TRAIN.DOUBLE_BIAS, sc.TRAIN.BIAS_DECAY)[0] == 1.0
 
 
 def test_initialize_raises_on_missing_pretrained(tmp_path):

@@ -66,11 +66,25 @@ def _run_e2e(tag):
     for k, v in L.items():
         assert abs(float(v) - float(g['loss.' + k])) < 1e-4 * max(1, abs(float(g['loss.' + k]))), (k, float(v), g['loss.' + k])
     grads = net.backward()
+    w0 = {n: net.p[n].detach().clone() for n in net.trainable}
     net.sgd_step()
     names = sorted({k[2:].rsplit('.', 1)[0] for k in g if k.startswith('g.')})
     for n in names:
         check_digest(g, 'g.' + n, grads[n].numpy(), rtol=2e-4, atol=1e-7)
         check_digest(g, 'w1.' + n, net.p[n].detach().numpy(), rtol=1e-5, atol=1e-7)
+    # the solver rule spelled out on the reference's own post-step weights (w1.* comes from the optimiser the reference's
+    # SolverWrapper.construct_graph() of this variant built): a language-side tensor moves by 10 x lr outside the two cycle solvers
+    lr, wd = float(g['solver.LEARNING_RATE']), float(g['solver.WEIGHT_DECAY'])
+    mult = OW.SOLVERS[variant_of(g)]['lang_lr_mult']
+    for n in names:
+        if not any(t in n for t in OW.LANG_KEYS) or 'bias' in n:
+            continue
+        stride = int(g['w1.' + n + '.stride'])
+        step_ref = w0[n].numpy().ravel()[::stride][:2048].astype(np.float64) - g['w1.' + n + '.sample'].astype(np.float64)
+        unit = (grads[n] + wd * w0[n]).numpy().ravel()[::stride][:2048].astype(np.float64)          # first step: momentum buffer = d
+        big = np.abs(unit) > 0.05 * np.abs(unit).max()
+        ratio = np.median(step_ref[big] / unit[big]) / lr
+        assert abs(ratio - mult) < 0.15 * mult, (n, ratio, mult)        # (float32 weights: the step is a few ulps of the weight)
 
 
 def test_train_step_tiny():
@@ -132,3 +146,33 @@ def test_test_mode(tag):
     check_digest(g, 't.mask_prob', out['mask_prob'].numpy())
     pm = net.predict_masks_from_boxes_and_labels(out['net_conv'], g['pm.boxes'], g['pm.labels'])
     assert np.allclose(pm.numpy(), g['pm.masks'], atol=1e-5)
+
+
+TRAIN_TAGS = ['tiny', 'tiny_align', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg',
+              'full', 'full_spatial', 'full_cycle_response', 'full_vgg']
+
+
+@pytest.mark.parametrize('tag', TRAIN_TAGS)
+def test_solver_param_groups_vs_reference(tag):
+    """every fixture carries the param-group table (key, lr, weight decay) of the optimiser the reference's own SolverWrapper of that
+    variant built (make_golden.reference_solver -> construct_graph): the oracle's rule must reproduce it key by key."""
+    g = load(tag)
+    v = variant_of(g)
+    assert str(g['solver.module']) == OW.SOLVERS[v]['module']
+    ct = dict(ON.DEFAULT_CFG['TRAIN'], **OW.SOLVERS[v]['cfg'])
+    for k in ('LEARNING_RATE', 'MOMENTUM', 'WEIGHT_DECAY', 'GAMMA'):
+        assert float(g['solver.' + k]) == float(ct[k]), (k, g['solver.' + k], ct[k])
+    assert bool(g['solver.DOUBLE_BIAS']) == bool(ct['DOUBLE_BIAS']) and bool(g['solver.BIAS_DECAY']) == bool(ct['BIAS_DECAY'])
+    keys = [str(k) for k in g['solver.keys']]
+    assert len(keys) > 50 and len(set(keys)) == len(keys)
+    seen_lang = 0
+    for k, lr, wd in zip(keys, g['solver.lr'], g['solver.wd']):
+        mult, w = OW.param_group(v, k, ON.DEFAULT_CFG['TRAIN'])
+        assert abs(ct['LEARNING_RATE'] * mult - float(lr)) <= 1e-12 and abs(w - float(wd)) <= 1e-15, (k, mult, w, lr, wd)
+        seen_lang += any(t in k for t in OW.LANG_KEYS)
+    assert seen_lang >= 13
+    # the oracle trains what the reference trains
+    opt, sd, blob, cfg, samp = setup_from_fixture(g)
+    onet = ON.OracleNet.__new__(ON.OracleNet); onet.cfg = cfg
+    # (resnet.fc: a parameter of the reference's module that no loss reaches - torch.optim.SGD skips it, the synthetic state dict omits it)
+    assert sorted(k for k in sd if onet._is_trainable(k)) == sorted(k for k in keys if not k.startswith('resnet.fc.'))

@@ -176,15 +176,37 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
     # gradients (reference layout) and post-SGD weights vs the fixture
     # (the VGG trunk's gradients cross 9 un-normalised 3x3 convolutions and two max-pools: 1e-3 like the full-size test)
     names = _check_grads(g, net, dtype, 1e-3 if tag == 'tiny_vgg' else 5e-4, ref_net=None if f32 else _f32_reference_step(tag))
-    SGD(net, 1e-4).step()
+    # the optimiser of this variant's solver (model.train_val.make_optimizer: param groups of the reference's construct_graph(), lr x 10 on
+    # the language side outside the cycle solvers, config_vgg's WEIGHT_DECAY / DOUBLE_BIAS); w1.* in the fixture is what the reference's own
+    # SolverWrapper of the variant left after optimizer.step()
+    from lang2seg_amd.model.train_val import make_optimizer
+    w0 = {nme: net.state_dict()[nme].numpy().copy() for nme in names if any(s_ in nme for s_ in ('rnn_encoder', 'dynamic_fc', 'response'))}
+    sgd = make_optimizer(net)
+    assert sgd.lr == float(g['solver.LEARNING_RATE']) and sgd.weight_decay == float(g['solver.WEIGHT_DECAY']) and sgd.momentum == float(g['solver.MOMENTUM'])
+    sgd.step()
     torch.cuda.synchronize()
     sd1 = net.state_dict()
+    if f32:
+        # spelled out: a language-side weight moves by lang_lr_mult x lr x (g + wd w) in the first step
+        from lang2seg_amd.nets.variants import SOLVERS
+        mult = SOLVERS[variant_of(g)]['lang_lr_mult']
+        P = net.P
+        for nme, w_old in w0.items():
+            if 'bias' in nme:
+                continue
+            gr = np.asarray(_grad_of(net, nme))
+            unit = (gr + sgd.weight_decay * w_old).ravel().astype(np.float64)
+            step = (w_old - sd1[nme].numpy()).ravel().astype(np.float64)
+            big = np.abs(unit) > 0.05 * np.abs(unit).max()
+            ratio = float(np.median(step[big] / unit[big])) / sgd.lr
+            assert abs(ratio - mult) < 0.15 * mult, (nme, ratio, mult)
     for nme in names:
         # f32: 1e-5 of the weight scale.  bf16: the update is lr x gradient, and the gradient of a tensor may deviate from the f32 step's by
         # what _check_grads allows (cosine >= BF16_COS, norm within BF16_NORM): that deviation times the learning rate is allowed on top - it
         # matters for the tensors with large gradients (the dynamic-filter FC bias of the baseline network: the sum over its 1024 entries moved
         # past 1e-5 of the weight scale when the round-3 tiles changed the rounding pattern upstream)
-        dev_ = 0.0 if f32 else 1e-4 * (BF16_NORM + (2 * (1 - BF16_COS)) ** 0.5)
+        lr_k = sgd.lr * net.P.param_group(nme, *net.P.seg_rule[:2])[0]        # this tensor's own learning rate (10 x lr on the language side of four solvers)
+        dev_ = 0.0 if f32 else lr_k * (BF16_NORM + (2 * (1 - BF16_COS)) ** 0.5)
         check_digest(g, 'w1.' + nme, sd1[nme].numpy(), rtol=1e-5, atol=1e-7,
                      extra_sample=dev_ * float(np.abs(g['g.' + nme + '.sample']).max()), extra_sum=dev_ * float(g['g.' + nme + '.abssum']))
 

@@ -62,6 +62,17 @@ def main(args, variant='cycle'):
         cfg_from_file(osp.join(ROOT, args['cfg_file']))
     if args['set_cfgs']:
         cfg_from_list(args['set_cfgs'])
+    if variant == 'vgg':
+        # tools/train_vgg.py:24 merges the yaml / --set list into model/config_vgg.py's cfg, the object its solver reads
+        # (train_val_vgg.py:12: WEIGHT_DECAY 5e-4, DOUBLE_BIAS True by default there), while nets/network_vgg.py:29 and the layers read
+        # model/config.py - which the reference therefore leaves at its defaults for this entry point.  Here both objects receive the
+        # overrides: with the shipped vgg16.yml / train_vgg.sh the values the network reads are the defaults either way, and a
+        # network-side override (TRAIN.RPN_BATCHSIZE ...) is honoured instead of silently dropped.
+        from lang2seg_amd.model import config_vgg
+        if args['cfg_file'] and osp.exists(osp.join(ROOT, args['cfg_file'])):
+            config_vgg.cfg_from_file(osp.join(ROOT, args['cfg_file']))
+        if args['set_cfgs']:
+            config_vgg.cfg_from_list(args['set_cfgs'])
     cfg.COMPUTE_DTYPE = args['dtype']
     if variant == 'vgg':
         from lang2seg_amd.nets.vgg16 import vgg16
