@@ -156,6 +156,37 @@ class ParamStore(object):
                     return False
         return True
 
+    def shadow_only(self, k):
+        """True when every kernel reads trainable tensor `k` through the dtype shadow ONLY (ParamStore.shadow = bf16(rowscale * param)) and
+        never through the fp32 master in ParamStore.param: the weights of the trainable ConvOps in bf16 mode - forward from ConvOp.wf (a
+        view of the shadow), data gradient from the transposed copy refresh_weights builds FROM the shadow (nets/network.py).  Everything
+        else is read as fp32 master somewhere: every bias (ConvOp.bias), the language encoder and the captioner (resnet_v1.py _encoder /
+        _caption*), the dynamic-filter FCs (dyn_w / dyn_b), mask_pred_net.weight (maskpred_bwd), mask_up_sampling.weight (its forward
+        operand is a transpose of the master), and in f32 mode all of it.  The data-parallel sharded update puts the shadow on the wire only
+        for ranges of such tensors and the masters for the rest (parallel.GradReducer);
+        tests/test_train_step_gpu.py::test_sharded_update_stale_masters_are_never_read poisons the masters this predicate says nobody reads."""
+        from .._lib import BF16
+        if self.dt != BF16 or not k.endswith('.weight') or k not in self.offsets:
+            return False
+        if k.startswith(('resnet.layer', 'vgg.features.', 'vgg.classifier.')):
+            return True
+        return k in ('rpn_net.weight', 'cls_score_net.weight', 'bbox_pred_net.weight', 'rpn_cls_score_net.weight', 'rpn_bbox_pred_net.weight',
+                     'caption_model.att_embed.0.weight')
+
+    def shadow_only_runs(self):
+        """the flat buffer as maximal runs [(lo, hi, shadow_only)] in offset order (alignment gaps / group padding go with the tensor in front)"""
+        runs = []
+        ks = self.trainable
+        for i, k in enumerate(ks):
+            lo = self.offsets[k] if i else 0
+            hi = self.offsets[ks[i + 1]] if i + 1 < len(ks) else self.total
+            so = self.shadow_only(k)
+            if runs and runs[-1][2] == so:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi, so])
+        return [tuple(r) for r in runs]
+
     @staticmethod
     def bn_of(k):
         """BN module whose frozen scale folds into conv weight `k` (None if none)."""
@@ -182,6 +213,8 @@ class ParamStore(object):
         # att_embed, layer4, RoI / mask heads, RPN - form ONE contiguous range, `defer_range`, see optim.SGD.defer)
         take(lambda k: k.startswith('caption_model.') and '.att_embed.' not in k)
         n_cap_rest = len(order)
+        # (bias in front of the weight: the weight is read through the dtype shadow only and then adjoins layer4's, shadow_only() below)
+        take(lambda k: k.startswith('caption_model.') and k.endswith('.bias'))
         take(lambda k: k.startswith('caption_model.'))
         take(lambda k: k.startswith('vgg.classifier.3.'))
         take(lambda k: k.startswith('vgg.classifier.0.'))
@@ -234,10 +267,11 @@ class ParamStore(object):
             for k in [k for k in tr if p(k) and k not in self.offsets]:
                 off = (off + 63) // 64 * 64
                 place(k)
-        for i in reversed(range(31)):
-            for k in [k for k in tr if k.startswith('vgg.features.%d.' % i) and k not in self.offsets]:
-                off = (off + 63) // 64 * 64
-                place(k)
+        for sfx in ('.bias', '.weight'):                  # the VGG trunk: its biases (read as fp32 masters) together, then its weights (shadow_only())
+            for i in reversed(range(31)):
+                for k in [k for k in tr if k.startswith('vgg.features.%d.' % i) and k.endswith(sfx) and k not in self.offsets]:
+                    off = (off + 63) // 64 * 64
+                    place(k)
         for li in (3, 2, 1):
             for b in reversed(range(self.nblocks[li - 1])):
                 for k in [k for k in tr if k.startswith('resnet.layer%d.%d.' % (li, b)) and k not in self.offsets]:

@@ -181,6 +181,7 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
     # SolverWrapper of the variant left after optimizer.step()
     from lang2seg_amd.model.train_val import make_optimizer
     w0 = {nme: net.state_dict()[nme].numpy().copy() for nme in names if any(s_ in nme for s_ in ('rnn_encoder', 'dynamic_fc', 'response'))}
+    g0 = {nme: np.asarray(_grad_of(net, nme)).copy() for nme in w0}              # (the update clears the gradients it consumes)
     sgd = make_optimizer(net)
     assert sgd.lr == float(g['solver.LEARNING_RATE']) and sgd.weight_decay == float(g['solver.WEIGHT_DECAY']) and sgd.momentum == float(g['solver.MOMENTUM'])
     sgd.step()
@@ -194,7 +195,7 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
         for nme, w_old in w0.items():
             if 'bias' in nme:
                 continue
-            gr = np.asarray(_grad_of(net, nme))
+            gr = g0[nme]
             unit = (gr + sgd.weight_decay * w_old).ravel().astype(np.float64)
             step = (w_old - sd1[nme].numpy()).ravel().astype(np.float64)
             big = np.abs(unit) > 0.05 * np.abs(unit).max()
