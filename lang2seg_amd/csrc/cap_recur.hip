@@ -44,6 +44,9 @@ __device__ __forceinline__ void put(gu64* g, unsigned tag, float v) { __hip_atom
 
 // every thread of the workgroup polls granules tid, tid + NT, ... (NR per thread) of g[0, n) until their tags match, then dst[i] = value.
 // Returns false when the workgroup has to give up (bounded spin; *dead is an LDS word shared by the workgroup).
+// A give-up also ends the launch's epoch (workgroup 0 bumps state[0] on that path too): the granules the failed launch left behind carry
+// the old epoch's tags and cannot satisfy the next launch; state[1] stays set until the host has seen it (Network.train_step reads and
+// clears it when a loss comes back non-finite and raises L2SError).
 template <int NR>
 __device__ __forceinline__ bool gather(gu64* g, int n, unsigned tag, float* dst, int* dead, unsigned* err) {
   const int tid = threadIdx.x;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NT) void cap_recur_fwd_kernel(l2s_cap_recur_fwd_arg
       for (int r = 2; r < 12; ++r) { const float s = wave_sum(dot8(wa[r], wb[r], ha, hb)); if (lane == r) mine = s; }
       if (lane >= 2 && lane < 12) s_l[10 * wv + lane - 2] = mine + brow;
     }
-    if (!gather<1>(G1, AH, tag, ah_l, dead, state + 1)) { a.hs[R + tid] = NAN; return; }      // a give-up poisons h(0): the caption loss turns NaN, nothing passes silently
+    if (!gather<1>(G1, AH, tag, ah_l, dead, state + 1)) { a.hs[R + tid] = NAN; if (w == 0 && tid == 0) state[0] = state[0] + 1u; return; }      // a give-up poisons h(0): the caption loss turns NaN, nothing passes silently
     // ---- B: attention dots of the own locations (one wave each) ----
     {
       const int l = LPW * w + wv;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(NT) void cap_recur_fwd_kernel(l2s_cap_recur_fwd_arg
         if (lane == 0) put(G2 + l, tag + 1, s + ab);
       }
     }
-    if (!gather<1>(G2, L, tag + 1, e_l, dead, state + 1)) { a.hs[R + tid] = NAN; return; }      // a give-up poisons h(0): the caption loss turns NaN, nothing passes silently
+    if (!gather<1>(G2, L, tag + 1, e_l, dead, state + 1)) { a.hs[R + tid] = NAN; if (w == 0 && tid == 0) state[0] = state[0] + 1u; return; }      // a give-up poisons h(0): the caption loss turns NaN, nothing passes silently
     // ---- C: softmax over the L locations (every wave computes the statistics; waves 0-3 store a quarter of the weights each) ----
     {
       float v[4], mx = -INFINITY;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(NT) void cap_recur_fwd_kernel(l2s_cap_recur_fwd_arg
         for (int g = 0; g < 5; ++g) sg[g] = a.sums[(long)(t + 1) * 5 * R + (long)g * R + j];
       }
     }
-    if (t + 1 < S && !gather<1>(G3, R, tag + 2, h_l, dead, state + 1)) { a.hs[R + tid] = NAN; return; }      // a give-up poisons h(0): the caption loss turns NaN, nothing passes silently
+    if (t + 1 < S && !gather<1>(G3, R, tag + 2, h_l, dead, state + 1)) { a.hs[R + tid] = NAN; if (w == 0 && tid == 0) state[0] = state[0] + 1u; return; }      // a give-up poisons h(0): the caption loss turns NaN, nothing passes silently
   }
   if (w == 0 && tid == 0) state[0] = state[0] + 1u;
 }
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(NT) void cap_recur_bwd_kernel(l2s_cap_recur_bwd_arg
       v_l[jj] = d0s; v_l[16 + jj] = d1s; v_l[32 + jj] = d2s; v_l[48 + jj] = d0; v_l[64 + jj] = d1;
       dc = dcn * fg;
     }
-    if (!gather<2>(G1, 2 * R, tag, g_l, dead, state + 1)) { a.dsums[tid] = NAN; return; }      // a give-up poisons d(sums): the captioner's gradients turn NaN
+    if (!gather<2>(G1, 2 * R, tag, g_l, dead, state + 1)) { a.dsums[tid] = NAN; if (w == 0 && tid == 0) state[0] = state[0] + 1u; return; }      // a give-up poisons d(sums): the captioner's gradients turn NaN
     // ---- 2: d(weight) of the own locations: P[l] . d(a2c), one wave each ----
     {
       const int l = LPW * w + wv;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(NT) void cap_recur_bwd_kernel(l2s_cap_recur_bwd_arg
         if (lane == 0) put(G2 + l, tag + 1, acc);
       }
     }
-    if (!gather<1>(G2, L, tag + 1, dw_l, dead, state + 1)) { a.dsums[tid] = NAN; return; }      // a give-up poisons d(sums): the captioner's gradients turn NaN
+    if (!gather<1>(G2, L, tag + 1, dw_l, dead, state + 1)) { a.dsums[tid] = NAN; if (w == 0 && tid == 0) state[0] = state[0] + 1u; return; }      // a give-up poisons d(sums): the captioner's gradients turn NaN
     // ---- 3: softmax backward (every wave the statistics; waves 0-3 store a quarter of ddot each) ----
     {
       float dwv[4], dot = 0.f;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(NT) void cap_recur_bwd_kernel(l2s_cap_recur_bwd_arg
       for (int n = 0; n < 96; ++n) acc = fmaf(v_l[n], wr[n], acc);
       put(G3 + (long)(tid >> 4) * 512 + w * 16 + (tid & 15), tag + 2, acc);
     }
-    if (!gather<1>(G3 + (long)w * 512, 512, tag + 2, rs_l, dead, state + 1)) { a.dsums[tid] = NAN; return; }      // a give-up poisons d(sums): the captioner's gradients turn NaN
+    if (!gather<1>(G3 + (long)w * 512, 512, tag + 2, rs_l, dead, state + 1)) { a.dsums[tid] = NAN; if (w == 0 && tid == 0) state[0] = state[0] + 1u; return; }      // a give-up poisons d(sums): the captioner's gradients turn NaN
     if (tid < UPW) {
       float s = 0.f;
 #pragma unroll

@@ -641,6 +641,9 @@ class Network(object):
         """(name, fp32 tensor in the REFERENCE layout) for every trainable tensor (TV:194-220 iterates these)."""
         from .params import from_internal
         self.join_update()
+        dp = getattr(self, 'dp', None)
+        if dp is not None and getattr(dp, 'master_stale', False):      # as state_dict(): the masters of other ranks' shadow-gathered slices are behind
+            raise RuntimeError('named_parameters() of a sharded data-parallel run: call net.dp.gather_master() on every rank first')
         for k in self.P.trainable:
             yield k, from_internal(k, self.P.view(k), self.P.shapes[k])
 
@@ -785,7 +788,27 @@ class Network(object):
     def train_step(self, blobs, idx, train_op):
         loss = self.train_step_async(blobs, idx, train_op)
         vals = loss.cpu().numpy()          # the single host sync of the step (the reference does seven, NET:704-710)
+        if not np.isfinite(vals[np.asarray(self._loss_slots())]).all():
+            self.check_cap_recur()
         return tuple(float(vals[i]) for i in self._loss_slots())
+
+    def check_cap_recur(self):
+        """The resident captioner recurrence (csrc/cap_recur.hip) poisons its outputs with NaN when a workgroup gives up its bounded spin
+        (its peers were not co-resident) and leaves an error word in its exchange state.  Called when a loss comes back non-finite: the word is
+        read, cleared together with the exchange state, and the cause is raised instead of a bare NaN (the caller may set
+        `cap_persistent = False` to continue on the per-token launches)."""
+        from .._lib import L2SError
+        st = getattr(self, '_cap_state', None)
+        if st is None:
+            return
+        torch.cuda.synchronize()
+        err = [int(s[1].item()) for s in st]              # state[1]: the give-up flag (int32 words: launch count, flag, ...)
+        if any(err):
+            for s in st:
+                s.zero_()
+            raise L2SError('captioner recurrence: a workgroup of the resident %s launch gave up waiting for its peers (not co-resident); the '
+                           'exchange state was reset - set Network.cap_persistent = False to run the per-token launches' %
+                           ' / '.join(n for n, e in zip(('forward', 'backward'), err) if e))
 
     def _loss_slots(self):
         from .variants import loss_names, SLOT

@@ -23,7 +23,10 @@ class SGD(object):
         net.defer_heads = self.defer_active
         # the plain side-stream update records when the LAST segments (layer2) are done: the next step's layer2 waits for that only
         net.update_split = bool(self.side_active and getattr(net, 'dp', None) is None and not self.defer_active)
-        net.layer2_side = bool(net.update_split and self.layer2_side)
+        # layer2's weight gradients + the update of what the early partial updates left, on 'wg2': only when what is left IS layer2 alone, i.e.
+        # layer2 is the last trainable stage (FIXED_BLOCKS = 1).  With FIXED_BLOCKS = 0 the tail also holds layer1, whose weight gradients run
+        # on 'wg': an update on 'wg2' would race them.  (FIXED_BLOCKS >= 2 / VGG: no 'layer2' flush at all.)
+        net.layer2_side = bool(net.update_split and self.layer2_side and getattr(net.P, 'fixed_blocks', 1) == 1 and not getattr(net.P, 'is_vgg', False))
         # keep_grad=False: the update kernel zeroes every gradient it consumes (optimizer.zero_grad(), TV:383, folded in), and
         # forward_backward no longer clears the buffer (it is zero when the network is built, and every update leaves it zero; a second
         # backward pass without an update in between is refused); keep_grad=True leaves the step's gradients in P.grad (tests read them there)
@@ -237,6 +240,13 @@ class SGD(object):
         # shadow (a rank's slice whose dtype shadow goes on the wire instead of its weights, GradReducer.gather_shadow): written with the update
         O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay, self.grad_scale,
                              P.shadow if (full or shadow) else None, int(bool(full and self.clear_grad)), lo, hi, c_lo, c_hi)
+
+    def refresh_shadow_range(self, lo, hi):
+        """dtype shadow of the elements [lo, hi) from the parameters there (a sub-bucket whose fp32 masters the ranks have just gathered)"""
+        P = self.net.P
+        c_lo, c_hi = P.chunk_range(lo, hi)
+        if c_hi > c_lo:
+            O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, 0.0, 1.0, 0.0, 0.0, P.shadow, 2, lo, hi, c_lo, c_hi)
 
     def refresh_shadow(self):
         """dtype shadow of every tensor from the (gathered) parameters: shadow = dtype(rowscale * param), no update"""

@@ -51,6 +51,28 @@ def replay_segments(stages, run_segment, dp):
     run_segment(len(stages))
 
 
+def shard_plan(P, lo, hi, min_shadow_run=1 << 18):
+    """the sub-buckets of the gradient bucket [lo, hi) for the sharded update: [(a, b, on_wire)] with on_wire = 'shadow' where EVERY tensor
+    of [a, b) is read through the dtype shadow only (ParamStore.shadow_only: the bf16 convolution weights) - its all-gather carries the
+    shadow, half the bytes, and the fp32 masters of the other ranks' slices stay behind until gather_master() - and 'master' elsewhere: the
+    all-gather carries the fp32 master weights and every rank rewrites the shadow of the range from them.  'master' is right for any
+    tensor, so a shadow-only run shorter than `min_shadow_run` elements joins its neighbours instead of paying for its own collective."""
+    if not hasattr(P, 'shadow_only_runs'):
+        return [(lo, hi, 'master')]
+    cut = []
+    for a, b, so in P.shadow_only_runs():
+        a, b = max(a, lo), min(b, hi)
+        if b > a:
+            cut.append([a, b, 'shadow' if (so and b - a >= min_shadow_run) else 'master'])
+    out = []
+    for c in cut:
+        if out and out[-1][2] == c[2]:
+            out[-1][1] = c[1]
+        else:
+            out.append(c)
+    return [tuple(c) for c in out]
+
+
 class GradReducer(object):
     """Bucketed gradient exchange on a side stream.
 
@@ -86,12 +108,20 @@ class GradReducer(object):
         # the rest of the backward pass instead of trailing the step.  Momentum of the other slices is never read on this rank.
         self.shard_update = shard_update
         # Round 5: what the all-gather of a sharded bucket carries is the dtype SHADOW the kernels read (bf16(scale * w) in the benchmarked mode), not
-        # the fp32 master weights: half the bytes on the wire (203 -> 102 MB per step at 70 M parameters), and the shadow-only pass over the whole
-        # buffer at the end of the step (0.23 GB of HBM) is gone - every rank writes the shadow of its slice in the update and receives the others'.
-        # The fp32 master weights and the momentum of a slice then live on its owner ONLY; gather_master() (a collective: every rank calls it,
-        # model/train_val.py before a snapshot, Network.state_dict through it) brings the masters together again.
+        # the fp32 master weights: half the bytes on the wire, and the shadow-only pass over the whole buffer at the end of the step is gone -
+        # every rank writes the shadow of its slice in the update and receives the others'.
+        # Round 6: that is only right for tensors NO kernel reads as fp32 master.  The language encoder, the captioner, every
+        # bias, the dynamic-filter FCs, mask_pred / mask_up_sampling are read from ParamStore.param directly, and in round 5 the other ranks'
+        # slices of those stayed at their initial values on every rank (the ranks diverged; the world-1 GPU test and the shadow-only gloo check
+        # could not see it).  Now every bucket is cut into sub-buckets by what its tensors are read through (shard_plan): 'shadow' sub-buckets
+        # (the bf16 convolution weights: 47 of 73 M elements of the cycle network) gather the shadow as before, 'master' sub-buckets gather the
+        # fp32 masters and rewrite their shadow locally.  Per step on the wire: 94 MB of shadow + 104 MB of masters (280 MB if every all-gather
+        # carried masters).  The fp32 masters of a 'shadow' slice then live on its owner ONLY; gather_master() (a collective: every rank calls
+        # it, model/train_val.py before a snapshot, Network.state_dict through it) brings them together again.
         self.gather_shadow = shard_update is not None and getattr(net.P, 'shadow', None) is not None
-        self._parts = {}             # bucket lo -> (m, per): the partition of every sharded bucket, for gather_master()
+        self._parts = {}             # sub-bucket lo -> (m, per): the partition of every sharded sub-bucket
+        self._plans = {}             # bucket lo -> shard_plan(...)
+        self._stale = []             # (lo, m, per) of the sub-buckets whose all-gather carried the shadow since the last gather_master()
         self.master_stale = False    # other ranks' slices of P.param are behind (until gather_master())
         self.rank = rank if rank is not None else (dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0)
         # experiment only (bench.py --dp-skip-allreduce): 1 = keep the stream structure but issue no collective, 2 = do nothing.
@@ -135,7 +165,7 @@ class GradReducer(object):
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 
-    def _exchange_sharded(self, seg, lo, hi):
+    def _exchange_sharded(self, seg, lo, hi, on_wire='shadow'):
         """bucket [lo, hi): reduce-scatter the gradients, update this rank's slice, all-gather the weights (the < 4 world elements that do not
         split evenly are all-reduced and updated by every rank)"""
         W, r, P = self.world, self.rank, self.net.P
@@ -158,10 +188,11 @@ class GradReducer(object):
             own = seg[r * per:(r + 1) * per]
             self._cast(sh, own) if self.wire == 'bf16' else own.copy_(sh)
             self._parts[lo] = (m, per)
-            if self.gather_shadow:
+            if self.gather_shadow and on_wire == 'shadow':
                 self.shard_update.update_range(lo + r * per, lo + (r + 1) * per, shadow=True)
                 wsl = P.shadow[lo:lo + m]
                 self.master_stale = W > 1
+                self._stale.append((lo, m, per))
             else:
                 self.shard_update.update_range(lo + r * per, lo + (r + 1) * per)
                 wsl = P.param[lo:lo + m]
@@ -174,6 +205,8 @@ class GradReducer(object):
                 mine = self._wshard[:per]
                 mine.copy_(wsl[r * per:(r + 1) * per])
                 dist.all_gather_into_tensor(wsl, mine)
+            if self.gather_shadow and on_wire != 'shadow':
+                self.shard_update.refresh_shadow_range(lo, lo + m)       # the shadow of the gathered masters (this rank's slice included)
         if m < n:
             tail = seg[m:]
             if self.wire == 'bf16':
@@ -181,10 +214,8 @@ class GradReducer(object):
                 self._cast(tail, tb); dist.all_reduce(tb, op=dist.ReduceOp.SUM); self._cast(tb, tail)
             else:
                 dist.all_reduce(tail, op=dist.ReduceOp.SUM)
-            if self.gather_shadow:
-                self.shard_update.update_range(lo + m, hi, shadow=True)
-            else:
-                self.shard_update.update_range(lo + m, hi)
+            # (every rank updates the tail from the all-reduced gradients: master and shadow are both current everywhere)
+            self.shard_update.update_range(lo + m, hi, shadow=bool(self.gather_shadow))
 
     def gather_master(self):
         """sharded update with the shadow on the wire: all-gather the fp32 master weights of every bucket (each rank contributes the slices it owns).
@@ -196,17 +227,32 @@ class GradReducer(object):
         P, W, r = self.net.P, self.world, self.rank
         if self.on_gpu:
             torch.cuda.synchronize()
-        for lo, (m, per) in sorted(self._parts.items()):
+        for lo, m, per in sorted(set(self._stale)):
             wsl = P.param[lo:lo + m]
             mine = wsl[r * per:(r + 1) * per].clone()
             dist.all_gather_into_tensor(wsl, mine)
         if self.on_gpu:
             torch.cuda.synchronize()
         self.master_stale = False
+        del self._stale[:]
+
+    def stale_master_ranges(self):
+        """[(lo, hi)] of the flat buffer whose fp32 masters this rank does NOT hold current (other ranks' slices of the sub-buckets whose
+        all-gather carried the shadow) - until gather_master()"""
+        out = []
+        for lo, m, per in sorted(set(self._stale)):
+            for j in range(self.world):
+                if j != self.rank:
+                    out.append((lo + j * per, lo + (j + 1) * per))
+        return out
 
     def _exchange(self, seg, lo, hi):
         if self.shard_update is not None:
-            return self._exchange_sharded(seg, lo, hi)
+            if lo not in self._plans:
+                self._plans[lo] = shard_plan(self.net.P, lo, hi) if self.gather_shadow else [(lo, hi, 'master')]
+            for a, b, on_wire in self._plans[lo]:
+                self._exchange_sharded(seg[a - lo:b - lo], a, b, on_wire)
+            return
         if self.wire == 'bf16':
             if self._pack is None:
                 self._pack = torch.empty(self.net.P.total, dtype=torch.bfloat16, device=seg.device)

@@ -17,4 +17,4 @@ def _restore_pooling_cfg():
     yield
     mod = sys.modules.get('lang2seg_amd.model.config')
     if mod is not None:
-        mod.cfg.POOLING_MODE = 'crop'; mod.cfg.POOLING_ALIGN = False; mod.cfg.RESNET.MAX_POOL = False
+        mod.cfg.POOLING_MODE = 'crop'; mod.cfg.POOLING_ALIGN = False; mod.cfg.RESNET.MAX_POOL = False; mod.cfg.RESNET.FIXED_BLOCKS = 1

@@ -218,7 +218,7 @@ def keys_from_log(n_total, cand, drawn, disable_mode):
     return keys
 
 
-def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain=4.0, full_tensors=True, variant='cycle', top_over=None):
+def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain=4.0, full_tensors=True, variant='cycle', top_over=None, resnet_over=None):
     from model.config import cfg
     import importlib
     var = OW.VARIANTS[variant]
@@ -234,6 +234,8 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
     top_saved = {}
     for k, v in (top_over or {}).items():            # top-level switches, e.g. POOLING_ALIGN (NET:569-570)
         top_saved[k] = getattr(cfg, k); setattr(cfg, k, v); ocfg[k] = v
+    for k, v in (resnet_over or {}).items():         # cfg.RESNET.* (FIXED_BLOCKS: RES:290-299 freezes layer1..FIXED_BLOCKS)
+        top_saved['RESNET.' + k] = getattr(cfg.RESNET, k); setattr(cfg.RESNET, k, v); ocfg[k] = v
     opt = OW.default_opt(vocab_size=V, seq_length=T)
     is_vgg = var.get('backbone') == 'vgg'
     if is_vgg:
@@ -374,6 +376,8 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
         gsel = ['vgg.features.10.weight', 'vgg.features.17.bias', 'vgg.features.28.weight', 'vgg.classifier.0.weight', 'vgg.classifier.3.bias',
                 'rpn_net.weight', 'rpn_cls_score_net.bias', 'cls_score_net.weight', 'bbox_pred_net.bias', 'dynamic_fc_3.weight', 'response_fc.weight',
                 'rnn_encoder.embedding.weight', 'rnn_encoder.rnn.weight_hh_l0_reverse', 'rnn_encoder.mlp.0.bias']
+    if (resnet_over or {}).get('FIXED_BLOCKS', 1) == 0:
+        gsel = gsel + ['resnet.layer1.0.conv1.weight', 'resnet.layer1.2.conv2.weight', 'resnet.layer1.0.downsample.0.weight']
     if var['nfilt'] == 1:
         gsel = [k for k in gsel if not k.startswith(('dynamic_fc_', 'response_fc'))] + ['dynamic_fc.weight', 'dynamic_fc.bias']
     if var['cap'] is None:
@@ -384,8 +388,13 @@ def run_reference(tag, H, W, T, V, cfg_over, seed_w=3, seed_blob=1234, head_gain
         flat('w1.' + k, digest(dict(net.named_parameters())[k]), out)
     for k, v in (top_over or {}).items():
         out['top.' + k] = int(v)
+    for k, v in (resnet_over or {}).items():
+        out['resnet.' + k] = int(v)
     for k, v in top_saved.items():
-        setattr(cfg, k, v)
+        if k.startswith('RESNET.'):
+            setattr(cfg.RESNET, k[7:], v)
+        else:
+            setattr(cfg, k, v)
     np.savez_compressed(os.path.join(HERE, 'ref_%s.npz' % tag), **out)
     print(tag, 'losses', L, 'num_fg', out['int.num_fg'], 'n_prop', n_prop, 'choices', [(len(e['a']), e['size']) for e in log])
     return out
@@ -682,6 +691,191 @@ def run_eval_split():
     print(out['pred_class'], out['pred_box'])
 
 
+SNAP_DIR = os.path.join(HERE, 'ref_snapshot')
+
+
+def _pth_records(path):
+    import zipfile
+    with zipfile.ZipFile(path) as z:
+        return [(i.filename, i.file_size, i.CRC, i.compress_type) for i in z.infolist()], {i.filename: z.read(i.filename) for i in z.infolist()
+                                                                                          if '/data/' not in i.filename}
+
+
+def run_snapshot():
+    """f3: a snapshot PAIR written by the reference's own SolverWrapper.snapshot() (train_val_cycle.py:57-104) and what its from_snapshot()
+    (:106-165) makes of it - full match, and the `[:, :-1]` partial rule (:121-124) on a file whose rpn_net.weight lacks the last input channel.
+    The .pth of the tiny cycle network is ~230 MB, so what is committed is everything of it EXCEPT the tensor payloads: the zip's non-payload
+    records as the reference wrote them (data.pkl = the pickled OrderedDict structure with its storage references, version, byteorder) and a
+    manifest with every payload record's size + CRC-32 and the key it belongs to.  The payloads are the deterministic synthetic weights
+    (oracle.weights.make_state_dict(seed=3, head_gain=4); keys the generator does not cover are zeroed before the snapshot or small enough to
+    sit in the manifest), so tests/test_snapshot_*.py rebuild the file bit for bit (checked record by record against the CRCs) and hand it to the
+    build's from_snapshot.  The .pkl sidecar is committed as the reference wrote it."""
+    import base64
+    import json
+    import random
+    import shutil
+    import tempfile
+    import zlib
+    from model.config import cfg
+    import importlib
+    H, W, T, V = 320, 416, 6, 60
+    variant = 'cycle'
+    var = OW.VARIANTS[variant]
+    RESM = importlib.import_module('nets.' + var['module'])
+    opt = OW.default_opt(vocab_size=V, seq_length=T)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant=variant)
+    tmp = tempfile.mkdtemp(prefix='l2s_ref_snapshot_')
+
+    def fresh(loader):
+        torch.manual_seed(0)
+        net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
+        sw, scfg = reference_solver(variant, net, output_dir=tmp, loader=loader)
+        sw.construct_graph()
+        return net, sw
+    ld = StubLoader()
+    net, sw = fresh(ld)
+    ref_sd = net.state_dict()
+    src = {}
+    for k, t in ref_sd.items():
+        if k in sd:
+            t.copy_(torch.from_numpy(sd[k])); src[k] = 'gen'
+        elif t.numel() * t.element_size() <= 64:
+            src[k] = 'inline'                                  # BatchNorm num_batches_tracked (int64 scalars)
+        else:
+            t.zero_(); src[k] = 'zeros'                        # resnet.fc.*: in the module, never used (RES:133)
+    # host RNG streams in a known, non-initial state
+    np.random.seed(1234); np.random.rand(5)
+    random.seed(77); random.random()
+    sfile, nfile = sw.snapshot(7)
+    recs, small = _pth_records(sfile)
+    # storage key of every tensor: torch.save numbers the storages in traversal order; confirmed by the payload CRCs
+    prefix = recs[0][0].split('/')[0]
+    by_name = {r[0]: r for r in recs}
+    keys = []
+    for i, (k, t) in enumerate(ref_sd.items()):
+        r = by_name['%s/data/%d' % (prefix, i)]
+        raw = t.detach().contiguous().numpy().tobytes()
+        assert r[1] == len(raw) and r[2] == (zlib.crc32(raw) & 0xFFFFFFFF) and r[3] == 0, (k, r)
+        e = dict(key=k, shape=list(t.shape), dtype=str(t.dtype), record=r[0], size=r[1], crc32=r[2], source=src[k])
+        if src[k] == 'inline':
+            e['bytes'] = base64.b64encode(raw).decode()
+        keys.append(e)
+    os.makedirs(SNAP_DIR, exist_ok=True)
+    for name, data in small.items():
+        with open(os.path.join(SNAP_DIR, 'pth.' + name.split('/', 1)[1].replace('/', '.')), 'wb') as f:
+            f.write(data)
+    shutil.copy(nfile, os.path.join(SNAP_DIR, os.path.basename(nfile)))
+    man = dict(prefix=prefix, pth=os.path.basename(sfile), pkl=os.path.basename(nfile), iter=7, records=[dict(name=r[0], size=r[1], crc32=r[2]) for r in recs],
+               keys=keys, meta=dict(H=H, W=W, T=T, V=V, seed_w=3, head_gain=4.0, variant=variant, torch=torch.__version__),
+               written_by='pyutils/mask-faster-rcnn/lib/model/train_val_cycle.py SolverWrapper.snapshot (reference, run by tests/golden/make_golden.py snapshot)')
+
+    # ---- what the reference's from_snapshot restores from its own pair ----
+    def restore(spath):
+        ld2 = StubLoader(seed=99); ld2.iterators = {'train': 0, 'val': 0}
+        net2, sw2 = fresh(ld2)
+        for k, t in net2.state_dict().items():               # current values that a partial copy must leave alone
+            if t.dtype.is_floating_point:
+                t.fill_(0.25)
+        np.random.seed(1); random.seed(1)
+        import io, contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            last = sw2.from_snapshot(spath, nfile)
+        out = dict(last_snapshot_iter=int(last), iter_train=int(ld2.iterators['train']), iter_val=int(ld2.iterators['val']),
+                   perm_train=[int(x) for x in ld2.perm['train']], perm_val=[int(x) for x in ld2.perm['val']],
+                   next_np_rand=[float(x) for x in np.random.rand(3)], next_py_random=random.random(),
+                   printed=[l for l in buf.getvalue().splitlines() if l.startswith('size ')])
+        return net2, out
+    net2, full = restore(sfile)
+    for k, t in net2.state_dict().items():
+        assert torch.equal(t, ref_sd[k]), k
+    man['restore_full'] = full
+    # the same pair with rpn_net.weight saved one input channel short: TV:121-124 copies it into param[:, :-1] and keeps the rest
+    sd_part = torch.load(sfile)
+    sd_part['rpn_net.weight'] = sd_part['rpn_net.weight'][:, :-1].clone()
+    pfile = os.path.join(tmp, 'partial.pth')
+    torch.save(sd_part, pfile)
+    net3, part = restore(pfile)
+    w = net3.state_dict()['rpn_net.weight']
+    assert torch.equal(w[:, :-1], ref_sd['rpn_net.weight'][:, :-1]) and bool((w[:, -1] == 0.25).all())
+    part['rpn_net.weight.sum'] = float(w.double().sum()); part['rpn_net.weight.last_channel'] = 0.25
+    man['restore_partial'] = part
+    with open(os.path.join(SNAP_DIR, 'manifest.json'), 'w') as f:
+        json.dump(man, f, indent=1)
+    print('snapshot: %d records, %d keys (%s); restore_full %s; partial %s' % (
+        len(recs), len(keys), {v: sum(1 for e in keys if e['source'] == v) for v in ('gen', 'zeros', 'inline')}, full['printed'], part['printed']))
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+def read_build_snapshot(src=None):
+    """f3, reverse direction: the snapshot pair the BUILD wrote on the MI355X (tests/test_train_step_gpu.py::
+    test_resume_from_reference_written_snapshot leaves its zip structure, sidecar and per-tensor CRCs in gpurun_out/build_snapshot/; its
+    payloads are the synthetic weights it had just restored, regenerated here and checked against those CRCs) is loaded by the REFERENCE's
+    own SolverWrapper.from_snapshot (train_val_cycle.py:106-165) into a fresh reference network.  The transcript is committed as
+    tests/golden/build_snapshot_readback.json together with the build-written structure (tests/golden/build_snapshot/)."""
+    import io
+    import contextlib
+    import json
+    import random
+    import shutil
+    import tempfile
+    import zipfile
+    import zlib
+    import importlib
+    src = src or os.path.join(ROOT, 'gpurun_out', 'build_snapshot')
+    man = json.load(open(os.path.join(src, 'manifest.json')))
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant='cycle')
+    tmp = tempfile.mkdtemp(prefix='l2s_build_snapshot_')
+    prefix = man['records'][0]['name'].split('/')[0]
+    by_rec = {'%s/data/%d' % (prefix, i): e for i, e in enumerate(man['keys'])}
+    sfile = os.path.join(tmp, man['pth'])
+    with zipfile.ZipFile(sfile, 'w', zipfile.ZIP_STORED) as z:
+        for r in man['records']:
+            name = r['name']
+            if name in by_rec:
+                e = by_rec[name]
+                dt = np.dtype(e['dtype'].replace('torch.', ''))
+                raw = (np.ascontiguousarray(sd[e['key']], dtype=dt) if e['key'] in sd else np.zeros(e['shape'], dt)).tobytes()
+                assert len(raw) == e['size'] and (zlib.crc32(raw) & 0xFFFFFFFF) == e['crc32'], ('payload differs from what the build wrote', e['key'])
+            else:
+                raw = open(os.path.join(src, 'pth.' + name.split('/', 1)[1].replace('/', '.')), 'rb').read()
+            assert len(raw) == r['size'] and (zlib.crc32(raw) & 0xFFFFFFFF) == r['crc32'], name
+            z.writestr(zipfile.ZipInfo(name), raw)
+    nfile = os.path.join(src, man['pkl'])
+    RESM = importlib.import_module('nets.' + OW.VARIANTS['cycle']['module'])
+    torch.manual_seed(0)
+    net = RESM.resnetv1(opt, batch_size=1, num_layers=101)
+    ld = StubLoader(seed=99); ld.iterators = {'train': 0, 'val': 0}
+    sw, scfg = reference_solver('cycle', net, output_dir=tmp, loader=ld)
+    sw.construct_graph()
+    for k, t in net.state_dict().items():
+        if t.dtype.is_floating_point:
+            t.fill_(0.25)
+    np.random.seed(1); random.seed(1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        last = sw.from_snapshot(sfile, nfile)
+    got = net.state_dict()
+    bad = [k for k, v in sd.items() if not np.array_equal(got[k].numpy(), v)]
+    exp = man['expect']
+    res = dict(reader='pyutils/mask-faster-rcnn/lib/model/train_val_cycle.py SolverWrapper.from_snapshot (reference)', written_by=man['written_by'],
+               printed=[l for l in buf.getvalue().splitlines() if l.startswith('size ')], last_snapshot_iter=int(last),
+               iter_train=int(ld.iterators['train']), iter_val=int(ld.iterators['val']),
+               perm_train=[int(x) for x in ld.perm['train']], perm_val=[int(x) for x in ld.perm['val']],
+               keys_in_file=len(man['keys']), keys_of_reference_net=len(got), tensors_equal_to_what_the_build_saved=len(sd) - len(bad), mismatching=bad,
+               keys_the_file_lacks=sorted(set(got) - {e['key'] for e in man['keys']})[:4] + ['...'],
+               ok=bool(not bad and int(last) == man['iter'] and ld.iterators['train'] == exp['iter_train'] and ld.iterators['val'] == exp['iter_val']
+                       and [int(x) for x in ld.perm['train']] == exp['perm_train'] and [int(x) for x in ld.perm['val']] == exp['perm_val']))
+    dst = os.path.join(HERE, 'build_snapshot')
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    json.dump(res, open(os.path.join(HERE, 'build_snapshot_readback.json'), 'w'), indent=1)
+    print('read_build_snapshot:', {k: v for k, v in res.items() if k not in ('perm_train', 'perm_val')})
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     install_harness()
@@ -706,6 +900,15 @@ if __name__ == '__main__':
         hook_proposals()
         run_reference('tiny_align', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64),
                       head_gain=4.0, top_over=dict(POOLING_ALIGN=True))
+    if what in ('snapshot', 'all'):
+        run_snapshot()
+    if what == 'read_build_snapshot':
+        read_build_snapshot(sys.argv[2] if len(sys.argv) > 2 else None)
+    if what in ('fb0', 'all'):
+        # cfg.RESNET.FIXED_BLOCKS = 0 (RES:290-299): layer1 trains too - its weight gradients and its part of the update are the last of the step
+        hook_proposals()
+        run_reference('tiny_fb0', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64),
+                      head_gain=4.0, resnet_over=dict(FIXED_BLOCKS=0))
     if what in ('test', 'all'):
         run_reference_test('test_tiny', 320, 416, 6, 60)
         run_reference_test('test_tiny_cycle_response', 320, 416, 6, 60, variant='cycle_response')

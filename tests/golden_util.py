@@ -60,6 +60,8 @@ def setup_from_fixture(g):
             cfg['TRAIN'][k[4:]] = int(g[k])
         if k.startswith('top.'):                     # top-level switches of the reference's cfg (POOLING_ALIGN, ...)
             cfg[k[4:]] = bool(int(g[k]))
+        if k.startswith('resnet.'):                  # cfg.RESNET.* of the reference (FIXED_BLOCKS)
+            cfg[k[7:]] = int(g[k])
     samp = dict(rpn_fg_keys=g['samp.rpn_fg_keys'], rpn_bg_keys=g['samp.rpn_bg_keys'],
                 roi_fg_keys=g['samp.roi_fg_keys'], roi_bg_keys=g['samp.roi_bg_keys'])
     return opt, sd, blob, cfg, samp
@@ -79,3 +81,50 @@ def setup_from_fixture_test(g):
         if int(g['meta_top_n']):
             cfg['TEST']['RPN_TOP_N'] = int(g['meta_top_n'])
     return opt, sd, blob, cfg, None
+
+
+def materialize_ref_snapshot(dst_dir, drop_last_cin_of=None):
+    """Rebuild the snapshot pair the REFERENCE's SolverWrapper.snapshot() wrote (tests/golden/make_golden.py run_snapshot; committed under
+    tests/golden/ref_snapshot/ without the ~230 MB of tensor payloads): the zip's structural records are the reference's bytes, every payload
+    record is regenerated from the deterministic synthetic weights and must match the size and CRC-32 the reference's file had.  Returns
+    (path of the .pth, path of the .pkl sidecar, manifest).  `drop_last_cin_of`: additionally write `<dst>/partial.pth`, the same state dict
+    with that 4-D tensor saved one input channel short (the `[:, :-1]` rule's input, TV:121-124), and return its path as manifest['_partial']."""
+    import base64
+    import json
+    import shutil
+    import zipfile
+    import zlib
+    import torch
+    from oracle import weights as OW
+    src = os.path.join(GOLD, 'ref_snapshot')
+    man = json.load(open(os.path.join(src, 'manifest.json')))
+    m = man['meta']
+    opt = OW.default_opt(vocab_size=m['V'], seq_length=m['T'])
+    sd = OW.make_state_dict(opt, seed=m['seed_w'], head_gain=m['head_gain'], variant=m['variant'])
+    by_rec = {e['record']: e for e in man['keys']}
+    os.makedirs(dst_dir, exist_ok=True)
+    sfile = os.path.join(dst_dir, man['pth'])
+    with zipfile.ZipFile(sfile, 'w', zipfile.ZIP_STORED) as z:
+        for r in man['records']:
+            name = r['name']
+            if name in by_rec:
+                e = by_rec[name]
+                dt = np.dtype(e['dtype'].replace('torch.', ''))
+                if e['source'] == 'gen':
+                    raw = np.ascontiguousarray(sd[e['key']], dtype=dt).tobytes()
+                elif e['source'] == 'zeros':
+                    raw = np.zeros(e['shape'], dt).tobytes()
+                else:
+                    raw = base64.b64decode(e['bytes'])
+            else:
+                raw = open(os.path.join(src, 'pth.' + name.split('/', 1)[1].replace('/', '.')), 'rb').read()
+            assert len(raw) == r['size'] and (zlib.crc32(raw) & 0xFFFFFFFF) == r['crc32'], ('record differs from what the reference wrote', name)
+            z.writestr(zipfile.ZipInfo(name), raw)
+    nfile = os.path.join(dst_dir, man['pkl'])
+    shutil.copy(os.path.join(src, man['pkl']), nfile)
+    if drop_last_cin_of:
+        full = torch.load(sfile, map_location='cpu')
+        full[drop_last_cin_of] = full[drop_last_cin_of][:, :-1].clone()
+        man['_partial'] = os.path.join(dst_dir, 'partial.pth')
+        torch.save(full, man['_partial'])
+    return sfile, nfile, man

@@ -212,40 +212,68 @@ def _dp_worker(rank, world, port, ret):
             if shadow:                                                   # (the HIP kernel writes dtype(rowscale * w); no BN fold in this stand-in)
                 P.shadow[lo:hi] = P.param[lo:hi].to(P.shadow.dtype)
             self.ranges.append((lo, hi))
-    w0 = torch.randn(P.total, generator=torch.Generator().manual_seed(7))
-    m0 = torch.randn(P.total, generator=torch.Generator().manual_seed(8))
-    want_g = sum(others) * (1.0 / world)
-    want_m = 0.9 * m0 + want_g
-    want_w = w0 - 0.1 * want_m
-    for wire, tol in (('fp32', 1e-6), ('bf16', 3e-2)):
-        P.grad.copy_(mine); P.param.copy_(w0); P.mom.copy_(m0)
-        upd = TorchSGD(P, 0.1, 0.9, 1.0 / world)
-        red = GradReducer(net, world, wire=wire, algo='rs_ag', shard_update=upd, rank=rank)
-        for st in ['caption', 'heads', 'language', 'layer3:16', 'layer3:8', 'layer3', 'layer2']:
-            red.ready(st)
-        red.finish()
-        scale = float(want_g.abs().max())
-        # round 5: the all-gathers carried the dtype SHADOW (what the kernels read); the fp32 masters of the other rank's slices are behind until
-        # gather_master() - a collective - brings them together (train_val.snapshot calls it on every rank)
-        ok = ok and red.gather_shadow and red.master_stale
-        ok = ok and torch.allclose(P.shadow.float(), want_w, atol=0.1 * tol * scale + 1e-6)
-        own = torch.zeros(P.total, dtype=torch.bool)
-        for l, h in upd.ranges:
-            own[l:h] = True
-        ok = ok and torch.allclose(P.param[own], want_w[own], atol=0.1 * tol * scale + 1e-6) and torch.equal(P.param[~own], w0[~own])
-        lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(lst, P.shadow.double().sum().reshape(1).clone())
-        ok = ok and all(torch.equal(lst[0], x) for x in lst)              # every rank holds the same shadow, bit for bit
-        red.gather_master()
-        ok = ok and not red.master_stale
-        ok = ok and torch.allclose(P.param, want_w, atol=0.1 * tol * scale + 1e-6)
-        covered = sum(h - l for l, h in upd.ranges)
-        ok = ok and covered < P.total * 0.51 + 64 * world                 # this rank updated about 1 / world of the elements (+ the bucket tails)
-        for l, h in upd.ranges:
-            ok = ok and torch.allclose(P.mom[l:h], want_m[l:h], atol=tol * scale + 1e-6)
-        lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(lst, P.param.double().sum().reshape(1).clone())
-        ok = ok and all(torch.equal(lst[0], x) for x in lst)              # every rank holds the same weights, bit for bit
+        def refresh_shadow_range(self, lo, hi):
+            self.P.shadow[lo:hi] = self.P.param[lo:hi].to(self.P.shadow.dtype)
+    from lang2seg_amd._lib import BF16
+    from lang2seg_amd.parallel import shard_plan
+    for dt in (F32, BF16):
+        # F32 compute mode: every tensor is read as fp32 master somewhere -> every all-gather carries masters.  BF16: the convolution weights are
+        # read through the shadow only -> their sub-buckets gather the shadow, everything else (encoder, captioner, biases, dynamic-filter FCs,
+        # mask head) gathers masters (in round 5 those stayed at their initial values on the ranks that do not own them)
+        net = Net(); net.P = ParamStore(opt, 50, 81, 12, 1, 'cpu', dt)
+        P = net.P
+        w0 = torch.randn(P.total, generator=torch.Generator().manual_seed(7))
+        m0 = torch.randn(P.total, generator=torch.Generator().manual_seed(8))
+        want_g = sum(others) * (1.0 / world)
+        want_m = 0.9 * m0 + want_g
+        want_w = w0 - 0.1 * want_m
+        so_mask = torch.zeros(P.total, dtype=torch.bool)
+        for lo_, hi_, so in P.shadow_only_runs():
+            so_mask[lo_:hi_] = bool(so)
+        ok = ok and (bool(so_mask.any()) == (dt == BF16))
+        for k in P.trainable:                                                # nothing but convolution weights may ever be shadow-only
+            if P.shadow_only(k):
+                ok = ok and k.endswith('.weight') and not k.startswith(('rnn_encoder.', 'dynamic_fc', 'response_fc', 'mask_', 'caption_model.core',
+                                                                           'caption_model.embed', 'caption_model.logit', 'caption_model.ctx2att'))
+        for wire, tol in (('fp32', 1e-6), ('bf16', 3e-2)):
+            P.grad.copy_(mine); P.param.copy_(w0); P.mom.copy_(m0); P.shadow.zero_()
+            upd = TorchSGD(P, 0.1, 0.9, 1.0 / world)
+            red = GradReducer(net, world, wire=wire, algo='rs_ag', shard_update=upd, rank=rank)
+            plans = []
+            lo_ = 0
+            for st in ['caption', 'heads', 'language', 'layer3:16', 'layer3:8', 'layer3', 'layer2']:
+                plans += shard_plan(P, lo_, red.bounds[st]); lo_ = red.bounds[st]
+                red.ready(st)
+            red.finish()
+            scale = float(want_g.abs().max())
+            stale = torch.zeros(P.total, dtype=torch.bool)
+            for l, h in red.stale_master_ranges():
+                stale[l:h] = True
+            ok = ok and red.gather_shadow and (red.master_stale == (dt == BF16)) and (bool(stale.any()) == (dt == BF16))
+            ok = ok and not bool((stale & ~so_mask).any())                 # a master may only be behind where NO kernel reads masters
+            if dt == BF16:
+                ok = ok and {c for _, _, c in plans} == {'shadow', 'master'} and len(plans) <= 12
+            stol = 0.1 * tol * scale + 1e-6 + (2.0 ** -8 * float(want_w.abs().max()) if dt == BF16 else 0.0)
+            ok = ok and torch.allclose(P.shadow.float(), want_w, atol=stol)   # the shadow is current everywhere, on every rank
+            ok = ok and torch.allclose(P.param[~stale], want_w[~stale], atol=0.1 * tol * scale + 1e-6) and torch.equal(P.param[stale], w0[stale])
+            lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(lst, P.shadow.double().sum().reshape(1).clone())
+            ok = ok and all(torch.equal(lst[0], x) for x in lst)              # every rank holds the same shadow, bit for bit
+            lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(lst, P.param[~so_mask].double().sum().reshape(1).clone())
+            ok = ok and all(torch.equal(lst[0], x) for x in lst)              # ... and the same masters wherever masters are read
+            red.gather_master()
+            ok = ok and not red.master_stale and not red.stale_master_ranges()
+            ok = ok and torch.allclose(P.param, want_w, atol=0.1 * tol * scale + 1e-6)
+            own = torch.zeros(P.total, dtype=torch.bool)
+            for l, h in upd.ranges:
+                own[l:h] = True
+            ok = ok and int(own.sum()) < P.total * 0.51 + 64 * world * len(plans)   # this rank updated about 1 / world of the elements (+ the sub-bucket tails)
+            for l, h in upd.ranges:
+                ok = ok and torch.allclose(P.mom[l:h], want_m[l:h], atol=tol * scale + 1e-6)
+            lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(lst, P.param.double().sum().reshape(1).clone())
+            ok = ok and all(torch.equal(lst[0], x) for x in lst)              # every rank holds the same weights, bit for bit
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -475,6 +503,77 @@ class _FakeSolverNet(object):
 
     def seed_counter(self):
         return self.ctr
+
+
+def test_from_snapshot_reads_the_reference_written_pair(tmp_path):
+    """f3 against files the REFERENCE wrote: SolverWrapper.snapshot() of train_val_cycle.py:57-104, driven by tests/golden/make_golden.py on the
+    tiny cycle network (tests/golden/ref_snapshot/: its zip structure + sidecar as written, payloads regenerated and CRC-checked record by record,
+    golden_util.materialize_ref_snapshot).  The build's from_snapshot must restore from it what the reference's own from_snapshot (:106-165)
+    restores - recorded in the manifest: every key by name + shape, the `[:, :-1]` partial rule (:121-124), numpy / python RNG streams, loader
+    cursors and permutations, the iteration."""
+    import random
+    from golden_util import materialize_ref_snapshot
+    from lang2seg_amd.model.train_val import SolverWrapper
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    sfile, nfile, man = materialize_ref_snapshot(str(tmp_path / 'snap'), drop_last_cin_of='rpn_net.weight')
+    saved = torch.load(sfile, map_location='cpu')
+    assert [e['key'] for e in man['keys']] == list(saved.keys())             # the reference's key order, names, shapes, dtypes
+    for e in man['keys']:
+        assert list(saved[e['key']].shape) == e['shape'] and str(saved[e['key']].dtype) == e['dtype'], e['key']
+
+    class Net(_FakeSolverNet):
+        def __init__(self):
+            _FakeSolverNet.__init__(self)
+            self.w = {k: torch.full(tuple(v.shape), 0.25, dtype=v.dtype) if v.dtype.is_floating_point else torch.zeros_like(v) for k, v in saved.items()}
+
+    for spath, want in ((sfile, man['restore_full']), (man['_partial'], man['restore_partial'])):
+        ld = SyntheticLoader(num_images=2, H=32, W=32, T=3, vocab_size=10)
+        net = Net()
+        sw = SolverWrapper(net, ld, str(tmp_path / 'o'), str(tmp_path / 't'))
+        np.random.seed(1); random.seed(1)
+        # (the reference's loader of this fixture has 11 train / 5 val images: from_snapshot checks the permutation against the shard it feeds)
+        ld.split_ix = {'train': list(range(11)), 'val': list(range(5))}
+        last = sw.from_snapshot(spath, nfile)
+        assert last == want['last_snapshot_iter'] == man['iter']
+        assert ld.iterators['train'] == want['iter_train'] and ld.iterators['val'] == want['iter_val']
+        assert [int(x) for x in ld.perm['train']] == want['perm_train'] and [int(x) for x in ld.perm['val']] == want['perm_val']
+        assert [float(x) for x in np.random.rand(3)] == want['next_np_rand'] and random.random() == want['next_py_random']
+        got = net.state_dict()
+        for k, v in saved.items():
+            if spath != sfile and k == 'rpn_net.weight':
+                continue
+            assert torch.equal(got[k], v), k
+        if spath != sfile:
+            w = got['rpn_net.weight']
+            assert torch.equal(w[:, :-1], saved['rpn_net.weight'][:, :-1]) and bool((w[:, -1] == want['rpn_net.weight.last_channel']).all())
+            assert abs(float(w.double().sum()) - want['rpn_net.weight.sum']) < 1e-6 * abs(want['rpn_net.weight.sum']) + 1e-9
+    assert net.ctr.item() == 0                                               # a reference-written sidecar ends at the iteration: no device RNG counter
+
+
+def test_reference_reads_the_build_written_pair():
+    """f3, the reverse direction: the pair the build's SolverWrapper.snapshot() wrote on the MI355X (structure + sidecar committed under
+    tests/golden/build_snapshot/, written by tests/test_train_step_gpu.py::test_resume_from_reference_written_snapshot) was loaded by the
+    REFERENCE's from_snapshot in the build container (tests/golden/make_golden.py read_build_snapshot; transcript
+    tests/golden/build_snapshot_readback.json): every tensor of the synthetic weight set arrives, the cursors and the iteration are the
+    build's, and the only keys the reference misses are BatchNorm's num_batches_tracked (a torch >= 0.4 buffer its own files never had)."""
+    import json, pickle
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    r = json.load(open(os.path.join(here, 'build_snapshot_readback.json')))
+    man = json.load(open(os.path.join(here, 'build_snapshot', 'manifest.json')))
+    ref_man = json.load(open(os.path.join(here, 'ref_snapshot', 'manifest.json')))
+    assert r['ok'] and not r['mismatching'] and r['last_snapshot_iter'] == man['iter'] == 9
+    assert r['printed'][0] == 'size partially match: 0'
+    lacking = int(r['printed'][1].split(':')[1])
+    assert lacking == sum(1 for e in ref_man['keys'] if e['key'].endswith('num_batches_tracked')) == r['keys_of_reference_net'] - r['keys_in_file']
+    assert (r['iter_train'], r['iter_val'], r['perm_train'], r['perm_val']) == (man['expect']['iter_train'], man['expect']['iter_val'],
+                                                                                  man['expect']['perm_train'], man['expect']['perm_val'])
+    # the build's file keeps the reference's key order / shapes / dtypes (minus those BatchNorm counters)
+    assert [(e['key'], e['shape'], e['dtype']) for e in man['keys']] == [(e['key'], e['shape'], e['dtype']) for e in ref_man['keys']
+                                                                          if not e['key'].endswith('num_batches_tracked')]
+    with open(os.path.join(here, 'build_snapshot', man['pkl']), 'rb') as f:      # the sidecar: the reference's seven fields in its order, then one more
+        st0, st1, it_tr, perm_tr, it_val, perm_val, it = [pickle.load(f) for _ in range(7)]
+        extra = pickle.load(f)
+    assert st0[0] == 'MT19937' and isinstance(st1, tuple) and it == 9 and isinstance(extra, int)
 
 
 @pytest.mark.parametrize('tag', ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg'])

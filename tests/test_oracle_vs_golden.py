@@ -97,6 +97,11 @@ def test_train_step_tiny_pooling_align():
     _run_e2e('tiny_align')
 
 
+def test_train_step_tiny_fixed_blocks_0():
+    """cfg.RESNET.FIXED_BLOCKS = 0 in the reference (RES:290-299): layer1 trains as well (conv1 / bn1 stay frozen)."""
+    _run_e2e('tiny_fb0')
+
+
 @pytest.mark.parametrize('variant', ['baseline', 'spatial', 'response', 'cycle_response', 'vgg'])
 def test_train_step_tiny_variants(variant):
     """the reference's other ResNet network variants (network.py, network_7f.py, network_7f_response.py,
@@ -148,7 +153,7 @@ def test_test_mode(tag):
     assert np.allclose(pm.numpy(), g['pm.masks'], atol=1e-5)
 
 
-TRAIN_TAGS = ['tiny', 'tiny_align', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg',
+TRAIN_TAGS = ['tiny', 'tiny_align', 'tiny_fb0', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg',
               'full', 'full_spatial', 'full_cycle_response', 'full_vgg']
 
 

@@ -18,8 +18,11 @@ def _setup(dtype, tag='tiny'):
     opt, sd, blob, ocfg, samp = setup_from_fixture(g)
     samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
     over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
-    net = selftest.build_net(opt, over, dtype, sd, variant=variant_of(g))
     from lang2seg_amd.model.config import cfg
+    for k in g:                                  # (before the network is built: FIXED_BLOCKS decides what is trainable; reset by conftest)
+        if k.startswith('resnet.'):
+            cfg.RESNET[k[7:]] = int(g[k])
+    net = selftest.build_net(opt, over, dtype, sd, variant=variant_of(g))
     for k in g:
         if k.startswith('top.'):                 # e.g. POOLING_ALIGN (reset by conftest after the test)
             cfg[k[4:]] = bool(int(g[k]))
@@ -37,7 +40,7 @@ def _setup(dtype, tag='tiny'):
 # proposals are teacher-forced).
 BF16_LOSS_RTOL, BF16_COS, BF16_NORM = 1e-2, 0.99, 0.25
 BF16_NORM_DYN_FULL = 0.10      # dynamic-filter FCs at the BASELINE size (measured <= 0.03)
-VARIANT_TAGS = ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align']
+VARIANT_TAGS = ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align', 'tiny_fb0']
 
 
 def _grad_of(net, nme):
@@ -87,6 +90,8 @@ def _check_grads(g, net, dtype, rtol_f32, ref_net=None, norm_tol=None):
             # except dynamic_fc_5 of the tiny cycle fixture - 0.89 of the f32 norm before, 0.76 / cosine 0.985 after: the same handful of pixels, re-rolled.
             # Tiny fixtures only: cosine 0.97 for these tensors; the BASELINE-size gates are unchanged.)
             ctol = 0.97 if (dyn and norm_tol is None) else BF16_COS
+            if k.startswith('resnet.layer1.') and norm_tol is None:
+                ctol = 0.98      # FIXED_BLOCKS = 0 only: the deepest gradients of the step, through 33 blocks of bf16 activations (measured 0.987 on layer1.0.conv1)
             if not (cos >= ctol and abs(nb / na - 1.0) <= ntol):
                 bad.append((k, cos, nb / na))
     _log_grad_table(g, dtype, table)
@@ -105,6 +110,30 @@ def _log_grad_table(g, dtype, table):
                                 ('cos_maxerr_l2err_vs_reference_sample' if dtype == 'f32' else 'cos_normratio_vs_f32_device'): table}) + '\n')
     except OSError:
         pass
+
+
+def _proposal_agreement(tag, dtype, mine, ref):
+    """how well the device's own proposal list (bf16: scores from bf16 activations reorder near-ties at the 12 000 cut and inside the greedy
+    scan) describes the same boxes as the reference's: IoU-matched recall of the reference's boxes at IoU >= 0.9 / 0.7 (+1 areas, as
+    utils/bbox.py:21-29) and the share of device boxes within 4 px of a reference box.  Logged per fixture (gpurun_out/proposal_agreement.jsonl)."""
+    import json, os
+    a, b = mine[:, 1:5].astype(np.float64), ref[:, 1:5].astype(np.float64)
+    iw = np.clip(np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]) + 1, 0, None)
+    ih = np.clip(np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]) + 1, 0, None)
+    aa = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1); ab = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    iou = iw * ih / (aa[:, None] + ab[None, :] - iw * ih)
+    best_for_ref = iou.max(0)
+    D = np.abs(a[:, None] - b[None, :]).max(-1)
+    out = dict(tag=tag, dtype=dtype, n_device=int(a.shape[0]), n_reference=int(b.shape[0]), recall_iou90=float((best_for_ref >= 0.9).mean()),
+               recall_iou70=float((best_for_ref >= 0.7).mean()), precision_iou90=float((iou.max(1) >= 0.9).mean()), within_4px=float((D.min(1) < 4.0).mean()))
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'proposal_agreement.jsonl'), 'a') as f:
+            f.write(json.dumps(out) + '\n')
+    except OSError:
+        pass
+    return out
 
 
 def _f32_reference_step(tag):
@@ -142,8 +171,8 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
         assert D.min(1).max() < 2e-2 and D.min(0).max() < 2e-2, (D.min(1).max(), D.min(0).max())
     else:
         # bf16 scores reorder near-ties, so a few keeps differ; the lists must still describe the same boxes
-        D = np.abs(mine[:, None, 1:] - ref[None, :, 1:]).max(-1)
-        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and (D.min(1) < 4.0).mean() > 0.8, (n, ref.shape, float((D.min(1) < 4.0).mean()))
+        pa = _proposal_agreement(tag, dtype, mine, ref)
+        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and pa['within_4px'] > 0.8, pa
     # integer outputs: bit-exact (proposals teacher-forced)
     assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
     assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
@@ -268,7 +297,8 @@ def test_train_step_full_size(tag, dtype):
     else:
         # (bf16 scores reorder near-ties: measured 0.78 ... 0.9 of the device's boxes within 4 px of a reference box over the four fixtures)
         # and 0.61 on the VGG trunk, whose un-normalised 3x3 stack lets bf16 activations drift furthest; everything downstream is teacher-forced)
-        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and (D.min(1) < 4.0).mean() > (0.8 if tag == 'full' else 0.5), (n, ref.shape[0], float((D.min(1) < 4.0).mean()))
+        pa = _proposal_agreement(tag, dtype, mine, ref)
+        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and pa['within_4px'] > (0.5 if tag == 'full_vgg' else 0.8), pa
     assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
     assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
     nfg = int(t['counts'][0].item())
@@ -607,6 +637,96 @@ def test_train_net_snapshot_and_resume(tmp_path):
     finally:
         for k, v in saved.items():
             cfg.TRAIN[k] = v
+
+
+def test_resume_from_reference_written_snapshot(tmp_path):
+    """f3 pinned against files the REFERENCE wrote: the snapshot pair of train_val_cycle.py:57-104 (tests/golden/ref_snapshot/,
+    produced by the reference's own SolverWrapper.snapshot() in tests/golden/make_golden.py; payload records regenerated and CRC-checked) is
+    restored by the build's from_snapshot into a freshly initialised network on the device - every tensor equal to what the reference saved,
+    cursors / RNG streams / iteration as the reference's from_snapshot restores them - and the step that follows matches the reference's own
+    step from those weights (the `tiny` fixture: same synthetic weights, same image) at the f32 tolerance.  Then the reverse direction's
+    input: the pair the BUILD writes keeps the reference's key order, shapes and dtypes; its structure goes to gpurun_out/build_snapshot/ for
+    tests/golden/make_golden.py `read_build_snapshot`, which has the reference's from_snapshot load it."""
+    import json, os, pickle, random, zipfile, zlib
+    from golden_util import materialize_ref_snapshot
+    from lang2seg_amd import selftest
+    from lang2seg_amd.model.train_val import SolverWrapper
+    from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
+    from lang2seg_amd.nets.variants import loss_names, SLOT
+    sfile, nfile, man = materialize_ref_snapshot(str(tmp_path / 'snap'))
+    g = load('tiny')
+    opt, sd, blob, ocfg, samp = setup_from_fixture(g)
+    samp['forced_proposals'] = (g['int.proposal_rois'], g['int.proposal_scores'])
+    over = {k[4:]: int(g[k]) for k in g if k.startswith('cfg.')}
+    net = selftest.build_net(opt, over, 'f32', None)                        # its own initialisers: everything must come from the snapshot
+    ld = SyntheticLoader(num_images=3, sents_per_image=2, H=160, W=224, T=6, vocab_size=60)
+    ld.split_ix = {'train': list(range(11)), 'val': list(range(5))}         # (the reference-side stub loader of the fixture: 11 / 5 images)
+    sw = SolverWrapper(net, ld, str(tmp_path / 'out'), str(tmp_path / 'tb'))
+    sw.construct_graph()
+    before = net.state_dict()
+    assert any(float((before[k].float() - torch.from_numpy(sd[k])).abs().max()) > 0 for k in ('rpn_net.weight', 'resnet.layer3.5.conv2.weight'))
+    np.random.seed(1); random.seed(1)
+    last = sw.from_snapshot(sfile, nfile)
+    want = man['restore_full']
+    assert last == want['last_snapshot_iter'] and ld.iterators['train'] == want['iter_train'] and ld.iterators['val'] == want['iter_val']
+    assert [int(x) for x in ld.perm['train']] == want['perm_train'] and [int(x) for x in ld.perm['val']] == want['perm_val']
+    assert [float(x) for x in np.random.rand(3)] == want['next_np_rand'] and random.random() == want['next_py_random']
+    saved = torch.load(sfile, map_location='cpu')
+    got = net.state_dict()
+    for k, v in saved.items():
+        if k.endswith('num_batches_tracked'):
+            continue                                                        # BatchNorm bookkeeping the frozen-BN network has no use for
+        assert k in got and torch.equal(got[k], v), k
+    # ---- the pair the build writes (before the step: its payloads are then the restored weights, which the container-side read-back can
+    # regenerate): the reference's format - key order, shapes, dtypes; sidecar fields in its order ----
+    np.random.seed(4321); np.random.rand(2); random.seed(55)
+    ld.iterators['train'], ld.iterators['val'] = 3, 1
+    bs, bn = sw.snapshot(9)
+    ck = torch.load(bs, map_location='cpu')
+    ref_keys = [e['key'] for e in man['keys'] if not e['key'].endswith('num_batches_tracked')]
+    assert list(ck.keys()) == ref_keys
+    for e in man['keys']:
+        if e['key'] in ck:
+            assert list(ck[e['key']].shape) == e['shape'] and str(ck[e['key']].dtype) == e['dtype'], e['key']
+    with open(bn, 'rb') as f:
+        st0, st1, it_tr, perm_tr, it_val, perm_val, it9 = [pickle.load(f) for _ in range(7)]
+    assert st0[0] == 'MT19937' and it_tr == 3 and it_val == 1 and it9 == 9 and len(perm_tr) == 11 and len(perm_val) == 5
+    try:                                                                    # structure + payload CRCs for the container-side reference read-back
+        outd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'build_snapshot')
+        os.makedirs(outd, exist_ok=True)
+        recs = []
+        with zipfile.ZipFile(bs) as z:
+            for i in z.infolist():
+                recs.append(dict(name=i.filename, size=i.file_size, crc32=i.CRC))
+                if '/data/' not in i.filename:
+                    with open(os.path.join(outd, 'pth.' + i.filename.split('/', 1)[1].replace('/', '.')), 'wb') as f:
+                        f.write(z.read(i.filename))
+        keys = []
+        for i, (k, t) in enumerate(ck.items()):
+            raw = t.contiguous().numpy().tobytes()
+            keys.append(dict(key=k, shape=list(t.shape), dtype=str(t.dtype), size=len(raw), crc32=zlib.crc32(raw) & 0xFFFFFFFF,
+                             sum=float(t.double().sum()), abssum=float(t.double().abs().sum())))
+        with open(bn, 'rb') as f, open(os.path.join(outd, os.path.basename(bn)), 'wb') as o:
+            o.write(f.read())
+        json.dump(dict(pth=os.path.basename(bs), pkl=os.path.basename(bn), iter=9, records=recs, keys=keys, torch=torch.__version__,
+                       expect=dict(iter_train=3, iter_val=1, perm_train=[int(x) for x in perm_tr], perm_val=[int(x) for x in perm_val]),
+                       written_by='lang2seg_amd/model/train_val.py SolverWrapper.snapshot on the MI355X, right after restoring the reference-written snapshot'),
+                  open(os.path.join(outd, 'manifest.json'), 'w'), indent=1)
+    except OSError:
+        pass
+    # the step after the restore = the reference's step from these weights
+    net.parity = selftest.parity_from_samp(samp)
+    loss = net.forward_backward(net.upload_blob(blob, 0))
+    torch.cuda.synchronize()
+    lv = loss.cpu().numpy()
+    for k in loss_names('cycle'):
+        assert abs(lv[SLOT[k]] - float(g['loss.' + k])) < 1e-4 * max(1.0, abs(float(g['loss.' + k]))), (k, lv[SLOT[k]], g['loss.' + k])
+    names = _check_grads(g, net, 'f32', 5e-4)
+    sw.optimizer.step()
+    torch.cuda.synchronize()
+    sd1 = net.state_dict()
+    for nme in names:
+        check_digest(g, 'w1.' + nme, sd1[nme].numpy(), rtol=1e-5, atol=1e-7)
 
 
 def _edge_blob(kind):
@@ -993,6 +1113,110 @@ def test_no_gradient_lands_behind_its_bucket(variant):
         if rel(b, 2.0 * a) > 2e-3:                      # (fp32 summation-order noise only; a late gradient shows as a factor 1 or 1.5)
             bad.append((k, rel(b, 2.0 * a)))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('variant,rank', [('cycle', 0), ('cycle', 1), ('vgg', 1), ('baseline', 0)])
+def test_sharded_update_stale_masters_are_never_read(variant, rank):
+    """with the dtype shadow on the wire of the sharded data-parallel update, the fp32 masters of the OTHER ranks' slices are
+    never updated on this rank - and the encoder, the captioner, every bias, the dynamic-filter FCs and the mask head read masters.  Two ranks in
+    ONE process: net A runs as rank `rank` of a world of 2 whose other rank sees the same image (the collectives are stand-ins: a sum of two
+    equal gradients, and all-gathers that deliver what the other rank would send - taken from net R, the same network stepping alone), and
+    every master the reducer reports as behind (GradReducer.stale_master_ranges) is POISONED with NaN as soon as its shadow arrives.  The next
+    steps must not see the poison, must train exactly like R, and gather_master() must bring every master back."""
+    import types
+    from lang2seg_amd import selftest, parallel
+    from lang2seg_amd.optim import SGD
+    from lang2seg_amd.parallel import GradReducer
+    from oracle import weights as OW, synth as OS
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    if variant == 'vgg':
+        opt['C4_feat_dim'] = 512
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant=variant)
+    over = dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300, RPN_BATCHSIZE=64)
+    blob = OS.make_blob(320, 416, 6, 60, seed=5)
+    W, LR = 2, 2e-3
+    R = selftest.build_net(opt, over, 'bf16', sd, variant=variant)
+    A = selftest.build_net(opt, over, 'bf16', sd, variant=variant)
+    for n_ in (R, A):
+        n_.use_tape = False
+    gathered = {'shadow': 0, 'param': 0}
+
+    def locate(t):
+        for name in ('shadow', 'param'):
+            buf = getattr(A.P, name)
+            off = (t.data_ptr() - buf.data_ptr()) // buf.element_size()
+            if t.dtype == buf.dtype and 0 <= off < buf.numel() and (t.data_ptr() - buf.data_ptr()) % buf.element_size() == 0:
+                return name, int(off)
+        raise AssertionError('all-gather into a buffer that is neither the shadow nor the masters')
+
+    class FakeDist(object):
+        ReduceOp = types.SimpleNamespace(SUM=0)
+
+        @staticmethod
+        def reduce_scatter_tensor(out, inp, op=None):
+            per = out.numel()
+            out.copy_(inp[rank * per:(rank + 1) * per]); out.mul_(W)          # the other rank contributes the same gradients
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            t.mul_(W)
+
+        @staticmethod
+        def all_gather_into_tensor(out, inp):
+            name, off = locate(out)
+            per = inp.numel()
+            truth = getattr(R.P, name)
+            for j in range(W):
+                if j == rank:
+                    if out[j * per:(j + 1) * per].data_ptr() != inp.data_ptr():
+                        out[j * per:(j + 1) * per].copy_(inp)
+                    continue
+                out[j * per:(j + 1) * per].copy_(truth[off + j * per:off + (j + 1) * per])     # what rank j updated and sent
+                if name == 'shadow' and poison[0]:
+                    A.P.param[off + j * per:off + (j + 1) * per].fill_(float('nan'))           # its master never arrives here
+            gathered[name] += out.numel()
+    poison = [True]
+    saved = parallel.dist
+    parallel.dist = FakeDist
+    try:
+        A.dp = GradReducer(A, W, wire='fp32', algo='rs_ag', shard_update=True, rank=rank)
+        sgd_r = SGD(R, LR)
+        sgd_a = SGD(A, LR, grad_scale=1.0 / W)
+        assert A.dp.shard_update is sgd_a and A.dp.gather_shadow
+        lr_, la_ = [], []
+        for step in range(3):
+            lr_.append(R.train_step(dict(blob), 0, sgd_r)); torch.cuda.synchronize()
+            la_.append(A.train_step(dict(blob), 0, sgd_a)); torch.cuda.synchronize()
+        assert gathered['shadow'] > 0 and gathered['param'] > 0, gathered
+        assert np.isfinite(np.array(la_)).all(), la_                       # no kernel read a poisoned master
+        assert abs(lr_[2][-1] - lr_[0][-1]) > 1e-3 * abs(lr_[0][-1])       # (the steps really trained)
+        for a_, r_ in zip(la_, lr_):
+            assert np.allclose(a_, r_, rtol=2e-3, atol=2e-4), (la_, lr_)   # same losses as the network that stepped alone
+        # what the reducer says is behind is exactly what was poisoned, and only where no kernel reads masters
+        stale = torch.zeros(A.P.total, dtype=torch.bool, device=A.P.param.device)
+        for l, h in A.dp.stale_master_ranges():
+            stale[l:h] = True
+        nan = torch.isnan(A.P.param)
+        assert bool(nan.any()) and not bool((nan & ~stale).any())
+        so = torch.zeros(A.P.total, dtype=torch.bool, device=stale.device)
+        for l, h, f in A.P.shadow_only_runs():
+            so[l:h] = bool(f)
+        assert not bool((stale & ~so).any())
+        with pytest.raises(RuntimeError, match='gather_master'):
+            A.state_dict()
+        with pytest.raises(RuntimeError, match='gather_master'):
+            next(iter(A.named_parameters()))
+        # the shadow (what the convolutions read) and every master that is read agree with the lone network's
+        assert rel(A.P.shadow.float(), R.P.shadow.float()) < 2e-3
+        assert rel(A.P.param[~so], R.P.param[~so]) < 1e-4
+        poison[0] = False
+        A.dp.gather_master()
+        assert not A.dp.master_stale and not bool(torch.isnan(A.P.param).any())
+        assert rel(A.P.param, R.P.param) < 1e-4
+        a_sd, r_sd = A.state_dict(), R.state_dict()
+        assert all(rel(a_sd[k].float(), r_sd[k].float()) < 1e-3 for k in r_sd if float(r_sd[k].abs().max()) > 0)
+    finally:
+        parallel.dist = saved
 
 
 @pytest.mark.parametrize('variant', ['cycle', 'vgg'])
