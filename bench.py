@@ -630,6 +630,34 @@ def main(argv=None, hooks=None):
             net.train_step_async(blobs[i % 4], 0, optim)
         barrier()
         lt.on = False
+    # ---- the exact-f32 verification mode beside the bf16 headline: the mode in which losses / seg-logits match the reference
+    # to 1e-4 and the proposal lists to the box (tests/test_train_step_gpu.py f32 legs); its own network, same inputs, pipelined like the headline
+    if args.extras and world == 1 and args.dtype == 'bf16' and not experiment:
+        try:
+            cfg.COMPUTE_DTYPE = 'f32'
+            if variant == 'vgg':
+                net32 = vgg16(opt, batch_size=1)
+            else:
+                net32 = resnetv1(opt, batch_size=1, num_layers=101, variant=variant)
+            net32.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+            net32.train(); net32.use_tape = True; net32.use_graph = False
+            op32 = make_optimizer(net32, None, 1)
+            n32 = max(3, min(args.steps, 10))
+            for i in range(3):
+                l32 = net32.train_step_async(blobs[i % 4], 0, op32)
+            barrier()
+            t0 = time.time()
+            for i in range(n32):
+                l32 = net32.train_step_async(blobs[i % 4], 0, op32)
+            barrier()
+            d32 = time.time() - t0
+            if np.isfinite(l32.cpu().numpy()[:7]).all():
+                extras['f32_train_step'] = {'ms_per_step': d32 / n32 * 1e3, 'value': n32 / d32, 'unit': 'img/s', 'steps': n32,
+                                            'note': 'the same pipelined step in the exact-f32 verification mode (f32 activations / weights, f32-exact MFMA): the mode '
+                                                    'the 1e-4 parity claim is tested in; not the headline'}
+            del net32, op32
+        finally:
+            cfg.COMPUTE_DTYPE = args.dtype
     # a run whose network went non-finite measured nothing (NaN activations are silently zeroed by the next ReLU)
     if not (np.isfinite(lv[:7]).all() and bool(torch.isfinite(net.P.param).all())):
         raise RuntimeError('non-finite losses or parameters after the run: %s' % lv[:7])
@@ -652,6 +680,8 @@ def main(argv=None, hooks=None):
         out.update(extras)
         if 'sync_train_step' in extras:
             out['sync_train_step_value'] = extras['sync_train_step']['value']      # Network.train_step as the reference calls it (seven floats read back per step)
+        if 'f32_train_step' in extras:
+            out['f32_train_step_value'] = extras['f32_train_step']['value']        # exact-f32 verification mode (parity 1e-4), beside the bf16 headline
         if 'dropin_train_step' in extras:
             out['dropin_train_step_value'] = extras['dropin_train_step']['value']  # ... with the image uploaded before every step as well: the reference's unit as it stands
         if hooks.lib or hooks.note:

@@ -196,7 +196,8 @@ int l2s_sort_topk(const float* scores, const float* boxes, int n, int k, int* ws
  * stage's mask is that of its own boxes and what earlier stages kept enters as one OR word per 64 boxes - plus those words: 2 MB at
  * n = 12000, where the reference's mask is 18 MB).  max_keep >= 1.  keep_out[max_keep] int32 (indices into the sorted list),
  * num_out[1] int32 — both DEVICE memory (the 18 MB D2H + host loop of nms_cuda.c:47-58 is gone); the stages after the first return
- * at once when keep_out is already full. */
+ * at once when keep_out is already full.  num_out[0] = -1: a wave of the scan gave up a bounded wait (not reachable while the scan's
+ * workgroup runs as a whole); the remaining stages return at once and l2s_gather_rois emits an empty list. */
 size_t l2s_nms_workspace_bytes(int n);
 int l2s_nms(const float* sorted_boxes, int n, float thresh, int cmp_mode, int max_keep, uint64_t* mask_ws,
             int* keep_out, int* num_out, hipStream_t s);
@@ -260,6 +261,7 @@ int l2s_roialign_bwd(const void* dout, int H, int W, int C, const float* rois, i
  * grid computed from the RoI in image pixels over the image size (im_info) instead of roi/16 over the map size */
 int l2s_cropalign_fwd(const void* feat, int H, int W, int C, const float* rois, int R, int P, float im_h, float im_w,
                       void* out, int dtype, hipStream_t s);
+/* d(feat) is WRITTEN, like l2s_roialign_bwd's: a caller that accumulates into an existing gradient adds the result itself */
 int l2s_cropalign_bwd(const void* dout, int H, int W, int C, const float* rois, int R, int P, float im_h, float im_w,
                       float* dfeat, int dtype, hipStream_t s);
 
@@ -514,6 +516,12 @@ typedef struct { long offset; long count; int row_len; int weight_decay; long ro
 int l2s_sgd_momentum_range(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
                            float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int flags,
                            long lo, long hi, int chunk_lo, int chunk_hi, hipStream_t s);
+/* the ranged update with the gradients read from a bf16 buffer instead: element o of the flat buffer takes grad_bf16[o - grad_lo] (grad_lo a
+ * multiple of 4, grad_bf16 8-byte aligned, every updated element at or behind grad_lo).  Data parallel: the reduce-scattered bf16 shard of a
+ * bucket feeds the update as it is - no cast pass back into the f32 gradient buffer, which this call neither reads nor clears. */
+int l2s_sgd_momentum_range_g16(float* param, const void* grad_bf16, long grad_lo, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+                               float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype,
+                               long lo, long hi, int chunk_lo, int chunk_hi, hipStream_t s);
 int l2s_sgd_chunk(void);          /* elements of one work chunk of the update kernel */
 int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
                      float lr, float momentum, float wd, float grad_scale, void* shadow /*optional: dtype copy of rowscale*param at the same offsets*/,

@@ -178,6 +178,7 @@ SIGS = {
     'l2s_sgd_momentum': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, i32, vp]),
     'l2s_wgrad_grouped_ws_bytes': (sz, [i32]),
     'l2s_sgd_momentum_range': (i32, [vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, i32, i64, i64, i32, i32, vp]),
+    'l2s_sgd_momentum_range_g16': (i32, [vp, vp, i64, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, i64, i64, i32, i32, vp]),
     'l2s_sgd_chunk': (i32, []),
     'l2s_mul_f32': (i32, [vp, vp, vp, i64, vp]),
     'l2s_add_f32': (i32, [vp, vp, vp, i64, vp]),

@@ -558,7 +558,7 @@ __device__ __forceinline__ void sgd_elem(float g, float& w, float& m, float rs, 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ mom,
                                                   const l2s_sgd_seg* __restrict__ segs, int nseg, const float* __restrict__ rowscale,
                                                   float lr, float momentum, float wd, float gscale, void* shadow, int sdt, int flags,
-                                                  long lo, long hi, int chunk_lo, int chunk_hi) {
+                                                  long lo, long hi, int chunk_lo, int chunk_hi, const bf16_t* __restrict__ g16, long g16_lo) {
   const bool clear = flags & 1, shadow_only = flags & 2;
   const int c0 = segs[0].chunk0;
   int total = segs[nseg - 1].chunk0 - c0 + (int)((segs[nseg - 1].count + SGD_CHUNK - 1) / SGD_CHUNK);
@@ -585,7 +585,13 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
       const int v = threadIdx.x + j * 256;
       if (v < nv) {
         w4[j] = *(const float4*)(param + o0 + 4 * v);
-        if (!shadow_only) { g4[j] = *(const float4*)(grad + o0 + 4 * v); m4[j] = *(const float4*)(mom + o0 + 4 * v); }
+        if (!shadow_only) {
+          if (g16) {                                   // the reduce-scattered bf16 shard itself (data parallel): no cast pass back into the f32 gradient buffer
+            const uint2 pk = *(const uint2*)(g16 + (o0 + 4 * v - g16_lo));
+            g4[j] = make_float4(bf2f((bf16_t)(pk.x & 0xffffu)), bf2f((bf16_t)(pk.x >> 16)), bf2f((bf16_t)(pk.y & 0xffffu)), bf2f((bf16_t)(pk.y >> 16)));
+          } else g4[j] = *(const float4*)(grad + o0 + 4 * v);
+          m4[j] = *(const float4*)(mom + o0 + 4 * v);
+        }
       }
     }
 #pragma unroll
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
         for (int e = 0; e < 4; ++e) sgd_elem(gg[e], ww[e], mm[e], rs, gscale, lwd, momentum, llr);
         *(float4*)(mom + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
         *(float4*)(param + o) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-        if (clr) *(float4*)(grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (clr && !g16) *(float4*)(grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if (shadow) {
         if (sdt) {
@@ -617,9 +623,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ param, flo
       float w = param[o];
       if (!shadow_only) {
         float m = mom[o];
-        sgd_elem(grad[o], w, m, rs, gscale, lwd, momentum, llr);
+        sgd_elem(g16 ? bf2f(g16[o - g16_lo]) : grad[o], w, m, rs, gscale, lwd, momentum, llr);
         mom[o] = m; param[o] = w;
-        if (clr) grad[o] = 0.f;
+        if (clr && !g16) grad[o] = 0.f;
       }
       if (shadow) stx(shadow, o, sdt, w * rs);
     }
@@ -770,7 +776,7 @@ extern "C" int l2s_sgd_momentum(float* param, float* grad, float* mom, const l2s
                                 float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype, int clear_grad, hipStream_t s) {
   if (nseg <= 0) return L2S_OK;
   L2S_LAUNCH(sgd_kernel, dim3(l2s_knobs::sgd_blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype,
-             clear_grad, 0L, (long)1 << 62, 0, -1);
+             clear_grad, 0L, (long)1 << 62, 0, -1, (const bf16_t*)nullptr, 0L);
   return l2s_check_launch();
 }
 extern "C" int l2s_sgd_momentum_range(float* param, float* grad, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
@@ -781,7 +787,19 @@ extern "C" int l2s_sgd_momentum_range(float* param, float* grad, float* mom, con
   int blocks = l2s_knobs::sgd_blocks;
   if (chunk_hi >= 0 && chunk_hi - chunk_lo < blocks) blocks = chunk_hi - chunk_lo;
   L2S_LAUNCH(sgd_kernel, dim3(blocks), dim3(256), 0, s, param, grad, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype, flags,
-             lo, hi, chunk_lo, chunk_hi);
+             lo, hi, chunk_lo, chunk_hi, (const bf16_t*)nullptr, 0L);
+  return l2s_check_launch();
+}
+extern "C" int l2s_sgd_momentum_range_g16(float* param, const void* grad_bf16, long grad_lo, float* mom, const l2s_sgd_seg* segs, int nseg, const float* rowscale,
+                                          float lr, float momentum, float wd, float grad_scale, void* shadow, int shadow_dtype,
+                                          long lo, long hi, int chunk_lo, int chunk_hi, hipStream_t s) {
+  if (nseg <= 0 || hi <= lo) return L2S_OK;
+  if (chunk_hi >= 0 && chunk_hi <= chunk_lo) return L2S_OK;
+  if (!grad_bf16 || lo < grad_lo || ((grad_lo & 3) != 0) || ((uintptr_t)grad_bf16 & 7)) return L2S_EINVAL;
+  int blocks = l2s_knobs::sgd_blocks;
+  if (chunk_hi >= 0 && chunk_hi - chunk_lo < blocks) blocks = chunk_hi - chunk_lo;
+  L2S_LAUNCH(sgd_kernel, dim3(blocks), dim3(256), 0, s, param, (float*)nullptr, mom, segs, nseg, rowscale, lr, momentum, wd, grad_scale, shadow, shadow_dtype, 0,
+             lo, hi, chunk_lo, chunk_hi, (const bf16_t*)grad_bf16, grad_lo);
   return l2s_check_launch();
 }
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cbk = blockIdx.x * 4 + wv;
   int nk = 0;
-  if (row0 > 0) { nk = *nk_p; if (nk >= max_keep) return; }
+  if (row0 > 0) { nk = *nk_p; if (nk < 0 || nk >= max_keep) return; }
   else if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < carry_words; i += 256) carry_all[i] = 0ull;
   const bool diag = (int)blockIdx.y < sbw;
   const int rb = blockIdx.y;
@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
 //   waves 1 .. 15, wave w owns blocks w - 1, w + 14, ...: loads the block's column-form words (whatever the chain decides), ANDs word c with
 //           keep word c as soon as kdone > c, stores the OR, the raw words of the newest LAG blocks and the diagonal word into the block's LDS
 //           slot, and sets ready[b].
-// A wave that has waited 2^22 polls aborts the launch (it cannot happen while the other waves of the workgroup run).
+// A wave that has waited 2^22 polls gives up (it cannot happen while the other waves of the workgroup run): it writes the error sentinel
+// *num_out = -1 and ends; the waves that wait for it time out the same way, the later stages return at once on the sentinel, and the
+// consumers of the count (gather_rois, the samplers) treat it as an empty list - the context survives, the caller sees num_out < 0.
 __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask, int n, int cb, int max_keep, int* keep, int* num_out,
                                                           int row0, const unsigned long long* __restrict__ carry) {
   constexpr int LAG = NMS_LAG, SLOT = NMS_SLOT, NBULK = 15;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
   unsigned long long* csh = ksh + cb;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: everything a wave branches on is uniform)
   int nk0 = 0;
-  if (row0 > 0) { nk0 = *num_out; if (nk0 >= max_keep) return; }
+  if (row0 > 0) { nk0 = *num_out; if (nk0 < 0 || nk0 >= max_keep) return; }
   for (int c = tid; c < cb; c += 1024) { ksh[c] = 0ull; csh[c] = carry ? carry[c] : 0ull; ready_sh[c] = 0; }
   if (tid == 0) { kdone_sh = 0; stop_sh = 0; }
   __syncthreads();
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
     int spins = 0;
     while (lds_ld(p) < want) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 22)) __builtin_trap();
+      if (++spins > (1 << 22)) { *(volatile int*)num_out = -1; __builtin_amdgcn_endpgm(); }   // give up: the count becomes the error sentinel, this wave ends
     }
   };
   if (wave == 0) {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
           int spins = 0;
           while (have < hi) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) __builtin_trap();
+            if (++spins > (1 << 22)) { *(volatile int*)num_out = -1; __builtin_amdgcn_endpgm(); }   // give up: the count becomes the error sentinel, this wave ends
             have = __builtin_amdgcn_readfirstlane(lds_ld(&kdone_sh));
           }
           t_k += NMS_T() - tk;

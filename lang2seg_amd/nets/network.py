@@ -542,6 +542,8 @@ class Network(object):
         if self.dp is None:
             self._early_op.partial(stage)                        # single process: the optimiser updates the finished prefix early
             return
+        if hasattr(self.dp, 'skips') and self.dp.skips(stage):   # this hand-off is not taken: the gradients ride with the next bucket, the tape is not cut
+            return
         rec = getattr(self, '_tape_stages', None) is not None
         if rec:
             O.tape_mark(); self._tape_stages.append(stage)

@@ -621,6 +621,12 @@ def sgd_momentum_range(param, grad, mom, segs_dev, nseg, rowscale, lr, momentum,
          float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, int(flags), int(lo), int(hi), int(chunk_lo), int(chunk_hi), stream())
 
 
+def sgd_momentum_range_g16(param, grad_bf16, grad_lo, mom, segs_dev, nseg, rowscale, lr, momentum, wd, gscale, shadow, lo, hi, chunk_lo, chunk_hi):
+    """the ranged update with the gradients of [lo, hi) read from `grad_bf16[o - grad_lo]` (a reduce-scattered bf16 shard)"""
+    call('l2s_sgd_momentum_range_g16', ptr(param), ptr(grad_bf16), int(grad_lo), ptr(mom), ptr(segs_dev), nseg, ptr(rowscale), float(lr), float(momentum),
+         float(wd), float(gscale), ptr(shadow), dt_of(shadow) if shadow is not None else 0, int(lo), int(hi), int(chunk_lo), int(chunk_hi), stream())
+
+
 def sgd_chunk():
     return int(_lib.load().l2s_sgd_chunk())
 

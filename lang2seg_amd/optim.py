@@ -223,7 +223,7 @@ class SGD(object):
         self.net.refresh_weights()
 
     # ---- data parallel, sharded update (parallel.GradReducer(shard_update=...)): a rank updates only ITS slice of a reduce-scattered bucket ----
-    def update_range(self, lo, hi, full=False, shadow=False):
+    def update_range(self, lo, hi, full=False, shadow=False, grad_bf16=None):
         """the update on the elements [lo, hi) of the flat buffer, on the current stream (gradients there are final and summed over ranks).
         full: also rewrite the dtype shadow and clear the gradients consumed (a whole bucket updated on this rank: GradReducer.bucket_update);
         otherwise weights and momentum only (a rank's slice: the shadow follows the all-gather, the clear the next step's memset)."""
@@ -237,6 +237,12 @@ class SGD(object):
             stale = P.stale_marked(s0, s1, getattr(self.net, '_fresh', ()))
             if stale:
                 P.mark_overwritten(P._ow_key - frozenset(stale))
+        if grad_bf16 is not None:
+            # the slice's summed gradients are the reduce-scattered bf16 shard itself (element o = grad_bf16[o - lo]): no cast back into P.grad
+            assert not full
+            O.sgd_momentum_range_g16(P.param, grad_bf16, lo, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay, self.grad_scale,
+                                     P.shadow if shadow else None, lo, hi, c_lo, c_hi)
+            return
         # shadow (a rank's slice whose dtype shadow goes on the wire instead of its weights, GradReducer.gather_shadow): written with the update
         O.sgd_momentum_range(P.param, P.grad, P.mom, P.segs_dev, P.nseg, P.rowscale, self.lr, self.momentum, self.weight_decay, self.grad_scale,
                              P.shadow if (full or shadow) else None, int(bool(full and self.clear_grad)), lo, hi, c_lo, c_hi)

@@ -89,6 +89,10 @@ class GradReducer(object):
     `timing=True` records HIP events around every bucket and around the wait in finish(); `report()` returns per-bucket durations and
     the exposed wait (what the main stream actually stalled for) of the last step."""
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
+    # hand-offs that are NOT taken (Network.dp_ready): their gradients ride with the next stage's bucket - fewer, larger collectives and fewer
+    # cuts of the launch tape.  A comma list or a tuple; '' = every hand-off (seven buckets per step).
+    SKIP_STAGES = ()
+    shard_g16 = True             # bf16 wire: the sharded update reads the reduce-scattered bf16 shard directly (False: cast back to f32 first)
 
     def __init__(self, net, world, backend_stream=True, skip_allreduce=0, wire='fp32', algo='allreduce', timing=False, shard_update=None, rank=None,
                  bucket_update=None):
@@ -120,7 +124,7 @@ class GradReducer(object):
         # it, model/train_val.py before a snapshot, Network.state_dict through it) brings them together again.
         self.gather_shadow = shard_update is not None and getattr(net.P, 'shadow', None) is not None
         self._parts = {}             # sub-bucket lo -> (m, per): the partition of every sharded sub-bucket
-        self._plans = {}             # bucket lo -> shard_plan(...)
+        self._plans = {}             # bucket (lo, hi) -> shard_plan(...)
         self._stale = []             # (lo, m, per) of the sub-buckets whose all-gather carried the shadow since the last gather_master()
         self.master_stale = False    # other ranks' slices of P.param are behind (until gather_master())
         self.rank = rank if rank is not None else (dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0)
@@ -186,15 +190,20 @@ class GradReducer(object):
             sh = self._shard[:per]
             dist.reduce_scatter_tensor(sh, src, op=dist.ReduceOp.SUM)
             own = seg[r * per:(r + 1) * per]
-            self._cast(sh, own) if self.wire == 'bf16' else own.copy_(sh)
+            # bf16 wire on the device: the update reads the reduce-scattered shard as it is (l2s_sgd_momentum_range_g16) - no cast back into
+            # the f32 gradient buffer, whose slice keeps this rank's local gradients until the next step overwrites them
+            g16 = sh if (self.wire == 'bf16' and self.on_gpu and self.shard_g16) else None
+            if g16 is None:
+                self._cast(sh, own) if self.wire == 'bf16' else own.copy_(sh)
+            kw = dict(grad_bf16=g16) if g16 is not None else {}
             self._parts[lo] = (m, per)
             if self.gather_shadow and on_wire == 'shadow':
-                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per, shadow=True)
+                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per, shadow=True, **kw)
                 wsl = P.shadow[lo:lo + m]
                 self.master_stale = W > 1
                 self._stale.append((lo, m, per))
             else:
-                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per)
+                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per, **kw)
                 wsl = P.param[lo:lo + m]
             if self.on_gpu:
                 # in place: this rank's slice already sits where the gathered buffer wants it (RCCL's in-place all-gather: send = recv + rank * count)
@@ -248,9 +257,9 @@ class GradReducer(object):
 
     def _exchange(self, seg, lo, hi):
         if self.shard_update is not None:
-            if lo not in self._plans:
-                self._plans[lo] = shard_plan(self.net.P, lo, hi) if self.gather_shadow else [(lo, hi, 'master')]
-            for a, b, on_wire in self._plans[lo]:
+            if (lo, hi) not in self._plans:
+                self._plans[(lo, hi)] = shard_plan(self.net.P, lo, hi) if self.gather_shadow else [(lo, hi, 'master')]
+            for a, b, on_wire in self._plans[(lo, hi)]:
                 self._exchange_sharded(seg[a - lo:b - lo], a, b, on_wire)
             return
         if self.wire == 'bf16':
@@ -265,8 +274,12 @@ class GradReducer(object):
         if self.bucket_update is not None and self.bucket_update is not True:
             self.bucket_update.update_range(lo, hi, full=True)
 
+    def skips(self, stage):
+        sk = self.SKIP_STAGES
+        return stage in (tuple(x for x in sk.split(',') if x) if isinstance(sk, str) else tuple(sk))
+
     def ready(self, stage):
-        if self.skip_allreduce == 2:
+        if self.skip_allreduce == 2 or self.skips(stage):
             return
         end = min(self.bounds[stage], self.net.P.total)
         if end <= self.done:

@@ -112,6 +112,23 @@ def _log_grad_table(g, dtype, table):
         pass
 
 
+# bf16 proposal lists against the reference's: IoU-matched recall of the reference's boxes.  Measured on the MI355X (round 6,
+# gpurun_out/proposal_agreement.jsonl -> profiles/r06_proposal_agreement.jsonl), recall at IoU >= 0.7 / >= 0.9:
+#   tiny .985/.858  tiny_spatial .983/.950  tiny_response .970/.923  tiny_cycle_response .980/.857  tiny_vgg .977/.780  tiny_align .985/.858  tiny_fb0 .985/.855
+#   full .991/.958  full_spatial .994/.941  full_cycle_response .993/.842
+# and the two outliers: tiny_baseline .577/.300 (its 300 proposals come from an RPN whose scores all sit within 1e-3 of each other: the
+# top-1500 cut and the greedy scan pick a different, equally valid subset once bf16 reorders them) and full_vgg .536/.312 (the un-normalised
+# 13-convolution VGG trunk lets bf16 activations drift furthest; 61 % of its boxes are still within 4 px of a reference box).
+# Gates = those measurements less a margin; everything downstream of the list is teacher-forced in these tests, and the f32 legs compare the lists box by box.
+PROPOSAL_GATES = {'tiny_baseline': (0.50, 0.25), 'full_vgg': (0.45, 0.25)}
+PROPOSAL_GATE_DEFAULT = (0.95, 0.75)
+
+
+def _proposal_gate(tag, pa, n, n_ref):
+    g70, g90 = PROPOSAL_GATES.get(tag, PROPOSAL_GATE_DEFAULT)
+    assert abs(n - n_ref) <= 0.1 * n_ref and pa['recall_iou70'] >= g70 and pa['recall_iou90'] >= g90, (tag, pa)
+
+
 def _proposal_agreement(tag, dtype, mine, ref):
     """how well the device's own proposal list (bf16: scores from bf16 activations reorder near-ties at the 12 000 cut and inside the greedy
     scan) describes the same boxes as the reference's: IoU-matched recall of the reference's boxes at IoU >= 0.9 / 0.7 (+1 areas, as
@@ -171,8 +188,7 @@ def test_train_step_vs_fixture_and_oracle(tag, dtype):
         assert D.min(1).max() < 2e-2 and D.min(0).max() < 2e-2, (D.min(1).max(), D.min(0).max())
     else:
         # bf16 scores reorder near-ties, so a few keeps differ; the lists must still describe the same boxes
-        pa = _proposal_agreement(tag, dtype, mine, ref)
-        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and pa['within_4px'] > 0.8, pa
+        _proposal_gate(tag, _proposal_agreement(tag, dtype, mine, ref), n, ref.shape[0])
     # integer outputs: bit-exact (proposals teacher-forced)
     assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
     assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
@@ -297,8 +313,7 @@ def test_train_step_full_size(tag, dtype):
     else:
         # (bf16 scores reorder near-ties: measured 0.78 ... 0.9 of the device's boxes within 4 px of a reference box over the four fixtures)
         # and 0.61 on the VGG trunk, whose un-normalised 3x3 stack lets bf16 activations drift furthest; everything downstream is teacher-forced)
-        pa = _proposal_agreement(tag, dtype, mine, ref)
-        assert abs(n - ref.shape[0]) <= 0.1 * ref.shape[0] and pa['within_4px'] > (0.5 if tag == 'full_vgg' else 0.8), pa
+        _proposal_gate(tag, _proposal_agreement(tag, dtype, mine, ref), n, ref.shape[0])
     assert np.array_equal(t['rpn_labels'].cpu().numpy().astype(np.int8), g['int.rpn_labels'].reshape(-1))
     assert np.array_equal(t['labels'].cpu().numpy().astype(np.int64), g['int.labels'])
     nfg = int(t['counts'][0].item())
@@ -531,10 +546,14 @@ def test_dp_sharded_update_matches_plain_update():
     out = {}
     # 'bucket': the unsharded form - every bucket is updated whole right behind its all-reduce (GradReducer.bucket_update), gradients
     # cleared / overwrite-marked as in the single-process step
-    for mode in ('plain', 'sharded', 'sharded+tape', 'bucket', 'bucket+tape'):
+    for mode in ('plain', 'sharded', 'sharded+tape', 'bucket', 'bucket+tape', 'sh16', 'sh16-cast', 'sh16+tape'):
         net = selftest.build_net(opt, over, 'bf16', sd)
         net.use_tape = mode.endswith('tape')
-        if mode.startswith('sharded'):
+        if mode.startswith('sh16'):
+            # bf16 wire: the update reads the reduce-scattered bf16 shard directly (l2s_sgd_momentum_range_g16) or, '-cast', after a cast back to f32
+            net.dp = GradReducer(net, 1, wire='bf16', algo='rs_ag', shard_update=True, rank=0)
+            net.dp.shard_g16 = mode != 'sh16-cast'
+        elif mode.startswith('sharded'):
             net.dp = GradReducer(net, 1, wire='fp32', algo='rs_ag', shard_update=True, rank=0)
         elif mode.startswith('bucket'):
             net.dp = GradReducer(net, 1, wire='fp32', algo='allreduce', bucket_update=True, rank=0)
@@ -555,6 +574,10 @@ def test_dp_sharded_update_matches_plain_update():
     for mode in ('sharded', 'sharded+tape', 'bucket', 'bucket+tape'):
         for a, b, nm in zip(out[mode], out['plain'], ('param', 'momentum', 'shadow')):
             assert torch.equal(a, b), (mode, nm, int((a != b).sum()))
+    for mode in ('sh16', 'sh16+tape'):                                  # same bits whether the shard is cast back first or read as it is
+        for a, b, nm in zip(out[mode], out['sh16-cast'], ('param', 'momentum', 'shadow')):
+            assert torch.equal(a, b), (mode, nm, int((a != b).sum()))
+    assert rel(out['sh16'][0], out['plain'][0]) < 1e-3 and not torch.equal(out['sh16'][1], out['plain'][1])     # (the gradients really went through bf16)
 
 
 def test_early_partial_sgd_matches_single_update():

@@ -21,7 +21,8 @@ ATTRS = {'fuse_roialign': ('Network', 'fuse_roialign', bool), 'wgrad_overwrite':
          'join_l1': ('Network', 'join_before_layer1', bool), 'stem_mfma': ('Network', 'stem_mfma', bool), 'cap_persist': ('Network', 'cap_persistent', bool),
          'layer1_fused': ('Network', 'layer1_fused', bool),
          'wgrad_min_wg': ('WgradQueue', 'MIN_WG', int), 'wgrad_v5_stream': ('WgradQueue', 'V5_STREAM', str), 'wgrad_small_tile': ('WgradQueue', 'SMALL_M_TILE', int),
-         'wgrad_v4_fill': ('WgradQueue', 'V4_FILL', int), 'defer': ('SGD', 'defer', bool), 'layer2_side': ('SGD', 'layer2_side', bool)}
+         'wgrad_v4_fill': ('WgradQueue', 'V4_FILL', int), 'defer': ('SGD', 'defer', bool), 'layer2_side': ('SGD', 'layer2_side', bool),
+         'dp_skip_stages': ('GradReducer', 'SKIP_STAGES', str), 'dp_g16': ('GradReducer', 'shard_g16', bool)}
 
 
 def main():
@@ -56,7 +57,8 @@ def main():
             from lang2seg_amd import _lib, ops
             from lang2seg_amd.nets.network import Network, WgradQueue
             from lang2seg_amd.optim import SGD
-            cls = {'Network': Network, 'WgradQueue': WgradQueue, 'SGD': SGD}
+            from lang2seg_amd.parallel import GradReducer
+            cls = {'Network': Network, 'WgradQueue': WgradQueue, 'SGD': SGD, 'GradReducer': GradReducer}
             for k, (c, at, t) in ATTRS.items():
                 v = getattr(a, k)
                 if v is not None:
