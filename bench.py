@@ -160,7 +160,7 @@ def _baseline_metric():
         return 'train images/sec (cycle loss on), 600×1000 input, at 1/2/4/8 MI355X'
 
 
-PROFILE_ROUND = 'r05'
+PROFILE_ROUND = 'r06'
 
 
 def src_hash():

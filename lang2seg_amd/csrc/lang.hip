@@ -226,16 +226,201 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmDir d0, LstmDir 
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (j >= Hh) return;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
+#if defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 10
+  float a2[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
+#if defined(L2S_LSTM_PROBE) && (L2S_LSTM_PROBE == 13 || L2S_LSTM_PROBE == 14 || (L2S_LSTM_PROBE >= 16 && L2S_LSTM_PROBE <= 19))
+  float a3[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
+#if defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 5
+  // probe 5: the same loop with a UNIFORM trip count (Hh % 256 == 0 in every caller of the probe): scalar loop control, no write of EXEC
+  // anywhere near the packed FMAs
+  const int trips = __builtin_amdgcn_readfirstlane(Hh >> 8);
+  for (int it = 0; it < trips; ++it) {
+    const int k = lane * 4 + (it << 8);
+#else
   for (int k = lane * 4; k < Hh; k += 256) {
+#endif
     const float4 hv = *(const float4*)(d.h_prev + k);
+#if defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 13
+    // probe 13 (packed build): v_pk_fma_f32 on NATURAL register pairs - (w.x, w.y) * (h.x, h.y) and (w.z, w.w) * (h.z, h.w) into a two-lane
+    // accumulator per gate, the lanes added after the loop: every packed source is an aligned pair exactly as the load delivered it (no
+    // v_mov shuffles, no op_sel); a different summation order, so compared only for run-to-run identity
+    {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const f2v h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wv = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
+        const f2v w01 = {wv.x, wv.y}, w23 = {wv.z, wv.w};
+        f2v acc = {a[q], a3[q]};
+        acc = __builtin_elementwise_fma(w23, h23, acc);
+        acc = __builtin_elementwise_fma(w01, h01, acc);
+        a[q] = acc.x; a3[q] = acc.y;
+      }
+    }
+#elif defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 14
+    // probe 14 (packed build; NOT the LSTM's arithmetic - compared for run-to-run identity only): natural source pairs as probe 13, but the second
+    // factor is one register broadcast to both lanes, i.e. v_pk_fma_f32 ... op_sel_hi:[1,0,1] / op_sel:[0,1,0] without any v_mov shuffle
+    {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const f2v hx = {hv.x, hv.x}, hy = {hv.y, hv.y}, hz = {hv.z, hv.z}, hw = {hv.w, hv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wv = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
+        const f2v w01 = {wv.x, wv.y}, w23 = {wv.z, wv.w};
+        f2v acc = {a[q], a3[q]};
+        acc = __builtin_elementwise_fma(w23, hw, acc);
+        acc = __builtin_elementwise_fma(w01, hz, acc);
+        acc = __builtin_elementwise_fma(w23, hy, acc);
+        acc = __builtin_elementwise_fma(w01, hx, acc);
+        a[q] = acc.x; a3[q] = acc.y;
+      }
+    }
+#elif defined(L2S_LSTM_PROBE) && (L2S_LSTM_PROBE == 18 || L2S_LSTM_PROBE == 19)
+    // probes 18 / 19 (NOT the LSTM's arithmetic): the OTHER broadcast form by hand - v_pk_fma_f32 acc, w, hh, acc op_sel:[0,1,0], i.e. BOTH lanes take
+    // hh's HIGH register (the low lane through op_sel, the high lane by default) - with hh's unused LOW register holding 18: 1000 x the value,
+    // 19: the same value
+    {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const float hcs[4] = {hv.w, hv.z, hv.y, hv.x};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wv = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
+        const f2v w01 = {wv.x, wv.y}, w23 = {wv.z, wv.w};
+        f2v acc = {a[q], a3[q]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f2v hh = {L2S_LSTM_PROBE == 19 ? hcs[c] : 1000.f * hcs[c], hcs[c]};
+          if (c & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(w01), "v"(hh));
+          else       asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "v"(w23), "v"(hh));
+        }
+        a[q] = acc.x; a3[q] = acc.y;
+      }
+    }
+#elif defined(L2S_LSTM_PROBE) && (L2S_LSTM_PROBE == 16 || L2S_LSTM_PROBE == 17)
+    // probes 16 / 17 (NOT the LSTM's arithmetic): the broadcast form written by hand - v_pk_fma_f32 acc, w, hh, acc op_sel_hi:[1,0,1], i.e. BOTH
+    // lanes take hh's LOW register - with hh's unused HIGH register holding 16: the same value (a wrong lane select cannot show), 17: 1000 x the
+    // value (a wrong lane select shows as a 1000 x too large term)
+    {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const float hcs[4] = {hv.w, hv.z, hv.y, hv.x};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wv = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
+        const f2v w01 = {wv.x, wv.y}, w23 = {wv.z, wv.w};
+        f2v acc = {a[q], a3[q]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f2v hh = {hcs[c], L2S_LSTM_PROBE == 16 ? hcs[c] : 1000.f * hcs[c]};
+          if (c & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w01), "v"(hh));
+          else       asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w23), "v"(hh));
+        }
+        a[q] = acc.x; a3[q] = acc.y;
+      }
+    }
+#elif defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 15
+    // probe 15 (packed build; NOT the LSTM's arithmetic): first factors assembled ACROSS two loads - (w_q.c, w_{q+1}.c), the pairs the compiler
+    // builds with v_mov_b32 in the product source - times NATURAL pairs of h (no broadcast, no op_sel)
+    {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const f2v h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+      float4 wq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wq[q] = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
+#pragma unroll
+      for (int q = 0; q < 4; q += 2) {
+        f2v acc = {a[q], a[q + 1]};
+        acc = __builtin_elementwise_fma((f2v){wq[q].w, wq[q + 1].w}, h23, acc);
+        acc = __builtin_elementwise_fma((f2v){wq[q].z, wq[q + 1].z}, h01, acc);
+        acc = __builtin_elementwise_fma((f2v){wq[q].y, wq[q + 1].y}, h23, acc);
+        acc = __builtin_elementwise_fma((f2v){wq[q].x, wq[q + 1].x}, h01, acc);
+        a[q] = acc.x; a[q + 1] = acc.y;
+      }
+    }
+#elif defined(L2S_LSTM_PROBE) && (L2S_LSTM_PROBE == 10 || L2S_LSTM_PROBE == 12)
+    // probes 10 / 12 (packed build): the same products in the same order per accumulator, but component by component across the four gates -
+    // 10: with a second set of accumulators for .w/.y so that a packed FMA never reads the result of the packed FMA two instructions before it;
+    // 12: with four wait states between the component steps
+    float4 wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[q] = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
+#if L2S_LSTM_PROBE == 10
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a2[q] = fmaf(wq[q].w, hv.w, a2[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = fmaf(wq[q].z, hv.z, a[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a2[q] = fmaf(wq[q].y, hv.y, a2[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = fmaf(wq[q].x, hv.x, a[q]);
+#else
+#define L2S_NOP4 asm volatile("s_nop 3" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = fmaf(wq[q].w, hv.w, a[q]);
+    L2S_NOP4
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = fmaf(wq[q].z, hv.z, a[q]);
+    L2S_NOP4
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = fmaf(wq[q].y, hv.y, a[q]);
+    L2S_NOP4
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = fmaf(wq[q].x, hv.x, a[q]);
+    L2S_NOP4
+#undef L2S_NOP4
+#endif
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 wv = *(const float4*)(d.w + (long)(q * Hh + j) * Hh + k);
       a[q] = fmaf(wv.x, hv.x, fmaf(wv.y, hv.y, fmaf(wv.z, hv.z, fmaf(wv.w, hv.w, a[q]))));
     }
+#endif
+#if defined(L2S_LSTM_PROBE) && (L2S_LSTM_PROBE == 4 || L2S_LSTM_PROBE == 7)
+    // probes 4 / 7: wait states between the last packed FMAs of an iteration and the loop control's write of EXEC (s_andn2_b64 exec)
+    asm volatile("s_nop 7" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+#endif
   }
+#if defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 10
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] += a2[q];
+#endif
+#if defined(L2S_LSTM_PROBE) && (L2S_LSTM_PROBE == 13 || L2S_LSTM_PROBE == 14 || (L2S_LSTM_PROBE >= 16 && L2S_LSTM_PROBE <= 19))
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] += a3[q];
+#endif
+#if defined(L2S_LSTM_PROBE)
+  // tools/lstm_pk_probe.sh only: variants of the hand-off between the accumulation loop - which the compiler pairs into
+  // v_pk_fma_f32 when packed fp32 ops are enabled - and the DPP reduction that reads the LOW halves of those pairs first.
+#if L2S_LSTM_PROBE == 1
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));                       // time only
+#elif L2S_LSTM_PROBE == 2 || L2S_LSTM_PROBE == 7
+  asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));   // a plain VALU read + rewrite of each half
+#elif L2S_LSTM_PROBE == 3
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));                                           // the constraint alone (register allocation changes, no instruction)
+#endif
+#endif
+#if defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 8
+  // probe 8 (packed build): the four reductions strictly one after the other (the compiler then separates dependent DPP steps by s_nop 1,
+  // as in the product build) instead of the two interleaved low-half chains it schedules behind v_pk_fma_f32
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a[q] = wave_sum(a[q]); __builtin_amdgcn_sched_barrier(0); }
+#elif defined(L2S_LSTM_PROBE) && L2S_LSTM_PROBE == 9
+  // probe 9 (UNPACKED build): two reductions interleaved step by step by hand, the shape the packed build's scheduler produces
+  {
+    float x = a[0], y = a[2];
+#define L2S_STEP(C, M) x += dpp_take<C, M>(0.f, x); __builtin_amdgcn_sched_barrier(0); y += dpp_take<C, M>(0.f, y); __builtin_amdgcn_sched_barrier(0);
+    L2S_STEP(0x111, 0xf) L2S_STEP(0x112, 0xf) L2S_STEP(0x114, 0xf) L2S_STEP(0x118, 0xf) L2S_STEP(0x142, 0xa) L2S_STEP(0x143, 0xc)
+#undef L2S_STEP
+    a[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    a[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 63));
+    a[1] = wave_sum(a[1]); a[3] = wave_sum(a[3]);
+  }
+#else
 #pragma unroll
   for (int q = 0; q < 4; ++q) a[q] = wave_sum(a[q]);
+#endif
   if (lane == 0) {
     float g[4];
 #pragma unroll
