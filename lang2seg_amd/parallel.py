@@ -91,7 +91,7 @@ class GradReducer(object):
     STAGES = ['caption', 'heads', 'language', 'layer3', 'layer2', 'layer1']
     # hand-offs that are NOT taken (Network.dp_ready): their gradients ride with the next stage's bucket - fewer, larger collectives and fewer
     # cuts of the launch tape.  A comma list or a tuple; '' = every hand-off (seven buckets per step).
-    SKIP_STAGES = ()
+    SKIP_STAGES = ('caption', 'layer3:16')     # five buckets per step: caption + heads | language | layer3 blocks 22-8 | layer3 blocks 7-0 | layer2 (round 6)
     shard_g16 = True             # bf16 wire: the sharded update reads the reduce-scattered bf16 shard directly (False: cast back to f32 first)
 
     def __init__(self, net, world, backend_stream=True, skip_allreduce=0, wire='fp32', algo='allreduce', timing=False, shard_update=None, rank=None,
@@ -203,7 +203,8 @@ class GradReducer(object):
                 self.master_stale = W > 1
                 self._stale.append((lo, m, per))
             else:
-                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per, **kw)
+                # (masters on the wire: this rank's slice gets its shadow from the update itself, the other ranks' slices from a ranged rewrite behind the gather)
+                self.shard_update.update_range(lo + r * per, lo + (r + 1) * per, shadow=bool(self.gather_shadow), **kw)
                 wsl = P.param[lo:lo + m]
             if self.on_gpu:
                 # in place: this rank's slice already sits where the gathered buffer wants it (RCCL's in-place all-gather: send = recv + rank * count)
@@ -215,7 +216,10 @@ class GradReducer(object):
                 mine.copy_(wsl[r * per:(r + 1) * per])
                 dist.all_gather_into_tensor(wsl, mine)
             if self.gather_shadow and on_wire != 'shadow':
-                self.shard_update.refresh_shadow_range(lo, lo + m)       # the shadow of the gathered masters (this rank's slice included)
+                if r > 0:
+                    self.shard_update.refresh_shadow_range(lo, lo + r * per)              # the shadow of the masters the other ranks sent
+                if r < W - 1:
+                    self.shard_update.refresh_shadow_range(lo + (r + 1) * per, lo + m)
         if m < n:
             tail = seg[m:]
             if self.wire == 'bf16':
