@@ -66,6 +66,8 @@ __C.TRAIN.USE_TAPE = True
 __C.TRAIN.ALLOW_RESHARD_RESUME = False
 # data parallel (one process per GPU, RCCL over xGMI; parallel.GradReducer): gradient buckets on the wire in bf16 or fp32, one all-reduce per
 # bucket or reduce-scatter + all-gather, and (with rs_ag) each rank updating only its slice of a bucket before the weights are gathered
+__C.TRAIN.DP_BACKEND = 'nccl'          # torch.distributed backend of tools/train*.py: 'nccl' = RCCL over xGMI; 'gloo' = the reducer's buffers staged through the host (a debug
+                                       # transport: two ranks can then share one GPU, tests/test_train_step_gpu.py::test_train_entry_point_two_ranks_one_gpu)
 __C.TRAIN.DP_WIRE = 'bf16'
 __C.TRAIN.DP_ALGO = 'rs_ag'
 __C.TRAIN.DP_SHARD_UPDATE = True

@@ -123,6 +123,7 @@ class GradReducer(object):
         # carried masters).  The fp32 masters of a 'shadow' slice then live on its owner ONLY; gather_master() (a collective: every rank calls
         # it, model/train_val.py before a snapshot, Network.state_dict through it) brings them together again.
         self.gather_shadow = shard_update is not None and getattr(net.P, 'shadow', None) is not None
+        self._host_staged = None     # device buffers on a gloo process group: collectives staged through the host (decided at the first collective)
         self._parts = {}             # sub-bucket lo -> (m, per): the partition of every sharded sub-bucket
         self._plans = {}             # bucket (lo, hi) -> shard_plan(...)
         self._stale = []             # (lo, m, per) of the sub-buckets whose all-gather carried the shadow since the last gather_master()
@@ -143,6 +144,41 @@ class GradReducer(object):
         self._events = []            # (stage, start, end) of the last step
         self._wait_events = None
 
+    # ---- the three collectives.  On RCCL (backend "nccl") they run on the device, on the current stream.  With device buffers on a "gloo" process
+    # group they are STAGED THROUGH THE HOST (a blocking copy out, the collective on CPU tensors, a copy back): no xGMI, no overlap - a debug
+    # transport that lets two real ranks share ONE GPU (tests/test_train_step_gpu.py::test_two_ranks_one_gpu_end_to_end; TRAIN.DP_BACKEND = 'gloo')
+    def _staged(self):
+        if self._host_staged is None:
+            self._host_staged = bool(self.on_gpu and dist.is_available() and dist.is_initialized() and dist.get_backend() == 'gloo')
+        return self._host_staged
+
+    def _rs(self, out, inp):
+        if self._staged():
+            h = inp.float().cpu()                              # (gloo sums fp32; a bf16 wire is rounded to bf16 again on the way back, as every RCCL partial sum is)
+            o = torch.empty(out.numel(), dtype=torch.float32)
+            dist.reduce_scatter_tensor(o, h, op=dist.ReduceOp.SUM)
+            out.copy_(o.to(out.dtype))
+        else:
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+
+    def _ag(self, out, inp):
+        if self._staged():
+            h = inp.cpu().contiguous()
+            hv = h.view(torch.uint8)                             # (bit patterns: a gather must not re-round anything, and gloo has no bf16)
+            o = torch.empty(out.numel() * out.element_size(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(o, hv)
+            out.copy_(o.view(h.dtype).to(out.device))
+        else:
+            dist.all_gather_into_tensor(out, inp)
+
+    def _ar(self, t):
+        if self._staged():
+            h = t.float().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h.to(t.dtype))
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
     # ---- one bucket, on the current stream (the side stream on the GPU) ----
     def _cast(self, src, dst):
         if self.on_gpu:
@@ -162,12 +198,12 @@ class GradReducer(object):
                 big = max(per, (max(self.bounds.values()) + W - 1) // W)
                 self._shard = torch.empty(big, dtype=buf.dtype, device=buf.device)
             sh = self._shard[:per]
-            dist.reduce_scatter_tensor(sh, buf[:m], op=dist.ReduceOp.SUM)
-            dist.all_gather_into_tensor(buf[:m], sh)
+            self._rs(sh, buf[:m])
+            self._ag(buf[:m], sh)
             if m < n:
-                dist.all_reduce(buf[m:], op=dist.ReduceOp.SUM)
+                self._ar(buf[m:])
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            self._ar(buf)
 
     def _exchange_sharded(self, seg, lo, hi, on_wire='shadow'):
         """bucket [lo, hi): reduce-scatter the gradients, update this rank's slice, all-gather the weights (the < 4 world elements that do not
@@ -188,7 +224,7 @@ class GradReducer(object):
                 big = max(per, (max(self.bounds.values()) + W - 1) // W)
                 self._shard = torch.empty(big, dtype=src.dtype, device=src.device)
             sh = self._shard[:per]
-            dist.reduce_scatter_tensor(sh, src, op=dist.ReduceOp.SUM)
+            self._rs(sh, src)
             own = seg[r * per:(r + 1) * per]
             # bf16 wire on the device: the update reads the reduce-scattered shard as it is (l2s_sgd_momentum_range_g16) - no cast back into
             # the f32 gradient buffer, whose slice keeps this rank's local gradients until the next step overwrites them
@@ -208,13 +244,13 @@ class GradReducer(object):
                 wsl = P.param[lo:lo + m]
             if self.on_gpu:
                 # in place: this rank's slice already sits where the gathered buffer wants it (RCCL's in-place all-gather: send = recv + rank * count)
-                dist.all_gather_into_tensor(wsl, wsl[r * per:(r + 1) * per])
+                self._ag(wsl, wsl[r * per:(r + 1) * per])
             else:
                 if self._wshard is None or self._wshard.numel() < per or self._wshard.dtype != wsl.dtype:
                     self._wshard = torch.empty(max(per, (max(self.bounds.values()) + W - 1) // W), dtype=wsl.dtype, device=wsl.device)
                 mine = self._wshard[:per]
                 mine.copy_(wsl[r * per:(r + 1) * per])
-                dist.all_gather_into_tensor(wsl, mine)
+                self._ag(wsl, mine)
             if self.gather_shadow and on_wire != 'shadow':
                 if r > 0:
                     self.shard_update.refresh_shadow_range(lo, lo + r * per)              # the shadow of the masters the other ranks sent
@@ -224,9 +260,9 @@ class GradReducer(object):
             tail = seg[m:]
             if self.wire == 'bf16':
                 tb = self._pack[lo + m:hi]
-                self._cast(tail, tb); dist.all_reduce(tb, op=dist.ReduceOp.SUM); self._cast(tb, tail)
+                self._cast(tail, tb); self._ar(tb); self._cast(tb, tail)
             else:
-                dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+                self._ar(tail)
             # (every rank updates the tail from the all-reduced gradients: master and shadow are both current everywhere)
             self.shard_update.update_range(lo + m, hi, shadow=bool(self.gather_shadow))
 
@@ -243,7 +279,7 @@ class GradReducer(object):
         for lo, m, per in sorted(set(self._stale)):
             wsl = P.param[lo:lo + m]
             mine = wsl[r * per:(r + 1) * per].clone()
-            dist.all_gather_into_tensor(wsl, mine)
+            self._ag(wsl, mine)
         if self.on_gpu:
             torch.cuda.synchronize()
         self.master_stale = False

@@ -23,9 +23,8 @@ def main(args, variant='cycle'):
     from lang2seg_amd.nets.resnet_v1 import resnetv1
     from lang2seg_amd.loaders.synthetic_loader import SyntheticLoader
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(local)
-    if world > 1:
-        torch.distributed.init_process_group('nccl')        # lazy communicator (see bench.py)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local % max(ndev, 1))                 # (TRAIN.DP_BACKEND gloo: more ranks than devices share them)
     torch.manual_seed(args['seed']); random.seed(args['seed'])
     T = 20 if args['dataset'] == 'refcocog' else 10
     V = 3349 if args['dataset'] == 'refcocog' else 1999
@@ -74,6 +73,8 @@ def main(args, variant='cycle'):
         if args['set_cfgs']:
             config_vgg.cfg_from_list(args['set_cfgs'])
     cfg.COMPUTE_DTYPE = args['dtype']
+    if world > 1:
+        torch.distributed.init_process_group(cfg.TRAIN.DP_BACKEND)   # 'nccl': lazy communicator (see bench.py)
     if variant == 'vgg':
         from lang2seg_amd.nets.vgg16 import vgg16
         net = vgg16(opt, batch_size=1)
