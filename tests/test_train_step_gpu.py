@@ -1286,7 +1286,7 @@ def _two_rank_worker(rank, world, port, outdir, wire, variant, steps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('variant,wire', [('cycle', 'fp32'), ('cycle', 'bf16'), ('baseline', 'bf16')])
+@pytest.mark.parametrize('variant,wire', [('cycle', 'fp32'), ('cycle', 'bf16'), ('baseline', 'bf16'), ('vgg', 'bf16'), ('cycle_response', 'fp32')])
 def test_two_ranks_one_gpu_end_to_end(tmp_path, variant, wire):
     """Data parallel with two REAL ranks - two processes, two networks, two different (image, expression) pairs, the segmented launch tape,
     the sharded update with the master / shadow split - on the one GPU of the box (RCCL refuses two ranks on one device, so the wire is a gloo
@@ -1306,6 +1306,8 @@ def test_two_ranks_one_gpu_end_to_end(tmp_path, variant, wire):
         p_.start()
     # ---- the single-process reference, meanwhile: one network per image (same weights, the ranks' RNG streams), gradients added, one update ----
     opt = OW.default_opt(vocab_size=60, seq_length=6)
+    if variant == 'vgg':
+        opt['C4_feat_dim'] = 512
     sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant=variant)
     nets, sgds, blobs = [], [], []
     for r in range(W):
