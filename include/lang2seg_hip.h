@@ -315,6 +315,11 @@ long l2s_maskpred_ws_floats(int fg_max, int C);
 int l2s_maskpred_bwd(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C,
                      const float* w /*[ncls][C]*/, const void* x, const void* relu_ref, void* dx, float* dw, float* db, float* ws, int dtype,
                      hipStream_t s);
+/* its two launches separately: l2s_maskpred_bwd_dx = dx and the partial sums into ws; l2s_maskpred_bwd_reduce = dW / db from ws (may run on another
+ * stream behind it: nothing of the data-gradient chain reads dW) */
+int l2s_maskpred_bwd_dx(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C, const float* w,
+                        const void* x, const void* relu_ref, void* dx, float* ws, int dtype, hipStream_t s);
+int l2s_maskpred_bwd_reduce(const float* ws, const int* labels, const int* num_fg, int fg_max, int C, float* dw, float* db, hipStream_t s);
 
 /* ---------------------------------------------------------------- language side ------------- */
 /* small-M linear layers, fp32: y[m][n] = act(sum_k x[m][k] w[n][k] + b[n] (+ y_in)) ; act 0 none, 1 relu, 2 tanh */

@@ -124,6 +124,8 @@ SIGS = {
     'l2s_total_loss': (i32, [vp, f32, vp]),
     'l2s_maskpred_ws_floats': (i64, [i32, i32]),
     'l2s_maskpred_bwd': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_maskpred_bwd_dx': (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    'l2s_maskpred_bwd_reduce': (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
     'l2s_linear_fwd': (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'l2s_linear_bwd_x': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, i64, vp]),
     'l2s_linear_bwd_x_ws_floats': (i64, [i32, i32, i32]),

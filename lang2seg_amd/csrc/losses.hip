@@ -185,15 +185,33 @@ __global__ __launch_bounds__(256) void maskpred_bwd_kernel(const float* dscore, 
     po[C] = sb;
   }
 }
+// The per-(RoI, pixel chunk) partial sums of maskpred_bwd_kernel, added per label in RoI order (no atomics: two RoIs of one label add in a fixed
+// order).  One thread per column c (the C weight columns + the bias).  Round 6: the running sums live in LDS ([ncls_max][256] floats per
+// workgroup, thread c touches column c only: conflict-free) instead of in dW itself - the old form read, added to and stored dW[label][c] once per
+// RoI, a store -> load round trip through memory per RoI (27 us for 64 RoIs); dW / db are added to ONCE per label at the end.  The sums are
+// formed in the same order from the same zero, so with dW cleared beforehand (it is: this kernel is its only writer) the bits are the same.
+constexpr int MPB_NCLS = 96;                              // label rows of the LDS table (mask_pred_net has 81 outputs)
 __global__ __launch_bounds__(256) void maskpred_bwd_reduce_kernel(const float* part, const int* labels, const int* num_fg, int fg_max, int C, int chunks,
                                                                  float* dw, float* db) {
-  const int nfg = min(*num_fg, fg_max);
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= C; c += gridDim.x * blockDim.x)
+  __shared__ float acc[MPB_NCLS][256];
+  __shared__ int used[MPB_NCLS];
+  const int nfg = min(*num_fg, fg_max), t = threadIdx.x;
+  const int c = blockIdx.x * blockDim.x + t;
+  for (int l = 0; l < MPB_NCLS; ++l) acc[l][t] = 0.f;
+  if (t < MPB_NCLS) used[t] = 0;
+  __syncthreads();
+  if (c <= C)
     for (int s = 0; s < nfg; ++s) {
       float v = 0.f;
       for (int q = 0; q < chunks; ++q) v += part[((long)s * chunks + q) * (C + 1) + c];
-      if (c < C) dw[(long)labels[s] * C + c] += v; else db[labels[s]] += v;
+      const int l = labels[s];
+      if (l >= 0 && l < MPB_NCLS) { acc[l][t] += v; if (t == 0) used[l] = 1; }
+      else if (c < C) dw[(long)l * C + c] += v; else db[l] += v;          // (a label beyond the table: the old path)
     }
+  __syncthreads();
+  if (c <= C)
+    for (int l = 0; l < MPB_NCLS; ++l)
+      if (used[l]) { if (c < C) dw[(long)l * C + c] += acc[l][t]; else db[l] += acc[l][t]; }
 }
 
 // ---- TEST-mode heads (NET:277-307, 650-658): class probabilities, de-normalised box deltas, mask probabilities ----
@@ -262,6 +280,19 @@ extern "C" int l2s_maskpred_bwd(const float* dscore, const int* labels, const in
   if (!ws) return L2S_EINVAL;                            // l2s_maskpred_ws_floats(fg_max, C) floats
   L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max, MPB_CHUNKS), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, ws, dtype);
   L2S_LAUNCH(maskpred_bwd_reduce_kernel, dim3(cdiv(C + 1, 256)), dim3(256), 0, s, (const float*)ws, labels, num_fg, fg_max, C, MPB_CHUNKS, dw, db);
+  return l2s_check_launch();
+}
+// the two launches of l2s_maskpred_bwd separately: the data gradient (+ the partial sums into ws) on the caller's critical path, the ordered reduction of
+// the partial sums into dW / db wherever the caller has room (the weight-gradient stream: nothing of the backward chain reads dW)
+extern "C" int l2s_maskpred_bwd_dx(const float* dscore, const int* labels, const int* num_fg, int fg_max, int ms2, int C, const float* w,
+                                   const void* x, const void* relu_ref, void* dx, float* ws, int dtype, hipStream_t s) {
+  if (!ws) return L2S_EINVAL;
+  L2S_LAUNCH(maskpred_bwd_kernel, dim3(fg_max, MPB_CHUNKS), dim3(256), 0, s, dscore, labels, num_fg, fg_max, ms2, C, w, x, relu_ref, dx, ws, dtype);
+  return l2s_check_launch();
+}
+extern "C" int l2s_maskpred_bwd_reduce(const float* ws, const int* labels, const int* num_fg, int fg_max, int C, float* dw, float* db, hipStream_t s) {
+  if (!ws) return L2S_EINVAL;
+  L2S_LAUNCH(maskpred_bwd_reduce_kernel, dim3(cdiv(C + 1, 256)), dim3(256), 0, s, ws, labels, num_fg, fg_max, C, MPB_CHUNKS, dw, db);
   return l2s_check_launch();
 }
 extern "C" int l2s_rcnn_predict(const float* heads, int ldh, int R, int ncls, const float* stds4, const float* means4, float* cls_prob,

@@ -376,6 +376,16 @@ def maskpred_bwd(dscore, labels, num_fg, fg_max, ms2, Cc, w, x, ref, dx, dw, db,
          ptr(dw), ptr(db), ptr(ws), dt_of(x), stream())
 
 
+def maskpred_bwd_dx(dscore, labels, num_fg, fg_max, ms2, Cc, w, x, ref, dx, ws):
+    """the first launch of maskpred_bwd: dx and the per-(RoI, pixel chunk) partial sums into ws"""
+    call('l2s_maskpred_bwd_dx', ptr(dscore), ptr(labels), ptr(num_fg), fg_max, ms2, Cc, ptr(w), ptr(x), ptr(ref), ptr(dx), ptr(ws), dt_of(x), stream())
+
+
+def maskpred_bwd_reduce(ws, labels, num_fg, fg_max, Cc, dw, db):
+    """the second: dW / db from ws, per label in RoI order (on the current stream: the caller puts it on a weight-gradient stream)"""
+    call('l2s_maskpred_bwd_reduce', ptr(ws), ptr(labels), ptr(num_fg), fg_max, Cc, ptr(dw), ptr(db), stream())
+
+
 # ------------------------------------------------------------------ language side (fp32)
 def linear_fwd(x, w, b, y, M, N, K, act=0, accumulate=False, ldx=None, ldy=None, ldw=None):
     call('l2s_linear_fwd', ptr(x), K if ldx is None else ldx, ptr(w), K if ldw is None else ldw, ptr(b), ptr(y),

@@ -5,7 +5,8 @@ by launch count: 0 = main, 1 = ...> [fold=1]"""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-sgd = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
+# one step = from one proposal gather (exactly one launch per step, in the middle of it) to the next
+sgd = [i for i, r in enumerate(rows) if 'gather_rois_kernel' in r['Kernel_Name']]
 win = rows[sgd[-2] + 1:sgd[-1] + 1]
 t0 = int(win[0]['Start_Timestamp'])
 def short(n): return re.sub(r'\(anonymous namespace\)::|void ', '', n)[:60]
