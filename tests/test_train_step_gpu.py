@@ -38,7 +38,15 @@ def _setup(dtype, tag='tiny'):
 # cosine >= 0.9903, norms within 3 % except the dynamic-filter FCs of the cycle fixture (6 %, one at 20 %: their gradient goes through
 # d(response)[p] = <dy[p], x[p]>, a 1024-term dot product of bf16 values that nearly cancels); integer outputs still bit-exact (they depend on the boxes, not on the activations, once the
 # proposals are teacher-forced).
-BF16_LOSS_RTOL, BF16_COS, BF16_NORM = 1e-2, 0.99, 0.25
+BF16_LOSS_RTOL, BF16_COS, BF16_NORM = 1e-2, 0.99, 0.10
+# Round 6: the tiny-fixture gates are the general ones (cosine >= 0.99, norm within 10 %: measured over the eight tiny fixtures, 59-160 tensors each,
+# profiles/r06_bf16_grad_agreement.jsonl: cosine >= 0.9947, norms within 7.6 %) with TWO named exceptions instead of a wide gate for a whole family:
+#   dynamic_fc_5 (weight and bias) of the CYCLE network's tiny fixtures (tiny, tiny_align, tiny_fb0): cosine 0.985-0.998, norm 0.76-0.89 of the f32 step's.  Its
+#     gradient is sum_p dresp[p] x[:, p] with dresp[p] = <dy[p], x[p]>, a 1024-term dot product of bf16 values that nearly cancels; on 520 pixels a handful of them
+#     carries the sum and its length re-rolls with every rounding pattern upstream (0.89 before layer1 was fused, 0.76 after).  The same tensor at the BASELINE size:
+#     within 2.3 %; every other dynamic-filter tensor of every fixture: within 7.6 %.
+#   resnet.layer1.* at FIXED_BLOCKS = 0: cosine 0.987 on layer1.0.conv1 - the deepest gradient of the step, behind 33 blocks of bf16 activations.
+BF16_EXCEPTIONS = {('cycle', 'dynamic_fc_5.weight'): (0.97, 0.30), ('cycle', 'dynamic_fc_5.bias'): (0.97, 0.30)}
 BF16_NORM_DYN_FULL = 0.10      # dynamic-filter FCs at the BASELINE size (measured <= 0.03)
 VARIANT_TAGS = ['tiny', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg', 'tiny_align', 'tiny_fb0']
 
@@ -85,13 +93,16 @@ def _check_grads(g, net, dtype, rtol_f32, ref_net=None, norm_tol=None):
             # BASELINE size (2394 pixels) the committed runs measure <= 2 % (profiles/r03_bf16_grad_agreement.jsonl, r04: <= 3 %), and the
             # gate there is 10 % for these tensors, `norm_tol` (5 %) for every other one.
             dyn = k.startswith(('dynamic_fc_', 'response_fc'))
+            # BASELINE size (norm_tol given): norm_tol for every tensor, 10 % for the dynamic-filter FCs (measured <= 2.8 %).  Tiny fixtures: BF16_NORM for
+            # every tensor but the named exceptions above
             ntol = BF16_NORM if norm_tol is None else (max(norm_tol, BF16_NORM_DYN_FULL) if dyn else norm_tol)
-            # (round 5: with layer1 fused its first shortcut is no longer rounded to bf16 before the add; every tensor of every fixture kept its agreement
-            # except dynamic_fc_5 of the tiny cycle fixture - 0.89 of the f32 norm before, 0.76 / cosine 0.985 after: the same handful of pixels, re-rolled.
-            # Tiny fixtures only: cosine 0.97 for these tensors; the BASELINE-size gates are unchanged.)
-            ctol = 0.97 if (dyn and norm_tol is None) else BF16_COS
-            if k.startswith('resnet.layer1.') and norm_tol is None:
-                ctol = 0.98      # FIXED_BLOCKS = 0 only: the deepest gradients of the step, through 33 blocks of bf16 activations (measured 0.987 on layer1.0.conv1)
+            ctol = BF16_COS
+            if norm_tol is None:
+                ex = BF16_EXCEPTIONS.get((variant_of(g), k))
+                if ex is not None:
+                    ctol, ntol = ex
+                elif k.startswith('resnet.layer1.'):
+                    ctol = 0.98
             if not (cos >= ctol and abs(nb / na - 1.0) <= ntol):
                 bad.append((k, cos, nb / na))
     _log_grad_table(g, dtype, table)
