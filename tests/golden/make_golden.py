@@ -912,6 +912,8 @@ if __name__ == '__main__':
     if what in ('test', 'all'):
         run_reference_test('test_tiny', 320, 416, 6, 60)
         run_reference_test('test_tiny_cycle_response', 320, 416, 6, 60, variant='cycle_response')
+        for v in ('baseline', 'spatial', 'response'):         # (round 6: TEST mode of the remaining ResNet variants)
+            run_reference_test('test_tiny_' + v, 320, 416, 6, 60, variant=v)
     if what in ('test_vgg', 'all'):
         run_reference_test('test_tiny_vgg', 320, 416, 6, 60, variant='vgg')
     if what in ('test_top', 'all'):
@@ -921,7 +923,7 @@ if __name__ == '__main__':
         run_reference('full', 600, 1000, 20, 3349, dict(BATCH_SIZE=256, RPN_PRE_NMS_TOP_N=12000,
                                                          RPN_POST_NMS_TOP_N=2000, RPN_BATCHSIZE=256))
     if what == 'full_variants':
-        # BASELINE.json configs 2, 4, 5 (and 1) at their stated size: 600x1000, 12000 -> 2000 proposals, 256 RoIs; expression length / vocabulary
+        # BASELINE.json configs 2, 4, 5 (and 1) at their stated size (round 6: also `full_variants baseline response`): 600x1000, 12000 -> 2000 proposals, 256 RoIs; expression length / vocabulary
         # of the config's dataset (refcoco(+) unc: 10 tokens, V = 1999; refcocog umd: 20 tokens, V = 3349).  Not part of 'all': minutes each.
         TV = dict(baseline=(10, 1999), spatial=(10, 1999), response=(10, 1999), cycle_response=(20, 3349), vgg=(10, 1999))
         for v in (sys.argv[2:] or ['spatial', 'cycle_response', 'vgg']):

@@ -130,7 +130,7 @@ def test_forward_full_size_variants(tag):
         assert abs(float(v) - float(g['loss.' + k])) < 1e-4 * max(1, abs(float(g['loss.' + k]))), (k, float(v), g['loss.' + k])
 
 
-@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top', 'test_tiny_vgg'])
+@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top', 'test_tiny_vgg', 'test_tiny_baseline', 'test_tiny_spatial', 'test_tiny_response'])
 def test_test_mode(tag):
     """TEST mode of the reference (test_image NET:684-699 + _predict_masks_from_boxes_and_labels NET:595-626):
     300 TEST proposals, class scores / probabilities, de-normalised box deltas, mask probabilities."""
@@ -154,7 +154,7 @@ def test_test_mode(tag):
 
 
 TRAIN_TAGS = ['tiny', 'tiny_align', 'tiny_fb0', 'tiny_baseline', 'tiny_spatial', 'tiny_response', 'tiny_cycle_response', 'tiny_vgg',
-              'full', 'full_spatial', 'full_cycle_response', 'full_vgg']
+              'full', 'full_spatial', 'full_cycle_response', 'full_vgg', 'full_baseline', 'full_response']
 
 
 @pytest.mark.parametrize('tag', TRAIN_TAGS)

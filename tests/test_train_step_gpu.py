@@ -127,11 +127,12 @@ def _log_grad_table(g, dtype, table):
 # gpurun_out/proposal_agreement.jsonl -> profiles/r06_proposal_agreement.jsonl), recall at IoU >= 0.7 / >= 0.9:
 #   tiny .985/.858  tiny_spatial .983/.950  tiny_response .970/.923  tiny_cycle_response .980/.857  tiny_vgg .977/.780  tiny_align .985/.858  tiny_fb0 .985/.855
 #   full .991/.958  full_spatial .994/.941  full_cycle_response .993/.842
-# and the two outliers: tiny_baseline .577/.300 (its 300 proposals come from an RPN whose scores all sit within 1e-3 of each other: the
+# and the outliers: tiny_baseline .577/.300 (the baseline network's RPN scores all sit within 1e-3 of each other on these weights: the
 # top-1500 cut and the greedy scan pick a different, equally valid subset once bf16 reorders them) and full_vgg .536/.312 (the un-normalised
 # 13-convolution VGG trunk lets bf16 activations drift furthest; 61 % of its boxes are still within 4 px of a reference box).
 # Gates = those measurements less a margin; everything downstream of the list is teacher-forced in these tests, and the f32 legs compare the lists box by box.
-PROPOSAL_GATES = {'tiny_baseline': (0.50, 0.25), 'full_vgg': (0.45, 0.25)}
+#   full_baseline .649/.206 (the same regime as tiny_baseline, at the BASELINE size), full_response: inside the default gate
+PROPOSAL_GATES = {'tiny_baseline': (0.50, 0.25), 'full_baseline': (0.55, 0.15), 'full_vgg': (0.45, 0.25)}
 PROPOSAL_GATE_DEFAULT = (0.95, 0.75)
 
 
@@ -294,7 +295,7 @@ def test_train_step_per_token_captioner_fallback():
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('tag', ['full', 'full_spatial', 'full_cycle_response', 'full_vgg'])
+@pytest.mark.parametrize('tag', ['full', 'full_spatial', 'full_cycle_response', 'full_vgg', 'full_baseline', 'full_response'])
 def test_train_step_full_size(tag, dtype):
     """Every BASELINE.json GPU config at its stated size (600x1000, 12000->2000 proposals, 256 RoIs; config 3 `full` = the headline with 20 tokens,
     V=3349; config 2 `full_spatial` and config 5 `full_vgg` with 10 tokens, V=1999; config 4 `full_cycle_response` with 20 tokens, V=3349) against the
@@ -382,7 +383,7 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top', 'test_tiny_vgg'])
+@pytest.mark.parametrize('tag', ['test_tiny', 'test_tiny_cycle_response', 'test_tiny_top', 'test_tiny_vgg', 'test_tiny_baseline', 'test_tiny_spatial', 'test_tiny_response'])
 def test_test_mode(tag):
     """TEST mode (test_image, _predict_masks_from_boxes_and_labels) against the reference's own TEST-mode outputs."""
     from golden_util import setup_from_fixture_test
