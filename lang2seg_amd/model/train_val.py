@@ -52,14 +52,13 @@ def scale_lr(optimizer, scale):
 def make_optimizer(net, solver_cfg=None, world=1, **kw):
     """The optimiser the reference's solver of this network's variant builds in construct_graph() (train_val.py:186-207 and its five
     siblings, see nets/variants.SOLVERS): torch.optim.SGD with momentum and one param group per tensor - weight decay on non-bias tensors
-    (BIAS_DECAY False), lr x (DOUBLE_BIAS + 1) on biases, lr x 10 on rnn_encoder / dynamic_fc / response keys outside the two cycle solvers;
+    (BIAS_DECAY False), lr x (DOUBLE_BIAS + 1) on biases, lr x 10 on rnn_encoder / dynamic_fc / response keys outside the two cycle solvers (or, with
+    TRAIN.FROM_FRCN, the detector fine-tuning rule of train_val.py:175-185: lr x GAMMA for everything but the mask branch);
     hyper-parameters from the config module THAT solver imports (config_vgg.py for VGG: WEIGHT_DECAY 5e-4, DOUBLE_BIAS True).  Here the
     groups are the rows of ParamStore's segment table and the update is one fused launch (optim.SGD)."""
     from ..nets.variants import solver_cfg as _scfg
     c = _scfg(net.variant) if solver_cfg is None else solver_cfg
-    if c.TRAIN.FROM_FRCN:
-        raise NotImplementedError('TRAIN.FROM_FRCN (train_val.py:175-185: a detector fine-tuning rule none of the lang2seg entry points sets)')
-    net.P.build_segments(double_bias=c.TRAIN.DOUBLE_BIAS, bias_decay=c.TRAIN.BIAS_DECAY)
+    net.P.build_segments(double_bias=c.TRAIN.DOUBLE_BIAS, bias_decay=c.TRAIN.BIAS_DECAY, from_frcn=bool(c.TRAIN.FROM_FRCN), gamma=c.TRAIN.GAMMA)
     return SGD(net, c.TRAIN.LEARNING_RATE, c.TRAIN.MOMENTUM, c.TRAIN.WEIGHT_DECAY, grad_scale=1.0 / world, **kw)
 
 

@@ -362,29 +362,34 @@ class ParamStore(object):
                 self.rowscale[o:o + s.numel()].copy_(s)
 
     # ---- SGD segment table: the param groups of the variant's construct_graph() ------------
-    def param_group(self, k, double_bias=False, bias_decay=False, lang_lr_mult=None):
+    def param_group(self, k, double_bias=False, bias_decay=False, lang_lr_mult=None, from_frcn=False, gamma=0.1):
         """(lr factor, weight-decay switch) of tensor `k` as the variant's solver groups it (FROM_FRCN False): train_val.py:186-205,
         train_val_response.py:186-205, train_val_vgg.py:186-205 give keys containing rnn_encoder / dynamic_fc / response lr x 10 (biases
         x 10 x (DOUBLE_BIAS + 1)); train_val_cycle.py:192-215 and train_val_cycle_response.py:186-209 do not (variants.SOLVERS)."""
         from .variants import SOLVERS, LANG_LR_KEYS
         mult = SOLVERS[self.variant]['lang_lr_mult'] if lang_lr_mult is None else float(lang_lr_mult)
         is_bias = 'bias' in k
-        f = mult if any(t in k for t in LANG_LR_KEYS) else 1.0
+        if from_frcn:
+            # cfg.TRAIN.FROM_FRCN (train_val.py:175-185, the same in all six solvers): fine-tuning from a detector - the mask branch at the full
+            # learning rate, everything else at lr x GAMMA; no language-side factor in this branch
+            f = 1.0 if 'mask' in k else float(gamma)
+        else:
+            f = mult if any(t in k for t in LANG_LR_KEYS) else 1.0
         if is_bias and double_bias:
             f *= 2.0
         return f, (1 if (not is_bias or bias_decay) else 0)
 
-    def build_segments(self, double_bias=False, bias_decay=False, lang_lr_mult=None):
+    def build_segments(self, double_bias=False, bias_decay=False, lang_lr_mult=None, from_frcn=False, gamma=0.1):
         segs = []
         for k in self.trainable:
             cnt = int(np.prod(self.shapes[k]))
             sg = SgdSeg()
             sg.offset, sg.count = self.offsets[k], cnt
             sg.row_len = cnt // self.shapes[k][0] if k in self.rowscale_off else 1
-            sg.lr_mult, sg.weight_decay = self.param_group(k, double_bias, bias_decay, lang_lr_mult)
+            sg.lr_mult, sg.weight_decay = self.param_group(k, double_bias, bias_decay, lang_lr_mult, from_frcn, gamma)
             sg.rowscale_off = self.rowscale_off.get(k, -1)
             segs.append(sg)
-        self.seg_rule = (bool(double_bias), bool(bias_decay), lang_lr_mult)
+        self.seg_rule = (bool(double_bias), bool(bias_decay), lang_lr_mult, bool(from_frcn), float(gamma))
         CH = int(O.sgd_chunk())
 
         def table(seq):

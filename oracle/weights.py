@@ -47,7 +47,10 @@ def param_group(variant, key, train_cfg):
     sv = SOLVERS[variant]
     ct = dict(train_cfg, **sv['cfg'])
     is_bias = 'bias' in key
-    mult = sv['lang_lr_mult'] if any(t in key for t in LANG_KEYS) else 1.0
+    if ct.get('FROM_FRCN'):                       # train_val.py:175-185: the mask branch at lr, everything else at lr x GAMMA
+        mult = 1.0 if 'mask' in key else ct['GAMMA']
+    else:
+        mult = sv['lang_lr_mult'] if any(t in key for t in LANG_KEYS) else 1.0
     if is_bias:
         return mult * ((2.0 if ct['DOUBLE_BIAS'] else 1.0)), (ct['WEIGHT_DECAY'] if ct['BIAS_DECAY'] else 0.0)
     return mult, ct['WEIGHT_DECAY']

@@ -807,6 +807,41 @@ def run_snapshot():
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def run_solver_tables():
+    """the param-group table (key, lr, weight decay) of every variant's reference solver in BOTH branches of construct_graph(): the usual one
+    (cfg.TRAIN.FROM_FRCN False) and the detector fine-tuning rule (True: lr x GAMMA for everything but the mask branch, train_val.py:175-185).
+    No network is run: construct_graph() only builds the architecture and the optimiser.  -> tests/golden/ref_solver_tables.json"""
+    import importlib
+    import json
+    out = {}
+    for variant in ('baseline', 'spatial', 'response', 'cycle', 'cycle_response', 'vgg'):
+        var = OW.VARIANTS[variant]
+        RESM = importlib.import_module('nets.' + var['module'])
+        opt = OW.default_opt(vocab_size=60, seq_length=6)
+        if var.get('backbone') == 'vgg':
+            opt['C4_feat_dim'] = 512
+        for frcn in (False, True):
+            torch.manual_seed(0)
+            net = RESM.vgg16(opt, batch_size=1) if var.get('backbone') == 'vgg' else RESM.resnetv1(opt, batch_size=1, num_layers=101)
+            sw, scfg = reference_solver(variant, net)
+            was = scfg.TRAIN.FROM_FRCN
+            scfg.TRAIN.FROM_FRCN = frcn
+            try:
+                import io, contextlib
+                with contextlib.redirect_stdout(io.StringIO()):
+                    lr0, optimizer = sw.construct_graph()
+            finally:
+                scfg.TRAIN.FROM_FRCN = was
+            group_of = {id(g['params'][0]): g for g in optimizer.param_groups}
+            rows = [(k, group_of[id(p)]['lr'], group_of[id(p)]['weight_decay']) for k, p in net.named_parameters() if p.requires_grad]
+            out['%s/%s' % (variant, 'from_frcn' if frcn else 'default')] = dict(
+                module=SOLVER_MODULE[variant], LEARNING_RATE=scfg.TRAIN.LEARNING_RATE, GAMMA=scfg.TRAIN.GAMMA, WEIGHT_DECAY=scfg.TRAIN.WEIGHT_DECAY,
+                DOUBLE_BIAS=bool(scfg.TRAIN.DOUBLE_BIAS), BIAS_DECAY=bool(scfg.TRAIN.BIAS_DECAY), momentum=optimizer.defaults['momentum'],
+                keys=[r[0] for r in rows], lr=[r[1] for r in rows], wd=[r[2] for r in rows])
+            print(variant, frcn, len(rows), sorted(set(round(r[1], 10) for r in rows)))
+    json.dump(out, open(os.path.join(HERE, 'ref_solver_tables.json'), 'w'))
+
+
 def read_build_snapshot(src=None):
     """f3, reverse direction: the snapshot pair the BUILD wrote on the MI355X (tests/test_train_step_gpu.py::
     test_resume_from_reference_written_snapshot leaves its zip structure, sidecar and per-tensor CRCs in gpurun_out/build_snapshot/; its
@@ -902,6 +937,8 @@ if __name__ == '__main__':
                       head_gain=4.0, top_over=dict(POOLING_ALIGN=True))
     if what in ('snapshot', 'all'):
         run_snapshot()
+    if what in ('solver_tables', 'all'):
+        run_solver_tables()
     if what == 'read_build_snapshot':
         read_build_snapshot(sys.argv[2] if len(sys.argv) > 2 else None)
     if what in ('fb0', 'all'):

@@ -505,6 +505,38 @@ class _FakeSolverNet(object):
         return self.ctr
 
 
+@pytest.mark.parametrize('variant', ['baseline', 'spatial', 'response', 'cycle', 'cycle_response', 'vgg'])
+@pytest.mark.parametrize('branch', ['default', 'from_frcn'])
+def test_both_branches_of_construct_graph(variant, branch):
+    """tests/golden/ref_solver_tables.json: the param groups of every variant's reference solver in both branches of construct_graph() -
+    cfg.TRAIN.FROM_FRCN False (the lr x 10 rule where the solver has it) and True (train_val.py:175-185: lr x GAMMA for everything but the mask
+    branch) - against ParamStore.param_group and the oracle's rule."""
+    import json
+    from lang2seg_amd._lib import F32
+    from lang2seg_amd.nets.params import ParamStore
+    from lang2seg_amd.nets.variants import solver_cfg
+    from oracle import weights as OW, net as ON
+    T = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_solver_tables.json')))['%s/%s' % (variant, branch)]
+    sc = solver_cfg(variant)
+    assert (T['LEARNING_RATE'], T['GAMMA'], T['WEIGHT_DECAY'], T['DOUBLE_BIAS'], T['BIAS_DECAY'], T['momentum']) == \
+        (sc.TRAIN.LEARNING_RATE, sc.TRAIN.GAMMA, sc.TRAIN.WEIGHT_DECAY, bool(sc.TRAIN.DOUBLE_BIAS), bool(sc.TRAIN.BIAS_DECAY), sc.TRAIN.MOMENTUM)
+    opt = OW.default_opt(vocab_size=60, seq_length=6)
+    if variant == 'vgg':
+        opt['C4_feat_dim'] = 512
+    P = ParamStore(opt, 101, 81, 12, 0 if variant == 'vgg' else 1, 'cpu', F32, variant)
+    ref = {k: (lr, wd) for k, lr, wd in zip(T['keys'], T['lr'], T['wd'])}
+    assert set(P.trainable) == set(ref) - {'resnet.fc.weight', 'resnet.fc.bias'}
+    frcn = branch == 'from_frcn'
+    ocfg = dict(ON.DEFAULT_CFG['TRAIN'], FROM_FRCN=frcn)
+    for k in P.trainable:
+        f, wd_on = P.param_group(k, sc.TRAIN.DOUBLE_BIAS, sc.TRAIN.BIAS_DECAY, None, frcn, sc.TRAIN.GAMMA)
+        assert abs(sc.TRAIN.LEARNING_RATE * f - ref[k][0]) <= 1e-12 and abs(wd_on * sc.TRAIN.WEIGHT_DECAY - ref[k][1]) <= 1e-15, (k, f, wd_on, ref[k])
+        m, w = OW.param_group(variant, k, ocfg)
+        assert abs(T['LEARNING_RATE'] * m - ref[k][0]) <= 1e-12 and abs(w - ref[k][1]) <= 1e-15, (k, m, w, ref[k])
+    if frcn:
+        assert any('mask' in k and abs(ref[k][0] - T['LEARNING_RATE'] * (2 if ('bias' in k and T['DOUBLE_BIAS']) else 1)) < 1e-15 for k in ref) or variant == 'vgg'
+
+
 def test_from_snapshot_reads_the_reference_written_pair(tmp_path):
     """f3 against files the REFERENCE wrote: SolverWrapper.snapshot() of train_val_cycle.py:57-104, driven by tests/golden/make_golden.py on the
     tiny cycle network (tests/golden/ref_snapshot/: its zip structure + sidecar as written, payloads regenerated and CRC-checked record by record,
