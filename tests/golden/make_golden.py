@@ -605,6 +605,14 @@ def eval_blobs(seed0=41, n_img=2, n_sent=2, H=160, W=224, T=6, V=60):
     return out
 
 
+def eval_state_dict_vgg(opt):
+    sd = OW.make_state_dict(opt, seed=3, head_gain=4.0, variant='vgg')
+    for k in ('bbox_pred_net', 'rpn_bbox_pred_net'):          # RoIs = anchors, predicted boxes = RoIs (as eval_state_dict)
+        sd[k + '.weight'] = np.zeros_like(sd[k + '.weight'])
+        sd[k + '.bias'] = np.zeros_like(sd[k + '.bias'])
+    return sd
+
+
 def eval_state_dict(opt):
     """weights of the eval_split fixture: the usual random set with both box-regression heads zeroed, so that the predicted box is the
     chosen anchor itself (untrained regressors throw every box to the image border and all intersections are empty)"""
@@ -911,6 +919,78 @@ def read_build_snapshot(src=None):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def run_eval_split_vgg():
+    """the reference's boxes-only evaluation loop of the VGG16 network (model/test_vgg.py:185-460 eval_split, :97-131 im_detect) on the tiny synthetic
+    split of run_eval_split: per sentence the chosen (RoI, class) and box, the box accuracy.  Only Network.test_image is replaced by the harness's
+    bypass of forward() (as in run_reference_test)."""
+    import importlib
+    from model.config import cfg
+    import model.test_vgg as MT
+    from oracle.net import DEFAULT_CFG
+    sys.modules['cv2'].resize = None
+    H, W, T, V = 160, 224, 6, 60
+    opt = OW.default_opt(vocab_size=V, seq_length=T); opt['C4_feat_dim'] = 512
+    sd = eval_state_dict_vgg(opt)
+    for k, v in DEFAULT_CFG['TEST'].items():
+        setattr(cfg.TEST, k, v)
+    cfg.TEST.MODE = 'nms'
+    cfg.ANCHOR_SCALES = list(DEFAULT_CFG['ANCHOR_SCALES']); cfg.ANCHOR_RATIOS = list(DEFAULT_CFG['ANCHOR_RATIOS'])
+    RESM = importlib.import_module('nets.' + OW.VARIANTS['vgg']['module'])
+    torch.manual_seed(0)
+    net = RESM.vgg16(opt, batch_size=1)
+    net.create_architecture(81, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    ref_sd = net.state_dict()
+    for k, v in sd.items():
+        ref_sd[k].copy_(torch.from_numpy(v))
+    net.eval()
+
+    def test_image(blobs):                      # network_vgg.py:701-718 with forward() bypassed (mode TEST)
+        net._image = torch.from_numpy(np.ascontiguousarray(blobs['data'].transpose([0, 3, 1, 2])))
+        net._im_info = blobs['im_info']
+        net._gt_boxes = torch.from_numpy(blobs['gt_boxes'])
+        net._gt_masks = blobs['gt_masks']
+        net._labels = torch.from_numpy(np.asarray(blobs['labels'].a))
+        net._cap_labels = None; net._cap_masks = None
+        net._mode = 'TEST'
+        net._image_gt_summaries = {}
+        with torch.no_grad():
+            pr = net._predict()
+            net_conv, rois, cls_prob, bbox_pred = pr[:4]
+            stds = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_STDS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
+            means = bbox_pred.data.new(cfg.TRAIN.BBOX_NORMALIZE_MEANS).repeat(net._num_classes).unsqueeze(0).expand_as(bbox_pred)
+            bbox_pred = bbox_pred.mul(stds).add(means)
+        return (net._predictions['cls_score'].numpy(), cls_prob.numpy(), bbox_pred.numpy(), rois.numpy(), net_conv)
+    net.test_image = test_image
+    imgs = eval_blobs(H=H, W=W, T=T, V=V)
+
+    class Loader(object):
+        def __init__(self):
+            self.i = 0
+
+        def getTestBatch(self, split):
+            b = dict(imgs[self.i]); self.i += 1
+            b['labels'] = _Labels(b['labels'])
+            b['bounds'] = dict(it_pos_now=self.i, it_max=len(imgs), wrapped=self.i >= len(imgs))
+            return b
+    picked = []
+    orig_detect = MT.im_detect
+
+    def rec_detect(model, blobs):
+        r = orig_detect(model, blobs)
+        sc, bx = r[0], r[1]
+        pr = np.where(sc == np.max(sc[:, 1:]))
+        picked.append((int(pr[0][0]), int(pr[1][0]), bx[pr[0][0], pr[1][0] * 4:(pr[1][0] + 1) * 4].copy()))
+        return r
+    MT.im_detect = rec_detect
+    with torch.no_grad():
+        acc, num_sent = MT.eval_split(Loader(), net, None, 'val', dict(verbose=False))
+    MT.im_detect = orig_detect
+    out = dict(acc=float(acc), num_sent=int(num_sent), pred_roi=np.array([p[0] for p in picked]), pred_class=np.array([p[1] for p in picked]),
+               pred_box=np.stack([p[2] for p in picked]).astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, 'ref_eval_split_vgg.npz'), **out)
+    print('eval_split_vgg: acc %.3f sents %d' % (acc, num_sent), out['pred_class'], out['pred_box'])
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     install_harness()
@@ -920,6 +1000,8 @@ if __name__ == '__main__':
         run_leaf_eval()
     if what in ('eval_split', 'all'):
         run_eval_split()
+    if what in ('eval_split_vgg', 'all'):
+        run_eval_split_vgg()
     if what in ('tiny', 'all'):
         hook_proposals()
         run_reference('tiny', 320, 416, 6, 60, dict(BATCH_SIZE=32, RPN_PRE_NMS_TOP_N=1500, RPN_POST_NMS_TOP_N=300,

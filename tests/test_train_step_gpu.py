@@ -440,6 +440,47 @@ def test_eval_split_runs():
     assert text.count('precision@') == 5 and 'overall IoU' in text
 
 
+def test_eval_split_vgg_vs_reference():
+    """model/test_vgg.py eval_split (boxes only) against the reference's own loop (model/test_vgg.py:185-460 run through the harness,
+    tests/golden/make_golden.py eval_split_vgg -> ref_eval_split_vgg.npz): chosen (RoI, class), predicted boxes, box accuracy."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_golden as MG
+    from lang2seg_amd import selftest
+    from lang2seg_amd.model import test as T, test_vgg as TVG
+    from oracle import weights as OW
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_eval_split_vgg.npz')))
+    opt = OW.default_opt(vocab_size=60, seq_length=6); opt['C4_feat_dim'] = 512
+    net = selftest.build_net(opt, {}, 'f32', MG.eval_state_dict_vgg(opt), variant='vgg')
+    imgs = MG.eval_blobs()
+
+    class Loader(object):
+        split_ix = {'val': [0, 1]}
+
+        def __init__(self):
+            self.i = 0
+
+        def getTestBatch(self, split):
+            b = dict(imgs[self.i]); self.i += 1
+            b['bounds'] = dict(it_pos_now=self.i, it_max=len(imgs), wrapped=self.i >= len(imgs))
+            return b
+    picked = []
+    orig = TVG.best_detection
+
+    def rec(scores, boxes):
+        r = orig(scores, boxes)
+        picked.append(r)
+        return r
+    TVG.best_detection = rec
+    try:
+        acc, num_sent = TVG.eval_split(Loader(), net, None, 'val', dict(verbose=False))
+    finally:
+        TVG.best_detection = orig
+    assert num_sent == int(g['num_sent']) and acc == float(g['acc'])
+    assert [p[1] for p in picked] == list(g['pred_class'])
+    assert np.allclose(np.stack([p[2] for p in picked]), g['pred_box'], atol=1e-2)
+
+
 def test_eval_split_vs_reference():
     """model/test.py eval_split against the reference's own evaluation loop (model/test.py:185-450, run through the harness on the same
     tiny synthetic split by tests/golden/make_golden.py eval_split -> ref_eval_split.npz): chosen (RoI, class), predicted boxes, box
