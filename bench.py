@@ -571,6 +571,10 @@ def main(argv=None, hooks=None):
                 extras['dp'] = rep
     if args.extras:
         # ---- the reference's unit as it stands: train_step() reads the losses back every step (NET:704-710: seven .data[0]) ----
+        # (the measurement leg above evicted every launch tape: two untimed steps record the step's tape again - until round 6 that recording,
+        # an eagerly issued step with two device syncs, sat inside this leg's timed region and cost it ~4 %: sync came out BELOW dropin)
+        for i in range(2):
+            net.train_step_async(blobs[i % 4], 0, optim)
         barrier()
         t0 = time.time()
         for i in range(args.steps):
