@@ -657,7 +657,7 @@ def main(argv=None, hooks=None):
             d32 = time.time() - t0
             if np.isfinite(l32.cpu().numpy()[:7]).all():
                 extras['f32_train_step'] = {'ms_per_step': d32 / n32 * 1e3, 'value': n32 / d32, 'unit': 'img/s', 'steps': n32,
-                                            'note': 'the same pipelined step in the exact-f32 verification mode (f32 activations / weights, f32-exact MFMA): the mode '
+                                            'note': 'the same pipelined step in the exact-f32 verification mode (f32 activations / weights, v_mfma_f32_16x16x4_f32): the mode '
                                                     'the 1e-4 parity claim is tested in; not the headline'}
             del net32, op32
         finally:
