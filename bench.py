@@ -57,6 +57,8 @@ class Hooks(object):
     dp_bucket_update = False
     knockout = ''             # EXPERIMENT: leave parts of the step out (wgrad,cap); the line is marked invalid
     tape, graph, main_prio = True, False, False
+    dp_backend = 'nccl'       # 'gloo' (tools/ab.py --dp-backend gloo): the reducer's buffers staged through the host - several ranks may then share one GPU;
+                              # a functional run of the N > 1 path, its figures say nothing about RCCL (the line is marked)
     note = ''                 # what was changed, for the JSON line
 
     def before_net(self):     # class attributes / library tunables, before the network exists
@@ -449,12 +451,12 @@ def main(argv=None, hooks=None):
         dist.destroy_process_group()
         return 0
 
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if hooks.dp_backend == 'nccl' else local % max(torch.cuda.device_count(), 1))
     use_dp = world > 1 or hooks.force_dp
     if use_dp:
         # no device_id: binding the process group to the device eagerly costs 7 % of the step on this stack even when no collective
         # is ever issued (112 vs 121 img/s at one rank); the communicator is created by the first all-reduce
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(hooks.dp_backend, rank=rank, world_size=world)
     from lang2seg_amd.model.config import cfg
     from lang2seg_amd.nets.resnet_v1 import resnetv1
     from lang2seg_amd.optim import SGD  # noqa: F401
@@ -513,7 +515,7 @@ def main(argv=None, hooks=None):
 
     def rank_max(dt):
         if world > 1:
-            tt = torch.tensor([dt], device='cuda')
+            tt = torch.tensor([dt], device='cuda' if hooks.dp_backend == 'nccl' else 'cpu')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         return dt
@@ -563,7 +565,7 @@ def main(argv=None, hooks=None):
     ranks_seen = 1
     extras = {}
     if use_dp:
-        c = torch.ones(1, device='cuda'); dist.all_reduce(c); ranks_seen = int(c.item())
+        c = torch.ones(1, device='cuda' if hooks.dp_backend == 'nccl' else 'cpu'); dist.all_reduce(c); ranks_seen = int(c.item())
         assert ranks_seen == world, (ranks_seen, world)
         if getattr(net, 'dp', None) is not None:
             rep = net.dp.report()                   # HIP events of the LAST timed step: per-bucket exchange time, and what the main stream waited for
@@ -690,6 +692,8 @@ def main(argv=None, hooks=None):
             out['dropin_train_step_value'] = extras['dropin_train_step']['value']  # ... with the image uploaded before every step as well: the reference's unit as it stands
         if hooks.lib or hooks.note:
             out['ab'] = 'A/B run (tools/ab.py): %s %s' % (hooks.note, hooks.lib)
+        if hooks.dp_backend != 'nccl':
+            out['experiment'] = 'INVALID as a measurement: collectives staged through the host on a %s group (functional run of the N > 1 path)' % hooks.dp_backend
         if experiment:
             out['experiment'] = 'INVALID as a measurement: knockout=%s dp_skip_allreduce=%d' % (sorted(net.knockout), hooks.dp_skip_allreduce)
         if args.extras:

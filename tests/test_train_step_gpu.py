@@ -1414,6 +1414,27 @@ def test_two_ranks_one_gpu_end_to_end(tmp_path, variant, wire):
     assert not np.allclose(out[0]['losses'][0], out[1]['losses'][0], rtol=1e-3)
 
 
+def test_bench_two_ranks_one_gpu():
+    """bench.py's N > 1 branch as the driver launches it (torch.distributed.run, one process per rank, --gpus 2) with two ranks on the one GPU:
+    tools/ab.py --dp-backend gloo stages the reducer's collectives through the host, everything else is the measured run's code - process group,
+    per-rank loaders, the default reducer (bf16 buckets, reduce-scatter + all-gather, sharded update, five buckets), barriers, the MAX over ranks,
+    ONE JSON line from rank 0.  The figures are marked invalid (no RCCL); the run must train (finite, moving losses) and count both ranks."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+           str(29700 + os.getpid() % 90), os.path.join(root, 'tools', 'ab.py'), '--dp-backend', 'gloo', '--',
+           '--gpus', '2', '--steps', '6', '--warmup', '3', '--no-cpu-baseline', '--extras', '0', '--mixed-shapes', '0']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and 'INVALID' in d['experiment']
+    assert 'dp2' in d['config']['parallelism'] and 'sharded update' in d['config']['parallelism'] and 'bf16' in d['config']['parallelism']
+    assert abs(d['value'] - 2 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']           # whole-job images per second: both ranks' images over the slower rank's time
+    assert all(np.isfinite(v) for v in d['final_losses'])
+
+
 def test_train_entry_point_two_ranks_one_gpu():
     """tools/train_cycle_2.py as experiments/scripts/train_cycle.sh launches it for N > 1 (torch.distributed.run, one process per rank, RANK /
     WORLD_SIZE from the environment) with two ranks on the box's one GPU (TRAIN.DP_BACKEND gloo: the reducer's buffers staged through the host):

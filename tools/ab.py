@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--sgd-early', type=int, default=None, help='optim.SGD.early of the run\'s optimiser')
     ap.add_argument('--lib', default='', help='another build of the library (tools/ab_build.sh <rev>)')
     ap.add_argument('--tape', type=int, default=1); ap.add_argument('--graph', type=int, default=0); ap.add_argument('--main-prio', type=int, default=0)
+    ap.add_argument('--dp-backend', default='nccl', help="'gloo': the reducer's collectives staged through the host (ranks may share a GPU; functional run only)")
     ap.add_argument('--force-dp', type=int, default=0, help='build the data-parallel reducer even for one rank (fixed costs of each form)')
     ap.add_argument('--dp-bucket-update', type=int, default=0)
     ap.add_argument('--knockout', default='', help='EXPERIMENT: leave parts of the step out (wgrad,cap); the line is marked invalid')
@@ -51,6 +52,7 @@ def main():
         lib = a.lib
         force_dp, dp_skip_allreduce, dp_bucket_update, knockout = bool(a.force_dp), a.dp_skip_allreduce, bool(a.dp_bucket_update), a.knockout
         tape, graph, main_prio = bool(a.tape), bool(a.graph), bool(a.main_prio)
+        dp_backend = a.dp_backend
         note = ' '.join(argv)
 
         def before_net(self):
