@@ -292,6 +292,43 @@ def test_grad_reducer_gloo_world2():
     assert ret.get(0) and ret.get(1)
 
 
+@pytest.mark.parametrize('variant', ['baseline', 'spatial', 'response', 'cycle', 'cycle_response', 'vgg'])
+def test_shard_plan_covers_every_bucket_and_never_shadows_a_master_read_tensor(variant):
+    """parallel.shard_plan over the default buckets of every variant (bf16 layout): the sub-buckets tile [0, total) without gap or overlap, a
+    'shadow' sub-bucket holds nothing but tensors no kernel reads as fp32 masters (ParamStore.shadow_only), and the plan keeps most of the
+    convolution weights on the bf16 wire (the point of it); f32 layout: everything 'master'."""
+    from lang2seg_amd._lib import F32, BF16
+    from lang2seg_amd.nets.params import ParamStore
+    from lang2seg_amd.parallel import GradReducer, bucket_bounds, shard_plan
+    from oracle import weights as OW
+    opt = OW.default_opt(vocab_size=3349, seq_length=20)
+    if variant == 'vgg':
+        opt['C4_feat_dim'] = 512
+    for dt in (BF16, F32):
+        P = ParamStore(opt, 101, 81, 12, 0 if variant == 'vgg' else 1, 'cpu', dt, variant)
+        b = bucket_bounds(P)
+        skip = set(GradReducer.SKIP_STAGES)
+        ends = sorted({b[s_] for s_ in b if s_ not in skip} | {P.total})
+        plan, lo = [], 0
+        for hi in ends:
+            if hi > lo:
+                plan += shard_plan(P, lo, hi); lo = hi
+        assert plan[0][0] == 0 and plan[-1][1] == P.total and all(x[1] == y[0] for x, y in zip(plan, plan[1:])) and all(x[1] > x[0] for x in plan)
+        so = np.zeros(P.total, bool)
+        for a_, b_, f in P.shadow_only_runs():
+            so[a_:b_] = bool(f)
+        n_shadow = 0
+        for a_, b_, cls in plan:
+            if cls == 'shadow':
+                assert so[a_:b_].all(), (variant, a_, b_)
+                n_shadow += b_ - a_
+        if dt == F32:
+            assert n_shadow == 0
+        else:
+            conv = sum(int(np.prod(P.shapes[k])) for k in P.trainable if P.shadow_only(k))
+            assert n_shadow >= 0.95 * conv and len(plan) <= 12, (variant, n_shadow, conv, len(plan))
+
+
 def test_dp_ready_flushes_queued_weight_gradients_first():
     """Network.dp_ready: the queued weight gradients of the stage are launched BEFORE the bucket goes to the reducer (or to the early
     optimiser update), whatever the backbone variant did or forgot"""
