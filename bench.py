@@ -662,6 +662,8 @@ def main(argv=None, hooks=None):
                                             'note': 'the same pipelined step in the exact-f32 verification mode (f32 activations / weights, v_mfma_f32_16x16x4_f32): the mode '
                                                     'the 1e-4 parity claim is tested in; not the headline'}
             del net32, op32
+        except Exception as e:                                    # (a side leg must not cost the run its headline line)
+            extras['f32_train_step'] = {'error': '%s: %s' % (type(e).__name__, e)}
         finally:
             cfg.COMPUTE_DTYPE = args.dtype
     # a run whose network went non-finite measured nothing (NaN activations are silently zeroed by the next ReLU)
@@ -686,7 +688,7 @@ def main(argv=None, hooks=None):
         out.update(extras)
         if 'sync_train_step' in extras:
             out['sync_train_step_value'] = extras['sync_train_step']['value']      # Network.train_step as the reference calls it (seven floats read back per step)
-        if 'f32_train_step' in extras:
+        if 'value' in extras.get('f32_train_step', {}):
             out['f32_train_step_value'] = extras['f32_train_step']['value']        # exact-f32 verification mode (parity 1e-4), beside the bf16 headline
         if 'dropin_train_step' in extras:
             out['dropin_train_step_value'] = extras['dropin_train_step']['value']  # ... with the image uploaded before every step as well: the reference's unit as it stands
