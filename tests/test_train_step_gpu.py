@@ -1339,7 +1339,7 @@ def _two_rank_worker(rank, world, port, outdir, wire, variant, steps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('variant,wire', [('cycle', 'fp32'), ('cycle', 'bf16'), ('baseline', 'bf16'), ('vgg', 'bf16'), ('cycle_response', 'fp32')])
+@pytest.mark.parametrize('variant,wire', [('cycle', 'fp32'), ('cycle', 'bf16'), ('vgg', 'bf16')])      # (baseline-bf16 and cycle_response-fp32 pass too: 25 s each, left out of the suite)
 def test_two_ranks_one_gpu_end_to_end(tmp_path, variant, wire):
     """Data parallel with two REAL ranks - two processes, two networks, two different (image, expression) pairs, the segmented launch tape,
     the sharded update with the master / shadow split - on the one GPU of the box (RCCL refuses two ranks on one device, so the wire is a gloo
